@@ -1,0 +1,160 @@
+"""
+Pins oracle/magphase_oracle.py against outputs of the REAL reference (tests/golden/*.npz, produced by
+oracle/gen_golden.py from /root/reference).  CPU only.  Tolerances: integers exact, float64 <= 1e-12
+relative to the array scale (in practice the restatement is bit-identical).
+"""
+import os
+import warnings
+
+import numpy as np
+import pytest
+
+from oracle import magphase_oracle as orc
+from oracle.gen_golden import proj
+from magphase_amd import synthetic as syn
+
+TOL = 1e-12
+
+
+def _close(a, b, tol=TOL):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    assert a.shape == b.shape
+    scale = max(1.0, float(np.max(np.abs(b[np.isfinite(b)]))) if np.isfinite(b).any() else 1.0)
+    assert np.array_equal(np.isfinite(a), np.isfinite(b))
+    fin = np.isfinite(b)
+    assert np.max(np.abs(a[fin] - b[fin]), initial=0.0) <= tol * scale
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name), allow_pickle=False)
+
+
+def test_g1_frame_bounds_exact(golden_dir):
+    g = _load(golden_dir, "g1_index.npz")
+    assert int(g["pinned"]) == 1
+    for i in range(int(g["ncases"])):
+        pm_plus, left, right, lens = orc.frame_bounds(g["c%d_pm" % i], int(g["c%d_n" % i]))
+        assert np.array_equal(pm_plus, g["c%d_pm_plus" % i])
+        assert np.array_equal(left, g["c%d_shift" % i])
+        assert np.array_equal(right, g["c%d_rights" % i])
+        assert np.array_equal(lens, g["c%d_lens" % i])
+
+
+@pytest.mark.parametrize("tag", ["48k", "16k"])
+def test_g2_g3_lossless(golden_dir, tag):
+    g = _load(golden_dir, "g2_lossless_%s.npz" % tag)
+    fs = int(g["fs"])
+    x = syn.pcm_to_float(g["pcm"])
+    with warnings.catch_warnings(record=True) as wl:
+        warnings.simplefilter("always")
+        m_mag, m_real, m_imag, v_f0, _, v_shift = orc.analysis_lossless_from_epochs(x, fs, g["pm_sec"], g["voi"])
+    assert sum("fft_len" in str(w.message) for w in wl) == int(g["n_trunc_warn"])
+    assert np.array_equal(v_shift, g["v_shift"])
+    assert np.array_equal(v_f0, g["v_f0"])  # fp64 op sequence identical (Q2)
+    sel = g["sel"]
+    for nm, m in (("mag", m_mag), ("real", m_real), ("imag", m_imag)):
+        _close(m[sel], g[nm + "_sel"])
+        pc, pr = proj(m)
+        _close(pc, g[nm + "_projc"], 1e-11)
+        _close(pr, g[nm + "_projr"], 1e-11)
+        assert np.max(np.abs(m.astype(np.float32) - g[nm + "32"])) <= 1e-6 * max(1.0, np.max(np.abs(m)))
+    v_syn = orc.synthesis_from_lossless(m_mag, m_real, m_imag, v_f0, fs)
+    assert len(v_syn) == len(g["v_syn"])
+    _close(v_syn, g["v_syn"])
+    # algebraic KAT: perfect reconstruction between first and last epoch
+    pm = orc.round_to_int(orc.clean_epochs(g["pm_sec"], g["voi"], len(x), fs)[0] * fs)
+    seg = slice(pm[0], pm[-1])
+    assert np.max(np.abs(v_syn[seg] - x[seg])) < 1e-12
+
+
+def test_g4_unwarp_matrices(golden_dir):
+    g = _load(golden_dir, "g4_unwarp.npz")
+    for tag, n, nb, alpha in (("mag48", 60, 2049, 0.77), ("mag16", 60, 1025, 0.58), ("q7", 44, 2049, 0.0)):
+        U = orc.unwarp_matrix(n, nb, alpha)
+        _close(U[:, ::16], g[tag + "_cols"])
+        pc, pr = proj(U)
+        _close(pc, g[tag + "_projc"], 1e-11)
+        _close(pr, g[tag + "_projr"], 1e-11)
+    for tag, pd, fft_len, fs, alpha in (("ph48", 45, 4096, 48000, 0.77), ("ph16", 45, 2048, 16000, 0.58),
+                                        ("ph48_10", 10, 4096, 48000, 0.77)):
+        R, I = orc.phase_uncompress_type1_mcep(np.eye(pd), np.eye(pd)[::-1].copy(), alpha, fft_len, fs)
+        _close(R[:, ::16], g[tag + "_R_cols"])
+        for nm, m in (("R", R), ("I", I)):
+            pc, pr = proj(m)
+            _close(pc, g["%s_%s_projc" % (tag, nm)], 1e-11)
+            _close(pr, g["%s_%s_projr" % (tag, nm)], 1e-11)
+
+
+def _hvd704(g):
+    m_mag = g["in_mag"].reshape(-1, 60).astype(np.float64)
+    m_real = g["in_real"].reshape(-1, 45).astype(np.float64)
+    m_imag = g["in_imag"].reshape(-1, 45).astype(np.float64)
+    return m_mag, m_real, m_imag, g["in_lf0"].astype(np.float64)
+
+
+def test_g6_post_filter(golden_dir):
+    g = _load(golden_dir, "g5_generation_hvd704.npz")
+    m_mag = _hvd704(g)[0]
+    _close(orc.post_filter(m_mag, 48000), g["pf48"])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        _close(orc.post_filter(m_mag, 16000), g["pf16"])
+    with pytest.raises(ValueError):
+        orc.post_filter(m_mag, 44100)
+
+
+def test_g5_generation_from_predicted(golden_dir):
+    g = _load(golden_dir, "g5_generation_hvd704.npz")
+    m_mag, m_real, m_imag, v_lf0 = _hvd704(g)
+    seed = int(g["seed"])
+    pf = orc.post_filter(m_mag, 48000)
+    for hpf in (True, False):
+        np.random.seed(seed)
+        v, dbg = orc.synthesis_from_compressed(pf, m_real, m_imag, v_lf0, 48000, b_out_hpf=hpf, return_debug=True)
+        assert np.array_equal(dbg["v_shift"], g["v_shift"])
+        _close(v, g["syn_pf_hpf%d" % int(hpf)])
+    np.random.seed(seed)
+    _close(orc.synthesis_from_compressed(m_mag, m_real, m_imag, v_lf0, 48000, per_phase_type="min_phase"),
+           g["syn_nopf_minphase"])
+    np.random.seed(seed)
+    _close(orc.synthesis_from_compressed(m_mag, m_real, m_imag, v_lf0, 48000, b_voi_ap_win=False),
+           g["syn_nopf_novoiwin"])
+
+
+def test_g7_const_rate_tables(golden_dir):
+    g = _load(golden_dir, "g7_const_rate.npz")
+    fs = int(g["fs"])
+    x = syn.pcm_to_float(g["pcm"])
+    m_mag, m_real, m_imag, v_f0, _, v_shift = orc.analysis_lossless_from_epochs(x, fs, g["pm_sec"], g["voi"])
+    assert np.array_equal(v_shift, g["v_shift"])
+    m_mag_c, _, _, v_f0_c = orc.to_const_rate(m_mag, m_real, m_imag, v_f0, v_shift, fs)
+    assert np.array_equal(v_f0_c, g["v_f0_c"])
+    _close(m_mag_c[:, ::32], g["mag_c_cols"])
+    shifts, locs = orc.get_shifts_and_frm_locs_from_const_shifts(orc.f0_to_shift(v_f0_c, fs), 5.0, fs)
+    assert np.array_equal(shifts, g["v_shift_vr"])  # serial fp64 scan reproduced bit-exactly (Q16)
+    assert np.array_equal(locs, g["v_locs"])
+    back = orc.interp_from_const_to_variable_rate(m_mag_c, locs, 5.0, fs)
+    _close(back[:, ::32], g["back_cols"])
+    pc, pr = proj(back)
+    _close(pc, g["back_projc"], 1e-11)
+
+
+def test_g8_compressed_analysis_unpinned_mcep(golden_dir):
+    """oracle-with-our-mcep: checks the restatement's plumbing around mcep, not SPTK itself."""
+    g = _load(golden_dir, "g8_compressed_analysis.npz")
+    assert int(g["pinned"]) == 0
+    fs = int(g["fs"])
+    x = syn.pcm_to_float(g["pcm"])
+    for tag, kw in (("vr45", dict(phase_dim=45)), ("cr45", dict(phase_dim=45, b_const_rate=True)),
+                    ("q7", dict(phase_dim=10, alpha_phase=False))):
+        r = orc.analysis_compressed_from_epochs(x, fs, g["pm_sec"], g["voi"], mag_dim=60, **kw)
+        _close(r[0], g[tag + "_mag"])
+        _close(r[1], g[tag + "_real"])
+        _close(r[2], g[tag + "_imag"])
+        assert np.array_equal(r[3], g[tag + "_lf0"])
+        assert np.array_equal(r[4], g[tag + "_shift"])
+        if tag == "cr45":
+            np.random.seed(int(g["cr45_seed"]))
+            v = orc.synthesis_from_compressed(r[0], r[1], r[2], r[3], fs, b_const_rate=True, b_out_hpf=False)
+            _close(v, g["cr45_syn"])
