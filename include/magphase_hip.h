@@ -1,0 +1,84 @@
+/*
+ * magphase_hip.h -- C ABI of libmagphase_hip.so: the MI355X (gfx950) implementation of the MagPhase
+ * per-frame analysis / synthesis hot path.
+ *
+ * The reference (CSTR-Edinburgh/magphase) has no FFI: its boundary is the Python module API of
+ * src/magphase.py.  These entry points are what magphase_amd/magphase.py binds through ctypes in
+ * place of the numpy loops cited on each function; INTEGRATION.md shows the reference-side stub.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the name ends in _host; the caller owns all buffers
+ *     (PyTorch-ROCm tensors are only the allocator); nothing is allocated or freed here;
+ *   - `stream` is a hipStream_t (passed as void*); all work is enqueued on it, nothing synchronises;
+ *   - fft_len N is 4096 or 2048; H = N/2+1; feature matrices are row-major float32 [F x H];
+ *   - return 0 on success, <0 on error (text via mpx_last_error()); re-entrant per stream.
+ */
+#ifndef MAGPHASE_HIP_H
+#define MAGPHASE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPX_ABI_VERSION 1
+
+#define MPX_OK 0
+#define MPX_ERR_ARG (-1)     /* bad argument (unsupported fft_len, null pointer, negative count) */
+#define MPX_ERR_HIP (-2)     /* a HIP runtime call failed */
+
+int mpx_version(void);
+const char* mpx_last_error(void);
+
+/* Number of bytes of the per-fft_len twiddle table, and its initialisation (host computes the table in
+ * float64, rounds to float32 and enqueues an H2D copy on `stream`).  The table is read-only afterwards
+ * and may be shared by every stream of the device. */
+size_t mpx_tables_bytes(int fft_len);
+int mpx_tables_init(void* stream, int fft_len, void* tables);
+
+/*
+ * Analysis of pitch-synchronous frames.  Replaces, for all frames of a batch at once:
+ *   magphase.py:74-119   windowing()               (Hann half windows, frame = sig[pm-left .. pm+right])
+ *   magphase.py:309-323  zero-pad/truncate to N, circular rotation (epoch -> index 0)
+ *   magphase.py:325      np.fft.fft, first H bins
+ *   magphase.py:457-476  compute_lossless_feats(): mag=|X|, real=Re X/|X|, imag=Im X/|X| (0 where |X|==0)
+ * sig        : float32 PCM of all utterances of the batch, concatenated
+ * frame_pos  : int64[n_frames]  absolute index in `sig` of each frame's epoch (utterance offset + pm)
+ * frame_left : int32[n_frames]  left length  (pm - previous epoch; == v_shift of the reference)
+ * frame_right: int32[n_frames]  right length (next epoch - pm)
+ * out_*      : float32 [n_frames x H]
+ * The host keeps the fp64 epoch/index math (np.round, int casts) -- it is never recomputed on the device.
+ */
+int mpx_analysis_frames(void* stream, int fft_len, const void* tables, const float* sig,
+                        const int64_t* frame_pos, const int32_t* frame_left, const int32_t* frame_right,
+                        int64_t n_frames, float* out_mag, float* out_real, float* out_imag);
+
+/*
+ * Lossless synthesis, per-frame part.  Replaces magphase.py:1761-1770 (synthesis_from_lossless):
+ *   X = mag * (real + j imag)/|real + j imag|  (|.|==0 -> 1), Hermitian extension with Im X[0]=Im X[N/2]=0
+ *   (libaudio.py:369-388), np.fft.ifft(.).real, np.fft.fftshift  (epoch at index N/2).
+ * frames_out : float32 [n_frames x N]
+ */
+int mpx_synthesis_lossless_frames(void* stream, int fft_len, const void* tables, const float* mag,
+                                  const float* real, const float* imag, int64_t n_frames, float* frames_out);
+
+/*
+ * PSOLA overlap-add, gather form, deterministic (ascending frame order).  Replaces magphase.py:34-62 ola():
+ * for utterance u, out[t] = sum_i frames[i][t + out_start[u] - pm_rel[i]] over its frames i with
+ * 0 <= t + out_start[u] - pm_rel[i] < N, for t in [0, out_off[u+1]-out_off[u]).
+ * utt_frame_off : int32[n_utts+1]  frame range of each utterance
+ * pm_rel        : int32[n_frames]  pm_i - pm_0 within the utterance (non-decreasing)
+ * out_start     : int32[n_utts]    first kept sample of the OLA buffer (python slice start N/2 - pm_0, resolved on host)
+ * out_off       : int64[n_utts+1]  sample offsets of each utterance in pcm_out
+ * max_out_len   : max over utterances of the output length (grid sizing)
+ */
+int mpx_ola_gather(void* stream, int fft_len, const float* frames, int32_t n_utts, const int32_t* utt_frame_off,
+                   const int32_t* pm_rel, const int32_t* out_start, const int64_t* out_off, int64_t max_out_len,
+                   float* pcm_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MAGPHASE_HIP_H */

@@ -1,0 +1,63 @@
+"""
+ctypes binding of libmagphase_hip.so (C ABI: include/magphase_hip.h).
+
+There is NO CPU fallback: if the library is missing or no ROCm device is visible the product raises.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmagphase_hip.so")
+
+# every symbol include/magphase_hip.h declares (tests/test_cabi_symbols.py checks the .so exports them all)
+SYMBOLS = (
+    "mpx_version",
+    "mpx_last_error",
+    "mpx_tables_bytes",
+    "mpx_tables_init",
+    "mpx_analysis_frames",
+    "mpx_synthesis_lossless_frames",
+    "mpx_ola_gather",
+)
+
+_lib = None
+
+
+class MagphaseHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Loads the shared library (once) and declares the prototypes."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise MagphaseHipError(
+            "libmagphase_hip.so not found at %s -- build it with `python -m magphase_amd.build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, i32, i64, sz = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_size_t
+    lib.mpx_version.restype = ctypes.c_int
+    lib.mpx_version.argtypes = []
+    lib.mpx_last_error.restype = ctypes.c_char_p
+    lib.mpx_last_error.argtypes = []
+    lib.mpx_tables_bytes.restype = sz
+    lib.mpx_tables_bytes.argtypes = [ctypes.c_int]
+    lib.mpx_tables_init.restype = ctypes.c_int
+    lib.mpx_tables_init.argtypes = [vp, ctypes.c_int, vp]
+    lib.mpx_analysis_frames.restype = ctypes.c_int
+    lib.mpx_analysis_frames.argtypes = [vp, ctypes.c_int, vp, vp, vp, vp, vp, i64, vp, vp, vp]
+    lib.mpx_synthesis_lossless_frames.restype = ctypes.c_int
+    lib.mpx_synthesis_lossless_frames.argtypes = [vp, ctypes.c_int, vp, vp, vp, vp, i64, vp]
+    lib.mpx_ola_gather.restype = ctypes.c_int
+    lib.mpx_ola_gather.argtypes = [vp, ctypes.c_int, vp, i32, vp, vp, vp, vp, i64, vp]
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().mpx_last_error()
+        raise MagphaseHipError("%s failed (%d): %s" % (what, rc, msg.decode("utf-8", "replace") if msg else ""))

@@ -1,0 +1,43 @@
+"""
+Builds libmagphase_hip.so (hipcc, gfx950 only) in-tree next to this file.
+
+    python -m magphase_amd.build
+
+-fno-slp-vectorize: the SLP vectoriser packs the butterflies into v_pk_*_f32 pairs, which have the same
+fp32 rate as the scalar ops on gfx950 but need register pairing moves -- the kernels spill without it.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "csrc", "magphase_hip.hip")
+DEPS = [SRC, os.path.join(HERE, "csrc", "wave_fft.hpp"), os.path.join(os.path.dirname(HERE), "include", "magphase_hip.h")]
+LIB = os.path.join(HERE, "libmagphase_hip.so")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-shared", "-fPIC"]
+
+
+def hipcc_path():
+    return shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+def is_stale():
+    if not os.path.isfile(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(d) > t for d in DEPS)
+
+
+def build(force=False, verbose=True, extra_flags=()):
+    if not force and not is_stale():
+        return LIB
+    cmd = [hipcc_path()] + FLAGS + list(extra_flags) + [SRC, "-o", LIB]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, extra_flags=[a for a in sys.argv[1:] if a.startswith("-R")])

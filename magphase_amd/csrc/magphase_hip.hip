@@ -1,0 +1,426 @@
+// magphase_hip.hip -- gfx950 kernels + C ABI (include/magphase_hip.h) for the MagPhase hot path.
+//
+// Kernel plan:
+//   k_analysis<P>           one wavefront per frame, persistent waves (grid-stride over frames):
+//                           gather+window+rotate -> 64*P-point complex FFT in registers/LDS -> real-FFT split
+//                           -> mag/real/imag epilogue, 3 x H coalesced float stores.   HBM-write bound.
+//   k_synth_lossless<P>     one wavefront per frame: 3 x H coalesced loads -> unit-phase spectrum ->
+//                           Hermitian merge -> inverse FFT -> epoch-centred frame.      HBM-read bound.
+//   k_ola_gather            one thread per output sample, ascending-frame gather (deterministic PSOLA).
+// No MFMA anywhere: nothing on this path is a dense contraction.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "../../include/magphase_hip.h"
+#include "wave_fft.hpp"
+
+namespace mpx {
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, const char* detail = "") {
+    snprintf(g_err, sizeof(g_err), fmt, detail);
+    return code;
+}
+
+#define MPX_HIP_CHECK(expr)                                                       \
+    do {                                                                          \
+        hipError_t e__ = (expr);                                                  \
+        if (e__ != hipSuccess) return fail(MPX_ERR_HIP, #expr ": %s", hipGetErrorString(e__)); \
+    } while (0)
+
+constexpr int kWavesPerBlock = 16;  // 1024 threads: one block per CU, 4 waves per SIMD
+constexpr int kThreads = kWavesPerBlock * 64;
+
+template <int P>
+constexpr size_t lds_bytes() {
+    return sizeof(float) * (size_t)(P * 64 * 2 + kWavesPerBlock * P * kXStride);
+}
+
+__device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// ---------------------------------------------------------------------------------------------
+// analysis
+// ---------------------------------------------------------------------------------------------
+// sin(pi t / 2)^2 for t in [0,1] without range reduction: Taylor polynomials on [0, pi/4]
+// (sin: degree 9, |err| < 2e-9; cos: degree 8, |err| < 2.5e-8), selected at t = 0.5.
+__device__ __forceinline__ float sin2_halfpi(float t) {
+    const float kHalfPi = 1.57079632679489662f;
+    const bool lo = t <= 0.5f;
+    const float y = kHalfPi * (lo ? t : 1.0f - t);
+    const float y2 = y * y;
+    float sp = fmaf(y2, 2.75573192e-6f, -1.98412698e-4f);
+    sp = fmaf(y2, sp, 8.33333333e-3f);
+    sp = fmaf(y2, sp, -1.66666667e-1f);
+    sp = fmaf(y2 * y, sp, y);
+    float cp = fmaf(y2, 2.48015873e-5f, -1.38888889e-3f);
+    cp = fmaf(y2, cp, 4.16666667e-2f);
+    cp = fmaf(y2, cp, -0.5f);
+    cp = fmaf(y2, cp, 1.0f);
+    const float v = lo ? sp : cp;
+    return v * v;
+}
+
+// Hann half windows of libaudio.py:70-84 evaluated analytically (np.hanning(1+2L)[k] = sin^2(pi k / 2L)):
+// rising  k <= L : sin^2(pi/2 * k/L)            (== 1 when L == 0: np.hanning(1) == [1.])
+// falling k >  L : cos^2(pi/2 * (k-L)/R) = sin^2(pi/2 * (L+R-k)/R)
+__device__ __forceinline__ float hann_half(int k, int L, int LR, int kadd, float invL, float invR) {
+    const bool rising = k <= L;
+    const int num = rising ? k + kadd : LR - k;
+    const float inv = rising ? invL : invR;
+    return sin2_halfpi((float)num * inv);
+}
+
+template <int P>
+__global__ __launch_bounds__(kThreads) void k_analysis(const float* __restrict__ sig,
+                                                       const long long* __restrict__ fpos,
+                                                       const int* __restrict__ fleft,
+                                                       const int* __restrict__ fright, long long nframes,
+                                                       const float2* __restrict__ tw_g, float* __restrict__ omag,
+                                                       float* __restrict__ oreal, float* __restrict__ oimag) {
+    constexpr int M = 64 * P, N = 2 * M, H = M + 1, LB = ilog2(P);
+    extern __shared__ float smem[];
+    float2* tw = reinterpret_cast<float2*>(smem);
+    const int lane_id = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    float* xbuf = smem + P * 64 * 2 + wave * (P * kXStride);
+    for (int i = threadIdx.x; i < P * 64; i += kThreads) tw[i] = tw_g[i];
+    __syncthreads();
+
+    // lane part of the split twiddle W_N^kappa = e^{-2 pi i kappa / N}
+    float wl_s0, wl_c0;
+    sincospif(-2.0f * (float)kappa<P>(lane_id) / (float)N, &wl_s0, &wl_c0);
+
+    const int wave_u = rfl(wave);
+    for (long long f = (long long)blockIdx.x * kWavesPerBlock + wave_u; f < nframes;
+         f += (long long)gridDim.x * kWavesPerBlock) {
+        // Launder the per-lane invariants once per frame: otherwise LICM hoists every (lane x register)
+        // twiddle product out of this loop and the kernel spills (128-VGPR budget at 4 waves/SIMD).
+        int lane = lane_id;
+        float wl_s = wl_s0, wl_c = wl_c0;
+        asm volatile("" : "+v"(lane), "+v"(wl_s), "+v"(wl_c));
+        const int kap = kappa<P>(lane);
+        const int src_lane = kappa<P>((64 - kap) & 63);
+        const bool lane0 = (kap == 0);
+        const long long pos = fpos[f];
+        const int L = fleft[f];
+        const int R = fright[f];
+        const int LR = L + R;
+        const int len = min(LR + 1, N);      // Q19: frames longer than N are truncated
+        const int rot = (L < N) ? L : 0;     // python slicing: rotation by >= N is the identity
+        // L == 0: the single rising sample (k == 0) has weight np.hanning(1) == 1 -> num = 1, inv = 1
+        const int kadd = (L == 0) ? 1 : 0;
+        const float invL = (L > 0) ? 1.0f / (float)L : 1.0f;
+        const float invR = (R > 0) ? 1.0f / (float)R : 0.0f;
+        const float* base = sig + (pos - L);
+
+        float re[P], im[P];
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+            const int m0 = 128 * j;
+            // buffer index m holds windowed sample k = (m + rot) mod N, valid iff k < len
+            const bool any = (m0 < len - rot) || (m0 + 127 >= N - rot);
+            float a = 0.0f, b = 0.0f;
+            if (any) {
+                const int m = m0 + 2 * lane;
+                int k0 = m + rot;
+                k0 = (k0 >= N) ? k0 - N : k0;
+                int k1 = m + 1 + rot;
+                k1 = (k1 >= N) ? k1 - N : k1;
+                if (k0 < len) a = base[k0] * hann_half(k0, L, LR, kadd, invL, invR);
+                if (k1 < len) b = base[k1] * hann_half(k1, L, LR, kadd, invL, invR);
+            }
+            re[j] = a;
+            im[j] = b;
+        }
+
+        wave_fft<P, -1>(re, im, tw, xbuf, lane);
+
+        float* mrow = omag + f * H;
+        float* rrow = oreal + f * H;
+        float* irow = oimag + f * H;
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            const int q = brev(i, LB);
+            // partner Z[M-k]: lane src_lane register P-1-i; for kappa==0 the own register holding (P-q)%P
+            const int i0 = brev((P - q) % P, LB);
+            float pr = __shfl(re[P - 1 - i], src_lane);
+            float pi = __shfl(im[P - 1 - i], src_lane);
+            pr = lane0 ? re[i0] : pr;
+            pi = lane0 ? im[i0] : pi;
+            const float er = 0.5f * (re[i] + pr), ei = 0.5f * (im[i] - pi);
+            const float orr = 0.5f * (im[i] + pi), oi = -0.5f * (re[i] - pr);
+            // W_N^k = W_N^kappa * e^{-2 pi i q/(2P)}
+            const float cq = cos2p<P>(q), sq = -sin2p<P>(q);
+            const float wr = wl_c * cq - wl_s * sq, wi = wl_c * sq + wl_s * cq;
+            const float xr = er + (wr * orr - wi * oi);
+            const float xi = ei + (wr * oi + wi * orr);
+            const float s = xr * xr + xi * xi;
+            const float r = (s > 0.0f) ? __builtin_amdgcn_rsqf(s) : 0.0f;
+            const int k = kap + 64 * q;
+            mrow[k] = s * r;
+            rrow[k] = xr * r;
+            irow[k] = xi * r;
+        }
+        if (lane0) {  // Nyquist bin X[M] = Re Z[0] - Im Z[0]
+            const float x = re[0] - im[0];
+            mrow[M] = fabsf(x);
+            rrow[M] = (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : 0.0f);
+            irow[M] = 0.0f;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// lossless synthesis: per-frame spectrum rebuild + inverse real FFT (epoch at N/2)
+// ---------------------------------------------------------------------------------------------
+template <int P>
+__global__ __launch_bounds__(kThreads) void k_synth_lossless(const float* __restrict__ mag,
+                                                             const float* __restrict__ real,
+                                                             const float* __restrict__ imag, long long nframes,
+                                                             const float2* __restrict__ tw_g,
+                                                             float* __restrict__ frames) {
+    constexpr int M = 64 * P, N = 2 * M, H = M + 1, LB = ilog2(P);
+    extern __shared__ float smem[];
+    float2* tw = reinterpret_cast<float2*>(smem);
+    const int lane_id = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    float* xbuf = smem + P * 64 * 2 + wave * (P * kXStride);
+    for (int i = threadIdx.x; i < P * 64; i += kThreads) tw[i] = tw_g[i];
+    __syncthreads();
+
+    // input layout is natural (k = lane + 64 j): lane twiddle conj(W_N^lane) = e^{+2 pi i lane/N}
+    float wl_s0, wl_c0;
+    sincospif(2.0f * (float)lane_id / (float)N, &wl_s0, &wl_c0);
+
+    const int wave_u = rfl(wave);
+    for (long long f = (long long)blockIdx.x * kWavesPerBlock + wave_u; f < nframes;
+         f += (long long)gridDim.x * kWavesPerBlock) {
+        int lane = lane_id;  // laundered per frame (see k_analysis)
+        float wl_s = wl_s0, wl_c = wl_c0;
+        asm volatile("" : "+v"(lane), "+v"(wl_s), "+v"(wl_c));
+        const int src_lane = (64 - lane) & 63;
+        const bool lane0 = (lane == 0);
+        // fftshift of the output == (-1)^k on the spectrum; k parity == lane parity.  0.5/M = merge + IFFT scale.
+        const float sgn_scale = ((lane & 1) ? -1.0f : 1.0f) * (0.5f / (float)M);
+        const int kap = kappa<P>(lane);
+        const float* mrow = mag + f * H;
+        const float* rrow = real + f * H;
+        const float* irow = imag + f * H;
+        float xr[P], xi[P];
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+            const int k = lane + 64 * j;
+            const float m = mrow[k], a = rrow[k], b = irow[k];
+            const float s = a * a + b * b;
+            const float g = (s > 0.0f) ? m * sgn_scale * __builtin_amdgcn_rsqf(s) : 0.0f;
+            xr[j] = a * g;
+            xi[j] = b * g;
+        }
+        float xm = 0.0f;  // Nyquist bin (real part only, Q5); (-1)^M == +1
+        if (lane0) {
+            xi[0] = 0.0f;  // DC imaginary part dropped (Q5)
+            const float m = mrow[M], a = rrow[M], b = irow[M];
+            const float s = a * a + b * b;
+            xm = (s > 0.0f) ? m * (0.5f / (float)M) * a * __builtin_amdgcn_rsqf(s) : 0.0f;
+        }
+        // Hermitian merge Z[k] = E[k] + i O[k], in place, two bins (j, P-1-j) per step so that no second
+        // register array is live.  Partner bin M-k: lane (64-lane)&63, register P-1-j; lane 0 pairs (j, P-j)
+        // instead, served from a one-bin stash of the original register P-j (overwritten one step earlier).
+        float st_r = 0.0f, st_i = 0.0f;
+#pragma unroll
+        for (int j = 0; j < P / 2; ++j) {
+            const int jp = P - 1 - j;
+            const float ar = xr[j], ai = xi[j], br = xr[jp], bi = xi[jp];
+            float par = __shfl(br, src_lane), pai = __shfl(bi, src_lane);
+            float pbr = __shfl(ar, src_lane), pbi = __shfl(ai, src_lane);
+            const float l0ar = (j == 0) ? xm : st_r, l0ai = (j == 0) ? 0.0f : st_i;
+            const float l0br = (j + 1 == jp) ? br : xr[j + 1], l0bi = (j + 1 == jp) ? bi : xi[j + 1];
+            par = lane0 ? l0ar : par;
+            pai = lane0 ? l0ai : pai;
+            pbr = lane0 ? l0br : pbr;
+            pbi = lane0 ? l0bi : pbi;
+            st_r = br;
+            st_i = bi;
+            {   // bin j:  E = X + conj(Xp), T = X - conj(Xp), O = conj(W_N^k) T, conj(W_N^k) = e^{+2 pi i (lane/N + j/2P)}
+                const float er = ar + par, ei = ai - pai, tr = ar - par, ti = ai + pai;
+                const float cq = cos2p<P>(j), sq = sin2p<P>(j);
+                const float wr = wl_c * cq - wl_s * sq, wi = wl_c * sq + wl_s * cq;
+                xr[j] = er - (wr * ti + wi * tr);
+                xi[j] = ei + (wr * tr - wi * ti);
+            }
+            {   // bin P-1-j
+                const float er = br + pbr, ei = bi - pbi, tr = br - pbr, ti = bi + pbi;
+                const float cq = cos2p<P>(jp), sq = sin2p<P>(jp);
+                const float wr = wl_c * cq - wl_s * sq, wi = wl_c * sq + wl_s * cq;
+                xr[jp] = er - (wr * ti + wi * tr);
+                xi[jp] = ei + (wr * tr - wi * ti);
+            }
+        }
+
+        wave_fft<P, +1>(xr, xi, tw, xbuf, lane);
+
+        float2* out = reinterpret_cast<float2*>(frames + f * N);
+#pragma unroll
+        for (int i = 0; i < P; ++i) out[kap + 64 * brev(i, LB)] = make_float2(xr[i], xi[i]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// PSOLA gather (deterministic): magphase.py:34-62
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_ola_gather(const float* __restrict__ frames, int N,
+                                                    const int* __restrict__ utt_frame_off,
+                                                    const int* __restrict__ pm_rel,
+                                                    const int* __restrict__ out_start,
+                                                    const long long* __restrict__ out_off,
+                                                    float* __restrict__ pcm) {
+    const int u = blockIdx.y;
+    const long long o0 = out_off[u];
+    const long long len = out_off[u + 1] - o0;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= len) return;
+    const int f0 = utt_frame_off[u], f1 = utt_frame_off[u + 1];
+    const long long b = t + out_start[u];  // index in the reference's un-trimmed OLA buffer
+    // first frame i in [f0,f1) with pm_rel[i] > b - N   (pm_rel non-decreasing)
+    int lo = f0, hi = f1;
+    const long long thr = b - N;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if ((long long)pm_rel[mid] > thr) hi = mid; else lo = mid + 1;
+    }
+    float acc = 0.0f;
+    for (int i = lo; i < f1; ++i) {
+        const long long off = b - pm_rel[i];
+        if (off < 0) break;
+        acc += frames[(long long)i * N + off];
+    }
+    pcm[o0 + t] = acc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+static int p_of(int fft_len) { return fft_len == 4096 ? 32 : (fft_len == 2048 ? 16 : 0); }
+
+static int grid_for(long long nframes) {
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    }
+    long long need = (nframes + kWavesPerBlock - 1) / kWavesPerBlock;
+    return (int)std::max<long long>(1, std::min<long long>(need, cus));
+}
+
+template <typename K>
+static int set_lds(K kernel, size_t bytes) {
+    MPX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return MPX_OK;
+}
+
+}  // namespace mpx
+
+using namespace mpx;
+
+extern "C" {
+
+int mpx_version(void) { return MPX_ABI_VERSION; }
+
+const char* mpx_last_error(void) { return g_err; }
+
+size_t mpx_tables_bytes(int fft_len) {
+    const int P = p_of(fft_len);
+    return P ? sizeof(float) * 2 * 64 * (size_t)P : 0;
+}
+
+int mpx_tables_init(void* stream, int fft_len, void* tables) {
+    const int P = p_of(fft_len);
+    if (!P) return fail(MPX_ERR_ARG, "mpx_tables_init: fft_len must be 2048 or 4096%s");
+    if (!tables) return fail(MPX_ERR_ARG, "mpx_tables_init: null tables%s");
+    const int M = 64 * P;
+    std::vector<float> h(2 * 64 * (size_t)P);
+    for (int k1 = 0; k1 < P; ++k1)
+        for (int l = 0; l < 64; ++l) {
+            const double a = 2.0 * M_PI * (double)((long long)l * k1 % M) / (double)M;
+            h[2 * (k1 * 64 + l) + 0] = (float)std::cos(a);
+            h[2 * (k1 * 64 + l) + 1] = (float)std::sin(a);
+        }
+    // pageable source: hipMemcpyAsync stages it before returning, so the local vector may die
+    MPX_HIP_CHECK(hipMemcpyAsync(tables, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice,
+                                 (hipStream_t)stream));
+    MPX_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    return MPX_OK;
+}
+
+int mpx_analysis_frames(void* stream, int fft_len, const void* tables, const float* sig, const int64_t* frame_pos,
+                        const int32_t* frame_left, const int32_t* frame_right, int64_t n_frames, float* out_mag,
+                        float* out_real, float* out_imag) {
+    const int P = p_of(fft_len);
+    if (!P) return fail(MPX_ERR_ARG, "mpx_analysis_frames: fft_len must be 2048 or 4096%s");
+    if (n_frames < 0) return fail(MPX_ERR_ARG, "mpx_analysis_frames: negative n_frames%s");
+    if (n_frames == 0) return MPX_OK;
+    if (!tables || !sig || !frame_pos || !frame_left || !frame_right || !out_mag || !out_real || !out_imag)
+        return fail(MPX_ERR_ARG, "mpx_analysis_frames: null pointer%s");
+    const dim3 grid(grid_for(n_frames)), block(kThreads);
+    hipStream_t s = (hipStream_t)stream;
+    if (P == 32) {
+        if (int rc = set_lds(k_analysis<32>, lds_bytes<32>())) return rc;
+        hipLaunchKernelGGL(k_analysis<32>, grid, block, lds_bytes<32>(), s, sig, (const long long*)frame_pos,
+                           frame_left, frame_right, (long long)n_frames, (const float2*)tables, out_mag, out_real,
+                           out_imag);
+    } else {
+        if (int rc = set_lds(k_analysis<16>, lds_bytes<16>())) return rc;
+        hipLaunchKernelGGL(k_analysis<16>, grid, block, lds_bytes<16>(), s, sig, (const long long*)frame_pos,
+                           frame_left, frame_right, (long long)n_frames, (const float2*)tables, out_mag, out_real,
+                           out_imag);
+    }
+    MPX_HIP_CHECK(hipGetLastError());
+    return MPX_OK;
+}
+
+int mpx_synthesis_lossless_frames(void* stream, int fft_len, const void* tables, const float* mag, const float* real,
+                                  const float* imag, int64_t n_frames, float* frames_out) {
+    const int P = p_of(fft_len);
+    if (!P) return fail(MPX_ERR_ARG, "mpx_synthesis_lossless_frames: fft_len must be 2048 or 4096%s");
+    if (n_frames < 0) return fail(MPX_ERR_ARG, "mpx_synthesis_lossless_frames: negative n_frames%s");
+    if (n_frames == 0) return MPX_OK;
+    if (!tables || !mag || !real || !imag || !frames_out)
+        return fail(MPX_ERR_ARG, "mpx_synthesis_lossless_frames: null pointer%s");
+    const dim3 grid(grid_for(n_frames)), block(kThreads);
+    hipStream_t s = (hipStream_t)stream;
+    if (P == 32) {
+        if (int rc = set_lds(k_synth_lossless<32>, lds_bytes<32>())) return rc;
+        hipLaunchKernelGGL(k_synth_lossless<32>, grid, block, lds_bytes<32>(), s, mag, real, imag,
+                           (long long)n_frames, (const float2*)tables, frames_out);
+    } else {
+        if (int rc = set_lds(k_synth_lossless<16>, lds_bytes<16>())) return rc;
+        hipLaunchKernelGGL(k_synth_lossless<16>, grid, block, lds_bytes<16>(), s, mag, real, imag,
+                           (long long)n_frames, (const float2*)tables, frames_out);
+    }
+    MPX_HIP_CHECK(hipGetLastError());
+    return MPX_OK;
+}
+
+int mpx_ola_gather(void* stream, int fft_len, const float* frames, int32_t n_utts, const int32_t* utt_frame_off,
+                   const int32_t* pm_rel, const int32_t* out_start, const int64_t* out_off, int64_t max_out_len,
+                   float* pcm_out) {
+    if (!p_of(fft_len)) return fail(MPX_ERR_ARG, "mpx_ola_gather: fft_len must be 2048 or 4096%s");
+    if (n_utts < 0 || max_out_len < 0) return fail(MPX_ERR_ARG, "mpx_ola_gather: negative size%s");
+    if (n_utts == 0 || max_out_len == 0) return MPX_OK;
+    if (!frames || !utt_frame_off || !pm_rel || !out_start || !out_off || !pcm_out)
+        return fail(MPX_ERR_ARG, "mpx_ola_gather: null pointer%s");
+    if (n_utts > 65535) return fail(MPX_ERR_ARG, "mpx_ola_gather: at most 65535 utterances per call%s");
+    const dim3 block(256), grid((unsigned)((max_out_len + 255) / 256), (unsigned)n_utts);
+    hipLaunchKernelGGL(k_ola_gather, grid, block, 0, (hipStream_t)stream, frames, fft_len, utt_frame_off, pm_rel,
+                       out_start, (const long long*)out_off, pcm_out);
+    MPX_HIP_CHECK(hipGetLastError());
+    return MPX_OK;
+}
+
+}  // extern "C"

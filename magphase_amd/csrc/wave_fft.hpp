@@ -1,0 +1,199 @@
+// wave_fft.hpp -- one-wavefront complex FFT for gfx950 (CDNA4), M = 64*P points, P in {16, 32}.
+//
+// Layout contract (validated against numpy in tests/test_fft_dataflow_model.py):
+//   input : lane l, register j      holds z[l + 64*j]                       (natural order)
+//   pass 1: P-point DIF FFT in registers over j            -> register i holds k1 = brev(i)
+//           multiply by W_M^(l*k1)  (table in LDS, shared by the workgroup)
+//           transpose through a per-wave LDS buffer (row stride 65 floats: conflict-free both ways)
+//   pass 2: 64-point FFT over l = radix-(64/P) butterflies ACROSS lanes + P-point DIF in registers
+//   output: lane l, register i      holds Z[kappa(l) + 64*brev(i)]
+//           kappa(l) = l for P=32; for P=16 kappa swaps lane bits 4 and 5 (an involution).
+//
+// No __syncthreads(): every wave owns its LDS buffer; ordering is wave-local (LDS ops of one wave
+// execute in issue order), the fences below only stop the compiler from reordering.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace mpx {
+
+constexpr int kXStride = 65;  // floats per k1 row of the per-wave transpose buffer
+
+__host__ __device__ constexpr int ilog2(int v) { return v <= 1 ? 0 : 1 + ilog2(v >> 1); }
+
+__host__ __device__ constexpr int brev(int i, int bits) {
+    int r = 0;
+    for (int b = 0; b < bits; ++b) r |= ((i >> b) & 1) << (bits - 1 - b);
+    return r;
+}
+
+// cos/sin(2*pi*k/32), k < 16
+__device__ __forceinline__ constexpr float c32(int k) {
+    constexpr float t[16] = {1.000000000e+00f, 9.807852507e-01f, 9.238795042e-01f, 8.314695954e-01f,
+                             7.071067691e-01f, 5.555702448e-01f, 3.826834261e-01f, 1.950903237e-01f,
+                             0.0f,             -1.950903237e-01f, -3.826834261e-01f, -5.555702448e-01f,
+                             -7.071067691e-01f, -8.314695954e-01f, -9.238795042e-01f, -9.807852507e-01f};
+    return t[k];
+}
+__device__ __forceinline__ constexpr float s32(int k) {
+    constexpr float t[16] = {0.000000000e+00f, 1.950903237e-01f, 3.826834261e-01f, 5.555702448e-01f,
+                             7.071067691e-01f, 8.314695954e-01f, 9.238795042e-01f, 9.807852507e-01f,
+                             1.000000000e+00f, 9.807852507e-01f, 9.238795042e-01f, 8.314695954e-01f,
+                             7.071067691e-01f, 5.555702448e-01f, 3.826834261e-01f, 1.950903237e-01f};
+    return t[k];
+}
+// cos/sin(2*pi*k/64), k < 32
+__device__ __forceinline__ constexpr float c64(int k) {
+    constexpr float t[32] = {1.000000000e+00f, 9.951847196e-01f, 9.807852507e-01f, 9.569403529e-01f,
+                             9.238795042e-01f, 8.819212914e-01f, 8.314695954e-01f, 7.730104327e-01f,
+                             7.071067691e-01f, 6.343932748e-01f, 5.555702448e-01f, 4.713967443e-01f,
+                             3.826834261e-01f, 2.902846634e-01f, 1.950903237e-01f, 9.801714122e-02f,
+                             0.0f,             -9.801714122e-02f, -1.950903237e-01f, -2.902846634e-01f,
+                             -3.826834261e-01f, -4.713967443e-01f, -5.555702448e-01f, -6.343932748e-01f,
+                             -7.071067691e-01f, -7.730104327e-01f, -8.314695954e-01f, -8.819212914e-01f,
+                             -9.238795042e-01f, -9.569403529e-01f, -9.807852507e-01f, -9.951847196e-01f};
+    return t[k];
+}
+__device__ __forceinline__ constexpr float s64(int k) {
+    constexpr float t[32] = {0.000000000e+00f, 9.801714122e-02f, 1.950903237e-01f, 2.902846634e-01f,
+                             3.826834261e-01f, 4.713967443e-01f, 5.555702448e-01f, 6.343932748e-01f,
+                             7.071067691e-01f, 7.730104327e-01f, 8.314695954e-01f, 8.819212914e-01f,
+                             9.238795042e-01f, 9.569403529e-01f, 9.807852507e-01f, 9.951847196e-01f,
+                             1.000000000e+00f, 9.951847196e-01f, 9.807852507e-01f, 9.569403529e-01f,
+                             9.238795042e-01f, 8.819212914e-01f, 8.314695954e-01f, 7.730104327e-01f,
+                             7.071067691e-01f, 6.343932748e-01f, 5.555702448e-01f, 4.713967443e-01f,
+                             3.826834261e-01f, 2.902846634e-01f, 1.950903237e-01f, 9.801714122e-02f};
+    return t[k];
+}
+
+// e^{SIGN * 2*pi*i * q / (2P)}: register part of the real-FFT split twiddle W_N^{64 q}, N = 128 P.
+template <int P>
+__device__ __forceinline__ constexpr float cos2p(int q) { return P == 32 ? c64(q) : c32(q); }
+template <int P>
+__device__ __forceinline__ constexpr float sin2p(int q) { return P == 32 ? s64(q) : s32(q); }
+
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ---------------------------------------------------------------------------------------------
+// P-point radix-2 DIF FFT on statically indexed registers; output register i holds index brev(i).
+// SIGN = -1: forward (e^{-i...}), +1: inverse (unnormalised).
+// ---------------------------------------------------------------------------------------------
+template <int P, int SIGN>
+__device__ __forceinline__ void fft_inreg(float (&re)[P], float (&im)[P]) {
+#pragma unroll
+    for (int s = P / 2; s >= 1; s >>= 1) {
+#pragma unroll
+        for (int g = 0; g < P; g += 2 * s) {
+#pragma unroll
+            for (int k = 0; k < s; ++k) {
+                const int i0 = g + k, i1 = g + k + s;
+                const int t = k * (16 / s);  // twiddle W_{2s}^k = W_32^t, t in [0,16)
+                const float ar = re[i0], ai = im[i0], br = re[i1], bi = im[i1];
+                re[i0] = ar + br;
+                im[i0] = ai + bi;
+                const float tr = ar - br, ti = ai - bi;
+                if (t == 0) {
+                    re[i1] = tr;
+                    im[i1] = ti;
+                } else if (t == 8) {  // W = SIGN * i
+                    re[i1] = (SIGN < 0) ? ti : -ti;
+                    im[i1] = (SIGN < 0) ? -tr : tr;
+                } else {
+                    const float c = c32(t), sn = (SIGN < 0) ? -s32(t) : s32(t);
+                    re[i1] = tr * c - ti * sn;
+                    im[i1] = tr * sn + ti * c;
+                }
+            }
+        }
+    }
+}
+
+// Per-wave LDS transpose of one plane: in: register i holds (k1 = brev(i), l = lane);
+// out: register l' holds (k1 = lane % P, l = (lane / P) * P + l').
+template <int P>
+__device__ __forceinline__ void lds_transpose(float (&x)[P], float* xbuf, int lane) {
+    constexpr int LB = ilog2(P);
+#pragma unroll
+    for (int i = 0; i < P; ++i) xbuf[brev(i, LB) * kXStride + lane] = x[i];
+    wave_sync();
+    const float* src = xbuf + (lane % P) * kXStride + (lane / P) * P;
+#pragma unroll
+    for (int lp = 0; lp < P; ++lp) x[lp] = src[lp];
+    wave_sync();
+}
+
+// Radix-2 DIF butterflies across lanes (partner = lane ^ PARTNER).  Lower lane: own + oth; upper lane:
+// (oth - own) * e^{SIGN 2 pi i lp / TWN}, times (SIGN*i) where `rot` (only the P=16 first stage).
+// The twiddle multiply sits in ONE exec-masked region with literal constants: selecting the constants per
+// lane instead makes them loop-invariant VGPRs that LICM hoists out of the frame loop (64 registers).
+template <int P, int SIGN, int PARTNER, int TWN>
+__device__ __forceinline__ void cross_lane_stage(float (&re)[P], float (&im)[P], bool upper, bool rot) {
+    const float sg = upper ? -1.0f : 1.0f;
+#pragma unroll
+    for (int lp = 0; lp < P; ++lp) {
+        const float orr = __shfl_xor(re[lp], PARTNER);
+        const float oii = __shfl_xor(im[lp], PARTNER);
+        re[lp] = fmaf(re[lp], sg, orr);
+        im[lp] = fmaf(im[lp], sg, oii);
+    }
+    if (upper) {
+#pragma unroll
+        for (int lp = 1; lp < P; ++lp) {
+            const float cw = (TWN == 64) ? c64(lp) : c32(lp);
+            const float sw0 = (TWN == 64) ? s64(lp) : s32(lp);
+            const float sw = (SIGN < 0) ? -sw0 : sw0;
+            const float xr = re[lp] * cw - im[lp] * sw;
+            const float xi = re[lp] * sw + im[lp] * cw;
+            re[lp] = xr;
+            im[lp] = xi;
+        }
+    }
+    if (PARTNER == 32 && P == 16) {
+        if (rot) {  // W_4^{c0}: multiply by SIGN*i
+#pragma unroll
+            for (int lp = 0; lp < P; ++lp) {
+                const float xr = re[lp], xi = im[lp];
+                re[lp] = (SIGN < 0) ? xi : -xi;
+                im[lp] = (SIGN < 0) ? -xr : xr;
+            }
+        }
+    }
+}
+
+// kappa(lane): which residue (mod 64) of the output index this lane holds after wave_fft.
+template <int P>
+__device__ __forceinline__ int kappa(int lane) {
+    if (P == 32) return lane;
+    return (lane & 15) | (((lane >> 5) & 1) << 4) | (((lane >> 4) & 1) << 5);
+}
+
+// Full M = 64*P point FFT of one wave.  tw: LDS table [P][64] float2 = (cos, sin)(2 pi l k1 / M)
+// (sign applied here).  xbuf: this wave's P*65-float LDS buffer.
+template <int P, int SIGN>
+__device__ __forceinline__ void wave_fft(float (&re)[P], float (&im)[P], const float2* tw, float* xbuf, int lane) {
+    constexpr int LB = ilog2(P);
+    fft_inreg<P, SIGN>(re, im);
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        const float2 w = tw[brev(i, LB) * 64 + lane];
+        const float ws = (SIGN < 0) ? -w.y : w.y;
+        const float xr = re[i] * w.x - im[i] * ws;
+        const float xi = re[i] * ws + im[i] * w.x;
+        re[i] = xr;
+        im[i] = xi;
+    }
+    lds_transpose<P>(re, xbuf, lane);
+    lds_transpose<P>(im, xbuf, lane);
+    if (P == 32) {
+        cross_lane_stage<P, SIGN, 32, 64>(re, im, (lane & 32) != 0, false);
+    } else {
+        cross_lane_stage<P, SIGN, 32, 64>(re, im, (lane & 32) != 0, (lane & 48) == 48);
+        cross_lane_stage<P, SIGN, 16, 32>(re, im, (lane & 16) != 0, false);
+    }
+    fft_inreg<P, SIGN>(re, im);
+}
+
+}  // namespace mpx

@@ -1,0 +1,106 @@
+"""
+Host-side float64 index arithmetic of the MagPhase hot path.
+
+The reference computes every epoch / shift / frame index in float64 numpy with np.round (half-to-even),
+truncating int casts and sequential cumsum.  "Bit-exact indices" means reproducing
+that IEEE-754 op sequence, so it stays on the host in numpy and is never recomputed on the device.
+Reference lines are cited per function.
+"""
+import warnings
+
+import numpy as np
+
+MAGIC = -1.0e10  # libaudio.py:17
+
+
+def round_to_int(x):
+    """libutils.py:131-133."""
+    return np.round(x).astype(int)
+
+
+def define_alpha(fs):
+    """magphase.py:3279-3290."""
+    table = {16000: 0.58, 22050: 0.65, 44100: 0.76, 48000: 0.77}
+    if fs not in table:
+        raise ValueError("Sample rate %d not supported yet." % fs)
+    return table[fs]
+
+
+def define_fft_len(fs):
+    """magphase.py:3292-3299."""
+    if fs in (22050, 16000):
+        return 2048
+    if fs == 8000:
+        return 1024
+    return 4096
+
+
+def define_crossfade_params(fs):
+    """magphase.py:3301-3317."""
+    crsf_bw = 2000
+    if fs == 48000:
+        return 5000, crsf_bw
+    if fs == 16000:
+        return 2500, crsf_bw
+    warnings.warn("Constant crsf_cf not tested nor tunned to synthesise at fs=%d Hz." % fs)
+    return (4500 if fs == 44100 else 3500), crsf_bw
+
+
+def clean_epochs(v_pm_sec, v_voi, check_len_smpls=-1, fs=-1):
+    """libaudio.py:435-447: the two protections applied to REAPER's epoch list."""
+    if (check_len_smpls > 0) and (fs == -1):
+        raise ValueError("If check_len_smpls given, fs must be provided as well.")
+    v_pm_sec = np.asarray(v_pm_sec, dtype=np.float64)
+    v_voi = np.asarray(v_voi, dtype=np.float64)
+    keep = np.hstack((True, np.diff(v_pm_sec) > 0))
+    v_pm_sec, v_voi = v_pm_sec[keep], v_voi[keep]
+    if check_len_smpls > 0:
+        pm = round_to_int(v_pm_sec * fs)
+        if pm[-1] >= (check_len_smpls - 1):
+            keep2 = pm < (check_len_smpls - 1)
+            v_pm_sec, v_voi = v_pm_sec[keep2], v_voi[keep2]
+    return v_pm_sec, v_voi
+
+
+def frame_bounds(v_pm_smpls, n_smpls):
+    """
+    magphase.py:77-83,90-98: epochs rounded (Q1), extended with 0 and n-1 (Q4).
+    Returns (pm int64[F], left int64[F], right int64[F]); left is the reference's v_shift.
+    """
+    pm = round_to_int(np.asarray(v_pm_smpls))
+    ext = np.hstack((0, pm, n_smpls - 1))
+    return pm.astype(np.int64), (ext[1:-1] - ext[:-2]).astype(np.int64), (ext[2:] - ext[1:-1]).astype(np.int64)
+
+
+def shift_to_f0(v_shift, v_voi, fs):
+    """magphase.py:2198-2207 with b_smooth=False (Q2)."""
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return v_voi * fs / v_shift.astype("float64")
+
+
+def f0_to_shift(v_f0_in, fs, unv_frm_rate_ms=5):
+    """magphase.py:2210-2215 (Q3)."""
+    v_f0 = np.array(v_f0_in, dtype=np.float64)
+    v_f0[v_f0 == 0] = 1000.0 / unv_frm_rate_ms
+    return fs / v_f0
+
+
+def ola_plan(v_pm, frmlen):
+    """
+    Index bookkeeping of magphase.py:34-62 (ola): returns (pm_rel int64[F], out_start, out_len) such that
+    out[t] = sum_i frame_i[t + out_start - pm_rel[i]].  Python slice semantics are kept, including the
+    negative-start case ``v_sig[(frmlen/2 - pm_0):]`` when the first epoch lies beyond frmlen/2.
+    """
+    v_pm = np.asarray(v_pm).astype(int)
+    buf_len = int(v_pm[-1]) + frmlen
+    start = frmlen // 2 - int(v_pm[0])
+    if start < 0:
+        start = max(buf_len + start, 0)
+    start = min(start, buf_len)
+    len1 = buf_len - start
+    last_shift = int(v_pm[-1] - v_pm[-2]) if v_pm.size > 1 else int(v_pm[-1])
+    stop = int(v_pm[-1]) + last_shift + 1
+    if stop < 0:
+        stop = max(len1 + stop, 0)
+    out_len = min(len1, stop)
+    return (v_pm - v_pm[0]).astype(np.int64), int(start), int(out_len)

@@ -1,0 +1,138 @@
+"""
+Drop-in counterpart of the reference's vocoder API (src/magphase.py) for the analysis/synthesis hot path.
+
+Same function names, positional order, defaults and return arity as the reference
+(SURVEY.md section 8b); numpy float64 arrays in and out, float32 feature files on disk.  The per-frame
+arithmetic runs in hand-written gfx950 kernels (libmagphase_hip.so via ctypes); the float64
+epoch/index arithmetic stays on the host (hostmath.py).  There is no CPU fallback.
+
+Epochs: the reference shells out to the REAPER binary (magphase.py:2875-2876).  REAPER is outside the hot path
+(SURVEY.md section 8f #1); epochs come, in this order, from a provider set with ``set_epoch_provider``,
+from ``<wav stem>.est`` next to the wav (REAPER text format), or from a REAPER binary if one is installed.
+"""
+import os
+import warnings
+
+import numpy as np
+
+from . import hostmath as hm
+from . import libaudio as la
+from . import libutils as lu
+from .engine import LosslessAnalysisPlan, LosslessSynthesisPlan, get_engine
+
+_epoch_provider = None
+
+_WARN_LONG = ("fft_len (%d) is shorter than the current detected frame length (%d). "
+              "This issue is not very critical, but if it occurs often "
+              "(e.g., more than 3 times per utterance), please increase de FFT length.")
+
+
+def set_epoch_provider(fn):
+    """fn(wav_file) -> (v_pm_sec, v_voi) or None.  Replaces the REAPER call of magphase.py:2875-2876."""
+    global _epoch_provider
+    _epoch_provider = fn
+
+
+def _epochs_for(wav_file):
+    if _epoch_provider is not None:
+        r = _epoch_provider(wav_file)
+        if r is not None:
+            return np.asarray(r[0], dtype=np.float64), np.asarray(r[1], dtype=np.float64)
+    est = os.path.splitext(wav_file)[0] + ".est"
+    if os.path.isfile(est):
+        m = np.atleast_2d(np.loadtxt(est, skiprows=7, usecols=[0, 1]))
+        return m[:, 0], m[:, 1]
+    est_tmp = lu.ins_pid("temp.est")
+    la.reaper(wav_file, est_tmp)
+    try:
+        m = np.atleast_2d(np.loadtxt(est_tmp, skiprows=7, usecols=[0, 1]))
+    finally:
+        if os.path.exists(est_tmp):
+            os.remove(est_tmp)
+    return m[:, 0], m[:, 1]
+
+
+# constants (magphase.py:3279-3317)
+define_alpha = hm.define_alpha
+define_fft_len = hm.define_fft_len
+define_crossfade_params = hm.define_crossfade_params
+shift_to_f0_raw = hm.shift_to_f0
+f0_to_shift = hm.f0_to_shift
+
+
+def write_featfile(m_data, out_dir, filename):
+    """magphase.py:2787-2791."""
+    lu.write_binfile(m_data, os.path.join(out_dir, filename))
+
+
+# ======================================================================================================
+# lossless analysis
+# ======================================================================================================
+def analysis_lossless_batch(utts, fft_len=None, engine=None, return_device=False):
+    """
+    Batched magphase.py:2869-2906 for utterances that already have epochs.
+    utts: list of (v_sig, fs, v_pm_sec, v_voi).  Returns a list of
+    (m_mag, m_real, m_imag, v_f0, fs, v_shift) in float64 numpy (or device tensors if return_device).
+    """
+    engine = engine or get_engine()
+    plan = LosslessAnalysisPlan(engine, utts, fft_len=fft_len)
+    for lens in plan.long_frame_lens:
+        for n in lens:  # Q19: truncation warns, it does not raise (magphase.py:311-315)
+            warnings.warn(_WARN_LONG % (plan.fft_len, n))
+    mag, real, imag = plan.run()
+    out = []
+    for u in range(len(utts)):
+        a, b = int(plan.frame_off[u]), int(plan.frame_off[u + 1])
+        if return_device:
+            feats = (mag[a:b], real[a:b], imag[a:b])
+        else:
+            feats = tuple(t[a:b].cpu().numpy().astype(np.float64) for t in (mag, real, imag))
+        out.append(feats + (plan.v_f0[u], plan.fs[u], plan.v_shift[u].astype(int)))
+    return out
+
+
+def analysis_lossless_from_epochs(v_sig, fs, v_pm_sec, v_voi, fft_len=None):
+    """magphase.py:2869-2906 from the point where the epochs have been read (array interface)."""
+    return analysis_lossless_batch([(v_sig, fs, v_pm_sec, v_voi)], fft_len=fft_len)[0]
+
+
+def analysis_lossless(wav_file, fft_len=None, out_dir=None):
+    """magphase.py:2869-2906."""
+    v_sig, fs = la.read_audio_file(wav_file)
+    v_pm_sec, v_voi = _epochs_for(wav_file)
+    m_mag, m_real, m_imag, v_f0, fs, v_shift = analysis_lossless_from_epochs(v_sig, fs, v_pm_sec, v_voi, fft_len)
+    if type(out_dir) is str:
+        file_id = os.path.basename(wav_file).split(".")[0]
+        write_featfile(m_mag, out_dir, file_id + ".mag")
+        write_featfile(m_real, out_dir, file_id + ".real")
+        write_featfile(m_imag, out_dir, file_id + ".imag")
+        write_featfile(v_f0, out_dir, file_id + ".f0")
+        write_featfile(v_shift, out_dir, file_id + ".shift")
+        return
+    return m_mag, m_real, m_imag, v_f0, fs, v_shift
+
+
+# ======================================================================================================
+# lossless synthesis
+# ======================================================================================================
+def synthesis_from_lossless_batch(feats, engine=None):
+    """
+    Batched magphase.py:1759-1776.  feats: list of (m_mag, m_real, m_imag, v_f0, fs), all with the same
+    number of bins.  Returns a list of float64 numpy signals.
+    """
+    engine = engine or get_engine()
+    torch = __import__("torch")
+    H = int(np.shape(feats[0][0])[1])
+    fft_len = 2 * (H - 1)
+    plan = LosslessSynthesisPlan(engine, [f[3] for f in feats], [f[4] for f in feats], fft_len)
+    cat = []
+    for k in range(3):
+        parts = [f[k] if torch.is_tensor(f[k]) else engine.to_device(np.asarray(f[k]), np.float32) for f in feats]
+        cat.append(parts[0].contiguous() if len(parts) == 1 else torch.cat(parts, dim=0))
+    pcm = plan.run(cat[0], cat[1], cat[2]).cpu().numpy().astype(np.float64)
+    return [pcm[plan.out_off_host[u]:plan.out_off_host[u + 1]] for u in range(len(feats))]
+
+
+def synthesis_from_lossless(m_mag, m_real, m_imag, v_f0, fs):
+    """magphase.py:1759-1776."""
+    return synthesis_from_lossless_batch([(m_mag, m_real, m_imag, v_f0, fs)])[0]
