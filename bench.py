@@ -8,7 +8,7 @@ bench.py -- MagPhase hot-path benchmark on MI355X (contract: see the task statem
 
 Workload (BASELINE.json configs[1], per GPU): 64 synthetic 48 kHz 5 s utterances, lossless analysis +
 synthesis, FFT=4096, variable (pitch-synchronous) frame rate.  A step = one pass of the hot path over the
-batch: k_analysis -> k_synth_lossless -> k_ola_gather, with PCM and frame descriptors already resident in HBM.
+batch: k_analysis -> k_synth_ola -> k_ola_fixup, with PCM and frame descriptors already resident in HBM.
 Utterances shard across ranks with no data-path collective (weak scaling: every rank owns 64 utterances).
 Metric: frames/s (whole job) = frames processed by all ranks / max-over-ranks wall time of the K steps.
 """
@@ -120,12 +120,12 @@ def main():
     H = N // 2 + 1
     F = aplan.total_frames
     feats = tuple(eng.empty((F, H)) for _ in range(3))
-    frames = eng.empty((F, N))
+    strips = eng.empty((splan.strip_floats,))
     pcm_out = eng.empty((splan.total_out,))
 
     def step():
         aplan.run(out=feats)
-        splan.run(feats[0], feats[1], feats[2], frames=frames, out=pcm_out)
+        splan.run(feats[0], feats[1], feats[2], strips=strips, out=pcm_out)
 
     def barrier():
         if dist is not None:
@@ -151,7 +151,7 @@ def main():
         total_frames = float(F)
 
     # ---- per-kernel durations with HIP events on the launch stream (separate, untimed-for-value loop)
-    names = ("k_analysis", "k_synth_lossless", "k_ola_gather")
+    names = ("k_analysis", "k_synth_ola", "k_ola_fixup")
     acc = [0.0, 0.0, 0.0]
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
     reps = max(5, min(args.steps, 20))
@@ -159,17 +159,18 @@ def main():
         ev[0].record()
         aplan.run(out=feats)
         ev[1].record()
-        eng.synthesis_lossless_frames(N, feats[0], feats[1], feats[2], out=frames)
+        eng.synthesis_lossless_ola(N, feats[0], feats[1], feats[2], splan.chunks, splan.n_chunks, splan.pm_rel,
+                                   splan.territory, strips)
         ev[2].record()
-        eng.ola_gather(N, frames, splan.utt_frame_off, splan.pm_rel, splan.out_start, splan.out_off,
-                       splan.max_out_len, splan.total_out, out=pcm_out)
+        eng.ola_fixup(N, splan.territory, strips, splan.utt_chunk_off, splan.strip_id, splan.out_start,
+                      splan.out_off, splan.max_out_len, splan.total_out, out=pcm_out)
         ev[3].record()
         torch.cuda.synchronize()
         for k in range(3):
             acc[k] += ev[k].elapsed_time(ev[k + 1])
     ms = [a / reps for a in acc]
     # algorithmic bytes per launch: features are materialised once (the API returns them),
-    # every PCM sample is read once and written once; the frames scratch is NOT algorithmic traffic.
+    # every PCM sample is read once and written once; the OLA strips are NOT algorithmic traffic.
     alg = [12.0 * H * F + 4.0 * aplan.total_smpls, 12.0 * H * F, 4.0 * splan.total_out]
     kern = [{"name": names[k], "ms": round(ms[k], 4), "alg_bytes": alg[k],
              "alg_GBps": round(alg[k] / (ms[k] * 1e-3) / 1e9, 1)} for k in range(3)]
@@ -199,6 +200,7 @@ def main():
                        "frames_per_gpu": F, "audio_s_per_gpu": UTTS_PER_GPU * DUR_S,
                        "x_realtime": round(UTTS_PER_GPU * DUR_S * world / (dt / args.steps), 1),
                        "parallelism": "utterance-sharded x%d, no collective" % world,
+                       "ola_territory": splan.territory, "ola_chunks": splan.n_chunks,
                        "host_plan_build_s": round(t_plan, 3)},
             "roofline": roof,
         }

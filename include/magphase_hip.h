@@ -78,6 +78,26 @@ int mpx_ola_gather(void* stream, int fft_len, const float* frames, int32_t n_utt
                    const int32_t* pm_rel, const int32_t* out_start, const int64_t* out_off, int64_t max_out_len,
                    float* pcm_out);
 
+/*
+ * Fused lossless synthesis + PSOLA (the production path; the two calls above stay as the reference form).
+ * The OLA buffer of every utterance (magphase.py:38) is cut into territories of `territory` samples
+ * (multiple of 64, >= N/2); a CHUNK is the run of consecutive frames of one utterance whose centre
+ * pm_rel + N/2 falls in one territory.  mpx_synthesis_lossless_ola overlap-adds each chunk's frames, in
+ * ascending frame order, into the chunk's strip (territory + N floats: N/2 of halo on each side);
+ * mpx_ola_fixup sums, for every output sample, the strips of territories c-1, c, c+1 in that fixed order
+ * (deterministic; differs from the reference's single ascending sum only by fp32 re-association).
+ * chunks        : n_chunks x {int32 frame_begin, frame_end, x0, pad}; x0 = c*territory - N/2
+ * strips        : float32 [n_chunks x (territory + N)], strip i belongs to chunk i
+ * utt_chunk_off : int32[n_utts+1] territory range of each utterance in strip_id
+ * strip_id      : int32[sum of territories]  chunk index owning the territory, or -1 if it has no frame
+ */
+int mpx_synthesis_lossless_ola(void* stream, int fft_len, const void* tables, const float* mag, const float* real,
+                               const float* imag, const void* chunks, int32_t n_chunks, const int32_t* pm_rel,
+                               int32_t territory, float* strips);
+int mpx_ola_fixup(void* stream, int fft_len, int32_t territory, const float* strips, int32_t n_utts,
+                  const int32_t* utt_chunk_off, const int32_t* strip_id, const int32_t* out_start,
+                  const int64_t* out_off, int64_t max_out_len, float* pcm_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -18,6 +18,8 @@ SYMBOLS = (
     "mpx_analysis_frames",
     "mpx_synthesis_lossless_frames",
     "mpx_ola_gather",
+    "mpx_synthesis_lossless_ola",
+    "mpx_ola_fixup",
 )
 
 _lib = None
@@ -53,6 +55,10 @@ def load():
     lib.mpx_synthesis_lossless_frames.argtypes = [vp, ctypes.c_int, vp, vp, vp, vp, i64, vp]
     lib.mpx_ola_gather.restype = ctypes.c_int
     lib.mpx_ola_gather.argtypes = [vp, ctypes.c_int, vp, i32, vp, vp, vp, vp, i64, vp]
+    lib.mpx_synthesis_lossless_ola.restype = ctypes.c_int
+    lib.mpx_synthesis_lossless_ola.argtypes = [vp, ctypes.c_int, vp, vp, vp, vp, vp, i32, vp, i32, vp]
+    lib.mpx_ola_fixup.restype = ctypes.c_int
+    lib.mpx_ola_fixup.argtypes = [vp, ctypes.c_int, i32, vp, i32, vp, vp, vp, vp, i64, vp]
     _lib = lib
     return lib
 

@@ -175,6 +175,95 @@ __global__ __launch_bounds__(kThreads) void k_analysis(const float* __restrict__
     }
 }
 
+// Hermitian merge Z[k] = E[k] + i O[k] of the half spectrum held as lane l, register j <-> bin l + 64 j
+// (values pre-scaled by 0.5/M, fftshift sign folded in), in place, two bins (j, P-1-j) per step so that no
+// second register array is live.  Partner bin M-k: lane (64-lane)&63, register P-1-j; lane 0 pairs (j, P-j)
+// instead, served from a one-bin stash of the original register P-j (overwritten one step earlier).
+// xm = Nyquist bin (real), only meaningful on lane 0.  (wl_c, wl_s) = e^{+2 pi i lane/N}.
+template <int P>
+__device__ __forceinline__ void hermitian_merge(float (&xr)[P], float (&xi)[P], float xm, int lane, float wl_c,
+                                                float wl_s) {
+    const int src_lane = (64 - lane) & 63;
+    const bool lane0 = (lane == 0);
+    float st_r = 0.0f, st_i = 0.0f;
+#pragma unroll
+    for (int j = 0; j < P / 2; ++j) {
+        const int jp = P - 1 - j;
+        const float ar = xr[j], ai = xi[j], br = xr[jp], bi = xi[jp];
+        float par = __shfl(br, src_lane), pai = __shfl(bi, src_lane);
+        float pbr = __shfl(ar, src_lane), pbi = __shfl(ai, src_lane);
+        const float l0ar = (j == 0) ? xm : st_r, l0ai = (j == 0) ? 0.0f : st_i;
+        const float l0br = (j + 1 == jp) ? br : xr[j + 1], l0bi = (j + 1 == jp) ? bi : xi[j + 1];
+        par = lane0 ? l0ar : par;
+        pai = lane0 ? l0ai : pai;
+        pbr = lane0 ? l0br : pbr;
+        pbi = lane0 ? l0bi : pbi;
+        st_r = br;
+        st_i = bi;
+        {   // bin j:  E = X + conj(Xp), T = X - conj(Xp), O = conj(W_N^k) T, conj(W_N^k) = e^{+2 pi i (lane/N + j/2P)}
+            const float er = ar + par, ei = ai - pai, tr = ar - par, ti = ai + pai;
+            const float cq = cos2p<P>(j), sq = sin2p<P>(j);
+            const float wr = wl_c * cq - wl_s * sq, wi = wl_c * sq + wl_s * cq;
+            xr[j] = er - (wr * ti + wi * tr);
+            xi[j] = ei + (wr * tr - wi * ti);
+        }
+        {   // bin P-1-j
+            const float er = br + pbr, ei = bi - pbi, tr = br - pbr, ti = bi + pbi;
+            const float cq = cos2p<P>(jp), sq = sin2p<P>(jp);
+            const float wr = wl_c * cq - wl_s * sq, wi = wl_c * sq + wl_s * cq;
+            xr[jp] = er - (wr * ti + wi * tr);
+            xi[jp] = ei + (wr * tr - wi * ti);
+        }
+    }
+}
+
+// Loads one frame's lossless features (bins lane + 64 j, plus the Nyquist bin on lane 0) and turns them into the
+// scaled unit-phase spectrum X = mag (R + jI)/|R + jI| (0 where |R + jI| == 0), magphase.py:1761-1766, with
+// DC/Nyquist imaginary parts dropped (Q5) and the (-1)^k fftshift sign and the 0.5/M scale folded in.
+template <int P>
+struct FrameFeat {
+    float m[P], a[P], b[P];
+    float mM, aM, bM;
+};
+
+template <int P>
+__device__ __forceinline__ void feat_load(FrameFeat<P>& ff, const float* __restrict__ mrow,
+                                          const float* __restrict__ rrow, const float* __restrict__ irow, int lane) {
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+        const int k = lane + 64 * j;
+        ff.m[j] = mrow[k];
+        ff.a[j] = rrow[k];
+        ff.b[j] = irow[k];
+    }
+    ff.mM = ff.aM = ff.bM = 0.0f;
+    if (lane == 0) {
+        ff.mM = mrow[64 * P];
+        ff.aM = rrow[64 * P];
+        ff.bM = irow[64 * P];
+    }
+}
+
+template <int P>
+__device__ __forceinline__ void feat_convert(const FrameFeat<P>& ff, float (&xr)[P], float (&xi)[P], float& xm,
+                                             int lane) {
+    constexpr int M = 64 * P;
+    const float sgn_scale = ((lane & 1) ? -1.0f : 1.0f) * (0.5f / (float)M);
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+        const float s = ff.a[j] * ff.a[j] + ff.b[j] * ff.b[j];
+        const float g = (s > 0.0f) ? ff.m[j] * sgn_scale * __builtin_amdgcn_rsqf(s) : 0.0f;
+        xr[j] = ff.a[j] * g;
+        xi[j] = ff.b[j] * g;
+    }
+    xm = 0.0f;
+    if (lane == 0) {
+        xi[0] = 0.0f;
+        const float s = ff.aM * ff.aM + ff.bM * ff.bM;
+        xm = (s > 0.0f) ? ff.mM * (0.5f / (float)M) * ff.aM * __builtin_amdgcn_rsqf(s) : 0.0f;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // lossless synthesis: per-frame spectrum rebuild + inverse real FFT (epoch at N/2)
 // ---------------------------------------------------------------------------------------------
@@ -203,64 +292,12 @@ __global__ __launch_bounds__(kThreads) void k_synth_lossless(const float* __rest
         int lane = lane_id;  // laundered per frame (see k_analysis)
         float wl_s = wl_s0, wl_c = wl_c0;
         asm volatile("" : "+v"(lane), "+v"(wl_s), "+v"(wl_c));
-        const int src_lane = (64 - lane) & 63;
-        const bool lane0 = (lane == 0);
-        // fftshift of the output == (-1)^k on the spectrum; k parity == lane parity.  0.5/M = merge + IFFT scale.
-        const float sgn_scale = ((lane & 1) ? -1.0f : 1.0f) * (0.5f / (float)M);
         const int kap = kappa<P>(lane);
-        const float* mrow = mag + f * H;
-        const float* rrow = real + f * H;
-        const float* irow = imag + f * H;
-        float xr[P], xi[P];
-#pragma unroll
-        for (int j = 0; j < P; ++j) {
-            const int k = lane + 64 * j;
-            const float m = mrow[k], a = rrow[k], b = irow[k];
-            const float s = a * a + b * b;
-            const float g = (s > 0.0f) ? m * sgn_scale * __builtin_amdgcn_rsqf(s) : 0.0f;
-            xr[j] = a * g;
-            xi[j] = b * g;
-        }
-        float xm = 0.0f;  // Nyquist bin (real part only, Q5); (-1)^M == +1
-        if (lane0) {
-            xi[0] = 0.0f;  // DC imaginary part dropped (Q5)
-            const float m = mrow[M], a = rrow[M], b = irow[M];
-            const float s = a * a + b * b;
-            xm = (s > 0.0f) ? m * (0.5f / (float)M) * a * __builtin_amdgcn_rsqf(s) : 0.0f;
-        }
-        // Hermitian merge Z[k] = E[k] + i O[k], in place, two bins (j, P-1-j) per step so that no second
-        // register array is live.  Partner bin M-k: lane (64-lane)&63, register P-1-j; lane 0 pairs (j, P-j)
-        // instead, served from a one-bin stash of the original register P-j (overwritten one step earlier).
-        float st_r = 0.0f, st_i = 0.0f;
-#pragma unroll
-        for (int j = 0; j < P / 2; ++j) {
-            const int jp = P - 1 - j;
-            const float ar = xr[j], ai = xi[j], br = xr[jp], bi = xi[jp];
-            float par = __shfl(br, src_lane), pai = __shfl(bi, src_lane);
-            float pbr = __shfl(ar, src_lane), pbi = __shfl(ai, src_lane);
-            const float l0ar = (j == 0) ? xm : st_r, l0ai = (j == 0) ? 0.0f : st_i;
-            const float l0br = (j + 1 == jp) ? br : xr[j + 1], l0bi = (j + 1 == jp) ? bi : xi[j + 1];
-            par = lane0 ? l0ar : par;
-            pai = lane0 ? l0ai : pai;
-            pbr = lane0 ? l0br : pbr;
-            pbi = lane0 ? l0bi : pbi;
-            st_r = br;
-            st_i = bi;
-            {   // bin j:  E = X + conj(Xp), T = X - conj(Xp), O = conj(W_N^k) T, conj(W_N^k) = e^{+2 pi i (lane/N + j/2P)}
-                const float er = ar + par, ei = ai - pai, tr = ar - par, ti = ai + pai;
-                const float cq = cos2p<P>(j), sq = sin2p<P>(j);
-                const float wr = wl_c * cq - wl_s * sq, wi = wl_c * sq + wl_s * cq;
-                xr[j] = er - (wr * ti + wi * tr);
-                xi[j] = ei + (wr * tr - wi * ti);
-            }
-            {   // bin P-1-j
-                const float er = br + pbr, ei = bi - pbi, tr = br - pbr, ti = bi + pbi;
-                const float cq = cos2p<P>(jp), sq = sin2p<P>(jp);
-                const float wr = wl_c * cq - wl_s * sq, wi = wl_c * sq + wl_s * cq;
-                xr[jp] = er - (wr * ti + wi * tr);
-                xi[jp] = ei + (wr * tr - wi * ti);
-            }
-        }
+        FrameFeat<P> ff;
+        feat_load<P>(ff, mag + f * H, real + f * H, imag + f * H, lane);
+        float xr[P], xi[P], xm;
+        feat_convert<P>(ff, xr, xi, xm, lane);
+        hermitian_merge<P>(xr, xi, xm, lane, wl_c, wl_s);
 
         wave_fft<P, +1>(xr, xi, tw, xbuf, lane);
 
@@ -268,6 +305,138 @@ __global__ __launch_bounds__(kThreads) void k_synth_lossless(const float* __rest
 #pragma unroll
         for (int i = 0; i < P; ++i) out[kap + 64 * brev(i, LB)] = make_float2(xr[i], xi[i]);
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// fused lossless synthesis + PSOLA.  One wavefront owns one CHUNK = the consecutive frames of one
+// utterance whose centres fall in a territory of T samples of the reference's OLA buffer; it rebuilds
+// each frame (as k_synth_lossless) and overlap-adds it, in ascending frame order, into a ring buffer in
+// LDS, streaming the finished part out to the chunk's private strip (T + N floats: the territory plus
+// N/2 of halo on each side).  k_ola_fixup then sums the <= 3 strips covering each output sample.
+// HBM traffic: features read once, (T+N)/T * 4 B per output sample written -- the [F x N] frame
+// scratch of the two-kernel path (16 KB per frame written + read) is gone.
+// ---------------------------------------------------------------------------------------------
+constexpr int kSynWaves = 5;  // LDS: 16 KB twiddles + 5 x (8.1 KB transpose + 16.25 KB ring) = 138 KB
+template <int P>
+constexpr int ring_len() { return 128 * P + 64; }
+template <int P>
+constexpr size_t lds_bytes_ola() {
+    return sizeof(float) * (size_t)(P * 64 * 2 + kSynWaves * (P * kXStride + ring_len<P>()));
+}
+
+struct ChunkDesc {
+    int frame_begin, frame_end;  // global frame indices (rows of mag/real/imag, entries of pm_rel)
+    int x0;                      // OLA-buffer coordinate of strip element 0 (= c*T - N/2, may be negative)
+    int pad;
+};
+
+template <int P>
+__global__ __launch_bounds__(kSynWaves * 64) void k_synth_ola(const float* __restrict__ mag,
+                                                              const float* __restrict__ real,
+                                                              const float* __restrict__ imag,
+                                                              const ChunkDesc* __restrict__ chunks, int nchunks,
+                                                              const int* __restrict__ pm_rel, int T,
+                                                              const float2* __restrict__ tw_g,
+                                                              float* __restrict__ strips) {
+    constexpr int M = 64 * P, N = 2 * M, H = M + 1, LB = ilog2(P), R = ring_len<P>();
+    extern __shared__ float smem[];
+    float2* tw = reinterpret_cast<float2*>(smem);
+    const int lane_id = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    float* xbuf = smem + P * 64 * 2 + wave * (P * kXStride + R);
+    float* ring = xbuf + P * kXStride;
+    for (int i = threadIdx.x; i < P * 64; i += kSynWaves * 64) tw[i] = tw_g[i];
+    __syncthreads();
+
+    float wl_s0, wl_c0;
+    sincospif(2.0f * (float)lane_id / (float)N, &wl_s0, &wl_c0);
+    const int wave_u = rfl(wave);
+    const int strip_len = T + N;
+
+    for (int ci = blockIdx.x * kSynWaves + wave_u; ci < nchunks; ci += gridDim.x * kSynWaves) {
+        const ChunkDesc cd = chunks[ci];
+        float* strip = strips + (long long)ci * strip_len;
+        for (int i = lane_id; i < R; i += 64) ring[i] = 0.0f;
+        wave_sync();
+        int flushed = 0;  // strip elements [0, flushed) are final and written
+
+        FrameFeat<P> ff;
+        {
+            const long long f = cd.frame_begin;
+            feat_load<P>(ff, mag + f * H, real + f * H, imag + f * H, lane_id);
+        }
+        for (int fi = cd.frame_begin; fi < cd.frame_end; ++fi) {
+            int lane = lane_id;  // laundered per frame (see k_analysis)
+            float wl_s = wl_s0, wl_c = wl_c0;
+            asm volatile("" : "+v"(lane), "+v"(wl_s), "+v"(wl_c));
+            float xr[P], xi[P], xm;
+            feat_convert<P>(ff, xr, xi, xm, lane);
+            if (fi + 1 < cd.frame_end) {  // prefetch the next frame's features behind this frame's FFT
+                const long long f = fi + 1;
+                feat_load<P>(ff, mag + f * H, real + f * H, imag + f * H, lane);
+            }
+            hermitian_merge<P>(xr, xi, xm, lane, wl_c, wl_s);
+            wave_fft<P, +1>(xr, xi, tw, xbuf, lane);
+
+            // strip coordinate of this frame's first sample, and the ring window [flushed, flushed + R)
+            const int x = pm_rel[fi] - cd.x0;   // in [0, T)
+            const int target = x & ~63;
+            for (int b0 = flushed; b0 < target; b0 += 64) {  // everything below x is final: stream it out
+                const int b = b0 + lane;
+                const int slot = b % R;
+                strip[b] = ring[slot];
+                ring[slot] = 0.0f;
+            }
+            flushed = max(flushed, target);
+            wave_sync();
+            const int kap = kappa<P>(lane);
+            int base = (x % R) + 2 * kap;  // slot of sample n = 2*kap (+128 q), before wrap
+#pragma unroll
+            for (int i = 0; i < P; ++i) {
+                int s0 = base + 128 * brev(i, LB);
+                s0 = (s0 >= R) ? s0 - R : s0;
+                int s1 = s0 + 1;
+                s1 = (s1 >= R) ? s1 - R : s1;
+                atomicAdd(&ring[s0], xr[i]);  // wave-private LDS: ds_add_f32, no contention
+                atomicAdd(&ring[s1], xi[i]);
+            }
+            wave_sync();
+        }
+        for (int b0 = flushed; b0 < strip_len; b0 += 64) {
+            const int b = b0 + lane_id;
+            if (b < strip_len) strip[b] = ring[b % R];
+        }
+        wave_sync();
+    }
+}
+
+// out[t] = sum over the strips of chunks c-1, c, c+1 (c = territory of b = t + out_start) -- fixed order.
+__global__ __launch_bounds__(256) void k_ola_fixup(const float* __restrict__ strips, int N, int T,
+                                                   const int* __restrict__ utt_chunk_off,
+                                                   const int* __restrict__ strip_id,
+                                                   const int* __restrict__ out_start,
+                                                   const long long* __restrict__ out_off,
+                                                   float* __restrict__ pcm) {
+    const int u = blockIdx.y;
+    const long long o0 = out_off[u];
+    const long long len = out_off[u + 1] - o0;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= len) return;
+    const int c0 = utt_chunk_off[u], nc = utt_chunk_off[u + 1] - c0;
+    const long long b = t + out_start[u];
+    const int c = (int)(b / T);
+    const int strip_len = T + N;
+    float acc = 0.0f;
+#pragma unroll
+    for (int d = -1; d <= 1; ++d) {
+        const int cc = c + d;
+        if (cc < 0 || cc >= nc) continue;
+        const int sid = strip_id[c0 + cc];
+        if (sid < 0) continue;
+        const long long idx = b - ((long long)cc * T - N / 2);
+        if (idx >= 0 && idx < strip_len) acc += strips[(long long)sid * strip_len + idx];
+    }
+    pcm[o0 + t] = acc;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -419,6 +588,58 @@ int mpx_ola_gather(void* stream, int fft_len, const float* frames, int32_t n_utt
     const dim3 block(256), grid((unsigned)((max_out_len + 255) / 256), (unsigned)n_utts);
     hipLaunchKernelGGL(k_ola_gather, grid, block, 0, (hipStream_t)stream, frames, fft_len, utt_frame_off, pm_rel,
                        out_start, (const long long*)out_off, pcm_out);
+    MPX_HIP_CHECK(hipGetLastError());
+    return MPX_OK;
+}
+
+int mpx_synthesis_lossless_ola(void* stream, int fft_len, const void* tables, const float* mag, const float* real,
+                               const float* imag, const void* chunks, int32_t n_chunks, const int32_t* pm_rel,
+                               int32_t territory, float* strips) {
+    const int P = p_of(fft_len);
+    if (!P) return fail(MPX_ERR_ARG, "mpx_synthesis_lossless_ola: fft_len must be 2048 or 4096%s");
+    if (n_chunks < 0) return fail(MPX_ERR_ARG, "mpx_synthesis_lossless_ola: negative n_chunks%s");
+    if (territory < fft_len / 2 || (territory % 64) != 0)
+        return fail(MPX_ERR_ARG, "mpx_synthesis_lossless_ola: territory must be a multiple of 64 and >= fft_len/2%s");
+    if (n_chunks == 0) return MPX_OK;
+    if (!tables || !mag || !real || !imag || !chunks || !pm_rel || !strips)
+        return fail(MPX_ERR_ARG, "mpx_synthesis_lossless_ola: null pointer%s");
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+    }
+    const int need = (n_chunks + kSynWaves - 1) / kSynWaves;
+    const dim3 grid(std::max(1, std::min(need, cus))), block(kSynWaves * 64);
+    hipStream_t s = (hipStream_t)stream;
+    if (P == 32) {
+        if (int rc = set_lds(k_synth_ola<32>, lds_bytes_ola<32>())) return rc;
+        hipLaunchKernelGGL(k_synth_ola<32>, grid, block, lds_bytes_ola<32>(), s, mag, real, imag,
+                           (const ChunkDesc*)chunks, (int)n_chunks, pm_rel, (int)territory, (const float2*)tables,
+                           strips);
+    } else {
+        if (int rc = set_lds(k_synth_ola<16>, lds_bytes_ola<16>())) return rc;
+        hipLaunchKernelGGL(k_synth_ola<16>, grid, block, lds_bytes_ola<16>(), s, mag, real, imag,
+                           (const ChunkDesc*)chunks, (int)n_chunks, pm_rel, (int)territory, (const float2*)tables,
+                           strips);
+    }
+    MPX_HIP_CHECK(hipGetLastError());
+    return MPX_OK;
+}
+
+int mpx_ola_fixup(void* stream, int fft_len, int32_t territory, const float* strips, int32_t n_utts,
+                  const int32_t* utt_chunk_off, const int32_t* strip_id, const int32_t* out_start,
+                  const int64_t* out_off, int64_t max_out_len, float* pcm_out) {
+    if (!p_of(fft_len)) return fail(MPX_ERR_ARG, "mpx_ola_fixup: fft_len must be 2048 or 4096%s");
+    if (n_utts < 0 || max_out_len < 0) return fail(MPX_ERR_ARG, "mpx_ola_fixup: negative size%s");
+    if (territory < fft_len / 2 || (territory % 64) != 0)
+        return fail(MPX_ERR_ARG, "mpx_ola_fixup: territory must be a multiple of 64 and >= fft_len/2%s");
+    if (n_utts == 0 || max_out_len == 0) return MPX_OK;
+    if (!strips || !utt_chunk_off || !strip_id || !out_start || !out_off || !pcm_out)
+        return fail(MPX_ERR_ARG, "mpx_ola_fixup: null pointer%s");
+    if (n_utts > 65535) return fail(MPX_ERR_ARG, "mpx_ola_fixup: at most 65535 utterances per call%s");
+    const dim3 block(256), grid((unsigned)((max_out_len + 255) / 256), (unsigned)n_utts);
+    hipLaunchKernelGGL(k_ola_fixup, grid, block, 0, (hipStream_t)stream, strips, fft_len, (int)territory,
+                       utt_chunk_off, strip_id, out_start, (const long long*)out_off, pcm_out);
     MPX_HIP_CHECK(hipGetLastError());
     return MPX_OK;
 }

@@ -9,6 +9,8 @@ Data layout in HBM (all float32, row-major):
   frames   [F_tot x N]          epoch-centred time-domain frames (scratch between IFFT and PSOLA)
   pcm_out  [sum_u len_u]        resynthesised PCM, concatenated
 """
+import os
+
 import numpy as np
 
 from . import _lib, hostmath as hm
@@ -101,6 +103,33 @@ class Engine:
         return out
 
 
+    def synthesis_lossless_ola(self, fft_len, mag, real, imag, chunks, n_chunks, pm_rel, territory, strips):
+        torch = _torch()
+        tab = self.tables(fft_len)
+        with torch.cuda.device(self.device):
+            _lib.check(
+                self.lib.mpx_synthesis_lossless_ola(self.stream_ptr(), int(fft_len), tab.data_ptr(), mag.data_ptr(),
+                                                    real.data_ptr(), imag.data_ptr(), chunks.data_ptr(),
+                                                    int(n_chunks), pm_rel.data_ptr(), int(territory),
+                                                    strips.data_ptr()),
+                "mpx_synthesis_lossless_ola")
+        return strips
+
+    def ola_fixup(self, fft_len, territory, strips, utt_chunk_off, strip_id, out_start, out_off, max_out_len,
+                  total_out, out=None):
+        torch = _torch()
+        if out is None:
+            out = self.empty((int(total_out),))
+        n_utts = int(out_start.numel())
+        with torch.cuda.device(self.device):
+            _lib.check(
+                self.lib.mpx_ola_fixup(self.stream_ptr(), int(fft_len), int(territory), strips.data_ptr(), n_utts,
+                                       utt_chunk_off.data_ptr(), strip_id.data_ptr(), out_start.data_ptr(),
+                                       out_off.data_ptr(), int(max_out_len), out.data_ptr()),
+                "mpx_ola_fixup")
+        return out
+
+
 _ENGINES = {}
 
 
@@ -174,9 +203,10 @@ class LosslessSynthesisPlan:
     -> ola() offsets and trimming (magphase.py:34-62).  All float64/int host math; device gets int tables.
     """
 
-    def __init__(self, engine, f0_list, fs_list, fft_len):
+    def __init__(self, engine, f0_list, fs_list, fft_len, territory=None):
         self.engine = engine
         self.fft_len = fft_len
+        self.territory = int(territory) if territory else int(os.environ.get("MAGPHASE_OLA_TERRITORY", fft_len))
         pm_rel, starts, lens, nfr = [], [], [], []
         self.v_pm = []
         for v_f0, fs in zip(f0_list, fs_list):
@@ -197,8 +227,30 @@ class LosslessSynthesisPlan:
         self.pm_rel = e.to_device(np.concatenate(pm_rel) if pm_rel else np.zeros(0), np.int32)
         self.out_start = e.to_device(np.asarray(starts), np.int32)
         self.out_off = e.to_device(self.out_off_host, np.int64)
+        self._build_chunks(pm_rel, nfr)
 
-    def run(self, mag, real, imag, frames=None, out=None):
+    def _build_chunks(self, pm_rel_list, nfr):
+        """Territories of the OLA buffer -> chunks (include/magphase_hip.h: mpx_synthesis_lossless_ola)."""
+        rows, terr_off, owner_all = hm.ola_chunks(pm_rel_list, self.fft_len, self.territory)
+        e = self.engine
+        self.n_chunks = int(rows.shape[0])
+        self.chunks = e.to_device(rows, np.int32)
+        self.utt_chunk_off = e.to_device(np.asarray(terr_off), np.int32)
+        self.strip_id = e.to_device(owner_all, np.int32)
+        self.strip_floats = self.n_chunks * (T + N)
+
+    def run(self, mag, real, imag, strips=None, out=None):
+        """Fused path: k_synth_ola (per-chunk LDS overlap-add) + k_ola_fixup."""
+        e = self.engine
+        if strips is None:
+            strips = e.empty((self.strip_floats,))
+        e.synthesis_lossless_ola(self.fft_len, mag, real, imag, self.chunks, self.n_chunks, self.pm_rel,
+                                 self.territory, strips)
+        return e.ola_fixup(self.fft_len, self.territory, strips, self.utt_chunk_off, self.strip_id, self.out_start,
+                           self.out_off, self.max_out_len, self.total_out, out=out)
+
+    def run_unfused(self, mag, real, imag, frames=None, out=None):
+        """Two-kernel form: frames to HBM, then the ascending-order gather (bit-for-bit the reference's sum order)."""
         e = self.engine
         frames = e.synthesis_lossless_frames(self.fft_len, mag, real, imag, out=frames)
         return e.ola_gather(self.fft_len, frames, self.utt_frame_off, self.pm_rel, self.out_start, self.out_off,

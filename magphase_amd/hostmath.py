@@ -104,3 +104,41 @@ def ola_plan(v_pm, frmlen):
         stop = max(len1 + stop, 0)
     out_len = min(len1, stop)
     return (v_pm - v_pm[0]).astype(np.int64), int(start), int(out_len)
+
+
+def ola_chunks(pm_rel_list, fft_len, territory):
+    """
+    Cuts every utterance's OLA buffer (magphase.py:38) into territories of ``territory`` samples and groups the
+    frames by the territory their centre pm_rel + N/2 falls in (include/magphase_hip.h:
+    mpx_synthesis_lossless_ola).  Returns
+      rows      int64[n_chunks x 4]  (frame_begin, frame_end, x0 = c*T - N/2, 0), longest chunk first,
+      terr_off  int64[U+1]           territory range of each utterance in ``owner``,
+      owner     int64[sum territories] chunk (row) index owning the territory, -1 if it holds no frame centre.
+    """
+    N, T = int(fft_len), int(territory)
+    if T % 64 != 0 or T < N // 2:
+        raise ValueError("territory must be a multiple of 64 and >= fft_len/2")
+    chunk_rows, terr_off, terr_owner = [], [0], []
+    f_base = 0
+    for rel in pm_rel_list:
+        rel = np.asarray(rel, dtype=np.int64)
+        n = rel.size
+        n_terr = int((rel[-1] + N - 1) // T) + 1
+        c = (rel + N // 2) // T  # non-decreasing
+        cut = np.flatnonzero(np.diff(c)) + 1
+        begins = np.concatenate(([0], cut))
+        ends = np.concatenate((cut, [n]))
+        owner = np.full(n_terr, -1, dtype=np.int64)
+        for b, e_ in zip(begins, ends):
+            owner[int(c[b])] = len(chunk_rows)
+            chunk_rows.append((f_base + int(b), f_base + int(e_), int(c[b]) * T - N // 2, 0))
+        terr_owner.append(owner)
+        terr_off.append(terr_off[-1] + n_terr)
+        f_base += n
+    rows = np.asarray(chunk_rows, dtype=np.int64).reshape(-1, 4)
+    order = np.argsort(-(rows[:, 1] - rows[:, 0]), kind="stable")  # longest chunks first (load balance)
+    rank = np.empty_like(order)
+    rank[order] = np.arange(order.size)
+    owner_all = np.concatenate(terr_owner) if terr_owner else np.zeros(0, dtype=np.int64)
+    owner_all = np.where(owner_all >= 0, rank[np.maximum(owner_all, 0)], -1)
+    return rows[order], np.asarray(terr_off, dtype=np.int64), owner_all

@@ -203,3 +203,27 @@ def test_full_size_config2_roundtrip_property(mp, orc):
         y = out[splan.out_off_host[u]:splan.out_off_host[u + 1]]
         assert len(y) == len(ref)
         assert np.max(np.abs(y - ref)) <= 2 * PCM_TOL * np.max(np.abs(ref))
+
+
+@pytest.mark.parametrize("fs,terr", [(48000, 4096), (48000, 2048), (48000, 8192), (16000, 2048), (16000, 1024)])
+def test_fused_ola_equals_two_kernel_form(mp, fs, terr):
+    """k_synth_ola + k_ola_fixup (any territory size) vs frames-to-HBM + ascending gather: same sums up to fp32 re-association."""
+    import torch
+    from magphase_amd import synthetic as syn
+    from magphase_amd.engine import LosslessAnalysisPlan, LosslessSynthesisPlan, get_engine
+    eng = get_engine()
+    utts = []
+    for u in range(6):
+        pcm, pm, voi = syn.make_utterance(70 + u, dur_s=0.7 + 0.35 * u, fs=fs)
+        utts.append((pcm, fs, pm, voi))
+    plan = LosslessAnalysisPlan(eng, utts)
+    mag, real, imag = plan.run()
+    f0 = [f.copy() for f in plan.v_f0]
+    f0[2][0] = 15.0 if fs == 48000 else 6.0   # first epoch beyond N/2: negative python slice start + empty territories
+    splan = LosslessSynthesisPlan(eng, f0, plan.fs, plan.fft_len, territory=terr)
+    a = splan.run(mag, real, imag).cpu().numpy()
+    b = splan.run_unfused(mag, real, imag).cpu().numpy()
+    a2 = splan.run(mag, real, imag).cpu().numpy()
+    assert a.shape == b.shape
+    assert np.array_equal(a, a2)                                   # deterministic
+    assert np.max(np.abs(a - b)) <= 2e-6 * np.max(np.abs(b))
