@@ -33,7 +33,14 @@ static int fail(int code, const char* fmt, const char* detail = "") {
         if (e__ != hipSuccess) return fail(MPX_ERR_HIP, #expr ": %s", hipGetErrorString(e__)); \
     } while (0)
 
-constexpr int kWavesPerBlock = 16;  // 1024 threads: one block per CU, 4 waves per SIMD
+// Build-time knobs (tools/ab_bench.py builds variants with -D... and times them interleaved in one process).
+#ifndef MPX_WAVES_PER_BLOCK
+#define MPX_WAVES_PER_BLOCK 16
+#endif
+#ifndef MPX_SYN_WAVES
+#define MPX_SYN_WAVES 5
+#endif
+constexpr int kWavesPerBlock = MPX_WAVES_PER_BLOCK;  // 16: 1024 threads, one block per CU, 4 waves per SIMD
 constexpr int kThreads = kWavesPerBlock * 64;
 
 template <int P>
@@ -131,8 +138,13 @@ __global__ __launch_bounds__(kThreads) void k_analysis(const float* __restrict__
                 k0 = (k0 >= N) ? k0 - N : k0;
                 int k1 = m + 1 + rot;
                 k1 = (k1 >= N) ? k1 - N : k1;
+#ifdef MPX_PROBE_NOLOAD
+                if (k0 < len) a = 0.37f * hann_half(k0, L, LR, kadd, invL, invR);
+                if (k1 < len) b = -0.21f * hann_half(k1, L, LR, kadd, invL, invR);
+#else
                 if (k0 < len) a = base[k0] * hann_half(k0, L, LR, kadd, invL, invR);
                 if (k1 < len) b = base[k1] * hann_half(k1, L, LR, kadd, invL, invR);
+#endif
             }
             re[j] = a;
             im[j] = b;
@@ -140,13 +152,20 @@ __global__ __launch_bounds__(kThreads) void k_analysis(const float* __restrict__
 
         wave_fft<P, -1>(re, im, tw, xbuf, lane);
 
-        float* mrow = omag + f * H;
-        float* rrow = oreal + f * H;
-        float* irow = oimag + f * H;
+        // Real-FFT split, one (k, M-k) bin pair per step: lane kappa owns k = kappa + 64 q for q < P/2 (the even
+        // registers) and also produces the mirrored bin M-k from the same E/T terms:
+        //   E = (Z[k] + conj Z[M-k])/2, T = W_N^k (Z[k] - conj Z[M-k])/(2i), X[k] = E + T, X[M-k] = conj(E - T).
+        // Z[M-k] lives in lane (64-kappa)&63, register P-1-i (lane 0: own register holding bin (P-q)%P).
+        // Bin M/2 is its own mirror (lane 0, register 1: X = conj Z); bin M comes out of the k = 0 pair.
+        float* mlo = omag + f * H + kap;          // X[k]   : ascending lanes, +64 q
+        float* rlo = oreal + f * H + kap;
+        float* ilo = oimag + f * H + kap;
+        float* mhi = omag + f * H + (M - kap);    // X[M-k] : descending lanes, -64 q
+        float* rhi = oreal + f * H + (M - kap);
+        float* ihi = oimag + f * H + (M - kap);
 #pragma unroll
-        for (int i = 0; i < P; ++i) {
-            const int q = brev(i, LB);
-            // partner Z[M-k]: lane src_lane register P-1-i; for kappa==0 the own register holding (P-q)%P
+        for (int i = 0; i < P; i += 2) {
+            const int q = brev(i, LB);            // q < P/2
             const int i0 = brev((P - q) % P, LB);
             float pr = __shfl(re[P - 1 - i], src_lane);
             float pi = __shfl(im[P - 1 - i], src_lane);
@@ -154,23 +173,41 @@ __global__ __launch_bounds__(kThreads) void k_analysis(const float* __restrict__
             pi = lane0 ? im[i0] : pi;
             const float er = 0.5f * (re[i] + pr), ei = 0.5f * (im[i] - pi);
             const float orr = 0.5f * (im[i] + pi), oi = -0.5f * (re[i] - pr);
-            // W_N^k = W_N^kappa * e^{-2 pi i q/(2P)}
-            const float cq = cos2p<P>(q), sq = -sin2p<P>(q);
+            const float cq = cos2p<P>(q), sq = -sin2p<P>(q);   // W_N^k = W_N^kappa * e^{-2 pi i q/(2P)}
             const float wr = wl_c * cq - wl_s * sq, wi = wl_c * sq + wl_s * cq;
-            const float xr = er + (wr * orr - wi * oi);
-            const float xi = ei + (wr * oi + wi * orr);
-            const float s = xr * xr + xi * xi;
-            const float r = (s > 0.0f) ? __builtin_amdgcn_rsqf(s) : 0.0f;
-            const int k = kap + 64 * q;
-            mrow[k] = s * r;
-            rrow[k] = xr * r;
-            irow[k] = xi * r;
+            const float tr = wr * orr - wi * oi, ti = wr * oi + wi * orr;
+            {
+                const float xr = er + tr, xi = ei + ti;
+                const float s2 = xr * xr + xi * xi;
+                const float r = (s2 > 0.0f) ? __builtin_amdgcn_rsqf(s2) : 0.0f;
+#ifdef MPX_PROBE_NOSTORE
+                asm volatile("" ::"v"(s2 * r), "v"(xr * r), "v"(xi * r));
+#else
+                mlo[64 * q] = s2 * r;
+                rlo[64 * q] = xr * r;
+                ilo[64 * q] = xi * r;
+#endif
+            }
+            {
+                const float xr = er - tr, xi = ti - ei;
+                const float s2 = xr * xr + xi * xi;
+                const float r = (s2 > 0.0f) ? __builtin_amdgcn_rsqf(s2) : 0.0f;
+#ifdef MPX_PROBE_NOSTORE
+                asm volatile("" ::"v"(s2 * r), "v"(xr * r), "v"(xi * r));
+#else
+                mhi[-64 * q] = s2 * r;
+                rhi[-64 * q] = xr * r;
+                ihi[-64 * q] = xi * r;
+#endif
+            }
         }
-        if (lane0) {  // Nyquist bin X[M] = Re Z[0] - Im Z[0]
-            const float x = re[0] - im[0];
-            mrow[M] = fabsf(x);
-            rrow[M] = (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : 0.0f);
-            irow[M] = 0.0f;
+        if (lane0) {  // bin M/2 (register 1 holds q = P/2): X = conj Z
+            const float xr = re[1], xi = -im[1];
+            const float s2 = xr * xr + xi * xi;
+            const float r = (s2 > 0.0f) ? __builtin_amdgcn_rsqf(s2) : 0.0f;
+            mlo[M / 2] = s2 * r;
+            rlo[M / 2] = xr * r;
+            ilo[M / 2] = xi * r;
         }
     }
 }
@@ -316,12 +353,35 @@ __global__ __launch_bounds__(kThreads) void k_synth_lossless(const float* __rest
 // HBM traffic: features read once, (T+N)/T * 4 B per output sample written -- the [F x N] frame
 // scratch of the two-kernel path (16 KB per frame written + read) is gone.
 // ---------------------------------------------------------------------------------------------
-constexpr int kSynWaves = 5;  // LDS: 16 KB twiddles + 5 x (8.1 KB transpose + 16.25 KB ring) = 138 KB
+constexpr int kSynWaves = MPX_SYN_WAVES;  // LDS: 16 KB twiddles + 5 x (8.1 KB transpose + 16.5 KB ring) = 139 KB
+// Ring of R strip elements, stored as two halves: even strip positions b in ringE[b/2 mod R/2], odd ones in
+// ringO.  A lane's two samples (2m, 2m+1) of a frame then hit ringE/ringO[c + m] with m consecutive across
+// lanes: conflict-free 4-byte accesses whatever the parity of the frame position.  (LDS float atomics
+// -- ds_add_f32 -- measured ~190 LDS cycles per wave instruction on gfx950: plain read/add/write instead.)
 template <int P>
-constexpr int ring_len() { return 128 * P + 64; }
+constexpr int ring_len() { return 128 * P + 128; }
 template <int P>
 constexpr size_t lds_bytes_ola() {
     return sizeof(float) * (size_t)(P * 64 * 2 + kSynWaves * (P * kXStride + ring_len<P>()));
+}
+
+// Streams strip elements [from, to) out of the ring (to global) and clears their slots.  from is a multiple of 64.
+template <int R>
+__device__ __forceinline__ void flush_ring(float* ring, float* __restrict__ strip, int from, int to, int strip_len,
+                                           int lane) {
+    constexpr int RH = R / 2;
+    // element b = b0 + lane: half = b & 1 (b0 even => lane parity), index (b >> 1) mod RH
+    float* half = ring + ((lane & 1) ? RH : 0);
+    int idx = ((from >> 1) % RH) + (lane >> 1);
+    idx = (idx >= RH) ? idx - RH : idx;
+    for (int b0 = from; b0 < to; b0 += 64) {
+        const int b = b0 + lane;
+        const float v = half[idx];
+        if (b < strip_len) strip[b] = v;
+        half[idx] = 0.0f;
+        idx += 32;
+        idx = (idx >= RH) ? idx - RH : idx;
+    }
 }
 
 struct ChunkDesc {
@@ -352,12 +412,12 @@ __global__ __launch_bounds__(kSynWaves * 64) void k_synth_ola(const float* __res
     sincospif(2.0f * (float)lane_id / (float)N, &wl_s0, &wl_c0);
     const int wave_u = rfl(wave);
     const int strip_len = T + N;
+    for (int i = lane_id; i < R; i += 64) ring[i] = 0.0f;  // every chunk's tail flush leaves the ring cleared
+    wave_sync();
 
     for (int ci = blockIdx.x * kSynWaves + wave_u; ci < nchunks; ci += gridDim.x * kSynWaves) {
         const ChunkDesc cd = chunks[ci];
         float* strip = strips + (long long)ci * strip_len;
-        for (int i = lane_id; i < R; i += 64) ring[i] = 0.0f;
-        wave_sync();
         int flushed = 0;  // strip elements [0, flushed) are final and written
 
         FrameFeat<P> ff;
@@ -371,41 +431,52 @@ __global__ __launch_bounds__(kSynWaves * 64) void k_synth_ola(const float* __res
             asm volatile("" : "+v"(lane), "+v"(wl_s), "+v"(wl_c));
             float xr[P], xi[P], xm;
             feat_convert<P>(ff, xr, xi, xm, lane);
-            if (fi + 1 < cd.frame_end) {  // prefetch the next frame's features behind this frame's FFT
+            hermitian_merge<P>(xr, xi, xm, lane, wl_c, wl_s);
+            wave_fft_front<P, +1>(xr, xi, tw, xbuf, lane);
+            // Prefetch the next frame's features behind the second FFT pass + overlap-add.  Placed HERE (not
+            // right after the conversion): earlier, 99 old + 99 new feature registers + the 64 spectrum
+            // registers exceed 256 VGPRs and the compiler spills freshly loaded values with a vmcnt(0) each.
+            __builtin_amdgcn_sched_barrier(0);
+            if (fi + 1 < cd.frame_end) {
                 const long long f = fi + 1;
                 feat_load<P>(ff, mag + f * H, real + f * H, imag + f * H, lane);
             }
-            hermitian_merge<P>(xr, xi, xm, lane, wl_c, wl_s);
-            wave_fft<P, +1>(xr, xi, tw, xbuf, lane);
+            __builtin_amdgcn_sched_barrier(0);
+            fft_inreg<P, +1>(xr, xi);
 
-            // strip coordinate of this frame's first sample, and the ring window [flushed, flushed + R)
+            // strip coordinate of this frame's first sample; the ring holds strip elements [flushed, flushed + R)
             const int x = pm_rel[fi] - cd.x0;   // in [0, T)
             const int target = x & ~63;
-            for (int b0 = flushed; b0 < target; b0 += 64) {  // everything below x is final: stream it out
-                const int b = b0 + lane;
-                const int slot = b % R;
-                strip[b] = ring[slot];
-                ring[slot] = 0.0f;
+            if (flushed < target) {              // everything below x is final: stream it out, clear the slots
+                flush_ring<R>(ring, strip, flushed, target, strip_len, lane);
+                flushed = target;
             }
-            flushed = max(flushed, target);
             wave_sync();
-            const int kap = kappa<P>(lane);
-            int base = (x % R) + 2 * kap;  // slot of sample n = 2*kap (+128 q), before wrap
+            {
+                constexpr int RH = R / 2;
+                const int kap = kappa<P>(lane);
+                // sample n = 2m + e of the frame sits at strip position x + n: even x: (e=0 -> E[x/2 + m], e=1 -> O[x/2 + m]);
+                // odd x: (e=0 -> O[(x-1)/2 + m], e=1 -> E[(x+1)/2 + m]).
+                const int odd = x & 1;
+                float* r0 = ring + (odd ? RH : 0);       // half receiving the e = 0 samples
+                float* r1 = ring + (odd ? 0 : RH);       // half receiving the e = 1 samples
+                const int c0 = ((x >> 1) % RH) + kap;
+                const int c1 = (((x + 1) >> 1) % RH) + kap;
 #pragma unroll
-            for (int i = 0; i < P; ++i) {
-                int s0 = base + 128 * brev(i, LB);
-                s0 = (s0 >= R) ? s0 - R : s0;
-                int s1 = s0 + 1;
-                s1 = (s1 >= R) ? s1 - R : s1;
-                atomicAdd(&ring[s0], xr[i]);  // wave-private LDS: ds_add_f32, no contention
-                atomicAdd(&ring[s1], xi[i]);
+                for (int i = 0; i < P; ++i) {
+                    int s0 = c0 + 64 * brev(i, LB);
+                    s0 = (s0 >= RH) ? s0 - RH : s0;
+                    int s1 = c1 + 64 * brev(i, LB);
+                    s1 = (s1 >= RH) ? s1 - RH : s1;
+                    r0[s0] += xr[i];
+                    r1[s1] += xi[i];
+                }
             }
             wave_sync();
         }
-        for (int b0 = flushed; b0 < strip_len; b0 += 64) {
-            const int b = b0 + lane_id;
-            if (b < strip_len) strip[b] = ring[b % R];
-        }
+        // tail: stream out the rest of the strip; slots are cleared as they go, so strip elements beyond the
+        // ring window (aliases of already-flushed slots) read 0 and the ring is clean for the next chunk
+        flush_ring<R>(ring, strip, flushed, strip_len, strip_len, lane_id);
         wave_sync();
     }
 }

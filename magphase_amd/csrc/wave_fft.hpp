@@ -170,10 +170,11 @@ __device__ __forceinline__ int kappa(int lane) {
     return (lane & 15) | (((lane >> 5) & 1) << 4) | (((lane >> 4) & 1) << 5);
 }
 
-// Full M = 64*P point FFT of one wave.  tw: LDS table [P][64] float2 = (cos, sin)(2 pi l k1 / M)
+// Full M = 64*P point FFT of one wave, in two halves so that a caller can place independent work
+// (e.g. the next frame's global loads) between them.  tw: LDS table [P][64] float2 = (cos, sin)(2 pi l k1 / M)
 // (sign applied here).  xbuf: this wave's P*65-float LDS buffer.
 template <int P, int SIGN>
-__device__ __forceinline__ void wave_fft(float (&re)[P], float (&im)[P], const float2* tw, float* xbuf, int lane) {
+__device__ __forceinline__ void wave_fft_front(float (&re)[P], float (&im)[P], const float2* tw, float* xbuf, int lane) {
     constexpr int LB = ilog2(P);
     fft_inreg<P, SIGN>(re, im);
 #pragma unroll
@@ -193,6 +194,11 @@ __device__ __forceinline__ void wave_fft(float (&re)[P], float (&im)[P], const f
         cross_lane_stage<P, SIGN, 32, 64>(re, im, (lane & 32) != 0, (lane & 48) == 48);
         cross_lane_stage<P, SIGN, 16, 32>(re, im, (lane & 16) != 0, false);
     }
+}
+
+template <int P, int SIGN>
+__device__ __forceinline__ void wave_fft(float (&re)[P], float (&im)[P], const float2* tw, float* xbuf, int lane) {
+    wave_fft_front<P, SIGN>(re, im, tw, xbuf, lane);
     fft_inreg<P, SIGN>(re, im);
 }
 

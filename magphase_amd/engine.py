@@ -237,7 +237,7 @@ class LosslessSynthesisPlan:
         self.chunks = e.to_device(rows, np.int32)
         self.utt_chunk_off = e.to_device(np.asarray(terr_off), np.int32)
         self.strip_id = e.to_device(owner_all, np.int32)
-        self.strip_floats = self.n_chunks * (T + N)
+        self.strip_floats = self.n_chunks * (self.territory + self.fft_len)
 
     def run(self, mag, real, imag, strips=None, out=None):
         """Fused path: k_synth_ola (per-chunk LDS overlap-add) + k_ola_fixup."""

@@ -81,3 +81,36 @@ def test_ola_chunks_cover_every_frame_once_and_strips_cover_the_buffer(N, T):
                         got[b] += strips[owner[terr_off[u] + cc], idx]
         assert np.max(np.abs(got - ref)) < 1e-12
         f0 += n
+
+
+class _FakeEngine:
+    """Stands in for engine.Engine on a box without a GPU: descriptor tensors stay numpy arrays."""
+
+    def to_device(self, arr, dtype):
+        return np.ascontiguousarray(arr, dtype=dtype)
+
+
+def test_plans_build_without_gpu_and_match_oracle_indices():
+    from magphase_amd import synthetic as syn
+    from magphase_amd.engine import LosslessAnalysisPlan, LosslessSynthesisPlan
+    utts = []
+    for u in range(3):
+        pcm, pm, voi = syn.make_utterance(20 + u, dur_s=0.6, fs=48000)
+        utts.append((pcm, 48000, pm, voi))
+    ap = LosslessAnalysisPlan(_FakeEngine(), utts)
+    sp = LosslessSynthesisPlan(_FakeEngine(), ap.v_f0, ap.fs, ap.fft_len)
+    off = 0
+    for u, (pcm, fs, pm, voi) in enumerate(utts):
+        x = syn.pcm_to_float(pcm)
+        o = orc.analysis_lossless_from_epochs(x, fs, pm, voi)
+        assert np.array_equal(ap.v_shift[u], o[5])
+        assert np.array_equal(ap.v_f0[u], o[3])
+        a, b = ap.frame_off[u], ap.frame_off[u + 1]
+        assert np.array_equal(ap.left[a:b], o[5])
+        assert np.array_equal(ap.pos[a:b] - off, orc.round_to_int(orc.clean_epochs(pm, voi, len(x), fs)[0] * fs))
+        ref = orc.synthesis_from_lossless(o[0], o[1], o[2], o[3], fs)
+        assert sp.out_len[u] == len(ref)
+        off += len(x)
+    assert sp.total_frames == ap.total_frames
+    assert sp.strip_floats == sp.n_chunks * (sp.territory + sp.fft_len)
+    assert sp.chunks.shape == (sp.n_chunks, 4)
