@@ -159,8 +159,7 @@ def main():
         ev[0].record()
         aplan.run(out=feats)
         ev[1].record()
-        eng.synthesis_lossless_ola(N, feats[0], feats[1], feats[2], splan.chunks, splan.n_chunks, splan.pm_rel,
-                                   splan.territory, strips)
+        eng.synthesis_lossless_ola(N, feats[0], feats[1], feats[2], splan, strips)
         ev[2].record()
         eng.ola_fixup(N, splan.territory, strips, splan.utt_chunk_off, splan.strip_id, splan.out_start,
                       splan.out_off, splan.max_out_len, splan.total_out, out=pcm_out)

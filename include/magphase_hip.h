@@ -87,12 +87,17 @@ int mpx_ola_gather(void* stream, int fft_len, const float* frames, int32_t n_utt
  * mpx_ola_fixup sums, for every output sample, the strips of territories c-1, c, c+1 in that fixed order
  * (deterministic; differs from the reference's single ascending sum only by fp32 re-association).
  * chunks        : n_chunks x {int32 frame_begin, frame_end, x0, pad}; x0 = c*territory - N/2
+ * slot_off      : int32[n_slots+1], slot_chunks : int32[n_chunks] -- work list: wave slot s processes chunks
+ *                 slot_chunks[slot_off[s] .. slot_off[s+1]) in that order (one wavefront per slot; the host
+ *                 balances the lists, longest-processing-time first, for mpx_synth_ola_slots() slots)
  * strips        : float32 [n_chunks x (territory + N)], strip i belongs to chunk i
  * utt_chunk_off : int32[n_utts+1] territory range of each utterance in strip_id
  * strip_id      : int32[sum of territories]  chunk index owning the territory, or -1 if it has no frame
  */
+int mpx_synth_ola_slots(void); /* wave slots the current device runs concurrently (CUs x waves per block) */
 int mpx_synthesis_lossless_ola(void* stream, int fft_len, const void* tables, const float* mag, const float* real,
-                               const float* imag, const void* chunks, int32_t n_chunks, const int32_t* pm_rel,
+                               const float* imag, const void* chunks, int32_t n_chunks, const int32_t* slot_off,
+                               const int32_t* slot_chunks, int32_t n_slots, const int32_t* pm_rel,
                                int32_t territory, float* strips);
 int mpx_ola_fixup(void* stream, int fft_len, int32_t territory, const float* strips, int32_t n_utts,
                   const int32_t* utt_chunk_off, const int32_t* strip_id, const int32_t* out_start,

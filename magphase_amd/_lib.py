@@ -18,6 +18,7 @@ SYMBOLS = (
     "mpx_analysis_frames",
     "mpx_synthesis_lossless_frames",
     "mpx_ola_gather",
+    "mpx_synth_ola_slots",
     "mpx_synthesis_lossless_ola",
     "mpx_ola_fixup",
 )
@@ -56,7 +57,9 @@ def load():
     lib.mpx_ola_gather.restype = ctypes.c_int
     lib.mpx_ola_gather.argtypes = [vp, ctypes.c_int, vp, i32, vp, vp, vp, vp, i64, vp]
     lib.mpx_synthesis_lossless_ola.restype = ctypes.c_int
-    lib.mpx_synthesis_lossless_ola.argtypes = [vp, ctypes.c_int, vp, vp, vp, vp, vp, i32, vp, i32, vp]
+    lib.mpx_synth_ola_slots.restype = ctypes.c_int
+    lib.mpx_synth_ola_slots.argtypes = []
+    lib.mpx_synthesis_lossless_ola.argtypes = [vp, ctypes.c_int, vp, vp, vp, vp, vp, i32, vp, vp, i32, vp, i32, vp]
     lib.mpx_ola_fixup.restype = ctypes.c_int
     lib.mpx_ola_fixup.argtypes = [vp, ctypes.c_int, i32, vp, i32, vp, vp, vp, vp, i64, vp]
     _lib = lib

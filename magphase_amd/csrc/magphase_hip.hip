@@ -35,12 +35,12 @@ static int fail(int code, const char* fmt, const char* detail = "") {
 
 // Build-time knobs (tools/ab_bench.py builds variants with -D... and times them interleaved in one process).
 #ifndef MPX_WAVES_PER_BLOCK
-#define MPX_WAVES_PER_BLOCK 16
+#define MPX_WAVES_PER_BLOCK 12
 #endif
 #ifndef MPX_SYN_WAVES
 #define MPX_SYN_WAVES 5
 #endif
-constexpr int kWavesPerBlock = MPX_WAVES_PER_BLOCK;  // 16: 1024 threads, one block per CU, 4 waves per SIMD
+constexpr int kWavesPerBlock = MPX_WAVES_PER_BLOCK;  // 12: 768 threads, one block per CU, 3 waves per SIMD (<=168 VGPRs: no spills -- scratch traffic counts in vmcnt)
 constexpr int kThreads = kWavesPerBlock * 64;
 
 template <int P>
@@ -82,6 +82,46 @@ __device__ __forceinline__ float hann_half(int k, int L, int LR, int kadd, float
     return sin2_halfpi((float)num * inv);
 }
 
+struct FrameGeom {
+    const float* base;  // &sig[pos - L]: sample k of the windowed frame is base[k]
+    int L, LR, len, rot, kadd;
+    float invL, invR;
+};
+
+__device__ __forceinline__ FrameGeom frame_geom(const float* __restrict__ sig, long long pos, int L, int R, int N) {
+    FrameGeom g;
+    g.L = L;
+    g.LR = L + R;
+    g.len = min(g.LR + 1, N);            // Q19: frames longer than N are truncated
+    g.rot = (L < N) ? L : 0;             // python slicing: rotation by >= N is the identity
+    g.kadd = (L == 0) ? 1 : 0;           // L == 0: the single rising sample has weight np.hanning(1) == 1
+    g.invL = (L > 0) ? 1.0f / (float)L : 1.0f;
+    g.invR = (R > 0) ? 1.0f / (float)R : 0.0f;
+    g.base = sig + (pos - L);
+    return g;
+}
+
+// Asynchronous HBM -> LDS copy of the frame's samples [tile0, tile0 + tile_len) in sample order (clamped reads;
+// samples >= len are masked by the window later): one global_load_lds_dword per 64 samples, no VGPR destination.
+// Issued through inline asm on purpose: the compiler does not track these copies, so it cannot pessimise them into
+// vmcnt(0) waits (which on gfx9 -- one in-order counter for loads AND stores -- would drain the 99 stores of the
+// previous frame); the caller waits with staged_wait<N>() instead.  LDS address = M0 + 4*lane (wave-uniform base).
+__device__ __forceinline__ void stage_samples_async(const FrameGeom& g, int tile0, int tile_len, unsigned lds_byte,
+                                                    int lane) {
+    const int nrow = (min(g.len - tile0, tile_len) + 63) >> 6;
+    for (int c = 0; c < nrow; ++c) {
+        const float* src = g.base + min(tile0 + 64 * c + lane, g.len - 1);
+        const unsigned m0v = __builtin_amdgcn_readfirstlane(lds_byte + 256u * (unsigned)c);
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(src), "s"(m0v) : "m0", "memory");
+    }
+}
+
+template <int N>
+__device__ __forceinline__ void staged_wait() {
+    if (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
+}
+
 template <int P>
 __global__ __launch_bounds__(kThreads) void k_analysis(const float* __restrict__ sig,
                                                        const long long* __restrict__ fpos,
@@ -89,12 +129,14 @@ __global__ __launch_bounds__(kThreads) void k_analysis(const float* __restrict__
                                                        const int* __restrict__ fright, long long nframes,
                                                        const float2* __restrict__ tw_g, float* __restrict__ omag,
                                                        float* __restrict__ oreal, float* __restrict__ oimag) {
-    constexpr int M = 64 * P, N = 2 * M, H = M + 1, LB = ilog2(P);
+    constexpr int M = 64 * P, N = 2 * M, H = M + 1, LB = ilog2(P), kTile = 64 * P;
     extern __shared__ float smem[];
     float2* tw = reinterpret_cast<float2*>(smem);
     const int lane_id = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     float* xbuf = smem + P * 64 * 2 + wave * (P * kXStride);
+    // byte address of xbuf in LDS (the dynamic segment starts at 0: the kernel has no static __shared__)
+    const unsigned xbuf_byte = 4u * (unsigned)(P * 64 * 2 + rfl(wave) * (P * kXStride));
     for (int i = threadIdx.x; i < P * 64; i += kThreads) tw[i] = tw_g[i];
     __syncthreads();
 
@@ -103,54 +145,72 @@ __global__ __launch_bounds__(kThreads) void k_analysis(const float* __restrict__
     sincospif(-2.0f * (float)kappa<P>(lane_id) / (float)N, &wl_s0, &wl_c0);
 
     const int wave_u = rfl(wave);
-    for (long long f = (long long)blockIdx.x * kWavesPerBlock + wave_u; f < nframes;
-         f += (long long)gridDim.x * kWavesPerBlock) {
+    const long long fstep = (long long)gridDim.x * kWavesPerBlock;
+    long long f = (long long)blockIdx.x * kWavesPerBlock + wave_u;
+    if (f >= nframes) return;
+
+    // Software pipeline: the samples of the wave's next frame are copied HBM -> LDS (into the transpose buffer, idle
+    // after the FFT's exchange) while this frame's second FFT pass and epilogue run.  All 99 stores of the epilogue
+    // are issued after that copy, so "copy landed" == vmcnt <= 63: no wait on the store drain.
+    FrameGeom g = frame_geom(sig, fpos[f], fleft[f], fright[f], N);
+    stage_samples_async(g, 0, kTile, xbuf_byte, lane_id);
+    staged_wait<0>();
+
+    for (; f < nframes; f += fstep) {
         // Launder the per-lane invariants once per frame: otherwise LICM hoists every (lane x register)
-        // twiddle product out of this loop and the kernel spills (128-VGPR budget at 4 waves/SIMD).
+        // twiddle product out of this loop and the kernel spills.
         int lane = lane_id;
         float wl_s = wl_s0, wl_c = wl_c0;
         asm volatile("" : "+v"(lane), "+v"(wl_s), "+v"(wl_c));
         const int kap = kappa<P>(lane);
         const int src_lane = kappa<P>((64 - kap) & 63);
         const bool lane0 = (kap == 0);
-        const long long pos = fpos[f];
-        const int L = fleft[f];
-        const int R = fright[f];
-        const int LR = L + R;
-        const int len = min(LR + 1, N);      // Q19: frames longer than N are truncated
-        const int rot = (L < N) ? L : 0;     // python slicing: rotation by >= N is the identity
-        // L == 0: the single rising sample (k == 0) has weight np.hanning(1) == 1 -> num = 1, inv = 1
-        const int kadd = (L == 0) ? 1 : 0;
-        const float invL = (L > 0) ? 1.0f / (float)L : 1.0f;
-        const float invR = (R > 0) ? 1.0f / (float)R : 0.0f;
-        const float* base = sig + (pos - L);
 
+        // ---- window in sample order (in place in LDS), then gather in FFT order
         float re[P], im[P];
 #pragma unroll
-        for (int j = 0; j < P; ++j) {
-            const int m0 = 128 * j;
-            // buffer index m holds windowed sample k = (m + rot) mod N, valid iff k < len
-            const bool any = (m0 < len - rot) || (m0 + 127 >= N - rot);
-            float a = 0.0f, b = 0.0f;
-            if (any) {
-                const int m = m0 + 2 * lane;
-                int k0 = m + rot;
-                k0 = (k0 >= N) ? k0 - N : k0;
-                int k1 = m + 1 + rot;
-                k1 = (k1 >= N) ? k1 - N : k1;
-#ifdef MPX_PROBE_NOLOAD
-                if (k0 < len) a = 0.37f * hann_half(k0, L, LR, kadd, invL, invR);
-                if (k1 < len) b = -0.21f * hann_half(k1, L, LR, kadd, invL, invR);
-#else
-                if (k0 < len) a = base[k0] * hann_half(k0, L, LR, kadd, invL, invR);
-                if (k1 < len) b = base[k1] * hann_half(k1, L, LR, kadd, invL, invR);
-#endif
+        for (int j = 0; j < P; ++j) re[j] = im[j] = 0.0f;
+        const int ntiles = (g.len + kTile - 1) / kTile;   // 1 except for frames longer than 64*P samples
+        for (int t = 0; t < ntiles; ++t) {
+            const int tile0 = t * kTile;
+            if (t > 0) {                                   // rare slow path: not prefetched
+                stage_samples_async(g, tile0, kTile, xbuf_byte, lane);
+                staged_wait<0>();
             }
-            re[j] = a;
-            im[j] = b;
+            const int hi = min(g.len, tile0 + kTile);
+            for (int k = tile0 + lane; k < hi; k += 64)
+                xbuf[k - tile0] *= hann_half(k, g.L, g.LR, g.kadd, g.invL, g.invR);
+            wave_sync();
+#pragma unroll
+            for (int j = 0; j < P; ++j) {
+                const int m0 = 128 * j;
+                // buffer index m holds windowed sample k = (m + rot) mod N, valid iff k < len
+                const bool any = (m0 < g.len - g.rot) || (m0 + 127 >= N - g.rot);
+                if (any) {
+                    const int m = m0 + 2 * lane;
+                    int k0 = m + g.rot;
+                    k0 = (k0 >= N) ? k0 - N : k0;
+                    int k1 = m + 1 + g.rot;
+                    k1 = (k1 >= N) ? k1 - N : k1;
+                    if (k0 >= tile0 && k0 < hi) re[j] = xbuf[k0 - tile0];
+                    if (k1 >= tile0 && k1 < hi) im[j] = xbuf[k1 - tile0];
+                }
+            }
+            wave_sync();
         }
 
-        wave_fft<P, -1>(re, im, tw, xbuf, lane);
+        wave_fft_front<P, -1>(re, im, tw, xbuf, lane);
+
+        // ---- the exchange buffer is idle from here on: start the copy of the next frame's samples into it
+        const long long fn = f + fstep;
+        FrameGeom gn = g;
+        if (fn < nframes) {
+            gn = frame_geom(sig, fpos[fn], fleft[fn], fright[fn], N);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the exchange's own LDS reads have returned
+            stage_samples_async(gn, 0, kTile, xbuf_byte, lane);
+        }
+
+        fft_inreg<P, -1>(re, im);
 
         // Real-FFT split, one (k, M-k) bin pair per step: lane kappa owns k = kappa + 64 q for q < P/2 (the even
         // registers) and also produces the mirrored bin M-k from the same E/T terms:
@@ -209,6 +269,8 @@ __global__ __launch_bounds__(kThreads) void k_analysis(const float* __restrict__
             rlo[M / 2] = xr * r;
             ilo[M / 2] = xi * r;
         }
+        g = gn;
+        if (fn < nframes) staged_wait<63>();   // >= 63 stores were issued after the copy: it has landed
     }
 }
 
@@ -394,7 +456,9 @@ template <int P>
 __global__ __launch_bounds__(kSynWaves * 64) void k_synth_ola(const float* __restrict__ mag,
                                                               const float* __restrict__ real,
                                                               const float* __restrict__ imag,
-                                                              const ChunkDesc* __restrict__ chunks, int nchunks,
+                                                              const ChunkDesc* __restrict__ chunks,
+                                                              const int* __restrict__ slot_off,
+                                                              const int* __restrict__ slot_chunks, int nslots,
                                                               const int* __restrict__ pm_rel, int T,
                                                               const float2* __restrict__ tw_g,
                                                               float* __restrict__ strips) {
@@ -415,7 +479,11 @@ __global__ __launch_bounds__(kSynWaves * 64) void k_synth_ola(const float* __res
     for (int i = lane_id; i < R; i += 64) ring[i] = 0.0f;  // every chunk's tail flush leaves the ring cleared
     wave_sync();
 
-    for (int ci = blockIdx.x * kSynWaves + wave_u; ci < nchunks; ci += gridDim.x * kSynWaves) {
+    // work list of this wave slot (host-side LPT balancing: hostmath.balance_chunks)
+    const int slot = blockIdx.x * kSynWaves + wave_u;
+    if (slot >= nslots) return;
+    for (int wi = slot_off[slot]; wi < slot_off[slot + 1]; ++wi) {
+        const int ci = slot_chunks[wi];
         const ChunkDesc cd = chunks[ci];
         float* strip = strips + (long long)ci * strip_len;
         int flushed = 0;  // strip elements [0, flushed) are final and written
@@ -663,35 +731,39 @@ int mpx_ola_gather(void* stream, int fft_len, const float* frames, int32_t n_utt
     return MPX_OK;
 }
 
-int mpx_synthesis_lossless_ola(void* stream, int fft_len, const void* tables, const float* mag, const float* real,
-                               const float* imag, const void* chunks, int32_t n_chunks, const int32_t* pm_rel,
-                               int32_t territory, float* strips) {
-    const int P = p_of(fft_len);
-    if (!P) return fail(MPX_ERR_ARG, "mpx_synthesis_lossless_ola: fft_len must be 2048 or 4096%s");
-    if (n_chunks < 0) return fail(MPX_ERR_ARG, "mpx_synthesis_lossless_ola: negative n_chunks%s");
-    if (territory < fft_len / 2 || (territory % 64) != 0)
-        return fail(MPX_ERR_ARG, "mpx_synthesis_lossless_ola: territory must be a multiple of 64 and >= fft_len/2%s");
-    if (n_chunks == 0) return MPX_OK;
-    if (!tables || !mag || !real || !imag || !chunks || !pm_rel || !strips)
-        return fail(MPX_ERR_ARG, "mpx_synthesis_lossless_ola: null pointer%s");
+int mpx_synth_ola_slots(void) {
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
     }
-    const int need = (n_chunks + kSynWaves - 1) / kSynWaves;
-    const dim3 grid(std::max(1, std::min(need, cus))), block(kSynWaves * 64);
+    return cus * kSynWaves;
+}
+
+int mpx_synthesis_lossless_ola(void* stream, int fft_len, const void* tables, const float* mag, const float* real,
+                               const float* imag, const void* chunks, int32_t n_chunks, const int32_t* slot_off,
+                               const int32_t* slot_chunks, int32_t n_slots, const int32_t* pm_rel,
+                               int32_t territory, float* strips) {
+    const int P = p_of(fft_len);
+    if (!P) return fail(MPX_ERR_ARG, "mpx_synthesis_lossless_ola: fft_len must be 2048 or 4096%s");
+    if (n_chunks < 0 || n_slots < 0) return fail(MPX_ERR_ARG, "mpx_synthesis_lossless_ola: negative count%s");
+    if (territory < fft_len / 2 || (territory % 64) != 0)
+        return fail(MPX_ERR_ARG, "mpx_synthesis_lossless_ola: territory must be a multiple of 64 and >= fft_len/2%s");
+    if (n_chunks == 0 || n_slots == 0) return MPX_OK;
+    if (!tables || !mag || !real || !imag || !chunks || !slot_off || !slot_chunks || !pm_rel || !strips)
+        return fail(MPX_ERR_ARG, "mpx_synthesis_lossless_ola: null pointer%s");
+    const dim3 grid((n_slots + kSynWaves - 1) / kSynWaves), block(kSynWaves * 64);
     hipStream_t s = (hipStream_t)stream;
     if (P == 32) {
         if (int rc = set_lds(k_synth_ola<32>, lds_bytes_ola<32>())) return rc;
         hipLaunchKernelGGL(k_synth_ola<32>, grid, block, lds_bytes_ola<32>(), s, mag, real, imag,
-                           (const ChunkDesc*)chunks, (int)n_chunks, pm_rel, (int)territory, (const float2*)tables,
-                           strips);
+                           (const ChunkDesc*)chunks, slot_off, slot_chunks, (int)n_slots, pm_rel, (int)territory,
+                           (const float2*)tables, strips);
     } else {
         if (int rc = set_lds(k_synth_ola<16>, lds_bytes_ola<16>())) return rc;
         hipLaunchKernelGGL(k_synth_ola<16>, grid, block, lds_bytes_ola<16>(), s, mag, real, imag,
-                           (const ChunkDesc*)chunks, (int)n_chunks, pm_rel, (int)territory, (const float2*)tables,
-                           strips);
+                           (const ChunkDesc*)chunks, slot_off, slot_chunks, (int)n_slots, pm_rel, (int)territory,
+                           (const float2*)tables, strips);
     }
     MPX_HIP_CHECK(hipGetLastError());
     return MPX_OK;

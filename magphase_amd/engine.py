@@ -103,15 +103,22 @@ class Engine:
         return out
 
 
-    def synthesis_lossless_ola(self, fft_len, mag, real, imag, chunks, n_chunks, pm_rel, territory, strips):
+    def synth_ola_slots(self):
+        torch = _torch()
+        with torch.cuda.device(self.device):
+            return int(self.lib.mpx_synth_ola_slots())
+
+    def synthesis_lossless_ola(self, fft_len, mag, real, imag, plan, strips):
+        """plan: LosslessSynthesisPlan (chunk + slot tables resident on this device)."""
         torch = _torch()
         tab = self.tables(fft_len)
         with torch.cuda.device(self.device):
             _lib.check(
                 self.lib.mpx_synthesis_lossless_ola(self.stream_ptr(), int(fft_len), tab.data_ptr(), mag.data_ptr(),
-                                                    real.data_ptr(), imag.data_ptr(), chunks.data_ptr(),
-                                                    int(n_chunks), pm_rel.data_ptr(), int(territory),
-                                                    strips.data_ptr()),
+                                                    real.data_ptr(), imag.data_ptr(), plan.chunks.data_ptr(),
+                                                    int(plan.n_chunks), plan.slot_off.data_ptr(),
+                                                    plan.slot_chunks.data_ptr(), int(plan.n_slots),
+                                                    plan.pm_rel.data_ptr(), int(plan.territory), strips.data_ptr()),
                 "mpx_synthesis_lossless_ola")
         return strips
 
@@ -238,14 +245,18 @@ class LosslessSynthesisPlan:
         self.utt_chunk_off = e.to_device(np.asarray(terr_off), np.int32)
         self.strip_id = e.to_device(owner_all, np.int32)
         self.strip_floats = self.n_chunks * (self.territory + self.fft_len)
+        n_slots = e.synth_ola_slots() if hasattr(e, "synth_ola_slots") else 1280
+        slot_off, slot_chunks = hm.balance_chunks(rows[:, 1] - rows[:, 0], n_slots)
+        self.n_slots = int(slot_off.size - 1)
+        self.slot_off = e.to_device(slot_off, np.int32)
+        self.slot_chunks = e.to_device(slot_chunks, np.int32)
 
     def run(self, mag, real, imag, strips=None, out=None):
         """Fused path: k_synth_ola (per-chunk LDS overlap-add) + k_ola_fixup."""
         e = self.engine
         if strips is None:
             strips = e.empty((self.strip_floats,))
-        e.synthesis_lossless_ola(self.fft_len, mag, real, imag, self.chunks, self.n_chunks, self.pm_rel,
-                                 self.territory, strips)
+        e.synthesis_lossless_ola(self.fft_len, mag, real, imag, self, strips)
         return e.ola_fixup(self.fft_len, self.territory, strips, self.utt_chunk_off, self.strip_id, self.out_start,
                            self.out_off, self.max_out_len, self.total_out, out=out)
 

@@ -142,3 +142,24 @@ def ola_chunks(pm_rel_list, fft_len, territory):
     owner_all = np.concatenate(terr_owner) if terr_owner else np.zeros(0, dtype=np.int64)
     owner_all = np.where(owner_all >= 0, rank[np.maximum(owner_all, 0)], -1)
     return rows[order], np.asarray(terr_off, dtype=np.int64), owner_all
+
+
+def balance_chunks(n_frames_per_chunk, n_slots, overhead=2):
+    """
+    Longest-processing-time-first assignment of chunks (already sorted longest first) to wave slots.
+    cost(chunk) = frames + overhead (ring tail flush ~ 2 frames' worth of LDS/global work).
+    Returns (slot_off int64[n_slots+1], slot_chunks int64[n_chunks]).
+    """
+    import heapq
+
+    n_frames_per_chunk = np.asarray(n_frames_per_chunk, dtype=np.int64)
+    n_slots = int(max(1, min(n_slots, max(1, n_frames_per_chunk.size))))
+    heap = [(0, s) for s in range(n_slots)]
+    lists = [[] for _ in range(n_slots)]
+    for ci in np.argsort(-n_frames_per_chunk, kind="stable"):
+        load, s_ = heapq.heappop(heap)
+        lists[s_].append(int(ci))
+        heapq.heappush(heap, (load + int(n_frames_per_chunk[ci]) + overhead, s_))
+    slot_off = np.concatenate(([0], np.cumsum([len(l) for l in lists]))).astype(np.int64)
+    slot_chunks = np.asarray([c for l in lists for c in l], dtype=np.int64)
+    return slot_off, slot_chunks
