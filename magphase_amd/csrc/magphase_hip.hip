@@ -35,12 +35,12 @@ static int fail(int code, const char* fmt, const char* detail = "") {
 
 // Build-time knobs (tools/ab_bench.py builds variants with -D... and times them interleaved in one process).
 #ifndef MPX_WAVES_PER_BLOCK
-#define MPX_WAVES_PER_BLOCK 12
+#define MPX_WAVES_PER_BLOCK 8
 #endif
 #ifndef MPX_SYN_WAVES
 #define MPX_SYN_WAVES 5
 #endif
-constexpr int kWavesPerBlock = MPX_WAVES_PER_BLOCK;  // 12: 768 threads, one block per CU, 3 waves per SIMD (<=168 VGPRs: no spills -- scratch traffic counts in vmcnt)
+constexpr int kWavesPerBlock = MPX_WAVES_PER_BLOCK;  // 8: 512 threads, one block per CU, 2 waves per SIMD; measured best of 8/10/12/16 (tools/ab_bench.py); must not spill: scratch traffic counts in vmcnt
 constexpr int kThreads = kWavesPerBlock * 64;
 
 template <int P>
