@@ -1,2 +1,6 @@
-"""Import shim: ``import magphase as mp`` (reference scripts add <repo>/src to sys.path) -> the MI355X implementation."""
-from magphase_amd.magphase import *  # noqa: F401,F403
+"""Import shim: the reference's scripts add <repo>/src to sys.path and import magphase; this forwards to magphase_amd.magphase."""
+import os as _os
+import sys as _sys
+
+_sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))
+from magphase_amd.magphase import *  # noqa: E402,F401,F403
