@@ -103,6 +103,52 @@ int mpx_ola_fixup(void* stream, int fft_len, int32_t territory, const float* str
                   const int32_t* utt_chunk_off, const int32_t* strip_id, const int32_t* out_start,
                   const int64_t* out_off, int64_t max_out_len, float* pcm_out);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Compressed-feature synthesis (magphase.py:825-997 synthesis_from_compressed, b_fbank_mel=False, per_phase_type='magphase')
+ * ------------------------------------------------------------------------------------------------------------------ */
+
+/*
+ * Mel unwarp of the three feature streams as the linear maps they are:
+ *   out_mag  = exp(a_mag  [F x k_mag]   @ u_mag   [k_mag   x n_bins])   la.sp_mel_unwarp + np.exp   (magphase.py:854)
+ *   out_real =     a_real [F x k_phase] @ u_phase [k_phase x n_bins]    phase_uncompress_type1_mcep (magphase.py:1219-1235,
+ *   out_imag =     a_imag [F x k_phase] @ u_phase                        nearest-neighbour extension folded into u_phase)
+ * The matrices are computed on the host in float64 (magphase_amd/hostmath.py: unwarp_matrix, phase_unwarp_matrix).
+ */
+int mpx_mel_unwarp(void* stream, int64_t n_frames, int32_t n_bins, const float* a_mag, int32_t k_mag,
+                   const float* u_mag, float* out_mag, const float* a_real, const float* a_imag, int32_t k_phase,
+                   const float* u_phase, float* out_real, float* out_imag);
+
+/*
+ * Noise-gain statistics (magphase.py:886-903, Q10/Q11): for every frame, the windowed noise frame
+ * (frame_wtype 0: Hann halves, 1: np.bartlett**2.5 halves; epoch at index 0) is transformed and
+ * out_sum[f] = sum_{k=1}^{N/2-1} (ln|Ns[k]|)^2.  The host turns the per-class means into the two gains per utterance.
+ * noise / frame_pos / frame_left / frame_right as sig / frame_* of mpx_analysis_frames.
+ */
+int mpx_noise_stats(void* stream, int fft_len, const void* tables, const float* noise, const int64_t* frame_pos,
+                    const int32_t* frame_left, const int32_t* frame_right, const int32_t* frame_wtype,
+                    int64_t n_frames, float* out_sum);
+
+/*
+ * Spectrum assembly + inverse FFT + anti-ringing window + PSOLA for compressed-feature synthesis
+ * (magphase.py:908-976; chunk / slot / strip tables exactly as mpx_synthesis_lossless_ola, output through mpx_ola_fixup).
+ * Per frame f (all arrays int32/float32[n_frames] unless noted):
+ *   noise_pos(int64)/noise_left/noise_right/noise_wtype : this frame's noise frame (recomputed here)
+ *   voiced, inv_gain                                    : class flag and 1/gain of its class
+ *   row0,row1,row_t : the frame's mag/real/imag row = (1-row_t)*row[row0] + row_t*row[row1] of the [rows x H] matrices
+ *                     (constant -> variable frame rate, magphase.py:2242-2252; row0 == row1 for variable-rate input)
+ *   win_left, win_right : anti-ringing window half lengths (Q14);  pm_rel : as mpx_ola_gather
+ * per_v, ap_v, ap_u : float32[H] per-bin constants (hostmath.synthesis_bin_curves: tilt x sqrt(mask) etc., Q12/Q13)
+ */
+int mpx_synthesis_compressed_ola(void* stream, int fft_len, const void* tables, const float* mag, const float* real,
+                                 const float* imag, const float* noise, const int64_t* noise_pos,
+                                 const int32_t* noise_left, const int32_t* noise_right, const int32_t* noise_wtype,
+                                 const int32_t* voiced, const float* inv_gain, const int32_t* row0,
+                                 const int32_t* row1, const float* row_t, const int32_t* win_left,
+                                 const int32_t* win_right, const int32_t* pm_rel, const float* per_v,
+                                 const float* ap_v, const float* ap_u, const void* chunks, int32_t n_chunks,
+                                 const int32_t* slot_off, const int32_t* slot_chunks, int32_t n_slots,
+                                 int32_t territory, float* strips);
+
 #ifdef __cplusplus
 }
 #endif

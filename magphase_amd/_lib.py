@@ -21,6 +21,9 @@ SYMBOLS = (
     "mpx_synth_ola_slots",
     "mpx_synthesis_lossless_ola",
     "mpx_ola_fixup",
+    "mpx_mel_unwarp",
+    "mpx_noise_stats",
+    "mpx_synthesis_compressed_ola",
 )
 
 _lib = None
@@ -62,6 +65,12 @@ def load():
     lib.mpx_synthesis_lossless_ola.argtypes = [vp, ctypes.c_int, vp, vp, vp, vp, vp, i32, vp, vp, i32, vp, i32, vp]
     lib.mpx_ola_fixup.restype = ctypes.c_int
     lib.mpx_ola_fixup.argtypes = [vp, ctypes.c_int, i32, vp, i32, vp, vp, vp, vp, i64, vp]
+    lib.mpx_mel_unwarp.restype = ctypes.c_int
+    lib.mpx_mel_unwarp.argtypes = [vp, i64, i32, vp, i32, vp, vp, vp, vp, i32, vp, vp, vp]
+    lib.mpx_noise_stats.restype = ctypes.c_int
+    lib.mpx_noise_stats.argtypes = [vp, ctypes.c_int, vp, vp, vp, vp, vp, vp, i64, vp]
+    lib.mpx_synthesis_compressed_ola.restype = ctypes.c_int
+    lib.mpx_synthesis_compressed_ola.argtypes = [vp, ctypes.c_int, vp] + [vp] * 19 + [vp, i32, vp, vp, i32, i32, vp]
     _lib = lib
     return lib
 

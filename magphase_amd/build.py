@@ -13,7 +13,9 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "magphase_hip.hip")
-DEPS = [SRC, os.path.join(HERE, "csrc", "wave_fft.hpp"), os.path.join(os.path.dirname(HERE), "include", "magphase_hip.h")]
+SRCS = [SRC, os.path.join(HERE, "csrc", "magphase_comp.hip")]
+DEPS = SRCS + [os.path.join(HERE, "csrc", "wave_fft.hpp"), os.path.join(HERE, "csrc", "mpx_common.hpp"),
+               os.path.join(os.path.dirname(HERE), "include", "magphase_hip.h")]
 LIB = os.path.join(HERE, "libmagphase_hip.so")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-shared", "-fPIC"]
 
@@ -32,7 +34,7 @@ def is_stale():
 def build(force=False, verbose=True, extra_flags=()):
     if not force and not is_stale():
         return LIB
-    cmd = [hipcc_path()] + FLAGS + list(extra_flags) + [SRC, "-o", LIB]
+    cmd = [hipcc_path()] + FLAGS + list(extra_flags) + SRCS + ["-o", LIB]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -1,0 +1,448 @@
+// magphase_comp.hip -- compressed-feature synthesis kernels (synthesis_from_compressed, magphase.py:825-997).
+//
+//   k_mel_unwarp          [F x K] x [K x H] -> exp / identity: la.sp_mel_unwarp and phase_uncompress_type1_mcep as the
+//                         linear maps they are, K <= 64.  fp32 VALU GEMM, A tile broadcast from LDS.
+//   k_noise_stats<P>      per frame: windowed noise frame -> FFT -> sum_k (ln|Ns[k]|)^2, k = 1..N/2-1 (Q10 gain statistics)
+//   k_synth_comp_ola<P>   per chunk of frames: noise FFT (recomputed) + periodic/aperiodic spectrum assembly
+//                         (Appendix A2 steps 9-12) + inverse FFT + anti-ringing window + LDS overlap-add (as k_synth_ola)
+#include "mpx_common.hpp"
+
+namespace mpx {
+
+// ---------------------------------------------------------------------------------------------
+// mel unwarp GEMM
+// ---------------------------------------------------------------------------------------------
+struct UnwarpJob {
+    const float* A;  // [F x K] mel-domain features
+    const float* U;  // [K x H] unwarp matrix
+    float* out;      // [F x H]
+    int K;
+    int op;          // 0: identity, 1: exp
+};
+struct UnwarpJobs {
+    UnwarpJob j[3];
+};
+
+constexpr int kGemmFrames = 64;   // frames per block
+constexpr int kGemmKMax = 64;
+
+__global__ __launch_bounds__(256) void k_mel_unwarp(UnwarpJobs jobs, long long F, int H) {
+    __shared__ float As[kGemmKMax][kGemmFrames];   // transposed tile: As[n][f]
+    const UnwarpJob job = jobs.j[blockIdx.z];
+    const long long f0 = (long long)blockIdx.y * kGemmFrames;
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    const int K = job.K;
+    for (int i = threadIdx.x; i < K * kGemmFrames; i += 256) {
+        const int fl = i / K, n = i - fl * K;      // coalesced read of the [64 x K] slab
+        const long long f = f0 + fl;
+        As[n][fl] = (f < F) ? job.A[f * K + n] : 0.0f;
+    }
+    __syncthreads();
+    if (k >= H) return;
+    float acc[kGemmFrames];
+#pragma unroll
+    for (int f = 0; f < kGemmFrames; ++f) acc[f] = 0.0f;
+    const float* ucol = job.U + k;
+    for (int n = 0; n < K; ++n) {
+        const float u = ucol[(long long)n * H];
+        const float4* a4 = reinterpret_cast<const float4*>(&As[n][0]);
+#pragma unroll
+        for (int q = 0; q < kGemmFrames / 4; ++q) {
+            const float4 a = a4[q];   // same address in every lane: LDS broadcast
+            acc[4 * q + 0] = fmaf(a.x, u, acc[4 * q + 0]);
+            acc[4 * q + 1] = fmaf(a.y, u, acc[4 * q + 1]);
+            acc[4 * q + 2] = fmaf(a.z, u, acc[4 * q + 2]);
+            acc[4 * q + 3] = fmaf(a.w, u, acc[4 * q + 3]);
+        }
+    }
+    float* o = job.out + f0 * H + k;
+#pragma unroll
+    for (int f = 0; f < kGemmFrames; ++f) {
+        if (f0 + f < F) o[(long long)f * H] = job.op ? expf(acc[f]) : acc[f];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// noise frame -> half spectrum in registers
+// ---------------------------------------------------------------------------------------------
+// Windowed noise frame (magphase.py:886-897: windowing() with per-frame window list, epoch moved to index 0 by
+// frm_list_to_matrix + fftshift) -> N-point real FFT -> Ns[k] for the bins kappa(lane) + 64 j, j = 0..P-1
+// (natural j), plus the Nyquist bin (real) on the lane with kappa == 0.  Synchronous staging (no prefetch).
+template <int P>
+__device__ __forceinline__ void noise_spectrum(const FrameGeom& g, int wtype, const float2* tw, float* xbuf,
+                                               unsigned xbuf_byte, int lane, float wl_c, float wl_s,
+                                               float (&nr)[P], float (&ni)[P], float& nM) {
+    constexpr int M = 64 * P, N = 2 * M, LB = ilog2(P), kTile = 64 * P;
+    float re[P], im[P];
+#pragma unroll
+    for (int j = 0; j < P; ++j) re[j] = im[j] = 0.0f;
+    const int ntiles = (g.len + kTile - 1) / kTile;
+    for (int t = 0; t < ntiles; ++t) {
+        const int tile0 = t * kTile;
+        stage_samples_async(g, tile0, kTile, xbuf_byte, lane);
+        staged_wait<0>();
+        const int hi = min(g.len, tile0 + kTile);
+        for (int k = tile0 + lane; k < hi; k += 64)
+            xbuf[k - tile0] *= half_window(k, g.L, g.LR, g.kadd, g.invL, g.invR, wtype);
+        wave_sync();
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+            const int m0 = 128 * j;
+            const bool any = (m0 < g.len - g.rot) || (m0 + 127 >= N - g.rot);
+            if (any) {
+                const int m = m0 + 2 * lane;
+                int k0 = m + g.rot;
+                k0 = (k0 >= N) ? k0 - N : k0;
+                int k1 = m + 1 + g.rot;
+                k1 = (k1 >= N) ? k1 - N : k1;
+                if (k0 >= tile0 && k0 < hi) re[j] = xbuf[k0 - tile0];
+                if (k1 >= tile0 && k1 < hi) im[j] = xbuf[k1 - tile0];
+            }
+        }
+        wave_sync();
+    }
+    wave_fft<P, -1>(re, im, tw, xbuf, lane);
+
+    // real-FFT split for every own bin (redundant form: each lane evaluates X[k] for all its bins)
+    const int kap = kappa<P>(lane);
+    const int src_lane = kappa<P>((64 - kap) & 63);
+    const bool lane0 = (kap == 0);
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        const int q = brev(i, LB);
+        const int i0 = brev((P - q) % P, LB);
+        float pr = __shfl(re[P - 1 - i], src_lane);
+        float pi = __shfl(im[P - 1 - i], src_lane);
+        pr = lane0 ? re[i0] : pr;
+        pi = lane0 ? im[i0] : pi;
+        const float er = 0.5f * (re[i] + pr), ei = 0.5f * (im[i] - pi);
+        const float orr = 0.5f * (im[i] + pi), oi = -0.5f * (re[i] - pr);
+        const float cq = cos2p<P>(q), sq = -sin2p<P>(q);
+        const float wr = wl_c * cq - wl_s * sq, wi = wl_c * sq + wl_s * cq;
+        nr[q] = er + (wr * orr - wi * oi);
+        ni[q] = ei + (wr * oi + wi * orr);
+    }
+    nM = re[0] - im[0];   // Nyquist bin X[M] = Re Z[0] - Im Z[0] (meaningful on the kappa == 0 lane)
+}
+
+template <int P>
+__global__ __launch_bounds__(kThreads) void k_noise_stats(const float* __restrict__ noise,
+                                                          const long long* __restrict__ npos,
+                                                          const int* __restrict__ nleft,
+                                                          const int* __restrict__ nright,
+                                                          const int* __restrict__ wtype, long long nframes,
+                                                          const float2* __restrict__ tw_g,
+                                                          float* __restrict__ out_sum) {
+    constexpr int M = 64 * P, N = 2 * M;
+    extern __shared__ float smem[];
+    float2* tw = reinterpret_cast<float2*>(smem);
+    const int lane_id = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    float* xbuf = smem + P * 64 * 2 + wave * (P * kXStride);
+    const unsigned xbuf_byte = 4u * (unsigned)(P * 64 * 2 + rfl(wave) * (P * kXStride));
+    for (int i = threadIdx.x; i < P * 64; i += kThreads) tw[i] = tw_g[i];
+    __syncthreads();
+    float wl_s0, wl_c0;
+    sincospif(-2.0f * (float)kappa<P>(lane_id) / (float)N, &wl_s0, &wl_c0);
+    const int wave_u = rfl(wave);
+    for (long long f = (long long)blockIdx.x * kWavesPerBlock + wave_u; f < nframes;
+         f += (long long)gridDim.x * kWavesPerBlock) {
+        int lane = lane_id;
+        float wl_s = wl_s0, wl_c = wl_c0;
+        asm volatile("" : "+v"(lane), "+v"(wl_s), "+v"(wl_c));
+        const FrameGeom g = frame_geom(noise, npos[f], nleft[f], nright[f], N);
+        float nr[P], ni[P], nM;
+        noise_spectrum<P>(g, wtype[f], tw, xbuf, xbuf_byte, lane, wl_c, wl_s, nr, ni, nM);
+        // sum over bins 1..M-1 of (ln|Ns|)^2 = (0.5 ln |Ns|^2)^2 ; |Ns| == 0 -> protected log MAGIC = -1e10 (libaudio.py:241-248)
+        const bool lane0 = (kappa<P>(lane) == 0);
+        float acc = 0.0f;
+#pragma unroll
+        for (int q = 0; q < P; ++q) {
+            const float s = nr[q] * nr[q] + ni[q] * ni[q];
+            const float lg = (s > 0.0f) ? 0.5f * __logf(s) : -1.0e10f;
+            const float term = lg * lg;
+            acc += (q == 0 && lane0) ? 0.0f : term;   // bin 0 excluded
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
+        if (lane_id == 0) out_sum[f] = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// compressed synthesis + PSOLA
+// ---------------------------------------------------------------------------------------------
+struct CompFrameTabs {
+    const long long* npos;   // noise frame epoch (absolute index into the noise buffer)
+    const int* nleft;
+    const int* nright;
+    const int* wtype;        // 0 hann / 1 bartlett^2.5
+    const int* voiced;       // 0 / 1
+    const float* inv_gain;   // 1 / noise gain of the frame's class (Q10)
+    const int* row0;         // feature rows to interpolate between (constant -> variable rate), row0 == row1 if none
+    const int* row1;
+    const float* rowt;       // interpolation weight of row1
+    const int* win_l;        // anti-ringing window half lengths (Q14)
+    const int* win_r;
+    const int* pm_rel;
+};
+
+template <int P>
+__global__ __launch_bounds__(kSynWaves * 64) void k_synth_comp_ola(const float* __restrict__ mag,
+                                                                   const float* __restrict__ real,
+                                                                   const float* __restrict__ imag,
+                                                                   const float* __restrict__ noise,
+                                                                   CompFrameTabs tb,
+                                                                   const float* __restrict__ per_v,
+                                                                   const float* __restrict__ ap_v,
+                                                                   const float* __restrict__ ap_u,
+                                                                   const ChunkDesc* __restrict__ chunks,
+                                                                   const int* __restrict__ slot_off,
+                                                                   const int* __restrict__ slot_chunks, int nslots,
+                                                                   int T, const float2* __restrict__ tw_g,
+                                                                   float* __restrict__ strips) {
+    constexpr int M = 64 * P, N = 2 * M, H = M + 1, LB = ilog2(P), R = ring_len<P>();
+    extern __shared__ float smem[];
+    float2* tw = reinterpret_cast<float2*>(smem);
+    const int lane_id = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    float* xbuf = smem + P * 64 * 2 + wave * (P * kXStride + R);
+    float* ring = xbuf + P * kXStride;
+    const unsigned xbuf_byte = 4u * (unsigned)(P * 64 * 2 + rfl(wave) * (P * kXStride + R));
+    for (int i = threadIdx.x; i < P * 64; i += kSynWaves * 64) tw[i] = tw_g[i];
+    __syncthreads();
+
+    float wa_s0, wa_c0, ws_s0, ws_c0;   // analysis-side lane twiddle W_N^kappa and synthesis-side conj(W_N^lane)
+    sincospif(-2.0f * (float)kappa<P>(lane_id) / (float)N, &wa_s0, &wa_c0);
+    sincospif(2.0f * (float)lane_id / (float)N, &ws_s0, &ws_c0);
+    const int wave_u = rfl(wave);
+    const int strip_len = T + N;
+    for (int i = lane_id; i < R; i += 64) ring[i] = 0.0f;
+    wave_sync();
+
+    const int slot = blockIdx.x * kSynWaves + wave_u;
+    if (slot >= nslots) return;
+    for (int wi = slot_off[slot]; wi < slot_off[slot + 1]; ++wi) {
+        const int ci = slot_chunks[wi];
+        const ChunkDesc cd = chunks[ci];
+        float* strip = strips + (long long)ci * strip_len;
+        int flushed = 0;
+        for (int fi = cd.frame_begin; fi < cd.frame_end; ++fi) {
+            int lane = lane_id;
+            float wa_s = wa_s0, wa_c = wa_c0, ws_s = ws_s0, ws_c = ws_c0;
+            asm volatile("" : "+v"(lane), "+v"(wa_s), "+v"(wa_c), "+v"(ws_s), "+v"(ws_c));
+
+            // ---- aperiodic source: spectrum of this frame's windowed noise
+            const FrameGeom g = frame_geom(noise, tb.npos[fi], tb.nleft[fi], tb.nright[fi], N);
+            float xr[P], xi[P], nM;
+            noise_spectrum<P>(g, tb.wtype[fi], tw, xbuf, xbuf_byte, lane, wa_c, wa_s, xr, xi, nM);
+            if (P == 16) {   // FFT output lanes hold bins kappa(lane)+64j; the merge below wants bins lane+64j
+                const int src = kappa<P>(lane);   // kappa is an involution: lane l needs the data of lane kappa(l)
+#pragma unroll
+                for (int j = 0; j < P; ++j) {
+                    xr[j] = __shfl(xr[j], src);
+                    xi[j] = __shfl(xi[j], src);
+                }
+                nM = __shfl(nM, src);
+            }
+
+            // ---- spectrum assembly (Appendix A2 steps 9-12), bins k = lane + 64 j
+            const int voiced = tb.voiced[fi];
+            const float ig = tb.inv_gain[fi];
+            const int r0 = tb.row0[fi], r1 = tb.row1[fi];
+            const float rt = tb.rowt[fi];
+            const float* m0p = mag + (long long)r0 * H;
+            const float* a0p = real + (long long)r0 * H;
+            const float* b0p = imag + (long long)r0 * H;
+            const float* m1p = mag + (long long)r1 * H;
+            const float* a1p = real + (long long)r1 * H;
+            const float* b1p = imag + (long long)r1 * H;
+            const bool interp = (r0 != r1);
+            const float sgn_scale = ((lane & 1) ? -1.0f : 1.0f) * (0.5f / (float)M);
+#pragma unroll
+            for (int j = 0; j < P; ++j) {
+                const int k = lane + 64 * j;
+                float m = m0p[k], a = a0p[k], b = b0p[k];
+                if (interp) {   // linear interpolation between constant-rate rows (magphase.py:2242-2252)
+                    m = fmaf(m1p[k] - m, rt, m);
+                    a = fmaf(a1p[k] - a, rt, a);
+                    b = fmaf(b1p[k] - b, rt, b);
+                }
+                float pr_ = 0.0f, pi_ = 0.0f, apf;
+                if (voiced) {
+                    const float s = a * a + b * b;
+                    const float u = (s > 0.0f) ? m * per_v[k] * __builtin_amdgcn_rsqf(s) : 0.0f;
+                    pr_ = a * u;
+                    pi_ = b * u;
+                    apf = m * ap_v[k] * ig;
+                } else {
+                    apf = m * ap_u[k] * ig;
+                }
+                float vr = fmaf(xr[j], apf, pr_), vi = fmaf(xi[j], apf, pi_);
+                if (j == 0 && lane == 0) {   // DC: X = |X| (magphase.py:958-961)
+                    vr = __builtin_sqrtf(vr * vr + vi * vi);
+                    vi = 0.0f;
+                }
+                xr[j] = vr * sgn_scale;
+                xi[j] = vi * sgn_scale;
+            }
+            float xm = 0.0f;
+            if (lane == 0) {   // Nyquist bin: noise spectrum is real there; X = |X|
+                float m = m0p[M], a = a0p[M], b = b0p[M];
+                if (interp) {
+                    m = fmaf(m1p[M] - m, rt, m);
+                    a = fmaf(a1p[M] - a, rt, a);
+                    b = fmaf(b1p[M] - b, rt, b);
+                }
+                float pr_ = 0.0f, pi_ = 0.0f, apf;
+                if (voiced) {
+                    const float s = a * a + b * b;
+                    const float u = (s > 0.0f) ? m * per_v[M] * __builtin_amdgcn_rsqf(s) : 0.0f;
+                    pr_ = a * u;
+                    pi_ = b * u;
+                    apf = m * ap_v[M] * ig;
+                } else {
+                    apf = m * ap_u[M] * ig;
+                }
+                const float vr = fmaf(nM, apf, pr_), vi = pi_;
+                xm = __builtin_sqrtf(vr * vr + vi * vi) * (0.5f / (float)M);   // (-1)^M = +1
+            }
+
+            hermitian_merge<P>(xr, xi, xm, lane, ws_c, ws_s);
+            wave_fft<P, +1>(xr, xi, tw, xbuf, lane);
+
+            // ---- anti-ringing window (magphase.py:969-973, Q14): centred asymmetric Hann, zero outside
+            const int wl = tb.win_l[fi], wr = tb.win_r[fi];
+            const float inv_wl = (wl > 0) ? 1.0f / (float)wl : 1.0f;
+            const float inv_wr = (wr > 0) ? 1.0f / (float)wr : 0.0f;
+            const int kadd = (wl == 0) ? 1 : 0;
+            const int n_lo = N / 2 - wl, n_hi = N / 2 + wr;   // support [n_lo, n_hi]
+
+            const int x = tb.pm_rel[fi] - cd.x0;
+            const int target = x & ~63;
+            if (flushed < target) {
+                flush_ring<R>(ring, strip, flushed, target, strip_len, lane);
+                flushed = target;
+            }
+            wave_sync();
+            {
+                constexpr int RH = R / 2;
+                const int kap = kappa<P>(lane);
+                const int odd = x & 1;
+                float* r0p = ring + (odd ? RH : 0);
+                float* r1p = ring + (odd ? 0 : RH);
+                const int c0 = ((x >> 1) % RH) + kap;
+                const int c1 = (((x + 1) >> 1) % RH) + kap;
+#pragma unroll
+                for (int i = 0; i < P; ++i) {
+                    const int q = brev(i, LB);
+                    // samples n = 2*(kap + 64 q) + e; skip register rows entirely outside the window support
+                    if (128 * q + 127 < n_lo || 128 * q > n_hi) continue;
+                    const int n0 = 2 * (kap + 64 * q);
+                    const int ks0 = n0 - n_lo, ks1 = n0 + 1 - n_lo;
+                    const float w0 = (ks0 >= 0 && n0 <= n_hi) ? half_window(ks0, wl, wl + wr, kadd, inv_wl, inv_wr, 0) : 0.0f;
+                    const float w1 = (ks1 >= 0 && n0 + 1 <= n_hi) ? half_window(ks1, wl, wl + wr, kadd, inv_wl, inv_wr, 0) : 0.0f;
+                    int s0 = c0 + 64 * q;
+                    s0 = (s0 >= RH) ? s0 - RH : s0;
+                    int s1 = c1 + 64 * q;
+                    s1 = (s1 >= RH) ? s1 - RH : s1;
+                    r0p[s0] += xr[i] * w0;
+                    r1p[s1] += xi[i] * w1;
+                }
+            }
+            wave_sync();
+        }
+        flush_ring<R>(ring, strip, flushed, strip_len, strip_len, lane_id);
+        wave_sync();
+    }
+}
+
+}  // namespace mpx
+
+using namespace mpx;
+
+extern "C" {
+
+int mpx_mel_unwarp(void* stream, int64_t n_frames, int32_t n_bins, const float* a_mag, int32_t k_mag,
+                   const float* u_mag, float* out_mag, const float* a_real, const float* a_imag, int32_t k_phase,
+                   const float* u_phase, float* out_real, float* out_imag) {
+    if (n_frames < 0 || n_bins <= 0) return fail(MPX_ERR_ARG, "mpx_mel_unwarp: bad size%s");
+    if (k_mag <= 0 || k_mag > kGemmKMax || k_phase <= 0 || k_phase > kGemmKMax)
+        return fail(MPX_ERR_ARG, "mpx_mel_unwarp: coefficient count must be in 1..64%s");
+    if (n_frames == 0) return MPX_OK;
+    if (!a_mag || !u_mag || !out_mag || !a_real || !a_imag || !u_phase || !out_real || !out_imag)
+        return fail(MPX_ERR_ARG, "mpx_mel_unwarp: null pointer%s");
+    UnwarpJobs jobs;
+    jobs.j[0] = {a_mag, u_mag, out_mag, (int)k_mag, 1};
+    jobs.j[1] = {a_real, u_phase, out_real, (int)k_phase, 0};
+    jobs.j[2] = {a_imag, u_phase, out_imag, (int)k_phase, 0};
+    const dim3 grid((unsigned)((n_bins + 255) / 256), (unsigned)((n_frames + kGemmFrames - 1) / kGemmFrames), 3);
+    if (grid.y > 65535) return fail(MPX_ERR_ARG, "mpx_mel_unwarp: too many frames per call (max 4194240)%s");
+    hipLaunchKernelGGL(k_mel_unwarp, grid, dim3(256), 0, (hipStream_t)stream, jobs, (long long)n_frames, (int)n_bins);
+    MPX_HIP_CHECK(hipGetLastError());
+    return MPX_OK;
+}
+
+int mpx_noise_stats(void* stream, int fft_len, const void* tables, const float* noise, const int64_t* frame_pos,
+                    const int32_t* frame_left, const int32_t* frame_right, const int32_t* frame_wtype,
+                    int64_t n_frames, float* out_sum) {
+    const int P = p_of(fft_len);
+    if (!P) return fail(MPX_ERR_ARG, "mpx_noise_stats: fft_len must be 2048 or 4096%s");
+    if (n_frames < 0) return fail(MPX_ERR_ARG, "mpx_noise_stats: negative n_frames%s");
+    if (n_frames == 0) return MPX_OK;
+    if (!tables || !noise || !frame_pos || !frame_left || !frame_right || !frame_wtype || !out_sum)
+        return fail(MPX_ERR_ARG, "mpx_noise_stats: null pointer%s");
+    const dim3 grid(grid_for(n_frames)), block(kThreads);
+    hipStream_t s = (hipStream_t)stream;
+    if (P == 32) {
+        if (int rc = set_lds(k_noise_stats<32>, lds_bytes<32>())) return rc;
+        hipLaunchKernelGGL(k_noise_stats<32>, grid, block, lds_bytes<32>(), s, noise, (const long long*)frame_pos,
+                           frame_left, frame_right, frame_wtype, (long long)n_frames, (const float2*)tables, out_sum);
+    } else {
+        if (int rc = set_lds(k_noise_stats<16>, lds_bytes<16>())) return rc;
+        hipLaunchKernelGGL(k_noise_stats<16>, grid, block, lds_bytes<16>(), s, noise, (const long long*)frame_pos,
+                           frame_left, frame_right, frame_wtype, (long long)n_frames, (const float2*)tables, out_sum);
+    }
+    MPX_HIP_CHECK(hipGetLastError());
+    return MPX_OK;
+}
+
+int mpx_synthesis_compressed_ola(void* stream, int fft_len, const void* tables, const float* mag, const float* real,
+                                 const float* imag, const float* noise, const int64_t* noise_pos,
+                                 const int32_t* noise_left, const int32_t* noise_right, const int32_t* noise_wtype,
+                                 const int32_t* voiced, const float* inv_gain, const int32_t* row0,
+                                 const int32_t* row1, const float* row_t, const int32_t* win_left,
+                                 const int32_t* win_right, const int32_t* pm_rel, const float* per_v,
+                                 const float* ap_v, const float* ap_u, const void* chunks, int32_t n_chunks,
+                                 const int32_t* slot_off, const int32_t* slot_chunks, int32_t n_slots,
+                                 int32_t territory, float* strips) {
+    const int P = p_of(fft_len);
+    if (!P) return fail(MPX_ERR_ARG, "mpx_synthesis_compressed_ola: fft_len must be 2048 or 4096%s");
+    if (n_chunks < 0 || n_slots < 0) return fail(MPX_ERR_ARG, "mpx_synthesis_compressed_ola: negative count%s");
+    if (territory < fft_len / 2 || (territory % 64) != 0)
+        return fail(MPX_ERR_ARG, "mpx_synthesis_compressed_ola: territory must be a multiple of 64 and >= fft_len/2%s");
+    if (n_chunks == 0 || n_slots == 0) return MPX_OK;
+    if (!tables || !mag || !real || !imag || !noise || !noise_pos || !noise_left || !noise_right || !noise_wtype ||
+        !voiced || !inv_gain || !row0 || !row1 || !row_t || !win_left || !win_right || !pm_rel || !per_v || !ap_v ||
+        !ap_u || !chunks || !slot_off || !slot_chunks || !strips)
+        return fail(MPX_ERR_ARG, "mpx_synthesis_compressed_ola: null pointer%s");
+    CompFrameTabs tb{(const long long*)noise_pos, noise_left, noise_right, noise_wtype, voiced, inv_gain,
+                     row0, row1, row_t, win_left, win_right, pm_rel};
+    const dim3 grid((n_slots + kSynWaves - 1) / kSynWaves), block(kSynWaves * 64);
+    hipStream_t s = (hipStream_t)stream;
+    if (P == 32) {
+        if (int rc = set_lds(k_synth_comp_ola<32>, lds_bytes_ola<32>())) return rc;
+        hipLaunchKernelGGL(k_synth_comp_ola<32>, grid, block, lds_bytes_ola<32>(), s, mag, real, imag, noise, tb,
+                           per_v, ap_v, ap_u, (const ChunkDesc*)chunks, slot_off, slot_chunks, (int)n_slots,
+                           (int)territory, (const float2*)tables, strips);
+    } else {
+        if (int rc = set_lds(k_synth_comp_ola<16>, lds_bytes_ola<16>())) return rc;
+        hipLaunchKernelGGL(k_synth_comp_ola<16>, grid, block, lds_bytes_ola<16>(), s, mag, real, imag, noise, tb,
+                           per_v, ap_v, ap_u, (const ChunkDesc*)chunks, slot_off, slot_chunks, (int)n_slots,
+                           (int)territory, (const float2*)tables, strips);
+    }
+    MPX_HIP_CHECK(hipGetLastError());
+    return MPX_OK;
+}
+
+}  // extern "C"

@@ -8,119 +8,9 @@
 //                           Hermitian merge -> inverse FFT -> epoch-centred frame.      HBM-read bound.
 //   k_ola_gather            one thread per output sample, ascending-frame gather (deterministic PSOLA).
 // No MFMA anywhere: nothing on this path is a dense contraction.
-#include <hip/hip_runtime.h>
-#include <cmath>
-#include <cstdint>
-#include <cstdio>
-#include <cstring>
-#include <vector>
-
-#include "../../include/magphase_hip.h"
-#include "wave_fft.hpp"
+#include "mpx_common.hpp"
 
 namespace mpx {
-
-static thread_local char g_err[512] = "";
-
-static int fail(int code, const char* fmt, const char* detail = "") {
-    snprintf(g_err, sizeof(g_err), fmt, detail);
-    return code;
-}
-
-#define MPX_HIP_CHECK(expr)                                                       \
-    do {                                                                          \
-        hipError_t e__ = (expr);                                                  \
-        if (e__ != hipSuccess) return fail(MPX_ERR_HIP, #expr ": %s", hipGetErrorString(e__)); \
-    } while (0)
-
-// Build-time knobs (tools/ab_bench.py builds variants with -D... and times them interleaved in one process).
-#ifndef MPX_WAVES_PER_BLOCK
-#define MPX_WAVES_PER_BLOCK 8
-#endif
-#ifndef MPX_SYN_WAVES
-#define MPX_SYN_WAVES 5
-#endif
-constexpr int kWavesPerBlock = MPX_WAVES_PER_BLOCK;  // 8: 512 threads, one block per CU, 2 waves per SIMD; measured best of 8/10/12/16 (tools/ab_bench.py); must not spill: scratch traffic counts in vmcnt
-constexpr int kThreads = kWavesPerBlock * 64;
-
-template <int P>
-constexpr size_t lds_bytes() {
-    return sizeof(float) * (size_t)(P * 64 * 2 + kWavesPerBlock * P * kXStride);
-}
-
-__device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
-
-// ---------------------------------------------------------------------------------------------
-// analysis
-// ---------------------------------------------------------------------------------------------
-// sin(pi t / 2)^2 for t in [0,1] without range reduction: Taylor polynomials on [0, pi/4]
-// (sin: degree 9, |err| < 2e-9; cos: degree 8, |err| < 2.5e-8), selected at t = 0.5.
-__device__ __forceinline__ float sin2_halfpi(float t) {
-    const float kHalfPi = 1.57079632679489662f;
-    const bool lo = t <= 0.5f;
-    const float y = kHalfPi * (lo ? t : 1.0f - t);
-    const float y2 = y * y;
-    float sp = fmaf(y2, 2.75573192e-6f, -1.98412698e-4f);
-    sp = fmaf(y2, sp, 8.33333333e-3f);
-    sp = fmaf(y2, sp, -1.66666667e-1f);
-    sp = fmaf(y2 * y, sp, y);
-    float cp = fmaf(y2, 2.48015873e-5f, -1.38888889e-3f);
-    cp = fmaf(y2, cp, 4.16666667e-2f);
-    cp = fmaf(y2, cp, -0.5f);
-    cp = fmaf(y2, cp, 1.0f);
-    const float v = lo ? sp : cp;
-    return v * v;
-}
-
-// Hann half windows of libaudio.py:70-84 evaluated analytically (np.hanning(1+2L)[k] = sin^2(pi k / 2L)):
-// rising  k <= L : sin^2(pi/2 * k/L)            (== 1 when L == 0: np.hanning(1) == [1.])
-// falling k >  L : cos^2(pi/2 * (k-L)/R) = sin^2(pi/2 * (L+R-k)/R)
-__device__ __forceinline__ float hann_half(int k, int L, int LR, int kadd, float invL, float invR) {
-    const bool rising = k <= L;
-    const int num = rising ? k + kadd : LR - k;
-    const float inv = rising ? invL : invR;
-    return sin2_halfpi((float)num * inv);
-}
-
-struct FrameGeom {
-    const float* base;  // &sig[pos - L]: sample k of the windowed frame is base[k]
-    int L, LR, len, rot, kadd;
-    float invL, invR;
-};
-
-__device__ __forceinline__ FrameGeom frame_geom(const float* __restrict__ sig, long long pos, int L, int R, int N) {
-    FrameGeom g;
-    g.L = L;
-    g.LR = L + R;
-    g.len = min(g.LR + 1, N);            // Q19: frames longer than N are truncated
-    g.rot = (L < N) ? L : 0;             // python slicing: rotation by >= N is the identity
-    g.kadd = (L == 0) ? 1 : 0;           // L == 0: the single rising sample has weight np.hanning(1) == 1
-    g.invL = (L > 0) ? 1.0f / (float)L : 1.0f;
-    g.invR = (R > 0) ? 1.0f / (float)R : 0.0f;
-    g.base = sig + (pos - L);
-    return g;
-}
-
-// Asynchronous HBM -> LDS copy of the frame's samples [tile0, tile0 + tile_len) in sample order (clamped reads;
-// samples >= len are masked by the window later): one global_load_lds_dword per 64 samples, no VGPR destination.
-// Issued through inline asm on purpose: the compiler does not track these copies, so it cannot pessimise them into
-// vmcnt(0) waits (which on gfx9 -- one in-order counter for loads AND stores -- would drain the 99 stores of the
-// previous frame); the caller waits with staged_wait<N>() instead.  LDS address = M0 + 4*lane (wave-uniform base).
-__device__ __forceinline__ void stage_samples_async(const FrameGeom& g, int tile0, int tile_len, unsigned lds_byte,
-                                                    int lane) {
-    const int nrow = (min(g.len - tile0, tile_len) + 63) >> 6;
-    for (int c = 0; c < nrow; ++c) {
-        const float* src = g.base + min(tile0 + 64 * c + lane, g.len - 1);
-        const unsigned m0v = __builtin_amdgcn_readfirstlane(lds_byte + 256u * (unsigned)c);
-        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(src), "s"(m0v) : "m0", "memory");
-    }
-}
-
-template <int N>
-__device__ __forceinline__ void staged_wait() {
-    if (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
-}
 
 template <int P>
 __global__ __launch_bounds__(kThreads) void k_analysis(const float* __restrict__ sig,
@@ -274,95 +164,6 @@ __global__ __launch_bounds__(kThreads) void k_analysis(const float* __restrict__
     }
 }
 
-// Hermitian merge Z[k] = E[k] + i O[k] of the half spectrum held as lane l, register j <-> bin l + 64 j
-// (values pre-scaled by 0.5/M, fftshift sign folded in), in place, two bins (j, P-1-j) per step so that no
-// second register array is live.  Partner bin M-k: lane (64-lane)&63, register P-1-j; lane 0 pairs (j, P-j)
-// instead, served from a one-bin stash of the original register P-j (overwritten one step earlier).
-// xm = Nyquist bin (real), only meaningful on lane 0.  (wl_c, wl_s) = e^{+2 pi i lane/N}.
-template <int P>
-__device__ __forceinline__ void hermitian_merge(float (&xr)[P], float (&xi)[P], float xm, int lane, float wl_c,
-                                                float wl_s) {
-    const int src_lane = (64 - lane) & 63;
-    const bool lane0 = (lane == 0);
-    float st_r = 0.0f, st_i = 0.0f;
-#pragma unroll
-    for (int j = 0; j < P / 2; ++j) {
-        const int jp = P - 1 - j;
-        const float ar = xr[j], ai = xi[j], br = xr[jp], bi = xi[jp];
-        float par = __shfl(br, src_lane), pai = __shfl(bi, src_lane);
-        float pbr = __shfl(ar, src_lane), pbi = __shfl(ai, src_lane);
-        const float l0ar = (j == 0) ? xm : st_r, l0ai = (j == 0) ? 0.0f : st_i;
-        const float l0br = (j + 1 == jp) ? br : xr[j + 1], l0bi = (j + 1 == jp) ? bi : xi[j + 1];
-        par = lane0 ? l0ar : par;
-        pai = lane0 ? l0ai : pai;
-        pbr = lane0 ? l0br : pbr;
-        pbi = lane0 ? l0bi : pbi;
-        st_r = br;
-        st_i = bi;
-        {   // bin j:  E = X + conj(Xp), T = X - conj(Xp), O = conj(W_N^k) T, conj(W_N^k) = e^{+2 pi i (lane/N + j/2P)}
-            const float er = ar + par, ei = ai - pai, tr = ar - par, ti = ai + pai;
-            const float cq = cos2p<P>(j), sq = sin2p<P>(j);
-            const float wr = wl_c * cq - wl_s * sq, wi = wl_c * sq + wl_s * cq;
-            xr[j] = er - (wr * ti + wi * tr);
-            xi[j] = ei + (wr * tr - wi * ti);
-        }
-        {   // bin P-1-j
-            const float er = br + pbr, ei = bi - pbi, tr = br - pbr, ti = bi + pbi;
-            const float cq = cos2p<P>(jp), sq = sin2p<P>(jp);
-            const float wr = wl_c * cq - wl_s * sq, wi = wl_c * sq + wl_s * cq;
-            xr[jp] = er - (wr * ti + wi * tr);
-            xi[jp] = ei + (wr * tr - wi * ti);
-        }
-    }
-}
-
-// Loads one frame's lossless features (bins lane + 64 j, plus the Nyquist bin on lane 0) and turns them into the
-// scaled unit-phase spectrum X = mag (R + jI)/|R + jI| (0 where |R + jI| == 0), magphase.py:1761-1766, with
-// DC/Nyquist imaginary parts dropped (Q5) and the (-1)^k fftshift sign and the 0.5/M scale folded in.
-template <int P>
-struct FrameFeat {
-    float m[P], a[P], b[P];
-    float mM, aM, bM;
-};
-
-template <int P>
-__device__ __forceinline__ void feat_load(FrameFeat<P>& ff, const float* __restrict__ mrow,
-                                          const float* __restrict__ rrow, const float* __restrict__ irow, int lane) {
-#pragma unroll
-    for (int j = 0; j < P; ++j) {
-        const int k = lane + 64 * j;
-        ff.m[j] = mrow[k];
-        ff.a[j] = rrow[k];
-        ff.b[j] = irow[k];
-    }
-    ff.mM = ff.aM = ff.bM = 0.0f;
-    if (lane == 0) {
-        ff.mM = mrow[64 * P];
-        ff.aM = rrow[64 * P];
-        ff.bM = irow[64 * P];
-    }
-}
-
-template <int P>
-__device__ __forceinline__ void feat_convert(const FrameFeat<P>& ff, float (&xr)[P], float (&xi)[P], float& xm,
-                                             int lane) {
-    constexpr int M = 64 * P;
-    const float sgn_scale = ((lane & 1) ? -1.0f : 1.0f) * (0.5f / (float)M);
-#pragma unroll
-    for (int j = 0; j < P; ++j) {
-        const float s = ff.a[j] * ff.a[j] + ff.b[j] * ff.b[j];
-        const float g = (s > 0.0f) ? ff.m[j] * sgn_scale * __builtin_amdgcn_rsqf(s) : 0.0f;
-        xr[j] = ff.a[j] * g;
-        xi[j] = ff.b[j] * g;
-    }
-    xm = 0.0f;
-    if (lane == 0) {
-        xi[0] = 0.0f;
-        const float s = ff.aM * ff.aM + ff.bM * ff.bM;
-        xm = (s > 0.0f) ? ff.mM * (0.5f / (float)M) * ff.aM * __builtin_amdgcn_rsqf(s) : 0.0f;
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
 // lossless synthesis: per-frame spectrum rebuild + inverse real FFT (epoch at N/2)
 // ---------------------------------------------------------------------------------------------
@@ -415,43 +216,6 @@ __global__ __launch_bounds__(kThreads) void k_synth_lossless(const float* __rest
 // HBM traffic: features read once, (T+N)/T * 4 B per output sample written -- the [F x N] frame
 // scratch of the two-kernel path (16 KB per frame written + read) is gone.
 // ---------------------------------------------------------------------------------------------
-constexpr int kSynWaves = MPX_SYN_WAVES;  // LDS: 16 KB twiddles + 5 x (8.1 KB transpose + 16.5 KB ring) = 139 KB
-// Ring of R strip elements, stored as two halves: even strip positions b in ringE[b/2 mod R/2], odd ones in
-// ringO.  A lane's two samples (2m, 2m+1) of a frame then hit ringE/ringO[c + m] with m consecutive across
-// lanes: conflict-free 4-byte accesses whatever the parity of the frame position.  (LDS float atomics
-// -- ds_add_f32 -- measured ~190 LDS cycles per wave instruction on gfx950: plain read/add/write instead.)
-template <int P>
-constexpr int ring_len() { return 128 * P + 128; }
-template <int P>
-constexpr size_t lds_bytes_ola() {
-    return sizeof(float) * (size_t)(P * 64 * 2 + kSynWaves * (P * kXStride + ring_len<P>()));
-}
-
-// Streams strip elements [from, to) out of the ring (to global) and clears their slots.  from is a multiple of 64.
-template <int R>
-__device__ __forceinline__ void flush_ring(float* ring, float* __restrict__ strip, int from, int to, int strip_len,
-                                           int lane) {
-    constexpr int RH = R / 2;
-    // element b = b0 + lane: half = b & 1 (b0 even => lane parity), index (b >> 1) mod RH
-    float* half = ring + ((lane & 1) ? RH : 0);
-    int idx = ((from >> 1) % RH) + (lane >> 1);
-    idx = (idx >= RH) ? idx - RH : idx;
-    for (int b0 = from; b0 < to; b0 += 64) {
-        const int b = b0 + lane;
-        const float v = half[idx];
-        if (b < strip_len) strip[b] = v;
-        half[idx] = 0.0f;
-        idx += 32;
-        idx = (idx >= RH) ? idx - RH : idx;
-    }
-}
-
-struct ChunkDesc {
-    int frame_begin, frame_end;  // global frame indices (rows of mag/real/imag, entries of pm_rel)
-    int x0;                      // OLA-buffer coordinate of strip element 0 (= c*T - N/2, may be negative)
-    int pad;
-};
-
 template <int P>
 __global__ __launch_bounds__(kSynWaves * 64) void k_synth_ola(const float* __restrict__ mag,
                                                               const float* __restrict__ real,
@@ -608,28 +372,6 @@ __global__ __launch_bounds__(256) void k_ola_gather(const float* __restrict__ fr
         acc += frames[(long long)i * N + off];
     }
     pcm[o0 + t] = acc;
-}
-
-// ---------------------------------------------------------------------------------------------
-// host side
-// ---------------------------------------------------------------------------------------------
-static int p_of(int fft_len) { return fft_len == 4096 ? 32 : (fft_len == 2048 ? 16 : 0); }
-
-static int grid_for(long long nframes) {
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) {
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-    }
-    long long need = (nframes + kWavesPerBlock - 1) / kWavesPerBlock;
-    return (int)std::max<long long>(1, std::min<long long>(need, cus));
-}
-
-template <typename K>
-static int set_lds(K kernel, size_t bytes) {
-    MPX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-    return MPX_OK;
 }
 
 }  // namespace mpx

@@ -266,3 +266,205 @@ class LosslessSynthesisPlan:
         frames = e.synthesis_lossless_frames(self.fft_len, mag, real, imag, out=frames)
         return e.ola_gather(self.fft_len, frames, self.utt_frame_off, self.pm_rel, self.out_start, self.out_off,
                             self.max_out_len, self.total_out, out=out)
+
+
+# ======================================================================================================
+# compressed-feature synthesis (magphase.py:825-997)
+# ======================================================================================================
+class CompressedSynthesisPlan:
+    """
+    Host fp64 bookkeeping + device tables for a batch of utterances synthesised from compressed features.
+    utts: list of (m_mag_mel_log [F x mag_dim], m_real_mel [F x phase_dim], m_imag_mel, v_lf0 [F]) float arrays.
+    Follows magphase.py:836-897 (constants, f0/voicing/shift, constant->variable rate scan, epochs, noise length,
+    noise windows) and :969-976 (anti-ringing lengths, ola) -- all index math in float64/int on the host.
+    """
+
+    def __init__(self, engine, utts, fs, fft_len=None, b_voi_ap_win=True, b_const_rate=False, alpha_phase=None,
+                 noise=None, territory=None):
+        from scipy import interpolate
+
+        self.engine = e = engine
+        self.fs = fs
+        N = self.fft_len = int(fft_len) if fft_len else hm.define_fft_len(fs)
+        H = N // 2 + 1
+        self.territory = int(territory) if territory else int(os.environ.get("MAGPHASE_OLA_TERRITORY", N))
+        alpha = hm.define_alpha(fs)
+        self.alpha_phase = alpha if alpha_phase is None else alpha_phase
+        self.mag_dim = int(np.shape(utts[0][0])[1])
+        self.phase_dim = int(np.shape(utts[0][1])[1])
+
+        a_mag, a_real, a_imag = [], [], []
+        npos, nleft, nright, wtype, voiced, row0, row1, rowt, win_l, win_r = ([] for _ in range(10))
+        pm_rel, starts, lens, nfr, noises = [], [], [], [], []
+        self.v_shift, self.v_pm, self.v_voi, self.ns_len = [], [], [], []
+        row_base, noise_base = 0, 0
+        for ui, (mml, rm, im, lf0) in enumerate(utts):
+            mml = np.atleast_2d(np.asarray(mml, dtype=np.float64))
+            rm = np.atleast_2d(np.asarray(rm, dtype=np.float64))
+            im = np.atleast_2d(np.asarray(im, dtype=np.float64))
+            lf0 = np.atleast_1d(np.asarray(lf0, dtype=np.float64))
+            n_rows = mml.shape[0]
+            v_f0 = np.exp(lf0)                                         # magphase.py:846
+            v_voi = v_f0 > 1.0                                         # :847
+            v_shift = hm.f0_to_shift(v_f0, fs)                         # :848
+            if b_const_rate:                                           # :861-870
+                v_shift, v_locs = _const_to_variable_scan(v_shift, 5.0, fs)
+                step = fs * 5.0 / 1000
+                centres = step * np.arange(1, n_rows + 1)
+                v_voi = interpolate.interp1d(centres, v_voi, axis=0, kind="linear")(v_locs) > 0.5
+                idx = np.clip(np.searchsorted(centres, v_locs), 1, n_rows - 1)   # scipy's _call_linear bracketing
+                lo, hi = idx - 1, idx
+                t = (v_locs - centres[lo]) / (centres[hi] - centres[lo])
+            else:
+                lo = hi = np.arange(n_rows)
+                t = np.zeros(n_rows)
+            v_shift = v_shift.astype(int)                              # :879
+            v_pm = np.cumsum(v_shift)                                  # :880
+            n = v_pm.size
+            ns_len = int(v_pm[-1] + (v_pm[-1] - v_pm[-2]))             # :882
+            _, lft, rgt = hm.frame_bounds(v_pm, ns_len)                # windowing(v_ns, v_pm): magphase.py:77-98
+            if np.any(lft > N // 2) or np.any(rgt + 1 > N // 2):
+                raise ValueError("negative dimensions are not allowed")   # np.zeros(<0) in la.frm_list_to_matrix
+            se = np.r_[v_shift[0], v_shift, v_shift[-1], v_shift[-1]]   # :969
+            wl, wr = se[:n] + se[1:n + 1], se[2:n + 2] + se[3:n + 3]
+            if np.any(wl > N // 2) or np.any(wr + 1 > N // 2):
+                raise ValueError("could not broadcast input array (anti-ringing window longer than the frame)")
+            rel, start, out_len = hm.ola_plan(v_pm, N)
+            if noise is not None:
+                v_ns = np.asarray(noise[ui], dtype=np.float64)
+                if v_ns.size != ns_len:
+                    raise ValueError("noise length %d != ns_len %d" % (v_ns.size, ns_len))
+            else:
+                v_ns = np.random.uniform(-1, 1, ns_len)                # :883 (global numpy RNG, as the reference)
+            a_mag.append(mml), a_real.append(rm), a_imag.append(im)
+            npos.append(v_pm + noise_base), nleft.append(lft), nright.append(rgt)
+            wtype.append((v_voi & bool(b_voi_ap_win)).astype(np.int32))
+            voiced.append(v_voi.astype(np.int32))
+            row0.append(lo + row_base), row1.append(hi + row_base), rowt.append(t)
+            win_l.append(wl), win_r.append(wr)
+            pm_rel.append(rel), starts.append(start), lens.append(out_len), nfr.append(n), noises.append(v_ns)
+            self.v_shift.append(v_shift), self.v_pm.append(v_pm), self.v_voi.append(v_voi), self.ns_len.append(ns_len)
+            row_base += n_rows
+            noise_base += ns_len
+
+        cat = np.concatenate
+        self.n_rows = row_base
+        self.total_frames = int(sum(nfr))
+        self.frame_off = cat(([0], np.cumsum(nfr))).astype(np.int64)
+        self.out_len = [int(x) for x in lens]
+        self.out_off_host = cat(([0], np.cumsum(lens))).astype(np.int64)
+        self.total_out = int(self.out_off_host[-1])
+        self.max_out_len = int(max(lens))
+        self.voiced_host = cat(voiced).astype(bool)
+        self.a_mag = e.to_device(cat(a_mag), np.float32)
+        self.a_real = e.to_device(cat(a_real), np.float32)
+        self.a_imag = e.to_device(cat(a_imag), np.float32)
+        self.noise = e.to_device(cat(noises), np.float32)
+        self.npos = e.to_device(cat(npos), np.int64)
+        self.nleft = e.to_device(cat(nleft), np.int32)
+        self.nright = e.to_device(cat(nright), np.int32)
+        self.wtype = e.to_device(cat(wtype), np.int32)
+        self.voiced = e.to_device(cat(voiced), np.int32)
+        self.row0 = e.to_device(cat(row0), np.int32)
+        self.row1 = e.to_device(cat(row1), np.int32)
+        self.rowt = e.to_device(cat(rowt), np.float32)
+        self.win_l = e.to_device(cat(win_l), np.int32)
+        self.win_r = e.to_device(cat(win_r), np.int32)
+        self.pm_rel = e.to_device(cat(pm_rel), np.int32)
+        self.out_start = e.to_device(np.asarray(starts), np.int32)
+        self.out_off = e.to_device(self.out_off_host, np.int64)
+        # constants: unwarp matrices and per-bin curves (float64 -> float32)
+        self.u_mag = e.to_device(hm.unwarp_matrix(self.mag_dim, H, alpha), np.float32)
+        self.u_phase = e.to_device(hm.phase_unwarp_matrix(self.phase_dim, N, fs, self.alpha_phase), np.float32)
+        per_v, ap_v, ap_u = hm.synthesis_bin_curves(fs, N)
+        self.per_v, self.ap_v, self.ap_u = (e.to_device(x, np.float32) for x in (per_v, ap_v, ap_u))
+        # OLA chunks
+        rows, terr_off, owner_all = hm.ola_chunks(pm_rel, N, self.territory)
+        self.n_chunks = int(rows.shape[0])
+        self.chunks = e.to_device(rows, np.int32)
+        self.utt_chunk_off = e.to_device(terr_off, np.int32)
+        self.strip_id = e.to_device(owner_all, np.int32)
+        self.strip_floats = self.n_chunks * (self.territory + N)
+        n_slots = e.synth_ola_slots() if hasattr(e, "synth_ola_slots") else 1280
+        slot_off, slot_chunks = hm.balance_chunks(rows[:, 1] - rows[:, 0], n_slots)
+        self.n_slots = int(slot_off.size - 1)
+        self.slot_off = e.to_device(slot_off, np.int32)
+        self.slot_chunks = e.to_device(slot_chunks, np.int32)
+        self.gains = None
+
+    def noise_gains(self, sums_host):
+        """magphase.py:902-906 (Q10) from the per-frame sums of (ln|Ns|)^2: two gains per utterance, float64."""
+        H = self.fft_len // 2 + 1
+        inv = np.ones(self.total_frames)
+        gains = []
+        for u in range(len(self.out_len)):
+            a, b = int(self.frame_off[u]), int(self.frame_off[u + 1])
+            s = np.asarray(sums_host[a:b], dtype=np.float64)
+            v = self.voiced_host[a:b]
+            g = []
+            for cls in (v, ~v):
+                ncls = int(np.sum(cls))
+                g.append(np.sqrt(np.exp(np.sum(s[cls]) / (ncls * (H - 2)))) if ncls else np.nan)
+                if ncls:
+                    inv[a:b][cls] = 1.0 / g[-1]
+            gains.append(tuple(g))
+        self.gains = gains
+        return inv
+
+    def run(self, out=None, keep=False):
+        e, lib, N = self.engine, self.engine.lib, self.fft_len
+        torch = _torch()
+        H = N // 2 + 1
+        tab = e.tables(N)
+        mag, real, imag = (e.empty((self.n_rows, H)) for _ in range(3))
+        sums = e.empty((self.total_frames,))
+        strips = e.empty((self.strip_floats,))
+        with torch.cuda.device(e.device):
+            st = e.stream_ptr()
+            _lib.check(lib.mpx_mel_unwarp(st, self.n_rows, H, self.a_mag.data_ptr(), self.mag_dim, self.u_mag.data_ptr(),
+                                          mag.data_ptr(), self.a_real.data_ptr(), self.a_imag.data_ptr(),
+                                          self.phase_dim, self.u_phase.data_ptr(), real.data_ptr(), imag.data_ptr()),
+                       "mpx_mel_unwarp")
+            _lib.check(lib.mpx_noise_stats(st, N, tab.data_ptr(), self.noise.data_ptr(), self.npos.data_ptr(),
+                                           self.nleft.data_ptr(), self.nright.data_ptr(), self.wtype.data_ptr(),
+                                           self.total_frames, sums.data_ptr()), "mpx_noise_stats")
+            inv = self.noise_gains(sums.cpu().numpy())   # two scalars per utterance: float64 on the host
+            inv_gain = e.to_device(inv, np.float32)
+            _lib.check(lib.mpx_synthesis_compressed_ola(
+                st, N, tab.data_ptr(), mag.data_ptr(), real.data_ptr(), imag.data_ptr(), self.noise.data_ptr(),
+                self.npos.data_ptr(), self.nleft.data_ptr(), self.nright.data_ptr(), self.wtype.data_ptr(),
+                self.voiced.data_ptr(), inv_gain.data_ptr(), self.row0.data_ptr(), self.row1.data_ptr(),
+                self.rowt.data_ptr(), self.win_l.data_ptr(), self.win_r.data_ptr(), self.pm_rel.data_ptr(),
+                self.per_v.data_ptr(), self.ap_v.data_ptr(), self.ap_u.data_ptr(), self.chunks.data_ptr(),
+                self.n_chunks, self.slot_off.data_ptr(), self.slot_chunks.data_ptr(), self.n_slots, self.territory,
+                strips.data_ptr()), "mpx_synthesis_compressed_ola")
+        pcm = e.ola_fixup(N, self.territory, strips, self.utt_chunk_off, self.strip_id, self.out_start, self.out_off,
+                          self.max_out_len, self.total_out, out=out)
+        if keep:
+            self.debug = dict(mag=mag, real=real, imag=imag, sums=sums)
+        return pcm
+
+
+def _const_to_variable_scan(v_shift_c_rate, frm_rate_ms, fs):
+    """
+    magphase.py:1426-1449 (Q16): serial backward scan pos_{k-1} = pos_k - lerp(shift)(pos_k) from the last
+    constant-rate centre until the position leaves the grid; same scipy interp1d call as the reference, so the float64
+    results (and the integer shifts cast from them) are bit-identical.
+    """
+    from scipy import interpolate
+
+    n = np.size(v_shift_c_rate, 0)
+    step = fs * frm_rate_ms / 1000
+    centres = step * np.arange(1, n + 1)
+    f = interpolate.interp1d(centres, v_shift_c_rate, axis=0, kind="linear")
+    shifts, locs = np.zeros(n * 2), np.zeros(n * 2)
+    pos = centres[-1]
+    for i in range(2 * n - 1, 0, -1):
+        locs[i] = pos
+        try:
+            shifts[i] = f(pos)
+        except ValueError:
+            locs, shifts = locs[i + 1:], shifts[i + 1:]
+            break
+        pos = pos - shifts[i]
+    return shifts, locs

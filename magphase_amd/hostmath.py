@@ -163,3 +163,84 @@ def balance_chunks(n_frames_per_chunk, n_slots, overhead=2):
     slot_off = np.concatenate(([0], np.cumsum([len(l) for l in lists]))).astype(np.int64)
     slot_chunks = np.asarray([c for l in lists for c in l], dtype=np.int64)
     return slot_off, slot_chunks
+
+
+# ======================================================================================================
+# compressed-feature constants (float64 on the host, uploaded once per (fs, dims) as float32)
+# ======================================================================================================
+def warp_axis(alpha, nbins):
+    """libaudio.py:612-614 / :711-715: all-pass warped frequency axis on nbins points in [0, pi]."""
+    w = np.linspace(0, np.pi, num=nbins)
+    ww = np.arctan((1 - alpha ** 2) * np.sin(w) / ((1 + alpha ** 2) * np.cos(w) - 2 * alpha))
+    ww[ww < 0] += np.pi
+    return ww
+
+
+def build_mel_curve(alpha, nbins, amp=np.pi):
+    """libaudio.py:711-718."""
+    return warp_axis(alpha, nbins) * (amp / np.pi)
+
+
+def unwarp_matrix(ncoeffs, nbins_out, alpha):
+    """
+    la.sp_mel_unwarp(in_type='log') (libaudio.py:667-684) as the matrix it is: out = x @ U,
+    U[ncoeffs x nbins_out].  Even extension -> real IFFT -> coefficients 1..ncoeffs-3 doubled (Q6) ->
+    cosine matrix on the alpha-warped axis (libaudio.py:605-619).
+    """
+    eye = np.eye(ncoeffs)
+    ext = np.hstack((eye, eye[:, -2:0:-1]))
+    ceps = np.fft.ifft(ext).real[:, :ncoeffs]
+    ceps[:, 1:(ncoeffs - 2)] *= 2
+    cosm = np.cos(np.arange(ncoeffs)[:, None] * warp_axis(alpha, nbins_out)[None, :])
+    return ceps @ cosm
+
+
+def get_num_full_mel_coeffs_from_num_phase_coeffs(freq_hz, phase_dim, alpha, fs):
+    """magphase.py:2479-2487."""
+    cw = 2 * np.pi * freq_hz / float(fs)
+    cf_mel = np.arctan((1 - alpha ** 2) * np.sin(cw) / ((1 + alpha ** 2) * np.cos(cw) - 2 * alpha))
+    if cf_mel < 0:
+        cf_mel += np.pi
+    return int(round_to_int(1 + (np.pi * (phase_dim - 1) / float(cf_mel))))
+
+
+def phase_unwarp_matrix(phase_dim, fft_len, fs, alpha):
+    """
+    magphase.py:1219-1235 as a matrix [phase_dim x H]: nearest-neighbour extension phase_dim -> K (the last
+    coefficient repeated) followed by the K-coefficient unwarp: rows >= phase_dim-1 of U_K fold into the last row.
+    """
+    cf = define_crossfade_params(fs)[0]
+    k_full = get_num_full_mel_coeffs_from_num_phase_coeffs(cf, phase_dim, alpha, fs)
+    u_full = unwarp_matrix(k_full, fft_len // 2 + 1, alpha)
+    if k_full <= phase_dim:
+        return u_full[:phase_dim].copy() if k_full == phase_dim else np.vstack(
+            (u_full, np.zeros((phase_dim - k_full, u_full.shape[1]))))  # (index >= K never read: columns cut)
+    u = u_full[:phase_dim].copy()
+    u[phase_dim - 1] += u_full[phase_dim:].sum(axis=0)
+    return u
+
+
+def crossfade_lowpass_curve(nbins_half, cut_off, bw, fs):
+    """libaudio.py:160-186 for (ones, zeros): 1 below bin_l, falling Hann half on [bin_l, bin_r], 0 above."""
+    nfft = (nbins_half - 1) * 2
+    bin_l = int(round_to_int((cut_off - bw / 2.0) * nfft / float(fs)))
+    bin_r = int(round_to_int((cut_off + bw / 2.0) * nfft / float(fs)))
+    bw_bin = bin_r - bin_l
+    return np.hstack((np.ones(bin_l), np.hanning(2 * bw_bin + 1)[bw_bin:], np.zeros(nbins_half - bin_r - 1)))
+
+
+def synthesis_bin_curves(fs, fft_len):
+    """
+    Per-bin constant vectors of synthesis_from_compressed (magphase.py:873-875, 917-918, 940-941, 946-952):
+      per_v = tilt_voiced * sqrt(mask)      periodic component of voiced frames  (0 where mask == 0)
+      ap_v  = sqrt(1 - mask)                aperiodic component of voiced frames (0 where mask == 1)
+      ap_u  = tilt_unvoiced                 aperiodic component of unvoiced frames (mask == 0 there)
+    tilt_voiced = 10**(melcurve(0.6, H, 2.0)/20); tilt_unvoiced = 10**((melcurve(alpha, H, 3.5) - 3.5)/20) (Q13).
+    """
+    half = fft_len // 2 + 1
+    cf, bw = define_crossfade_params(fs)
+    alpha = define_alpha(fs)
+    mask = crossfade_lowpass_curve(half, cf, bw, fs)
+    tilt_v = 10 ** (build_mel_curve(0.6, half, amp=2.0) / 20)
+    tilt_u = 10 ** ((build_mel_curve(alpha, half, amp=3.5) - 3.5) / 20)
+    return tilt_v * mask ** 0.5, (1 - mask) ** 0.5, tilt_u

@@ -18,7 +18,7 @@ import numpy as np
 from . import hostmath as hm
 from . import libaudio as la
 from . import libutils as lu
-from .engine import LosslessAnalysisPlan, LosslessSynthesisPlan, get_engine
+from .engine import CompressedSynthesisPlan, LosslessAnalysisPlan, LosslessSynthesisPlan, get_engine
 
 _epoch_provider = None
 
@@ -136,3 +136,99 @@ def synthesis_from_lossless_batch(feats, engine=None):
 def synthesis_from_lossless(m_mag, m_real, m_imag, v_f0, fs):
     """magphase.py:1759-1776."""
     return synthesis_from_lossless_batch([(m_mag, m_real, m_imag, v_f0, fs)])[0]
+
+
+# ======================================================================================================
+# compressed-feature synthesis
+# ======================================================================================================
+def post_filter(m_mag_mel_log, fs, av_len_at_zero=None, av_len_at_nyq=None, boost_at_zero=None, boost_at_nyq=None):
+    """
+    magphase.py:2300-2378 (Q20).  [F x 60] float64 on the host, vectorised over frames: 0.5 KB per frame, not worth
+    a kernel launch.  Same defaults, warnings and ValueError as the reference.
+    """
+    m_mag_mel_log = np.asarray(m_mag_mel_log, dtype=np.float64)
+    nfrms, mag_dim = m_mag_mel_log.shape
+    if mag_dim != 60:
+        warnings.warn('Post-filter: It has been only tested with 60 dimensional mag data. '
+                      'If you use another dimension, the result may be suboptimal.')
+    opts = [av_len_at_zero, av_len_at_nyq, boost_at_zero, boost_at_nyq]
+    if fs == 48000:
+        defaults = [hm.round_to_int(11.0 * (mag_dim / 60.0)), hm.round_to_int(3.0 * (mag_dim / 60.0)), 1.8, 2.0]
+    elif fs == 16000:
+        if any(o is None for o in opts):
+            warnings.warn('Post-filter: The default parameters for 16kHz sample rate have not being tunned.')
+        defaults = [hm.round_to_int(9.0 * (mag_dim / 60.0)), hm.round_to_int(12.0 * (mag_dim / 60.0)), 2.0, 1.6]
+    else:
+        if any(o is None for o in opts):
+            raise ValueError('Post-filter: It has only been tested with 16kHz and 48kHz sample rates.'
+                             '\nProvide your own values for the options: av_len_at_zero, av_len_at_nyq, '
+                             'boost_at_zero,\nboost_at_nyq if you use another sample rate')
+        defaults = opts
+    av0, avn, b0, bn = [d if o is None else o for o, d in zip(opts, defaults)]
+    v_nx = np.arange(np.floor(av0 / 2), mag_dim - np.floor(avn / 2)).astype(int)
+    v_lens = (2 * np.ceil(np.linspace(av0, avn, v_nx.size) / 2) - 1).astype(int)
+    half = v_lens // 2
+    m_ave = np.zeros((nfrms, mag_dim))
+    for j, nxb in enumerate(v_nx):
+        m_ave[:, nxb] = np.mean(m_mag_mel_log[:, nxb - half[j]:nxb + half[j] + 1], axis=1)
+    m_ave[:, :v_nx[0]] = m_ave[:, [v_nx[0]]]
+    m_ave[:, v_nx[-1]:] = m_ave[:, [v_nx[-1]]]
+    m_enh = (m_mag_mel_log - m_ave) * np.linspace(b0, bn, mag_dim)[None, :] + m_ave
+    m_enh[:, 0] = m_mag_mel_log[:, 0]
+    m_enh[:, -1] = m_mag_mel_log[:, -1]
+    return m_enh
+
+
+def _output_hpf(v_syn_sig, fs):
+    """magphase.py:981-995: 4th-order Butterworth high-pass at 40 Hz, float64 on the host (poles at |z|~0.997)."""
+    from scipy import signal
+
+    v_b, v_a = signal.butter(4, 40 / (fs / 2.0), btype='highpass')
+    return signal.lfilter(v_b, v_a, v_syn_sig)
+
+
+def synthesis_from_compressed_batch(utts, fs, fft_len=None, b_voi_ap_win=True, b_const_rate=False, alpha_phase=None,
+                                    b_out_hpf=True, noise=None, engine=None):
+    """Batched synthesis_from_compressed; utts: list of (m_mag_mel_log, m_real_mel, m_imag_mel, v_lf0)."""
+    engine = engine or get_engine()
+    plan = CompressedSynthesisPlan(engine, utts, fs, fft_len=fft_len, b_voi_ap_win=b_voi_ap_win,
+                                   b_const_rate=b_const_rate, alpha_phase=alpha_phase, noise=noise)
+    pcm = plan.run().cpu().numpy().astype(np.float64)
+    out = [pcm[plan.out_off_host[u]:plan.out_off_host[u + 1]] for u in range(len(utts))]
+    if b_out_hpf:
+        out = [_output_hpf(v, fs) for v in out]
+    return out
+
+
+def synthesis_from_compressed(m_mag_mel_log, m_real_mel, m_imag_mel, v_lf0, fs, fft_len=None, b_voi_ap_win=True,
+                              b_fbank_mel=False, b_const_rate=False, per_phase_type='magphase', alpha_phase=None,
+                              b_out_hpf=True):
+    """magphase.py:825-997.  The experimental branches (b_fbank_mel, per_phase_type != 'magphase') are not on the path."""
+    if b_fbank_mel:
+        raise NotImplementedError("b_fbank_mel=True (experimental filter-bank warping) is outside the hot path")
+    if per_phase_type != 'magphase':
+        raise NotImplementedError("per_phase_type=%r: only the default 'magphase' branch runs on the GPU path" % per_phase_type)
+    return synthesis_from_compressed_batch([(m_mag_mel_log, m_real_mel, m_imag_mel, v_lf0)], fs, fft_len=fft_len,
+                                           b_voi_ap_win=b_voi_ap_win, b_const_rate=b_const_rate,
+                                           alpha_phase=alpha_phase, b_out_hpf=b_out_hpf)[0]
+
+
+def synthesis_from_acoustic_modelling(in_feats_dir, filename_token, out_syn_dir, mag_dim, phase_dim, fs,
+                                      fft_len=None, pf_type='no', b_const_rate=False):
+    """magphase.py:3229-3275."""
+    print("\nSynthesising file: " + filename_token + '.wav............................')
+    m_mag_mel_log = lu.read_binfile(in_feats_dir + '/' + filename_token + '.mag', dim=mag_dim)
+    m_real_mel = lu.read_binfile(in_feats_dir + '/' + filename_token + '.real', dim=phase_dim)
+    m_imag_mel = lu.read_binfile(in_feats_dir + '/' + filename_token + '.imag', dim=phase_dim)
+    v_lf0 = lu.read_binfile(in_feats_dir + '/' + filename_token + '.lf0', dim=1)
+    if pf_type == 'magphase':
+        print('Using MagPhase postfilter...')
+        m_mag_mel_log = post_filter(m_mag_mel_log, fs)
+    elif pf_type == 'merlin':
+        raise NotImplementedError("pf_type='merlin' shells out to nine SPTK binaries (magphase.py:3375-3465): out of scope")
+    elif pf_type == 'no':
+        print('No postfilter...')
+    v_syn_sig = synthesis_from_compressed(m_mag_mel_log, m_real_mel, m_imag_mel, v_lf0, fs, fft_len=fft_len,
+                                          b_const_rate=b_const_rate)
+    la.write_audio_file(out_syn_dir + '/' + filename_token + '.wav', v_syn_sig, fs)
+    return

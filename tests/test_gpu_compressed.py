@@ -1,0 +1,113 @@
+"""
+-m gpu parity tests of the compressed-feature synthesis path (mpx_mel_unwarp, mpx_noise_stats,
+mpx_synthesis_compressed_ola through magphase_amd.magphase) against the committed outputs of the real reference
+(tests/golden G5: bundled predicted features hvd_704; G8: constant-rate case) and against the CPU oracle.
+
+Tolerances (fp32 device vs fp64 reference): unwarped spectra rel 2e-6 (mag) / abs 2e-6 (real, imag);
+noise gains rel 1e-6; resynthesised PCM <= COMP_PCM_TOL of the signal peak.  Noise is the reference's own draw:
+np.random.seed(k) then one np.random.uniform(-1, 1, ns_len) (magphase.py:883).
+"""
+import os
+import warnings
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+COMP_PCM_TOL = 2e-5
+
+
+@pytest.fixture(scope="module")
+def mp():
+    from magphase_amd import magphase as m
+    return m
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import magphase_oracle as o
+    return o
+
+
+def _hvd704(golden_dir):
+    g = np.load(os.path.join(golden_dir, "g5_generation_hvd704.npz"))
+    mm = g["in_mag"].reshape(-1, 60).astype(np.float64)
+    rr = g["in_real"].reshape(-1, 45).astype(np.float64)
+    ii = g["in_imag"].reshape(-1, 45).astype(np.float64)
+    return g, mm, rr, ii, g["in_lf0"].astype(np.float64)
+
+
+def test_unwarp_and_noise_gains_match_oracle(orc, golden_dir):
+    from magphase_amd.engine import CompressedSynthesisPlan, get_engine
+    g, mm, rr, ii, lf = _hvd704(golden_dir)
+    np.random.seed(11)
+    plan = CompressedSynthesisPlan(get_engine(), [(mm, rr, ii, lf)], 48000)
+    plan.run(keep=True)
+    np.random.seed(11)
+    _, dbg = orc.synthesis_from_compressed(mm, rr, ii, lf, 48000, return_debug=True)
+    mag = plan.debug["mag"].cpu().numpy().astype(np.float64)
+    real = plan.debug["real"].cpu().numpy().astype(np.float64)
+    imag = plan.debug["imag"].cpu().numpy().astype(np.float64)
+    assert np.max(np.abs(mag - dbg["m_mag"]) / dbg["m_mag"]) < 2e-6
+    assert np.max(np.abs(real - dbg["m_real"])) < 2e-6
+    assert np.max(np.abs(imag - dbg["m_imag"])) < 2e-6
+    g_voi, g_unv = plan.gains[0]
+    assert abs(g_voi - dbg["g_voi"]) < 1e-6 * dbg["g_voi"]
+    assert abs(g_unv - dbg["g_unv"]) < 1e-6 * dbg["g_unv"]
+
+
+def test_generation_from_predicted_features_matches_reference_golden(mp, golden_dir):
+    g, mm, rr, ii, lf = _hvd704(golden_dir)
+    seed = int(g["seed"])
+    pf = mp.post_filter(mm, 48000)
+    assert np.max(np.abs(pf - g["pf48"])) < 1e-12
+    for hpf in (True, False):
+        np.random.seed(seed)
+        v = mp.synthesis_from_compressed(pf, rr, ii, lf, 48000, b_out_hpf=hpf)
+        ref = g["syn_pf_hpf%d" % int(hpf)]
+        assert len(v) == len(ref)
+        assert np.max(np.abs(v - ref)) <= COMP_PCM_TOL * np.max(np.abs(ref)), np.max(np.abs(v - ref))
+    np.random.seed(seed)
+    v = mp.synthesis_from_compressed(mm, rr, ii, lf, 48000, b_voi_ap_win=False)
+    ref = g["syn_nopf_novoiwin"]
+    assert len(v) == len(ref)
+    assert np.max(np.abs(v - ref)) <= COMP_PCM_TOL * np.max(np.abs(ref))
+
+
+def test_constant_rate_input_matches_reference_golden(mp, golden_dir):
+    g = np.load(os.path.join(golden_dir, "g8_compressed_analysis.npz"))
+    np.random.seed(int(g["cr45_seed"]))
+    v = mp.synthesis_from_compressed(g["cr45_mag"], g["cr45_real"], g["cr45_imag"], g["cr45_lf0"], int(g["fs"]),
+                                     b_const_rate=True, b_out_hpf=False)
+    ref = g["cr45_syn"]
+    assert len(v) == len(ref)
+    assert np.max(np.abs(v - ref)) <= COMP_PCM_TOL * np.max(np.abs(ref)), np.max(np.abs(v - ref))
+
+
+def test_16k_and_batch_match_oracle(mp, orc):
+    from magphase_amd import synthetic as syn
+    feats = []
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for u in range(3):
+            pcm, pm, voi = syn.make_utterance(90 + u, dur_s=0.5 + 0.2 * u, fs=16000)
+            r = orc.analysis_compressed_from_epochs(syn.pcm_to_float(pcm), 16000, pm, voi, mag_dim=60, phase_dim=45)
+            feats.append(r[:4])
+        refs = []
+        np.random.seed(21)
+        for f in feats:
+            refs.append(orc.synthesis_from_compressed(f[0], f[1], f[2], f[3], 16000))
+        np.random.seed(21)
+        got = mp.synthesis_from_compressed_batch(feats, 16000)
+    for v, ref in zip(got, refs):
+        assert len(v) == len(ref)
+        assert np.max(np.abs(v - ref)) <= COMP_PCM_TOL * np.max(np.abs(ref)), np.max(np.abs(v - ref))
+
+
+def test_unsupported_branches_and_errors(mp, golden_dir):
+    g, mm, rr, ii, lf = _hvd704(golden_dir)
+    with pytest.raises(NotImplementedError):
+        mp.synthesis_from_compressed(mm, rr, ii, lf, 48000, per_phase_type="min_phase")
+    with pytest.raises(ValueError):
+        mp.synthesis_from_compressed(mm, rr, ii, lf, 44100 + 1)   # define_alpha: unsupported rate

@@ -26,7 +26,7 @@ def build_variant(name, flags):
     out_dir = os.path.join(ROOT, "gpurun_out", "ab")
     os.makedirs(out_dir, exist_ok=True)
     lib = os.path.join(out_dir, "libmagphase_hip_%s.so" % name)
-    cmd = [build.hipcc_path()] + build.FLAGS + flags + [build.SRC, "-o", lib]
+    cmd = [build.hipcc_path()] + build.FLAGS + flags + build.SRCS + ["-o", lib]
     subprocess.check_call(cmd)
     return lib
 
