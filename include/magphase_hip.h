@@ -149,6 +149,25 @@ int mpx_synthesis_compressed_ola(void* stream, int fft_len, const void* tables, 
                                  const int32_t* slot_off, const int32_t* slot_chunks, int32_t n_slots,
                                  int32_t territory, float* strips);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Compressed-feature analysis (magphase.py:2490-2544 format_for_modelling, :2947-2988 analysis_compressed)
+ * ------------------------------------------------------------------------------------------------------------------ */
+
+/*
+ * Mel warp of the lossless features (la.sp_mel_warp, libaudio.py:643-661 = SPTK-3.9 ``mcep -j 0`` + alpha=0 cosine matrix;
+ * the SPTK part is a restatement, PARITY UNPINNED) as linear maps of the log-periodogram, plus the epilogues of
+ * format_for_modelling:
+ *   out_mag  [F x mag_dim]   = W_mag   . ln(mag^2 + 1e-8)                                  (== la.log(sp_mel_warp(mag)))
+ *   out_real [F x phase_dim] = clip(voiced * (W_phase . ln(exp(real)^2 + 1e-8)), -1, 1)    (same for imag)
+ * W_mag [mag_dim x n_bins], W_phase [phase_dim x n_bins] float32 from hostmath.warp_matrix (float64 on the host).
+ * row0/row1/row_t (all null, or int32/int32/float32 [F]): output frame f reads the interpolated input row
+ * (1-row_t)*x[row0] + row_t*x[row1] (variable -> constant frame rate, magphase.py:2219-2239); null = row f.
+ */
+int mpx_mel_warp(void* stream, int64_t n_frames, int32_t n_bins, const float* mag, const float* real, const float* imag,
+                 const int32_t* row0, const int32_t* row1, const float* row_t, const float* w_mag, int32_t mag_dim,
+                 const float* w_phase, int32_t phase_dim, const float* voiced, float* out_mag, float* out_real,
+                 float* out_imag);
+
 #ifdef __cplusplus
 }
 #endif

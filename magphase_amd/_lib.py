@@ -24,6 +24,7 @@ SYMBOLS = (
     "mpx_mel_unwarp",
     "mpx_noise_stats",
     "mpx_synthesis_compressed_ola",
+    "mpx_mel_warp",
 )
 
 _lib = None
@@ -71,6 +72,8 @@ def load():
     lib.mpx_noise_stats.argtypes = [vp, ctypes.c_int, vp, vp, vp, vp, vp, vp, i64, vp]
     lib.mpx_synthesis_compressed_ola.restype = ctypes.c_int
     lib.mpx_synthesis_compressed_ola.argtypes = [vp, ctypes.c_int, vp] + [vp] * 19 + [vp, i32, vp, vp, i32, i32, vp]
+    lib.mpx_mel_warp.restype = ctypes.c_int
+    lib.mpx_mel_warp.argtypes = [vp, i64, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, vp, vp, vp, vp]
     _lib = lib
     return lib
 

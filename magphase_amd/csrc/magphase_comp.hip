@@ -63,6 +63,96 @@ __global__ __launch_bounds__(256) void k_mel_unwarp(UnwarpJobs jobs, long long F
 }
 
 // ---------------------------------------------------------------------------------------------
+// mel warp GEMM (compressed analysis): out[f][i] = post( sum_k W[i][k] * pre(x[f][k]) ), i < nout <= 64, k < H
+// ---------------------------------------------------------------------------------------------
+// la.sp_mel_warp (libaudio.py:643-661) = SPTK ``mcep -j 0`` (log-periodogram -> real IFFT -> halve c0, c_{N/2} ->
+// freqt) followed by the alpha = 0 cosine matrix: a LINEAR map of the log-periodogram, precomputed on the host as W
+// (hostmath.warp_matrix).  pre: mode 0 (|f(w)|, mcep -q 3): ln(x^2 + 1e-8); mode 1 (ln|f(w)|, -q 2): ln(exp(x)^2 + 1e-8).
+// Rows may be interpolated on the fly (variable -> constant frame rate, magphase.py:2219-2239) BEFORE pre().
+// post: mode 0: none (the reference's exp followed by la.log); mode 1: * voiced, clip to [-1, 1] (magphase.py:2527-2532).
+struct WarpJob {
+    const float* x;      // [rows x H]
+    const float* W;      // [nout x H]
+    float* out;          // [F x nout]
+    const float* voi;    // [F] or null
+    int nout;
+    int mode;
+};
+struct WarpJobs {
+    WarpJob j[3];
+};
+
+constexpr int kWarpTile = 64;
+constexpr int kWarpStride = 68;   // floats per LDS row (multiple of 4 for float4 reads)
+
+__global__ __launch_bounds__(256) void k_mel_warp(WarpJobs jobs, long long F, int H, const int* __restrict__ row0,
+                                                  const int* __restrict__ row1, const float* __restrict__ rowt) {
+    __shared__ __attribute__((aligned(16))) float As[kWarpTile][kWarpStride];   // As[kk][f]
+    __shared__ __attribute__((aligned(16))) float Ws[kWarpTile][kWarpStride];   // Ws[kk][i]
+    const WarpJob job = jobs.j[blockIdx.z];
+    const long long f0 = (long long)blockIdx.y * kWarpTile;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int kk = threadIdx.x & 63, fq = threadIdx.x >> 6;   // staging roles
+    float acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = 0.0f;
+
+    for (int k0 = 0; k0 < H; k0 += kWarpTile) {
+        const int k = k0 + kk;
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+            const int fl = fq + 4 * p;
+            const long long f = f0 + fl;
+            float v = 0.0f;
+            if (f < F && k < H) {
+                float x;
+                if (row0) {
+                    const int r0 = row0[f], r1 = row1[f];
+                    const float x0 = job.x[(long long)r0 * H + k];
+                    x = (r0 != r1) ? fmaf(job.x[(long long)r1 * H + k] - x0, rowt[f], x0) : x0;
+                } else {
+                    x = job.x[f * H + k];
+                }
+                const float e = (job.mode == 0) ? x : expf(x);
+                v = logf(fmaf(e, e, 1.0e-8f));
+            }
+            As[kk][fl] = v;
+            const int i = fl;   // same index range 0..63 used for the W tile rows
+            Ws[kk][i] = (i < job.nout && k < H) ? job.W[(long long)i * H + k] : 0.0f;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int q = 0; q < kWarpTile; ++q) {
+            const float4 a = *reinterpret_cast<const float4*>(&As[q][4 * ty]);
+            const float4 w = *reinterpret_cast<const float4*>(&Ws[q][4 * tx]);
+            const float av[4] = {a.x, a.y, a.z, a.w};
+            const float wv[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[r][c] = fmaf(av[r], wv[c], acc[r][c]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const long long f = f0 + 4 * ty + r;
+        if (f >= F) continue;
+        const float vo = job.voi ? job.voi[f] : 1.0f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int i = 4 * tx + c;
+            if (i >= job.nout) continue;
+            float y = acc[r][c];
+            if (job.mode == 1) y = fminf(fmaxf(y * vo, -1.0f), 1.0f);
+            job.out[f * job.nout + i] = y;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // noise frame -> half spectrum in registers
 // ---------------------------------------------------------------------------------------------
 // Windowed noise frame (magphase.py:886-897: windowing() with per-frame window list, epoch moved to index 0 by
@@ -441,6 +531,30 @@ int mpx_synthesis_compressed_ola(void* stream, int fft_len, const void* tables, 
                            per_v, ap_v, ap_u, (const ChunkDesc*)chunks, slot_off, slot_chunks, (int)n_slots,
                            (int)territory, (const float2*)tables, strips);
     }
+    MPX_HIP_CHECK(hipGetLastError());
+    return MPX_OK;
+}
+
+int mpx_mel_warp(void* stream, int64_t n_frames, int32_t n_bins, const float* mag, const float* real, const float* imag,
+                 const int32_t* row0, const int32_t* row1, const float* row_t, const float* w_mag, int32_t mag_dim,
+                 const float* w_phase, int32_t phase_dim, const float* voiced, float* out_mag, float* out_real,
+                 float* out_imag) {
+    if (n_frames < 0 || n_bins <= 0) return fail(MPX_ERR_ARG, "mpx_mel_warp: bad size%s");
+    if (mag_dim <= 0 || mag_dim > kWarpTile || phase_dim <= 0 || phase_dim > kWarpTile)
+        return fail(MPX_ERR_ARG, "mpx_mel_warp: output dimension must be in 1..64%s");
+    if (n_frames == 0) return MPX_OK;
+    if (!mag || !real || !imag || !w_mag || !w_phase || !voiced || !out_mag || !out_real || !out_imag)
+        return fail(MPX_ERR_ARG, "mpx_mel_warp: null pointer%s");
+    if ((row0 == nullptr) != (row1 == nullptr) || (row0 == nullptr) != (row_t == nullptr))
+        return fail(MPX_ERR_ARG, "mpx_mel_warp: row0/row1/row_t must be all null or all given%s");
+    WarpJobs jobs;
+    jobs.j[0] = {mag, w_mag, out_mag, nullptr, (int)mag_dim, 0};
+    jobs.j[1] = {real, w_phase, out_real, voiced, (int)phase_dim, 1};
+    jobs.j[2] = {imag, w_phase, out_imag, voiced, (int)phase_dim, 1};
+    const dim3 grid(1, (unsigned)((n_frames + kWarpTile - 1) / kWarpTile), 3);
+    if (grid.y > 65535) return fail(MPX_ERR_ARG, "mpx_mel_warp: too many frames per call (max 4194240)%s");
+    hipLaunchKernelGGL(k_mel_warp, grid, dim3(256), 0, (hipStream_t)stream, jobs, (long long)n_frames, (int)n_bins,
+                       row0, row1, row_t);
     MPX_HIP_CHECK(hipGetLastError());
     return MPX_OK;
 }

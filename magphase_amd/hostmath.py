@@ -244,3 +244,77 @@ def synthesis_bin_curves(fs, fft_len):
     tilt_v = 10 ** (build_mel_curve(0.6, half, amp=2.0) / 20)
     tilt_u = 10 ** ((build_mel_curve(alpha, half, amp=3.5) - 3.5) / 20)
     return tilt_v * mask ** 0.5, (1 - mask) ** 0.5, tilt_u
+
+
+# ======================================================================================================
+# mel warp (compressed analysis) as a matrix -- SPTK-3.9 ``mcep -j 0`` restated (PARITY UNPINNED: external binary)
+# ======================================================================================================
+def freqt_matrix(n_in, order_out, alpha):
+    """
+    Frequency transformation of cepstra by a first-order all-pass (Tokuda et al. 1994; SPTK ``freqt``) as a matrix
+    A[(order_out+1) x n_in]: mc = A @ c.  The recursion consumes the input from c[n_in-1] down to c[0]; running it on
+    the identity gives the matrix.  alpha == 0 is the identity truncation.
+    """
+    m2 = int(order_out)
+    if alpha == 0.0:
+        a_mat = np.zeros((m2 + 1, n_in))
+        a_mat[np.arange(min(m2 + 1, n_in)), np.arange(min(m2 + 1, n_in))] = 1.0
+        return a_mat
+    b = 1.0 - alpha * alpha
+    g = np.zeros((n_in, m2 + 1))          # one "frame" per unit input vector
+    for i in range(n_in - 1, -1, -1):
+        d = g.copy()
+        g[:, 0] = alpha * d[:, 0]
+        g[i, 0] += 1.0                     # c1[-i] of the unit vector e_i
+        if m2 >= 1:
+            g[:, 1] = b * d[:, 0] + alpha * d[:, 1]
+        for j in range(2, m2 + 1):
+            g[:, j] = d[:, j - 1] + alpha * (d[:, j] - g[:, j - 1])
+    return g.T.copy()
+
+
+_WARP_CACHE = {}
+
+
+def warp_matrix(nbins_out, nbins_half, alpha, nrows=None):
+    """
+    la.sp_mel_warp (libaudio.py:643-661) as W[nrows x nbins_half] acting on the log-periodogram:
+      c[n]  = (1/N) sum_k w_k logP[k] cos(2 pi k n / N), n = 0..N/2   (real IFFT of the even extension; w_0 = w_{N/2} = 1, else 2)
+      c[0] /= 2, c[N/2] /= 2 ;  mc = freqt(c, nbins_out - 1, alpha) ;  out[i] = sum_n mc[n] cos(n pi i / (nbins_out - 1))
+    alpha is rounded to two decimals as on the mcep command line (libaudio.py:589).  nrows: keep only the first rows
+    (the phase features are cut to phase_dim, magphase.py:2523-2524).
+    """
+    key = (int(nbins_out), int(nbins_half), float("%1.2f" % alpha))
+    if key not in _WARP_CACHE:
+        nb, half = key[0], key[1]
+        n_fft = 2 * (half - 1)
+        w = np.full(half, 2.0)
+        w[0] = w[-1] = 1.0
+        idct = np.cos(2 * np.pi * np.outer(np.arange(half), np.arange(half)) / n_fft) * w[None, :] / n_fft
+        idct[0] *= 0.5
+        idct[-1] *= 0.5
+        a_mat = freqt_matrix(half, nb - 1, key[2])
+        cosm = np.cos(np.arange(nb)[:, None] * np.linspace(0, np.pi, nb)[None, :]).T
+        _WARP_CACHE[key] = cosm @ (a_mat @ idct)
+    wm = _WARP_CACHE[key]
+    return wm if nrows is None else wm[:nrows]
+
+
+def var_to_const_rate_table(v_pm_smpls, const_rate_ms, fs):
+    """
+    Row/weight table of magphase.py:2219-2239 (Q15): grid arange(step, pm[-1], step); the first row is duplicated at
+    t = 0 when pm[0] > 0.  Returns (row_lo, row_hi int64[Fc], t float64[Fc]) with out = (1-t)*rows[lo] + t*rows[hi].
+    """
+    v_pm_smpls = np.asarray(v_pm_smpls)
+    step = fs * const_rate_ms / 1000
+    centres = np.arange(step, v_pm_smpls[-1], step)
+    if v_pm_smpls[0] > 0:
+        x = np.r_[0, v_pm_smpls]
+        node_row = np.r_[0, np.arange(v_pm_smpls.size)]
+    else:
+        x = v_pm_smpls
+        node_row = np.arange(v_pm_smpls.size)
+    idx = np.clip(np.searchsorted(x, centres), 1, x.size - 1)   # scipy interp1d's bracketing
+    lo, hi = idx - 1, idx
+    t = (centres - x[lo]) / (x[hi] - x[lo]).astype(np.float64)
+    return node_row[lo].astype(np.int64), node_row[hi].astype(np.int64), t

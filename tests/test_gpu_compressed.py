@@ -111,3 +111,48 @@ def test_unsupported_branches_and_errors(mp, golden_dir):
         mp.synthesis_from_compressed(mm, rr, ii, lf, 48000, per_phase_type="min_phase")
     with pytest.raises(ValueError):
         mp.synthesis_from_compressed(mm, rr, ii, lf, 44100 + 1)   # define_alpha: unsupported rate
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# compressed analysis (mel warp).  The SPTK mcep arithmetic is a restatement -> golden G8 is "oracle-with-our-mcep".
+# Tolerances: log-mag mel abs 2e-4 (fp32 GEMM over 2049 log-power terms of size ~10), real/imag abs 2e-4, lf0 and
+# shifts exact (host fp64).
+# ---------------------------------------------------------------------------------------------------------------
+WARP_TOL = 2e-4
+
+
+@pytest.mark.parametrize("tag,kw", [("vr45", dict(phase_dim=45)), ("cr45", dict(phase_dim=45, b_const_rate=True)),
+                                     ("q7", dict(phase_dim=10, alpha_phase=False))])
+def test_compressed_analysis_matches_golden(mp, golden_dir, tag, kw):
+    from magphase_amd import synthetic as syn
+    g = np.load(os.path.join(golden_dir, "g8_compressed_analysis.npz"))
+    fs = int(g["fs"])
+    x = syn.pcm_to_float(g["pcm"])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        r = mp.analysis_compressed_batch([(x, fs, g["pm_sec"], g["voi"])], mag_dim=60, **kw)[0]
+    assert r[0].shape == g[tag + "_mag"].shape and r[1].shape == g[tag + "_real"].shape
+    assert np.max(np.abs(r[0] - g[tag + "_mag"])) < WARP_TOL
+    assert np.max(np.abs(r[1] - g[tag + "_real"])) < WARP_TOL
+    assert np.max(np.abs(r[2] - g[tag + "_imag"])) < WARP_TOL
+    assert np.array_equal(r[3], g[tag + "_lf0"])
+    assert np.array_equal(r[4], g[tag + "_shift"])
+    assert r[5] == fs and r[6] == 4096
+
+
+def test_low_dim_copy_synthesis_roundtrip(mp, orc):
+    """demo_copy_synthesis_low_dim call sequence on the device path vs the same sequence in the oracle."""
+    from magphase_amd import synthetic as syn
+    pcm, pm, voi = syn.make_utterance(77, dur_s=0.8, fs=48000)
+    x = syn.pcm_to_float(pcm)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        a = mp.analysis_compressed_batch([(x, 48000, pm, voi)], mag_dim=60, phase_dim=45, b_const_rate=True)[0]
+        o = orc.analysis_compressed_from_epochs(x, 48000, pm, voi, mag_dim=60, phase_dim=45, b_const_rate=True)
+        np.random.seed(3)
+        v = mp.synthesis_from_compressed(a[0], a[1], a[2], a[3], 48000, b_const_rate=True, b_out_hpf=False)
+        np.random.seed(3)
+        ref = orc.synthesis_from_compressed(o[0], o[1], o[2], o[3], 48000, b_const_rate=True, b_out_hpf=False)
+    assert len(v) == len(ref)
+    # features differ by ~1e-4 (fp32 warp) -> the waveform by a few 1e-4 of peak
+    assert np.max(np.abs(v - ref)) <= 2e-3 * np.max(np.abs(ref))
