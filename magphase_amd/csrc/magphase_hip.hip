@@ -263,17 +263,28 @@ __global__ __launch_bounds__(kSynWaves * 64) void k_synth_ola(const float* __res
             asm volatile("" : "+v"(lane), "+v"(wl_s), "+v"(wl_c));
             float xr[P], xi[P], xm;
             feat_convert<P>(ff, xr, xi, xm, lane);
-            hermitian_merge<P>(xr, xi, xm, lane, wl_c, wl_s);
-            wave_fft_front<P, +1>(xr, xi, tw, xbuf, lane);
-            // Prefetch the next frame's features behind the second FFT pass + overlap-add.  Placed HERE (not
-            // right after the conversion): earlier, 99 old + 99 new feature registers + the 64 spectrum
-            // registers exceed 256 VGPRs and the compiler spills freshly loaded values with a vmcnt(0) each.
+#ifdef MPX_SYN_EARLY_PREFETCH
+            // one wave per SIMD (512 VGPRs): the next frame's features can be requested a whole frame ahead
             __builtin_amdgcn_sched_barrier(0);
             if (fi + 1 < cd.frame_end) {
                 const long long f = fi + 1;
                 feat_load<P>(ff, mag + f * H, real + f * H, imag + f * H, lane);
             }
             __builtin_amdgcn_sched_barrier(0);
+#endif
+            hermitian_merge<P>(xr, xi, xm, lane, wl_c, wl_s);
+            wave_fft_front<P, +1>(xr, xi, tw, xbuf, lane);
+            // Prefetch the next frame's features behind the second FFT pass + overlap-add.  Placed HERE (not
+            // right after the conversion): earlier, 99 old + 99 new feature registers + the 64 spectrum
+            // registers exceed 256 VGPRs and the compiler spills freshly loaded values with a vmcnt(0) each.
+#ifndef MPX_SYN_EARLY_PREFETCH
+            __builtin_amdgcn_sched_barrier(0);
+            if (fi + 1 < cd.frame_end) {
+                const long long f = fi + 1;
+                feat_load<P>(ff, mag + f * H, real + f * H, imag + f * H, lane);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#endif
             fft_inreg<P, +1>(xr, xi);
 
             // strip coordinate of this frame's first sample; the ring holds strip elements [flushed, flushed + R)
@@ -310,6 +321,154 @@ __global__ __launch_bounds__(kSynWaves * 64) void k_synth_ola(const float* __res
         // ring window (aliases of already-flushed slots) read 0 and the ring is clean for the next chunk
         flush_ring<R>(ring, strip, flushed, strip_len, strip_len, lane_id);
         wave_sync();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_synth_ola_pair: same work as k_synth_ola, but TWO wavefronts share one chunk and one LDS ring: they take
+// alternate frames, rebuild them concurrently, and enter the overlap-add strictly in frame order (a ticket word
+// in LDS; LDS serves one CU's waves in order, so "ticket seen" implies the partner's ring writes are done).
+// Why: the ring (16.5 KB) limits k_synth_ola to 5 waves per CU = 1.25 per SIMD, and a lone wave cannot hide its own
+// LDS / memory latencies (measured 53 % issue-active).  Sharing the ring gives 8 waves per CU in the same LDS.
+// Summation order is unchanged (ascending frames), so results are bit-identical to k_synth_ola.
+// ---------------------------------------------------------------------------------------------
+constexpr int kPairWaves = 8;                    // 4 pairs per workgroup
+constexpr int kPairs = kPairWaves / 2;
+template <int P>
+constexpr size_t lds_bytes_pair() {
+    return sizeof(float) * (size_t)(P * 64 * 2 + kPairWaves * (P * kXStride) + kPairs * ring_len<P>() + 16);
+}
+
+template <int P>
+__global__ __launch_bounds__(kPairWaves * 64) void k_synth_ola_pair(const float* __restrict__ mag,
+                                                                    const float* __restrict__ real,
+                                                                    const float* __restrict__ imag,
+                                                                    const ChunkDesc* __restrict__ chunks,
+                                                                    const int* __restrict__ slot_off,
+                                                                    const int* __restrict__ slot_chunks, int nslots,
+                                                                    const int* __restrict__ pm_rel, int T,
+                                                                    const float2* __restrict__ tw_g,
+                                                                    float* __restrict__ strips) {
+    constexpr int M = 64 * P, N = 2 * M, H = M + 1, LB = ilog2(P), R = ring_len<P>();
+    extern __shared__ float smem[];
+    float2* tw = reinterpret_cast<float2*>(smem);
+    const int lane_id = threadIdx.x & 63;
+    const int wave = rfl(threadIdx.x >> 6);
+    const int pair = wave >> 1, half = wave & 1;
+    float* xbuf = smem + P * 64 * 2 + wave * (P * kXStride);
+    float* ring = smem + P * 64 * 2 + kPairWaves * (P * kXStride) + pair * R;
+    int* turn = reinterpret_cast<int*>(smem + P * 64 * 2 + kPairWaves * (P * kXStride) + kPairs * R) + pair;
+    for (int i = threadIdx.x; i < P * 64; i += kPairWaves * 64) tw[i] = tw_g[i];
+    for (int i = threadIdx.x; i < kPairs * R; i += kPairWaves * 64)
+        smem[P * 64 * 2 + kPairWaves * (P * kXStride) + i] = 0.0f;
+    if (threadIdx.x < kPairs) turn[threadIdx.x - pair] = 0;   // thread t < kPairs has pair == 0
+    __syncthreads();
+
+    float wl_s0, wl_c0;
+    sincospif(2.0f * (float)lane_id / (float)N, &wl_s0, &wl_c0);
+    const int strip_len = T + N;
+    const int slot = blockIdx.x * kPairs + pair;
+    if (slot >= nslots) return;
+
+    // Cursor over this wave's frames: every second frame of every chunk of the pair's work list, as ONE stream, so
+    // that the feature prefetch runs across chunk boundaries (no per-chunk start-up bubble).
+    struct Cursor {   // plain ints only: a bool member made the struct copies go through scratch (VMEM -> vmcnt waits)
+        int wi, fi, ci, ticket_base, fb, fe, x0, valid;
+    };
+    const int wi_end = slot_off[slot + 1];
+    auto settle = [&](Cursor& c) {   // move to the first chunk (from c.wi on) that has a frame for this wave
+        while (c.wi < wi_end) {
+            c.ci = slot_chunks[c.wi];
+            const ChunkDesc cd = chunks[c.ci];
+            c.fb = cd.frame_begin;
+            c.fe = cd.frame_end;
+            c.x0 = cd.x0;
+            c.fi = c.fb + half;
+            if (c.fi < c.fe) {
+                c.valid = 1;
+                return;
+            }
+            c.ticket_base += c.fe - c.fb;
+            ++c.wi;
+        }
+        c.valid = 0;
+    };
+    auto advance = [&](Cursor& c) {
+        c.fi += 2;
+        if (c.fi >= c.fe) {
+            c.ticket_base += c.fe - c.fb;
+            ++c.wi;
+            settle(c);
+        }
+    };
+    Cursor cur;
+    cur.wi = slot_off[slot];
+    cur.ticket_base = 0;
+    settle(cur);
+    if (!cur.valid) return;
+
+    FrameFeat<P> ff;
+    {
+        const long long f = cur.fi;
+        feat_load<P>(ff, mag + f * H, real + f * H, imag + f * H, lane_id);
+    }
+    while (cur.valid) {
+        int lane = lane_id;  // laundered per frame (see k_analysis)
+        float wl_s = wl_s0, wl_c = wl_c0;
+        asm volatile("" : "+v"(lane), "+v"(wl_s), "+v"(wl_c));
+        Cursor nxt = cur;
+        advance(nxt);
+
+        float xr[P], xi[P], xm;
+        feat_convert<P>(ff, xr, xi, xm, lane);
+        hermitian_merge<P>(xr, xi, xm, lane, wl_c, wl_s);
+        wave_fft_front<P, +1>(xr, xi, tw, xbuf, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        if (nxt.valid) {   // this wave's next frame (possibly in the next chunk)
+            const long long f = nxt.fi;
+            feat_load<P>(ff, mag + f * H, real + f * H, imag + f * H, lane);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        fft_inreg<P, +1>(xr, xi);
+
+        // ---- ordered section: wait for this frame's ticket
+        const int fi = cur.fi;
+        float* strip = strips + (long long)cur.ci * strip_len;
+        const int ticket = cur.ticket_base + (fi - cur.fb);
+        while (__hip_atomic_load(turn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != ticket)
+            __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");
+        const int x = pm_rel[fi] - cur.x0;   // in [0, T)
+        const int target = x & ~63;
+        const int flushed = (fi == cur.fb) ? 0 : ((pm_rel[fi - 1] - cur.x0) & ~63);
+        if (flushed < target) flush_ring<R>(ring, strip, flushed, target, strip_len, lane);
+        wave_sync();
+        {
+            constexpr int RH = R / 2;
+            const int kap = kappa<P>(lane);
+            const int odd = x & 1;
+            float* r0 = ring + (odd ? RH : 0);
+            float* r1 = ring + (odd ? 0 : RH);
+            const int c0 = ((x >> 1) % RH) + kap;
+            const int c1 = (((x + 1) >> 1) % RH) + kap;
+#pragma unroll
+            for (int i = 0; i < P; ++i) {
+                int s0 = c0 + 64 * brev(i, LB);
+                s0 = (s0 >= RH) ? s0 - RH : s0;
+                int s1 = c1 + 64 * brev(i, LB);
+                s1 = (s1 >= RH) ? s1 - RH : s1;
+                r0[s0] += xr[i];
+                r1[s1] += xi[i];
+            }
+        }
+        wave_sync();
+        if (fi == cur.fe - 1) {   // last frame of the chunk: stream out the rest, leave the ring cleared
+            flush_ring<R>(ring, strip, target, strip_len, strip_len, lane);
+            wave_sync();
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __hip_atomic_store(turn, ticket + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        cur = nxt;
     }
 }
 
@@ -479,7 +638,11 @@ int mpx_synth_ola_slots(void) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
     }
+#ifdef MPX_SYN_NO_PAIR
     return cus * kSynWaves;
+#else
+    return cus * kPairs;
+#endif
 }
 
 int mpx_synthesis_lossless_ola(void* stream, int fft_len, const void* tables, const float* mag, const float* real,
@@ -494,8 +657,26 @@ int mpx_synthesis_lossless_ola(void* stream, int fft_len, const void* tables, co
     if (n_chunks == 0 || n_slots == 0) return MPX_OK;
     if (!tables || !mag || !real || !imag || !chunks || !slot_off || !slot_chunks || !pm_rel || !strips)
         return fail(MPX_ERR_ARG, "mpx_synthesis_lossless_ola: null pointer%s");
-    const dim3 grid((n_slots + kSynWaves - 1) / kSynWaves), block(kSynWaves * 64);
     hipStream_t s = (hipStream_t)stream;
+#ifndef MPX_SYN_NO_PAIR
+    {
+        const dim3 grid((n_slots + kPairs - 1) / kPairs), block(kPairWaves * 64);
+        if (P == 32) {
+            if (int rc = set_lds(k_synth_ola_pair<32>, lds_bytes_pair<32>())) return rc;
+            hipLaunchKernelGGL(k_synth_ola_pair<32>, grid, block, lds_bytes_pair<32>(), s, mag, real, imag,
+                               (const ChunkDesc*)chunks, slot_off, slot_chunks, (int)n_slots, pm_rel, (int)territory,
+                               (const float2*)tables, strips);
+        } else {
+            if (int rc = set_lds(k_synth_ola_pair<16>, lds_bytes_pair<16>())) return rc;
+            hipLaunchKernelGGL(k_synth_ola_pair<16>, grid, block, lds_bytes_pair<16>(), s, mag, real, imag,
+                               (const ChunkDesc*)chunks, slot_off, slot_chunks, (int)n_slots, pm_rel, (int)territory,
+                               (const float2*)tables, strips);
+        }
+        MPX_HIP_CHECK(hipGetLastError());
+        return MPX_OK;
+    }
+#endif
+    const dim3 grid((n_slots + kSynWaves - 1) / kSynWaves), block(kSynWaves * 64);
     if (P == 32) {
         if (int rc = set_lds(k_synth_ola<32>, lds_bytes_ola<32>())) return rc;
         hipLaunchKernelGGL(k_synth_ola<32>, grid, block, lds_bytes_ola<32>(), s, mag, real, imag,

@@ -46,6 +46,7 @@ def main():
     aplan = LosslessAnalysisPlan(first, utts)
     terr = int(os.environ.get("MAGPHASE_OLA_TERRITORY", aplan.fft_len))
     splan = LosslessSynthesisPlan(first, aplan.v_f0, aplan.fs, aplan.fft_len, territory=terr)
+    splans = {n: LosslessSynthesisPlan(engines[n], aplan.v_f0, aplan.fs, aplan.fft_len, territory=terr) for n, _ in specs}
     N, H, F = aplan.fft_len, aplan.fft_len // 2 + 1, aplan.total_frames
     feats = tuple(first.empty((F, H)) for _ in range(3))
     strips = first.empty((splan.strip_floats,))
@@ -58,7 +59,7 @@ def main():
             ev[0].record()
             e.analysis_frames(N, aplan.sig, aplan.pos, aplan.left, aplan.right, out=feats)
             ev[1].record()
-            e.synthesis_lossless_ola(N, feats[0], feats[1], feats[2], splan, strips)
+            e.synthesis_lossless_ola(N, feats[0], feats[1], feats[2], splans[name], strips)
             ev[2].record()
             e.ola_fixup(N, splan.territory, strips, splan.utt_chunk_off, splan.strip_id, splan.out_start,
                         splan.out_off, splan.max_out_len, splan.total_out, out=pcm)
