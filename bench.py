@@ -8,7 +8,7 @@ bench.py -- MagPhase hot-path benchmark on MI355X (contract: see the task statem
 
 Workload (BASELINE.json configs[1], per GPU): 64 synthetic 48 kHz 5 s utterances, lossless analysis +
 synthesis, FFT=4096, variable (pitch-synchronous) frame rate.  A step = one pass of the hot path over the
-batch: k_analysis -> k_synth_ola -> k_ola_fixup, with PCM and frame descriptors already resident in HBM.
+batch: k_analysis -> k_synth_ola_pair -> k_ola_fixup, with PCM and frame descriptors already resident in HBM.
 Utterances shard across ranks with no data-path collective (weak scaling: every rank owns 64 utterances).
 Metric: frames/s (whole job) = frames processed by all ranks / max-over-ranks wall time of the K steps.
 """
@@ -151,7 +151,7 @@ def main():
         total_frames = float(F)
 
     # ---- per-kernel durations with HIP events on the launch stream (separate, untimed-for-value loop)
-    names = ("k_analysis", "k_synth_ola", "k_ola_fixup")
+    names = ("k_analysis", "k_synth_ola_pair", "k_ola_fixup")
     acc = [0.0, 0.0, 0.0]
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
     reps = max(5, min(args.steps, 20))
@@ -174,8 +174,17 @@ def main():
     kern = [{"name": names[k], "ms": round(ms[k], 4), "alg_bytes": alg[k],
              "alg_GBps": round(alg[k] / (ms[k] * 1e-3) / 1e9, 1)} for k in range(3)]
     dom = int(np.argmax(ms))
+    # HBM traffic per launch of the dominant kernel from the committed rocprofv3 PMC passes of this same command
+    # (profiles/traffic.json, written by tools/pmc_summary.py --traffic; FETCH_SIZE doubled as MI355X_MICROARCH.md
+    # prescribes for gfx950); null when no such measurement is committed for the kernel.
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
+            traffic = json.load(fh).get(names[dom], {}).get("hbm_bytes_per_launch")
+    except Exception:
+        traffic = None
     roof = {"bound": "hbm", "kernel": names[dom], "achieved": kern[dom]["alg_GBps"], "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": round(kern[dom]["alg_GBps"] / HBM_PEAK_GBS, 4), "traffic": None,
+            "unit": "GB/s", "frac": round(kern[dom]["alg_GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic,
             "kernels": kern,
             "path_alg_GBps": round(sum(alg) / (sum(ms) * 1e-3) / 1e9, 1)}
 
