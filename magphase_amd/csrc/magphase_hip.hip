@@ -482,23 +482,34 @@ __global__ __launch_bounds__(256) void k_ola_fixup(const float* __restrict__ str
     const int u = blockIdx.y;
     const long long o0 = out_off[u];
     const long long len = out_off[u + 1] - o0;
-    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= len) return;
     const int c0 = utt_chunk_off[u], nc = utt_chunk_off[u + 1] - c0;
-    const long long b = t + out_start[u];
-    const int c = (int)(b / T);
+    const int start = out_start[u];
     const int strip_len = T + N;
-    float acc = 0.0f;
+    // 4 independent samples per thread (coalesced per step): 12 loads in flight instead of 3 -- the kernel is
+    // latency-bound, not bandwidth-bound (123 MB read + 61 MB written)
+    float acc[4];
 #pragma unroll
-    for (int d = -1; d <= 1; ++d) {
-        const int cc = c + d;
-        if (cc < 0 || cc >= nc) continue;
-        const int sid = strip_id[c0 + cc];
-        if (sid < 0) continue;
-        const long long idx = b - ((long long)cc * T - N / 2);
-        if (idx >= 0 && idx < strip_len) acc += strips[(long long)sid * strip_len + idx];
+    for (int s4 = 0; s4 < 4; ++s4) {
+        const long long t = (long long)blockIdx.x * 1024 + s4 * 256 + threadIdx.x;
+        acc[s4] = 0.0f;
+        if (t >= len) continue;
+        const long long b = t + start;
+        const int c = (int)(b / T);
+#pragma unroll
+        for (int d = -1; d <= 1; ++d) {
+            const int cc = c + d;
+            if (cc < 0 || cc >= nc) continue;
+            const int sid = strip_id[c0 + cc];
+            if (sid < 0) continue;
+            const long long idx = b - ((long long)cc * T - N / 2);
+            if (idx >= 0 && idx < strip_len) acc[s4] += strips[(long long)sid * strip_len + idx];
+        }
     }
-    pcm[o0 + t] = acc;
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+        const long long t = (long long)blockIdx.x * 1024 + s4 * 256 + threadIdx.x;
+        if (t < len) pcm[o0 + t] = acc[s4];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -703,7 +714,7 @@ int mpx_ola_fixup(void* stream, int fft_len, int32_t territory, const float* str
     if (!strips || !utt_chunk_off || !strip_id || !out_start || !out_off || !pcm_out)
         return fail(MPX_ERR_ARG, "mpx_ola_fixup: null pointer%s");
     if (n_utts > 65535) return fail(MPX_ERR_ARG, "mpx_ola_fixup: at most 65535 utterances per call%s");
-    const dim3 block(256), grid((unsigned)((max_out_len + 255) / 256), (unsigned)n_utts);
+    const dim3 block(256), grid((unsigned)((max_out_len + 1023) / 1024), (unsigned)n_utts);
     hipLaunchKernelGGL(k_ola_fixup, grid, block, 0, (hipStream_t)stream, strips, fft_len, (int)territory,
                        utt_chunk_off, strip_id, out_start, (const long long*)out_off, pcm_out);
     MPX_HIP_CHECK(hipGetLastError());

@@ -26,7 +26,11 @@ def build_variant(name, flags):
     out_dir = os.path.join(ROOT, "gpurun_out", "ab")
     os.makedirs(out_dir, exist_ok=True)
     lib = os.path.join(out_dir, "libmagphase_hip_%s.so" % name)
-    cmd = [build.hipcc_path()] + build.FLAGS + flags + build.SRCS + ["-o", lib]
+    srcs = build.SRCS
+    if "PREV" in flags:   # build the snapshot of the previous kernel sources kept (untracked) under tools/_ab_prev
+        flags = [f for f in flags if f != "PREV"]
+        srcs = [s.replace(ROOT, os.path.join(ROOT, "tools", "_ab_prev")) for s in build.SRCS]
+    cmd = [build.hipcc_path()] + build.FLAGS + flags + srcs + ["-o", lib]
     subprocess.check_call(cmd)
     return lib
 
