@@ -97,15 +97,22 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # BENCH_DIST_BACKEND=gloo + BENCH_SHARE_DEVICE=1: test hook to exercise the N > 1 code path on a 1-GPU box
+    backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
+    dev_index = 0 if os.environ.get("BENCH_SHARE_DEVICE") else local_rank
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(dev_index)
+        if backend == "nccl":   # "nccl" is RCCL on ROCm; only the barrier and two scalar reductions use it
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend=backend)
     else:
         dist = None
         torch.cuda.set_device(0)
+    red_dev = "cuda" if backend == "nccl" else "cpu"
 
     from magphase_amd.engine import LosslessAnalysisPlan, LosslessSynthesisPlan, get_engine
 
@@ -141,10 +148,10 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        fr = torch.tensor([float(F)], dtype=torch.float64, device="cuda")
+        fr = torch.tensor([float(F)], dtype=torch.float64, device=red_dev)
         dist.all_reduce(fr, op=dist.ReduceOp.SUM)
         total_frames = float(fr.item())
     else:
