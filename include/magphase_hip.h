@@ -139,6 +139,7 @@ int mpx_noise_stats(void* stream, int fft_len, const void* tables, const float* 
  *   win_left, win_right : anti-ringing window half lengths (Q14);  pm_rel : as mpx_ola_gather
  * per_v, ap_v, ap_u : float32[H] per-bin constants (hostmath.synthesis_bin_curves: tilt x sqrt(mask) etc., Q12/Q13)
  */
+int mpx_synth_comp_slots(void); /* wave slots of mpx_synthesis_compressed_ola on the current device */
 int mpx_synthesis_compressed_ola(void* stream, int fft_len, const void* tables, const float* mag, const float* real,
                                  const float* imag, const float* noise, const int64_t* noise_pos,
                                  const int32_t* noise_left, const int32_t* noise_right, const int32_t* noise_wtype,

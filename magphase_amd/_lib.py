@@ -23,6 +23,7 @@ SYMBOLS = (
     "mpx_ola_fixup",
     "mpx_mel_unwarp",
     "mpx_noise_stats",
+    "mpx_synth_comp_slots",
     "mpx_synthesis_compressed_ola",
     "mpx_mel_warp",
 )
@@ -70,6 +71,8 @@ def load():
     lib.mpx_mel_unwarp.argtypes = [vp, i64, i32, vp, i32, vp, vp, vp, vp, i32, vp, vp, vp]
     lib.mpx_noise_stats.restype = ctypes.c_int
     lib.mpx_noise_stats.argtypes = [vp, ctypes.c_int, vp, vp, vp, vp, vp, vp, i64, vp]
+    lib.mpx_synth_comp_slots.restype = ctypes.c_int
+    lib.mpx_synth_comp_slots.argtypes = []
     lib.mpx_synthesis_compressed_ola.restype = ctypes.c_int
     lib.mpx_synthesis_compressed_ola.argtypes = [vp, ctypes.c_int, vp] + [vp] * 19 + [vp, i32, vp, vp, i32, i32, vp]
     lib.mpx_mel_warp.restype = ctypes.c_int

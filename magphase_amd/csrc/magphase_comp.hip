@@ -277,8 +277,16 @@ struct CompFrameTabs {
     const int* pm_rel;
 };
 
+// 4 waves per workgroup = one per SIMD: the kernel keeps the noise spectrum, the features and the FFT working set live
+// at once (> 256 VGPRs); with 512 registers per wave nothing spills to scratch (scratch = VMEM = vmcnt stalls).
+constexpr int kCompWaves = 4;
 template <int P>
-__global__ __launch_bounds__(kSynWaves * 64) void k_synth_comp_ola(const float* __restrict__ mag,
+constexpr size_t lds_bytes_comp() {
+    return sizeof(float) * (size_t)(P * 64 * 2 + kCompWaves * (P * kXStride + ring_len<P>()));
+}
+
+template <int P>
+__global__ __launch_bounds__(kCompWaves * 64) void k_synth_comp_ola(const float* __restrict__ mag,
                                                                    const float* __restrict__ real,
                                                                    const float* __restrict__ imag,
                                                                    const float* __restrict__ noise,
@@ -299,7 +307,7 @@ __global__ __launch_bounds__(kSynWaves * 64) void k_synth_comp_ola(const float* 
     float* xbuf = smem + P * 64 * 2 + wave * (P * kXStride + R);
     float* ring = xbuf + P * kXStride;
     const unsigned xbuf_byte = 4u * (unsigned)(P * 64 * 2 + rfl(wave) * (P * kXStride + R));
-    for (int i = threadIdx.x; i < P * 64; i += kSynWaves * 64) tw[i] = tw_g[i];
+    for (int i = threadIdx.x; i < P * 64; i += kCompWaves * 64) tw[i] = tw_g[i];
     __syncthreads();
 
     float wa_s0, wa_c0, ws_s0, ws_c0;   // analysis-side lane twiddle W_N^kappa and synthesis-side conj(W_N^lane)
@@ -310,7 +318,7 @@ __global__ __launch_bounds__(kSynWaves * 64) void k_synth_comp_ola(const float* 
     for (int i = lane_id; i < R; i += 64) ring[i] = 0.0f;
     wave_sync();
 
-    const int slot = blockIdx.x * kSynWaves + wave_u;
+    const int slot = blockIdx.x * kCompWaves + wave_u;
     if (slot >= nslots) return;
     for (int wi = slot_off[slot]; wi < slot_off[slot + 1]; ++wi) {
         const int ci = slot_chunks[wi];
@@ -497,6 +505,8 @@ int mpx_noise_stats(void* stream, int fft_len, const void* tables, const float* 
     return MPX_OK;
 }
 
+int mpx_synth_comp_slots(void) { return device_cus() * kCompWaves; }
+
 int mpx_synthesis_compressed_ola(void* stream, int fft_len, const void* tables, const float* mag, const float* real,
                                  const float* imag, const float* noise, const int64_t* noise_pos,
                                  const int32_t* noise_left, const int32_t* noise_right, const int32_t* noise_wtype,
@@ -518,16 +528,16 @@ int mpx_synthesis_compressed_ola(void* stream, int fft_len, const void* tables, 
         return fail(MPX_ERR_ARG, "mpx_synthesis_compressed_ola: null pointer%s");
     CompFrameTabs tb{(const long long*)noise_pos, noise_left, noise_right, noise_wtype, voiced, inv_gain,
                      row0, row1, row_t, win_left, win_right, pm_rel};
-    const dim3 grid((n_slots + kSynWaves - 1) / kSynWaves), block(kSynWaves * 64);
+    const dim3 grid((n_slots + kCompWaves - 1) / kCompWaves), block(kCompWaves * 64);
     hipStream_t s = (hipStream_t)stream;
     if (P == 32) {
-        if (int rc = set_lds(k_synth_comp_ola<32>, lds_bytes_ola<32>())) return rc;
-        hipLaunchKernelGGL(k_synth_comp_ola<32>, grid, block, lds_bytes_ola<32>(), s, mag, real, imag, noise, tb,
+        if (int rc = set_lds(k_synth_comp_ola<32>, lds_bytes_comp<32>())) return rc;
+        hipLaunchKernelGGL(k_synth_comp_ola<32>, grid, block, lds_bytes_comp<32>(), s, mag, real, imag, noise, tb,
                            per_v, ap_v, ap_u, (const ChunkDesc*)chunks, slot_off, slot_chunks, (int)n_slots,
                            (int)territory, (const float2*)tables, strips);
     } else {
-        if (int rc = set_lds(k_synth_comp_ola<16>, lds_bytes_ola<16>())) return rc;
-        hipLaunchKernelGGL(k_synth_comp_ola<16>, grid, block, lds_bytes_ola<16>(), s, mag, real, imag, noise, tb,
+        if (int rc = set_lds(k_synth_comp_ola<16>, lds_bytes_comp<16>())) return rc;
+        hipLaunchKernelGGL(k_synth_comp_ola<16>, grid, block, lds_bytes_comp<16>(), s, mag, real, imag, noise, tb,
                            per_v, ap_v, ap_u, (const ChunkDesc*)chunks, slot_off, slot_chunks, (int)n_slots,
                            (int)territory, (const float2*)tables, strips);
     }

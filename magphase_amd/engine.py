@@ -108,6 +108,11 @@ class Engine:
         with torch.cuda.device(self.device):
             return int(self.lib.mpx_synth_ola_slots())
 
+    def synth_comp_slots(self):
+        torch = _torch()
+        with torch.cuda.device(self.device):
+            return int(self.lib.mpx_synth_comp_slots())
+
     def synthesis_lossless_ola(self, fft_len, mag, real, imag, plan, strips):
         """plan: LosslessSynthesisPlan (chunk + slot tables resident on this device)."""
         torch = _torch()
@@ -385,7 +390,7 @@ class CompressedSynthesisPlan:
         self.utt_chunk_off = e.to_device(terr_off, np.int32)
         self.strip_id = e.to_device(owner_all, np.int32)
         self.strip_floats = self.n_chunks * (self.territory + N)
-        n_slots = e.synth_ola_slots() if hasattr(e, "synth_ola_slots") else 1280
+        n_slots = e.synth_comp_slots() if hasattr(e, "synth_comp_slots") else 1024
         slot_off, slot_chunks = hm.balance_chunks(rows[:, 1] - rows[:, 0], n_slots)
         self.n_slots = int(slot_off.size - 1)
         self.slot_off = e.to_device(slot_off, np.int32)
@@ -468,3 +473,87 @@ def _const_to_variable_scan(v_shift_c_rate, frm_rate_ms, fs):
             break
         pos = pos - shifts[i]
     return shifts, locs
+
+
+
+# ======================================================================================================
+# compressed-feature analysis (magphase.py:2947-2988, 2490-2544)
+# ======================================================================================================
+class CompressedAnalysisPlan:
+    """
+    Lossless analysis plan + host tables for the mel warp of a batch (one sample rate).  run() = k_analysis ->
+    k_mel_warp, everything resident on the device; host fp64 does f0 / lf0 / constant-rate tables only.
+    """
+
+    def __init__(self, engine, utts, fft_len=None, mag_dim=60, phase_dim=10, b_const_rate=False, alpha_phase=None):
+        self.engine = e = engine
+        self.lossless = plan = LosslessAnalysisPlan(engine, utts, fft_len=fft_len)
+        fs = self.fs = plan.fs[0]
+        if any(f != fs for f in plan.fs):
+            raise ValueError("one sample rate per batch")
+        N = self.fft_len = plan.fft_len
+        H = N // 2 + 1
+        self.mag_dim, self.phase_dim, self.b_const_rate = int(mag_dim), int(phase_dim), bool(b_const_rate)
+        alpha = hm.define_alpha(fs)
+        a_ph = alpha if alpha_phase is None else alpha_phase
+        cf, _ = hm.define_crossfade_params(fs)
+        k_full = hm.get_num_full_mel_coeffs_from_num_phase_coeffs(cf, phase_dim, a_ph, fs)
+        self.w_mag = e.to_device(hm.warp_matrix(mag_dim, H, alpha), np.float32)
+        self.w_ph = e.to_device(hm.warp_matrix(k_full, H, a_ph, nrows=phase_dim), np.float32)
+        row0, row1, rowt, self.f0_out = [], [], [], []
+        for u in range(len(utts)):
+            v_f0 = plan.v_f0[u]
+            base = int(plan.frame_off[u])
+            if b_const_rate:
+                v_pm = np.cumsum(plan.v_shift[u])
+                lo, hi, t = hm.var_to_const_rate_table(v_pm, 5.0, fs)
+                v_f0 = _const_rate_f0_voi(v_f0, v_pm, fs)
+            else:
+                lo = hi = np.arange(plan.n_frames[u])
+                t = np.zeros(plan.n_frames[u])
+            row0.append(lo + base), row1.append(hi + base), rowt.append(t), self.f0_out.append(v_f0)
+        self.out_off = np.concatenate(([0], np.cumsum([len(f) for f in self.f0_out]))).astype(np.int64)
+        self.total_out_frames = int(self.out_off[-1])
+        self.voi = e.to_device(np.concatenate([(f > 0).astype(np.float64) for f in self.f0_out]), np.float32)
+        if b_const_rate:
+            self.row0 = e.to_device(np.concatenate(row0), np.int32)
+            self.row1 = e.to_device(np.concatenate(row1), np.int32)
+            self.rowt = e.to_device(np.concatenate(rowt), np.float32)
+        else:
+            self.row0 = self.row1 = self.rowt = None
+
+    def run(self, feats=None, out=None):
+        e, torch = self.engine, _torch()
+        H = self.fft_len // 2 + 1
+        mag, real, imag = self.lossless.run(out=feats)
+        if out is None:
+            out = (e.empty((self.total_out_frames, self.mag_dim)), e.empty((self.total_out_frames, self.phase_dim)),
+                   e.empty((self.total_out_frames, self.phase_dim)))
+        ptr = (lambda t: t.data_ptr() if t is not None else None)
+        with torch.cuda.device(e.device):
+            _lib.check(e.lib.mpx_mel_warp(e.stream_ptr(), self.total_out_frames, H, mag.data_ptr(), real.data_ptr(),
+                                          imag.data_ptr(), ptr(self.row0), ptr(self.row1), ptr(self.rowt),
+                                          self.w_mag.data_ptr(), self.mag_dim, self.w_ph.data_ptr(), self.phase_dim,
+                                          self.voi.data_ptr(), out[0].data_ptr(), out[1].data_ptr(),
+                                          out[2].data_ptr()), "mpx_mel_warp")
+        return out
+
+
+def _const_rate_f0_voi(v_f0, v_pm_smpls, fs, const_rate_ms=5.0):
+    """magphase.py:2975-2980: f0 interpolated through the voiced points only, voicing by interpolation > 0.5."""
+    from scipy import interpolate
+
+    step = fs * const_rate_ms / 1000
+
+    def interp1(y, x):
+        centres = np.arange(step, x[-1], step)
+        if x[0] > 0:
+            f = interpolate.interp1d(np.r_[0, x], np.r_[y[0], y], axis=0, kind='linear')
+        else:
+            f = interpolate.interp1d(x, y, axis=0, kind='linear')
+        return f(centres)
+
+    v_voi = v_f0 > 1.0
+    v_f0_c = interp1(np.r_[v_f0[v_voi][0], v_f0[v_voi], v_f0[v_voi][-1]], np.r_[0, v_pm_smpls[v_voi], v_pm_smpls[-1]])
+    v_voi_c = interp1(v_voi.astype(np.float64), v_pm_smpls) > 0.5
+    return v_f0_c * v_voi_c

@@ -18,7 +18,8 @@ import numpy as np
 from . import hostmath as hm
 from . import libaudio as la
 from . import libutils as lu
-from .engine import CompressedSynthesisPlan, LosslessAnalysisPlan, LosslessSynthesisPlan, get_engine
+from .engine import (CompressedAnalysisPlan, CompressedSynthesisPlan, LosslessAnalysisPlan, LosslessSynthesisPlan,
+                     get_engine)
 
 _epoch_provider = None
 
@@ -237,26 +238,6 @@ def synthesis_from_acoustic_modelling(in_feats_dir, filename_token, out_syn_dir,
 # ======================================================================================================
 # compressed-feature analysis
 # ======================================================================================================
-def _const_rate_f0_voi(v_f0, v_pm_smpls, fs, const_rate_ms=5.0):
-    """magphase.py:2975-2980: f0 interpolated through the voiced points only, voicing by interpolation > 0.5."""
-    from scipy import interpolate
-
-    step = fs * const_rate_ms / 1000
-
-    def interp1(y, x):
-        centres = np.arange(step, x[-1], step)
-        if x[0] > 0:
-            f = interpolate.interp1d(np.r_[0, x], np.r_[y[0], y], axis=0, kind='linear')
-        else:
-            f = interpolate.interp1d(x, y, axis=0, kind='linear')
-        return f(centres)
-
-    v_voi = v_f0 > 1.0
-    v_f0_c = interp1(np.r_[v_f0[v_voi][0], v_f0[v_voi], v_f0[v_voi][-1]], np.r_[0, v_pm_smpls[v_voi], v_pm_smpls[-1]])
-    v_voi_c = interp1(v_voi.astype(np.float64), v_pm_smpls) > 0.5
-    return v_f0_c * v_voi_c
-
-
 def analysis_compressed_batch(utts, fft_len=None, mag_dim=60, phase_dim=10, b_const_rate=False, alpha_phase=None,
                               engine=None):
     """
@@ -267,63 +248,20 @@ def analysis_compressed_batch(utts, fft_len=None, mag_dim=60, phase_dim=10, b_co
     from scipy import signal
 
     engine = engine or get_engine()
-    torch = __import__("torch")
-    plan = LosslessAnalysisPlan(engine, utts, fft_len=fft_len)
-    for lens in plan.long_frame_lens:
+    plan = CompressedAnalysisPlan(engine, utts, fft_len=fft_len, mag_dim=mag_dim, phase_dim=phase_dim,
+                                  b_const_rate=b_const_rate, alpha_phase=alpha_phase)
+    for lens in plan.lossless.long_frame_lens:
         for n in lens:
             warnings.warn(_WARN_LONG % (plan.fft_len, n))
-    fs = plan.fs[0]
-    if any(f != fs for f in plan.fs):
-        raise ValueError("one sample rate per batch")
-    N, H = plan.fft_len, plan.fft_len // 2 + 1
-    alpha = hm.define_alpha(fs)
-    a_ph = alpha if alpha_phase is None else alpha_phase
-    cf, _ = hm.define_crossfade_params(fs)
-    k_full = hm.get_num_full_mel_coeffs_from_num_phase_coeffs(cf, phase_dim, a_ph, fs)
-    w_mag = engine.to_device(hm.warp_matrix(mag_dim, H, alpha), np.float32)
-    w_ph = engine.to_device(hm.warp_matrix(k_full, H, a_ph, nrows=phase_dim), np.float32)
-    mag, real, imag = plan.run()
-
-    # host fp64: f0 track, (optional) constant-rate tables, lf0 (magphase.py:2497-2501, 2967-2980)
-    row0, row1, rowt, f0_out = [], [], [], []
-    for u in range(len(utts)):
-        v_f0 = plan.v_f0[u]
-        base = int(plan.frame_off[u])
-        if b_const_rate:
-            v_pm = np.cumsum(plan.v_shift[u])
-            lo, hi, t = hm.var_to_const_rate_table(v_pm, 5.0, fs)
-            v_f0 = _const_rate_f0_voi(v_f0, v_pm, fs)
-        else:
-            lo = hi = np.arange(plan.n_frames[u])
-            t = np.zeros(plan.n_frames[u])
-        row0.append(lo + base), row1.append(hi + base), rowt.append(t), f0_out.append(v_f0)
-    n_out = [len(f) for f in f0_out]
-    out_off = np.concatenate(([0], np.cumsum(n_out))).astype(np.int64)
-    f_tot = int(out_off[-1])
-    voi_all = np.concatenate([(f > 0).astype(np.float64) for f in f0_out])
-    d_voi = engine.to_device(voi_all, np.float32)
-    o_mag, o_real, o_imag = engine.empty((f_tot, mag_dim)), engine.empty((f_tot, phase_dim)), engine.empty((f_tot, phase_dim))
-    if b_const_rate:
-        d_r0 = engine.to_device(np.concatenate(row0), np.int32)
-        d_r1 = engine.to_device(np.concatenate(row1), np.int32)
-        d_rt = engine.to_device(np.concatenate(rowt), np.float32)
-        r0p, r1p, rtp = d_r0.data_ptr(), d_r1.data_ptr(), d_rt.data_ptr()
-    else:
-        r0p = r1p = rtp = None
-    from . import _lib
-    with torch.cuda.device(engine.device):
-        _lib.check(engine.lib.mpx_mel_warp(engine.stream_ptr(), f_tot, H, mag.data_ptr(), real.data_ptr(),
-                                           imag.data_ptr(), r0p, r1p, rtp, w_mag.data_ptr(), mag_dim,
-                                           w_ph.data_ptr(), phase_dim, d_voi.data_ptr(), o_mag.data_ptr(),
-                                           o_real.data_ptr(), o_imag.data_ptr()), "mpx_mel_warp")
-    h_mag, h_real, h_imag = (t_.cpu().numpy().astype(np.float64) for t_ in (o_mag, o_real, o_imag))
+    h_mag, h_real, h_imag = (t_.cpu().numpy().astype(np.float64) for t_ in plan.run())
     res = []
     for u in range(len(utts)):
-        a, b = int(out_off[u]), int(out_off[u + 1])
-        v_f0 = f0_out[u]
+        a, b = int(plan.out_off[u]), int(plan.out_off[u + 1])
+        v_f0 = plan.f0_out[u]
         v_voi = (v_f0 > 0).astype('float')
         v_lf0 = la.f0_to_lf0(v_voi * signal.medfilt(v_f0))                 # magphase.py:2499-2501
-        res.append((h_mag[a:b], h_real[a:b], h_imag[a:b], v_lf0, plan.v_shift[u].astype(int), fs, N))
+        res.append((h_mag[a:b], h_real[a:b], h_imag[a:b], v_lf0, plan.lossless.v_shift[u].astype(int), plan.fs,
+                    plan.fft_len))
     return res
 
 
