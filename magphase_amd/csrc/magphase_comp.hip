@@ -99,28 +99,39 @@ __global__ __launch_bounds__(256) void k_mel_warp(WarpJobs jobs, long long F, in
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = 0.0f;
 
+    // per-frame row table of this block (row0 == row1 == f, t == 0 without interpolation), staged once
+    __shared__ int s_r0[kWarpTile], s_r1[kWarpTile];
+    __shared__ float s_rt[kWarpTile];
+    if (threadIdx.x < kWarpTile) {
+        const long long f = min(f0 + (long long)threadIdx.x, F - 1);
+        s_r0[threadIdx.x] = row0 ? row0[f] : (int)f;
+        s_r1[threadIdx.x] = row0 ? row1[f] : (int)f;
+        s_rt[threadIdx.x] = row0 ? rowt[f] : 0.0f;
+    }
+    __syncthreads();
+
     for (int k0 = 0; k0 < H; k0 += kWarpTile) {
         const int k = k0 + kk;
+        const int kc = min(k, H - 1);   // clamped: every load below is unconditional (branch-free) so that the 32
+        const bool kok = k < H;         // loads of a chunk are in flight together instead of one vmcnt(0) wait each
+        float xv[16], xw[16], wv16[16];
 #pragma unroll
         for (int p = 0; p < 16; ++p) {
             const int fl = fq + 4 * p;
-            const long long f = f0 + fl;
-            float v = 0.0f;
-            if (f < F && k < H) {
-                float x;
-                if (row0) {
-                    const int r0 = row0[f], r1 = row1[f];
-                    const float x0 = job.x[(long long)r0 * H + k];
-                    x = (r0 != r1) ? fmaf(job.x[(long long)r1 * H + k] - x0, rowt[f], x0) : x0;
-                } else {
-                    x = job.x[f * H + k];
-                }
-                const float e = (job.mode == 0) ? x : expf(x);
-                v = logf(fmaf(e, e, 1.0e-8f));
-            }
-            As[kk][fl] = v;
-            const int i = fl;   // same index range 0..63 used for the W tile rows
-            Ws[kk][i] = (i < job.nout && k < H) ? job.W[(long long)i * H + k] : 0.0f;
+            xv[p] = job.x[(long long)s_r0[fl] * H + kc];
+            xw[p] = job.x[(long long)s_r1[fl] * H + kc];
+            wv16[p] = job.W[(long long)min(fl, job.nout - 1) * H + kc];
+        }
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+            const int fl = fq + 4 * p;
+            const float x = fmaf(xw[p] - xv[p], s_rt[fl], xv[p]);
+            // hardware exp2/log2 (v_exp_f32 / v_log_f32, ~1 ulp): the 1e-7 error is far below the stated tolerance
+            // of this (ill-conditioned, unpinned) stage
+            const float e = (job.mode == 0) ? x : __expf(x);
+            const float v = __logf(fmaf(e, e, 1.0e-8f));
+            As[kk][fl] = (kok && f0 + fl < F) ? v : 0.0f;
+            Ws[kk][fl] = (kok && fl < job.nout) ? wv16[p] : 0.0f;
         }
         __syncthreads();
 #pragma unroll 8
@@ -330,6 +341,30 @@ __global__ __launch_bounds__(kCompWaves * 64) void k_synth_comp_ola(const float*
             float wa_s = wa_s0, wa_c = wa_c0, ws_s = ws_s0, ws_c = ws_c0;
             asm volatile("" : "+v"(lane), "+v"(wa_s), "+v"(wa_c), "+v"(ws_s), "+v"(ws_c));
 
+            // ---- this frame's features and per-bin curves: ALL loads issued up front, branch-free, so that they share
+            // one memory latency and overlap the noise FFT ("load, then use in the same branch" made the compiler
+            // wait vmcnt(0) once per bin: 32+ serial round trips per frame, measured 70 us per frame).
+            const int voiced = tb.voiced[fi];
+            const float ig = tb.inv_gain[fi];
+            const int r0 = tb.row0[fi], r1 = tb.row1[fi];
+            const float rt = tb.rowt[fi];           // 0 when r0 == r1: the lerp below is then exact
+            FrameFeat<P> f0v, f1v;
+            feat_load<P>(f0v, mag + (long long)r0 * H, real + (long long)r0 * H, imag + (long long)r0 * H, lane);
+            feat_load<P>(f1v, mag + (long long)r1 * H, real + (long long)r1 * H, imag + (long long)r1 * H, lane);
+            const float* apc = voiced ? ap_v : ap_u;   // aperiodic curve of the frame's class (uniform select)
+            const float pvs = voiced ? 1.0f : 0.0f;     // periodic component only in voiced frames
+            float cpv[P], cap[P];
+#pragma unroll
+            for (int j = 0; j < P; ++j) {
+                cpv[j] = per_v[lane + 64 * j];
+                cap[j] = apc[lane + 64 * j];
+            }
+            float cpvM = 0.0f, capM = 0.0f;
+            if (lane == 0) {
+                cpvM = per_v[M];
+                capM = apc[M];
+            }
+
             // ---- aperiodic source: spectrum of this frame's windowed noise
             const FrameGeom g = frame_geom(noise, tb.npos[fi], tb.nleft[fi], tb.nright[fi], N);
             float xr[P], xi[P], nM;
@@ -345,38 +380,17 @@ __global__ __launch_bounds__(kCompWaves * 64) void k_synth_comp_ola(const float*
             }
 
             // ---- spectrum assembly (Appendix A2 steps 9-12), bins k = lane + 64 j
-            const int voiced = tb.voiced[fi];
-            const float ig = tb.inv_gain[fi];
-            const int r0 = tb.row0[fi], r1 = tb.row1[fi];
-            const float rt = tb.rowt[fi];
-            const float* m0p = mag + (long long)r0 * H;
-            const float* a0p = real + (long long)r0 * H;
-            const float* b0p = imag + (long long)r0 * H;
-            const float* m1p = mag + (long long)r1 * H;
-            const float* a1p = real + (long long)r1 * H;
-            const float* b1p = imag + (long long)r1 * H;
-            const bool interp = (r0 != r1);
             const float sgn_scale = ((lane & 1) ? -1.0f : 1.0f) * (0.5f / (float)M);
 #pragma unroll
             for (int j = 0; j < P; ++j) {
-                const int k = lane + 64 * j;
-                float m = m0p[k], a = a0p[k], b = b0p[k];
-                if (interp) {   // linear interpolation between constant-rate rows (magphase.py:2242-2252)
-                    m = fmaf(m1p[k] - m, rt, m);
-                    a = fmaf(a1p[k] - a, rt, a);
-                    b = fmaf(b1p[k] - b, rt, b);
-                }
-                float pr_ = 0.0f, pi_ = 0.0f, apf;
-                if (voiced) {
-                    const float s = a * a + b * b;
-                    const float u = (s > 0.0f) ? m * per_v[k] * __builtin_amdgcn_rsqf(s) : 0.0f;
-                    pr_ = a * u;
-                    pi_ = b * u;
-                    apf = m * ap_v[k] * ig;
-                } else {
-                    apf = m * ap_u[k] * ig;
-                }
-                float vr = fmaf(xr[j], apf, pr_), vi = fmaf(xi[j], apf, pi_);
+                // linear interpolation between constant-rate rows (magphase.py:2242-2252); rt == 0 for variable-rate input
+                const float m = fmaf(f1v.m[j] - f0v.m[j], rt, f0v.m[j]);
+                const float a = fmaf(f1v.a[j] - f0v.a[j], rt, f0v.a[j]);
+                const float b = fmaf(f1v.b[j] - f0v.b[j], rt, f0v.b[j]);
+                const float s = a * a + b * b;
+                const float u = (s > 0.0f) ? m * cpv[j] * pvs * __builtin_amdgcn_rsqf(s) : 0.0f;
+                const float apf = m * cap[j] * ig;
+                float vr = fmaf(xr[j], apf, a * u), vi = fmaf(xi[j], apf, b * u);
                 if (j == 0 && lane == 0) {   // DC: X = |X| (magphase.py:958-961)
                     vr = __builtin_sqrtf(vr * vr + vi * vi);
                     vi = 0.0f;
@@ -385,24 +399,14 @@ __global__ __launch_bounds__(kCompWaves * 64) void k_synth_comp_ola(const float*
                 xi[j] = vi * sgn_scale;
             }
             float xm = 0.0f;
-            if (lane == 0) {   // Nyquist bin: noise spectrum is real there; X = |X|
-                float m = m0p[M], a = a0p[M], b = b0p[M];
-                if (interp) {
-                    m = fmaf(m1p[M] - m, rt, m);
-                    a = fmaf(a1p[M] - a, rt, a);
-                    b = fmaf(b1p[M] - b, rt, b);
-                }
-                float pr_ = 0.0f, pi_ = 0.0f, apf;
-                if (voiced) {
-                    const float s = a * a + b * b;
-                    const float u = (s > 0.0f) ? m * per_v[M] * __builtin_amdgcn_rsqf(s) : 0.0f;
-                    pr_ = a * u;
-                    pi_ = b * u;
-                    apf = m * ap_v[M] * ig;
-                } else {
-                    apf = m * ap_u[M] * ig;
-                }
-                const float vr = fmaf(nM, apf, pr_), vi = pi_;
+            if (lane == 0) {   // Nyquist bin: the noise spectrum is real there; X = |X|
+                const float m = fmaf(f1v.mM - f0v.mM, rt, f0v.mM);
+                const float a = fmaf(f1v.aM - f0v.aM, rt, f0v.aM);
+                const float b = fmaf(f1v.bM - f0v.bM, rt, f0v.bM);
+                const float s = a * a + b * b;
+                const float u = (s > 0.0f) ? m * cpvM * pvs * __builtin_amdgcn_rsqf(s) : 0.0f;
+                const float apf = m * capM * ig;
+                const float vr = fmaf(nM, apf, a * u), vi = b * u;
                 xm = __builtin_sqrtf(vr * vr + vi * vi) * (0.5f / (float)M);   // (-1)^M = +1
             }
 
