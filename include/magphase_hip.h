@@ -169,6 +169,17 @@ int mpx_mel_warp(void* stream, int64_t n_frames, int32_t n_bins, const float* ma
                  const float* w_phase, int32_t phase_dim, const float* voiced, float* out_mag, float* out_real,
                  float* out_imag);
 
+/*
+ * Minimum-phase spectrum of a magnitude spectrum by the complex cepstrum (la.build_min_phase_from_mag_spec,
+ * libaudio.py:920-934; synthesis_from_compressed(per_phase_type='min_phase'), magphase.py:937-938).
+ * For output frame f: m = (1-row_t)*mag[row0] + row_t*mag[row1] ([rows x H]); out_mag[f] = m and
+ * (out_real, out_imag)[f] = (cos phi, sin phi), phi = Im FFT(causal fold(IFFT(ln m))) -- the unit phasor the
+ * synthesis kernel expects in place of the unwarped phase features ([n_frames x H] each).
+ */
+int mpx_min_phase(void* stream, int fft_len, const void* tables, const float* mag, const int32_t* row0,
+                  const int32_t* row1, const float* row_t, int64_t n_frames, float* out_mag, float* out_real,
+                  float* out_imag);
+
 #ifdef __cplusplus
 }
 #endif

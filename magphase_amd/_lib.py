@@ -26,6 +26,7 @@ SYMBOLS = (
     "mpx_synth_comp_slots",
     "mpx_synthesis_compressed_ola",
     "mpx_mel_warp",
+    "mpx_min_phase",
 )
 
 _lib = None
@@ -77,6 +78,8 @@ def load():
     lib.mpx_synthesis_compressed_ola.argtypes = [vp, ctypes.c_int, vp] + [vp] * 19 + [vp, i32, vp, vp, i32, i32, vp]
     lib.mpx_mel_warp.restype = ctypes.c_int
     lib.mpx_mel_warp.argtypes = [vp, i64, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, vp, vp, vp, vp]
+    lib.mpx_min_phase.restype = ctypes.c_int
+    lib.mpx_min_phase.argtypes = [vp, ctypes.c_int, vp, vp, vp, vp, vp, i64, vp, vp, vp]
     _lib = lib
     return lib
 

@@ -271,6 +271,122 @@ __global__ __launch_bounds__(kThreads) void k_noise_stats(const float* __restric
 }
 
 // ---------------------------------------------------------------------------------------------
+// minimum-phase spectrum from a magnitude spectrum (complex cepstrum), la.build_min_phase_from_mag_spec
+// (libaudio.py:920-934): ln|X| -> even extension -> real IFFT (cepstrum c) -> causal fold (c[1..N/2-1] *= 2,
+// c[N/2+1..] = 0) -> FFT -> exp.  Since Re FFT(fold c) == ln|X|, only the phase phi = Im FFT(fold c) is new: the
+// kernel writes the unit phasor (cos phi, sin phi) where the synthesis kernel expects the (real, imag) phase
+// features, and the (row-interpolated) magnitude it was computed from.  One wavefront per frame, two FFTs.
+// ---------------------------------------------------------------------------------------------
+template <int P>
+__global__ __launch_bounds__(kThreads) void k_min_phase(const float* __restrict__ mag, const int* __restrict__ row0,
+                                                        const int* __restrict__ row1,
+                                                        const float* __restrict__ rowt, long long nframes,
+                                                        const float2* __restrict__ tw_g, float* __restrict__ omag,
+                                                        float* __restrict__ oreal, float* __restrict__ oimag) {
+    constexpr int M = 64 * P, N = 2 * M, H = M + 1, LB = ilog2(P);
+    extern __shared__ float smem[];
+    float2* tw = reinterpret_cast<float2*>(smem);
+    const int lane_id = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    float* xbuf = smem + P * 64 * 2 + wave * (P * kXStride);
+    for (int i = threadIdx.x; i < P * 64; i += kThreads) tw[i] = tw_g[i];
+    __syncthreads();
+    float wa_s0, wa_c0, ws_s0, ws_c0;
+    sincospif(-2.0f * (float)kappa<P>(lane_id) / (float)N, &wa_s0, &wa_c0);
+    sincospif(2.0f * (float)lane_id / (float)N, &ws_s0, &ws_c0);
+    const int wave_u = rfl(wave);
+    for (long long f = (long long)blockIdx.x * kWavesPerBlock + wave_u; f < nframes;
+         f += (long long)gridDim.x * kWavesPerBlock) {
+        int lane = lane_id;
+        float wa_s = wa_s0, wa_c = wa_c0, ws_s = ws_s0, ws_c = ws_c0;
+        asm volatile("" : "+v"(lane), "+v"(wa_s), "+v"(wa_c), "+v"(ws_s), "+v"(ws_c));
+        const int r0 = row0[f], r1 = row1[f];
+        const float rt = rowt[f];
+        const float* m0p = mag + (long long)r0 * H;
+        const float* m1p = mag + (long long)r1 * H;
+        // ---- ln|X| (protected log, libaudio.py:241-248) on bins lane + 64 j, scaled for the inverse transform
+        float xr[P], xi[P], mv[P];
+        const float scale = 0.5f / (float)M;
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+            const float a = m0p[lane + 64 * j], b = m1p[lane + 64 * j];
+            mv[j] = fmaf(b - a, rt, a);
+        }
+        float mM = 0.0f;
+        if (lane == 0) {
+            const float a = m0p[M], b = m1p[M];
+            mM = fmaf(b - a, rt, a);
+        }
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+            xr[j] = ((mv[j] > 0.0f) ? logf(mv[j]) : -1.0e10f) * scale;
+            xi[j] = 0.0f;
+        }
+        const float xm = ((mM > 0.0f) ? logf(mM) : -1.0e10f) * scale;
+        hermitian_merge<P>(xr, xi, xm, lane, ws_c, ws_s);
+        wave_fft<P, +1>(xr, xi, tw, xbuf, lane);
+        // ---- cepstrum samples n = 2m, 2m+1 with m = kappa + 64 brev(i): causal fold
+        const int kap = kappa<P>(lane);
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            const int n0 = 2 * (kap + 64 * brev(i, LB));
+            const float w0 = (n0 == 0) ? 1.0f : ((n0 < M) ? 2.0f : ((n0 == M) ? 1.0f : 0.0f));
+            const float w1 = (n0 + 1 < M) ? 2.0f : ((n0 + 1 == M) ? 1.0f : 0.0f);
+            xr[i] *= w0;
+            xi[i] *= w1;
+        }
+        // ---- forward real FFT of the folded cepstrum: input register j must hold z[lane + 64 j]
+        float re[P], im[P];
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            re[brev(i, LB)] = xr[i];
+            im[brev(i, LB)] = xi[i];
+        }
+        if (P == 16) {
+            const int src = kappa<P>(lane);
+#pragma unroll
+            for (int j = 0; j < P; ++j) {
+                re[j] = __shfl(re[j], src);
+                im[j] = __shfl(im[j], src);
+            }
+        }
+        wave_fft<P, -1>(re, im, tw, xbuf, lane);
+        const int src_lane = kappa<P>((64 - kap) & 63);
+        const bool lane0 = (kap == 0);
+        float* mo = omag + f * H;
+        float* ro = oreal + f * H;
+        float* io = oimag + f * H;
+        // the magnitude row is stored from the lanes that loaded it (bins lane + 64 j)
+#pragma unroll
+        for (int j = 0; j < P; ++j) mo[lane + 64 * j] = mv[j];
+        if (lane == 0) mo[M] = mM;
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            const int q = brev(i, LB);
+            const int i0 = brev((P - q) % P, LB);
+            float pr = __shfl(re[P - 1 - i], src_lane);
+            float pi = __shfl(im[P - 1 - i], src_lane);
+            pr = lane0 ? re[i0] : pr;
+            pi = lane0 ? im[i0] : pi;
+            const float ei = 0.5f * (im[i] - pi);
+            const float orr = 0.5f * (im[i] + pi), oi = -0.5f * (re[i] - pr);
+            const float cq = cos2p<P>(q), sq = -sin2p<P>(q);
+            const float wr = wa_c * cq - wa_s * sq, wi = wa_c * sq + wa_s * cq;
+            const float phi = ei + (wr * oi + wi * orr);   // Im S[k]
+            float sn, cs;
+            sincosf(phi, &sn, &cs);
+            const int k = kap + 64 * q;
+            ro[k] = cs;
+            io[k] = sn;
+        }
+        if (lane0) {   // Nyquist bin of a real sequence: phase 0
+            ro[M] = 1.0f;
+            io[M] = 0.0f;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // compressed synthesis + PSOLA
 // ---------------------------------------------------------------------------------------------
 struct CompFrameTabs {
@@ -569,6 +685,30 @@ int mpx_mel_warp(void* stream, int64_t n_frames, int32_t n_bins, const float* ma
     if (grid.y > 65535) return fail(MPX_ERR_ARG, "mpx_mel_warp: too many frames per call (max 4194240)%s");
     hipLaunchKernelGGL(k_mel_warp, grid, dim3(256), 0, (hipStream_t)stream, jobs, (long long)n_frames, (int)n_bins,
                        row0, row1, row_t);
+    MPX_HIP_CHECK(hipGetLastError());
+    return MPX_OK;
+}
+
+int mpx_min_phase(void* stream, int fft_len, const void* tables, const float* mag, const int32_t* row0,
+                  const int32_t* row1, const float* row_t, int64_t n_frames, float* out_mag, float* out_real,
+                  float* out_imag) {
+    const int P = p_of(fft_len);
+    if (!P) return fail(MPX_ERR_ARG, "mpx_min_phase: fft_len must be 2048 or 4096%s");
+    if (n_frames < 0) return fail(MPX_ERR_ARG, "mpx_min_phase: negative n_frames%s");
+    if (n_frames == 0) return MPX_OK;
+    if (!tables || !mag || !row0 || !row1 || !row_t || !out_mag || !out_real || !out_imag)
+        return fail(MPX_ERR_ARG, "mpx_min_phase: null pointer%s");
+    const dim3 grid(grid_for(n_frames)), block(kThreads);
+    hipStream_t s = (hipStream_t)stream;
+    if (P == 32) {
+        if (int rc = set_lds(k_min_phase<32>, lds_bytes<32>())) return rc;
+        hipLaunchKernelGGL(k_min_phase<32>, grid, block, lds_bytes<32>(), s, mag, row0, row1, row_t,
+                           (long long)n_frames, (const float2*)tables, out_mag, out_real, out_imag);
+    } else {
+        if (int rc = set_lds(k_min_phase<16>, lds_bytes<16>())) return rc;
+        hipLaunchKernelGGL(k_min_phase<16>, grid, block, lds_bytes<16>(), s, mag, row0, row1, row_t,
+                           (long long)n_frames, (const float2*)tables, out_mag, out_real, out_imag);
+    }
     MPX_HIP_CHECK(hipGetLastError());
     return MPX_OK;
 }

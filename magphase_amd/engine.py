@@ -285,8 +285,12 @@ class CompressedSynthesisPlan:
     """
 
     def __init__(self, engine, utts, fs, fft_len=None, b_voi_ap_win=True, b_const_rate=False, alpha_phase=None,
-                 noise=None, territory=None):
+                 noise=None, territory=None, per_phase_type="magphase"):
         from scipy import interpolate
+
+        if per_phase_type not in ("magphase", "min_phase", "linear"):
+            raise ValueError("per_phase_type must be 'magphase', 'min_phase' or 'linear'")
+        self.per_phase_type = per_phase_type
 
         self.engine = e = engine
         self.fs = fs
@@ -435,11 +439,29 @@ class CompressedSynthesisPlan:
                                            self.total_frames, sums.data_ptr()), "mpx_noise_stats")
             inv = self.noise_gains(sums.cpu().numpy())   # two scalars per utterance: float64 on the host
             inv_gain = e.to_device(inv, np.float32)
+            row0, row1, rowt = self.row0, self.row1, self.rowt
+            if self.per_phase_type != "magphase":
+                # periodic component's phase is not the transmitted one (magphase.py:933-938):
+                #   'min_phase': complex-cepstrum minimum phase of the (row-interpolated) magnitude, per frame
+                #   'linear'   : zero phase
+                F = self.total_frames
+                ident = torch.arange(F, dtype=torch.int32, device=e.device)
+                zeros_t = torch.zeros(F, dtype=torch.float32, device=e.device)
+                mag_v, real_v, imag_v = (e.empty((F, H)) for _ in range(3))
+                if self.per_phase_type == "min_phase":
+                    _lib.check(lib.mpx_min_phase(st, N, tab.data_ptr(), mag.data_ptr(), row0.data_ptr(),
+                                                 row1.data_ptr(), rowt.data_ptr(), F, mag_v.data_ptr(),
+                                                 real_v.data_ptr(), imag_v.data_ptr()), "mpx_min_phase")
+                    mag, real, imag = mag_v, real_v, imag_v
+                    row0, row1, rowt = ident, ident, zeros_t
+                else:
+                    real = torch.ones_like(real)
+                    imag = torch.zeros_like(imag)
             _lib.check(lib.mpx_synthesis_compressed_ola(
                 st, N, tab.data_ptr(), mag.data_ptr(), real.data_ptr(), imag.data_ptr(), self.noise.data_ptr(),
                 self.npos.data_ptr(), self.nleft.data_ptr(), self.nright.data_ptr(), self.wtype.data_ptr(),
-                self.voiced.data_ptr(), inv_gain.data_ptr(), self.row0.data_ptr(), self.row1.data_ptr(),
-                self.rowt.data_ptr(), self.win_l.data_ptr(), self.win_r.data_ptr(), self.pm_rel.data_ptr(),
+                self.voiced.data_ptr(), inv_gain.data_ptr(), row0.data_ptr(), row1.data_ptr(),
+                rowt.data_ptr(), self.win_l.data_ptr(), self.win_r.data_ptr(), self.pm_rel.data_ptr(),
                 self.per_v.data_ptr(), self.ap_v.data_ptr(), self.ap_u.data_ptr(), self.chunks.data_ptr(),
                 self.n_chunks, self.slot_off.data_ptr(), self.slot_chunks.data_ptr(), self.n_slots, self.territory,
                 strips.data_ptr()), "mpx_synthesis_compressed_ola")

@@ -189,11 +189,12 @@ def _output_hpf(v_syn_sig, fs):
 
 
 def synthesis_from_compressed_batch(utts, fs, fft_len=None, b_voi_ap_win=True, b_const_rate=False, alpha_phase=None,
-                                    b_out_hpf=True, noise=None, engine=None):
+                                    b_out_hpf=True, noise=None, engine=None, per_phase_type='magphase'):
     """Batched synthesis_from_compressed; utts: list of (m_mag_mel_log, m_real_mel, m_imag_mel, v_lf0)."""
     engine = engine or get_engine()
     plan = CompressedSynthesisPlan(engine, utts, fs, fft_len=fft_len, b_voi_ap_win=b_voi_ap_win,
-                                   b_const_rate=b_const_rate, alpha_phase=alpha_phase, noise=noise)
+                                   b_const_rate=b_const_rate, alpha_phase=alpha_phase, noise=noise,
+                                   per_phase_type=per_phase_type)
     pcm = plan.run().cpu().numpy().astype(np.float64)
     out = [pcm[plan.out_off_host[u]:plan.out_off_host[u + 1]] for u in range(len(utts))]
     if b_out_hpf:
@@ -204,14 +205,14 @@ def synthesis_from_compressed_batch(utts, fs, fft_len=None, b_voi_ap_win=True, b
 def synthesis_from_compressed(m_mag_mel_log, m_real_mel, m_imag_mel, v_lf0, fs, fft_len=None, b_voi_ap_win=True,
                               b_fbank_mel=False, b_const_rate=False, per_phase_type='magphase', alpha_phase=None,
                               b_out_hpf=True):
-    """magphase.py:825-997.  The experimental branches (b_fbank_mel, per_phase_type != 'magphase') are not on the path."""
+    """magphase.py:825-997, per_phase_type in {'magphase', 'min_phase', 'linear'}.  b_fbank_mel (experimental
+    filter-bank warping built on helpers outside the live path) is not provided."""
     if b_fbank_mel:
         raise NotImplementedError("b_fbank_mel=True (experimental filter-bank warping) is outside the hot path")
-    if per_phase_type != 'magphase':
-        raise NotImplementedError("per_phase_type=%r: only the default 'magphase' branch runs on the GPU path" % per_phase_type)
     return synthesis_from_compressed_batch([(m_mag_mel_log, m_real_mel, m_imag_mel, v_lf0)], fs, fft_len=fft_len,
                                            b_voi_ap_win=b_voi_ap_win, b_const_rate=b_const_rate,
-                                           alpha_phase=alpha_phase, b_out_hpf=b_out_hpf)[0]
+                                           alpha_phase=alpha_phase, b_out_hpf=b_out_hpf,
+                                           per_phase_type=per_phase_type)[0]
 
 
 def synthesis_from_acoustic_modelling(in_feats_dir, filename_token, out_syn_dir, mag_dim, phase_dim, fs,

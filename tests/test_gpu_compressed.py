@@ -105,10 +105,37 @@ def test_16k_and_batch_match_oracle(mp, orc):
         assert np.max(np.abs(v - ref)) <= COMP_PCM_TOL * np.max(np.abs(ref)), np.max(np.abs(v - ref))
 
 
+def test_min_phase_and_linear_branches(mp, orc, golden_dir):
+    """per_phase_type='min_phase' (complex-cepstrum minimum phase, libaudio.py:920-934) vs the reference's golden;
+    'linear' vs the oracle (the reference's own 'linear' branch raises under numpy 2: complex into a float array)."""
+    g, mm, rr, ii, lf = _hvd704(golden_dir)
+    np.random.seed(int(g["seed"]))
+    v = mp.synthesis_from_compressed(mm, rr, ii, lf, 48000, per_phase_type="min_phase")
+    ref = g["syn_nopf_minphase"]
+    assert len(v) == len(ref)
+    assert np.max(np.abs(v - ref)) <= 5 * COMP_PCM_TOL * np.max(np.abs(ref)), np.max(np.abs(v - ref))
+    np.random.seed(4)
+    v = mp.synthesis_from_compressed(mm, rr, ii, lf, 48000, per_phase_type="linear", b_out_hpf=False)
+    np.random.seed(4)
+    ref = orc.synthesis_from_compressed(mm, rr, ii, lf, 48000, per_phase_type="linear", b_out_hpf=False)
+    assert len(v) == len(ref)
+    assert np.max(np.abs(v - ref)) <= COMP_PCM_TOL * np.max(np.abs(ref))
+    # constant-rate input: the minimum phase is taken of the row-interpolated magnitude (magphase.py:861-865, 937-938)
+    g8 = np.load(os.path.join(golden_dir, "g8_compressed_analysis.npz"))
+    np.random.seed(8)
+    v = mp.synthesis_from_compressed(g8["cr45_mag"], g8["cr45_real"], g8["cr45_imag"], g8["cr45_lf0"], 48000,
+                                     b_const_rate=True, per_phase_type="min_phase", b_out_hpf=False)
+    np.random.seed(8)
+    ref = orc.synthesis_from_compressed(g8["cr45_mag"], g8["cr45_real"], g8["cr45_imag"], g8["cr45_lf0"], 48000,
+                                        b_const_rate=True, per_phase_type="min_phase", b_out_hpf=False)
+    assert len(v) == len(ref)
+    assert np.max(np.abs(v - ref)) <= 5 * COMP_PCM_TOL * np.max(np.abs(ref)), np.max(np.abs(v - ref))
+
+
 def test_unsupported_branches_and_errors(mp, golden_dir):
     g, mm, rr, ii, lf = _hvd704(golden_dir)
     with pytest.raises(NotImplementedError):
-        mp.synthesis_from_compressed(mm, rr, ii, lf, 48000, per_phase_type="min_phase")
+        mp.synthesis_from_compressed(mm, rr, ii, lf, 48000, b_fbank_mel=True)
     with pytest.raises(ValueError):
         mp.synthesis_from_compressed(mm, rr, ii, lf, 44100 + 1)   # define_alpha: unsupported rate
 
