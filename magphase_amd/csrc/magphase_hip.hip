@@ -407,11 +407,6 @@ __global__ __launch_bounds__(kPairWaves * 64) void k_synth_ola_pair(const float*
     settle(cur);
     if (!cur.valid) return;
 
-    FrameFeat<P> ff;
-    {
-        const long long f = cur.fi;
-        feat_load<P>(ff, mag + f * H, real + f * H, imag + f * H, lane_id);
-    }
     while (cur.valid) {
         int lane = lane_id;  // laundered per frame (see k_analysis)
         float wl_s = wl_s0, wl_c = wl_c0;
@@ -419,24 +414,28 @@ __global__ __launch_bounds__(kPairWaves * 64) void k_synth_ola_pair(const float*
         Cursor nxt = cur;
         advance(nxt);
 
+        // Features are loaded right where they are used: no register prefetch.  With two waves per SIMD the partner
+        // wave covers the memory latency (a prefetch behind the FFT measured 4 % SLOWER), and the 99 registers are
+        // worth more as room to keep many LDS operations in flight -- this kernel's stalls are LDS latency
+        // (bpermutes of the merge, the exchange, the ring's read-add-write), not HBM.
+        FrameFeat<P> ff;
+        {
+            const long long f = cur.fi;
+            feat_load<P>(ff, mag + f * H, real + f * H, imag + f * H, lane);
+        }
         float xr[P], xi[P], xm;
         feat_convert<P>(ff, xr, xi, xm, lane);
         hermitian_merge<P>(xr, xi, xm, lane, wl_c, wl_s);
-        wave_fft_front<P, +1>(xr, xi, tw, xbuf, lane);
-        __builtin_amdgcn_sched_barrier(0);
-        if (nxt.valid) {   // this wave's next frame (possibly in the next chunk)
-            const long long f = nxt.fi;
-            feat_load<P>(ff, mag + f * H, real + f * H, imag + f * H, lane);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        fft_inreg<P, +1>(xr, xi);
+        wave_fft<P, +1>(xr, xi, tw, xbuf, lane);
 
         // ---- ordered section: wait for this frame's ticket
         const int fi = cur.fi;
         float* strip = strips + (long long)cur.ci * strip_len;
         const int ticket = cur.ticket_base + (fi - cur.fb);
+#ifndef MPX_PROBE_NOTICKET
         while (__hip_atomic_load(turn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != ticket)
             __builtin_amdgcn_s_sleep(1);
+#endif
         asm volatile("" ::: "memory");
         const int x = pm_rel[fi] - cur.x0;   // in [0, T)
         const int target = x & ~63;

@@ -130,35 +130,30 @@ __device__ __forceinline__ void hermitian_merge(float (&xr)[P], float (&xi)[P], 
                                                 float wl_s) {
     const int src_lane = (64 - lane) & 63;
     const bool lane0 = (lane == 0);
-    float st_r = 0.0f, st_i = 0.0f;
+    // 1) fetch every partner bin first (64 ds_bpermute in flight together: one LDS latency instead of 16);
+    //    partner of bin (lane, j) = bin M-k: lane (64-lane)&63, register P-1-j; on lane 0: own register (P-j)%P, and
+    //    the Nyquist bin for j == 0.
+    float pr[P], pi[P];
 #pragma unroll
-    for (int j = 0; j < P / 2; ++j) {
-        const int jp = P - 1 - j;
-        const float ar = xr[j], ai = xi[j], br = xr[jp], bi = xi[jp];
-        float par = __shfl(br, src_lane), pai = __shfl(bi, src_lane);
-        float pbr = __shfl(ar, src_lane), pbi = __shfl(ai, src_lane);
-        const float l0ar = (j == 0) ? xm : st_r, l0ai = (j == 0) ? 0.0f : st_i;
-        const float l0br = (j + 1 == jp) ? br : xr[j + 1], l0bi = (j + 1 == jp) ? bi : xi[j + 1];
-        par = lane0 ? l0ar : par;
-        pai = lane0 ? l0ai : pai;
-        pbr = lane0 ? l0br : pbr;
-        pbi = lane0 ? l0bi : pbi;
-        st_r = br;
-        st_i = bi;
-        {   // bin j:  E = X + conj(Xp), T = X - conj(Xp), O = conj(W_N^k) T, conj(W_N^k) = e^{+2 pi i (lane/N + j/2P)}
-            const float er = ar + par, ei = ai - pai, tr = ar - par, ti = ai + pai;
-            const float cq = cos2p<P>(j), sq = sin2p<P>(j);
-            const float wr = wl_c * cq - wl_s * sq, wi = wl_c * sq + wl_s * cq;
-            xr[j] = er - (wr * ti + wi * tr);
-            xi[j] = ei + (wr * tr - wi * ti);
-        }
-        {   // bin P-1-j
-            const float er = br + pbr, ei = bi - pbi, tr = br - pbr, ti = bi + pbi;
-            const float cq = cos2p<P>(jp), sq = sin2p<P>(jp);
-            const float wr = wl_c * cq - wl_s * sq, wi = wl_c * sq + wl_s * cq;
-            xr[jp] = er - (wr * ti + wi * tr);
-            xi[jp] = ei + (wr * tr - wi * ti);
-        }
+    for (int j = 0; j < P; ++j) {
+        pr[j] = __shfl(xr[P - 1 - j], src_lane);
+        pi[j] = __shfl(xi[P - 1 - j], src_lane);
+    }
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+        const float l0r = (j == 0) ? xm : xr[(P - j) % P];
+        const float l0i = (j == 0) ? 0.0f : xi[(P - j) % P];
+        pr[j] = lane0 ? l0r : pr[j];
+        pi[j] = lane0 ? l0i : pi[j];
+    }
+    // 2) E = X + conj(Xp), T = X - conj(Xp), O = conj(W_N^k) T, Z = E + i O   (conj(W_N^k) = e^{+2 pi i (lane/N + j/2P)})
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+        const float er = xr[j] + pr[j], ei = xi[j] - pi[j], tr = xr[j] - pr[j], ti = xi[j] + pi[j];
+        const float cq = cos2p<P>(j), sq = sin2p<P>(j);
+        const float wr = wl_c * cq - wl_s * sq, wi = wl_c * sq + wl_s * cq;
+        xr[j] = er - (wr * ti + wi * tr);
+        xi[j] = ei + (wr * tr - wi * ti);
     }
 }
 
