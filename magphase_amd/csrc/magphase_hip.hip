@@ -450,14 +450,24 @@ __global__ __launch_bounds__(kPairWaves * 64) void k_synth_ola_pair(const float*
             float* r1 = ring + (odd ? 0 : RH);
             const int c0 = ((x >> 1) % RH) + kap;
             const int c1 = (((x + 1) >> 1) % RH) + kap;
+            // read all 64 ring values first, then add, then write: one LDS latency instead of 32 dependent chains
+            float o0[P], o1[P];
+            int a0[P], a1[P];
 #pragma unroll
             for (int i = 0; i < P; ++i) {
                 int s0 = c0 + 64 * brev(i, LB);
                 s0 = (s0 >= RH) ? s0 - RH : s0;
                 int s1 = c1 + 64 * brev(i, LB);
                 s1 = (s1 >= RH) ? s1 - RH : s1;
-                r0[s0] += xr[i];
-                r1[s1] += xi[i];
+                a0[i] = s0;
+                a1[i] = s1;
+                o0[i] = r0[s0];
+                o1[i] = r1[s1];
+            }
+#pragma unroll
+            for (int i = 0; i < P; ++i) {
+                r0[a0[i]] = o0[i] + xr[i];
+                r1[a1[i]] = o1[i] + xi[i];
             }
         }
         wave_sync();
