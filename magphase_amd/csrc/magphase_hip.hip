@@ -68,8 +68,16 @@ __global__ __launch_bounds__(kThreads) void k_analysis(const float* __restrict__
                 staged_wait<0>();
             }
             const int hi = min(g.len, tile0 + kTile);
-            for (int k = tile0 + lane; k < hi; k += 64)
-                xbuf[k - tile0] *= hann_half(k, g.L, g.LR, g.kadd, g.invL, g.invR);
+            for (int kb = tile0 + lane; kb < hi; kb += 256) {   // 4 rows per step: 4 LDS reads in flight, not 1
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = (kb + 64 * r < hi) ? xbuf[kb + 64 * r - tile0] : 0.0f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int k = kb + 64 * r;
+                    if (k < hi) xbuf[k - tile0] = v[r] * hann_half(k, g.L, g.LR, g.kadd, g.invL, g.invR);
+                }
+            }
             wave_sync();
 #pragma unroll
             for (int j = 0; j < P; ++j) {
@@ -113,14 +121,18 @@ __global__ __launch_bounds__(kThreads) void k_analysis(const float* __restrict__
         float* mhi = omag + f * H + (M - kap);    // X[M-k] : descending lanes, -64 q
         float* rhi = oreal + f * H + (M - kap);
         float* ihi = oimag + f * H + (M - kap);
+        float zpr[P / 2], zpi[P / 2];   // all partner bins first: P lane exchanges in flight together
+#pragma unroll
+        for (int i = 0; i < P; i += 2) {
+            zpr[i / 2] = __shfl(re[P - 1 - i], src_lane);
+            zpi[i / 2] = __shfl(im[P - 1 - i], src_lane);
+        }
 #pragma unroll
         for (int i = 0; i < P; i += 2) {
             const int q = brev(i, LB);            // q < P/2
             const int i0 = brev((P - q) % P, LB);
-            float pr = __shfl(re[P - 1 - i], src_lane);
-            float pi = __shfl(im[P - 1 - i], src_lane);
-            pr = lane0 ? re[i0] : pr;
-            pi = lane0 ? im[i0] : pi;
+            const float pr = lane0 ? re[i0] : zpr[i / 2];
+            const float pi = lane0 ? im[i0] : zpi[i / 2];
             const float er = 0.5f * (re[i] + pr), ei = 0.5f * (im[i] - pi);
             const float orr = 0.5f * (im[i] + pi), oi = -0.5f * (re[i] - pr);
             const float cq = cos2p<P>(q), sq = -sin2p<P>(q);   // W_N^k = W_N^kappa * e^{-2 pi i q/(2P)}

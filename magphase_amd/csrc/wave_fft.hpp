@@ -132,12 +132,16 @@ __device__ __forceinline__ void lds_transpose(float (&x)[P], float* xbuf, int la
 template <int P, int SIGN, int PARTNER, int TWN>
 __device__ __forceinline__ void cross_lane_stage(float (&re)[P], float (&im)[P], bool upper, bool rot) {
     const float sg = upper ? -1.0f : 1.0f;
+    float orr[P], oii[P];   // all 2P lane exchanges in flight together, then the butterflies
 #pragma unroll
     for (int lp = 0; lp < P; ++lp) {
-        const float orr = __shfl_xor(re[lp], PARTNER);
-        const float oii = __shfl_xor(im[lp], PARTNER);
-        re[lp] = fmaf(re[lp], sg, orr);
-        im[lp] = fmaf(im[lp], sg, oii);
+        orr[lp] = __shfl_xor(re[lp], PARTNER);
+        oii[lp] = __shfl_xor(im[lp], PARTNER);
+    }
+#pragma unroll
+    for (int lp = 0; lp < P; ++lp) {
+        re[lp] = fmaf(re[lp], sg, orr[lp]);
+        im[lp] = fmaf(im[lp], sg, oii[lp]);
     }
     if (upper) {
 #pragma unroll
