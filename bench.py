@@ -174,7 +174,7 @@ def main():
         eng.synthesis_lossless_ola(N, feats[0], feats[1], feats[2], splan, strips)
         ev[2].record()
         eng.ola_fixup(N, splan.territory, strips, splan.utt_chunk_off, splan.strip_id, splan.out_start,
-                      splan.out_off, splan.max_out_len, splan.total_out, out=pcm_out)
+                      splan.out_off, splan.max_territories, splan.total_out, out=pcm_out)
         ev[3].record()
         torch.cuda.synchronize()
         for k in range(3):

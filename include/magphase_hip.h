@@ -101,7 +101,8 @@ int mpx_synthesis_lossless_ola(void* stream, int fft_len, const void* tables, co
                                int32_t territory, float* strips);
 int mpx_ola_fixup(void* stream, int fft_len, int32_t territory, const float* strips, int32_t n_utts,
                   const int32_t* utt_chunk_off, const int32_t* strip_id, const int32_t* out_start,
-                  const int64_t* out_off, int64_t max_out_len, float* pcm_out);
+                  const int64_t* out_off, int32_t max_territories /* max over utterances of their territory count */,
+                  float* pcm_out);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Compressed-feature synthesis (magphase.py:825-997 synthesis_from_compressed, b_fbank_mel=False, per_phase_type='magphase')

@@ -67,7 +67,7 @@ def load():
     lib.mpx_synth_ola_slots.argtypes = []
     lib.mpx_synthesis_lossless_ola.argtypes = [vp, ctypes.c_int, vp, vp, vp, vp, vp, i32, vp, vp, i32, vp, i32, vp]
     lib.mpx_ola_fixup.restype = ctypes.c_int
-    lib.mpx_ola_fixup.argtypes = [vp, ctypes.c_int, i32, vp, i32, vp, vp, vp, vp, i64, vp]
+    lib.mpx_ola_fixup.argtypes = [vp, ctypes.c_int, i32, vp, i32, vp, vp, vp, vp, i32, vp]
     lib.mpx_mel_unwarp.restype = ctypes.c_int
     lib.mpx_mel_unwarp.argtypes = [vp, i64, i32, vp, i32, vp, vp, vp, vp, i32, vp, vp, vp]
     lib.mpx_noise_stats.restype = ctypes.c_int

@@ -500,36 +500,32 @@ __global__ __launch_bounds__(256) void k_ola_fixup(const float* __restrict__ str
                                                    const int* __restrict__ out_start,
                                                    const long long* __restrict__ out_off,
                                                    float* __restrict__ pcm) {
+    // One block per (utterance, territory): the three strip ids are block-uniform, every load is independent.
     const int u = blockIdx.y;
+    const int c = blockIdx.x;
+    const int c0 = utt_chunk_off[u], nc = utt_chunk_off[u + 1] - c0;
     const long long o0 = out_off[u];
     const long long len = out_off[u + 1] - o0;
-    const int c0 = utt_chunk_off[u], nc = utt_chunk_off[u + 1] - c0;
-    const int start = out_start[u];
+    const long long start = out_start[u];
+    if ((long long)c * T >= start + len) return;   // no output sample in this territory
     const int strip_len = T + N;
-    // 4 independent samples per thread (coalesced per step): 12 loads in flight instead of 3 -- the kernel is
-    // latency-bound, not bandwidth-bound (123 MB read + 61 MB written)
-    float acc[4];
-#pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) {
-        const long long t = (long long)blockIdx.x * 1024 + s4 * 256 + threadIdx.x;
-        acc[s4] = 0.0f;
-        if (t >= len) continue;
-        const long long b = t + start;
-        const int c = (int)(b / T);
-#pragma unroll
-        for (int d = -1; d <= 1; ++d) {
-            const int cc = c + d;
-            if (cc < 0 || cc >= nc) continue;
-            const int sid = strip_id[c0 + cc];
-            if (sid < 0) continue;
-            const long long idx = b - ((long long)cc * T - N / 2);
-            if (idx >= 0 && idx < strip_len) acc[s4] += strips[(long long)sid * strip_len + idx];
-        }
-    }
-#pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) {
-        const long long t = (long long)blockIdx.x * 1024 + s4 * 256 + threadIdx.x;
-        if (t < len) pcm[o0 + t] = acc[s4];
+    // territories at or beyond nc hold no frame: their output samples (the reference's zero tail) are written as 0
+    const int sid_p = (c > 0 && c - 1 < nc) ? strip_id[c0 + c - 1] : -1;
+    const int sid_o = (c < nc) ? strip_id[c0 + c] : -1;
+    const int sid_n = (c + 1 < nc) ? strip_id[c0 + c + 1] : -1;
+    const float* sp = strips + (long long)max(sid_p, 0) * strip_len;
+    const float* so = strips + (long long)max(sid_o, 0) * strip_len;
+    const float* sn = strips + (long long)max(sid_n, 0) * strip_len;
+    // territory sample r = b - c*T in [0, T): strip indices  prev: r + T + N/2 (valid r < N/2),  own: r + N/2,
+    // next: r - T + N/2 (valid r >= T - N/2); summed in the order prev, own, next (fixed -> deterministic)
+    for (int r = threadIdx.x; r < T; r += 256) {
+        const long long t = (long long)c * T + r - start;   // output index of buffer position b = c*T + r
+        if (t < 0 || t >= len) continue;
+        float acc = 0.0f;
+        if (sid_p >= 0 && r < N / 2) acc += sp[r + T + N / 2];
+        if (sid_o >= 0) acc += so[r + N / 2];
+        if (sid_n >= 0 && r >= T - N / 2) acc += sn[r - T + N / 2];
+        pcm[o0 + t] = acc;
     }
 }
 
@@ -726,16 +722,16 @@ int mpx_synthesis_lossless_ola(void* stream, int fft_len, const void* tables, co
 
 int mpx_ola_fixup(void* stream, int fft_len, int32_t territory, const float* strips, int32_t n_utts,
                   const int32_t* utt_chunk_off, const int32_t* strip_id, const int32_t* out_start,
-                  const int64_t* out_off, int64_t max_out_len, float* pcm_out) {
+                  const int64_t* out_off, int32_t max_territories, float* pcm_out) {
     if (!p_of(fft_len)) return fail(MPX_ERR_ARG, "mpx_ola_fixup: fft_len must be 2048 or 4096%s");
-    if (n_utts < 0 || max_out_len < 0) return fail(MPX_ERR_ARG, "mpx_ola_fixup: negative size%s");
+    if (n_utts < 0 || max_territories < 0) return fail(MPX_ERR_ARG, "mpx_ola_fixup: negative size%s");
     if (territory < fft_len / 2 || (territory % 64) != 0)
         return fail(MPX_ERR_ARG, "mpx_ola_fixup: territory must be a multiple of 64 and >= fft_len/2%s");
-    if (n_utts == 0 || max_out_len == 0) return MPX_OK;
+    if (n_utts == 0 || max_territories == 0) return MPX_OK;
     if (!strips || !utt_chunk_off || !strip_id || !out_start || !out_off || !pcm_out)
         return fail(MPX_ERR_ARG, "mpx_ola_fixup: null pointer%s");
     if (n_utts > 65535) return fail(MPX_ERR_ARG, "mpx_ola_fixup: at most 65535 utterances per call%s");
-    const dim3 block(256), grid((unsigned)((max_out_len + 1023) / 1024), (unsigned)n_utts);
+    const dim3 block(256), grid((unsigned)max_territories, (unsigned)n_utts);
     hipLaunchKernelGGL(k_ola_fixup, grid, block, 0, (hipStream_t)stream, strips, fft_len, (int)territory,
                        utt_chunk_off, strip_id, out_start, (const long long*)out_off, pcm_out);
     MPX_HIP_CHECK(hipGetLastError());

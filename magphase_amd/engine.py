@@ -127,7 +127,7 @@ class Engine:
                 "mpx_synthesis_lossless_ola")
         return strips
 
-    def ola_fixup(self, fft_len, territory, strips, utt_chunk_off, strip_id, out_start, out_off, max_out_len,
+    def ola_fixup(self, fft_len, territory, strips, utt_chunk_off, strip_id, out_start, out_off, max_territories,
                   total_out, out=None):
         torch = _torch()
         if out is None:
@@ -137,9 +137,17 @@ class Engine:
             _lib.check(
                 self.lib.mpx_ola_fixup(self.stream_ptr(), int(fft_len), int(territory), strips.data_ptr(), n_utts,
                                        utt_chunk_off.data_ptr(), strip_id.data_ptr(), out_start.data_ptr(),
-                                       out_off.data_ptr(), int(max_out_len), out.data_ptr()),
+                                       out_off.data_ptr(), int(max_territories), out.data_ptr()),
                 "mpx_ola_fixup")
         return out
+
+
+def _max_territories(terr_off, starts, out_lens, territory):
+    """grid.x of k_ola_fixup: territories holding frames, or output samples of the zero tail, whichever is more."""
+    terr_off = np.asarray(terr_off)
+    n_frames_terr = np.diff(terr_off) if terr_off.size > 1 else np.zeros(0, dtype=np.int64)
+    n_out_terr = [-(-(int(s_) + int(l_)) // int(territory)) for s_, l_ in zip(starts, out_lens)]
+    return int(max([0] + list(n_frames_terr) + n_out_terr))
 
 
 _ENGINES = {}
@@ -238,6 +246,7 @@ class LosslessSynthesisPlan:
         self.utt_frame_off = e.to_device(np.concatenate(([0], np.cumsum(nfr))), np.int32)
         self.pm_rel = e.to_device(np.concatenate(pm_rel) if pm_rel else np.zeros(0), np.int32)
         self.out_start = e.to_device(np.asarray(starts), np.int32)
+        self._starts_host = [int(x) for x in starts]
         self.out_off = e.to_device(self.out_off_host, np.int64)
         self._build_chunks(pm_rel, nfr)
 
@@ -248,6 +257,7 @@ class LosslessSynthesisPlan:
         self.n_chunks = int(rows.shape[0])
         self.chunks = e.to_device(rows, np.int32)
         self.utt_chunk_off = e.to_device(np.asarray(terr_off), np.int32)
+        self.max_territories = _max_territories(terr_off, self._starts_host, self.out_len, self.territory)
         self.strip_id = e.to_device(owner_all, np.int32)
         self.strip_floats = self.n_chunks * (self.territory + self.fft_len)
         n_slots = e.synth_ola_slots() if hasattr(e, "synth_ola_slots") else 1280
@@ -263,7 +273,7 @@ class LosslessSynthesisPlan:
             strips = e.empty((self.strip_floats,))
         e.synthesis_lossless_ola(self.fft_len, mag, real, imag, self, strips)
         return e.ola_fixup(self.fft_len, self.territory, strips, self.utt_chunk_off, self.strip_id, self.out_start,
-                           self.out_off, self.max_out_len, self.total_out, out=out)
+                           self.out_off, self.max_territories, self.total_out, out=out)
 
     def run_unfused(self, mag, real, imag, frames=None, out=None):
         """Two-kernel form: frames to HBM, then the ascending-order gather (bit-for-bit the reference's sum order)."""
@@ -392,6 +402,7 @@ class CompressedSynthesisPlan:
         self.n_chunks = int(rows.shape[0])
         self.chunks = e.to_device(rows, np.int32)
         self.utt_chunk_off = e.to_device(terr_off, np.int32)
+        self.max_territories = _max_territories(terr_off, starts, self.out_len, self.territory)
         self.strip_id = e.to_device(owner_all, np.int32)
         self.strip_floats = self.n_chunks * (self.territory + N)
         n_slots = e.synth_comp_slots() if hasattr(e, "synth_comp_slots") else 1024
@@ -466,7 +477,7 @@ class CompressedSynthesisPlan:
                 self.n_chunks, self.slot_off.data_ptr(), self.slot_chunks.data_ptr(), self.n_slots, self.territory,
                 strips.data_ptr()), "mpx_synthesis_compressed_ola")
         pcm = e.ola_fixup(N, self.territory, strips, self.utt_chunk_off, self.strip_id, self.out_start, self.out_off,
-                          self.max_out_len, self.total_out, out=out)
+                          self.max_territories, self.total_out, out=out)
         if keep:
             self.debug = dict(mag=mag, real=real, imag=imag, sums=sums)
         return pcm

@@ -66,7 +66,7 @@ def main():
             e.synthesis_lossless_ola(N, feats[0], feats[1], feats[2], splans[name], strips)
             ev[2].record()
             e.ola_fixup(N, splan.territory, strips, splan.utt_chunk_off, splan.strip_id, splan.out_start,
-                        splan.out_off, splan.max_out_len, splan.total_out, out=pcm)
+                        splan.out_off, splan.max_territories, splan.total_out, out=pcm)
             ev[3].record()
             torch.cuda.synchronize()
             if r >= 2:
