@@ -1,34 +1,44 @@
 #!/usr/bin/env python
 """
-Python-3 counterpart of the reference's demos/demo_copy_synthesis_lossless.py (same call sequence, :57-91):
-analysis_lossless -> synthesis_from_lossless -> write_audio_file.  Runs on the MI355X path.
-Input wav needs epochs: a <stem>.est next to it (demos/make_demo_data.py writes synthetic wav + est pairs).
+Lossless copy synthesis on the MI355X path: analysis_lossless -> synthesis_from_lossless -> wav.
+
+Counterpart (python 3) of the reference demo of the same name: same three library calls in the same order and the same
+output file name (<token>_copy_syn_lossless.wav).  The input wav needs epochs next to it (<stem>.est, REAPER text
+format); without arguments a synthetic utterance with exact epochs is generated first (demos/make_demo_data.py).
+
+    python demos/demo_copy_synthesis_lossless.py [--wav FILE] [--out-dir DIR]
 """
+import argparse
 import os
 import sys
 
-this_dir = os.path.dirname(os.path.realpath(__file__))
-sys.path.append(os.path.realpath(this_dir + '/../src'))
+HERE = os.path.dirname(os.path.realpath(__file__))
+sys.path.append(os.path.realpath(os.path.join(HERE, "..", "src")))
 
-import libutils as lu  # noqa: E402
 import libaudio as la  # noqa: E402
+import libutils as lu  # noqa: E402
 import magphase as mp  # noqa: E402
 
-if __name__ == '__main__':
-    wav_file_orig = sys.argv[1] if len(sys.argv) > 1 else os.path.join(this_dir, 'data_48k/wavs_nat/syn_000.wav')
-    out_dir = sys.argv[2] if len(sys.argv) > 2 else os.path.join(this_dir, 'data_48k/wavs_syn')
-    if not os.path.isfile(wav_file_orig):
+
+def main():
+    ap = argparse.ArgumentParser(description=__doc__.split("\n\n")[0])
+    ap.add_argument("--wav", default=os.path.join(HERE, "data_48k", "wavs_nat", "syn_000.wav"))
+    ap.add_argument("--out-dir", default=os.path.join(HERE, "data_48k", "wavs_syn"))
+    args = ap.parse_args()
+    if not os.path.isfile(args.wav):
+        sys.path.insert(0, HERE)
         import make_demo_data
-        make_demo_data.main()
-    lu.mkdir(out_dir)
+        make_demo_data.main(out_dir=os.path.dirname(args.wav))
+    lu.mkdir(args.out_dir)
 
-    print("Analysing.....................................................")
-    m_mag, m_real, m_imag, v_f0, fs, v_shift = mp.analysis_lossless(wav_file_orig)
+    features = mp.analysis_lossless(args.wav)                    # (m_mag, m_real, m_imag, v_f0, fs, v_shift)
+    m_mag, m_real, m_imag, v_f0, fs = features[:5]
+    print("analysed %d pitch-synchronous frames x %d bins at %d Hz" % (m_mag.shape[0], m_mag.shape[1], fs))
+    v_syn = mp.synthesis_from_lossless(m_mag, m_real, m_imag, v_f0, fs)
+    target = os.path.join(args.out_dir, lu.get_filename(args.wav) + "_copy_syn_lossless.wav")
+    la.write_audio_file(target, v_syn, fs)
+    print("wrote", target)
 
-    print("Synthesising.................................................")
-    v_syn_sig = mp.synthesis_from_lossless(m_mag, m_real, m_imag, v_f0, fs)
 
-    print("Saving wav file..............................................")
-    wav_file_syn = out_dir + '/' + lu.get_filename(wav_file_orig) + '_copy_syn_lossless.wav'
-    la.write_audio_file(wav_file_syn, v_syn_sig, fs)
-    print('Done!')
+if __name__ == "__main__":
+    main()

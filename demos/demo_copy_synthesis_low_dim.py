@@ -1,44 +1,50 @@
 #!/usr/bin/env python
 """
-Python-3 counterpart of the reference's demos/demo_copy_synthesis_low_dim.py (:60-90): analysis_compressed ->
-(optional post_filter) -> synthesis_from_compressed(b_out_hpf=False) -> write_audio_file.  MI355X path.
+Low-dimensional copy synthesis on the MI355X path: analysis_compressed -> post_filter -> synthesis_from_compressed.
+
+Counterpart (python 3) of the reference demo of the same name (same calls, same defaults: 60 magnitude and 45 phase
+coefficients, variable frame rate, post-filter on, no output high-pass) and the same output file name pattern.
+
+    python demos/demo_copy_synthesis_low_dim.py [--wav FILE] [--out-dir DIR] [--const-rate] [--no-postfilter]
 """
+import argparse
 import os
 import sys
 
-this_dir = os.path.dirname(os.path.realpath(__file__))
-sys.path.append(os.path.realpath(this_dir + '/../src'))
+HERE = os.path.dirname(os.path.realpath(__file__))
+sys.path.append(os.path.realpath(os.path.join(HERE, "..", "src")))
 
-import libutils as lu  # noqa: E402
 import libaudio as la  # noqa: E402
+import libutils as lu  # noqa: E402
 import magphase as mp  # noqa: E402
 
-if __name__ == '__main__':
-    wav_file_orig = sys.argv[1] if len(sys.argv) > 1 else os.path.join(this_dir, 'data_48k/wavs_nat/syn_000.wav')
-    out_dir = sys.argv[2] if len(sys.argv) > 2 else os.path.join(this_dir, 'data_48k/wavs_syn')
-    mag_dim = 60         # Number of Mel-scaled frequency bins.
-    phase_dim = 45       # Number of Mel-scaled frequency bins kept for phase features (real and imag).
-    b_const_rate = False
-    b_postfilter = True
-    if not os.path.isfile(wav_file_orig):
+
+def main():
+    ap = argparse.ArgumentParser(description=__doc__.split("\n\n")[0])
+    ap.add_argument("--wav", default=os.path.join(HERE, "data_48k", "wavs_nat", "syn_000.wav"))
+    ap.add_argument("--out-dir", default=os.path.join(HERE, "data_48k", "wavs_syn"))
+    ap.add_argument("--mag-dim", type=int, default=60)
+    ap.add_argument("--phase-dim", type=int, default=45)
+    ap.add_argument("--const-rate", action="store_true", help="5 ms constant frame rate instead of pitch-synchronous")
+    ap.add_argument("--no-postfilter", action="store_true")
+    args = ap.parse_args()
+    if not os.path.isfile(args.wav):
+        sys.path.insert(0, HERE)
         import make_demo_data
-        make_demo_data.main()
-    lu.mkdir(out_dir)
+        make_demo_data.main(out_dir=os.path.dirname(args.wav))
+    lu.mkdir(args.out_dir)
 
-    print("Analysing.....................................................")
-    m_mag_mel_log, m_real_mel, m_imag_mel, v_lf0, v_shift, fs, fft_len = mp.analysis_compressed(
-        wav_file_orig, mag_dim=mag_dim, phase_dim=phase_dim, b_const_rate=b_const_rate)
+    mag_mel_log, real_mel, imag_mel, lf0, _shift, fs, _n = mp.analysis_compressed(
+        args.wav, mag_dim=args.mag_dim, phase_dim=args.phase_dim, b_const_rate=args.const_rate)
+    if not args.no_postfilter:
+        mag_mel_log = mp.post_filter(mag_mel_log, fs)
+    v_syn = mp.synthesis_from_compressed(mag_mel_log, real_mel, imag_mel, lf0, fs, b_const_rate=args.const_rate,
+                                         b_out_hpf=False)
+    name = "%s_copy_syn_low_dim_mag_dim_%d_ph_dim_%d_const_rate_%d.wav" % (
+        lu.get_filename(args.wav), args.mag_dim, args.phase_dim, args.const_rate)
+    la.write_audio_file(os.path.join(args.out_dir, name), v_syn, fs)
+    print("wrote", os.path.join(args.out_dir, name))
 
-    if b_postfilter:
-        print("Postfiltering.................................................")
-        m_mag_mel_log = mp.post_filter(m_mag_mel_log, fs)
 
-    print("Synthesising.................................................")
-    v_syn_sig = mp.synthesis_from_compressed(m_mag_mel_log, m_real_mel, m_imag_mel, v_lf0, fs,
-                                             b_const_rate=b_const_rate, b_out_hpf=False)
-
-    print("Saving wav file..............................................")
-    wav_file_syn = out_dir + '/' + lu.get_filename(wav_file_orig) + \
-        '_copy_syn_low_dim_mag_dim_%d_ph_dim_%d_const_rate_%d.wav' % (mag_dim, phase_dim, b_const_rate)
-    la.write_audio_file(wav_file_syn, v_syn_sig, fs)
-    print('Done!')
+if __name__ == "__main__":
+    main()

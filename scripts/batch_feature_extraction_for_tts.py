@@ -1,32 +1,46 @@
 #!/usr/bin/env python
 """
-Python-3 counterpart of the reference's scripts/batch_feature_extraction_for_tts.py (:33-62): for every token of the
-scp list, mp.analysis_for_acoustic_modelling(wav, out_dir) -> <tok>.{mag,real,imag,lf0,shift} float32 files.
-On the GPU path the utterances of a process are handled in sequence on its device (b_multiproc is ignored); shard the
-scp list over processes / GPUs with magphase_amd.sharding for a node (one process per GPU, no collective).
+Corpus feature extraction for TTS (Merlin) on the MI355X path.
+
+Counterpart (python 3) of the reference script of the same name: every token of the .scp list goes through
+mp.analysis_for_acoustic_modelling(wav, out_dir), which writes <token>.mag/.real/.imag/.lf0 (+ .shift) as raw float32.
+The reference fans tokens out over a multiprocessing.Pool; here each process drives one GPU and, under
+`python -m torch.distributed.run --nproc-per-node N`, takes its share of the list (magphase_amd.sharding: by file
+size, longest first; no data is exchanged between ranks).
+
+    python scripts/batch_feature_extraction_for_tts.py [--scp LIST] [--wav-dir DIR] [--out-dir DIR]
 """
+import argparse
 import os
 import sys
 
-curr_dir = os.path.dirname(os.path.realpath(__file__))
-sys.path.append(os.path.realpath(curr_dir + '/../src'))
+HERE = os.path.dirname(os.path.realpath(__file__))
+sys.path.append(os.path.realpath(os.path.join(HERE, "..", "src")))
+
 import libutils as lu  # noqa: E402
 import magphase as mp  # noqa: E402
+from magphase_amd import sharding  # noqa: E402
 
 
-def feat_extraction(in_wav_dir, file_name_token, out_feats_dir):
-    print("\nAnalysing file: " + file_name_token + '.wav............................')
-    wav_file = os.path.join(in_wav_dir, file_name_token + '.wav')
-    mp.analysis_for_acoustic_modelling(wav_file, out_feats_dir)
-    return
+def main():
+    demo = os.path.realpath(os.path.join(HERE, "..", "demos", "data_48k"))
+    ap = argparse.ArgumentParser(description=__doc__.split("\n\n")[0])
+    ap.add_argument("--scp", default=os.path.join(demo, "file_id.scp"))
+    ap.add_argument("--wav-dir", default=os.path.join(demo, "wavs_nat"))
+    ap.add_argument("--out-dir", default=os.path.join(demo, "params_nat"))
+    args = ap.parse_args()
+    lu.mkdir(args.out_dir)
+    tokens = [str(t) for t in lu.read_text_file2(args.scp, dtype="string", comments="#").tolist()]
+    rank, local_rank, world = sharding.dist_env()
+    if world > 1:
+        import torch
+        torch.cuda.set_device(local_rank)
+    sizes = [os.path.getsize(os.path.join(args.wav_dir, t + ".wav")) for t in tokens]
+    for i in sharding.shard_by_cost(sizes, world)[rank]:
+        print("[rank %d] analysing %s.wav" % (rank, tokens[i]))
+        mp.analysis_for_acoustic_modelling(os.path.join(args.wav_dir, tokens[i] + ".wav"), args.out_dir)
+    print("rank %d done" % rank)
 
 
-if __name__ == '__main__':
-    files_scp = sys.argv[1] if len(sys.argv) > 1 else curr_dir + '/../demos/data_48k/file_id.scp'
-    in_wav_dir = sys.argv[2] if len(sys.argv) > 2 else curr_dir + '/../demos/data_48k/wavs_nat'
-    out_feats_dir = sys.argv[3] if len(sys.argv) > 3 else curr_dir + '/../demos/data_48k/params_nat'
-    lu.mkdir(out_feats_dir)
-    l_file_tokns = lu.read_text_file2(files_scp, dtype='string', comments='#').tolist()
-    for file_name_token in l_file_tokns:
-        feat_extraction(in_wav_dir, file_name_token, out_feats_dir)
-    print('Done!')
+if __name__ == "__main__":
+    main()

@@ -1,34 +1,50 @@
 #!/usr/bin/env python
 """
-Python-3 counterpart of the reference's scripts/batch_waveform_generation.py (:28-64): for every token,
-mp.synthesis_from_acoustic_modelling(in_feats_dir, tok, out_dir, mag_dim, phase_dim, fs, pf_type, b_const_rate=False).
-Default input: the predicted features the reference bundles (demos/data_48k/params_predicted, copied as data).
+Waveform generation from predicted low-dimensional features on the MI355X path.
+
+Counterpart (python 3) of the reference script of the same name: for every token,
+mp.synthesis_from_acoustic_modelling(feats_dir, token, out_dir, mag_dim, phase_dim, fs, pf_type, b_const_rate=False)
+reads <token>.mag/.real/.imag/.lf0, applies the MagPhase post-filter and writes <token>.wav.  Defaults point at the
+predicted features the reference bundles (copied as data under demos/data_48k/params_predicted).  One process per
+GPU under torch.distributed.run; tokens are dealt to ranks by feature-file size, nothing is exchanged.
+
+    python scripts/batch_waveform_generation.py [--scp LIST] [--feats-dir DIR] [--out-dir DIR] [--pf-type magphase|no]
 """
+import argparse
 import os
 import sys
 
-curr_dir = os.path.dirname(os.path.realpath(__file__))
-sys.path.append(os.path.realpath(curr_dir + '/../src'))
+HERE = os.path.dirname(os.path.realpath(__file__))
+sys.path.append(os.path.realpath(os.path.join(HERE, "..", "src")))
+
 import libutils as lu  # noqa: E402
 import magphase as mp  # noqa: E402
+from magphase_amd import sharding  # noqa: E402
 
 
-def synthesis(in_feats_dir, filename_token, out_syn_dir, mag_dim, phase_dim, fs, pf_type):
-    mp.synthesis_from_acoustic_modelling(in_feats_dir, filename_token, out_syn_dir, mag_dim, phase_dim, fs,
-                                         pf_type=pf_type, b_const_rate=False)
-    return
+def main():
+    demo = os.path.realpath(os.path.join(HERE, "..", "demos", "data_48k"))
+    ap = argparse.ArgumentParser(description=__doc__.split("\n\n")[0])
+    ap.add_argument("--scp", default=os.path.join(demo, "file_id_predict.scp"))
+    ap.add_argument("--feats-dir", default=os.path.join(demo, "params_predicted"))
+    ap.add_argument("--out-dir", default=os.path.join(demo, "wavs_syn_from_predicted"))
+    ap.add_argument("--fs", type=int, default=48000)
+    ap.add_argument("--mag-dim", type=int, default=60)
+    ap.add_argument("--phase-dim", type=int, default=45)
+    ap.add_argument("--pf-type", default="magphase", choices=["magphase", "no"])
+    args = ap.parse_args()
+    lu.mkdir(args.out_dir)
+    tokens = [str(t) for t in lu.read_text_file2(args.scp, dtype="string", comments="#").tolist()]
+    rank, local_rank, world = sharding.dist_env()
+    if world > 1:
+        import torch
+        torch.cuda.set_device(local_rank)
+    sizes = [os.path.getsize(os.path.join(args.feats_dir, t + ".mag")) for t in tokens]
+    for i in sharding.shard_by_cost(sizes, world)[rank]:
+        mp.synthesis_from_acoustic_modelling(args.feats_dir, tokens[i], args.out_dir, args.mag_dim, args.phase_dim,
+                                             args.fs, pf_type=args.pf_type, b_const_rate=False)
+    print("rank %d done" % rank)
 
 
-if __name__ == '__main__':
-    fs = 48000
-    files_scp = sys.argv[1] if len(sys.argv) > 1 else curr_dir + '/../demos/data_48k/file_id_predict.scp'
-    in_feats_dir = sys.argv[2] if len(sys.argv) > 2 else curr_dir + '/../demos/data_48k/params_predicted'
-    out_syn_dir = sys.argv[3] if len(sys.argv) > 3 else curr_dir + '/../demos/data_48k/wavs_syn_from_predicted'
-    mag_dim = 60
-    phase_dim = 45
-    pf_type = 'magphase'
-    lu.mkdir(out_syn_dir)
-    l_file_tokns = lu.read_text_file2(files_scp, dtype='string', comments='#').tolist()
-    for file_tokn in l_file_tokns:
-        synthesis(in_feats_dir, file_tokn, out_syn_dir, mag_dim, phase_dim, fs, pf_type)
-    print('Done!')
+if __name__ == "__main__":
+    main()

@@ -31,16 +31,19 @@ def test_demos_and_batch_scripts(tmp_path):
     assert scp.read_text().split() == toks
     syn_dir = tmp_path / "syn"
     # lossless copy synthesis
-    _run([os.path.join(ROOT, "demos", "demo_copy_synthesis_lossless.py"), str(wav_dir / "syn_000.wav"), str(syn_dir)], ROOT)
+    _run([os.path.join(ROOT, "demos", "demo_copy_synthesis_lossless.py"), "--wav", str(wav_dir / "syn_000.wav"),
+          "--out-dir", str(syn_dir)], ROOT)
     n_in, fs = _wav_len(str(wav_dir / "syn_000.wav"))
     n_out, fs2 = _wav_len(str(syn_dir / "syn_000_copy_syn_lossless.wav"))
     assert fs == fs2 == 48000 and abs(n_out - n_in) < 2000
     # low-dim copy synthesis
-    _run([os.path.join(ROOT, "demos", "demo_copy_synthesis_low_dim.py"), str(wav_dir / "syn_000.wav"), str(syn_dir)], ROOT)
+    _run([os.path.join(ROOT, "demos", "demo_copy_synthesis_low_dim.py"), "--wav", str(wav_dir / "syn_000.wav"),
+          "--out-dir", str(syn_dir)], ROOT)
     assert os.path.isfile(str(syn_dir / "syn_000_copy_syn_low_dim_mag_dim_60_ph_dim_45_const_rate_0.wav"))
     # batch feature extraction (Q7: phase_dim 10, alpha_phase False -> 44 linear-cepstral bins cut to 10)
     feats = tmp_path / "params_nat"
-    _run([os.path.join(ROOT, "scripts", "batch_feature_extraction_for_tts.py"), str(scp), str(wav_dir), str(feats)], ROOT)
+    _run([os.path.join(ROOT, "scripts", "batch_feature_extraction_for_tts.py"), "--scp", str(scp), "--wav-dir",
+          str(wav_dir), "--out-dir", str(feats)], ROOT)
     for tok in toks:
         mag = np.fromfile(str(feats / (tok + ".mag")), dtype=np.float32)
         real = np.fromfile(str(feats / (tok + ".real")), dtype=np.float32)
@@ -49,9 +52,7 @@ def test_demos_and_batch_scripts(tmp_path):
         assert mag.size == 60 * lf0.size and real.size == 10 * lf0.size and shift.size == lf0.size
     # batch generation from the bundled predicted features
     gen = tmp_path / "gen"
-    _run([os.path.join(ROOT, "scripts", "batch_waveform_generation.py"),
-          os.path.join(ROOT, "demos", "data_48k", "file_id_predict.scp"),
-          os.path.join(ROOT, "demos", "data_48k", "params_predicted"), str(gen)], ROOT)
+    _run([os.path.join(ROOT, "scripts", "batch_waveform_generation.py"), "--out-dir", str(gen)], ROOT)
     for tok in ("hvd_704", "hvd_705", "hvd_706", "hvd_708"):
         n, fsw = _wav_len(str(gen / (tok + ".wav")))
         assert fsw == 48000 and n > 40000
