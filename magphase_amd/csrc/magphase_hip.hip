@@ -141,7 +141,7 @@ __global__ __launch_bounds__(kThreads) void k_analysis(const float* __restrict__
             {
                 const float xr = er + tr, xi = ei + ti;
                 const float s2 = xr * xr + xi * xi;
-                const float r = (s2 > 0.0f) ? __builtin_amdgcn_rsqf(s2) : 0.0f;
+                const float r = __builtin_amdgcn_rsqf(fmaxf(s2, 1.0e-37f));   // X == 0 -> xr = xi = s2 = 0 -> all three outputs 0
 #ifdef MPX_PROBE_NOSTORE
                 asm volatile("" ::"v"(s2 * r), "v"(xr * r), "v"(xi * r));
 #else
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(kThreads) void k_analysis(const float* __restrict__
             {
                 const float xr = er - tr, xi = ti - ei;
                 const float s2 = xr * xr + xi * xi;
-                const float r = (s2 > 0.0f) ? __builtin_amdgcn_rsqf(s2) : 0.0f;
+                const float r = __builtin_amdgcn_rsqf(fmaxf(s2, 1.0e-37f));   // X == 0 -> xr = xi = s2 = 0 -> all three outputs 0
 #ifdef MPX_PROBE_NOSTORE
                 asm volatile("" ::"v"(s2 * r), "v"(xr * r), "v"(xi * r));
 #else
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(kThreads) void k_analysis(const float* __restrict__
         if (lane0) {  // bin M/2 (register 1 holds q = P/2): X = conj Z
             const float xr = re[1], xi = -im[1];
             const float s2 = xr * xr + xi * xi;
-            const float r = (s2 > 0.0f) ? __builtin_amdgcn_rsqf(s2) : 0.0f;
+            const float r = __builtin_amdgcn_rsqf(fmaxf(s2, 1.0e-37f));   // X == 0 -> xr = xi = s2 = 0 -> all three outputs 0
             mlo[M / 2] = s2 * r;
             rlo[M / 2] = xr * r;
             ilo[M / 2] = xi * r;

@@ -45,23 +45,17 @@ __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlan
 // ---------------------------------------------------------------------------------------------
 // analysis
 // ---------------------------------------------------------------------------------------------
-// sin(pi t / 2)^2 for t in [0,1] without range reduction: Taylor polynomials on [0, pi/4]
-// (sin: degree 9, |err| < 2e-9; cos: degree 8, |err| < 2.5e-8), selected at t = 0.5.
+// sin(pi t / 2)^2 = 0.5 + 0.5 sin(pi (t - 0.5)) for t in [0,1]: one odd degree-9 polynomial for sin(pi u) on
+// u in [-0.5, 0.5] (least squares on Chebyshev nodes, |err| < 4e-9; 1.2e-7 after fp32 evaluation), no range
+// reduction, no branches: 8 VALU per window sample.
 __device__ __forceinline__ float sin2_halfpi(float t) {
-    const float kHalfPi = 1.57079632679489662f;
-    const bool lo = t <= 0.5f;
-    const float y = kHalfPi * (lo ? t : 1.0f - t);
-    const float y2 = y * y;
-    float sp = fmaf(y2, 2.75573192e-6f, -1.98412698e-4f);
-    sp = fmaf(y2, sp, 8.33333333e-3f);
-    sp = fmaf(y2, sp, -1.66666667e-1f);
-    sp = fmaf(y2 * y, sp, y);
-    float cp = fmaf(y2, 2.48015873e-5f, -1.38888889e-3f);
-    cp = fmaf(y2, cp, 4.16666667e-2f);
-    cp = fmaf(y2, cp, -0.5f);
-    cp = fmaf(y2, cp, 1.0f);
-    const float v = lo ? sp : cp;
-    return v * v;
+    const float u = t - 0.5f;
+    const float u2 = u * u;
+    float p = fmaf(u2, 7.721838616e-02f, -5.980441939e-01f);
+    p = fmaf(u2, p, 2.550031194e+00f);
+    p = fmaf(u2, p, -5.167706866e+00f);
+    p = fmaf(u2, p, 3.141592580e+00f);
+    return fmaf(0.5f * u, p, 0.5f);
 }
 
 // Half windows of libaudio.py:70-84 evaluated analytically.  t = k/L on the rising half (k <= L; t = 1 when L == 0:
@@ -191,8 +185,9 @@ __device__ __forceinline__ void feat_convert(const FrameFeat<P>& ff, float (&xr)
     const float sgn_scale = ((lane & 1) ? -1.0f : 1.0f) * (0.5f / (float)M);
 #pragma unroll
     for (int j = 0; j < P; ++j) {
+        // |R + jI| == 0 -> 0 (magphase.py:1764-1766): rsq(max(s, tiny)) is finite and multiplies a == b == 0
         const float s = ff.a[j] * ff.a[j] + ff.b[j] * ff.b[j];
-        const float g = (s > 0.0f) ? ff.m[j] * sgn_scale * __builtin_amdgcn_rsqf(s) : 0.0f;
+        const float g = ff.m[j] * sgn_scale * __builtin_amdgcn_rsqf(fmaxf(s, 1.0e-37f));
         xr[j] = ff.a[j] * g;
         xi[j] = ff.b[j] * g;
     }

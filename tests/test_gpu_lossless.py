@@ -227,3 +227,22 @@ def test_fused_ola_equals_two_kernel_form(mp, fs, terr):
     assert a.shape == b.shape
     assert np.array_equal(a, a2)                                   # deterministic
     assert np.max(np.abs(a - b)) <= 2e-6 * np.max(np.abs(b))
+
+
+def test_digital_silence_gives_zero_features(mp, orc):
+    """Frames of exact zeros: |X| == 0 -> mag = real = imag = 0 (magphase.py:460-470), no NaN/inf from the rsq path."""
+    from magphase_amd import synthetic as syn
+    pcm, pm, voi = syn.make_utterance(123, dur_s=0.6, fs=48000)
+    x = syn.pcm_to_float(pcm)
+    x[9000:20000] = 0.0
+    a = mp.analysis_lossless_from_epochs(x, 48000, pm, voi)
+    o = orc.analysis_lossless_from_epochs(x, 48000, pm, voi)
+    zero_rows = np.nonzero(np.max(o[0], axis=1) == 0.0)[0]
+    assert zero_rows.size > 3
+    for k in range(3):
+        assert np.all(np.isfinite(a[k]))
+        assert np.all(a[k][zero_rows] == 0.0)
+    _check_feats(a[:3], o[:3])
+    v = mp.synthesis_from_lossless(a[0], a[1], a[2], a[3], 48000)
+    ref = orc.synthesis_from_lossless(o[0], o[1], o[2], o[3], 48000)
+    assert np.all(np.isfinite(v)) and np.max(np.abs(v - ref)) <= PCM_TOL * np.max(np.abs(ref))
