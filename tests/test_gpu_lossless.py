@@ -246,3 +246,28 @@ def test_digital_silence_gives_zero_features(mp, orc):
     v = mp.synthesis_from_lossless(a[0], a[1], a[2], a[3], 48000)
     ref = orc.synthesis_from_lossless(o[0], o[1], o[2], o[3], 48000)
     assert np.all(np.isfinite(v)) and np.max(np.abs(v - ref)) <= PCM_TOL * np.max(np.abs(ref))
+
+
+@pytest.mark.parametrize("nfr", [1, 2, 3])
+def test_tiny_utterances(mp, orc, nfr):
+    """Ragged extremes: utterances of 1-3 frames (alone and batched with a normal one)."""
+    rng = np.random.RandomState(nfr)
+    fs, N = 48000, 4096
+    x = rng.uniform(-0.3, 0.3, 1500 + 400 * nfr)
+    pm_sec = (300 + 350 * np.arange(nfr)) / fs
+    voi = np.ones(nfr)
+    a = mp.analysis_lossless_from_epochs(x, fs, pm_sec, voi)
+    o = orc.analysis_lossless_from_epochs(x, fs, pm_sec, voi)
+    assert a[0].shape == o[0].shape == (nfr, N // 2 + 1)
+    _check_feats(a[:3], o[:3])
+    ref = orc.synthesis_from_lossless(o[0], o[1], o[2], o[3], fs)
+    got = mp.synthesis_from_lossless(a[0], a[1], a[2], a[3], fs)
+    assert len(got) == len(ref)
+    assert np.max(np.abs(got - ref)) <= PCM_TOL * max(np.max(np.abs(ref)), 1e-3)
+    from magphase_amd import synthetic as syn
+    pcm, pm2, voi2 = syn.make_utterance(55, dur_s=0.3, fs=fs)
+    b = mp.analysis_lossless_batch([(x, fs, pm_sec, voi), (syn.pcm_to_float(pcm), fs, pm2, voi2)])
+    for k in range(3):
+        assert np.array_equal(b[0][k], a[k])
+    outs = mp.synthesis_from_lossless_batch([tuple(b[0][:5]), tuple(b[1][:5])])
+    assert np.array_equal(outs[0], got)
