@@ -181,6 +181,23 @@ int mpx_min_phase(void* stream, int fft_len, const void* tables, const float* ma
                   const int32_t* row1, const float* row_t, int64_t n_frames, float* out_mag, float* out_real,
                   float* out_imag);
 
+/*
+ * Noise gains on the device (magphase.py:902-906, Q10): per utterance u and class c (0 voiced, 1 unvoiced)
+ * g = sqrt(exp( sum of out_sum over the class's frames / (n_frames_of_class * bins_per_frame) )), float64;
+ * inv_gain[f] = 1/g(class of f) (float32, input of mpx_synthesis_compressed_ola); gains (optional, may be null):
+ * float64 [n_utts x 2].  bins_per_frame = N/2 - 1.
+ */
+int mpx_noise_gains(void* stream, const float* sums, const int32_t* voiced, const int32_t* utt_frame_off,
+                    int32_t n_utts, int32_t bins_per_frame, float* inv_gain, double* gains);
+
+/*
+ * MagPhase post-filter (magphase.py:2300-2378, Q20) on [n_frames x dim] log-mel magnitudes.  half_len: int32
+ * [nx_last - nx_first + 1] half lengths of the centred moving average of bins nx_first..nx_last (host table,
+ * magphase.py:2342-2344); tilt: float32[dim] enhancement factors (np.linspace(boost_at_zero, boost_at_nyq, dim)).
+ */
+int mpx_post_filter(void* stream, const float* mag_mel_log, int64_t n_frames, int32_t dim, const int32_t* half_len,
+                    int32_t nx_first, int32_t nx_last, const float* tilt, float* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -27,6 +27,8 @@ SYMBOLS = (
     "mpx_synthesis_compressed_ola",
     "mpx_mel_warp",
     "mpx_min_phase",
+    "mpx_noise_gains",
+    "mpx_post_filter",
 )
 
 _lib = None
@@ -80,6 +82,10 @@ def load():
     lib.mpx_mel_warp.argtypes = [vp, i64, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, vp, vp, vp, vp]
     lib.mpx_min_phase.restype = ctypes.c_int
     lib.mpx_min_phase.argtypes = [vp, ctypes.c_int, vp, vp, vp, vp, vp, i64, vp, vp, vp]
+    lib.mpx_noise_gains.restype = ctypes.c_int
+    lib.mpx_noise_gains.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp]
+    lib.mpx_post_filter.restype = ctypes.c_int
+    lib.mpx_post_filter.argtypes = [vp, vp, i64, i32, vp, i32, i32, vp, vp]
     _lib = lib
     return lib
 

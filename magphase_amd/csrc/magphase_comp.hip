@@ -271,6 +271,79 @@ __global__ __launch_bounds__(kThreads) void k_noise_stats(const float* __restric
 }
 
 // ---------------------------------------------------------------------------------------------
+// noise gains (magphase.py:902-906, Q10): per utterance and class (voiced / unvoiced)
+//   g = sqrt(exp(mean over the class's frames and bins 1..N/2-1 of (ln|Ns|)^2)),  inv_gain[f] = 1 / g(class of f)
+// from the per-frame sums of k_noise_stats.  One block per utterance, float64 accumulation; an empty class gives
+// NaN exactly like np.mean of an empty selection (it is never applied to a frame).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_noise_gains(const float* __restrict__ sums, const int* __restrict__ voiced,
+                                                     const int* __restrict__ utt_frame_off, int bins_per_frame,
+                                                     float* __restrict__ inv_gain, double* __restrict__ gains) {
+    __shared__ double s_sum[2][256];
+    __shared__ int s_cnt[2][256];
+    const int u = blockIdx.x;
+    const int f0 = utt_frame_off[u], f1 = utt_frame_off[u + 1];
+    double acc[2] = {0.0, 0.0};
+    int cnt[2] = {0, 0};
+    for (int f = f0 + threadIdx.x; f < f1; f += 256) {
+        const int c = voiced[f] ? 0 : 1;
+        acc[c] += (double)sums[f];
+        cnt[c] += 1;
+    }
+    for (int c = 0; c < 2; ++c) {
+        s_sum[c][threadIdx.x] = acc[c];
+        s_cnt[c][threadIdx.x] = cnt[c];
+    }
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if (threadIdx.x < off) {
+            for (int c = 0; c < 2; ++c) {
+                s_sum[c][threadIdx.x] += s_sum[c][threadIdx.x + off];
+                s_cnt[c][threadIdx.x] += s_cnt[c][threadIdx.x + off];
+            }
+        }
+        __syncthreads();
+    }
+    double g[2];
+    for (int c = 0; c < 2; ++c)
+        g[c] = (s_cnt[c][0] > 0) ? sqrt(exp(s_sum[c][0] / ((double)s_cnt[c][0] * (double)bins_per_frame))) : nan("");
+    if (threadIdx.x == 0 && gains) {
+        gains[2 * u + 0] = g[0];
+        gains[2 * u + 1] = g[1];
+    }
+    for (int f = f0 + threadIdx.x; f < f1; f += 256) inv_gain[f] = (float)(1.0 / g[voiced[f] ? 0 : 1]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// post-filter (magphase.py:2300-2378, Q20) on the log-mel magnitude [F x D]: per bin a centred moving average of odd
+// length lens[b] (host table, linearly shrinking/growing with frequency), enhancement
+// y = (x - ave) * tilt[b] + ave, the two end bins copied.  One thread per (frame, bin); D <= 256.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_post_filter(const float* __restrict__ x, long long F, int D,
+                                                     const int* __restrict__ half_len, int nx0, int nx1,
+                                                     const float* __restrict__ tilt, float* __restrict__ y) {
+    extern __shared__ float row[];   // rows_per_block x D
+    const int rows_per_block = blockDim.x / D;
+    const int rl = threadIdx.x / D, b = threadIdx.x - rl * D;
+    const long long f = (long long)blockIdx.x * rows_per_block + rl;
+    const bool live = (rl < rows_per_block) && (f < F);
+    if (live) row[rl * D + b] = x[f * D + b];
+    __syncthreads();
+    if (!live) return;
+    const float* r = row + rl * D;
+    // averages exist for bins nx0..nx1 (inclusive); outside they repeat the boundary value (magphase.py:2357-2358:
+    // v_ave[:v_nx[0]] = v_ave[v_nx[0]] ; v_ave[v_nx[-1]:] = v_ave[v_nx[-1]])
+    const int bc = min(max(b, nx0), nx1);
+    const int h = half_len[bc - nx0];
+    float acc = 0.0f;
+    for (int k = bc - h; k <= bc + h; ++k) acc += r[k];
+    const float ave = acc / (float)(2 * h + 1);
+    float out = (r[b] - ave) * tilt[b] + ave;
+    if (b == 0 || b == D - 1) out = r[b];
+    y[f * D + b] = out;
+}
+
+// ---------------------------------------------------------------------------------------------
 // minimum-phase spectrum from a magnitude spectrum (complex cepstrum), la.build_min_phase_from_mag_spec
 // (libaudio.py:920-934): ln|X| -> even extension -> real IFFT (cepstrum c) -> causal fold (c[1..N/2-1] *= 2,
 // c[N/2+1..] = 0) -> FFT -> exp.  Since Re FFT(fold c) == ln|X|, only the phase phi = Im FFT(fold c) is new: the
@@ -709,6 +782,31 @@ int mpx_min_phase(void* stream, int fft_len, const void* tables, const float* ma
         hipLaunchKernelGGL(k_min_phase<16>, grid, block, lds_bytes<16>(), s, mag, row0, row1, row_t,
                            (long long)n_frames, (const float2*)tables, out_mag, out_real, out_imag);
     }
+    MPX_HIP_CHECK(hipGetLastError());
+    return MPX_OK;
+}
+
+int mpx_noise_gains(void* stream, const float* sums, const int32_t* voiced, const int32_t* utt_frame_off,
+                    int32_t n_utts, int32_t bins_per_frame, float* inv_gain, double* gains) {
+    if (n_utts < 0 || bins_per_frame <= 0) return fail(MPX_ERR_ARG, "mpx_noise_gains: bad size%s");
+    if (n_utts == 0) return MPX_OK;
+    if (!sums || !voiced || !utt_frame_off || !inv_gain) return fail(MPX_ERR_ARG, "mpx_noise_gains: null pointer%s");
+    hipLaunchKernelGGL(k_noise_gains, dim3((unsigned)n_utts), dim3(256), 0, (hipStream_t)stream, sums, voiced,
+                       utt_frame_off, (int)bins_per_frame, inv_gain, gains);
+    MPX_HIP_CHECK(hipGetLastError());
+    return MPX_OK;
+}
+
+int mpx_post_filter(void* stream, const float* mag_mel_log, int64_t n_frames, int32_t dim, const int32_t* half_len,
+                    int32_t nx_first, int32_t nx_last, const float* tilt, float* out) {
+    if (n_frames < 0 || dim < 3 || dim > 256) return fail(MPX_ERR_ARG, "mpx_post_filter: dim must be in 3..256%s");
+    if (nx_first < 0 || nx_last >= dim || nx_first > nx_last) return fail(MPX_ERR_ARG, "mpx_post_filter: bad bin range%s");
+    if (n_frames == 0) return MPX_OK;
+    if (!mag_mel_log || !half_len || !tilt || !out) return fail(MPX_ERR_ARG, "mpx_post_filter: null pointer%s");
+    const int rows = 256 / dim;
+    const dim3 grid((unsigned)((n_frames + rows - 1) / rows)), block(256);
+    hipLaunchKernelGGL(k_post_filter, grid, block, sizeof(float) * (size_t)rows * dim, (hipStream_t)stream,
+                       mag_mel_log, (long long)n_frames, (int)dim, half_len, (int)nx_first, (int)nx_last, tilt, out);
     MPX_HIP_CHECK(hipGetLastError());
     return MPX_OK;
 }

@@ -108,6 +108,19 @@ class Engine:
         with torch.cuda.device(self.device):
             return int(self.lib.mpx_synth_ola_slots())
 
+    def post_filter(self, mag_mel_log, fs, **kw):
+        """Device MagPhase post-filter (mpx_post_filter) of a float32 [F x D] tensor; kw as magphase.post_filter."""
+        torch = _torch()
+        F, D = int(mag_mel_log.shape[0]), int(mag_mel_log.shape[1])
+        nx0, nx1, half, tilt = hm.post_filter_tables(D, fs, **kw)
+        d_half = self.to_device(half, np.int32)
+        d_tilt = self.to_device(tilt, np.float32)
+        out = self.empty((F, D))
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.mpx_post_filter(self.stream_ptr(), mag_mel_log.data_ptr(), F, D, d_half.data_ptr(),
+                                                nx0, nx1, d_tilt.data_ptr(), out.data_ptr()), "mpx_post_filter")
+        return out
+
     def synth_comp_slots(self):
         torch = _torch()
         with torch.cuda.device(self.device):
@@ -295,8 +308,10 @@ class CompressedSynthesisPlan:
     """
 
     def __init__(self, engine, utts, fs, fft_len=None, b_voi_ap_win=True, b_const_rate=False, alpha_phase=None,
-                 noise=None, territory=None, per_phase_type="magphase"):
+                 noise=None, territory=None, per_phase_type="magphase", post_filter=False):
         from scipy import interpolate
+
+        self.apply_post_filter = bool(post_filter)
 
         if per_phase_type not in ("magphase", "min_phase", "linear"):
             raise ValueError("per_phase_type must be 'magphase', 'min_phase' or 'linear'")
@@ -375,6 +390,8 @@ class CompressedSynthesisPlan:
         self.total_out = int(self.out_off_host[-1])
         self.max_out_len = int(max(lens))
         self.voiced_host = cat(voiced).astype(bool)
+        self.utt_frame_off = e.to_device(self.frame_off, np.int32)
+        self.n_utts = len(nfr)
         self.a_mag = e.to_device(cat(a_mag), np.float32)
         self.a_real = e.to_device(cat(a_real), np.float32)
         self.a_imag = e.to_device(cat(a_imag), np.float32)
@@ -410,7 +427,15 @@ class CompressedSynthesisPlan:
         self.n_slots = int(slot_off.size - 1)
         self.slot_off = e.to_device(slot_off, np.int32)
         self.slot_chunks = e.to_device(slot_chunks, np.int32)
-        self.gains = None
+        self._gains_dev = None
+
+    @property
+    def gains(self):
+        """[(g_voiced, g_unvoiced)] per utterance (float64), fetched from the device on demand."""
+        if self._gains_dev is None:
+            return None
+        g = self._gains_dev.cpu().numpy()
+        return [(float(a), float(b)) for a, b in g]
 
     def noise_gains(self, sums_host):
         """magphase.py:902-906 (Q10) from the per-frame sums of (ln|Ns|)^2: two gains per utterance, float64."""
@@ -428,7 +453,6 @@ class CompressedSynthesisPlan:
                 if ncls:
                     inv[a:b][cls] = 1.0 / g[-1]
             gains.append(tuple(g))
-        self.gains = gains
         return inv
 
     def run(self, out=None, keep=False):
@@ -441,15 +465,20 @@ class CompressedSynthesisPlan:
         strips = e.empty((self.strip_floats,))
         with torch.cuda.device(e.device):
             st = e.stream_ptr()
-            _lib.check(lib.mpx_mel_unwarp(st, self.n_rows, H, self.a_mag.data_ptr(), self.mag_dim, self.u_mag.data_ptr(),
+            a_mag = e.post_filter(self.a_mag, self.fs) if self.apply_post_filter else self.a_mag   # magphase.py:3259-3261
+            _lib.check(lib.mpx_mel_unwarp(st, self.n_rows, H, a_mag.data_ptr(), self.mag_dim, self.u_mag.data_ptr(),
                                           mag.data_ptr(), self.a_real.data_ptr(), self.a_imag.data_ptr(),
                                           self.phase_dim, self.u_phase.data_ptr(), real.data_ptr(), imag.data_ptr()),
                        "mpx_mel_unwarp")
             _lib.check(lib.mpx_noise_stats(st, N, tab.data_ptr(), self.noise.data_ptr(), self.npos.data_ptr(),
                                            self.nleft.data_ptr(), self.nright.data_ptr(), self.wtype.data_ptr(),
                                            self.total_frames, sums.data_ptr()), "mpx_noise_stats")
-            inv = self.noise_gains(sums.cpu().numpy())   # two scalars per utterance: float64 on the host
-            inv_gain = e.to_device(inv, np.float32)
+            # two gains per utterance (Q10): float64 reduction on the device, no host round trip
+            inv_gain = e.empty((self.total_frames,))
+            self._gains_dev = torch.empty((self.n_utts, 2), dtype=torch.float64, device=e.device)
+            _lib.check(lib.mpx_noise_gains(st, sums.data_ptr(), self.voiced.data_ptr(), self.utt_frame_off.data_ptr(),
+                                           self.n_utts, H - 2, inv_gain.data_ptr(), self._gains_dev.data_ptr()),
+                       "mpx_noise_gains")
             row0, row1, rowt = self.row0, self.row1, self.rowt
             if self.per_phase_type != "magphase":
                 # periodic component's phase is not the transmitted one (magphase.py:933-938):

@@ -318,3 +318,31 @@ def var_to_const_rate_table(v_pm_smpls, const_rate_ms, fs):
     lo, hi = idx - 1, idx
     t = (centres - x[lo]) / (x[hi] - x[lo]).astype(np.float64)
     return node_row[lo].astype(np.int64), node_row[hi].astype(np.int64), t
+
+
+def post_filter_tables(mag_dim, fs, av_len_at_zero=None, av_len_at_nyq=None, boost_at_zero=None, boost_at_nyq=None):
+    """
+    Host tables of the MagPhase post-filter (magphase.py:2300-2347, Q20): defaults per sample rate (same warnings /
+    ValueError as the reference), bins with a moving average v_nx, their half lengths, and the tilt factors.
+    Returns (nx_first, nx_last, half_len int64[], tilt float64[mag_dim]).
+    """
+    if mag_dim != 60:
+        warnings.warn('Post-filter: It has been only tested with 60 dimensional mag data. '
+                      'If you use another dimension, the result may be suboptimal.')
+    opts = [av_len_at_zero, av_len_at_nyq, boost_at_zero, boost_at_nyq]
+    if fs == 48000:
+        defaults = [round_to_int(11.0 * (mag_dim / 60.0)), round_to_int(3.0 * (mag_dim / 60.0)), 1.8, 2.0]
+    elif fs == 16000:
+        if any(o is None for o in opts):
+            warnings.warn('Post-filter: The default parameters for 16kHz sample rate have not being tunned.')
+        defaults = [round_to_int(9.0 * (mag_dim / 60.0)), round_to_int(12.0 * (mag_dim / 60.0)), 2.0, 1.6]
+    else:
+        if any(o is None for o in opts):
+            raise ValueError('Post-filter: It has only been tested with 16kHz and 48kHz sample rates.'
+                             '\nProvide your own values for the options: av_len_at_zero, av_len_at_nyq, '
+                             'boost_at_zero,\nboost_at_nyq if you use another sample rate')
+        defaults = opts
+    av0, avn, b0, bn = [d if o is None else o for o, d in zip(opts, defaults)]
+    v_nx = np.arange(np.floor(av0 / 2), mag_dim - np.floor(avn / 2)).astype(int)
+    v_lens = (2 * np.ceil(np.linspace(av0, avn, v_nx.size) / 2) - 1).astype(int)
+    return int(v_nx[0]), int(v_nx[-1]), (v_lens // 2).astype(np.int64), np.linspace(b0, bn, mag_dim)

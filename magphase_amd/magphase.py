@@ -189,12 +189,14 @@ def _output_hpf(v_syn_sig, fs):
 
 
 def synthesis_from_compressed_batch(utts, fs, fft_len=None, b_voi_ap_win=True, b_const_rate=False, alpha_phase=None,
-                                    b_out_hpf=True, noise=None, engine=None, per_phase_type='magphase'):
-    """Batched synthesis_from_compressed; utts: list of (m_mag_mel_log, m_real_mel, m_imag_mel, v_lf0)."""
+                                    b_out_hpf=True, noise=None, engine=None, per_phase_type='magphase',
+                                    b_post_filter=False):
+    """Batched synthesis_from_compressed; utts: list of (m_mag_mel_log, m_real_mel, m_imag_mel, v_lf0).
+    b_post_filter: apply the MagPhase post-filter to the log-mel magnitudes on the device first (pf_type='magphase')."""
     engine = engine or get_engine()
     plan = CompressedSynthesisPlan(engine, utts, fs, fft_len=fft_len, b_voi_ap_win=b_voi_ap_win,
                                    b_const_rate=b_const_rate, alpha_phase=alpha_phase, noise=noise,
-                                   per_phase_type=per_phase_type)
+                                   per_phase_type=per_phase_type, post_filter=b_post_filter)
     pcm = plan.run().cpu().numpy().astype(np.float64)
     out = [pcm[plan.out_off_host[u]:plan.out_off_host[u + 1]] for u in range(len(utts))]
     if b_out_hpf:

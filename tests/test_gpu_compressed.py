@@ -185,3 +185,19 @@ def test_low_dim_copy_synthesis_roundtrip(mp, orc):
     assert len(v) == len(ref)
     # features differ by ~1e-4 (fp32 warp) -> the waveform by a few 1e-4 of peak
     assert np.max(np.abs(v - ref)) <= 2e-3 * np.max(np.abs(ref))
+
+
+def test_device_post_filter_and_gains(mp, orc, golden_dir):
+    """mpx_post_filter vs the reference's post_filter golden (G6); batched generation with the device post-filter."""
+    from magphase_amd.engine import get_engine
+    g, mm, rr, ii, lf = _hvd704(golden_dir)
+    eng = get_engine()
+    for fs, key in ((48000, "pf48"), (16000, "pf16")):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            out = eng.post_filter(eng.to_device(mm, np.float32), fs).cpu().numpy().astype(np.float64)
+        assert np.max(np.abs(out - g[key])) < 5e-6
+    np.random.seed(int(g["seed"]))
+    v = mp.synthesis_from_compressed_batch([(mm, rr, ii, lf)], 48000, b_post_filter=True)[0]
+    ref = g["syn_pf_hpf1"]
+    assert len(v) == len(ref) and np.max(np.abs(v - ref)) <= COMP_PCM_TOL * np.max(np.abs(ref))
