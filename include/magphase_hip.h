@@ -198,6 +198,21 @@ int mpx_noise_gains(void* stream, const float* sums, const int32_t* voiced, cons
 int mpx_post_filter(void* stream, const float* mag_mel_log, int64_t n_frames, int32_t dim, const int32_t* half_len,
                     int32_t nx_first, int32_t nx_last, const float* tilt, float* out);
 
+/*
+ * Output high-pass filter (magphase.py:981-995: scipy.signal.butter(4, 40 Hz) + lfilter) in float64 on the device,
+ * as a cascade of the two second-order sections of the same Butterworth design (scipy output='sos'), each run as
+ * a blocked scan: zero-state recurrence per block of mpx_hpf_block() samples, block end states chained per
+ * utterance through A^B, free responses added from G[n] = C A^n.  (The 4th-order direct form cannot be chained in
+ * float64: clustered poles at |z| ~ 0.997.  The cascade agrees with lfilter to ~1e-7 of peak = lfilter's own noise.)
+ * sos_host: HOST pointer to 2 x 6 float64 (b0 b1 b2 a0 a1 a2 per section); pmat: float64 [2 x 4] (A^B row-major per
+ * section); gtab: float64 [2 x B x 2]; blk_off: int32[n_utts+1] cumulative block counts; zend/zstart: float64
+ * scratch [total_blocks x 2]; y_tmp, y: float64 [total samples] (y = output).  Tables: hostmath.hpf_tables.
+ */
+int mpx_hpf_block(void);
+int mpx_output_hpf(void* stream, const float* pcm, const int64_t* out_off, const int32_t* blk_off, int32_t n_utts,
+                   int64_t max_len, const double* sos_host, const double* pmat, const double* gtab, double* zend,
+                   double* zstart, double* y_tmp, double* y);
+
 #ifdef __cplusplus
 }
 #endif

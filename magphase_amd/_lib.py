@@ -29,6 +29,8 @@ SYMBOLS = (
     "mpx_min_phase",
     "mpx_noise_gains",
     "mpx_post_filter",
+    "mpx_hpf_block",
+    "mpx_output_hpf",
 )
 
 _lib = None
@@ -86,6 +88,10 @@ def load():
     lib.mpx_noise_gains.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp]
     lib.mpx_post_filter.restype = ctypes.c_int
     lib.mpx_post_filter.argtypes = [vp, vp, i64, i32, vp, i32, i32, vp, vp]
+    lib.mpx_hpf_block.restype = ctypes.c_int
+    lib.mpx_hpf_block.argtypes = []
+    lib.mpx_output_hpf.restype = ctypes.c_int
+    lib.mpx_output_hpf.argtypes = [vp, vp, vp, vp, i32, i64, vp, vp, vp, vp, vp, vp, vp]
     _lib = lib
     return lib
 

@@ -344,6 +344,75 @@ __global__ __launch_bounds__(256) void k_post_filter(const float* __restrict__ x
 }
 
 // ---------------------------------------------------------------------------------------------
+// output high-pass (magphase.py:981-995: butter(4, 40 Hz) + lfilter), float64, blocked scan over a CASCADE of two
+// second-order sections.  Each section's direct-form-II-transposed recurrence
+//   y = b0 x + z0 ; z0 = b1 x + z1 - a1 y ; z1 = b2 x - a2 y
+// is linear in (z, x): k_hpf_zero_state runs it per block of kHpfBlock samples from z = 0 (parallel over blocks),
+// k_hpf_carry chains the block end states z_{j+1} = A^B z_j + zs_j per utterance (2x2, serial, tiny), k_hpf_apply adds
+// each block's free response G[n] . z_start (G[n] = C A^n, host table).  Why a cascade: chaining the states of the
+// 4th-order direct form is hopeless in float64 (four poles at |z| ~ 0.997 within 0.005 of each other: A^1024 has
+// entries of 3e8 and the block hand-over loses everything -- measured), while the biquads' tables stay below 120.
+// The cascade differs from scipy's direct-form lfilter by ~1e-7 of peak, which is lfilter's own round-off noise.
+// ---------------------------------------------------------------------------------------------
+constexpr int kHpfBlock = 1024;
+
+struct BiquadCoef {
+    double b0, b1, b2, a1, a2;
+};
+
+template <typename TIn>
+__global__ __launch_bounds__(64) void k_hpf_zero_state(const TIn* __restrict__ x, const long long* __restrict__ off,
+                                                       const int* __restrict__ blk_off, BiquadCoef c,
+                                                       double* __restrict__ y, double* __restrict__ zend) {
+    // one thread per (utterance, block); blk_off[u] = first global block index of utterance u
+    const int u = blockIdx.y;
+    const int nb = blk_off[u + 1] - blk_off[u];
+    const int j = blockIdx.x * 64 + threadIdx.x;
+    if (j >= nb) return;
+    const long long n0 = off[u] + (long long)j * kHpfBlock;
+    const long long n1 = min(n0 + kHpfBlock, off[u + 1]);
+    double z0 = 0, z1 = 0;
+    for (long long n = n0; n < n1; ++n) {
+        const double xv = (double)x[n];
+        const double yv = c.b0 * xv + z0;
+        z0 = c.b1 * xv + z1 - c.a1 * yv;
+        z1 = c.b2 * xv - c.a2 * yv;
+        y[n] = yv;
+    }
+    double* ze = zend + 2 * (long long)(blk_off[u] + j);
+    ze[0] = z0;
+    ze[1] = z1;
+}
+
+__global__ __launch_bounds__(64) void k_hpf_carry(const int* __restrict__ blk_off, int n_utts,
+                                                  const double* __restrict__ pmat /* A^B, row-major 2x2 */,
+                                                  const double* __restrict__ zend, double* __restrict__ zstart) {
+    const int u = blockIdx.x * 64 + threadIdx.x;
+    if (u >= n_utts) return;
+    double z0 = 0, z1 = 0;
+    for (int g = blk_off[u]; g < blk_off[u + 1]; ++g) {
+        zstart[2 * (long long)g + 0] = z0;
+        zstart[2 * (long long)g + 1] = z1;
+        const double n0 = pmat[0] * z0 + pmat[1] * z1 + zend[2 * (long long)g + 0];
+        const double n1 = pmat[2] * z0 + pmat[3] * z1 + zend[2 * (long long)g + 1];
+        z0 = n0;
+        z1 = n1;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_hpf_apply(const long long* __restrict__ off, const int* __restrict__ blk_off,
+                                                   const double* __restrict__ gtab /* [kHpfBlock x 2] */,
+                                                   const double* __restrict__ zstart, double* __restrict__ y) {
+    const int u = blockIdx.y;
+    const long long len = off[u + 1] - off[u];
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= len) return;
+    const int j = (int)(t / kHpfBlock), r = (int)(t - (long long)j * kHpfBlock);
+    const double* z = zstart + 2 * (long long)(blk_off[u] + j);
+    y[off[u] + t] += gtab[2 * r] * z[0] + gtab[2 * r + 1] * z[1];
+}
+
+// ---------------------------------------------------------------------------------------------
 // minimum-phase spectrum from a magnitude spectrum (complex cepstrum), la.build_min_phase_from_mag_spec
 // (libaudio.py:920-934): ln|X| -> even extension -> real IFFT (cepstrum c) -> causal fold (c[1..N/2-1] *= 2,
 // c[N/2+1..] = 0) -> FFT -> exp.  Since Re FFT(fold c) == ln|X|, only the phase phi = Im FFT(fold c) is new: the
@@ -807,6 +876,38 @@ int mpx_post_filter(void* stream, const float* mag_mel_log, int64_t n_frames, in
     const dim3 grid((unsigned)((n_frames + rows - 1) / rows)), block(256);
     hipLaunchKernelGGL(k_post_filter, grid, block, sizeof(float) * (size_t)rows * dim, (hipStream_t)stream,
                        mag_mel_log, (long long)n_frames, (int)dim, half_len, (int)nx_first, (int)nx_last, tilt, out);
+    MPX_HIP_CHECK(hipGetLastError());
+    return MPX_OK;
+}
+
+int mpx_hpf_block(void) { return kHpfBlock; }
+
+int mpx_output_hpf(void* stream, const float* pcm, const int64_t* out_off, const int32_t* blk_off, int32_t n_utts,
+                   int64_t max_len, const double* sos_host, const double* pmat, const double* gtab, double* zend,
+                   double* zstart, double* y_tmp, double* y) {
+    if (n_utts < 0 || max_len < 0) return fail(MPX_ERR_ARG, "mpx_output_hpf: negative size%s");
+    if (n_utts == 0 || max_len == 0) return MPX_OK;
+    if (!pcm || !out_off || !blk_off || !sos_host || !pmat || !gtab || !zend || !zstart || !y_tmp || !y)
+        return fail(MPX_ERR_ARG, "mpx_output_hpf: null pointer%s");
+    if (n_utts > 65535) return fail(MPX_ERR_ARG, "mpx_output_hpf: at most 65535 utterances per call%s");
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned max_blocks = (unsigned)((max_len + kHpfBlock - 1) / kHpfBlock);
+    const dim3 gz((max_blocks + 63) / 64, (unsigned)n_utts), gc((unsigned)((n_utts + 63) / 64)),
+        ga((unsigned)((max_len + 255) / 256), (unsigned)n_utts);
+    for (int sec = 0; sec < 2; ++sec) {
+        const double* q = sos_host + 6 * sec;   // scipy sos row: b0 b1 b2 a0 a1 a2
+        const BiquadCoef c{q[0] / q[3], q[1] / q[3], q[2] / q[3], q[4] / q[3], q[5] / q[3]};
+        double* out = (sec == 0) ? y_tmp : y;
+        if (sec == 0)
+            hipLaunchKernelGGL(k_hpf_zero_state<float>, gz, dim3(64), 0, s, pcm, (const long long*)out_off, blk_off, c,
+                               out, zend);
+        else
+            hipLaunchKernelGGL(k_hpf_zero_state<double>, gz, dim3(64), 0, s, (const double*)y_tmp,
+                               (const long long*)out_off, blk_off, c, out, zend);
+        hipLaunchKernelGGL(k_hpf_carry, gc, dim3(64), 0, s, blk_off, (int)n_utts, pmat + 4 * sec, zend, zstart);
+        hipLaunchKernelGGL(k_hpf_apply, ga, dim3(256), 0, s, (const long long*)out_off, blk_off,
+                           gtab + 2 * (size_t)kHpfBlock * sec, zstart, out);
+    }
     MPX_HIP_CHECK(hipGetLastError());
     return MPX_OK;
 }

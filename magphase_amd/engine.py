@@ -121,6 +121,39 @@ class Engine:
                                                 nx0, nx1, d_tilt.data_ptr(), out.data_ptr()), "mpx_post_filter")
         return out
 
+    def output_hpf(self, pcm, out_off_host, fs):
+        """
+        magphase.py:981-995 on the device: float32 pcm [total] (utterances concatenated at out_off_host) ->
+        float64 tensor, every utterance filtered from a zero state (mpx_output_hpf: cascade of biquads, blocked scan).
+        """
+        torch = _torch()
+        block = int(self.lib.mpx_hpf_block())
+        key = ("hpf", int(fs))
+        if key not in self._tables:
+            sos, pm, g = hm.hpf_tables(fs, block)
+            self._tables[key] = (sos, self.to_device(pm, np.float64), self.to_device(g, np.float64))
+        sos, d_pm, d_g = self._tables[key]
+        out_off_host = np.asarray(out_off_host, dtype=np.int64)
+        lens = np.diff(out_off_host)
+        nblk = (lens + block - 1) // block
+        blk_off = np.concatenate(([0], np.cumsum(nblk))).astype(np.int32)
+        d_off = self.to_device(out_off_host, np.int64)
+        d_blk = self.to_device(blk_off, np.int32)
+        total, tb = int(out_off_host[-1]), int(blk_off[-1])
+        zend = torch.empty(2 * max(tb, 1), dtype=torch.float64, device=self.device)
+        zstart = torch.empty(2 * max(tb, 1), dtype=torch.float64, device=self.device)
+        y_tmp = torch.empty(max(total, 1), dtype=torch.float64, device=self.device)
+        y = torch.empty(max(total, 1), dtype=torch.float64, device=self.device)
+        import ctypes
+        sos_c = np.ascontiguousarray(sos, dtype=np.float64)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.mpx_output_hpf(self.stream_ptr(), pcm.data_ptr(), d_off.data_ptr(), d_blk.data_ptr(),
+                                               int(lens.size), int(lens.max()) if lens.size else 0,
+                                               sos_c.ctypes.data_as(ctypes.c_void_p), d_pm.data_ptr(), d_g.data_ptr(),
+                                               zend.data_ptr(), zstart.data_ptr(), y_tmp.data_ptr(), y.data_ptr()),
+                       "mpx_output_hpf")
+        return y[:total]
+
     def synth_comp_slots(self):
         torch = _torch()
         with torch.cuda.device(self.device):

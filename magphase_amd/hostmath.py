@@ -346,3 +346,26 @@ def post_filter_tables(mag_dim, fs, av_len_at_zero=None, av_len_at_nyq=None, boo
     v_nx = np.arange(np.floor(av0 / 2), mag_dim - np.floor(avn / 2)).astype(int)
     v_lens = (2 * np.ceil(np.linspace(av0, avn, v_nx.size) / 2) - 1).astype(int)
     return int(v_nx[0]), int(v_nx[-1]), (v_lens // 2).astype(np.int64), np.linspace(b0, bn, mag_dim)
+
+
+def hpf_tables(fs, block):
+    """
+    Output high-pass of synthesis_from_compressed (magphase.py:981-995): Butterworth order 4 at 40 Hz as two
+    second-order sections (the same design, scipy output='sos') and, per section, the tables of the blocked scan of
+    mpx_output_hpf: the direct-form-II-transposed state update z' = A z + Bx x with A = [[-a1, 1], [-a2, 0]],
+    y = z0 + b0 x.  Returns (sos [2 x 6], A^block [2 x 4], G [2 x block x 2] with G[n] = [1, 0] A^n), float64.
+    """
+    from scipy import signal
+
+    sos = np.ascontiguousarray(signal.butter(4, 40 / (fs / 2.0), btype='highpass', output='sos'), dtype=np.float64)
+    pm = np.zeros((2, 4))
+    g = np.zeros((2, block, 2))
+    for sec in range(2):
+        a1, a2 = sos[sec, 4] / sos[sec, 3], sos[sec, 5] / sos[sec, 3]
+        amat = np.array([[-a1, 1.0], [-a2, 0.0]])
+        row = np.array([1.0, 0.0])
+        for n in range(block):
+            g[sec, n] = row
+            row = row @ amat
+        pm[sec] = np.linalg.matrix_power(amat, block).reshape(-1)
+    return sos, pm, g

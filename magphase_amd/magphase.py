@@ -197,11 +197,12 @@ def synthesis_from_compressed_batch(utts, fs, fft_len=None, b_voi_ap_win=True, b
     plan = CompressedSynthesisPlan(engine, utts, fs, fft_len=fft_len, b_voi_ap_win=b_voi_ap_win,
                                    b_const_rate=b_const_rate, alpha_phase=alpha_phase, noise=noise,
                                    per_phase_type=per_phase_type, post_filter=b_post_filter)
-    pcm = plan.run().cpu().numpy().astype(np.float64)
-    out = [pcm[plan.out_off_host[u]:plan.out_off_host[u + 1]] for u in range(len(utts))]
-    if b_out_hpf:
-        out = [_output_hpf(v, fs) for v in out]
-    return out
+    pcm_dev = plan.run()
+    if b_out_hpf:   # magphase.py:981-995, float64 on the device (engine.output_hpf); _output_hpf is the host form
+        pcm = engine.output_hpf(pcm_dev, plan.out_off_host, fs).cpu().numpy()
+    else:
+        pcm = pcm_dev.cpu().numpy().astype(np.float64)
+    return [pcm[plan.out_off_host[u]:plan.out_off_host[u + 1]] for u in range(len(utts))]
 
 
 def synthesis_from_compressed(m_mag_mel_log, m_real_mel, m_imag_mel, v_lf0, fs, fft_len=None, b_voi_ap_win=True,

@@ -201,3 +201,20 @@ def test_device_post_filter_and_gains(mp, orc, golden_dir):
     v = mp.synthesis_from_compressed_batch([(mm, rr, ii, lf)], 48000, b_post_filter=True)[0]
     ref = g["syn_pf_hpf1"]
     assert len(v) == len(ref) and np.max(np.abs(v - ref)) <= COMP_PCM_TOL * np.max(np.abs(ref))
+
+
+def test_device_output_hpf_matches_lfilter(mp):
+    """mpx_output_hpf (cascade of biquads, blocked float64 scan) vs scipy.signal.lfilter on ragged utterances."""
+    from scipy import signal
+    from magphase_amd.engine import get_engine
+    eng = get_engine()
+    rng = np.random.RandomState(2)
+    for fs in (48000, 16000):
+        lens = [1, 5, 1023, 1024, 1025, 50000, 3000]
+        sigs = [rng.uniform(-1, 1, n).astype(np.float32) for n in lens]
+        off = np.concatenate(([0], np.cumsum(lens)))
+        y = eng.output_hpf(eng.to_device(np.concatenate(sigs), np.float32), off, fs).cpu().numpy()
+        b_, a_ = signal.butter(4, 40 / (fs / 2.0), btype="highpass")
+        for u, x in enumerate(sigs):
+            ref = signal.lfilter(b_, a_, x.astype(np.float64))
+            assert np.max(np.abs(y[off[u]:off[u + 1]] - ref)) <= 1e-6 * max(1.0, np.max(np.abs(ref)))
