@@ -27,6 +27,14 @@ __global__ __launch_bounds__(kThreads) void k_analysis(const float* __restrict__
     float* xbuf = smem + P * 64 * 2 + wave * (P * kXStride);
     // byte address of xbuf in LDS (the dynamic segment starts at 0: the kernel has no static __shared__)
     const unsigned xbuf_byte = 4u * (unsigned)(P * 64 * 2 + rfl(wave) * (P * kXStride));
+#ifdef MPX_ANA_STAGE2
+    // separate per-wave staging buffer: the next frame's samples are copied while the whole FFT runs
+    float* sbuf = smem + P * 64 * 2 + kWavesPerBlock * (P * kXStride) + wave * kTile;
+    const unsigned sbuf_byte = 4u * (unsigned)(P * 64 * 2 + kWavesPerBlock * (P * kXStride) + rfl(wave) * kTile);
+#else
+    float* sbuf = xbuf;
+    const unsigned sbuf_byte = xbuf_byte;
+#endif
     for (int i = threadIdx.x; i < P * 64; i += kThreads) tw[i] = tw_g[i];
     __syncthreads();
 
@@ -43,9 +51,13 @@ __global__ __launch_bounds__(kThreads) void k_analysis(const float* __restrict__
     // after the FFT's exchange) while this frame's second FFT pass and epilogue run.  All 99 stores of the epilogue
     // are issued after that copy, so "copy landed" == vmcnt <= 63: no wait on the store drain.
     FrameGeom g = frame_geom(sig, fpos[f], fleft[f], fright[f], N);
-    stage_samples_async(g, 0, kTile, xbuf_byte, lane_id);
+    stage_samples_async(g, 0, kTile, sbuf_byte, lane_id);
     staged_wait<0>();
 
+#ifdef MPX_PROBE_WAITCYC
+    long long cyc_wait = 0, cyc_frames = 0, cyc_r1 = 0, cyc_r2 = 0, cyc_r3 = 0, cyc_r4 = 0;
+    const long long cyc_t0 = clock64();
+#endif
     for (; f < nframes; f += fstep) {
         // Launder the per-lane invariants once per frame: otherwise LICM hoists every (lane x register)
         // twiddle product out of this loop and the kernel spills.
@@ -60,22 +72,67 @@ __global__ __launch_bounds__(kThreads) void k_analysis(const float* __restrict__
         float re[P], im[P];
 #pragma unroll
         for (int j = 0; j < P; ++j) re[j] = im[j] = 0.0f;
+#ifdef MPX_PROBE_WAITCYC
+        const long long tr0 = clock64();
+#endif
         const int ntiles = (g.len + kTile - 1) / kTile;   // 1 except for frames longer than 64*P samples
+#ifdef MPX_ANA_GATHER2   // measured equal to the in-place form below (0.387 vs 0.384 ms): kept for A/B only
+        // Gather in FFT order straight from the staged samples, window applied in registers.  Two passes so that no
+        // LDS read is consumed inside a branch (that costs one full LDS latency per element): (A) issue every read of
+        // the rows that hold samples, (B) window + mask.  Buffer index m holds sample k = (m + rot) mod N, valid iff
+        // k < len; row j <-> m in [128 j, 128 j + 128).
         for (int t = 0; t < ntiles; ++t) {
             const int tile0 = t * kTile;
             if (t > 0) {                                   // rare slow path: not prefetched
-                stage_samples_async(g, tile0, kTile, xbuf_byte, lane);
+                wave_sync();
+                stage_samples_async(g, tile0, kTile, sbuf_byte, lane);
+                staged_wait<0>();
+            }
+            const int hi = min(g.len, tile0 + kTile);
+            const int kbase = 2 * lane + g.rot;
+            float a0[P], a1[P];
+#pragma unroll
+            for (int j = 0; j < P; ++j) {
+                const int m0 = 128 * j;
+                const bool any = (m0 < g.len - g.rot) || (m0 + 127 >= N - g.rot);
+                a0[j] = a1[j] = 0.0f;
+                if (any) {
+                    const int k0 = (kbase + m0) & (N - 1), k1 = (kbase + m0 + 1) & (N - 1);
+                    a0[j] = sbuf[min(max(k0 - tile0, 0), kTile - 1)];
+                    a1[j] = sbuf[min(max(k1 - tile0, 0), kTile - 1)];
+                }
+            }
+            int kbase2 = kbase;   // laundered: pass B recomputes the indices instead of keeping 2P of them live
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kbase2)::"memory");
+#pragma unroll
+            for (int j = 0; j < P; ++j) {
+                const int m0 = 128 * j;
+                const bool any = (m0 < g.len - g.rot) || (m0 + 127 >= N - g.rot);
+                if (any) {
+                    const int k0 = (kbase2 + m0) & (N - 1), k1 = (kbase2 + m0 + 1) & (N - 1);
+                    const float w0 = hann_half(k0, g.L, g.LR, g.kadd, g.invL, g.invR);
+                    const float w1 = hann_half(k1, g.L, g.LR, g.kadd, g.invL, g.invR);
+                    re[j] = (k0 >= tile0 && k0 < hi) ? a0[j] * w0 : re[j];
+                    im[j] = (k1 >= tile0 && k1 < hi) ? a1[j] * w1 : im[j];
+                }
+            }
+        }
+#else
+        for (int t = 0; t < ntiles; ++t) {
+            const int tile0 = t * kTile;
+            if (t > 0) {                                   // rare slow path: not prefetched
+                stage_samples_async(g, tile0, kTile, sbuf_byte, lane);
                 staged_wait<0>();
             }
             const int hi = min(g.len, tile0 + kTile);
             for (int kb = tile0 + lane; kb < hi; kb += 256) {   // 4 rows per step: 4 LDS reads in flight, not 1
                 float v[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = (kb + 64 * r < hi) ? xbuf[kb + 64 * r - tile0] : 0.0f;
+                for (int r = 0; r < 4; ++r) v[r] = (kb + 64 * r < hi) ? sbuf[kb + 64 * r - tile0] : 0.0f;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int k = kb + 64 * r;
-                    if (k < hi) xbuf[k - tile0] = v[r] * hann_half(k, g.L, g.LR, g.kadd, g.invL, g.invR);
+                    if (k < hi) sbuf[k - tile0] = v[r] * hann_half(k, g.L, g.LR, g.kadd, g.invL, g.invR);
                 }
             }
             wave_sync();
@@ -90,25 +147,52 @@ __global__ __launch_bounds__(kThreads) void k_analysis(const float* __restrict__
                     k0 = (k0 >= N) ? k0 - N : k0;
                     int k1 = m + 1 + g.rot;
                     k1 = (k1 >= N) ? k1 - N : k1;
-                    if (k0 >= tile0 && k0 < hi) re[j] = xbuf[k0 - tile0];
-                    if (k1 >= tile0 && k1 < hi) im[j] = xbuf[k1 - tile0];
+                    if (k0 >= tile0 && k0 < hi) re[j] = sbuf[k0 - tile0];
+                    if (k1 >= tile0 && k1 < hi) im[j] = sbuf[k1 - tile0];
                 }
             }
             wave_sync();
         }
+#endif
 
+#ifdef MPX_PROBE_WAITCYC
+        asm volatile("" : "+v"(re[0]), "+v"(im[0]));
+        const long long tr1 = clock64();
+#endif
+        const long long fn = f + fstep;
+        FrameGeom gn = g;
+#ifdef MPX_ANA_STAGE2
+        if (fn < nframes) {
+            gn = frame_geom(sig, fpos[fn], fleft[fn], fright[fn], N);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the gather's LDS reads have returned
+            stage_samples_async(gn, 0, kTile, sbuf_byte, lane);
+        }
+        wave_fft_front<P, -1>(re, im, tw, xbuf, lane);
+#else
         wave_fft_front<P, -1>(re, im, tw, xbuf, lane);
 
         // ---- the exchange buffer is idle from here on: start the copy of the next frame's samples into it
-        const long long fn = f + fstep;
-        FrameGeom gn = g;
         if (fn < nframes) {
             gn = frame_geom(sig, fpos[fn], fleft[fn], fright[fn], N);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the exchange's own LDS reads have returned
-            stage_samples_async(gn, 0, kTile, xbuf_byte, lane);
+            stage_samples_async(gn, 0, kTile, sbuf_byte, lane);
         }
+#endif
+#ifdef MPX_PROBE_WAITCYC
+        asm volatile("" : "+v"(re[0]), "+v"(im[0]));
+        const long long tr2 = clock64();
+#endif
 
         fft_inreg<P, -1>(re, im);
+#ifdef MPX_PROBE_WAITCYC
+        asm volatile("" : "+v"(re[0]), "+v"(im[0]), "+v"(re[P - 1]), "+v"(im[P - 1]));
+        const long long tr3 = clock64();
+#endif
+#ifdef MPX_ANA_WAIT_EARLY
+        // Wait for the copy BEFORE this frame's store burst: what is outstanding here is the copy and the previous
+        // frame's stores (a whole frame old); the 99 stores below are then never waited for inside this frame.
+        if (fn < nframes) staged_wait<0>();
+#endif
 
         // Real-FFT split, one (k, M-k) bin pair per step: lane kappa owns k = kappa + 64 q for q < P/2 (the even
         // registers) and also produces the mirrored bin M-k from the same E/T terms:
@@ -172,8 +256,22 @@ __global__ __launch_bounds__(kThreads) void k_analysis(const float* __restrict__
             ilo[M / 2] = xi * r;
         }
         g = gn;
+#ifndef MPX_ANA_WAIT_EARLY
+#ifdef MPX_PROBE_WAITCYC
+        const long long tw0 = clock64();
+        cyc_r1 += tr1 - tr0; cyc_r2 += tr2 - tr1; cyc_r3 += tr3 - tr2; cyc_r4 += tw0 - tr3;
+#endif
         if (fn < nframes) staged_wait<63>();   // >= 63 stores were issued after the copy: it has landed
+#ifdef MPX_PROBE_WAITCYC
+        cyc_wait += clock64() - tw0;
+        ++cyc_frames;
+#endif
+#endif
     }
+#ifdef MPX_PROBE_WAITCYC
+    if (lane_id == 0 && (blockIdx.x % 37) == 0 && wave == 3)
+        printf("WAITCYC block %d frames %lld total %lld wait %lld r1 %lld r2 %lld r3 %lld r4 %lld\n", (int)blockIdx.x, cyc_frames, clock64() - cyc_t0, cyc_wait, cyc_r1, cyc_r2, cyc_r3, cyc_r4);
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -607,13 +705,13 @@ int mpx_analysis_frames(void* stream, int fft_len, const void* tables, const flo
     const dim3 grid(grid_for(n_frames)), block(kThreads);
     hipStream_t s = (hipStream_t)stream;
     if (P == 32) {
-        if (int rc = set_lds(k_analysis<32>, lds_bytes<32>())) return rc;
-        hipLaunchKernelGGL(k_analysis<32>, grid, block, lds_bytes<32>(), s, sig, (const long long*)frame_pos,
+        if (int rc = set_lds(k_analysis<32>, lds_bytes_ana<32>())) return rc;
+        hipLaunchKernelGGL(k_analysis<32>, grid, block, lds_bytes_ana<32>(), s, sig, (const long long*)frame_pos,
                            frame_left, frame_right, (long long)n_frames, (const float2*)tables, out_mag, out_real,
                            out_imag);
     } else {
-        if (int rc = set_lds(k_analysis<16>, lds_bytes<16>())) return rc;
-        hipLaunchKernelGGL(k_analysis<16>, grid, block, lds_bytes<16>(), s, sig, (const long long*)frame_pos,
+        if (int rc = set_lds(k_analysis<16>, lds_bytes_ana<16>())) return rc;
+        hipLaunchKernelGGL(k_analysis<16>, grid, block, lds_bytes_ana<16>(), s, sig, (const long long*)frame_pos,
                            frame_left, frame_right, (long long)n_frames, (const float2*)tables, out_mag, out_real,
                            out_imag);
     }

@@ -40,6 +40,15 @@ constexpr size_t lds_bytes() {
     return sizeof(float) * (size_t)(P * 64 * 2 + kWavesPerBlock * P * kXStride);
 }
 
+template <int P>
+constexpr size_t lds_bytes_ana() {
+#ifdef MPX_ANA_STAGE2
+    return lds_bytes<P>() + sizeof(float) * (size_t)(kWavesPerBlock * 64 * P);
+#else
+    return lds_bytes<P>();
+#endif
+}
+
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
 // ---------------------------------------------------------------------------------------------
