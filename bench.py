@@ -131,7 +131,7 @@ def main():
     N = aplan.fft_len
     H = N // 2 + 1
     F = aplan.total_frames
-    feats = tuple(eng.empty((F, H)) for _ in range(3))
+    feats = tuple(eng.empty_feats(F, H) for _ in range(3))
     strips = eng.empty((splan.strip_floats,))
     pcm_out = eng.empty((splan.total_out,))
 
@@ -244,7 +244,7 @@ def main_lowdim(args):
     utts = make_batch(0)
     aplan = CompressedAnalysisPlan(eng, utts, mag_dim=60, phase_dim=45, b_const_rate=True)
     N, H = aplan.fft_len, aplan.fft_len // 2 + 1
-    feats = tuple(eng.empty((aplan.lossless.total_frames, H)) for _ in range(3))
+    feats = tuple(eng.empty_feats(aplan.lossless.total_frames, H) for _ in range(3))
     out = aplan.run(feats=feats)
     torch.cuda.synchronize()
     res = [t.cpu().numpy().astype(np.float64) for t in out]

@@ -48,21 +48,32 @@ int mpx_tables_init(void* stream, int fft_len, void* tables);
  * frame_pos  : int64[n_frames]  absolute index in `sig` of each frame's epoch (utterance offset + pm)
  * frame_left : int32[n_frames]  left length  (pm - previous epoch; == v_shift of the reference)
  * frame_right: int32[n_frames]  right length (next epoch - pm)
- * out_*      : float32 [n_frames x H]
+ * out_*      : float32 [n_frames x H], row pitch `ld` floats (ld >= H; dense ld == H is the fastest, see mpx_feat_ld)
  * The host keeps the fp64 epoch/index math (np.round, int casts) -- it is never recomputed on the device.
  */
 int mpx_analysis_frames(void* stream, int fft_len, const void* tables, const float* sig,
                         const int64_t* frame_pos, const int32_t* frame_left, const int32_t* frame_right,
-                        int64_t n_frames, float* out_mag, float* out_real, float* out_imag);
+                        int64_t n_frames, float* out_mag, float* out_real, float* out_imag, int64_t ld);
+
+/*
+ * Row pitch (in floats) the lossless feature matrices should be allocated with.  Any ld >= H is CORRECT for every
+ * entry point that takes `ld` (so the matrices may live inside wider buffers); mpx_feat_ld() returns the pitch
+ * measured fastest on MI355X, which is the reference's dense [F x H] layout, ld == H: padding the rows to a
+ * multiple of 32 or 64 floats leaves one partially written 128-byte line per row (the lone Nyquist bin) and costs
+ * 7 % of the analysis kernel.  Returns 0 for an unsupported fft_len.
+ */
+int64_t mpx_feat_ld(int fft_len);
 
 /*
  * Lossless synthesis, per-frame part.  Replaces magphase.py:1761-1770 (synthesis_from_lossless):
  *   X = mag * (real + j imag)/|real + j imag|  (|.|==0 -> 1), Hermitian extension with Im X[0]=Im X[N/2]=0
  *   (libaudio.py:369-388), np.fft.ifft(.).real, np.fft.fftshift  (epoch at index N/2).
+ * mag/real/imag : float32 [n_frames x H], row pitch `ld` floats
  * frames_out : float32 [n_frames x N]
  */
 int mpx_synthesis_lossless_frames(void* stream, int fft_len, const void* tables, const float* mag,
-                                  const float* real, const float* imag, int64_t n_frames, float* frames_out);
+                                  const float* real, const float* imag, int64_t n_frames, float* frames_out,
+                                  int64_t ld);
 
 /*
  * PSOLA overlap-add, gather form, deterministic (ascending frame order).  Replaces magphase.py:34-62 ola():
@@ -98,7 +109,7 @@ int mpx_synth_ola_slots(void); /* wave slots the current device runs concurrentl
 int mpx_synthesis_lossless_ola(void* stream, int fft_len, const void* tables, const float* mag, const float* real,
                                const float* imag, const void* chunks, int32_t n_chunks, const int32_t* slot_off,
                                const int32_t* slot_chunks, int32_t n_slots, const int32_t* pm_rel,
-                               int32_t territory, float* strips);
+                               int32_t territory, float* strips, int64_t ld /* row pitch of mag/real/imag */);
 int mpx_ola_fixup(void* stream, int fft_len, int32_t territory, const float* strips, int32_t n_utts,
                   const int32_t* utt_chunk_off, const int32_t* strip_id, const int32_t* out_start,
                   const int64_t* out_off, int32_t max_territories /* max over utterances of their territory count */,
@@ -168,7 +179,7 @@ int mpx_synthesis_compressed_ola(void* stream, int fft_len, const void* tables, 
 int mpx_mel_warp(void* stream, int64_t n_frames, int32_t n_bins, const float* mag, const float* real, const float* imag,
                  const int32_t* row0, const int32_t* row1, const float* row_t, const float* w_mag, int32_t mag_dim,
                  const float* w_phase, int32_t phase_dim, const float* voiced, float* out_mag, float* out_real,
-                 float* out_imag);
+                 float* out_imag, int64_t ld /* row pitch of mag/real/imag in floats, >= n_bins */);
 
 /*
  * Minimum-phase spectrum of a magnitude spectrum by the complex cepstrum (la.build_min_phase_from_mag_spec,

@@ -15,6 +15,7 @@ SYMBOLS = (
     "mpx_last_error",
     "mpx_tables_bytes",
     "mpx_tables_init",
+    "mpx_feat_ld",
     "mpx_analysis_frames",
     "mpx_synthesis_lossless_frames",
     "mpx_ola_gather",
@@ -61,15 +62,17 @@ def load():
     lib.mpx_tables_init.restype = ctypes.c_int
     lib.mpx_tables_init.argtypes = [vp, ctypes.c_int, vp]
     lib.mpx_analysis_frames.restype = ctypes.c_int
-    lib.mpx_analysis_frames.argtypes = [vp, ctypes.c_int, vp, vp, vp, vp, vp, i64, vp, vp, vp]
+    lib.mpx_analysis_frames.argtypes = [vp, ctypes.c_int, vp, vp, vp, vp, vp, i64, vp, vp, vp, i64]
+    lib.mpx_feat_ld.restype = i64
+    lib.mpx_feat_ld.argtypes = [ctypes.c_int]
     lib.mpx_synthesis_lossless_frames.restype = ctypes.c_int
-    lib.mpx_synthesis_lossless_frames.argtypes = [vp, ctypes.c_int, vp, vp, vp, vp, i64, vp]
+    lib.mpx_synthesis_lossless_frames.argtypes = [vp, ctypes.c_int, vp, vp, vp, vp, i64, vp, i64]
     lib.mpx_ola_gather.restype = ctypes.c_int
     lib.mpx_ola_gather.argtypes = [vp, ctypes.c_int, vp, i32, vp, vp, vp, vp, i64, vp]
     lib.mpx_synthesis_lossless_ola.restype = ctypes.c_int
     lib.mpx_synth_ola_slots.restype = ctypes.c_int
     lib.mpx_synth_ola_slots.argtypes = []
-    lib.mpx_synthesis_lossless_ola.argtypes = [vp, ctypes.c_int, vp, vp, vp, vp, vp, i32, vp, vp, i32, vp, i32, vp]
+    lib.mpx_synthesis_lossless_ola.argtypes = [vp, ctypes.c_int, vp, vp, vp, vp, vp, i32, vp, vp, i32, vp, i32, vp, i64]
     lib.mpx_ola_fixup.restype = ctypes.c_int
     lib.mpx_ola_fixup.argtypes = [vp, ctypes.c_int, i32, vp, i32, vp, vp, vp, vp, i32, vp]
     lib.mpx_mel_unwarp.restype = ctypes.c_int
@@ -81,7 +84,7 @@ def load():
     lib.mpx_synthesis_compressed_ola.restype = ctypes.c_int
     lib.mpx_synthesis_compressed_ola.argtypes = [vp, ctypes.c_int, vp] + [vp] * 19 + [vp, i32, vp, vp, i32, i32, vp]
     lib.mpx_mel_warp.restype = ctypes.c_int
-    lib.mpx_mel_warp.argtypes = [vp, i64, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, vp, vp, vp, vp]
+    lib.mpx_mel_warp.argtypes = [vp, i64, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, vp, vp, vp, vp, i64]
     lib.mpx_min_phase.restype = ctypes.c_int
     lib.mpx_min_phase.argtypes = [vp, ctypes.c_int, vp, vp, vp, vp, vp, i64, vp, vp, vp]
     lib.mpx_noise_gains.restype = ctypes.c_int

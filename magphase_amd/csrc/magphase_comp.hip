@@ -86,7 +86,8 @@ constexpr int kWarpTile = 64;
 constexpr int kWarpStride = 68;   // floats per LDS row (multiple of 4 for float4 reads)
 
 __global__ __launch_bounds__(256) void k_mel_warp(WarpJobs jobs, long long F, int H, const int* __restrict__ row0,
-                                                  const int* __restrict__ row1, const float* __restrict__ rowt) {
+                                                  const int* __restrict__ row1, const float* __restrict__ rowt,
+                                                  long long ld) {
     __shared__ __attribute__((aligned(16))) float As[kWarpTile][kWarpStride];   // As[kk][f]
     __shared__ __attribute__((aligned(16))) float Ws[kWarpTile][kWarpStride];   // Ws[kk][i]
     const WarpJob job = jobs.j[blockIdx.z];
@@ -118,8 +119,8 @@ __global__ __launch_bounds__(256) void k_mel_warp(WarpJobs jobs, long long F, in
 #pragma unroll
         for (int p = 0; p < 16; ++p) {
             const int fl = fq + 4 * p;
-            xv[p] = job.x[(long long)s_r0[fl] * H + kc];
-            xw[p] = job.x[(long long)s_r1[fl] * H + kc];
+            xv[p] = job.x[(long long)s_r0[fl] * ld + kc];
+            xw[p] = job.x[(long long)s_r1[fl] * ld + kc];
             wv16[p] = job.W[(long long)min(fl, job.nout - 1) * H + kc];
         }
 #pragma unroll
@@ -810,8 +811,8 @@ int mpx_synthesis_compressed_ola(void* stream, int fft_len, const void* tables, 
 int mpx_mel_warp(void* stream, int64_t n_frames, int32_t n_bins, const float* mag, const float* real, const float* imag,
                  const int32_t* row0, const int32_t* row1, const float* row_t, const float* w_mag, int32_t mag_dim,
                  const float* w_phase, int32_t phase_dim, const float* voiced, float* out_mag, float* out_real,
-                 float* out_imag) {
-    if (n_frames < 0 || n_bins <= 0) return fail(MPX_ERR_ARG, "mpx_mel_warp: bad size%s");
+                 float* out_imag, int64_t ld) {
+    if (n_frames < 0 || n_bins <= 0 || ld < n_bins) return fail(MPX_ERR_ARG, "mpx_mel_warp: bad size%s");
     if (mag_dim <= 0 || mag_dim > kWarpTile || phase_dim <= 0 || phase_dim > kWarpTile)
         return fail(MPX_ERR_ARG, "mpx_mel_warp: output dimension must be in 1..64%s");
     if (n_frames == 0) return MPX_OK;
@@ -826,7 +827,7 @@ int mpx_mel_warp(void* stream, int64_t n_frames, int32_t n_bins, const float* ma
     const dim3 grid(1, (unsigned)((n_frames + kWarpTile - 1) / kWarpTile), 3);
     if (grid.y > 65535) return fail(MPX_ERR_ARG, "mpx_mel_warp: too many frames per call (max 4194240)%s");
     hipLaunchKernelGGL(k_mel_warp, grid, dim3(256), 0, (hipStream_t)stream, jobs, (long long)n_frames, (int)n_bins,
-                       row0, row1, row_t);
+                       row0, row1, row_t, (long long)ld);
     MPX_HIP_CHECK(hipGetLastError());
     return MPX_OK;
 }

@@ -13,13 +13,14 @@
 namespace mpx {
 
 template <int P>
-__global__ __launch_bounds__(kThreads) void k_analysis(const float* __restrict__ sig,
-                                                       const long long* __restrict__ fpos,
-                                                       const int* __restrict__ fleft,
-                                                       const int* __restrict__ fright, long long nframes,
-                                                       const float2* __restrict__ tw_g, float* __restrict__ omag,
-                                                       float* __restrict__ oreal, float* __restrict__ oimag) {
-    constexpr int M = 64 * P, N = 2 * M, H = M + 1, LB = ilog2(P), kTile = 64 * P;
+__global__ __launch_bounds__(kAnaThreads) void k_analysis(const float* __restrict__ sig,
+                                                          const long long* __restrict__ fpos,
+                                                          const int* __restrict__ fleft,
+                                                          const int* __restrict__ fright, long long nframes,
+                                                          const float2* __restrict__ tw_g, float* __restrict__ omag,
+                                                          float* __restrict__ oreal, float* __restrict__ oimag,
+                                                          long long ld) {
+    constexpr int M = 64 * P, N = 2 * M, LB = ilog2(P), kTile = 64 * P;
     extern __shared__ float smem[];
     float2* tw = reinterpret_cast<float2*>(smem);
     const int lane_id = threadIdx.x & 63;
@@ -27,15 +28,7 @@ __global__ __launch_bounds__(kThreads) void k_analysis(const float* __restrict__
     float* xbuf = smem + P * 64 * 2 + wave * (P * kXStride);
     // byte address of xbuf in LDS (the dynamic segment starts at 0: the kernel has no static __shared__)
     const unsigned xbuf_byte = 4u * (unsigned)(P * 64 * 2 + rfl(wave) * (P * kXStride));
-#ifdef MPX_ANA_STAGE2
-    // separate per-wave staging buffer: the next frame's samples are copied while the whole FFT runs
-    float* sbuf = smem + P * 64 * 2 + kWavesPerBlock * (P * kXStride) + wave * kTile;
-    const unsigned sbuf_byte = 4u * (unsigned)(P * 64 * 2 + kWavesPerBlock * (P * kXStride) + rfl(wave) * kTile);
-#else
-    float* sbuf = xbuf;
-    const unsigned sbuf_byte = xbuf_byte;
-#endif
-    for (int i = threadIdx.x; i < P * 64; i += kThreads) tw[i] = tw_g[i];
+    for (int i = threadIdx.x; i < P * 64; i += kAnaThreads) tw[i] = tw_g[i];
     __syncthreads();
 
     // lane part of the split twiddle W_N^kappa = e^{-2 pi i kappa / N}
@@ -43,21 +36,17 @@ __global__ __launch_bounds__(kThreads) void k_analysis(const float* __restrict__
     sincospif(-2.0f * (float)kappa<P>(lane_id) / (float)N, &wl_s0, &wl_c0);
 
     const int wave_u = rfl(wave);
-    const long long fstep = (long long)gridDim.x * kWavesPerBlock;
-    long long f = (long long)blockIdx.x * kWavesPerBlock + wave_u;
+    const long long fstep = (long long)gridDim.x * kAnaWaves;
+    long long f = (long long)blockIdx.x * kAnaWaves + wave_u;
     if (f >= nframes) return;
 
     // Software pipeline: the samples of the wave's next frame are copied HBM -> LDS (into the transpose buffer, idle
     // after the FFT's exchange) while this frame's second FFT pass and epilogue run.  All 99 stores of the epilogue
     // are issued after that copy, so "copy landed" == vmcnt <= 63: no wait on the store drain.
     FrameGeom g = frame_geom(sig, fpos[f], fleft[f], fright[f], N);
-    stage_samples_async(g, 0, kTile, sbuf_byte, lane_id);
+    stage_samples_async(g, 0, kTile, xbuf_byte, lane_id);
     staged_wait<0>();
 
-#ifdef MPX_PROBE_WAITCYC
-    long long cyc_wait = 0, cyc_frames = 0, cyc_r1 = 0, cyc_r2 = 0, cyc_r3 = 0, cyc_r4 = 0;
-    const long long cyc_t0 = clock64();
-#endif
     for (; f < nframes; f += fstep) {
         // Launder the per-lane invariants once per frame: otherwise LICM hoists every (lane x register)
         // twiddle product out of this loop and the kernel spills.
@@ -72,67 +61,22 @@ __global__ __launch_bounds__(kThreads) void k_analysis(const float* __restrict__
         float re[P], im[P];
 #pragma unroll
         for (int j = 0; j < P; ++j) re[j] = im[j] = 0.0f;
-#ifdef MPX_PROBE_WAITCYC
-        const long long tr0 = clock64();
-#endif
         const int ntiles = (g.len + kTile - 1) / kTile;   // 1 except for frames longer than 64*P samples
-#ifdef MPX_ANA_GATHER2   // measured equal to the in-place form below (0.387 vs 0.384 ms): kept for A/B only
-        // Gather in FFT order straight from the staged samples, window applied in registers.  Two passes so that no
-        // LDS read is consumed inside a branch (that costs one full LDS latency per element): (A) issue every read of
-        // the rows that hold samples, (B) window + mask.  Buffer index m holds sample k = (m + rot) mod N, valid iff
-        // k < len; row j <-> m in [128 j, 128 j + 128).
         for (int t = 0; t < ntiles; ++t) {
             const int tile0 = t * kTile;
             if (t > 0) {                                   // rare slow path: not prefetched
-                wave_sync();
-                stage_samples_async(g, tile0, kTile, sbuf_byte, lane);
-                staged_wait<0>();
-            }
-            const int hi = min(g.len, tile0 + kTile);
-            const int kbase = 2 * lane + g.rot;
-            float a0[P], a1[P];
-#pragma unroll
-            for (int j = 0; j < P; ++j) {
-                const int m0 = 128 * j;
-                const bool any = (m0 < g.len - g.rot) || (m0 + 127 >= N - g.rot);
-                a0[j] = a1[j] = 0.0f;
-                if (any) {
-                    const int k0 = (kbase + m0) & (N - 1), k1 = (kbase + m0 + 1) & (N - 1);
-                    a0[j] = sbuf[min(max(k0 - tile0, 0), kTile - 1)];
-                    a1[j] = sbuf[min(max(k1 - tile0, 0), kTile - 1)];
-                }
-            }
-            int kbase2 = kbase;   // laundered: pass B recomputes the indices instead of keeping 2P of them live
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kbase2)::"memory");
-#pragma unroll
-            for (int j = 0; j < P; ++j) {
-                const int m0 = 128 * j;
-                const bool any = (m0 < g.len - g.rot) || (m0 + 127 >= N - g.rot);
-                if (any) {
-                    const int k0 = (kbase2 + m0) & (N - 1), k1 = (kbase2 + m0 + 1) & (N - 1);
-                    const float w0 = hann_half(k0, g.L, g.LR, g.kadd, g.invL, g.invR);
-                    const float w1 = hann_half(k1, g.L, g.LR, g.kadd, g.invL, g.invR);
-                    re[j] = (k0 >= tile0 && k0 < hi) ? a0[j] * w0 : re[j];
-                    im[j] = (k1 >= tile0 && k1 < hi) ? a1[j] * w1 : im[j];
-                }
-            }
-        }
-#else
-        for (int t = 0; t < ntiles; ++t) {
-            const int tile0 = t * kTile;
-            if (t > 0) {                                   // rare slow path: not prefetched
-                stage_samples_async(g, tile0, kTile, sbuf_byte, lane);
+                stage_samples_async(g, tile0, kTile, xbuf_byte, lane);
                 staged_wait<0>();
             }
             const int hi = min(g.len, tile0 + kTile);
             for (int kb = tile0 + lane; kb < hi; kb += 256) {   // 4 rows per step: 4 LDS reads in flight, not 1
                 float v[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = (kb + 64 * r < hi) ? sbuf[kb + 64 * r - tile0] : 0.0f;
+                for (int r = 0; r < 4; ++r) v[r] = (kb + 64 * r < hi) ? xbuf[kb + 64 * r - tile0] : 0.0f;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int k = kb + 64 * r;
-                    if (k < hi) sbuf[k - tile0] = v[r] * hann_half(k, g.L, g.LR, g.kadd, g.invL, g.invR);
+                    if (k < hi) xbuf[k - tile0] = v[r] * hann_half(k, g.L, g.LR, g.kadd, g.invL, g.invR);
                 }
             }
             wave_sync();
@@ -147,76 +91,76 @@ __global__ __launch_bounds__(kThreads) void k_analysis(const float* __restrict__
                     k0 = (k0 >= N) ? k0 - N : k0;
                     int k1 = m + 1 + g.rot;
                     k1 = (k1 >= N) ? k1 - N : k1;
-                    if (k0 >= tile0 && k0 < hi) re[j] = sbuf[k0 - tile0];
-                    if (k1 >= tile0 && k1 < hi) im[j] = sbuf[k1 - tile0];
+                    if (k0 >= tile0 && k0 < hi) re[j] = xbuf[k0 - tile0];
+                    if (k1 >= tile0 && k1 < hi) im[j] = xbuf[k1 - tile0];
                 }
             }
             wave_sync();
         }
-#endif
 
-#ifdef MPX_PROBE_WAITCYC
-        asm volatile("" : "+v"(re[0]), "+v"(im[0]));
-        const long long tr1 = clock64();
-#endif
-        const long long fn = f + fstep;
-        FrameGeom gn = g;
-#ifdef MPX_ANA_STAGE2
-        if (fn < nframes) {
-            gn = frame_geom(sig, fpos[fn], fleft[fn], fright[fn], N);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the gather's LDS reads have returned
-            stage_samples_async(gn, 0, kTile, sbuf_byte, lane);
-        }
-        wave_fft_front<P, -1>(re, im, tw, xbuf, lane);
-#else
         wave_fft_front<P, -1>(re, im, tw, xbuf, lane);
 
         // ---- the exchange buffer is idle from here on: start the copy of the next frame's samples into it
+        const long long fn = f + fstep;
+        FrameGeom gn = g;
         if (fn < nframes) {
             gn = frame_geom(sig, fpos[fn], fleft[fn], fright[fn], N);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the exchange's own LDS reads have returned
-            stage_samples_async(gn, 0, kTile, sbuf_byte, lane);
+            stage_samples_async(gn, 0, kTile, xbuf_byte, lane);
         }
-#endif
-#ifdef MPX_PROBE_WAITCYC
-        asm volatile("" : "+v"(re[0]), "+v"(im[0]));
-        const long long tr2 = clock64();
-#endif
 
         fft_inreg<P, -1>(re, im);
-#ifdef MPX_PROBE_WAITCYC
-        asm volatile("" : "+v"(re[0]), "+v"(im[0]), "+v"(re[P - 1]), "+v"(im[P - 1]));
-        const long long tr3 = clock64();
-#endif
-#ifdef MPX_ANA_WAIT_EARLY
-        // Wait for the copy BEFORE this frame's store burst: what is outstanding here is the copy and the previous
-        // frame's stores (a whole frame old); the 99 stores below are then never waited for inside this frame.
-        if (fn < nframes) staged_wait<0>();
-#endif
 
-        // Real-FFT split, one (k, M-k) bin pair per step: lane kappa owns k = kappa + 64 q for q < P/2 (the even
-        // registers) and also produces the mirrored bin M-k from the same E/T terms:
+        // Real-FFT split, one (k, M-k) bin pair per step q = 0 .. P/2-1: lane kappa owns k = kappa + 64 q (register
+        // brev(q)) and also produces the mirrored bin M-k from the same E/T terms:
         //   E = (Z[k] + conj Z[M-k])/2, T = W_N^k (Z[k] - conj Z[M-k])/(2i), X[k] = E + T, X[M-k] = conj(E - T).
         // Z[M-k] lives in lane (64-kappa)&63, register P-1-i (lane 0: own register holding bin (P-q)%P).
         // Bin M/2 is its own mirror (lane 0, register 1: X = conj Z); bin M comes out of the k = 0 pair.
-        float* mlo = omag + f * H + kap;          // X[k]   : ascending lanes, +64 q
-        float* rlo = oreal + f * H + kap;
-        float* ilo = oimag + f * H + kap;
-        float* mhi = omag + f * H + (M - kap);    // X[M-k] : descending lanes, -64 q
-        float* rhi = oreal + f * H + (M - kap);
-        float* ihi = oimag + f * H + (M - kap);
+        //
+        // Store shape.  Measured (tools/ab_bench.py, 12 waves per CU): what costs is a 128-byte line that leaves L2
+        // partially written.  So (1) the steps run in natural q order -- each stream writes consecutive 256-byte
+        // blocks back to back and the shared lines between blocks complete at once (bit-reversed order: +35 %);
+        // (2) the mirrored bins of step q, M-64q-63 .. M-64q, are regrouped into blocks that start at a multiple of
+        // 64 floats from the row start, like the ascending stream's: lanes 1..63 hold the upper 63 floats of block
+        // S_q = [M-64q-64, M-64q-1], its lowest float, bin M-64(q+1), is lane 0's output of step q+1, so S_q is
+        // stored during step q+1 with data (lane 0 ? step q+1 : step q); lane 0's bin M (step 0) is a single-lane
+        // store and the lowest float of the last block is bin M/2.  With 128-byte aligned rows every block is then
+        // two full lines; with the dense pitch ld = H it is still 3 % faster than the unshifted form.
+        // (3) Dense rows (ld = H) beat padded ones (H -> 2080 / 2112: +7 %): the lone bin M shares its line with the
+        // next row, written by the neighbouring wave, instead of leaving a partial line per row.
+#ifdef MPX_PROBE_LD   // timing probe only: overrides the row pitch (rows may overlap)
+        const long long ldp = MPX_PROBE_LD;
+#else
+        const long long ldp = ld;
+#endif
+        float* row_m = omag + f * ldp;
+        float* row_r = oreal + f * ldp;
+        float* row_i = oimag + f * ldp;
+        float* mlo = row_m + kap;                     // X[k]   : ascending lanes, +64 q
+        float* rlo = row_r + kap;
+        float* ilo = row_i + kap;
+#ifdef MPX_ANA_NOSHIFT
+        const int hoff = M - kap;
+#else
+        const int hoff = lane0 ? M - 64 : M - kap;    // X[M-k] : descending lanes, -64 q (lane 0: one block lower)
+#endif
+        float* mhi = row_m + hoff;
+        float* rhi = row_r + hoff;
+        float* ihi = row_i + hoff;
         float zpr[P / 2], zpi[P / 2];   // all partner bins first: P lane exchanges in flight together
 #pragma unroll
-        for (int i = 0; i < P; i += 2) {
-            zpr[i / 2] = __shfl(re[P - 1 - i], src_lane);
-            zpi[i / 2] = __shfl(im[P - 1 - i], src_lane);
+        for (int q = 0; q < P / 2; ++q) {
+            const int i = brev(q, LB);
+            zpr[q] = __shfl(re[P - 1 - i], src_lane);
+            zpi[q] = __shfl(im[P - 1 - i], src_lane);
         }
+        float hm = 0.0f, hr = 0.0f, hi_ = 0.0f;       // mirror outputs of the previous step
 #pragma unroll
-        for (int i = 0; i < P; i += 2) {
-            const int q = brev(i, LB);            // q < P/2
+        for (int q = 0; q < P / 2; ++q) {
+            const int i = brev(q, LB);                // even register
             const int i0 = brev((P - q) % P, LB);
-            const float pr = lane0 ? re[i0] : zpr[i / 2];
-            const float pi = lane0 ? im[i0] : zpi[i / 2];
+            const float pr = lane0 ? re[i0] : zpr[q];
+            const float pi = lane0 ? im[i0] : zpi[q];
             const float er = 0.5f * (re[i] + pr), ei = 0.5f * (im[i] - pi);
             const float orr = 0.5f * (im[i] + pi), oi = -0.5f * (re[i] - pr);
             const float cq = cos2p<P>(q), sq = -sin2p<P>(q);   // W_N^k = W_N^kappa * e^{-2 pi i q/(2P)}
@@ -237,41 +181,57 @@ __global__ __launch_bounds__(kThreads) void k_analysis(const float* __restrict__
             {
                 const float xr = er - tr, xi = ti - ei;
                 const float s2 = xr * xr + xi * xi;
-                const float r = __builtin_amdgcn_rsqf(fmaxf(s2, 1.0e-37f));   // X == 0 -> xr = xi = s2 = 0 -> all three outputs 0
+                const float r = __builtin_amdgcn_rsqf(fmaxf(s2, 1.0e-37f));
+                const float cm = s2 * r, cr = xr * r, ci = xi * r;
 #ifdef MPX_PROBE_NOSTORE
-                asm volatile("" ::"v"(s2 * r), "v"(xr * r), "v"(xi * r));
+                asm volatile("" ::"v"(cm), "v"(cr), "v"(ci));
 #else
-                mhi[-64 * q] = s2 * r;
-                rhi[-64 * q] = xr * r;
-                ihi[-64 * q] = xi * r;
+#ifdef MPX_ANA_NOSHIFT
+                mhi[-64 * q] = cm;
+                rhi[-64 * q] = cr;
+                ihi[-64 * q] = ci;
+#else
+                if (q == 0) {
+                    if (lane0) {                      // bin M
+                        row_m[M] = cm;
+                        row_r[M] = cr;
+                        row_i[M] = ci;
+                    }
+                } else {                              // block S_{q-1}
+                    mhi[-64 * (q - 1)] = lane0 ? cm : hm;
+                    rhi[-64 * (q - 1)] = lane0 ? cr : hr;
+                    ihi[-64 * (q - 1)] = lane0 ? ci : hi_;
+                }
 #endif
+#endif
+                hm = cm;
+                hr = cr;
+                hi_ = ci;
             }
         }
-        if (lane0) {  // bin M/2 (register 1 holds q = P/2): X = conj Z
+        {   // block S_{P/2-1} = [M/2, M/2+63]: lane 0 supplies bin M/2 (register 1 holds q = P/2): X = conj Z
             const float xr = re[1], xi = -im[1];
             const float s2 = xr * xr + xi * xi;
-            const float r = __builtin_amdgcn_rsqf(fmaxf(s2, 1.0e-37f));   // X == 0 -> xr = xi = s2 = 0 -> all three outputs 0
-            mlo[M / 2] = s2 * r;
-            rlo[M / 2] = xr * r;
-            ilo[M / 2] = xi * r;
+            const float r = __builtin_amdgcn_rsqf(fmaxf(s2, 1.0e-37f));
+#ifdef MPX_PROBE_NOSTORE
+            asm volatile("" ::"v"(s2 * r), "v"(xr * r), "v"(xi * r), "v"(hm), "v"(hr), "v"(hi_));
+#else
+#ifdef MPX_ANA_NOSHIFT
+            if (lane0) {
+                row_m[M / 2] = s2 * r;
+                row_r[M / 2] = xr * r;
+                row_i[M / 2] = xi * r;
+            }
+#else
+            mhi[-64 * (P / 2 - 1)] = lane0 ? s2 * r : hm;
+            rhi[-64 * (P / 2 - 1)] = lane0 ? xr * r : hr;
+            ihi[-64 * (P / 2 - 1)] = lane0 ? xi * r : hi_;
+#endif
+#endif
         }
         g = gn;
-#ifndef MPX_ANA_WAIT_EARLY
-#ifdef MPX_PROBE_WAITCYC
-        const long long tw0 = clock64();
-        cyc_r1 += tr1 - tr0; cyc_r2 += tr2 - tr1; cyc_r3 += tr3 - tr2; cyc_r4 += tw0 - tr3;
-#endif
         if (fn < nframes) staged_wait<63>();   // >= 63 stores were issued after the copy: it has landed
-#ifdef MPX_PROBE_WAITCYC
-        cyc_wait += clock64() - tw0;
-        ++cyc_frames;
-#endif
-#endif
     }
-#ifdef MPX_PROBE_WAITCYC
-    if (lane_id == 0 && (blockIdx.x % 37) == 0 && wave == 3)
-        printf("WAITCYC block %d frames %lld total %lld wait %lld r1 %lld r2 %lld r3 %lld r4 %lld\n", (int)blockIdx.x, cyc_frames, clock64() - cyc_t0, cyc_wait, cyc_r1, cyc_r2, cyc_r3, cyc_r4);
-#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -282,7 +242,7 @@ __global__ __launch_bounds__(kThreads) void k_synth_lossless(const float* __rest
                                                              const float* __restrict__ real,
                                                              const float* __restrict__ imag, long long nframes,
                                                              const float2* __restrict__ tw_g,
-                                                             float* __restrict__ frames) {
+                                                             float* __restrict__ frames, long long ld) {
     constexpr int M = 64 * P, N = 2 * M, H = M + 1, LB = ilog2(P);
     extern __shared__ float smem[];
     float2* tw = reinterpret_cast<float2*>(smem);
@@ -304,7 +264,7 @@ __global__ __launch_bounds__(kThreads) void k_synth_lossless(const float* __rest
         asm volatile("" : "+v"(lane), "+v"(wl_s), "+v"(wl_c));
         const int kap = kappa<P>(lane);
         FrameFeat<P> ff;
-        feat_load<P>(ff, mag + f * H, real + f * H, imag + f * H, lane);
+        feat_load<P>(ff, mag + f * ld, real + f * ld, imag + f * ld, lane);
         float xr[P], xi[P], xm;
         feat_convert<P>(ff, xr, xi, xm, lane);
         hermitian_merge<P>(xr, xi, xm, lane, wl_c, wl_s);
@@ -335,7 +295,7 @@ __global__ __launch_bounds__(kSynWaves * 64) void k_synth_ola(const float* __res
                                                               const int* __restrict__ slot_chunks, int nslots,
                                                               const int* __restrict__ pm_rel, int T,
                                                               const float2* __restrict__ tw_g,
-                                                              float* __restrict__ strips) {
+                                                              float* __restrict__ strips, long long ld) {
     constexpr int M = 64 * P, N = 2 * M, H = M + 1, LB = ilog2(P), R = ring_len<P>();
     extern __shared__ float smem[];
     float2* tw = reinterpret_cast<float2*>(smem);
@@ -365,7 +325,7 @@ __global__ __launch_bounds__(kSynWaves * 64) void k_synth_ola(const float* __res
         FrameFeat<P> ff;
         {
             const long long f = cd.frame_begin;
-            feat_load<P>(ff, mag + f * H, real + f * H, imag + f * H, lane_id);
+            feat_load<P>(ff, mag + f * ld, real + f * ld, imag + f * ld, lane_id);
         }
         for (int fi = cd.frame_begin; fi < cd.frame_end; ++fi) {
             int lane = lane_id;  // laundered per frame (see k_analysis)
@@ -378,7 +338,7 @@ __global__ __launch_bounds__(kSynWaves * 64) void k_synth_ola(const float* __res
             __builtin_amdgcn_sched_barrier(0);
             if (fi + 1 < cd.frame_end) {
                 const long long f = fi + 1;
-                feat_load<P>(ff, mag + f * H, real + f * H, imag + f * H, lane);
+                feat_load<P>(ff, mag + f * ld, real + f * ld, imag + f * ld, lane);
             }
             __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -391,7 +351,7 @@ __global__ __launch_bounds__(kSynWaves * 64) void k_synth_ola(const float* __res
             __builtin_amdgcn_sched_barrier(0);
             if (fi + 1 < cd.frame_end) {
                 const long long f = fi + 1;
-                feat_load<P>(ff, mag + f * H, real + f * H, imag + f * H, lane);
+                feat_load<P>(ff, mag + f * ld, real + f * ld, imag + f * ld, lane);
             }
             __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -458,7 +418,7 @@ __global__ __launch_bounds__(kPairWaves * 64) void k_synth_ola_pair(const float*
                                                                     const int* __restrict__ slot_chunks, int nslots,
                                                                     const int* __restrict__ pm_rel, int T,
                                                                     const float2* __restrict__ tw_g,
-                                                                    float* __restrict__ strips) {
+                                                                    float* __restrict__ strips, long long ld) {
     constexpr int M = 64 * P, N = 2 * M, H = M + 1, LB = ilog2(P), R = ring_len<P>();
     extern __shared__ float smem[];
     float2* tw = reinterpret_cast<float2*>(smem);
@@ -531,7 +491,7 @@ __global__ __launch_bounds__(kPairWaves * 64) void k_synth_ola_pair(const float*
         FrameFeat<P> ff;
         {
             const long long f = cur.fi;
-            feat_load<P>(ff, mag + f * H, real + f * H, imag + f * H, lane);
+            feat_load<P>(ff, mag + f * ld, real + f * ld, imag + f * ld, lane);
         }
         float xr[P], xi[P], xm;
         feat_convert<P>(ff, xr, xi, xm, lane);
@@ -693,37 +653,44 @@ int mpx_tables_init(void* stream, int fft_len, void* tables) {
     return MPX_OK;
 }
 
+int64_t mpx_feat_ld(int fft_len) {
+    if (!p_of(fft_len)) return 0;
+    return (int64_t)(fft_len / 2 + 1);   // dense: measured best (see the header)
+}
+
 int mpx_analysis_frames(void* stream, int fft_len, const void* tables, const float* sig, const int64_t* frame_pos,
                         const int32_t* frame_left, const int32_t* frame_right, int64_t n_frames, float* out_mag,
-                        float* out_real, float* out_imag) {
+                        float* out_real, float* out_imag, int64_t ld) {
     const int P = p_of(fft_len);
     if (!P) return fail(MPX_ERR_ARG, "mpx_analysis_frames: fft_len must be 2048 or 4096%s");
     if (n_frames < 0) return fail(MPX_ERR_ARG, "mpx_analysis_frames: negative n_frames%s");
+    if (ld < fft_len / 2 + 1) return fail(MPX_ERR_ARG, "mpx_analysis_frames: ld < fft_len/2 + 1%s");
     if (n_frames == 0) return MPX_OK;
     if (!tables || !sig || !frame_pos || !frame_left || !frame_right || !out_mag || !out_real || !out_imag)
         return fail(MPX_ERR_ARG, "mpx_analysis_frames: null pointer%s");
-    const dim3 grid(grid_for(n_frames)), block(kThreads);
+    const dim3 grid(grid_for(n_frames, kAnaWaves)), block(kAnaThreads);
     hipStream_t s = (hipStream_t)stream;
     if (P == 32) {
         if (int rc = set_lds(k_analysis<32>, lds_bytes_ana<32>())) return rc;
         hipLaunchKernelGGL(k_analysis<32>, grid, block, lds_bytes_ana<32>(), s, sig, (const long long*)frame_pos,
                            frame_left, frame_right, (long long)n_frames, (const float2*)tables, out_mag, out_real,
-                           out_imag);
+                           out_imag, (long long)ld);
     } else {
         if (int rc = set_lds(k_analysis<16>, lds_bytes_ana<16>())) return rc;
         hipLaunchKernelGGL(k_analysis<16>, grid, block, lds_bytes_ana<16>(), s, sig, (const long long*)frame_pos,
                            frame_left, frame_right, (long long)n_frames, (const float2*)tables, out_mag, out_real,
-                           out_imag);
+                           out_imag, (long long)ld);
     }
     MPX_HIP_CHECK(hipGetLastError());
     return MPX_OK;
 }
 
 int mpx_synthesis_lossless_frames(void* stream, int fft_len, const void* tables, const float* mag, const float* real,
-                                  const float* imag, int64_t n_frames, float* frames_out) {
+                                  const float* imag, int64_t n_frames, float* frames_out, int64_t ld) {
     const int P = p_of(fft_len);
     if (!P) return fail(MPX_ERR_ARG, "mpx_synthesis_lossless_frames: fft_len must be 2048 or 4096%s");
     if (n_frames < 0) return fail(MPX_ERR_ARG, "mpx_synthesis_lossless_frames: negative n_frames%s");
+    if (ld < fft_len / 2 + 1) return fail(MPX_ERR_ARG, "mpx_synthesis_lossless_frames: ld < fft_len/2 + 1%s");
     if (n_frames == 0) return MPX_OK;
     if (!tables || !mag || !real || !imag || !frames_out)
         return fail(MPX_ERR_ARG, "mpx_synthesis_lossless_frames: null pointer%s");
@@ -732,11 +699,11 @@ int mpx_synthesis_lossless_frames(void* stream, int fft_len, const void* tables,
     if (P == 32) {
         if (int rc = set_lds(k_synth_lossless<32>, lds_bytes<32>())) return rc;
         hipLaunchKernelGGL(k_synth_lossless<32>, grid, block, lds_bytes<32>(), s, mag, real, imag,
-                           (long long)n_frames, (const float2*)tables, frames_out);
+                           (long long)n_frames, (const float2*)tables, frames_out, (long long)ld);
     } else {
         if (int rc = set_lds(k_synth_lossless<16>, lds_bytes<16>())) return rc;
         hipLaunchKernelGGL(k_synth_lossless<16>, grid, block, lds_bytes<16>(), s, mag, real, imag,
-                           (long long)n_frames, (const float2*)tables, frames_out);
+                           (long long)n_frames, (const float2*)tables, frames_out, (long long)ld);
     }
     MPX_HIP_CHECK(hipGetLastError());
     return MPX_OK;
@@ -774,10 +741,11 @@ int mpx_synth_ola_slots(void) {
 int mpx_synthesis_lossless_ola(void* stream, int fft_len, const void* tables, const float* mag, const float* real,
                                const float* imag, const void* chunks, int32_t n_chunks, const int32_t* slot_off,
                                const int32_t* slot_chunks, int32_t n_slots, const int32_t* pm_rel,
-                               int32_t territory, float* strips) {
+                               int32_t territory, float* strips, int64_t ld) {
     const int P = p_of(fft_len);
     if (!P) return fail(MPX_ERR_ARG, "mpx_synthesis_lossless_ola: fft_len must be 2048 or 4096%s");
     if (n_chunks < 0 || n_slots < 0) return fail(MPX_ERR_ARG, "mpx_synthesis_lossless_ola: negative count%s");
+    if (ld < fft_len / 2 + 1) return fail(MPX_ERR_ARG, "mpx_synthesis_lossless_ola: ld < fft_len/2 + 1%s");
     if (territory < fft_len / 2 || (territory % 64) != 0)
         return fail(MPX_ERR_ARG, "mpx_synthesis_lossless_ola: territory must be a multiple of 64 and >= fft_len/2%s");
     if (n_chunks == 0 || n_slots == 0) return MPX_OK;
@@ -791,12 +759,12 @@ int mpx_synthesis_lossless_ola(void* stream, int fft_len, const void* tables, co
             if (int rc = set_lds(k_synth_ola_pair<32>, lds_bytes_pair<32>())) return rc;
             hipLaunchKernelGGL(k_synth_ola_pair<32>, grid, block, lds_bytes_pair<32>(), s, mag, real, imag,
                                (const ChunkDesc*)chunks, slot_off, slot_chunks, (int)n_slots, pm_rel, (int)territory,
-                               (const float2*)tables, strips);
+                               (const float2*)tables, strips, (long long)ld);
         } else {
             if (int rc = set_lds(k_synth_ola_pair<16>, lds_bytes_pair<16>())) return rc;
             hipLaunchKernelGGL(k_synth_ola_pair<16>, grid, block, lds_bytes_pair<16>(), s, mag, real, imag,
                                (const ChunkDesc*)chunks, slot_off, slot_chunks, (int)n_slots, pm_rel, (int)territory,
-                               (const float2*)tables, strips);
+                               (const float2*)tables, strips, (long long)ld);
         }
         MPX_HIP_CHECK(hipGetLastError());
         return MPX_OK;
@@ -807,12 +775,12 @@ int mpx_synthesis_lossless_ola(void* stream, int fft_len, const void* tables, co
         if (int rc = set_lds(k_synth_ola<32>, lds_bytes_ola<32>())) return rc;
         hipLaunchKernelGGL(k_synth_ola<32>, grid, block, lds_bytes_ola<32>(), s, mag, real, imag,
                            (const ChunkDesc*)chunks, slot_off, slot_chunks, (int)n_slots, pm_rel, (int)territory,
-                           (const float2*)tables, strips);
+                           (const float2*)tables, strips, (long long)ld);
     } else {
         if (int rc = set_lds(k_synth_ola<16>, lds_bytes_ola<16>())) return rc;
         hipLaunchKernelGGL(k_synth_ola<16>, grid, block, lds_bytes_ola<16>(), s, mag, real, imag,
                            (const ChunkDesc*)chunks, slot_off, slot_chunks, (int)n_slots, pm_rel, (int)territory,
-                           (const float2*)tables, strips);
+                           (const float2*)tables, strips, (long long)ld);
     }
     MPX_HIP_CHECK(hipGetLastError());
     return MPX_OK;

@@ -40,13 +40,18 @@ constexpr size_t lds_bytes() {
     return sizeof(float) * (size_t)(P * 64 * 2 + kWavesPerBlock * P * kXStride);
 }
 
+#ifndef MPX_ANA_WAVES
+#define MPX_ANA_WAVES 12
+#endif
+// k_analysis: 12 waves = 3 per SIMD (<= 168 VGPRs).  A wave issues at most one instruction per ~5 cycles on this
+// chip (tools/clock_probe.hip), so 2 waves per SIMD leave the VALU idle half the time; the third wave only pays once
+// every store is a full aligned 256-byte block (tools/ab_bench.py: 8 -> 12 waves = +10 % time with the old store
+// shape, -20 % with the aligned one).
+constexpr int kAnaWaves = MPX_ANA_WAVES;
+constexpr int kAnaThreads = kAnaWaves * 64;
 template <int P>
 constexpr size_t lds_bytes_ana() {
-#ifdef MPX_ANA_STAGE2
-    return lds_bytes<P>() + sizeof(float) * (size_t)(kWavesPerBlock * 64 * P);
-#else
-    return lds_bytes<P>();
-#endif
+    return sizeof(float) * (size_t)(P * 64 * 2 + kAnaWaves * P * kXStride);
 }
 
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -250,13 +255,13 @@ struct ChunkDesc {
 // ---------------------------------------------------------------------------------------------
 inline int p_of(int fft_len) { return fft_len == 4096 ? 32 : (fft_len == 2048 ? 16 : 0); }
 
-inline int grid_for(long long nframes) {
+inline int grid_for(long long nframes, int waves_per_block = kWavesPerBlock) {
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
     }
-    long long need = (nframes + kWavesPerBlock - 1) / kWavesPerBlock;
+    long long need = (nframes + waves_per_block - 1) / waves_per_block;
     return (int)std::max<long long>(1, std::min<long long>(need, cus));
 }
 

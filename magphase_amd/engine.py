@@ -42,6 +42,34 @@ class Engine:
         torch = _torch()
         return torch.empty(shape, dtype=dtype or torch.float32, device=self.device)
 
+    def empty_feats(self, n_frames, n_bins, ld=None):
+        """
+        One lossless feature matrix [n_frames x n_bins] float32 on the device, as a VIEW of a buffer whose rows are
+        `ld` floats apart (default mpx_feat_ld(): the dense layout, measured fastest; MAGPHASE_FEAT_LD overrides it
+        for experiments).  .stride(0) is the `ld` the C entry points take.
+        """
+        ld = int(ld or os.environ.get("MAGPHASE_FEAT_LD", 0) or self.lib.mpx_feat_ld(2 * (int(n_bins) - 1)) or n_bins)
+        return self.empty((int(n_frames), ld))[:, :int(n_bins)]
+
+    def feats_to_device(self, arr):
+        """Host [F x H] array -> device float32 matrix (see empty_feats)."""
+        torch = _torch()
+        arr = np.ascontiguousarray(arr, dtype=np.float32)
+        out = self.empty_feats(arr.shape[0], arr.shape[1])
+        out.copy_(torch.from_numpy(arr))
+        return out
+
+    @staticmethod
+    def feat_ld(mag, real, imag):
+        """Common row pitch of three feature views (unit column stride, equal row stride) for the C ABI."""
+        ld = int(mag.stride(0)) if mag.shape[0] > 1 else max(int(mag.stride(0)), int(mag.shape[1]))
+        for t in (mag, real, imag):
+            if t.dim() != 2 or (t.shape[1] > 1 and t.stride(1) != 1):
+                raise ValueError("feature matrices must be 2-D with unit column stride")
+            if t.shape[0] > 1 and int(t.stride(0)) != ld:
+                raise ValueError("mag/real/imag must share one row pitch")
+        return ld
+
     def to_device(self, arr, dtype):
         torch = _torch()
         t = torch.from_numpy(np.ascontiguousarray(arr, dtype=dtype))
@@ -66,13 +94,14 @@ class Engine:
         nfr = int(pos.numel())
         H = fft_len // 2 + 1
         if out is None:
-            out = tuple(self.empty((nfr, H)) for _ in range(3))
+            out = tuple(self.empty_feats(nfr, H) for _ in range(3))
+        ld = self.feat_ld(*out)
         tab = self.tables(fft_len)
         with torch.cuda.device(self.device):
             _lib.check(
                 self.lib.mpx_analysis_frames(self.stream_ptr(), int(fft_len), tab.data_ptr(), sig.data_ptr(),
                                              pos.data_ptr(), left.data_ptr(), right.data_ptr(), nfr,
-                                             out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr()),
+                                             out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), ld),
                 "mpx_analysis_frames")
         return out
 
@@ -85,7 +114,8 @@ class Engine:
         with torch.cuda.device(self.device):
             _lib.check(
                 self.lib.mpx_synthesis_lossless_frames(self.stream_ptr(), int(fft_len), tab.data_ptr(), mag.data_ptr(),
-                                                       real.data_ptr(), imag.data_ptr(), nfr, out.data_ptr()),
+                                                       real.data_ptr(), imag.data_ptr(), nfr, out.data_ptr(),
+                                                       self.feat_ld(mag, real, imag)),
                 "mpx_synthesis_lossless_frames")
         return out
 
@@ -169,7 +199,8 @@ class Engine:
                                                     real.data_ptr(), imag.data_ptr(), plan.chunks.data_ptr(),
                                                     int(plan.n_chunks), plan.slot_off.data_ptr(),
                                                     plan.slot_chunks.data_ptr(), int(plan.n_slots),
-                                                    plan.pm_rel.data_ptr(), int(plan.territory), strips.data_ptr()),
+                                                    plan.pm_rel.data_ptr(), int(plan.territory), strips.data_ptr(),
+                                                    self.feat_ld(mag, real, imag)),
                 "mpx_synthesis_lossless_ola")
         return strips
 
@@ -630,7 +661,7 @@ class CompressedAnalysisPlan:
                                           imag.data_ptr(), ptr(self.row0), ptr(self.row1), ptr(self.rowt),
                                           self.w_mag.data_ptr(), self.mag_dim, self.w_ph.data_ptr(), self.phase_dim,
                                           self.voi.data_ptr(), out[0].data_ptr(), out[1].data_ptr(),
-                                          out[2].data_ptr()), "mpx_mel_warp")
+                                          out[2].data_ptr(), e.feat_ld(mag, real, imag)), "mpx_mel_warp")
         return out
 
 

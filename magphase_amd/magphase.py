@@ -126,10 +126,17 @@ def synthesis_from_lossless_batch(feats, engine=None):
     H = int(np.shape(feats[0][0])[1])
     fft_len = 2 * (H - 1)
     plan = LosslessSynthesisPlan(engine, [f[3] for f in feats], [f[4] for f in feats], fft_len)
+    rows = np.concatenate(([0], np.cumsum([int(np.shape(f[0])[0]) for f in feats])))
     cat = []
-    for k in range(3):
-        parts = [f[k] if torch.is_tensor(f[k]) else engine.to_device(np.asarray(f[k]), np.float32) for f in feats]
-        cat.append(parts[0].contiguous() if len(parts) == 1 else torch.cat(parts, dim=0))
+    for k in range(3):   # one device matrix per stream (engine.empty_feats)
+        if len(feats) == 1 and torch.is_tensor(feats[0][k]) and feats[0][k].dtype == torch.float32:
+            cat.append(feats[0][k])
+            continue
+        buf = engine.empty_feats(int(rows[-1]), H)
+        for u, f in enumerate(feats):
+            part = f[k] if torch.is_tensor(f[k]) else torch.from_numpy(np.ascontiguousarray(f[k], dtype=np.float32))
+            buf[int(rows[u]):int(rows[u + 1])].copy_(part)
+        cat.append(buf)
     pcm = plan.run(cat[0], cat[1], cat[2]).cpu().numpy().astype(np.float64)
     return [pcm[plan.out_off_host[u]:plan.out_off_host[u + 1]] for u in range(len(feats))]
 

@@ -34,11 +34,11 @@ def test_library_loads_and_exports_all_symbols():
 
 def test_argument_errors_without_gpu():
     lib = _lib.load()
-    rc = lib.mpx_analysis_frames(None, 1234, None, None, None, None, None, 1, None, None, None)
+    rc = lib.mpx_analysis_frames(None, 1234, None, None, None, None, None, 1, None, None, None, 618)
     assert rc == -1 and b"fft_len" in lib.mpx_last_error()
-    rc = lib.mpx_analysis_frames(None, 4096, None, None, None, None, None, 5, None, None, None)
+    rc = lib.mpx_analysis_frames(None, 4096, None, None, None, None, None, 5, None, None, None, 2049)
     assert rc == -1 and b"null" in lib.mpx_last_error()
-    assert lib.mpx_analysis_frames(None, 4096, None, None, None, None, None, 0, None, None, None) == 0
+    assert lib.mpx_analysis_frames(None, 4096, None, None, None, None, None, 0, None, None, None, 2112) == 0
 
 
 def test_product_fails_loudly_without_gpu():

@@ -271,3 +271,27 @@ def test_tiny_utterances(mp, orc, nfr):
         assert np.array_equal(b[0][k], a[k])
     outs = mp.synthesis_from_lossless_batch([tuple(b[0][:5]), tuple(b[1][:5])])
     assert np.array_equal(outs[0], got)
+
+
+def test_dense_and_pitched_rows_agree(mp):
+    """Any row pitch ld >= H is correct (include/magphase_hip.h): the reference's dense [F x H] layout and a padded
+    one give bit-identical features and PCM."""
+    import torch
+    from magphase_amd.engine import get_engine, LosslessAnalysisPlan, LosslessSynthesisPlan
+    from magphase_amd import synthetic
+    eng = get_engine()
+    utts = []
+    for u in range(3):
+        pcm, pm, voi = synthetic.make_utterance(u, dur_s=0.7)
+        utts.append((pcm, 48000, pm, voi))
+    plan = LosslessAnalysisPlan(eng, utts)
+    H, F = plan.fft_len // 2 + 1, plan.total_frames
+    dense = plan.run()
+    assert F > 1 and dense[0].stride(0) == H == eng.lib.mpx_feat_ld(plan.fft_len)
+    pitched = plan.run(out=tuple(eng.empty_feats(F, H, ld=H + 63) for _ in range(3)))
+    assert pitched[0].stride(0) == H + 63
+    for a, b in zip(pitched, dense):
+        assert torch.equal(a, b)
+    splan = LosslessSynthesisPlan(eng, plan.v_f0, plan.fs, plan.fft_len)
+    assert torch.equal(splan.run(*pitched), splan.run(*dense))
+    assert torch.equal(splan.run_unfused(*pitched), splan.run_unfused(*dense))

@@ -52,7 +52,7 @@ def main():
     splan = LosslessSynthesisPlan(first, aplan.v_f0, aplan.fs, aplan.fft_len, territory=terr)
     splans = {n: LosslessSynthesisPlan(engines[n], aplan.v_f0, aplan.fs, aplan.fft_len, territory=terr) for n, _ in specs}
     N, H, F = aplan.fft_len, aplan.fft_len // 2 + 1, aplan.total_frames
-    feats = tuple(first.empty((F, H)) for _ in range(3))
+    feats = tuple(first.empty_feats(F, H) for _ in range(3))
     strips = first.empty((splan.strip_floats,))
     pcm = first.empty((splan.total_out,))
     times = {n: ([], [], []) for n, _ in specs}
