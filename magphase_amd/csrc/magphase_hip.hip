@@ -402,8 +402,18 @@ __global__ __launch_bounds__(kSynWaves * 64) void k_synth_ola(const float* __res
 // LDS / memory latencies (measured 53 % issue-active).  Sharing the ring gives 8 waves per CU in the same LDS.
 // Summation order is unchanged (ascending frames), so results are bit-identical to k_synth_ola.
 // ---------------------------------------------------------------------------------------------
-constexpr int kPairWaves = 8;                    // 4 pairs per workgroup
-constexpr int kPairs = kPairWaves / 2;
+#ifndef MPX_SYN_PAIR_WAVES
+#define MPX_SYN_PAIR_WAVES 8
+#endif
+#ifndef MPX_SYN_GROUP
+#define MPX_SYN_GROUP 2
+#endif
+constexpr int kPairWaves = MPX_SYN_PAIR_WAVES;   // waves per workgroup
+constexpr int kGroup = MPX_SYN_GROUP;            // waves sharing one ring (2: the "pair"; 4 at the same occupancy measured
+                                                 // +11 %, 6 with 12 waves per CU +15 %: the in-order ring hand-over couples the
+                                                 // waves of a group, so more waves only pay with their own rings -- no LDS left)
+constexpr int kPairs = kPairWaves / kGroup;      // rings (= work-list slots) per workgroup
+static_assert(kPairWaves % kGroup == 0, "waves per workgroup must be a multiple of the group size");
 template <int P>
 constexpr size_t lds_bytes_pair() {
     return sizeof(float) * (size_t)(P * 64 * 2 + kPairWaves * (P * kXStride) + kPairs * ring_len<P>() + 16);
@@ -424,7 +434,7 @@ __global__ __launch_bounds__(kPairWaves * 64) void k_synth_ola_pair(const float*
     float2* tw = reinterpret_cast<float2*>(smem);
     const int lane_id = threadIdx.x & 63;
     const int wave = rfl(threadIdx.x >> 6);
-    const int pair = wave >> 1, half = wave & 1;
+    const int pair = wave / kGroup, half = wave % kGroup;   // ring, member index
     float* xbuf = smem + P * 64 * 2 + wave * (P * kXStride);
     float* ring = smem + P * 64 * 2 + kPairWaves * (P * kXStride) + pair * R;
     int* turn = reinterpret_cast<int*>(smem + P * 64 * 2 + kPairWaves * (P * kXStride) + kPairs * R) + pair;
@@ -464,7 +474,7 @@ __global__ __launch_bounds__(kPairWaves * 64) void k_synth_ola_pair(const float*
         c.valid = 0;
     };
     auto advance = [&](Cursor& c) {
-        c.fi += 2;
+        c.fi += kGroup;
         if (c.fi >= c.fe) {
             c.ticket_base += c.fe - c.fb;
             ++c.wi;
@@ -502,14 +512,16 @@ __global__ __launch_bounds__(kPairWaves * 64) void k_synth_ola_pair(const float*
         const int fi = cur.fi;
         float* strip = strips + (long long)cur.ci * strip_len;
         const int ticket = cur.ticket_base + (fi - cur.fb);
+        // frame positions first: their (scalar) loads must not sit behind the ticket inside the ordered section
+        const int x = pm_rel[fi] - cur.x0;   // in [0, T)
+        const int target = x & ~63;
+        const int flushed = (fi == cur.fb) ? 0 : ((pm_rel[fi - 1] - cur.x0) & ~63);
+        asm volatile("" ::"s"(x), "s"(flushed));
 #ifndef MPX_PROBE_NOTICKET
         while (__hip_atomic_load(turn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != ticket)
             __builtin_amdgcn_s_sleep(1);
 #endif
         asm volatile("" ::: "memory");
-        const int x = pm_rel[fi] - cur.x0;   // in [0, T)
-        const int target = x & ~63;
-        const int flushed = (fi == cur.fb) ? 0 : ((pm_rel[fi - 1] - cur.x0) & ~63);
         if (flushed < target) flush_ring<R>(ring, strip, flushed, target, strip_len, lane);
         wave_sync();
         {
@@ -518,26 +530,34 @@ __global__ __launch_bounds__(kPairWaves * 64) void k_synth_ola_pair(const float*
             const int odd = x & 1;
             float* r0 = ring + (odd ? RH : 0);
             float* r1 = ring + (odd ? 0 : RH);
+            // element i of a plane sits at ring index (c + 64 b) mod RH, b = brev(i), c = cb + kappa: no index arrays --
+            // the un-wrapped / wrapped base pointers pA / pB = pA - RH are selected per element (the wrap point differs
+            // by at most one b between lanes) and 64 b goes into the instruction's immediate offset.
             const int c0 = ((x >> 1) % RH) + kap;
             const int c1 = (((x + 1) >> 1) % RH) + kap;
-            // read all 64 ring values first, then add, then write: one LDS latency instead of 32 dependent chains
-            float o0[P], o1[P];
-            int a0[P], a1[P];
+            float* pA0 = r0 + c0;
+            float* pB0 = pA0 - RH;
+            float* pA1 = r1 + c1;
+            float* pB1 = pA1 - RH;
+            const int w0 = (RH - c0 + 63) >> 6;   // first b with c0 + 64 b >= RH
+            const int w1 = (RH - c1 + 63) >> 6;
+            // read all ring values first, then add, then write: one LDS latency instead of 2P dependent chains
+            constexpr int kRingBatch = P;
 #pragma unroll
-            for (int i = 0; i < P; ++i) {
-                int s0 = c0 + 64 * brev(i, LB);
-                s0 = (s0 >= RH) ? s0 - RH : s0;
-                int s1 = c1 + 64 * brev(i, LB);
-                s1 = (s1 >= RH) ? s1 - RH : s1;
-                a0[i] = s0;
-                a1[i] = s1;
-                o0[i] = r0[s0];
-                o1[i] = r1[s1];
-            }
+            for (int i0 = 0; i0 < P; i0 += kRingBatch) {
+                float o0[kRingBatch], o1[kRingBatch];
 #pragma unroll
-            for (int i = 0; i < P; ++i) {
-                r0[a0[i]] = o0[i] + xr[i];
-                r1[a1[i]] = o1[i] + xi[i];
+                for (int i = 0; i < kRingBatch; ++i) {
+                    const int bq = brev(i0 + i, LB);
+                    o0[i] = ((bq >= w0) ? pB0 : pA0)[64 * bq];
+                    o1[i] = ((bq >= w1) ? pB1 : pA1)[64 * bq];
+                }
+#pragma unroll
+                for (int i = 0; i < kRingBatch; ++i) {
+                    const int bq = brev(i0 + i, LB);
+                    ((bq >= w0) ? pB0 : pA0)[64 * bq] = o0[i] + xr[i0 + i];
+                    ((bq >= w1) ? pB1 : pA1)[64 * bq] = o1[i] + xi[i0 + i];
+                }
             }
         }
         wave_sync();

@@ -226,6 +226,8 @@ constexpr size_t lds_bytes_ola() {
 }
 
 // Streams strip elements [from, to) out of the ring (to global) and clears their slots.  from is a multiple of 64.
+// Four 64-element blocks per step: their LDS reads are in flight together (one LDS latency per 256 elements instead
+// of one per 64 -- this runs inside the ordered section of the ring, where every cycle is serial).
 template <int R>
 __device__ __forceinline__ void flush_ring(float* ring, float* __restrict__ strip, int from, int to, int strip_len,
                                            int lane) {
@@ -234,13 +236,24 @@ __device__ __forceinline__ void flush_ring(float* ring, float* __restrict__ stri
     float* half = ring + ((lane & 1) ? RH : 0);
     int idx = ((from >> 1) % RH) + (lane >> 1);
     idx = (idx >= RH) ? idx - RH : idx;
-    for (int b0 = from; b0 < to; b0 += 64) {
-        const int b = b0 + lane;
-        const float v = half[idx];
-        if (b < strip_len) strip[b] = v;
-        half[idx] = 0.0f;
-        idx += 32;
-        idx = (idx >= RH) ? idx - RH : idx;
+    for (int b0 = from; b0 < to; b0 += 256) {
+        int id[4];
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            id[r] = idx;
+            v[r] = half[idx];          // blocks past `to` are read but neither stored nor cleared
+            idx += 32;
+            idx = (idx >= RH) ? idx - RH : idx;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int b = b0 + 64 * r + lane;
+            if (b0 + 64 * r < to) {
+                if (b < strip_len) strip[b] = v[r];
+                half[id[r]] = 0.0f;
+            }
+        }
     }
 }
 
