@@ -113,3 +113,18 @@ def shift_to_pm(v_shift):
 def pm_to_shift(v_pm):
     """libaudio.py:65-67."""
     return np.diff(np.hstack((0, v_pm)))
+
+
+def convert_label_state_align_to_var_frame_rate(in_lab_st_file, v_dur_state, out_lab_st_file):
+    """
+    libaudio.py:687-708: rewrites the times of an HTS state-aligned label file so that state i lasts
+    v_dur_state[i] frames of 5 ms -- the "variable frame rate" labels a constant-rate trainer is given.
+    Times are written in units of 100 ns, the label strings (third column) are kept.
+    """
+    with open(in_lab_st_file, "r") as f:
+        l_names = [ln.split(" ")[2].rstrip("\n") for ln in f if ln.strip()]
+    v_edges = np.concatenate(([0.0], np.cumsum(np.asarray(v_dur_state, dtype=np.float64) * 5.0 * 10000.0)))
+    v_edges = v_edges.astype(int)
+    with open(out_lab_st_file, "w") as f:
+        for i, name in enumerate(l_names):
+            f.write("%d %d %s\n" % (v_edges[i], v_edges[i + 1], name))

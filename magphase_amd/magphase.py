@@ -299,3 +299,35 @@ def analysis_for_acoustic_modelling(wav_file, out_dir, fft_len=None, mag_dim=60,
     if not b_const_rate:
         write_featfile(v_shift, out_dir, file_id + '.shift')
     return
+
+
+# ======================================================================================================
+# label re-timing for constant-frame-rate trainers
+# ======================================================================================================
+def get_num_of_frms_per_state(v_shift, lab_state_align_file, fs, b_prevent_zeros=False, n_states_x_phone=5,
+                              nfrms_tolerance=6):
+    """
+    magphase.py:2111-2150: number of pitch-synchronous frames (epochs) that fall inside every line of an HTS
+    state-aligned label file ([start, end) in units of 100 ns).  Frames left over after the last line (at most
+    `nfrms_tolerance`: label files often end early) go to the last state; a total mismatch or a phone without any
+    frame raises ValueError like the reference.  Returns float64[n_states].
+    """
+    m_lab = np.loadtxt(lab_state_align_file, usecols=(0, 1), ndmin=2)
+    m_lab_ms = m_lab / 10000.0
+    v_ep_ms = np.cumsum(v_shift) * 1000.0 / fs
+    # epochs e with start <= e < end == (#epochs < end) - (#epochs < start); the epoch times are non-decreasing
+    v_ep_sorted = np.sort(v_ep_ms)
+    v_n = (np.searchsorted(v_ep_sorted, m_lab_ms[:, 1], side="left")
+           - np.searchsorted(v_ep_sorted, m_lab_ms[:, 0], side="left")).astype(np.float64)
+    v_n = np.maximum(v_n, 0.0)
+    n_left = np.size(v_shift) - np.sum(v_n)
+    if 0 < n_left <= nfrms_tolerance:
+        v_n[-1] += n_left
+    if np.sum(v_n) != np.size(v_shift):
+        raise ValueError("Total number of frames is different to the number of frames of the shifts.")
+    v_n_ph = v_n.reshape((v_n.size // n_states_x_phone, n_states_x_phone)).sum(axis=1)
+    if np.any(v_n_ph == 0.0):
+        raise ValueError("There is some phoneme(s) that do(es) not contain any frame.")
+    if b_prevent_zeros:
+        v_n[v_n == 0] = 1
+    return v_n

@@ -173,6 +173,58 @@ def gen_const_rate(mp, la):
     os.remove(wav)
 
 
+def _py3_loadtxt(orig):
+    """numpy-2 / python-3 stand-in for the reference's np.loadtxt(dtype='string') (python-2 numpy's name of str)."""
+    def f(*a, **k):
+        if k.get("dtype") == "string":
+            k["dtype"] = str
+        return orig(*a, **k)
+    return f
+
+
+def gen_labels(mp, la):
+    """G9: HTS state-aligned labels -> frames per state -> variable-frame-rate labels (magphase.py:2111-2150,
+    libaudio.py:687-708).  The label text is synthetic (5 states per phone, 5 ms grid)."""
+    rng = np.random.RandomState(77)
+    fs = 48000
+    v_shift = np.concatenate([rng.randint(180, 520, size=150), np.full(60, 240), rng.randint(200, 400, size=90)]).astype(int)
+    ep_ms = np.cumsum(v_shift) * 1000.0 / fs
+    n_ph, n_st = 14, 5
+    total_ms = float(np.ceil(ep_ms[-1] / 5.0) * 5.0 + 5.0)
+
+    def make_lab(end_ms, zero_state=None):
+        cuts = np.sort(rng.choice(np.arange(1, int(end_ms / 5.0)), size=n_ph * n_st - 1, replace=False)) * 5.0
+        edges = np.concatenate(([0.0], cuts, [end_ms]))
+        if zero_state is not None:   # a state shorter than any epoch interval: gets no frame
+            k = zero_state
+            edges[k + 1] = edges[k] + 0.0001 * 0 + 5.0
+        lines = []
+        for i in range(n_ph * n_st):
+            ph, st = divmod(i, n_st)
+            lines.append("%d %d x^p%d-p%d+p%d=y@%d_%d[%d]" % (int(round(edges[i] * 10000)), int(round(edges[i + 1] * 10000)),
+                                                           ph, ph + 1, ph + 2, ph % 3, ph % 4, st + 2))
+        return "\n".join(lines) + "\n"
+
+    out = {"fs": fs, "v_shift": v_shift}
+    cases = {"exact": make_lab(total_ms), "short_end": make_lab(float(np.floor(ep_ms[-4] / 5.0) * 5.0)),
+             "too_short": make_lab(float(np.floor(ep_ms[-40] / 5.0) * 5.0))}
+    la.np.loadtxt = _py3_loadtxt(np.loadtxt) if not hasattr(la.np.loadtxt, "__wrapped_py3__") else la.np.loadtxt
+    for name, text in cases.items():
+        with open(name + ".lab", "w") as f:
+            f.write(text)
+        out["lab_" + name] = np.array(text)
+        for pz in (False, True):
+            key = "%s_pz%d" % (name, int(pz))
+            try:
+                v_n = mp.get_num_of_frms_per_state(v_shift, name + ".lab", fs, b_prevent_zeros=pz)
+                out["nfrms_" + key] = np.asarray(v_n, dtype=np.float64)
+                la.convert_label_state_align_to_var_frame_rate(name + ".lab", v_n, name + "_out.lab")
+                out["outlab_" + key] = np.array(open(name + "_out.lab").read())
+            except ValueError as e:
+                out["error_" + key] = np.array(str(e))
+    np.savez_compressed(os.path.join(OUT, "g9_labels.npz"), **out)
+
+
 def main():
     if not ref_shim.reference_available():
         raise SystemExit("reference not present; golden vectors can only be generated in the build container")
@@ -188,6 +240,7 @@ def main():
             gen_unwarp(mp, la)
             gen_compressed_synthesis(mp, lu)
             gen_const_rate(mp, la)
+            gen_labels(mp, la)
         finally:
             os.chdir(cwd)
     for f in sorted(os.listdir(OUT)):
