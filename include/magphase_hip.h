@@ -128,7 +128,17 @@ int mpx_ola_fixup(void* stream, int fft_len, int32_t territory, const float* str
  */
 int mpx_mel_unwarp(void* stream, int64_t n_frames, int32_t n_bins, const float* a_mag, int32_t k_mag,
                    const float* u_mag, float* out_mag, const float* a_real, const float* a_imag, int32_t k_phase,
-                   const float* u_phase, float* out_real, float* out_imag);
+                   const float* u_phase, float* out_real, float* out_imag,
+                   int64_t ld /* row pitch of the three outputs in floats, >= n_bins; see mpx_spec_ld */);
+
+/*
+ * Row pitch the unwarped spectra (outputs of mpx_mel_unwarp / mpx_min_phase, inputs of mpx_synthesis_compressed_ola)
+ * should be allocated with: n_bins rounded up to a multiple of 32 floats.  mpx_mel_unwarp runs on the matrix cores
+ * (v_mfma_f32_32x32x2_f32) and a wave stores 32-float row segments; with 128-byte aligned rows every segment is one
+ * full line (measured: 0.80 -> 0.55 ms for the three matrices of 57 k frames), with the dense pitch every segment
+ * leaves two partially written lines behind.  Any ld >= n_bins is correct.
+ */
+int64_t mpx_spec_ld(int32_t n_bins);
 
 /*
  * Noise-gain statistics (magphase.py:886-903, Q10/Q11): for every frame, the windowed noise frame
@@ -160,7 +170,8 @@ int mpx_synthesis_compressed_ola(void* stream, int fft_len, const void* tables, 
                                  const int32_t* win_right, const int32_t* pm_rel, const float* per_v,
                                  const float* ap_v, const float* ap_u, const void* chunks, int32_t n_chunks,
                                  const int32_t* slot_off, const int32_t* slot_chunks, int32_t n_slots,
-                                 int32_t territory, float* strips);
+                                 int32_t territory, float* strips,
+                                 int64_t ld /* row pitch of mag/real/imag in floats, >= fft_len/2 + 1 */);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Compressed-feature analysis (magphase.py:2490-2544 format_for_modelling, :2947-2988 analysis_compressed)
@@ -190,7 +201,7 @@ int mpx_mel_warp(void* stream, int64_t n_frames, int32_t n_bins, const float* ma
  */
 int mpx_min_phase(void* stream, int fft_len, const void* tables, const float* mag, const int32_t* row0,
                   const int32_t* row1, const float* row_t, int64_t n_frames, float* out_mag, float* out_real,
-                  float* out_imag);
+                  float* out_imag, int64_t ld /* row pitch of mag and of the three outputs, floats */);
 
 /*
  * Noise gains on the device (magphase.py:902-906, Q10): per utterance u and class c (0 voiced, 1 unvoiced)

@@ -23,6 +23,7 @@ SYMBOLS = (
     "mpx_synthesis_lossless_ola",
     "mpx_ola_fixup",
     "mpx_mel_unwarp",
+    "mpx_spec_ld",
     "mpx_noise_stats",
     "mpx_synth_comp_slots",
     "mpx_synthesis_compressed_ola",
@@ -76,17 +77,19 @@ def load():
     lib.mpx_ola_fixup.restype = ctypes.c_int
     lib.mpx_ola_fixup.argtypes = [vp, ctypes.c_int, i32, vp, i32, vp, vp, vp, vp, i32, vp]
     lib.mpx_mel_unwarp.restype = ctypes.c_int
-    lib.mpx_mel_unwarp.argtypes = [vp, i64, i32, vp, i32, vp, vp, vp, vp, i32, vp, vp, vp]
+    lib.mpx_mel_unwarp.argtypes = [vp, i64, i32, vp, i32, vp, vp, vp, vp, i32, vp, vp, vp, i64]
+    lib.mpx_spec_ld.restype = i64
+    lib.mpx_spec_ld.argtypes = [i32]
     lib.mpx_noise_stats.restype = ctypes.c_int
     lib.mpx_noise_stats.argtypes = [vp, ctypes.c_int, vp, vp, vp, vp, vp, vp, i64, vp]
     lib.mpx_synth_comp_slots.restype = ctypes.c_int
     lib.mpx_synth_comp_slots.argtypes = []
     lib.mpx_synthesis_compressed_ola.restype = ctypes.c_int
-    lib.mpx_synthesis_compressed_ola.argtypes = [vp, ctypes.c_int, vp] + [vp] * 19 + [vp, i32, vp, vp, i32, i32, vp]
+    lib.mpx_synthesis_compressed_ola.argtypes = [vp, ctypes.c_int, vp] + [vp] * 19 + [vp, i32, vp, vp, i32, i32, vp, i64]
     lib.mpx_mel_warp.restype = ctypes.c_int
     lib.mpx_mel_warp.argtypes = [vp, i64, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, vp, vp, vp, vp, i64]
     lib.mpx_min_phase.restype = ctypes.c_int
-    lib.mpx_min_phase.argtypes = [vp, ctypes.c_int, vp, vp, vp, vp, vp, i64, vp, vp, vp]
+    lib.mpx_min_phase.argtypes = [vp, ctypes.c_int, vp, vp, vp, vp, vp, i64, vp, vp, vp, i64]
     lib.mpx_noise_gains.restype = ctypes.c_int
     lib.mpx_noise_gains.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp]
     lib.mpx_post_filter.restype = ctypes.c_int

@@ -42,4 +42,4 @@ def build(force=False, verbose=True, extra_flags=()):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv, extra_flags=[a for a in sys.argv[1:] if a.startswith("-R")])
+    build(force="--force" in sys.argv, extra_flags=[a for a in sys.argv[1:] if a.startswith(("-R", "-D"))])

@@ -26,7 +26,7 @@ struct UnwarpJobs {
 constexpr int kGemmFrames = 64;   // frames per block
 constexpr int kGemmKMax = 64;
 
-__global__ __launch_bounds__(256) void k_mel_unwarp(UnwarpJobs jobs, long long F, int H) {
+__global__ __launch_bounds__(256) void k_mel_unwarp(UnwarpJobs jobs, long long F, int H, long long ld) {
     __shared__ float As[kGemmKMax][kGemmFrames];   // transposed tile: As[n][f]
     const UnwarpJob job = jobs.j[blockIdx.z];
     const long long f0 = (long long)blockIdx.y * kGemmFrames;
@@ -55,10 +55,10 @@ __global__ __launch_bounds__(256) void k_mel_unwarp(UnwarpJobs jobs, long long F
             acc[4 * q + 3] = fmaf(a.w, u, acc[4 * q + 3]);
         }
     }
-    float* o = job.out + f0 * H + k;
+    float* o = job.out + f0 * ld + k;
 #pragma unroll
     for (int f = 0; f < kGemmFrames; ++f) {
-        if (f0 + f < F) o[(long long)f * H] = job.op ? expf(acc[f]) : acc[f];
+        if (f0 + f < F) o[(long long)f * ld] = job.op ? expf(acc[f]) : acc[f];
     }
 }
 
@@ -425,7 +425,8 @@ __global__ __launch_bounds__(kThreads) void k_min_phase(const float* __restrict_
                                                         const int* __restrict__ row1,
                                                         const float* __restrict__ rowt, long long nframes,
                                                         const float2* __restrict__ tw_g, float* __restrict__ omag,
-                                                        float* __restrict__ oreal, float* __restrict__ oimag) {
+                                                        float* __restrict__ oreal, float* __restrict__ oimag,
+                                                        long long ld) {
     constexpr int M = 64 * P, N = 2 * M, H = M + 1, LB = ilog2(P);
     extern __shared__ float smem[];
     float2* tw = reinterpret_cast<float2*>(smem);
@@ -445,8 +446,8 @@ __global__ __launch_bounds__(kThreads) void k_min_phase(const float* __restrict_
         asm volatile("" : "+v"(lane), "+v"(wa_s), "+v"(wa_c), "+v"(ws_s), "+v"(ws_c));
         const int r0 = row0[f], r1 = row1[f];
         const float rt = rowt[f];
-        const float* m0p = mag + (long long)r0 * H;
-        const float* m1p = mag + (long long)r1 * H;
+        const float* m0p = mag + (long long)r0 * ld;
+        const float* m1p = mag + (long long)r1 * ld;
         // ---- ln|X| (protected log, libaudio.py:241-248) on bins lane + 64 j, scaled for the inverse transform
         float xr[P], xi[P], mv[P];
         const float scale = 0.5f / (float)M;
@@ -496,9 +497,9 @@ __global__ __launch_bounds__(kThreads) void k_min_phase(const float* __restrict_
         wave_fft<P, -1>(re, im, tw, xbuf, lane);
         const int src_lane = kappa<P>((64 - kap) & 63);
         const bool lane0 = (kap == 0);
-        float* mo = omag + f * H;
-        float* ro = oreal + f * H;
-        float* io = oimag + f * H;
+        float* mo = omag + f * ld;
+        float* ro = oreal + f * ld;
+        float* io = oimag + f * ld;
         // the magnitude row is stored from the lanes that loaded it (bins lane + 64 j)
 #pragma unroll
         for (int j = 0; j < P; ++j) mo[lane + 64 * j] = mv[j];
@@ -568,7 +569,7 @@ __global__ __launch_bounds__(kCompWaves * 64) void k_synth_comp_ola(const float*
                                                                    const int* __restrict__ slot_off,
                                                                    const int* __restrict__ slot_chunks, int nslots,
                                                                    int T, const float2* __restrict__ tw_g,
-                                                                   float* __restrict__ strips) {
+                                                                   float* __restrict__ strips, long long ld) {
     constexpr int M = 64 * P, N = 2 * M, H = M + 1, LB = ilog2(P), R = ring_len<P>();
     extern __shared__ float smem[];
     float2* tw = reinterpret_cast<float2*>(smem);
@@ -608,8 +609,8 @@ __global__ __launch_bounds__(kCompWaves * 64) void k_synth_comp_ola(const float*
             const int r0 = tb.row0[fi], r1 = tb.row1[fi];
             const float rt = tb.rowt[fi];           // 0 when r0 == r1: the lerp below is then exact
             FrameFeat<P> f0v, f1v;
-            feat_load<P>(f0v, mag + (long long)r0 * H, real + (long long)r0 * H, imag + (long long)r0 * H, lane);
-            feat_load<P>(f1v, mag + (long long)r1 * H, real + (long long)r1 * H, imag + (long long)r1 * H, lane);
+            feat_load<P>(f0v, mag + (long long)r0 * ld, real + (long long)r0 * ld, imag + (long long)r0 * ld, lane);
+            feat_load<P>(f1v, mag + (long long)r1 * ld, real + (long long)r1 * ld, imag + (long long)r1 * ld, lane);
             const float* apc = voiced ? ap_v : ap_u;   // aperiodic curve of the frame's class (uniform select)
             const float pvs = voiced ? 1.0f : 0.0f;     // periodic component only in voiced frames
             float cpv[P], cap[P];
@@ -718,16 +719,140 @@ __global__ __launch_bounds__(kCompWaves * 64) void k_synth_comp_ola(const float*
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Mel unwarp on the matrix cores: out[F x H] = op(A[F x K] . U[K x H]) with v_mfma_f32_32x32x2_f32 (f32 in, f32
+// accumulate: bit-for-bit an fmaf chain in k order, so the result equals the VALU form's).  One wave = one task =
+// 32 frames x kUnwarpColTiles column tiles of 32 bins.  Nothing is staged in LDS: A (F x K, a few MB) and U (K x H,
+// < 0.5 MB) are L2 resident and a lane's fragment element is one dword either way; the kernel is bound by the
+// 12 H bytes per frame it writes.  A fragment: lane l holds A[f0 + (l & 31)][2t + (l >> 5)] for t < KH (kept for
+// the whole task); B fragment: U[2t + (l >> 5)][j0 + (l & 31)], the next tile's loads in flight behind this
+// tile's KH MFMAs; C: column j0 + (l & 31), row (r & 3) + 8 (r >> 2) + 4 (l >> 5) of register r.
+// ---------------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int kUnwarpColTiles = 16;   // 512 bins per task
+
+template <int KH>
+__global__ __launch_bounds__(256) void k_mel_unwarp_mfma(UnwarpJobs jobs, int job0, long long F, int H,
+                                                         int col_parts, long long n_tasks, int ld) {
+    const UnwarpJob job = jobs.j[job0 + blockIdx.y];
+    const int lane = threadIdx.x & 63;
+    const long long task = (long long)blockIdx.x * 4 + rfl((int)(threadIdx.x >> 6));   // wave-uniform, and known to be
+    if (task >= n_tasks) return;
+    // row tile fastest: the 4 waves of a workgroup work on the same columns at the same time and share their B
+    // fragments (the U slab) through the vector L1 -- with the column part fastest the kernel is bound by L2 -> L1 traffic
+    const long long row_tiles = n_tasks / col_parts;
+    const int cp = (int)(task / row_tiles);
+    const long long rt = task - cp * row_tiles;
+    const long long f0 = rt * 32;
+    const int K = job.K;
+    const int kk = lane >> 5, li = lane & 31;
+
+    float a[KH];
+    {
+        const long long f = min(f0 + li, F - 1);   // rows past F are computed on a copy of the last row, never stored
+        const float* arow = job.A + f * K;
+#pragma unroll
+        for (int t = 0; t < KH; ++t) {
+            const int k = 2 * t + kk;
+            a[t] = arow[min(k, K - 1)];
+            a[t] = (k < K) ? a[t] : 0.0f;
+        }
+    }
+    const int jbeg = cp * (kUnwarpColTiles * 32);
+    const int jend = min(H, jbeg + kUnwarpColTiles * 32);
+    if (jbeg >= jend) return;
+    // Two column tiles (64 bins) per step: their stores go out back to back, so every row gets 256 contiguous bytes at
+    // once.  The B fragments are refilled for the NEXT step right behind the MFMA that consumed them (a whole step of
+    // MFMA time for the L2 round trip, no second register set).
+    float b0[KH], b1[KH];
+    // U[2t + kk][col] through a buffer descriptor: wave-uniform scalar offset 2t H (bytes) + one per-lane offset
+    // (kk H + col) -- no per-t address registers; rows >= K fall outside the descriptor and read as 0 (their A element
+    // is 0 anyway), columns >= H read the next row's start and are never stored.
+    const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(job.U), 0, K * H * 4, 0x00020000);
+    const int row2 = 8 * H;   // bytes between rows 2t and 2t + 2
+    const bool op_exp = rfl(job.op) != 0;
+    const int nrows = (int)min((long long)32, F - f0);
+    const int HO = ld;   // output row pitch
+    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(job.out + f0 * HO, 0, nrows * HO * 4, 0x00020000);
+    // rows k >= K (K odd, or K/2 rounded up to the even KH) multiply a zero of A but must still read finite memory
+    // inside U: 2t >= K reads rows 0/1 (scalar select), 2t + 1 == K reads row 2t in both half-waves.
+    auto soff = [&](int t) { return (2 * t < K) ? t * row2 : 0; };
+    {
+        const int v0 = 4 * (kk * H + jbeg + li), v0e = 4 * (jbeg + li);
+#pragma unroll
+        for (int t = 0; t < KH; ++t) {
+            const int v = (2 * t + 1 == K) ? v0e : v0;
+            b0[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(urs, v, soff(t), 0));
+            b1[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(urs, v + 128, soff(t), 0));
+        }
+    }
+    const bool full_rows = nrows == 32;
+    for (int j0 = jbeg; j0 < jend; j0 += 64) {
+        const int vn0 = 4 * (kk * H + j0 + 64 + li), vn0e = 4 * (j0 + 64 + li);
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.0f;
+#pragma unroll
+        for (int t = 0; t < KH; ++t) {
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b0[t], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b1[t], acc1, 0, 0, 0);
+            const int v = (2 * t + 1 == K) ? vn0e : vn0;
+            b0[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(urs, v, soff(t), 0));
+            b1[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(urs, v + 128, soff(t), 0));
+        }
+        // Stores through a descriptor of this task's output rows: one wave-uniform scalar offset per accumulator
+        // register, no address arithmetic.  The bounds check of a raw buffer does not see the scalar offset, so the
+        // rows >= F of the last row tile are masked through the per-lane offset (out of range = dropped), like the
+        // columns >= H of the last column part.
+        const int c0 = j0 + li, c1 = c0 + 32;
+        const int vo0 = (c0 < jend) ? 4 * (4 * kk * HO + c0) : 0x7ffffff0;
+        const int vo1 = (c1 < jend) ? 4 * (4 * kk * HO + c1) : 0x7ffffff0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2);
+            const int so = row * (4 * HO);
+            const bool ok = full_rows || (row + 4 * kk < nrows);
+            const float v0 = op_exp ? __expf(acc0[r]) : acc0[r];
+            const float v1 = op_exp ? __expf(acc1[r]) : acc1[r];
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v0), ors, ok ? vo0 : 0x7ffffff0, so, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v1), ors, ok ? vo1 : 0x7ffffff0, so, 0);
+        }
+    }
+}
+
+template <int KH>
+static int launch_unwarp_mfma(hipStream_t s, const UnwarpJobs& jobs, int job0, int njobs, long long F, int H, int ld) {
+    const int col_parts = (H + kUnwarpColTiles * 32 - 1) / (kUnwarpColTiles * 32);
+    const long long n_tasks = ((F + 31) / 32) * col_parts;
+    const dim3 grid((unsigned)((n_tasks + 3) / 4), (unsigned)njobs);
+    hipLaunchKernelGGL(k_mel_unwarp_mfma<KH>, grid, dim3(256), 0, s, jobs, job0, F, H, col_parts, n_tasks, ld);
+    return MPX_OK;
+}
+
+static int dispatch_unwarp_mfma(hipStream_t s, const UnwarpJobs& jobs, int job0, int njobs, int K, long long F, int H,
+                                int ld) {
+    switch ((K + 3) / 4) {   // KH = K/2 rounded up to even: 16 instantiations cover K <= 64
+#define MPX_UNWARP_CASE(q) case q: return launch_unwarp_mfma<2 * q>(s, jobs, job0, njobs, F, H, ld);
+        MPX_UNWARP_CASE(1) MPX_UNWARP_CASE(2) MPX_UNWARP_CASE(3) MPX_UNWARP_CASE(4) MPX_UNWARP_CASE(5) MPX_UNWARP_CASE(6)
+        MPX_UNWARP_CASE(7) MPX_UNWARP_CASE(8) MPX_UNWARP_CASE(9) MPX_UNWARP_CASE(10) MPX_UNWARP_CASE(11) MPX_UNWARP_CASE(12)
+        MPX_UNWARP_CASE(13) MPX_UNWARP_CASE(14) MPX_UNWARP_CASE(15) MPX_UNWARP_CASE(16)
+#undef MPX_UNWARP_CASE
+    }
+    return fail(MPX_ERR_ARG, "mpx_mel_unwarp: coefficient count must be in 1..64%s");
+}
+
 }  // namespace mpx
 
 using namespace mpx;
 
 extern "C" {
 
+int64_t mpx_spec_ld(int32_t n_bins) { return n_bins <= 0 ? 0 : ((int64_t)n_bins + 31) / 32 * 32; }
+
 int mpx_mel_unwarp(void* stream, int64_t n_frames, int32_t n_bins, const float* a_mag, int32_t k_mag,
                    const float* u_mag, float* out_mag, const float* a_real, const float* a_imag, int32_t k_phase,
-                   const float* u_phase, float* out_real, float* out_imag) {
-    if (n_frames < 0 || n_bins <= 0) return fail(MPX_ERR_ARG, "mpx_mel_unwarp: bad size%s");
+                   const float* u_phase, float* out_real, float* out_imag, int64_t ld) {
+    if (n_frames < 0 || n_bins <= 0 || ld < n_bins || ld > (1 << 20)) return fail(MPX_ERR_ARG, "mpx_mel_unwarp: bad size%s");
     if (k_mag <= 0 || k_mag > kGemmKMax || k_phase <= 0 || k_phase > kGemmKMax)
         return fail(MPX_ERR_ARG, "mpx_mel_unwarp: coefficient count must be in 1..64%s");
     if (n_frames == 0) return MPX_OK;
@@ -737,9 +862,15 @@ int mpx_mel_unwarp(void* stream, int64_t n_frames, int32_t n_bins, const float* 
     jobs.j[0] = {a_mag, u_mag, out_mag, (int)k_mag, 1};
     jobs.j[1] = {a_real, u_phase, out_real, (int)k_phase, 0};
     jobs.j[2] = {a_imag, u_phase, out_imag, (int)k_phase, 0};
+#ifdef MPX_UNWARP_VALU
     const dim3 grid((unsigned)((n_bins + 255) / 256), (unsigned)((n_frames + kGemmFrames - 1) / kGemmFrames), 3);
     if (grid.y > 65535) return fail(MPX_ERR_ARG, "mpx_mel_unwarp: too many frames per call (max 4194240)%s");
-    hipLaunchKernelGGL(k_mel_unwarp, grid, dim3(256), 0, (hipStream_t)stream, jobs, (long long)n_frames, (int)n_bins);
+    hipLaunchKernelGGL(k_mel_unwarp, grid, dim3(256), 0, (hipStream_t)stream, jobs, (long long)n_frames, (int)n_bins,
+                       (long long)ld);
+#else
+    if (int rc = dispatch_unwarp_mfma((hipStream_t)stream, jobs, 0, 1, (int)k_mag, (long long)n_frames, (int)n_bins, (int)ld)) return rc;
+    if (int rc = dispatch_unwarp_mfma((hipStream_t)stream, jobs, 1, 2, (int)k_phase, (long long)n_frames, (int)n_bins, (int)ld)) return rc;
+#endif
     MPX_HIP_CHECK(hipGetLastError());
     return MPX_OK;
 }
@@ -778,7 +909,7 @@ int mpx_synthesis_compressed_ola(void* stream, int fft_len, const void* tables, 
                                  const int32_t* win_right, const int32_t* pm_rel, const float* per_v,
                                  const float* ap_v, const float* ap_u, const void* chunks, int32_t n_chunks,
                                  const int32_t* slot_off, const int32_t* slot_chunks, int32_t n_slots,
-                                 int32_t territory, float* strips) {
+                                 int32_t territory, float* strips, int64_t ld) {
     const int P = p_of(fft_len);
     if (!P) return fail(MPX_ERR_ARG, "mpx_synthesis_compressed_ola: fft_len must be 2048 or 4096%s");
     if (n_chunks < 0 || n_slots < 0) return fail(MPX_ERR_ARG, "mpx_synthesis_compressed_ola: negative count%s");
@@ -797,12 +928,12 @@ int mpx_synthesis_compressed_ola(void* stream, int fft_len, const void* tables, 
         if (int rc = set_lds(k_synth_comp_ola<32>, lds_bytes_comp<32>())) return rc;
         hipLaunchKernelGGL(k_synth_comp_ola<32>, grid, block, lds_bytes_comp<32>(), s, mag, real, imag, noise, tb,
                            per_v, ap_v, ap_u, (const ChunkDesc*)chunks, slot_off, slot_chunks, (int)n_slots,
-                           (int)territory, (const float2*)tables, strips);
+                           (int)territory, (const float2*)tables, strips, (long long)ld);
     } else {
         if (int rc = set_lds(k_synth_comp_ola<16>, lds_bytes_comp<16>())) return rc;
         hipLaunchKernelGGL(k_synth_comp_ola<16>, grid, block, lds_bytes_comp<16>(), s, mag, real, imag, noise, tb,
                            per_v, ap_v, ap_u, (const ChunkDesc*)chunks, slot_off, slot_chunks, (int)n_slots,
-                           (int)territory, (const float2*)tables, strips);
+                           (int)territory, (const float2*)tables, strips, (long long)ld);
     }
     MPX_HIP_CHECK(hipGetLastError());
     return MPX_OK;
@@ -834,7 +965,7 @@ int mpx_mel_warp(void* stream, int64_t n_frames, int32_t n_bins, const float* ma
 
 int mpx_min_phase(void* stream, int fft_len, const void* tables, const float* mag, const int32_t* row0,
                   const int32_t* row1, const float* row_t, int64_t n_frames, float* out_mag, float* out_real,
-                  float* out_imag) {
+                  float* out_imag, int64_t ld) {
     const int P = p_of(fft_len);
     if (!P) return fail(MPX_ERR_ARG, "mpx_min_phase: fft_len must be 2048 or 4096%s");
     if (n_frames < 0) return fail(MPX_ERR_ARG, "mpx_min_phase: negative n_frames%s");
@@ -846,11 +977,11 @@ int mpx_min_phase(void* stream, int fft_len, const void* tables, const float* ma
     if (P == 32) {
         if (int rc = set_lds(k_min_phase<32>, lds_bytes<32>())) return rc;
         hipLaunchKernelGGL(k_min_phase<32>, grid, block, lds_bytes<32>(), s, mag, row0, row1, row_t,
-                           (long long)n_frames, (const float2*)tables, out_mag, out_real, out_imag);
+                           (long long)n_frames, (const float2*)tables, out_mag, out_real, out_imag, (long long)ld);
     } else {
         if (int rc = set_lds(k_min_phase<16>, lds_bytes<16>())) return rc;
         hipLaunchKernelGGL(k_min_phase<16>, grid, block, lds_bytes<16>(), s, mag, row0, row1, row_t,
-                           (long long)n_frames, (const float2*)tables, out_mag, out_real, out_imag);
+                           (long long)n_frames, (const float2*)tables, out_mag, out_real, out_imag, (long long)ld);
     }
     MPX_HIP_CHECK(hipGetLastError());
     return MPX_OK;

@@ -524,7 +524,9 @@ class CompressedSynthesisPlan:
         torch = _torch()
         H = N // 2 + 1
         tab = e.tables(N)
-        mag, real, imag = (e.empty((self.n_rows, H)) for _ in range(3))
+        # unwarped spectra: internal matrices, rows 128-byte aligned (mpx_spec_ld: full-line stores of the MFMA unwarp)
+        ld = int(lib.mpx_spec_ld(H))
+        mag, real, imag = (e.empty((self.n_rows, ld))[:, :H] for _ in range(3))
         sums = e.empty((self.total_frames,))
         strips = e.empty((self.strip_floats,))
         with torch.cuda.device(e.device):
@@ -532,7 +534,7 @@ class CompressedSynthesisPlan:
             a_mag = e.post_filter(self.a_mag, self.fs) if self.apply_post_filter else self.a_mag   # magphase.py:3259-3261
             _lib.check(lib.mpx_mel_unwarp(st, self.n_rows, H, a_mag.data_ptr(), self.mag_dim, self.u_mag.data_ptr(),
                                           mag.data_ptr(), self.a_real.data_ptr(), self.a_imag.data_ptr(),
-                                          self.phase_dim, self.u_phase.data_ptr(), real.data_ptr(), imag.data_ptr()),
+                                          self.phase_dim, self.u_phase.data_ptr(), real.data_ptr(), imag.data_ptr(), ld),
                        "mpx_mel_unwarp")
             _lib.check(lib.mpx_noise_stats(st, N, tab.data_ptr(), self.noise.data_ptr(), self.npos.data_ptr(),
                                            self.nleft.data_ptr(), self.nright.data_ptr(), self.wtype.data_ptr(),
@@ -551,16 +553,16 @@ class CompressedSynthesisPlan:
                 F = self.total_frames
                 ident = torch.arange(F, dtype=torch.int32, device=e.device)
                 zeros_t = torch.zeros(F, dtype=torch.float32, device=e.device)
-                mag_v, real_v, imag_v = (e.empty((F, H)) for _ in range(3))
+                mag_v, real_v, imag_v = (e.empty((F, ld))[:, :H] for _ in range(3))
                 if self.per_phase_type == "min_phase":
                     _lib.check(lib.mpx_min_phase(st, N, tab.data_ptr(), mag.data_ptr(), row0.data_ptr(),
                                                  row1.data_ptr(), rowt.data_ptr(), F, mag_v.data_ptr(),
-                                                 real_v.data_ptr(), imag_v.data_ptr()), "mpx_min_phase")
+                                                 real_v.data_ptr(), imag_v.data_ptr(), ld), "mpx_min_phase")
                     mag, real, imag = mag_v, real_v, imag_v
                     row0, row1, rowt = ident, ident, zeros_t
                 else:
-                    real = torch.ones_like(real)
-                    imag = torch.zeros_like(imag)
+                    real.fill_(1.0)
+                    imag.fill_(0.0)
             _lib.check(lib.mpx_synthesis_compressed_ola(
                 st, N, tab.data_ptr(), mag.data_ptr(), real.data_ptr(), imag.data_ptr(), self.noise.data_ptr(),
                 self.npos.data_ptr(), self.nleft.data_ptr(), self.nright.data_ptr(), self.wtype.data_ptr(),
@@ -568,7 +570,7 @@ class CompressedSynthesisPlan:
                 rowt.data_ptr(), self.win_l.data_ptr(), self.win_r.data_ptr(), self.pm_rel.data_ptr(),
                 self.per_v.data_ptr(), self.ap_v.data_ptr(), self.ap_u.data_ptr(), self.chunks.data_ptr(),
                 self.n_chunks, self.slot_off.data_ptr(), self.slot_chunks.data_ptr(), self.n_slots, self.territory,
-                strips.data_ptr()), "mpx_synthesis_compressed_ola")
+                strips.data_ptr(), ld), "mpx_synthesis_compressed_ola")
         pcm = e.ola_fixup(N, self.territory, strips, self.utt_chunk_off, self.strip_id, self.out_start, self.out_off,
                           self.max_territories, self.total_out, out=out)
         if keep:
