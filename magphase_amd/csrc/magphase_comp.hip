@@ -720,6 +720,107 @@ __global__ __launch_bounds__(kCompWaves * 64) void k_synth_comp_ola(const float*
 }
 
 // ---------------------------------------------------------------------------------------------
+// Mel warp on the matrix cores: out[F x nout] = ln-prologue(x)[F x H] . W^T[H x nout], v_mfma_f32_16x16x4_f32.
+// One workgroup = 64 output frames x up to 64 outputs; the reduction runs over the H bins in chunks of 64.  Per chunk
+// the 256 threads stage the prologue values and the W slab into LDS as [row][k] (k contiguous, row stride 68 floats:
+// conflict-free dword writes with k across lanes, 16-byte fragment reads); wave w then owns the frames
+// 16 w .. 16 w + 15 and every 16-wide column tile.  The MFMA sums over k in any order, so lane group g = lane >> 4
+// takes k = 16 g + 4 q + {0..3} for the four instructions of step q: a lane's fragment is one ds_read_b128 per step.
+// Instructions of the column tiles are interleaved (dependent-accumulator latency 40 cycles > issue 32).
+// ---------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int NT>   // 16-wide column tiles in use: ceil(nout / 16)
+__global__ __launch_bounds__(256) void k_mel_warp_mfma(WarpJobs jobs, int job0, long long F, int H,
+                                                       const int* __restrict__ row0, const int* __restrict__ row1,
+                                                       const float* __restrict__ rowt, long long ld) {
+    __shared__ __attribute__((aligned(16))) float As[kWarpTile][kWarpStride];   // As[f][k]
+    __shared__ __attribute__((aligned(16))) float Ws[kWarpTile][kWarpStride];   // Ws[i][k]
+    __shared__ long long s_o0[kWarpTile], s_o1[kWarpTile];   // element offsets of the two input rows of a frame
+    __shared__ float s_rt[kWarpTile];
+    const WarpJob job = jobs.j[job0 + blockIdx.z];
+    const long long f0 = (long long)blockIdx.y * kWarpTile;
+    const int kk = threadIdx.x & 63, fq = threadIdx.x >> 6;   // staging roles: bin within the chunk, frame quarter
+    const int wave = rfl((int)(threadIdx.x >> 6));
+    const int li = kk & 15, g = kk >> 4;                      // fragment roles
+    if (threadIdx.x < kWarpTile) {
+        const long long f = min(f0 + (long long)threadIdx.x, F - 1);
+        s_o0[threadIdx.x] = (long long)(row0 ? row0[f] : (int)f) * ld;
+        s_o1[threadIdx.x] = (long long)(row0 ? row1[f] : (int)f) * ld;
+        s_rt[threadIdx.x] = row0 ? rowt[f] : 0.0f;
+    }
+    __syncthreads();
+    f32x4 acc[NT];
+#pragma unroll
+    for (int jt = 0; jt < NT; ++jt) acc[jt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+    // Every load is unconditional (clamped bin): the 48 loads of a chunk are in flight together, and the NEXT chunk's
+    // are issued right after this chunk's values are in LDS, so they fly behind the fragment reads and the MFMAs.
+    // (Refilling each staging register as soon as it is consumed costs a second register set: 204 VGPRs, 2 workgroups
+    // per CU instead of 3, measured 10 % slower.)
+    float xv[16], xw[16], wv16[16];
+    auto fetch = [&](int k0) {
+        const int kc = min(k0 + kk, H - 1);
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+            const int fl = fq + 4 * p;
+            xv[p] = job.x[s_o0[fl] + kc];
+            xw[p] = job.x[s_o1[fl] + kc];
+            wv16[p] = job.W[(long long)min(fl, job.nout - 1) * H + kc];
+        }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < H; k0 += kWarpTile) {
+        const bool kok = k0 + kk < H;
+#pragma unroll
+        for (int p = 0; p < 16; ++p) {
+            const int fl = fq + 4 * p;
+            const float x = fmaf(xw[p] - xv[p], s_rt[fl], xv[p]);
+            // hardware exp2/log2 (v_exp_f32 / v_log_f32, ~1 ulp): the 1e-7 error is far below the stated tolerance
+            // of this (ill-conditioned, unpinned) stage
+            const float e = (job.mode == 0) ? x : __expf(x);
+            const float v = __logf(fmaf(e, e, 1.0e-8f));
+            As[fl][kk] = (kok && f0 + fl < F) ? v : 0.0f;
+            Ws[fl][kk] = (kok && fl < job.nout) ? wv16[p] : 0.0f;
+        }
+        __syncthreads();
+        if (k0 + kWarpTile < H) fetch(k0 + kWarpTile);
+        const float* arow = &As[16 * wave + li][16 * g];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {   // 4 k per lane group and step: one 16-byte read per fragment
+            const float4 aq = *reinterpret_cast<const float4*>(arow + 4 * q);
+            float4 bq[NT];
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt) bq[jt] = *reinterpret_cast<const float4*>(&Ws[16 * jt + li][16 * g + 4 * q]);
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt) acc[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.x, bq[jt].x, acc[jt], 0, 0, 0);
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt) acc[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.y, bq[jt].y, acc[jt], 0, 0, 0);
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt) acc[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.z, bq[jt].z, acc[jt], 0, 0, 0);
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt) acc[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.w, bq[jt].w, acc[jt], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // C: column li of tile jt, row 4 g + r of this wave's 16 frames
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const long long f = f0 + 16 * wave + 4 * g + r;
+        if (f >= F) continue;
+        const float vo = job.voi ? job.voi[f] : 1.0f;
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt) {
+            const int i = 16 * jt + li;
+            if (i >= job.nout) continue;
+            float y = acc[jt][r];
+            if (job.mode == 1) y = fminf(fmaxf(y * vo, -1.0f), 1.0f);
+            job.out[f * job.nout + i] = y;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Mel unwarp on the matrix cores: out[F x H] = op(A[F x K] . U[K x H]) with v_mfma_f32_32x32x2_f32 (f32 in, f32
 // accumulate: bit-for-bit an fmaf chain in k order, so the result equals the VALU form's).  One wave = one task =
 // 32 frames x kUnwarpColTiles column tiles of 32 bins.  Nothing is staged in LDS: A (F x K, a few MB) and U (K x H,
@@ -957,8 +1058,27 @@ int mpx_mel_warp(void* stream, int64_t n_frames, int32_t n_bins, const float* ma
     jobs.j[2] = {imag, w_phase, out_imag, voiced, (int)phase_dim, 1};
     const dim3 grid(1, (unsigned)((n_frames + kWarpTile - 1) / kWarpTile), 3);
     if (grid.y > 65535) return fail(MPX_ERR_ARG, "mpx_mel_warp: too many frames per call (max 4194240)%s");
+#ifdef MPX_WARP_VALU
     hipLaunchKernelGGL(k_mel_warp, grid, dim3(256), 0, (hipStream_t)stream, jobs, (long long)n_frames, (int)n_bins,
                        row0, row1, row_t, (long long)ld);
+#else
+    // ONE launch for the three jobs (separate launches end in a half-empty last round of workgroups); the
+    // column-tile count is a template parameter, so it is sized for the wider job.
+    {
+        const int job0 = 0;
+        const dim3 g2(1, grid.y, 3);
+#define MPX_WARP_LAUNCH(NT)                                                                                        \
+    hipLaunchKernelGGL(k_mel_warp_mfma<NT>, g2, dim3(256), 0, (hipStream_t)stream, jobs, job0, (long long)n_frames, \
+                       (int)n_bins, row0, row1, row_t, (long long)ld)
+        switch ((std::max(mag_dim, phase_dim) + 15) / 16) {
+            case 1: MPX_WARP_LAUNCH(1); break;
+            case 2: MPX_WARP_LAUNCH(2); break;
+            case 3: MPX_WARP_LAUNCH(3); break;
+            default: MPX_WARP_LAUNCH(4); break;
+        }
+#undef MPX_WARP_LAUNCH
+    }
+#endif
     MPX_HIP_CHECK(hipGetLastError());
     return MPX_OK;
 }
