@@ -7,7 +7,8 @@
 //   k_synth_lossless<P>     one wavefront per frame: 3 x H coalesced loads -> unit-phase spectrum ->
 //                           Hermitian merge -> inverse FFT -> epoch-centred frame.      HBM-read bound.
 //   k_ola_gather            one thread per output sample, ascending-frame gather (deterministic PSOLA).
-// No MFMA anywhere: nothing on this path is a dense contraction.
+// No MFMA in this file: nothing on the lossless path is a dense contraction; the mel
+// warp / unwarp GEMMs of the compressed path (magphase_comp.hip) run on the fp32 MFMA.
 #include "mpx_common.hpp"
 
 namespace mpx {
