@@ -720,6 +720,268 @@ __global__ __launch_bounds__(kCompWaves * 64) void k_synth_comp_ola(const float*
 }
 
 // ---------------------------------------------------------------------------------------------
+// Compressed-feature synthesis + PSOLA, pair form: two waves share one LDS ring and alternate over the frames of the
+// pair's chunks (tickets in LDS, exactly as k_synth_ola_pair), 8 waves per CU.  The single-wave form above holds both
+// feature rows, the per-bin curves and the noise FFT at once (466 VGPRs, ONE wave per SIMD: at one instruction per
+// ~5.4 cycles and wave its ~7.5 k instructions per frame are the whole run time).  Here the noise spectrum is
+// computed first and the features are folded into it in place, half a spectrum (16 register rows) at a time:
+// 64 + 128 live registers instead of 64 + 262, so two waves fit a SIMD.
+// ---------------------------------------------------------------------------------------------
+constexpr int kCompPairWaves = 8;
+constexpr int kCompPairs = kCompPairWaves / 2;
+template <int P>
+constexpr size_t lds_bytes_comp_pair() {
+    return sizeof(float) * (size_t)(P * 64 * 2 + kCompPairWaves * (P * kXStride) + kCompPairs * ring_len<P>() + 16);
+}
+
+template <int P>
+__global__ __launch_bounds__(kCompPairWaves * 64) void k_synth_comp_pair(const float* __restrict__ mag,
+                                                                        const float* __restrict__ real,
+                                                                        const float* __restrict__ imag,
+                                                                        const float* __restrict__ noise,
+                                                                        CompFrameTabs tb,
+                                                                        const float* __restrict__ per_v,
+                                                                        const float* __restrict__ ap_v,
+                                                                        const float* __restrict__ ap_u,
+                                                                        const ChunkDesc* __restrict__ chunks,
+                                                                        const int* __restrict__ slot_off,
+                                                                        const int* __restrict__ slot_chunks,
+                                                                        int nslots, int T,
+                                                                        const float2* __restrict__ tw_g,
+                                                                        float* __restrict__ strips, long long ld) {
+    constexpr int M = 64 * P, N = 2 * M, LB = ilog2(P), R = ring_len<P>(), RH = R / 2;
+    extern __shared__ float smem[];
+    float2* tw = reinterpret_cast<float2*>(smem);
+    const int lane_id = threadIdx.x & 63;
+    const int wave = rfl((int)(threadIdx.x >> 6));
+    const int pair = wave >> 1, half = wave & 1;
+    float* xbuf = smem + P * 64 * 2 + wave * (P * kXStride);
+    const unsigned xbuf_byte = 4u * (unsigned)(P * 64 * 2 + wave * (P * kXStride));
+    float* ring = smem + P * 64 * 2 + kCompPairWaves * (P * kXStride) + pair * R;
+    int* turn = reinterpret_cast<int*>(smem + P * 64 * 2 + kCompPairWaves * (P * kXStride) + kCompPairs * R) + pair;
+    for (int i = threadIdx.x; i < P * 64; i += kCompPairWaves * 64) tw[i] = tw_g[i];
+    for (int i = threadIdx.x; i < kCompPairs * R; i += kCompPairWaves * 64)
+        smem[P * 64 * 2 + kCompPairWaves * (P * kXStride) + i] = 0.0f;
+    if (threadIdx.x < kCompPairs) turn[threadIdx.x - pair] = 0;   // thread t < kCompPairs has pair == 0
+    __syncthreads();
+
+    float wa_s0, wa_c0, ws_s0, ws_c0;   // analysis-side lane twiddle W_N^kappa and synthesis-side conj(W_N^lane)
+    sincospif(-2.0f * (float)kappa<P>(lane_id) / (float)N, &wa_s0, &wa_c0);
+    sincospif(2.0f * (float)lane_id / (float)N, &ws_s0, &ws_c0);
+    const int strip_len = T + N;
+    const int slot = blockIdx.x * kCompPairs + pair;
+    if (slot >= nslots) return;
+
+    // cursor over this wave's frames: every second frame of every chunk of the pair's work list (see k_synth_ola_pair)
+    struct Cursor {
+        int wi, fi, ci, ticket_base, fb, fe, x0, valid;
+    };
+    const int wi_end = slot_off[slot + 1];
+    auto settle = [&](Cursor& c) {
+        while (c.wi < wi_end) {
+            c.ci = slot_chunks[c.wi];
+            const ChunkDesc cd = chunks[c.ci];
+            c.fb = cd.frame_begin;
+            c.fe = cd.frame_end;
+            c.x0 = cd.x0;
+            c.fi = c.fb + half;
+            if (c.fi < c.fe) {
+                c.valid = 1;
+                return;
+            }
+            c.ticket_base += c.fe - c.fb;
+            ++c.wi;
+        }
+        c.valid = 0;
+    };
+    auto advance = [&](Cursor& c) {
+        c.fi += 2;
+        if (c.fi >= c.fe) {
+            c.ticket_base += c.fe - c.fb;
+            ++c.wi;
+            settle(c);
+        }
+    };
+    Cursor cur;
+    cur.wi = slot_off[slot];
+    cur.ticket_base = 0;
+    settle(cur);
+
+    while (cur.valid) {
+        int lane = lane_id;
+        float wa_s = wa_s0, wa_c = wa_c0, ws_s = ws_s0, ws_c = ws_c0;
+        asm volatile("" : "+v"(lane), "+v"(wa_s), "+v"(wa_c), "+v"(ws_s), "+v"(ws_c));
+        Cursor nxt = cur;
+        advance(nxt);
+        const int fi = cur.fi;
+
+        // ---- aperiodic source: spectrum of this frame's windowed noise, bins k = lane + 64 j
+        float xr[P], xi[P], nM;
+        {
+            const FrameGeom g = frame_geom(noise, tb.npos[fi], tb.nleft[fi], tb.nright[fi], N);
+            noise_spectrum<P>(g, tb.wtype[fi], tw, xbuf, xbuf_byte, lane, wa_c, wa_s, xr, xi, nM);
+            if (P == 16) {   // FFT output lanes hold bins kappa(lane)+64j; everything below wants bins lane+64j
+                const int src = kappa<P>(lane);
+#pragma unroll
+                for (int j = 0; j < P; ++j) {
+                    xr[j] = __shfl(xr[j], src);
+                    xi[j] = __shfl(xi[j], src);
+                }
+                nM = __shfl(nM, src);
+            }
+        }
+
+        // ---- spectrum assembly (Appendix A2 steps 9-12) in place, HB register rows at a time: all loads of a batch are
+        // issued together and branch-free (one memory latency per batch)
+        const int voiced = tb.voiced[fi];
+        const float ig = tb.inv_gain[fi];
+        const int r0 = tb.row0[fi], r1 = tb.row1[fi];
+        const float rt = tb.rowt[fi];               // 0 when r0 == r1: the lerp below is then exact
+        const float* apc = voiced ? ap_v : ap_u;    // aperiodic curve of the frame's class (uniform select)
+        const float pvs = voiced ? 1.0f : 0.0f;     // periodic component only in voiced frames
+        const float sgn_scale = ((lane & 1) ? -1.0f : 1.0f) * (0.5f / (float)M);
+        const float* m0p = mag + (long long)r0 * ld;
+        const float* a0p = real + (long long)r0 * ld;
+        const float* b0p = imag + (long long)r0 * ld;
+        const float* m1p = mag + (long long)r1 * ld;
+        const float* a1p = real + (long long)r1 * ld;
+        const float* b1p = imag + (long long)r1 * ld;
+        float xm = 0.0f;
+#ifndef MPX_COMP_FEAT_ROWS
+#define MPX_COMP_FEAT_ROWS 16
+#endif
+        constexpr int HB = MPX_COMP_FEAT_ROWS;   // register rows per batch: 8 x HB loads in flight
+#pragma unroll
+        for (int h = 0; h < P / HB; ++h) {
+            float m0[HB], a0[HB], b0[HB], m1[HB], a1[HB], b1[HB], cpv[HB], cap[HB];
+            // keep each half's loads where they are written: hoisted above the noise spectrum (or into the other
+            // half) they cost 190 spilled registers
+            // (the compiler moves loads of read-only memory across plain barriers: the lane offset is laundered with a
+            // fake dependency on the last value produced before this half)
+            int lo = lane;
+            {
+                const int c0 = (h == 0) ? 0 : (h - 1) * HB, c1 = (h == 0) ? P : h * HB;   // everything produced so far
+#pragma unroll
+                for (int c = c0; c < c1; c += 8)
+                    asm volatile("" : "+v"(lo)
+                                 : "v"(xr[c]), "v"(xr[c + 1]), "v"(xr[c + 2]), "v"(xr[c + 3]), "v"(xr[c + 4]), "v"(xr[c + 5]),
+                                   "v"(xr[c + 6]), "v"(xr[c + 7]), "v"(xi[c]), "v"(xi[c + 1]), "v"(xi[c + 2]), "v"(xi[c + 3]),
+                                   "v"(xi[c + 4]), "v"(xi[c + 5]), "v"(xi[c + 6]), "v"(xi[c + 7]));
+            }
+#pragma unroll
+            for (int jj = 0; jj < HB; ++jj) {
+                const int k = 64 * (h * HB + jj);
+                m0[jj] = m0p[lo + k];
+                a0[jj] = a0p[lo + k];
+                b0[jj] = b0p[lo + k];
+                m1[jj] = m1p[lo + k];
+                a1[jj] = a1p[lo + k];
+                b1[jj] = b1p[lo + k];
+                cpv[jj] = per_v[lo + k];
+                cap[jj] = apc[lo + k];
+            }
+#pragma unroll
+            for (int jj = 0; jj < HB; ++jj) {
+                const int j = h * HB + jj;
+                // linear interpolation between constant-rate rows (magphase.py:2242-2252); rt == 0 for variable-rate input
+                const float m = fmaf(m1[jj] - m0[jj], rt, m0[jj]);
+                const float a = fmaf(a1[jj] - a0[jj], rt, a0[jj]);
+                const float b = fmaf(b1[jj] - b0[jj], rt, b0[jj]);
+                const float s = a * a + b * b;
+                const float u = (s > 0.0f) ? m * cpv[jj] * pvs * __builtin_amdgcn_rsqf(s) : 0.0f;
+                const float apf = m * cap[jj] * ig;
+                float vr = fmaf(xr[j], apf, a * u), vi = fmaf(xi[j], apf, b * u);
+                if (j == 0 && lane == 0) {   // DC: X = |X| (magphase.py:958-961)
+                    vr = __builtin_sqrtf(vr * vr + vi * vi);
+                    vi = 0.0f;
+                }
+                xr[j] = vr * sgn_scale;
+                xi[j] = vi * sgn_scale;
+            }
+        }
+        if (lane == 0) {   // Nyquist bin: the noise spectrum is real there; X = |X|
+            const float m = fmaf(m1p[M] - m0p[M], rt, m0p[M]);
+            const float a = fmaf(a1p[M] - a0p[M], rt, a0p[M]);
+            const float b = fmaf(b1p[M] - b0p[M], rt, b0p[M]);
+            const float s = a * a + b * b;
+            const float u = (s > 0.0f) ? m * per_v[M] * pvs * __builtin_amdgcn_rsqf(s) : 0.0f;
+            const float apf = m * apc[M] * ig;
+            const float vr = fmaf(nM, apf, a * u), vi = b * u;
+            xm = __builtin_sqrtf(vr * vr + vi * vi) * (0.5f / (float)M);   // (-1)^M = +1
+        }
+
+        hermitian_merge<P>(xr, xi, xm, lane, ws_c, ws_s);
+        wave_fft<P, +1>(xr, xi, tw, xbuf, lane);
+
+        // ---- anti-ringing window (magphase.py:969-973, Q14): centred asymmetric Hann, zero outside
+        const int wl = tb.win_l[fi], wr = tb.win_r[fi];
+        const float inv_wl = (wl > 0) ? 1.0f / (float)wl : 1.0f;
+        const float inv_wr = (wr > 0) ? 1.0f / (float)wr : 0.0f;
+        const int kadd = (wl == 0) ? 1 : 0;
+        const int n_lo = N / 2 - wl, n_hi = N / 2 + wr;   // support [n_lo, n_hi]
+
+        // ---- ordered section: wait for this frame's ticket
+        float* strip = strips + (long long)cur.ci * strip_len;
+        const int ticket = cur.ticket_base + (fi - cur.fb);
+        const int x = tb.pm_rel[fi] - cur.x0;   // in [0, T)
+        const int target = x & ~63;
+        const int flushed = (fi == cur.fb) ? 0 : ((tb.pm_rel[fi - 1] - cur.x0) & ~63);
+        asm volatile("" ::"s"(x), "s"(flushed));
+        while (__hip_atomic_load(turn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != ticket)
+            __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");
+        if (flushed < target) flush_ring<R>(ring, strip, flushed, target, strip_len, lane);
+        wave_sync();
+        {
+            const int kap = kappa<P>(lane);
+            const int odd = x & 1;
+            float* r0p = ring + (odd ? RH : 0);
+            float* r1p = ring + (odd ? 0 : RH);
+            const int c0 = ((x >> 1) % RH) + kap;
+            const int c1 = (((x + 1) >> 1) % RH) + kap;
+            float* pA0 = r0p + c0;
+            float* pB0 = pA0 - RH;
+            float* pA1 = r1p + c1;
+            float* pB1 = pA1 - RH;
+            const int w0i = (RH - c0 + 63) >> 6;   // first q with c0 + 64 q >= RH
+            const int w1i = (RH - c1 + 63) >> 6;
+            // register rows whose samples all lie outside the window support add nothing: skipped (wave-uniform).
+            // Reads of all active rows first, then window + add + write: one LDS latency per frame.
+            float o0[P], o1[P];
+#pragma unroll
+            for (int i = 0; i < P; ++i) {
+                const int q = brev(i, LB);
+                o0[i] = o1[i] = 0.0f;
+                if (128 * q + 127 < n_lo || 128 * q > n_hi) continue;
+                o0[i] = ((q >= w0i) ? pB0 : pA0)[64 * q];
+                o1[i] = ((q >= w1i) ? pB1 : pA1)[64 * q];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < P; ++i) {
+                const int q = brev(i, LB);
+                if (128 * q + 127 < n_lo || 128 * q > n_hi) continue;
+                // samples n = 2*(kap + 64 q) + e
+                const int n0 = 2 * (kap + 64 * q);
+                const int ks0 = n0 - n_lo, ks1 = n0 + 1 - n_lo;
+                const float w0 = (ks0 >= 0 && n0 <= n_hi) ? half_window(ks0, wl, wl + wr, kadd, inv_wl, inv_wr, 0) : 0.0f;
+                const float w1 = (ks1 >= 0 && n0 + 1 <= n_hi) ? half_window(ks1, wl, wl + wr, kadd, inv_wl, inv_wr, 0) : 0.0f;
+                ((q >= w0i) ? pB0 : pA0)[64 * q] = fmaf(xr[i], w0, o0[i]);
+                ((q >= w1i) ? pB1 : pA1)[64 * q] = fmaf(xi[i], w1, o1[i]);
+            }
+        }
+        wave_sync();
+        if (fi == cur.fe - 1) {   // last frame of the chunk: stream out the rest, leave the ring cleared
+            flush_ring<R>(ring, strip, target, strip_len, strip_len, lane);
+            wave_sync();
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __hip_atomic_store(turn, ticket + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        cur = nxt;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Mel warp on the matrix cores: out[F x nout] = ln-prologue(x)[F x H] . W^T[H x nout], v_mfma_f32_16x16x4_f32.
 // One workgroup = 64 output frames x up to 64 outputs; the reduction runs over the H bins in chunks of 64.  Per chunk
 // the 256 threads stage the prologue values and the W slab into LDS as [row][k] (k contiguous, row stride 68 floats:
@@ -1000,7 +1262,11 @@ int mpx_noise_stats(void* stream, int fft_len, const void* tables, const float* 
     return MPX_OK;
 }
 
+#ifdef MPX_COMP_NO_PAIR
 int mpx_synth_comp_slots(void) { return device_cus() * kCompWaves; }
+#else
+int mpx_synth_comp_slots(void) { return device_cus() * kCompPairs; }
+#endif
 
 int mpx_synthesis_compressed_ola(void* stream, int fft_len, const void* tables, const float* mag, const float* real,
                                  const float* imag, const float* noise, const int64_t* noise_pos,
@@ -1025,6 +1291,24 @@ int mpx_synthesis_compressed_ola(void* stream, int fft_len, const void* tables, 
                      row0, row1, row_t, win_left, win_right, pm_rel};
     const dim3 grid((n_slots + kCompWaves - 1) / kCompWaves), block(kCompWaves * 64);
     hipStream_t s = (hipStream_t)stream;
+#ifndef MPX_COMP_NO_PAIR
+    {
+        const dim3 pgrid((n_slots + kCompPairs - 1) / kCompPairs), pblock(kCompPairWaves * 64);
+        if (P == 32) {
+            if (int rc = set_lds(k_synth_comp_pair<32>, lds_bytes_comp_pair<32>())) return rc;
+            hipLaunchKernelGGL(k_synth_comp_pair<32>, pgrid, pblock, lds_bytes_comp_pair<32>(), s, mag, real, imag, noise,
+                               tb, per_v, ap_v, ap_u, (const ChunkDesc*)chunks, slot_off, slot_chunks, (int)n_slots,
+                               (int)territory, (const float2*)tables, strips, (long long)ld);
+        } else {
+            if (int rc = set_lds(k_synth_comp_pair<16>, lds_bytes_comp_pair<16>())) return rc;
+            hipLaunchKernelGGL(k_synth_comp_pair<16>, pgrid, pblock, lds_bytes_comp_pair<16>(), s, mag, real, imag, noise,
+                               tb, per_v, ap_v, ap_u, (const ChunkDesc*)chunks, slot_off, slot_chunks, (int)n_slots,
+                               (int)territory, (const float2*)tables, strips, (long long)ld);
+        }
+        MPX_HIP_CHECK(hipGetLastError());
+        return MPX_OK;
+    }
+#endif
     if (P == 32) {
         if (int rc = set_lds(k_synth_comp_ola<32>, lds_bytes_comp<32>())) return rc;
         hipLaunchKernelGGL(k_synth_comp_ola<32>, grid, block, lds_bytes_comp<32>(), s, mag, real, imag, noise, tb,
