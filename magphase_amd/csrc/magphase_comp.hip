@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void k_mel_warp(WarpJobs jobs, long long F, in
 // Windowed noise frame (magphase.py:886-897: windowing() with per-frame window list, epoch moved to index 0 by
 // frm_list_to_matrix + fftshift) -> N-point real FFT -> Ns[k] for the bins kappa(lane) + 64 j, j = 0..P-1
 // (natural j), plus the Nyquist bin (real) on the lane with kappa == 0.  Synchronous staging (no prefetch).
-template <int P>
+template <int P, bool PRESTAGED = false>   // PRESTAGED: the caller already copied tile 0 into xbuf and waited for it
 __device__ __forceinline__ void noise_spectrum(const FrameGeom& g, int wtype, const float2* tw, float* xbuf,
                                                unsigned xbuf_byte, int lane, float wl_c, float wl_s,
                                                float (&nr)[P], float (&ni)[P], float& nM) {
@@ -181,8 +181,10 @@ __device__ __forceinline__ void noise_spectrum(const FrameGeom& g, int wtype, co
     const int ntiles = (g.len + kTile - 1) / kTile;
     for (int t = 0; t < ntiles; ++t) {
         const int tile0 = t * kTile;
-        stage_samples_async(g, tile0, kTile, xbuf_byte, lane);
-        staged_wait<0>();
+        if (!PRESTAGED || t > 0) {
+            stage_samples_async(g, tile0, kTile, xbuf_byte, lane);
+            staged_wait<0>();
+        }
         const int hi = min(g.len, tile0 + kTile);
         for (int k = tile0 + lane; k < hi; k += 64)
             xbuf[k - tile0] *= half_window(k, g.L, g.LR, g.kadd, g.invL, g.invR, wtype);
@@ -209,20 +211,29 @@ __device__ __forceinline__ void noise_spectrum(const FrameGeom& g, int wtype, co
     const int kap = kappa<P>(lane);
     const int src_lane = kappa<P>((64 - kap) & 63);
     const bool lane0 = (kap == 0);
+    // partner fetches in batches of 8 bins: 16 lane exchanges in flight per LDS latency instead of one
 #pragma unroll
-    for (int i = 0; i < P; ++i) {
-        const int q = brev(i, LB);
-        const int i0 = brev((P - q) % P, LB);
-        float pr = __shfl(re[P - 1 - i], src_lane);
-        float pi = __shfl(im[P - 1 - i], src_lane);
-        pr = lane0 ? re[i0] : pr;
-        pi = lane0 ? im[i0] : pi;
-        const float er = 0.5f * (re[i] + pr), ei = 0.5f * (im[i] - pi);
-        const float orr = 0.5f * (im[i] + pi), oi = -0.5f * (re[i] - pr);
-        const float cq = cos2p<P>(q), sq = -sin2p<P>(q);
-        const float wr = wl_c * cq - wl_s * sq, wi = wl_c * sq + wl_s * cq;
-        nr[q] = er + (wr * orr - wi * oi);
-        ni[q] = ei + (wr * oi + wi * orr);
+    for (int ib = 0; ib < P; ib += 8) {
+        float prb[8], pib[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            prb[u] = __shfl(re[P - 1 - (ib + u)], src_lane);
+            pib[u] = __shfl(im[P - 1 - (ib + u)], src_lane);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = ib + u;
+            const int q = brev(i, LB);
+            const int i0 = brev((P - q) % P, LB);
+            const float pr = lane0 ? re[i0] : prb[u];
+            const float pi = lane0 ? im[i0] : pib[u];
+            const float er = 0.5f * (re[i] + pr), ei = 0.5f * (im[i] - pi);
+            const float orr = 0.5f * (im[i] + pi), oi = -0.5f * (re[i] - pr);
+            const float cq = cos2p<P>(q), sq = -sin2p<P>(q);
+            const float wr = wl_c * cq - wl_s * sq, wi = wl_c * sq + wl_s * cq;
+            nr[q] = er + (wr * orr - wi * oi);
+            ni[q] = ei + (wr * oi + wi * orr);
+        }
     }
     nM = re[0] - im[0];   // Nyquist bin X[M] = Re Z[0] - Im Z[0] (meaningful on the kappa == 0 lane)
 }
@@ -806,6 +817,13 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_synth_comp_pair(const f
     cur.wi = slot_off[slot];
     cur.ticket_base = 0;
     settle(cur);
+    if (!cur.valid) return;
+
+    // the noise samples of a frame are copied HBM -> LDS (into the transpose buffer) while the previous frame's
+    // inverse FFT finishes and its overlap-add runs (same scheme as k_analysis)
+    constexpr int kTile = 64 * P;
+    FrameGeom g = frame_geom(noise, tb.npos[cur.fi], tb.nleft[cur.fi], tb.nright[cur.fi], N);
+    stage_samples_async(g, 0, kTile, xbuf_byte, lane_id);
 
     while (cur.valid) {
         int lane = lane_id;
@@ -818,8 +836,8 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_synth_comp_pair(const f
         // ---- aperiodic source: spectrum of this frame's windowed noise, bins k = lane + 64 j
         float xr[P], xi[P], nM;
         {
-            const FrameGeom g = frame_geom(noise, tb.npos[fi], tb.nleft[fi], tb.nright[fi], N);
-            noise_spectrum<P>(g, tb.wtype[fi], tw, xbuf, xbuf_byte, lane, wa_c, wa_s, xr, xi, nM);
+            staged_wait<0>();
+            noise_spectrum<P, true>(g, tb.wtype[fi], tw, xbuf, xbuf_byte, lane, wa_c, wa_s, xr, xi, nM);
             if (P == 16) {   // FFT output lanes hold bins kappa(lane)+64j; everything below wants bins lane+64j
                 const int src = kappa<P>(lane);
 #pragma unroll
@@ -911,7 +929,13 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_synth_comp_pair(const f
         }
 
         hermitian_merge<P>(xr, xi, xm, lane, ws_c, ws_s);
-        wave_fft<P, +1>(xr, xi, tw, xbuf, lane);
+        wave_fft_front<P, +1>(xr, xi, tw, xbuf, lane);
+        if (nxt.valid) {   // the exchange buffer is idle from here on: start the copy of the next frame's noise
+            g = frame_geom(noise, tb.npos[nxt.fi], tb.nleft[nxt.fi], tb.nright[nxt.fi], N);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            stage_samples_async(g, 0, kTile, xbuf_byte, lane);
+        }
+        fft_inreg<P, +1>(xr, xi);
 
         // ---- anti-ringing window (magphase.py:969-973, Q14): centred asymmetric Hann, zero outside
         const int wl = tb.win_l[fi], wr = tb.win_r[fi];
