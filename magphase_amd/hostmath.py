@@ -369,3 +369,67 @@ def hpf_tables(fs, block):
             row = row @ amat
         pm[sec] = np.linalg.matrix_power(amat, block).reshape(-1)
     return sos, pm, g
+
+
+# ======================================================================================================
+# Merlin-style mel-cepstral post-filter (magphase.py:3375-3465)
+# ======================================================================================================
+def _f32(x):
+    """One SPTK pipe boundary: every tool reads and writes float32, computes in double."""
+    return np.asarray(x, dtype=np.float32).astype(np.float64)
+
+
+def rceps_compact(m_log):
+    """
+    la.rceps(in_type='log', out_type='compact') (libaudio.py:252-270): real cepstrum of the even extension of
+    [F x n] log spectra (length 2(n-1)), first n coefficients, coefficients 1..n-3 doubled (the reference's slice
+    1:(ncoeffs-2) leaves n-2 undoubled, Q6).
+    """
+    m_log = np.asarray(m_log, dtype=np.float64)
+    n = m_log.shape[1]
+    m_ext = np.hstack((m_log, m_log[:, -2:0:-1]))
+    m_c = np.fft.ifft(m_ext).real
+    m_c[:, 1:(n - 2)] *= 2
+    return m_c[:, :n]
+
+
+def sptk_mc2b(m_mc, alpha):
+    """SPTK ``mc2b``: MLSA filter coefficients b[m] = mc[m] - alpha b[m+1], from the top coefficient down."""
+    m_b = np.array(m_mc, dtype=np.float64)
+    for m in range(m_b.shape[1] - 2, -1, -1):
+        m_b[:, m] -= alpha * m_b[:, m + 1]
+    return m_b
+
+
+def sptk_b2mc(m_b, alpha):
+    """SPTK ``b2mc`` (inverse of mc2b): mc[m] = b[m] + alpha b[m+1]."""
+    m_mc = np.array(m_b, dtype=np.float64)
+    m_mc[:, :-1] += alpha * np.asarray(m_b, dtype=np.float64)[:, 1:]
+    return m_mc
+
+
+_FREQT_CACHE = {}
+
+
+def sptk_freqt(m_c, order_out, alpha_in, alpha_out=0.0):
+    """SPTK ``freqt -m m1 -a alpha_in -M order_out -A alpha_out`` on [F x (m1+1)] cepstra, as one matrix product."""
+    a = (alpha_out - alpha_in) / (1.0 - alpha_in * alpha_out)
+    key = (m_c.shape[1], int(order_out), float(a))
+    if key not in _FREQT_CACHE:
+        _FREQT_CACHE[key] = freqt_matrix(m_c.shape[1], order_out, a).T.copy()   # [n_in x (order_out+1)]
+    return np.asarray(m_c, dtype=np.float64) @ _FREQT_CACHE[key]
+
+
+def sptk_c2acr_r0(m_c, fft_len):
+    """SPTK ``c2acr -M 0 -l fft_len``: r[0] = mean over the fft_len bins of exp(2 Re FFT(c)) -- the frame energy."""
+    m_x = np.zeros((m_c.shape[0], fft_len))
+    m_x[:, :m_c.shape[1]] = m_c
+    m_re = np.fft.fft(m_x, axis=1).real
+    return np.exp(2.0 * m_re).sum(axis=1) / fft_len
+
+
+def cos_matrix_log_spectrum(m_mcep, n_spbins):
+    """la.mcep_to_sp_cosmat(alpha=0.0, out_type='log') (libaudio.py:605-631): out[k] = sum_n mc[n] cos(n pi k/(n_spbins-1))."""
+    v_w = np.linspace(0, np.pi, num=n_spbins)
+    m_trans = np.cos(np.outer(np.arange(m_mcep.shape[1]), v_w))
+    return np.asarray(m_mcep, dtype=np.float64) @ m_trans

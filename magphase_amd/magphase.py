@@ -187,6 +187,38 @@ def post_filter(m_mag_mel_log, fs, av_len_at_zero=None, av_len_at_nyq=None, boos
     return m_enh
 
 
+def post_filter_merlin(m_mag_mel_log, fs, pf_coef=1.4):
+    """
+    magphase.py:3375-3465: Merlin / HTS style formant enhancement of the log mel magnitudes.  The reference pipes the
+    frames through nine SPTK-3.9 binaries; the same arithmetic is restated here on the host in float64 with a float32
+    rounding at every pipe boundary (SPTK's stream format) -- **parity unpinned**: neither SPTK nor any reference
+    output of this branch exists in the build container, the checks in tests/test_post_filter_merlin.py are
+    known-answer properties (pf_coef = 1 is the identity of the cepstral round trip; the frame energy r0 is kept).
+      mcep   = rceps(mag, 'log', 'compact')                           -> temp.mcep (float32)
+      r0     = c2acr_0(freqt_{alpha->0, 2047}(mcep)),  p_r0 = the same of mcep * lifter, lifter = (1, 1, pf, pf, ...)
+      b      = mc2b(mcep * lifter, alpha);  b0 += ln(r0 / p_r0) / 2;  mcep_pf = b2mc(b, alpha)
+      out    = cosine-matrix log spectrum of mcep_pf on mag_dim points (alpha = 0), NaN -> la.MAGIC
+    Host-side on purpose: [F x 60] per utterance, a few matrix products.
+    """
+    fft_len = 4096
+    minph_ord = fft_len // 2 - 1
+    alpha = define_alpha(fs)
+    ncoeffs = np.shape(m_mag_mel_log)[1]
+    m_mcep = hm._f32(hm.rceps_compact(m_mag_mel_log))
+    v_lifter = hm._f32(np.concatenate(([1.0, 1.0], np.full(ncoeffs - 2, float("%1.2f" % pf_coef)))))
+    m_mcep_w = hm._f32(m_mcep * v_lifter)                                    # vopr -m
+    v_r0 = hm._f32(hm.sptk_c2acr_r0(hm._f32(hm.sptk_freqt(m_mcep, minph_ord, alpha)), fft_len))
+    v_p_r0 = hm._f32(hm.sptk_c2acr_r0(hm._f32(hm.sptk_freqt(m_mcep_w, minph_ord, alpha)), fft_len))
+    m_b = hm._f32(hm.sptk_mc2b(m_mcep_w, alpha))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        v_p_b0 = hm._f32(hm._f32(np.log(hm._f32(v_r0 / v_p_r0)) / 2.0) + m_b[:, 0])   # vopr -d | sopr -LN -d 2 | vopr -a
+    m_b[:, 0] = v_p_b0                                                       # bcp 1..order | merge
+    m_mcep_pf = hm._f32(hm.sptk_b2mc(m_b, alpha))
+    m_out = hm.cos_matrix_log_spectrum(m_mcep_pf, ncoeffs)
+    m_out[np.isnan(m_out)] = la.MAGIC
+    return m_out
+
+
 def _output_hpf(v_syn_sig, fs):
     """magphase.py:981-995: 4th-order Butterworth high-pass at 40 Hz, float64 on the host (poles at |z|~0.997)."""
     from scipy import signal
@@ -237,7 +269,8 @@ def synthesis_from_acoustic_modelling(in_feats_dir, filename_token, out_syn_dir,
         print('Using MagPhase postfilter...')
         m_mag_mel_log = post_filter(m_mag_mel_log, fs)
     elif pf_type == 'merlin':
-        raise NotImplementedError("pf_type='merlin' shells out to nine SPTK binaries (magphase.py:3375-3465): out of scope")
+        print('Using Merlin postfilter...')
+        m_mag_mel_log = post_filter_merlin(m_mag_mel_log, fs)
     elif pf_type == 'no':
         print('No postfilter...')
     v_syn_sig = synthesis_from_compressed(m_mag_mel_log, m_real_mel, m_imag_mel, v_lf0, fs, fft_len=fft_len,
