@@ -59,6 +59,57 @@ class Engine:
         out.copy_(torch.from_numpy(arr))
         return out
 
+    # ------------------------------------------------------------------ pinned staging
+    def _pinned_pair(self, n_floats):
+        """Two page-locked float32 staging buffers of at least n_floats elements (grown on demand, kept)."""
+        torch = _torch()
+        cur = getattr(self, "_pinned", None)
+        if cur is None or cur[0].numel() < n_floats:
+            self._pinned = tuple(torch.empty(int(n_floats), dtype=torch.float32).pin_memory() for _ in range(2))
+        return self._pinned
+
+    def to_host_f64(self, t, chunk_bytes=64 << 20):
+        """
+        Device float32 tensor (1-D or 2-D, rows may be pitched) -> fresh float64 numpy array, through two pinned
+        staging buffers: chunk i+1 crosses PCIe (async copy on the current stream) while the host widens chunk i to
+        float64.  Bounded pinned memory (2 x chunk_bytes) whatever the matrix size; the pageable `.cpu()` path is
+        ~3x slower for the 1.4 GB of lossless features of a 64-utterance batch.
+        """
+        torch = _torch()
+        if t.dim() == 1:
+            return self.to_host_f64(t.view(1, -1), chunk_bytes).reshape(-1)
+        rows, cols = int(t.shape[0]), int(t.shape[1])
+        out = np.empty((rows, cols), dtype=np.float64)
+        if rows == 0 or cols == 0:
+            return out
+        rows_per = max(1, int(chunk_bytes) // (4 * cols))
+        bufs = self._pinned_pair(rows_per * cols)
+        events = [torch.cuda.Event(), torch.cuda.Event()]
+        starts = list(range(0, rows, rows_per))
+
+        def drain(i):
+            r0 = starts[i]
+            r1 = min(rows, r0 + rows_per)
+            events[i % 2].synchronize()
+            out[r0:r1] = bufs[i % 2][:(r1 - r0) * cols].view(r1 - r0, cols).numpy()
+
+        with torch.cuda.device(self.device):
+            for i, r0 in enumerate(starts):
+                r1 = min(rows, r0 + rows_per)
+                if i >= 2:
+                    drain(i - 2)                      # the buffer about to be overwritten
+                bufs[i % 2][:(r1 - r0) * cols].view(r1 - r0, cols).copy_(t[r0:r1], non_blocking=True)
+                events[i % 2].record()
+            for i in range(max(0, len(starts) - 2), len(starts)):
+                drain(i)
+        return out
+
+    def to_device_pinned(self, arr, dtype):
+        """Host array -> device tensor through a page-locked copy (async H2D on the current stream)."""
+        torch = _torch()
+        h = torch.from_numpy(np.ascontiguousarray(arr, dtype=dtype)).pin_memory()
+        return h.to(self.device, non_blocking=True)
+
     @staticmethod
     def feat_ld(mag, real, imag):
         """Common row pitch of three feature views (unit column stride, equal row stride) for the C ABI."""

@@ -81,13 +81,15 @@ def analysis_lossless_batch(utts, fft_len=None, engine=None, return_device=False
         for n in lens:  # Q19: truncation warns, it does not raise (magphase.py:311-315)
             warnings.warn(_WARN_LONG % (plan.fft_len, n))
     mag, real, imag = plan.run()
+    if not return_device:   # one pinned, chunked D2H per stream for the whole batch (engine.to_host_f64)
+        h_feats = tuple(engine.to_host_f64(t) for t in (mag, real, imag))
     out = []
     for u in range(len(utts)):
         a, b = int(plan.frame_off[u]), int(plan.frame_off[u + 1])
         if return_device:
             feats = (mag[a:b], real[a:b], imag[a:b])
         else:
-            feats = tuple(t[a:b].cpu().numpy().astype(np.float64) for t in (mag, real, imag))
+            feats = tuple(h[a:b].copy() for h in h_feats)   # fresh arrays owned by the caller, like the reference's
         out.append(feats + (plan.v_f0[u], plan.fs[u], plan.v_shift[u].astype(int)))
     return out
 
@@ -137,7 +139,7 @@ def synthesis_from_lossless_batch(feats, engine=None):
             part = f[k] if torch.is_tensor(f[k]) else torch.from_numpy(np.ascontiguousarray(f[k], dtype=np.float32))
             buf[int(rows[u]):int(rows[u + 1])].copy_(part)
         cat.append(buf)
-    pcm = plan.run(cat[0], cat[1], cat[2]).cpu().numpy().astype(np.float64)
+    pcm = engine.to_host_f64(plan.run(cat[0], cat[1], cat[2]))
     return [pcm[plan.out_off_host[u]:plan.out_off_host[u + 1]] for u in range(len(feats))]
 
 
@@ -240,7 +242,7 @@ def synthesis_from_compressed_batch(utts, fs, fft_len=None, b_voi_ap_win=True, b
     if b_out_hpf:   # magphase.py:981-995, float64 on the device (engine.output_hpf); _output_hpf is the host form
         pcm = engine.output_hpf(pcm_dev, plan.out_off_host, fs).cpu().numpy()
     else:
-        pcm = pcm_dev.cpu().numpy().astype(np.float64)
+        pcm = engine.to_host_f64(pcm_dev)
     return [pcm[plan.out_off_host[u]:plan.out_off_host[u + 1]] for u in range(len(utts))]
 
 
@@ -297,7 +299,7 @@ def analysis_compressed_batch(utts, fft_len=None, mag_dim=60, phase_dim=10, b_co
     for lens in plan.lossless.long_frame_lens:
         for n in lens:
             warnings.warn(_WARN_LONG % (plan.fft_len, n))
-    h_mag, h_real, h_imag = (t_.cpu().numpy().astype(np.float64) for t_ in plan.run())
+    h_mag, h_real, h_imag = (engine.to_host_f64(t_) for t_ in plan.run())
     res = []
     for u in range(len(utts)):
         a, b = int(plan.out_off[u]), int(plan.out_off[u + 1])

@@ -19,7 +19,7 @@ sys.path.append(os.path.realpath(os.path.join(HERE, "..", "src")))
 
 import libutils as lu  # noqa: E402
 import magphase as mp  # noqa: E402
-from magphase_amd import sharding  # noqa: E402
+from magphase_amd import iobatch, sharding  # noqa: E402
 
 
 def main():
@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--scp", default=os.path.join(demo, "file_id.scp"))
     ap.add_argument("--wav-dir", default=os.path.join(demo, "wavs_nat"))
     ap.add_argument("--out-dir", default=os.path.join(demo, "params_nat"))
+    ap.add_argument("--batch", type=int, default=16, help="utterances per kernel launch (0: one call per file, like the reference)")
     args = ap.parse_args()
     lu.mkdir(args.out_dir)
     tokens = [str(t) for t in lu.read_text_file2(args.scp, dtype="string", comments="#").tolist()]
@@ -36,9 +37,15 @@ def main():
         import torch
         torch.cuda.set_device(local_rank)
     sizes = [os.path.getsize(os.path.join(args.wav_dir, t + ".wav")) for t in tokens]
-    for i in sharding.shard_by_cost(sizes, world)[rank]:
-        print("[rank %d] analysing %s.wav" % (rank, tokens[i]))
-        mp.analysis_for_acoustic_modelling(os.path.join(args.wav_dir, tokens[i] + ".wav"), args.out_dir)
+    mine = sharding.shard_by_cost(sizes, world)[rank]
+    if args.batch > 0:   # reader thread / kernels / writer thread overlapped, args.batch utterances per launch
+        n = iobatch.extract_features_corpus([os.path.join(args.wav_dir, tokens[i] + ".wav") for i in mine], args.out_dir,
+                                            batch_utts=args.batch)
+        print("[rank %d] %d files analysed in %d batches" % (rank, len(mine), n))
+    else:
+        for i in mine:
+            print("[rank %d] analysing %s.wav" % (rank, tokens[i]))
+            mp.analysis_for_acoustic_modelling(os.path.join(args.wav_dir, tokens[i] + ".wav"), args.out_dir)
     print("rank %d done" % rank)
 
 

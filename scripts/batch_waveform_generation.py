@@ -19,7 +19,7 @@ sys.path.append(os.path.realpath(os.path.join(HERE, "..", "src")))
 
 import libutils as lu  # noqa: E402
 import magphase as mp  # noqa: E402
-from magphase_amd import sharding  # noqa: E402
+from magphase_amd import iobatch, sharding  # noqa: E402
 
 
 def main():
@@ -31,7 +31,8 @@ def main():
     ap.add_argument("--fs", type=int, default=48000)
     ap.add_argument("--mag-dim", type=int, default=60)
     ap.add_argument("--phase-dim", type=int, default=45)
-    ap.add_argument("--pf-type", default="magphase", choices=["magphase", "no"])
+    ap.add_argument("--pf-type", default="magphase", choices=["magphase", "merlin", "no"])
+    ap.add_argument("--batch", type=int, default=16, help="utterances per kernel launch (0: one call per file, like the reference)")
     args = ap.parse_args()
     lu.mkdir(args.out_dir)
     tokens = [str(t) for t in lu.read_text_file2(args.scp, dtype="string", comments="#").tolist()]
@@ -40,9 +41,15 @@ def main():
         import torch
         torch.cuda.set_device(local_rank)
     sizes = [os.path.getsize(os.path.join(args.feats_dir, t + ".mag")) for t in tokens]
-    for i in sharding.shard_by_cost(sizes, world)[rank]:
-        mp.synthesis_from_acoustic_modelling(args.feats_dir, tokens[i], args.out_dir, args.mag_dim, args.phase_dim,
-                                             args.fs, pf_type=args.pf_type, b_const_rate=False)
+    mine = sharding.shard_by_cost(sizes, world)[rank]
+    if args.batch > 0:   # reader thread / kernels / writer thread overlapped, args.batch utterances per launch
+        iobatch.generate_waveforms_corpus(args.feats_dir, [tokens[i] for i in mine], args.out_dir, args.mag_dim,
+                                          args.phase_dim, args.fs, pf_type=args.pf_type, b_const_rate=False,
+                                          batch_utts=args.batch)
+    else:
+        for i in mine:
+            mp.synthesis_from_acoustic_modelling(args.feats_dir, tokens[i], args.out_dir, args.mag_dim, args.phase_dim,
+                                                 args.fs, pf_type=args.pf_type, b_const_rate=False)
     print("rank %d done" % rank)
 
 

@@ -56,3 +56,56 @@ def test_demos_and_batch_scripts(tmp_path):
     for tok in ("hvd_704", "hvd_705", "hvd_706", "hvd_708"):
         n, fsw = _wav_len(str(gen / (tok + ".wav")))
         assert fsw == 48000 and n > 40000
+
+
+def test_corpus_batching_equals_the_per_file_calls(tmp_path):
+    """iobatch (reader thread / batched kernels / writer thread) writes the same files as one call per utterance."""
+    sys.path.insert(0, os.path.join(ROOT, "demos"))
+    import make_demo_data
+    from magphase_amd import iobatch, magphase as mp
+    wav_dir = tmp_path / "wavs"
+    toks = make_demo_data.main(n=3, out_dir=str(wav_dir))
+    wavs = [str(wav_dir / (t + ".wav")) for t in toks]
+    one, many = tmp_path / "one", tmp_path / "many"
+    os.makedirs(str(one))
+    for w in wavs:
+        mp.analysis_for_acoustic_modelling(w, str(one))
+    assert iobatch.extract_features_corpus(wavs, str(many), batch_utts=2, verbose=False) == 2
+    for t in toks:
+        for ext in (".mag", ".real", ".imag", ".lf0", ".shift"):
+            a = np.fromfile(str(one / (t + ext)), dtype=np.float32)
+            b = np.fromfile(str(many / (t + ext)), dtype=np.float32)
+            assert a.size == b.size and np.array_equal(a, b), (t, ext)
+    # generation: per-file (seeded) vs batched (same seed: the noise of the utterances is drawn in the same order)
+    gen1, gen2 = tmp_path / "gen1", tmp_path / "gen2"
+    os.makedirs(str(gen1))
+    feats = os.path.join(ROOT, "demos", "data_48k", "params_predicted")
+    gtoks = ["hvd_704", "hvd_705", "hvd_706"]
+    np.random.seed(11)
+    for t in gtoks:
+        mp.synthesis_from_acoustic_modelling(feats, t, str(gen1), 60, 45, 48000, pf_type="magphase")
+    np.random.seed(11)
+    iobatch.generate_waveforms_corpus(feats, gtoks, str(gen2), 60, 45, 48000, pf_type="magphase", batch_utts=3,
+                                      verbose=False)
+    for t in gtoks:
+        with wave.open(str(gen1 / (t + ".wav")), "rb") as w1, wave.open(str(gen2 / (t + ".wav")), "rb") as w2:
+            a = np.frombuffer(w1.readframes(w1.getnframes()), dtype=np.int16).astype(np.int32)
+            b = np.frombuffer(w2.readframes(w2.getnframes()), dtype=np.int16).astype(np.int32)
+        assert a.size == b.size and np.max(np.abs(a - b)) <= 2, t   # 16-bit PCM at 0.98 peak: +-1 LSB of fp32 re-association
+    # Merlin post-filter branch runs end to end
+    iobatch.generate_waveforms_corpus(feats, gtoks[:1], str(tmp_path / "gen3"), 60, 45, 48000, pf_type="merlin",
+                                      verbose=False)
+    assert _wav_len(str(tmp_path / "gen3" / "hvd_704.wav"))[0] > 40000
+
+
+def test_pinned_d2h_matches_plain_copy():
+    import torch
+    from magphase_amd.engine import get_engine
+    eng = get_engine()
+    t = torch.randn(1000, 2049, device=eng.device)
+    got = eng.to_host_f64(t, chunk_bytes=1 << 20)       # 8 chunks
+    assert got.dtype == np.float64 and np.array_equal(got, t.cpu().numpy().astype(np.float64))
+    v = eng.empty_feats(37, 2049, ld=2112)
+    v.copy_(torch.randn(37, 2049, device=eng.device))
+    assert np.array_equal(eng.to_host_f64(v), v.cpu().numpy().astype(np.float64))
+    assert np.array_equal(eng.to_host_f64(t[:, 0].contiguous()), t[:, 0].cpu().numpy().astype(np.float64))
