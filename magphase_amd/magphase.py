@@ -34,6 +34,17 @@ def set_epoch_provider(fn):
     _epoch_provider = fn
 
 
+def use_builtin_epoch_tracker(device=None):
+    """Installs magphase_amd.epochs.track_epochs as the epoch provider (instead of <wav>.est files / REAPER)."""
+    from . import epochs
+
+    def provider(wav_file):
+        v_sig, fs = la.read_audio_file(wav_file)
+        return epochs.track_epochs(v_sig, fs, device=device)
+
+    set_epoch_provider(provider)
+
+
 def _epochs_for(wav_file):
     if _epoch_provider is not None:
         r = _epoch_provider(wav_file)
@@ -43,6 +54,14 @@ def _epochs_for(wav_file):
     if os.path.isfile(est):
         m = np.atleast_2d(np.loadtxt(est, skiprows=7, usecols=[0, 1]))
         return m[:, 0], m[:, 1]
+    if la.find_reaper() is None and os.environ.get("MAGPHASE_EPOCHS", "builtin") == "builtin":
+        # no REAPER binary: the built-in zero-frequency-filtering tracker (magphase_amd/epochs.py).  Not REAPER: the
+        # epochs differ, hence so do the (pitch-synchronous) features -- parity unpinned for this front end.
+        warnings.warn("REAPER not found: epochs of %s from the built-in ZFF tracker (set MAGPHASE_EPOCHS=reaper to "
+                      "make this an error)" % wav_file)
+        from . import epochs
+        v_sig, fs = la.read_audio_file(wav_file)
+        return epochs.track_epochs(v_sig, fs)
     est_tmp = lu.ins_pid("temp.est")
     la.reaper(wav_file, est_tmp)
     try:

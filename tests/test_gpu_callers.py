@@ -109,3 +109,27 @@ def test_pinned_d2h_matches_plain_copy():
     v.copy_(torch.randn(37, 2049, device=eng.device))
     assert np.array_equal(eng.to_host_f64(v), v.cpu().numpy().astype(np.float64))
     assert np.array_equal(eng.to_host_f64(t[:, 0].contiguous()), t[:, 0].cpu().numpy().astype(np.float64))
+
+
+def test_builtin_epoch_tracker_end_to_end(tmp_path):
+    """wav without epochs -> built-in ZFF tracker on the device -> lossless analysis -> synthesis reproduces the signal
+    (the half-window pairs of consecutive frames sum to one whatever the epochs are)."""
+    import torch
+    from magphase_amd import epochs, libaudio as la, magphase as mp, synthetic as syn
+    pcm, pm, voi = syn.make_utterance(7, dur_s=1.5)
+    e_dev = epochs.track_epochs(pcm, 48000)                          # current ROCm device
+    e_cpu = epochs.track_epochs(pcm, 48000, device=torch.device("cpu"))
+    assert abs(e_dev[0].size - e_cpu[0].size) <= 2                   # same algorithm, float64 on both
+    wav = str(tmp_path / "x.wav")
+    la.write_audio_file(wav, pcm / 32768.0, 48000, norm=None)
+    mp.use_builtin_epoch_tracker()
+    try:
+        m_mag, m_real, m_imag, v_f0, fs, v_shift = mp.analysis_lossless(wav)
+        v_syn = mp.synthesis_from_lossless(m_mag, m_real, m_imag, v_f0, fs)
+    finally:
+        mp.set_epoch_provider(None)
+    x = pcm[:v_syn.size] / 32768.0
+    n0, n1 = int(0.05 * fs), min(x.size, v_syn.size) - int(0.05 * fs)
+    err = v_syn[n0:n1] - x[n0:n1]
+    snr = 10 * np.log10(np.sum(x[n0:n1] ** 2) / np.sum(err ** 2))
+    assert snr > 80.0, snr
