@@ -280,120 +280,15 @@ __global__ __launch_bounds__(kThreads) void k_synth_lossless(const float* __rest
 
 // ---------------------------------------------------------------------------------------------
 // fused lossless synthesis + PSOLA.  One wavefront owns one CHUNK = the consecutive frames of one
-// utterance whose centres fall in a territory of T samples of the reference's OLA buffer; it rebuilds
+// utterance whose centres fall in a territory of T samples of the reference's OLA buffer; a PAIR of wavefronts owns a
+// work list of chunks and alternates over their frames (k_synth_ola_pair below; the single-wave form it replaced is
+// in the history: 5 waves per CU, 0.53 ms); each frame is rebuilt
 // each frame (as k_synth_lossless) and overlap-adds it, in ascending frame order, into a ring buffer in
 // LDS, streaming the finished part out to the chunk's private strip (T + N floats: the territory plus
 // N/2 of halo on each side).  k_ola_fixup then sums the <= 3 strips covering each output sample.
 // HBM traffic: features read once, (T+N)/T * 4 B per output sample written -- the [F x N] frame
 // scratch of the two-kernel path (16 KB per frame written + read) is gone.
 // ---------------------------------------------------------------------------------------------
-template <int P>
-__global__ __launch_bounds__(kSynWaves * 64) void k_synth_ola(const float* __restrict__ mag,
-                                                              const float* __restrict__ real,
-                                                              const float* __restrict__ imag,
-                                                              const ChunkDesc* __restrict__ chunks,
-                                                              const int* __restrict__ slot_off,
-                                                              const int* __restrict__ slot_chunks, int nslots,
-                                                              const int* __restrict__ pm_rel, int T,
-                                                              const float2* __restrict__ tw_g,
-                                                              float* __restrict__ strips, long long ld) {
-    constexpr int M = 64 * P, N = 2 * M, H = M + 1, LB = ilog2(P), R = ring_len<P>();
-    extern __shared__ float smem[];
-    float2* tw = reinterpret_cast<float2*>(smem);
-    const int lane_id = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    float* xbuf = smem + P * 64 * 2 + wave * (P * kXStride + R);
-    float* ring = xbuf + P * kXStride;
-    for (int i = threadIdx.x; i < P * 64; i += kSynWaves * 64) tw[i] = tw_g[i];
-    __syncthreads();
-
-    float wl_s0, wl_c0;
-    sincospif(2.0f * (float)lane_id / (float)N, &wl_s0, &wl_c0);
-    const int wave_u = rfl(wave);
-    const int strip_len = T + N;
-    for (int i = lane_id; i < R; i += 64) ring[i] = 0.0f;  // every chunk's tail flush leaves the ring cleared
-    wave_sync();
-
-    // work list of this wave slot (host-side LPT balancing: hostmath.balance_chunks)
-    const int slot = blockIdx.x * kSynWaves + wave_u;
-    if (slot >= nslots) return;
-    for (int wi = slot_off[slot]; wi < slot_off[slot + 1]; ++wi) {
-        const int ci = slot_chunks[wi];
-        const ChunkDesc cd = chunks[ci];
-        float* strip = strips + (long long)ci * strip_len;
-        int flushed = 0;  // strip elements [0, flushed) are final and written
-
-        FrameFeat<P> ff;
-        {
-            const long long f = cd.frame_begin;
-            feat_load<P>(ff, mag + f * ld, real + f * ld, imag + f * ld, lane_id);
-        }
-        for (int fi = cd.frame_begin; fi < cd.frame_end; ++fi) {
-            int lane = lane_id;  // laundered per frame (see k_analysis)
-            float wl_s = wl_s0, wl_c = wl_c0;
-            asm volatile("" : "+v"(lane), "+v"(wl_s), "+v"(wl_c));
-            float xr[P], xi[P], xm;
-            feat_convert<P>(ff, xr, xi, xm, lane);
-#ifdef MPX_SYN_EARLY_PREFETCH
-            // one wave per SIMD (512 VGPRs): the next frame's features can be requested a whole frame ahead
-            __builtin_amdgcn_sched_barrier(0);
-            if (fi + 1 < cd.frame_end) {
-                const long long f = fi + 1;
-                feat_load<P>(ff, mag + f * ld, real + f * ld, imag + f * ld, lane);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#endif
-            hermitian_merge<P>(xr, xi, xm, lane, wl_c, wl_s);
-            wave_fft_front<P, +1>(xr, xi, tw, xbuf, lane);
-            // Prefetch the next frame's features behind the second FFT pass + overlap-add.  Placed HERE (not
-            // right after the conversion): earlier, 99 old + 99 new feature registers + the 64 spectrum
-            // registers exceed 256 VGPRs and the compiler spills freshly loaded values with a vmcnt(0) each.
-#ifndef MPX_SYN_EARLY_PREFETCH
-            __builtin_amdgcn_sched_barrier(0);
-            if (fi + 1 < cd.frame_end) {
-                const long long f = fi + 1;
-                feat_load<P>(ff, mag + f * ld, real + f * ld, imag + f * ld, lane);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#endif
-            fft_inreg<P, +1>(xr, xi);
-
-            // strip coordinate of this frame's first sample; the ring holds strip elements [flushed, flushed + R)
-            const int x = pm_rel[fi] - cd.x0;   // in [0, T)
-            const int target = x & ~63;
-            if (flushed < target) {              // everything below x is final: stream it out, clear the slots
-                flush_ring<R>(ring, strip, flushed, target, strip_len, lane);
-                flushed = target;
-            }
-            wave_sync();
-            {
-                constexpr int RH = R / 2;
-                const int kap = kappa<P>(lane);
-                // sample n = 2m + e of the frame sits at strip position x + n: even x: (e=0 -> E[x/2 + m], e=1 -> O[x/2 + m]);
-                // odd x: (e=0 -> O[(x-1)/2 + m], e=1 -> E[(x+1)/2 + m]).
-                const int odd = x & 1;
-                float* r0 = ring + (odd ? RH : 0);       // half receiving the e = 0 samples
-                float* r1 = ring + (odd ? 0 : RH);       // half receiving the e = 1 samples
-                const int c0 = ((x >> 1) % RH) + kap;
-                const int c1 = (((x + 1) >> 1) % RH) + kap;
-#pragma unroll
-                for (int i = 0; i < P; ++i) {
-                    int s0 = c0 + 64 * brev(i, LB);
-                    s0 = (s0 >= RH) ? s0 - RH : s0;
-                    int s1 = c1 + 64 * brev(i, LB);
-                    s1 = (s1 >= RH) ? s1 - RH : s1;
-                    r0[s0] += xr[i];
-                    r1[s1] += xi[i];
-                }
-            }
-            wave_sync();
-        }
-        // tail: stream out the rest of the strip; slots are cleared as they go, so strip elements beyond the
-        // ring window (aliases of already-flushed slots) read 0 and the ring is clean for the next chunk
-        flush_ring<R>(ring, strip, flushed, strip_len, strip_len, lane_id);
-        wave_sync();
-    }
-}
 
 // ---------------------------------------------------------------------------------------------
 // k_synth_ola_pair: same work as k_synth_ola, but TWO wavefronts share one chunk and one LDS ring: they take
@@ -752,11 +647,7 @@ int mpx_synth_ola_slots(void) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
     }
-#ifdef MPX_SYN_NO_PAIR
-    return cus * kSynWaves;
-#else
     return cus * kPairs;
-#endif
 }
 
 int mpx_synthesis_lossless_ola(void* stream, int fft_len, const void* tables, const float* mag, const float* real,
@@ -773,7 +664,6 @@ int mpx_synthesis_lossless_ola(void* stream, int fft_len, const void* tables, co
     if (!tables || !mag || !real || !imag || !chunks || !slot_off || !slot_chunks || !pm_rel || !strips)
         return fail(MPX_ERR_ARG, "mpx_synthesis_lossless_ola: null pointer%s");
     hipStream_t s = (hipStream_t)stream;
-#ifndef MPX_SYN_NO_PAIR
     {
         const dim3 grid((n_slots + kPairs - 1) / kPairs), block(kPairWaves * 64);
         if (P == 32) {
@@ -790,21 +680,6 @@ int mpx_synthesis_lossless_ola(void* stream, int fft_len, const void* tables, co
         MPX_HIP_CHECK(hipGetLastError());
         return MPX_OK;
     }
-#endif
-    const dim3 grid((n_slots + kSynWaves - 1) / kSynWaves), block(kSynWaves * 64);
-    if (P == 32) {
-        if (int rc = set_lds(k_synth_ola<32>, lds_bytes_ola<32>())) return rc;
-        hipLaunchKernelGGL(k_synth_ola<32>, grid, block, lds_bytes_ola<32>(), s, mag, real, imag,
-                           (const ChunkDesc*)chunks, slot_off, slot_chunks, (int)n_slots, pm_rel, (int)territory,
-                           (const float2*)tables, strips, (long long)ld);
-    } else {
-        if (int rc = set_lds(k_synth_ola<16>, lds_bytes_ola<16>())) return rc;
-        hipLaunchKernelGGL(k_synth_ola<16>, grid, block, lds_bytes_ola<16>(), s, mag, real, imag,
-                           (const ChunkDesc*)chunks, slot_off, slot_chunks, (int)n_slots, pm_rel, (int)territory,
-                           (const float2*)tables, strips, (long long)ld);
-    }
-    MPX_HIP_CHECK(hipGetLastError());
-    return MPX_OK;
 }
 
 int mpx_ola_fixup(void* stream, int fft_len, int32_t territory, const float* strips, int32_t n_utts,

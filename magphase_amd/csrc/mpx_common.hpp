@@ -29,9 +29,6 @@ inline int fail(int code, const char* fmt, const char* detail = "") {
 #ifndef MPX_WAVES_PER_BLOCK
 #define MPX_WAVES_PER_BLOCK 8
 #endif
-#ifndef MPX_SYN_WAVES
-#define MPX_SYN_WAVES 5
-#endif
 constexpr int kWavesPerBlock = MPX_WAVES_PER_BLOCK;  // 8: 512 threads, one block per CU, 2 waves per SIMD; measured best of 8/10/12/16 (tools/ab_bench.py); must not spill: scratch traffic counts in vmcnt
 constexpr int kThreads = kWavesPerBlock * 64;
 
@@ -213,17 +210,12 @@ __device__ __forceinline__ void feat_convert(const FrameFeat<P>& ff, float (&xr)
     }
 }
 
-constexpr int kSynWaves = MPX_SYN_WAVES;  // LDS: 16 KB twiddles + 5 x (8.1 KB transpose + 16.5 KB ring) = 139 KB
 // Ring of R strip elements, stored as two halves: even strip positions b in ringE[b/2 mod R/2], odd ones in
 // ringO.  A lane's two samples (2m, 2m+1) of a frame then hit ringE/ringO[c + m] with m consecutive across
 // lanes: conflict-free 4-byte accesses whatever the parity of the frame position.  (LDS float atomics
 // -- ds_add_f32 -- measured ~190 LDS cycles per wave instruction on gfx950: plain read/add/write instead.)
 template <int P>
 constexpr int ring_len() { return 128 * P + 128; }
-template <int P>
-constexpr size_t lds_bytes_ola() {
-    return sizeof(float) * (size_t)(P * 64 * 2 + kSynWaves * (P * kXStride + ring_len<P>()));
-}
 
 // Streams strip elements [from, to) out of the ring (to global) and clears their slots.  from is a multiple of 64.
 // Four 64-element blocks per step: their LDS reads are in flight together (one LDS latency per 256 elements instead
