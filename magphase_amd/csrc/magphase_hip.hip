@@ -641,14 +641,7 @@ int mpx_ola_gather(void* stream, int fft_len, const float* frames, int32_t n_utt
     return MPX_OK;
 }
 
-int mpx_synth_ola_slots(void) {
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) {
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-    }
-    return cus * kPairs;
-}
+int mpx_synth_ola_slots(void) { return device_cus() * kPairs; }
 
 int mpx_synthesis_lossless_ola(void* stream, int fft_len, const void* tables, const float* mag, const float* real,
                                const float* imag, const void* chunks, int32_t n_chunks, const int32_t* slot_off,

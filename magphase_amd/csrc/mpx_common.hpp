@@ -5,6 +5,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "../../include/magphase_hip.h"
@@ -260,31 +261,48 @@ struct ChunkDesc {
 // ---------------------------------------------------------------------------------------------
 inline int p_of(int fft_len) { return fft_len == 4096 ? 32 : (fft_len == 2048 ? 16 : 0); }
 
-inline int grid_for(long long nframes, int waves_per_block = kWavesPerBlock) {
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) {
+// Compute units of the current device (cached per device: hipGetDeviceProperties costs tens of microseconds, and this
+// is asked on every launch).
+inline int device_cus() {
+    static int cached[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cached[dev] == 0) {
         hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        cached[dev] = (hipGetDeviceProperties(&prop, dev) == hipSuccess) ? prop.multiProcessorCount : 256;
     }
-    long long need = (nframes + waves_per_block - 1) / waves_per_block;
-    return (int)std::max<long long>(1, std::min<long long>(need, cus));
+    return cached[dev];
 }
 
+inline int grid_for(long long nframes, int waves_per_block = kWavesPerBlock) {
+    long long need = (nframes + waves_per_block - 1) / waves_per_block;
+    return (int)std::max<long long>(1, std::min<long long>(need, device_cus()));
+}
+
+// Raises a kernel's dynamic LDS limit; remembered per (kernel, device, size) so that the runtime call is made once,
+// not on every launch.
 template <typename K>
 inline int set_lds(K kernel, size_t bytes) {
-    MPX_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    struct Entry {
+        const void* fn;
+        int dev;
+        size_t bytes;
+    };
+    static std::mutex mu;
+    static std::vector<Entry> done;
+    const void* fn = reinterpret_cast<const void*>(kernel);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        for (const Entry& e : done)
+            if (e.fn == fn && e.dev == dev && e.bytes == bytes) return MPX_OK;
+    }
+    MPX_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    std::lock_guard<std::mutex> lock(mu);
+    done.push_back({fn, dev, bytes});
     return MPX_OK;
 }
 
-
-inline int device_cus() {
-    int dev = 0, cus = 256;
-    if (hipGetDevice(&dev) == hipSuccess) {
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-    }
-    return cus;
-}
 
 }  // namespace mpx
