@@ -295,3 +295,42 @@ def test_dense_and_pitched_rows_agree(mp):
     splan = LosslessSynthesisPlan(eng, plan.v_f0, plan.fs, plan.fft_len)
     assert torch.equal(splan.run(*pitched), splan.run(*dense))
     assert torch.equal(splan.run_unfused(*pitched), splan.run_unfused(*dense))
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_epoch_patterns_match_oracle(mp, orc, seed):
+    """Fuzz: random signals with hostile epoch sets (epochs 1-3 samples apart, gaps longer than the FFT, first epoch
+    at 0-2 samples, last one near the end, mixed voicing) at both rates, several utterances per launch."""
+    rng = np.random.RandomState(4200 + seed)
+    fs = (48000, 16000)[seed % 2]
+    n_fft = 4096 if fs == 48000 else 2048
+    utts = []
+    for _u in range(3):
+        n = rng.randint(6000, 30000)
+        x = rng.uniform(-1, 1, n) * np.hanning(n) + 0.05 * np.sin(np.arange(n) * 0.05)
+        gaps = []
+        while sum(gaps) < n - 4:
+            kind = rng.randint(0, 10)
+            if kind == 0:
+                gaps.append(rng.randint(1, 4))                       # almost coincident epochs
+            elif kind == 1:
+                gaps.append(rng.randint(n_fft // 2, n_fft + 300))   # frame longer than the FFT: truncated + warning
+            else:
+                gaps.append(rng.randint(40, 700))
+        pm = np.cumsum(gaps).astype(np.float64)
+        pm = pm[pm < n - 3]
+        pm[0] = float(rng.randint(1, 3))     # (an epoch AT sample 0 gives shift 0 -> f0 = nan in the reference too)
+        pm = np.unique(pm)
+        voi = (rng.uniform(size=pm.size) > 0.4).astype(np.float64)
+        utts.append((x, fs, np.round(pm / fs, 7), voi))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        got = mp.analysis_lossless_batch(utts)
+        for (x, _fs, pm_sec, voi), a in zip(utts, got):
+            o = orc.analysis_lossless_from_epochs(x, fs, pm_sec, voi)
+            assert np.array_equal(a[5], o[5]) and np.array_equal(a[3], o[3], equal_nan=True)   # v_shift, v_f0: exact
+            _check_feats(a[:3], o[:3])
+            s_ref = orc.synthesis_from_lossless(o[0], o[1], o[2], o[3], fs)
+            s_got = mp.synthesis_from_lossless(a[0], a[1], a[2], a[3], fs)
+            assert s_got.shape == s_ref.shape
+            assert np.max(np.abs(s_got - s_ref)) <= PCM_TOL * max(1.0, np.max(np.abs(s_ref)))
