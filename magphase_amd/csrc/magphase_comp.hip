@@ -239,7 +239,7 @@ __device__ __forceinline__ void noise_spectrum(const FrameGeom& g, int wtype, co
 }
 
 template <int P>
-__global__ __launch_bounds__(kThreads) void k_noise_stats(const float* __restrict__ noise,
+__global__ __launch_bounds__(kAnaThreads) void k_noise_stats(const float* __restrict__ noise,
                                                           const long long* __restrict__ npos,
                                                           const int* __restrict__ nleft,
                                                           const int* __restrict__ nright,
@@ -253,13 +253,14 @@ __global__ __launch_bounds__(kThreads) void k_noise_stats(const float* __restric
     const int wave = threadIdx.x >> 6;
     float* xbuf = smem + P * 64 * 2 + wave * (P * kXStride);
     const unsigned xbuf_byte = 4u * (unsigned)(P * 64 * 2 + rfl(wave) * (P * kXStride));
-    for (int i = threadIdx.x; i < P * 64; i += kThreads) tw[i] = tw_g[i];
+    for (int i = threadIdx.x; i < P * 64; i += kAnaThreads) tw[i] = tw_g[i];
     __syncthreads();
     float wl_s0, wl_c0;
     sincospif(-2.0f * (float)kappa<P>(lane_id) / (float)N, &wl_s0, &wl_c0);
     const int wave_u = rfl(wave);
-    for (long long f = (long long)blockIdx.x * kWavesPerBlock + wave_u; f < nframes;
-         f += (long long)gridDim.x * kWavesPerBlock) {
+    // compute-only kernel (one float out per frame): 12 waves per CU like k_analysis (3 per SIMD)
+    for (long long f = (long long)blockIdx.x * kAnaWaves + wave_u; f < nframes;
+         f += (long long)gridDim.x * kAnaWaves) {
         int lane = lane_id;
         float wl_s = wl_s0, wl_c = wl_c0;
         asm volatile("" : "+v"(lane), "+v"(wl_s), "+v"(wl_c));
@@ -1426,15 +1427,15 @@ int mpx_noise_stats(void* stream, int fft_len, const void* tables, const float* 
     if (n_frames == 0) return MPX_OK;
     if (!tables || !noise || !frame_pos || !frame_left || !frame_right || !frame_wtype || !out_sum)
         return fail(MPX_ERR_ARG, "mpx_noise_stats: null pointer%s");
-    const dim3 grid(grid_for(n_frames)), block(kThreads);
+    const dim3 grid(grid_for(n_frames, kAnaWaves)), block(kAnaThreads);
     hipStream_t s = (hipStream_t)stream;
     if (P == 32) {
-        if (int rc = set_lds(k_noise_stats<32>, lds_bytes<32>())) return rc;
-        hipLaunchKernelGGL(k_noise_stats<32>, grid, block, lds_bytes<32>(), s, noise, (const long long*)frame_pos,
+        if (int rc = set_lds(k_noise_stats<32>, lds_bytes_ana<32>())) return rc;
+        hipLaunchKernelGGL(k_noise_stats<32>, grid, block, lds_bytes_ana<32>(), s, noise, (const long long*)frame_pos,
                            frame_left, frame_right, frame_wtype, (long long)n_frames, (const float2*)tables, out_sum);
     } else {
-        if (int rc = set_lds(k_noise_stats<16>, lds_bytes<16>())) return rc;
-        hipLaunchKernelGGL(k_noise_stats<16>, grid, block, lds_bytes<16>(), s, noise, (const long long*)frame_pos,
+        if (int rc = set_lds(k_noise_stats<16>, lds_bytes_ana<16>())) return rc;
+        hipLaunchKernelGGL(k_noise_stats<16>, grid, block, lds_bytes_ana<16>(), s, noise, (const long long*)frame_pos,
                            frame_left, frame_right, frame_wtype, (long long)n_frames, (const float2*)tables, out_sum);
     }
     MPX_HIP_CHECK(hipGetLastError());
