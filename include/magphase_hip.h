@@ -190,18 +190,7 @@ int mpx_synthesis_compressed_ola(void* stream, int fft_len, const void* tables, 
 int mpx_mel_warp(void* stream, int64_t n_frames, int32_t n_bins, const float* mag, const float* real, const float* imag,
                  const int32_t* row0, const int32_t* row1, const float* row_t, const float* w_mag, int32_t mag_dim,
                  const float* w_phase, int32_t phase_dim, const float* voiced, float* out_mag, float* out_real,
-                 float* out_imag, int64_t ld /* row pitch of mag/real/imag in floats, >= n_bins */,
-                 void* scratch /* device buffer of mpx_mel_warp_scratch_bytes() bytes, or null */);
-
-/*
- * Optional scratch of mpx_mel_warp: room for the two warp matrices re-packed (on the device, every call) into MFMA
- * fragment order.  With it an alternative, barrier-free kernel runs (one wavefront per 16 frames, feature rows by the
- * LDS DMA path); with scratch == null the LDS-staged kernel runs.  Same results up to fp32 summation order.  Measured
- * on configs[2] (64 k frames): LDS-staged 0.83 ms, DMA form 0.90 ms -- every wave re-reads the packed W from L2 (6 GB),
- * the staged form shares it between the 64 frames of a workgroup -- so callers should pass null unless their frame
- * counts are too small to fill workgroups of 64 frames.
- */
-size_t mpx_mel_warp_scratch_bytes(int32_t n_bins, int32_t mag_dim, int32_t phase_dim);
+                 float* out_imag, int64_t ld /* row pitch of mag/real/imag in floats, >= n_bins */);
 
 /*
  * Minimum-phase spectrum of a magnitude spectrum by the complex cepstrum (la.build_min_phase_from_mag_spec,

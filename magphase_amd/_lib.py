@@ -28,7 +28,6 @@ SYMBOLS = (
     "mpx_synth_comp_slots",
     "mpx_synthesis_compressed_ola",
     "mpx_mel_warp",
-    "mpx_mel_warp_scratch_bytes",
     "mpx_min_phase",
     "mpx_noise_gains",
     "mpx_post_filter",
@@ -88,9 +87,7 @@ def load():
     lib.mpx_synthesis_compressed_ola.restype = ctypes.c_int
     lib.mpx_synthesis_compressed_ola.argtypes = [vp, ctypes.c_int, vp] + [vp] * 19 + [vp, i32, vp, vp, i32, i32, vp, i64]
     lib.mpx_mel_warp.restype = ctypes.c_int
-    lib.mpx_mel_warp.argtypes = [vp, i64, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, vp, vp, vp, vp, i64, vp]
-    lib.mpx_mel_warp_scratch_bytes.restype = sz
-    lib.mpx_mel_warp_scratch_bytes.argtypes = [i32, i32, i32]
+    lib.mpx_mel_warp.argtypes = [vp, i64, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, vp, vp, vp, vp, i64]
     lib.mpx_min_phase.restype = ctypes.c_int
     lib.mpx_min_phase.argtypes = [vp, ctypes.c_int, vp, vp, vp, vp, vp, i64, vp, vp, vp, i64]
     lib.mpx_noise_gains.restype = ctypes.c_int

@@ -1108,161 +1108,6 @@ __global__ __launch_bounds__(256) void k_mel_warp_mfma(WarpJobs jobs, int job0, 
 }
 
 // ---------------------------------------------------------------------------------------------
-// Mel warp, barrier-free form.  In k_mel_warp_mfma the matrix pipe is busy 39 % of the time: the waves wait on the 48
-// register loads of a chunk and on two workgroup barriers per chunk.  Here a wave is on its own: it owns 16 output
-// frames and all column tiles for the whole reduction.
-//   * A operand: the RAW feature rows of its 16 frames (both interpolation rows) are copied HBM -> LDS by the DMA path
-//     (global_load_lds_dword: no registers, no VALU), double buffered, one chunk of 64 bins ahead; the prologue
-//     (row interpolation, ln(x^2 + 1e-8) / ln(e^{2x} + 1e-8)) is applied to the lane's own fragment after the
-//     16-byte LDS reads -- every A element belongs to exactly one lane, so nothing is computed twice.
-//   * B operand: W is re-packed once per call (k_warp_pack) into fragment order [chunk][tile][q][lane][4], zero padded:
-//     a wave's fragment of one tile and chunk is four fully coalesced 1 KB loads from L2.
-// No __syncthreads() in the chunk loop; vmcnt order per chunk: [DMA(c) | B(c) | DMA(c+1)], wait until only the last two
-// groups are outstanding.  MEASURED SLOWER than the staged form (0.90 vs 0.83 ms on 64 k frames): W is not shared
-// between waves any more (12 k waves x 0.5 MB from L2 / the vector L1, which is then 75 % busy), and one chunk of
-// look-ahead does not cover the HBM latency with 2 waves per SIMD.  Kept selectable (scratch != null) for small batches.
-// ---------------------------------------------------------------------------------------------
-constexpr int kWarpChunk = 64;                 // bins per chunk
-constexpr int kWarpRowStride = 68;             // floats per staged row: 16-byte aligned, conflict-free 16-byte reads
-
-__global__ __launch_bounds__(256) void k_warp_pack(const float* __restrict__ W, int nout, int H, int n_chunks, int nt,
-                                                   float* __restrict__ Wp) {
-    const long long total = (long long)n_chunks * nt * 4 * 64 * 4;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int e = (int)(i & 3), lane = (int)((i >> 2) & 63), q = (int)((i >> 8) & 3);
-        const long long cj = i >> 10;
-        const int jt = (int)(cj % nt), c = (int)(cj / nt);
-        const int k = kWarpChunk * c + 16 * (lane >> 4) + 4 * q + e, col = 16 * jt + (lane & 15);
-        Wp[i] = (k < H && col < nout) ? W[(long long)col * H + k] : 0.0f;
-    }
-}
-
-template <int NT, bool INTERP>
-__global__ __launch_bounds__(256) void k_mel_warp_dma(WarpJobs jobs, const float* __restrict__ wp_mag,
-                                                      const float* __restrict__ wp_phase, long long F, int H,
-                                                      const int* __restrict__ row0, const int* __restrict__ row1,
-                                                      const float* __restrict__ rowt, long long ld) {
-    constexpr int kPlanes = INTERP ? 2 : 1;
-    constexpr int kStage = kPlanes * 16 * kWarpRowStride;          // floats per stage and wave
-    extern __shared__ float smem[];
-    const WarpJob job = jobs.j[blockIdx.z];
-    const float* __restrict__ Wp = (blockIdx.z == 0) ? wp_mag : wp_phase;
-    const int lane = threadIdx.x & 63;
-    const int wave = rfl((int)(threadIdx.x >> 6));
-    const int li = lane & 15, g = lane >> 4;
-    float* stage0 = smem + wave * (2 * kStage);
-    const unsigned stage_byte = 4u * (unsigned)(wave * (2 * kStage));
-    const long long f0 = (long long)blockIdx.y * 64 + 16 * wave;     // this wave's first frame
-    if (f0 >= F) return;
-    const int n_chunks = (H + kWarpChunk - 1) / kWarpChunk;
-
-    // row base pointers of the wave's 16 frames (wave-uniform -> scalar registers) and the lane's interpolation weight
-    const float* rb0[16];
-    const float* rb1[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const long long f = min(f0 + r, F - 1);       // frames past F repeat the last one: computed, never stored
-        const int i0 = row0 ? row0[f] : (int)f;
-        const int i1 = row0 ? row1[f] : (int)f;
-        rb0[r] = job.x + (long long)rfl(i0) * ld;
-        rb1[r] = job.x + (long long)rfl(i1) * ld;
-    }
-    float rt = 0.0f;
-    if (INTERP) rt = rowt[min(f0 + li, F - 1)];
-
-    auto dma_chunk = [&](int c, int st) {   // 16 (x2) rows x 64 bins of chunk c -> stage st; bins past H-1 re-read bin H-1
-        const unsigned voff = 4u * (unsigned)min(kWarpChunk * c + lane, H - 1);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const unsigned m0a = stage_byte + 4u * (unsigned)(st * kStage + r * kWarpRowStride);
-            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff), "s"(rb0[r]), "s"(m0a)
-                         : "m0", "memory");
-            if (INTERP) {
-                const unsigned m0b = m0a + 4u * (unsigned)(16 * kWarpRowStride);
-                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1" ::"v"(voff), "s"(rb1[r]), "s"(m0b)
-                             : "m0", "memory");
-            }
-        }
-    };
-
-    f32x4 acc[NT];
-#pragma unroll
-    for (int jt = 0; jt < NT; ++jt) acc[jt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    dma_chunk(0, 0);
-    const float4* wp4 = reinterpret_cast<const float4*>(Wp) + lane;
-    for (int c = 0; c < n_chunks; ++c) {
-        const int st = c & 1;
-        // B fragments of this chunk (registers), then the DMA of the next chunk; then wait for this chunk's DMA only:
-        // everything issued after it (NT*4 fragment loads + the next DMA) may still be in flight
-        float4 b4[NT][4];
-#pragma unroll
-        for (int jt = 0; jt < NT; ++jt)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) b4[jt][q] = wp4[((long long)(c * NT + jt) * 4 + q) * 64];
-        const bool more = c + 1 < n_chunks;
-        if (more) dma_chunk(c + 1, st ^ 1);
-        if (more) {
-            if (INTERP) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NT * 4 + 32) : "memory");
-            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NT * 4 + 16) : "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NT * 4) : "memory");
-        }
-        // A fragment: frame li, bins 64 c + 16 g + t, t = 0..15
-        const float* srow = stage0 + st * kStage + li * kWarpRowStride + 16 * g;
-        float a[16];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const float4 x0 = *reinterpret_cast<const float4*>(srow + 4 * q);
-            float xs[4] = {x0.x, x0.y, x0.z, x0.w};
-            if (INTERP) {
-                const float4 x1 = *reinterpret_cast<const float4*>(srow + 16 * kWarpRowStride + 4 * q);
-                const float x1s[4] = {x1.x, x1.y, x1.z, x1.w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) xs[e] = fmaf(x1s[e] - xs[e], rt, xs[e]);
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                // hardware exp2/log2 (v_exp_f32 / v_log_f32, ~1 ulp): far below the tolerance of this (ill-conditioned,
-                // unpinned) stage
-                const float ex = (job.mode == 0) ? xs[e] : __expf(xs[e]);
-                a[4 * q + e] = __logf(fmaf(ex, ex, 1.0e-8f));
-            }
-        }
-        if (kWarpChunk * (c + 1) > H) {   // last chunk: bins past H-1 hold a copy of bin H-1 -- their A must be 0
-#pragma unroll
-            for (int t = 0; t < 16; ++t) a[t] = (kWarpChunk * c + 16 * g + t < H) ? a[t] : 0.0f;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // stage st is free for the DMA issued in the next iteration
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-#pragma unroll
-            for (int jt = 0; jt < NT; ++jt) acc[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * q + 0], b4[jt][q].x, acc[jt], 0, 0, 0);
-#pragma unroll
-            for (int jt = 0; jt < NT; ++jt) acc[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * q + 1], b4[jt][q].y, acc[jt], 0, 0, 0);
-#pragma unroll
-            for (int jt = 0; jt < NT; ++jt) acc[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * q + 2], b4[jt][q].z, acc[jt], 0, 0, 0);
-#pragma unroll
-            for (int jt = 0; jt < NT; ++jt) acc[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * q + 3], b4[jt][q].w, acc[jt], 0, 0, 0);
-        }
-    }
-    // C: column li of tile jt, row 4 g + r of this wave's 16 frames
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const long long f = f0 + 4 * g + r;
-        if (f >= F) continue;
-        const float vo = job.voi ? job.voi[f] : 1.0f;
-#pragma unroll
-        for (int jt = 0; jt < NT; ++jt) {
-            const int i = 16 * jt + li;
-            if (i >= job.nout) continue;
-            float y = acc[jt][r];
-            if (job.mode == 1) y = fminf(fmaxf(y * vo, -1.0f), 1.0f);
-            job.out[f * job.nout + i] = y;
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
 // Mel unwarp on the matrix cores: out[F x H] = op(A[F x K] . U[K x H]) with v_mfma_f32_32x32x2_f32 (f32 in, f32
 // accumulate: bit-for-bit an fmaf chain in k order, so the result equals the VALU form's).  One wave = one task =
 // 32 frames x kUnwarpColTiles column tiles of 32 bins.  Nothing is staged in LDS: A (F x K, a few MB) and U (K x H,
@@ -1504,17 +1349,10 @@ int mpx_synthesis_compressed_ola(void* stream, int fft_len, const void* tables, 
     return MPX_OK;
 }
 
-size_t mpx_mel_warp_scratch_bytes(int32_t n_bins, int32_t mag_dim, int32_t phase_dim) {
-    if (n_bins <= 0 || mag_dim <= 0 || phase_dim <= 0) return 0;
-    const int nt = (std::max(mag_dim, phase_dim) + 15) / 16;
-    const int n_chunks = ((int)n_bins + kWarpChunk - 1) / kWarpChunk;
-    return 2 * sizeof(float) * (size_t)n_chunks * nt * 4 * 64 * 4;
-}
-
 int mpx_mel_warp(void* stream, int64_t n_frames, int32_t n_bins, const float* mag, const float* real, const float* imag,
                  const int32_t* row0, const int32_t* row1, const float* row_t, const float* w_mag, int32_t mag_dim,
                  const float* w_phase, int32_t phase_dim, const float* voiced, float* out_mag, float* out_real,
-                 float* out_imag, int64_t ld, void* scratch) {
+                 float* out_imag, int64_t ld) {
     if (n_frames < 0 || n_bins <= 0 || ld < n_bins) return fail(MPX_ERR_ARG, "mpx_mel_warp: bad size%s");
     if (mag_dim <= 0 || mag_dim > kWarpTile || phase_dim <= 0 || phase_dim > kWarpTile)
         return fail(MPX_ERR_ARG, "mpx_mel_warp: output dimension must be in 1..64%s");
@@ -1533,49 +1371,15 @@ int mpx_mel_warp(void* stream, int64_t n_frames, int32_t n_bins, const float* ma
     hipLaunchKernelGGL(k_mel_warp, grid, dim3(256), 0, (hipStream_t)stream, jobs, (long long)n_frames, (int)n_bins,
                        row0, row1, row_t, (long long)ld);
 #else
-    const int nt = (std::max(mag_dim, phase_dim) + 15) / 16;   // one launch for the three jobs: sized for the wider one
-    const dim3 g2(1, grid.y, 3);
-#ifndef MPX_WARP_LDS
-    if (scratch) {
-        // barrier-free form: W re-packed into fragment order (two small kernels), then one wave per 16 frames
-        const int n_chunks = ((int)n_bins + kWarpChunk - 1) / kWarpChunk;
-        const size_t per = (size_t)n_chunks * nt * 4 * 64 * 4;
-        float* wp_mag = (float*)scratch;
-        float* wp_phase = wp_mag + per;
-        hipLaunchKernelGGL(k_warp_pack, dim3(128), dim3(256), 0, (hipStream_t)stream, w_mag, (int)mag_dim, (int)n_bins,
-                           n_chunks, nt, wp_mag);
-        hipLaunchKernelGGL(k_warp_pack, dim3(128), dim3(256), 0, (hipStream_t)stream, w_phase, (int)phase_dim,
-                           (int)n_bins, n_chunks, nt, wp_phase);
-        const bool interp = row0 != nullptr;
-        const size_t lds = sizeof(float) * 4 * 2 * (interp ? 2 : 1) * 16 * kWarpRowStride;
-#define MPX_WARP_DMA(NT, IP)                                                                                       \
-    do {                                                                                                           \
-        if (int rc = set_lds(k_mel_warp_dma<NT, IP>, lds)) return rc;                                              \
-        hipLaunchKernelGGL((k_mel_warp_dma<NT, IP>), g2, dim3(256), lds, (hipStream_t)stream, jobs,                \
-                           (const float*)wp_mag, (const float*)wp_phase, (long long)n_frames, (int)n_bins, row0,   \
-                           row1, row_t, (long long)ld);                                                            \
-    } while (0)
-        switch (nt * 2 + (interp ? 1 : 0)) {
-            case 2: MPX_WARP_DMA(1, false); break;
-            case 3: MPX_WARP_DMA(1, true); break;
-            case 4: MPX_WARP_DMA(2, false); break;
-            case 5: MPX_WARP_DMA(2, true); break;
-            case 6: MPX_WARP_DMA(3, false); break;
-            case 7: MPX_WARP_DMA(3, true); break;
-            case 8: MPX_WARP_DMA(4, false); break;
-            default: MPX_WARP_DMA(4, true); break;
-        }
-#undef MPX_WARP_DMA
-        MPX_HIP_CHECK(hipGetLastError());
-        return MPX_OK;
-    }
-#endif
-    {   // LDS-staged form (no scratch buffer given)
+    // ONE launch for the three jobs (separate launches end in a half-empty last round of workgroups); the
+    // column-tile count is a template parameter, so it is sized for the wider job.
+    {
         const int job0 = 0;
+        const dim3 g2(1, grid.y, 3);
 #define MPX_WARP_LAUNCH(NT)                                                                                        \
     hipLaunchKernelGGL(k_mel_warp_mfma<NT>, g2, dim3(256), 0, (hipStream_t)stream, jobs, job0, (long long)n_frames, \
                        (int)n_bins, row0, row1, row_t, (long long)ld)
-        switch (nt) {
+        switch ((std::max(mag_dim, phase_dim) + 15) / 16) {
             case 1: MPX_WARP_LAUNCH(1); break;
             case 2: MPX_WARP_LAUNCH(2); break;
             case 3: MPX_WARP_LAUNCH(3); break;

@@ -677,11 +677,6 @@ class CompressedAnalysisPlan:
         a_ph = alpha if alpha_phase is None else alpha_phase
         cf, _ = hm.define_crossfade_params(fs)
         k_full = hm.get_num_full_mel_coeffs_from_num_phase_coeffs(cf, phase_dim, a_ph, fs)
-        # scratch = None: the LDS-staged kernel (measured faster, 0.83 vs 0.90 ms); MAGPHASE_WARP_DMA=1 selects the
-        # barrier-free DMA form (include/magphase_hip.h: mpx_mel_warp_scratch_bytes)
-        self.warp_scratch = None
-        if os.environ.get("MAGPHASE_WARP_DMA", "0") == "1":
-            self.warp_scratch = e.empty((max(1, int(e.lib.mpx_mel_warp_scratch_bytes(H, mag_dim, phase_dim)) // 4),))
         self.w_mag = e.to_device(hm.warp_matrix(mag_dim, H, alpha), np.float32)
         self.w_ph = e.to_device(hm.warp_matrix(k_full, H, a_ph, nrows=phase_dim), np.float32)
         row0, row1, rowt, self.f0_out = [], [], [], []
@@ -719,9 +714,7 @@ class CompressedAnalysisPlan:
                                           imag.data_ptr(), ptr(self.row0), ptr(self.row1), ptr(self.rowt),
                                           self.w_mag.data_ptr(), self.mag_dim, self.w_ph.data_ptr(), self.phase_dim,
                                           self.voi.data_ptr(), out[0].data_ptr(), out[1].data_ptr(),
-                                          out[2].data_ptr(), e.feat_ld(mag, real, imag),
-                                          self.warp_scratch.data_ptr() if self.warp_scratch is not None else None),
-                       "mpx_mel_warp")
+                                          out[2].data_ptr(), e.feat_ld(mag, real, imag)), "mpx_mel_warp")
         return out
 
 

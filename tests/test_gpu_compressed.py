@@ -218,22 +218,3 @@ def test_device_output_hpf_matches_lfilter(mp):
         for u, x in enumerate(sigs):
             ref = signal.lfilter(b_, a_, x.astype(np.float64))
             assert np.max(np.abs(y[off[u]:off[u + 1]] - ref)) <= 1e-6 * max(1.0, np.max(np.abs(ref)))
-
-
-def test_warp_dma_form_matches_the_staged_form(mp, monkeypatch):
-    """mpx_mel_warp with a scratch buffer (barrier-free DMA kernel) vs without (LDS-staged kernel): same GEMM, different
-    fp32 summation order -- const-rate (interpolated rows) and variable-rate inputs, 48 k and 16 k."""
-    from magphase_amd import synthetic as syn
-    for fs, const_rate in ((48000, True), (48000, False), (16000, True)):
-        utts = []
-        for u in range(3):
-            pcm, pm, voi = syn.make_utterance(20 + u, dur_s=0.9, fs=fs)
-            utts.append((syn.pcm_to_float(pcm), fs, pm, voi))
-        monkeypatch.setenv("MAGPHASE_WARP_DMA", "0")
-        a = mp.analysis_compressed_batch(utts, mag_dim=60, phase_dim=45, b_const_rate=const_rate)
-        monkeypatch.setenv("MAGPHASE_WARP_DMA", "1")
-        b = mp.analysis_compressed_batch(utts, mag_dim=60, phase_dim=45, b_const_rate=const_rate)
-        for ra, rb in zip(a, b):
-            for k in range(3):
-                assert ra[k].shape == rb[k].shape
-                assert np.max(np.abs(ra[k] - rb[k])) <= 2e-4 * max(1.0, np.max(np.abs(ra[k]))), (fs, const_rate, k)
