@@ -1018,6 +1018,7 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_synth_comp_pair(const f
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int NT>   // 16-wide column tiles in use: ceil(nout / 16)
+__attribute__((amdgpu_waves_per_eu(4, 4)))   // <= 128 VGPRs: four workgroups (35 KB of LDS each) per CU, measured -5 %
 __global__ __launch_bounds__(256) void k_mel_warp_mfma(WarpJobs jobs, int job0, long long F, int H,
                                                        const int* __restrict__ row0, const int* __restrict__ row1,
                                                        const float* __restrict__ rowt, long long ld) {
