@@ -121,6 +121,12 @@ class Engine:
                 raise ValueError("mag/real/imag must share one row pitch")
         return ld
 
+    def constant(self, key, build, dtype=np.float32):
+        """Device-resident constant table, built (float64 on the host) and uploaded once per key."""
+        if key not in self._tables:
+            self._tables[key] = self.to_device(build(), dtype)
+        return self._tables[key]
+
     def to_device(self, arr, dtype):
         torch = _torch()
         t = torch.from_numpy(np.ascontiguousarray(arr, dtype=dtype))
@@ -525,10 +531,14 @@ class CompressedSynthesisPlan:
         self.out_start = e.to_device(np.asarray(starts), np.int32)
         self.out_off = e.to_device(self.out_off_host, np.int64)
         # constants: unwarp matrices and per-bin curves (float64 -> float32)
-        self.u_mag = e.to_device(hm.unwarp_matrix(self.mag_dim, H, alpha), np.float32)
-        self.u_phase = e.to_device(hm.phase_unwarp_matrix(self.phase_dim, N, fs, self.alpha_phase), np.float32)
-        per_v, ap_v, ap_u = hm.synthesis_bin_curves(fs, N)
-        self.per_v, self.ap_v, self.ap_u = (e.to_device(x, np.float32) for x in (per_v, ap_v, ap_u))
+        # (resident on the device per configuration: rebuilding them costs 7 ms on the host, as much as the rest of a
+        # single-utterance call -- tools/latency_probe.py)
+        self.u_mag = e.constant(("u_mag", self.mag_dim, H, float(alpha)),
+                                lambda: hm.unwarp_matrix(self.mag_dim, H, alpha))
+        self.u_phase = e.constant(("u_phase", self.phase_dim, N, int(fs), float(self.alpha_phase)),
+                                  lambda: hm.phase_unwarp_matrix(self.phase_dim, N, fs, self.alpha_phase))
+        self.per_v, self.ap_v, self.ap_u = (
+            e.constant(("bin_curve", k, int(fs), N), lambda k=k: hm.synthesis_bin_curves(fs, N)[k]) for k in range(3))
         # OLA chunks
         rows, terr_off, owner_all = hm.ola_chunks(pm_rel, N, self.territory)
         self.n_chunks = int(rows.shape[0])
@@ -677,8 +687,9 @@ class CompressedAnalysisPlan:
         a_ph = alpha if alpha_phase is None else alpha_phase
         cf, _ = hm.define_crossfade_params(fs)
         k_full = hm.get_num_full_mel_coeffs_from_num_phase_coeffs(cf, phase_dim, a_ph, fs)
-        self.w_mag = e.to_device(hm.warp_matrix(mag_dim, H, alpha), np.float32)
-        self.w_ph = e.to_device(hm.warp_matrix(k_full, H, a_ph, nrows=phase_dim), np.float32)
+        self.w_mag = e.constant(("w_mag", int(mag_dim), H, float(alpha)), lambda: hm.warp_matrix(mag_dim, H, alpha))
+        self.w_ph = e.constant(("w_ph", int(k_full), H, float(a_ph), int(phase_dim)),
+                               lambda: hm.warp_matrix(k_full, H, a_ph, nrows=phase_dim))
         row0, row1, rowt, self.f0_out = [], [], [], []
         for u in range(len(utts)):
             v_f0 = plan.v_f0[u]
