@@ -108,7 +108,8 @@ def analysis_lossless_batch(utts, fft_len=None, engine=None, return_device=False
         if return_device:
             feats = (mag[a:b], real[a:b], imag[a:b])
         else:
-            feats = tuple(h[a:b].copy() for h in h_feats)   # fresh arrays owned by the caller, like the reference's
+            # fresh arrays owned by the caller, like the reference's (a one-utterance batch already is one)
+            feats = h_feats if len(utts) == 1 else tuple(h[a:b].copy() for h in h_feats)
         out.append(feats + (plan.v_f0[u], plan.fs[u], plan.v_shift[u].astype(int)))
     return out
 

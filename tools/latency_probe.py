@@ -44,3 +44,35 @@ for _ in range(5):
     once()
 pr.disable()
 pstats.Stats(pr).sort_stats("cumulative").print_stats(18)
+
+# ---- lossless analysis + synthesis and low-dimensional analysis of one 5 s utterance (array API)
+from magphase_amd import synthetic as syn  # noqa: E402
+
+pcm, pm, voi = syn.make_utterance(3, dur_s=5.0)
+x = syn.pcm_to_float(pcm)
+
+
+def lossless():
+    a = mp.analysis_lossless_from_epochs(x, 48000, pm, voi)
+    return mp.synthesis_from_lossless(a[0], a[1], a[2], a[3], 48000)
+
+
+def lowdim():
+    return mp.analysis_compressed_batch([(x, 48000, pm, voi)], mag_dim=60, phase_dim=45)[0]
+
+
+for name, fn in (("lossless analysis + synthesis (numpy in, numpy out)", lossless), ("analysis_compressed", lowdim)):
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    t = time.time()
+    for _ in range(10):
+        fn()
+    torch.cuda.synchronize()
+    print("%s, 5 s utterance: %.2f ms per call" % (name, (time.time() - t) / 10 * 1e3))
+    pr = cProfile.Profile()
+    pr.enable()
+    for _ in range(3):
+        fn()
+    pr.disable()
+    pstats.Stats(pr).sort_stats("tottime").print_stats(8)
