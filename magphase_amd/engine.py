@@ -127,6 +127,34 @@ class Engine:
             self._tables[key] = self.to_device(build(), dtype)
         return self._tables[key]
 
+    def to_device_packed(self, items):
+        """
+        items: list of (name, array, numpy dtype).  ONE host-to-device copy for all of them (each ~25 us on its own: a
+        plan has 15-25 small index tables); returns {name: tensor}, the tensors being 256-byte aligned views of one
+        device buffer.
+        """
+        torch = _torch()
+        tmap = {np.dtype(np.float32): torch.float32, np.dtype(np.float64): torch.float64,
+                np.dtype(np.int32): torch.int32, np.dtype(np.int64): torch.int64}
+        prepared, offs, total = [], [], 0
+        for _name, arr, dt in items:
+            a = np.ascontiguousarray(arr, dtype=dt)
+            total = (total + 255) // 256 * 256
+            offs.append(total)
+            prepared.append(a)
+            total += a.nbytes
+        host = np.zeros(max(total, 1), dtype=np.uint8)
+        for off, a in zip(offs, prepared):
+            host[off:off + a.nbytes] = a.reshape(-1).view(np.uint8)
+        dev = torch.from_numpy(host).to(self.device, non_blocking=False)
+        out = {}
+        for (name, _arr, dt), off, a in zip(items, offs, prepared):
+            if a.nbytes == 0:
+                out[name] = torch.empty(a.shape, dtype=tmap[np.dtype(dt)], device=self.device)
+            else:
+                out[name] = dev[off:off + a.nbytes].view(tmap[np.dtype(dt)]).view(a.shape)
+        return out
+
     def to_device(self, arr, dtype):
         torch = _torch()
         t = torch.from_numpy(np.ascontiguousarray(arr, dtype=dtype))
@@ -377,28 +405,32 @@ class LosslessSynthesisPlan:
         self.max_out_len = int(max(lens)) if lens else 0
         self.total_frames = int(sum(nfr))
         e = engine
-        self.utt_frame_off = e.to_device(np.concatenate(([0], np.cumsum(nfr))), np.int32)
-        self.pm_rel = e.to_device(np.concatenate(pm_rel) if pm_rel else np.zeros(0), np.int32)
-        self.out_start = e.to_device(np.asarray(starts), np.int32)
+        _up = self._up = []   # (attribute, host array, dtype): uploaded together (Engine.to_device_packed)
+        _up.append(("utt_frame_off", np.concatenate(([0], np.cumsum(nfr))), np.int32))
+        _up.append(("pm_rel", np.concatenate(pm_rel) if pm_rel else np.zeros(0), np.int32))
+        _up.append(("out_start", np.asarray(starts), np.int32))
         self._starts_host = [int(x) for x in starts]
-        self.out_off = e.to_device(self.out_off_host, np.int64)
+        _up.append(("out_off", self.out_off_host, np.int64))
         self._build_chunks(pm_rel, nfr)
+        for _k, _t in e.to_device_packed(_up).items():
+            setattr(self, _k, _t)
+        del self._up
 
     def _build_chunks(self, pm_rel_list, nfr):
         """Territories of the OLA buffer -> chunks (include/magphase_hip.h: mpx_synthesis_lossless_ola)."""
         rows, terr_off, owner_all = hm.ola_chunks(pm_rel_list, self.fft_len, self.territory)
         e = self.engine
         self.n_chunks = int(rows.shape[0])
-        self.chunks = e.to_device(rows, np.int32)
-        self.utt_chunk_off = e.to_device(np.asarray(terr_off), np.int32)
+        self._up.append(("chunks", rows, np.int32))
+        self._up.append(("utt_chunk_off", np.asarray(terr_off), np.int32))
         self.max_territories = _max_territories(terr_off, self._starts_host, self.out_len, self.territory)
-        self.strip_id = e.to_device(owner_all, np.int32)
+        self._up.append(("strip_id", owner_all, np.int32))
         self.strip_floats = self.n_chunks * (self.territory + self.fft_len)
         n_slots = e.synth_ola_slots() if hasattr(e, "synth_ola_slots") else 1280
         slot_off, slot_chunks = hm.balance_chunks(rows[:, 1] - rows[:, 0], n_slots)
         self.n_slots = int(slot_off.size - 1)
-        self.slot_off = e.to_device(slot_off, np.int32)
-        self.slot_chunks = e.to_device(slot_chunks, np.int32)
+        self._up.append(("slot_off", slot_off, np.int32))
+        self._up.append(("slot_chunks", slot_chunks, np.int32))
 
     def run(self, mag, real, imag, strips=None, out=None):
         """Fused path: k_synth_ola (per-chunk LDS overlap-add) + k_ola_fixup."""
@@ -439,6 +471,7 @@ class CompressedSynthesisPlan:
         self.per_phase_type = per_phase_type
 
         self.engine = e = engine
+        _up = []   # (attribute, host array, dtype): uploaded together at the end (Engine.to_device_packed)
         self.fs = fs
         N = self.fft_len = int(fft_len) if fft_len else hm.define_fft_len(fs)
         H = N // 2 + 1
@@ -511,25 +544,25 @@ class CompressedSynthesisPlan:
         self.total_out = int(self.out_off_host[-1])
         self.max_out_len = int(max(lens))
         self.voiced_host = cat(voiced).astype(bool)
-        self.utt_frame_off = e.to_device(self.frame_off, np.int32)
+        _up.append(("utt_frame_off", self.frame_off, np.int32))
         self.n_utts = len(nfr)
-        self.a_mag = e.to_device(cat(a_mag), np.float32)
-        self.a_real = e.to_device(cat(a_real), np.float32)
-        self.a_imag = e.to_device(cat(a_imag), np.float32)
-        self.noise = e.to_device(cat(noises), np.float32)
-        self.npos = e.to_device(cat(npos), np.int64)
-        self.nleft = e.to_device(cat(nleft), np.int32)
-        self.nright = e.to_device(cat(nright), np.int32)
-        self.wtype = e.to_device(cat(wtype), np.int32)
-        self.voiced = e.to_device(cat(voiced), np.int32)
-        self.row0 = e.to_device(cat(row0), np.int32)
-        self.row1 = e.to_device(cat(row1), np.int32)
-        self.rowt = e.to_device(cat(rowt), np.float32)
-        self.win_l = e.to_device(cat(win_l), np.int32)
-        self.win_r = e.to_device(cat(win_r), np.int32)
-        self.pm_rel = e.to_device(cat(pm_rel), np.int32)
-        self.out_start = e.to_device(np.asarray(starts), np.int32)
-        self.out_off = e.to_device(self.out_off_host, np.int64)
+        _up.append(("a_mag", cat(a_mag), np.float32))
+        _up.append(("a_real", cat(a_real), np.float32))
+        _up.append(("a_imag", cat(a_imag), np.float32))
+        _up.append(("noise", cat(noises), np.float32))
+        _up.append(("npos", cat(npos), np.int64))
+        _up.append(("nleft", cat(nleft), np.int32))
+        _up.append(("nright", cat(nright), np.int32))
+        _up.append(("wtype", cat(wtype), np.int32))
+        _up.append(("voiced", cat(voiced), np.int32))
+        _up.append(("row0", cat(row0), np.int32))
+        _up.append(("row1", cat(row1), np.int32))
+        _up.append(("rowt", cat(rowt), np.float32))
+        _up.append(("win_l", cat(win_l), np.int32))
+        _up.append(("win_r", cat(win_r), np.int32))
+        _up.append(("pm_rel", cat(pm_rel), np.int32))
+        _up.append(("out_start", np.asarray(starts), np.int32))
+        _up.append(("out_off", self.out_off_host, np.int64))
         # constants: unwarp matrices and per-bin curves (float64 -> float32)
         # (resident on the device per configuration: rebuilding them costs 7 ms on the host, as much as the rest of a
         # single-utterance call -- tools/latency_probe.py)
@@ -542,17 +575,19 @@ class CompressedSynthesisPlan:
         # OLA chunks
         rows, terr_off, owner_all = hm.ola_chunks(pm_rel, N, self.territory)
         self.n_chunks = int(rows.shape[0])
-        self.chunks = e.to_device(rows, np.int32)
-        self.utt_chunk_off = e.to_device(terr_off, np.int32)
+        _up.append(("chunks", rows, np.int32))
+        _up.append(("utt_chunk_off", terr_off, np.int32))
         self.max_territories = _max_territories(terr_off, starts, self.out_len, self.territory)
-        self.strip_id = e.to_device(owner_all, np.int32)
+        _up.append(("strip_id", owner_all, np.int32))
         self.strip_floats = self.n_chunks * (self.territory + N)
         n_slots = e.synth_comp_slots() if hasattr(e, "synth_comp_slots") else 1024
         slot_off, slot_chunks = hm.balance_chunks(rows[:, 1] - rows[:, 0], n_slots)
         self.n_slots = int(slot_off.size - 1)
-        self.slot_off = e.to_device(slot_off, np.int32)
-        self.slot_chunks = e.to_device(slot_chunks, np.int32)
+        _up.append(("slot_off", slot_off, np.int32))
+        _up.append(("slot_chunks", slot_chunks, np.int32))
         self._gains_dev = None
+        for _k, _t in e.to_device_packed(_up).items():
+            setattr(self, _k, _t)
 
     @property
     def gains(self):

@@ -89,6 +89,9 @@ class _FakeEngine:
     def to_device(self, arr, dtype):
         return np.ascontiguousarray(arr, dtype=dtype)
 
+    def to_device_packed(self, items):
+        return {name: np.ascontiguousarray(arr, dtype=dt) for name, arr, dt in items}
+
 
 def test_plans_build_without_gpu_and_match_oracle_indices():
     from magphase_amd import synthetic as syn
