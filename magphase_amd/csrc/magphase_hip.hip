@@ -129,22 +129,13 @@ __global__ __launch_bounds__(kAnaThreads) void k_analysis(const float* __restric
         // two full lines; with the dense pitch ld = H it is still 3 % faster than the unshifted form.
         // (3) Dense rows (ld = H) beat padded ones (H -> 2080 / 2112: +7 %): the lone bin M shares its line with the
         // next row, written by the neighbouring wave, instead of leaving a partial line per row.
-#ifdef MPX_PROBE_LD   // timing probe only: overrides the row pitch (rows may overlap)
-        const long long ldp = MPX_PROBE_LD;
-#else
-        const long long ldp = ld;
-#endif
-        float* row_m = omag + f * ldp;
-        float* row_r = oreal + f * ldp;
-        float* row_i = oimag + f * ldp;
+        float* row_m = omag + f * ld;
+        float* row_r = oreal + f * ld;
+        float* row_i = oimag + f * ld;
         float* mlo = row_m + kap;                     // X[k]   : ascending lanes, +64 q
         float* rlo = row_r + kap;
         float* ilo = row_i + kap;
-#ifdef MPX_ANA_NOSHIFT
-        const int hoff = M - kap;
-#else
         const int hoff = lane0 ? M - 64 : M - kap;    // X[M-k] : descending lanes, -64 q (lane 0: one block lower)
-#endif
         float* mhi = row_m + hoff;
         float* rhi = row_r + hoff;
         float* ihi = row_i + hoff;
@@ -187,11 +178,6 @@ __global__ __launch_bounds__(kAnaThreads) void k_analysis(const float* __restric
 #ifdef MPX_PROBE_NOSTORE
                 asm volatile("" ::"v"(cm), "v"(cr), "v"(ci));
 #else
-#ifdef MPX_ANA_NOSHIFT
-                mhi[-64 * q] = cm;
-                rhi[-64 * q] = cr;
-                ihi[-64 * q] = ci;
-#else
                 if (q == 0) {
                     if (lane0) {                      // bin M
                         row_m[M] = cm;
@@ -203,7 +189,6 @@ __global__ __launch_bounds__(kAnaThreads) void k_analysis(const float* __restric
                     rhi[-64 * (q - 1)] = lane0 ? cr : hr;
                     ihi[-64 * (q - 1)] = lane0 ? ci : hi_;
                 }
-#endif
 #endif
                 hm = cm;
                 hr = cr;
@@ -217,17 +202,9 @@ __global__ __launch_bounds__(kAnaThreads) void k_analysis(const float* __restric
 #ifdef MPX_PROBE_NOSTORE
             asm volatile("" ::"v"(s2 * r), "v"(xr * r), "v"(xi * r), "v"(hm), "v"(hr), "v"(hi_));
 #else
-#ifdef MPX_ANA_NOSHIFT
-            if (lane0) {
-                row_m[M / 2] = s2 * r;
-                row_r[M / 2] = xr * r;
-                row_i[M / 2] = xi * r;
-            }
-#else
             mhi[-64 * (P / 2 - 1)] = lane0 ? s2 * r : hm;
             rhi[-64 * (P / 2 - 1)] = lane0 ? xr * r : hr;
             ihi[-64 * (P / 2 - 1)] = lane0 ? xi * r : hi_;
-#endif
 #endif
         }
         g = gn;
