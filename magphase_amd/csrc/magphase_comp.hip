@@ -3,7 +3,7 @@
 //   k_mel_unwarp          [F x K] x [K x H] -> exp / identity: la.sp_mel_unwarp and phase_uncompress_type1_mcep as the
 //                         linear maps they are, K <= 64.  fp32 VALU GEMM, A tile broadcast from LDS.
 //   k_noise_stats<P>      per frame: windowed noise frame -> FFT -> sum_k (ln|Ns[k]|)^2, k = 1..N/2-1 (Q10 gain statistics)
-//   k_synth_comp_ola<P>   per chunk of frames: noise FFT (recomputed) + periodic/aperiodic spectrum assembly
+//   k_synth_comp_pair<P>  per chunk of frames: noise FFT (recomputed) + periodic/aperiodic spectrum assembly
 //                         (Appendix A2 steps 9-12) + inverse FFT + anti-ringing window + LDS overlap-add (as k_synth_ola)
 #include "mpx_common.hpp"
 
@@ -562,180 +562,11 @@ struct CompFrameTabs {
 
 // 4 waves per workgroup = one per SIMD: the kernel keeps the noise spectrum, the features and the FFT working set live
 // at once (> 256 VGPRs); with 512 registers per wave nothing spills to scratch (scratch = VMEM = vmcnt stalls).
-constexpr int kCompWaves = 4;
-template <int P>
-constexpr size_t lds_bytes_comp() {
-    return sizeof(float) * (size_t)(P * 64 * 2 + kCompWaves * (P * kXStride + ring_len<P>()));
-}
-
-template <int P>
-__global__ __launch_bounds__(kCompWaves * 64) void k_synth_comp_ola(const float* __restrict__ mag,
-                                                                   const float* __restrict__ real,
-                                                                   const float* __restrict__ imag,
-                                                                   const float* __restrict__ noise,
-                                                                   CompFrameTabs tb,
-                                                                   const float* __restrict__ per_v,
-                                                                   const float* __restrict__ ap_v,
-                                                                   const float* __restrict__ ap_u,
-                                                                   const ChunkDesc* __restrict__ chunks,
-                                                                   const int* __restrict__ slot_off,
-                                                                   const int* __restrict__ slot_chunks, int nslots,
-                                                                   int T, const float2* __restrict__ tw_g,
-                                                                   float* __restrict__ strips, long long ld) {
-    constexpr int M = 64 * P, N = 2 * M, H = M + 1, LB = ilog2(P), R = ring_len<P>();
-    extern __shared__ float smem[];
-    float2* tw = reinterpret_cast<float2*>(smem);
-    const int lane_id = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    float* xbuf = smem + P * 64 * 2 + wave * (P * kXStride + R);
-    float* ring = xbuf + P * kXStride;
-    const unsigned xbuf_byte = 4u * (unsigned)(P * 64 * 2 + rfl(wave) * (P * kXStride + R));
-    for (int i = threadIdx.x; i < P * 64; i += kCompWaves * 64) tw[i] = tw_g[i];
-    __syncthreads();
-
-    float wa_s0, wa_c0, ws_s0, ws_c0;   // analysis-side lane twiddle W_N^kappa and synthesis-side conj(W_N^lane)
-    sincospif(-2.0f * (float)kappa<P>(lane_id) / (float)N, &wa_s0, &wa_c0);
-    sincospif(2.0f * (float)lane_id / (float)N, &ws_s0, &ws_c0);
-    const int wave_u = rfl(wave);
-    const int strip_len = T + N;
-    for (int i = lane_id; i < R; i += 64) ring[i] = 0.0f;
-    wave_sync();
-
-    const int slot = blockIdx.x * kCompWaves + wave_u;
-    if (slot >= nslots) return;
-    for (int wi = slot_off[slot]; wi < slot_off[slot + 1]; ++wi) {
-        const int ci = slot_chunks[wi];
-        const ChunkDesc cd = chunks[ci];
-        float* strip = strips + (long long)ci * strip_len;
-        int flushed = 0;
-        for (int fi = cd.frame_begin; fi < cd.frame_end; ++fi) {
-            int lane = lane_id;
-            float wa_s = wa_s0, wa_c = wa_c0, ws_s = ws_s0, ws_c = ws_c0;
-            asm volatile("" : "+v"(lane), "+v"(wa_s), "+v"(wa_c), "+v"(ws_s), "+v"(ws_c));
-
-            // ---- this frame's features and per-bin curves: ALL loads issued up front, branch-free, so that they share
-            // one memory latency and overlap the noise FFT ("load, then use in the same branch" made the compiler
-            // wait vmcnt(0) once per bin: 32+ serial round trips per frame, measured 70 us per frame).
-            const int voiced = tb.voiced[fi];
-            const float ig = tb.inv_gain[fi];
-            const int r0 = tb.row0[fi], r1 = tb.row1[fi];
-            const float rt = tb.rowt[fi];           // 0 when r0 == r1: the lerp below is then exact
-            FrameFeat<P> f0v, f1v;
-            feat_load<P>(f0v, mag + (long long)r0 * ld, real + (long long)r0 * ld, imag + (long long)r0 * ld, lane);
-            feat_load<P>(f1v, mag + (long long)r1 * ld, real + (long long)r1 * ld, imag + (long long)r1 * ld, lane);
-            const float* apc = voiced ? ap_v : ap_u;   // aperiodic curve of the frame's class (uniform select)
-            const float pvs = voiced ? 1.0f : 0.0f;     // periodic component only in voiced frames
-            float cpv[P], cap[P];
-#pragma unroll
-            for (int j = 0; j < P; ++j) {
-                cpv[j] = per_v[lane + 64 * j];
-                cap[j] = apc[lane + 64 * j];
-            }
-            float cpvM = 0.0f, capM = 0.0f;
-            if (lane == 0) {
-                cpvM = per_v[M];
-                capM = apc[M];
-            }
-
-            // ---- aperiodic source: spectrum of this frame's windowed noise
-            const FrameGeom g = frame_geom(noise, tb.npos[fi], tb.nleft[fi], tb.nright[fi], N);
-            float xr[P], xi[P], nM;
-            noise_spectrum<P>(g, tb.wtype[fi], tw, xbuf, xbuf_byte, lane, wa_c, wa_s, xr, xi, nM);
-            if (P == 16) {   // FFT output lanes hold bins kappa(lane)+64j; the merge below wants bins lane+64j
-                const int src = kappa<P>(lane);   // kappa is an involution: lane l needs the data of lane kappa(l)
-#pragma unroll
-                for (int j = 0; j < P; ++j) {
-                    xr[j] = __shfl(xr[j], src);
-                    xi[j] = __shfl(xi[j], src);
-                }
-                nM = __shfl(nM, src);
-            }
-
-            // ---- spectrum assembly (Appendix A2 steps 9-12), bins k = lane + 64 j
-            const float sgn_scale = ((lane & 1) ? -1.0f : 1.0f) * (0.5f / (float)M);
-#pragma unroll
-            for (int j = 0; j < P; ++j) {
-                // linear interpolation between constant-rate rows (magphase.py:2242-2252); rt == 0 for variable-rate input
-                const float m = fmaf(f1v.m[j] - f0v.m[j], rt, f0v.m[j]);
-                const float a = fmaf(f1v.a[j] - f0v.a[j], rt, f0v.a[j]);
-                const float b = fmaf(f1v.b[j] - f0v.b[j], rt, f0v.b[j]);
-                const float s = a * a + b * b;
-                const float u = (s > 0.0f) ? m * cpv[j] * pvs * __builtin_amdgcn_rsqf(s) : 0.0f;
-                const float apf = m * cap[j] * ig;
-                float vr = fmaf(xr[j], apf, a * u), vi = fmaf(xi[j], apf, b * u);
-                if (j == 0 && lane == 0) {   // DC: X = |X| (magphase.py:958-961)
-                    vr = __builtin_sqrtf(vr * vr + vi * vi);
-                    vi = 0.0f;
-                }
-                xr[j] = vr * sgn_scale;
-                xi[j] = vi * sgn_scale;
-            }
-            float xm = 0.0f;
-            if (lane == 0) {   // Nyquist bin: the noise spectrum is real there; X = |X|
-                const float m = fmaf(f1v.mM - f0v.mM, rt, f0v.mM);
-                const float a = fmaf(f1v.aM - f0v.aM, rt, f0v.aM);
-                const float b = fmaf(f1v.bM - f0v.bM, rt, f0v.bM);
-                const float s = a * a + b * b;
-                const float u = (s > 0.0f) ? m * cpvM * pvs * __builtin_amdgcn_rsqf(s) : 0.0f;
-                const float apf = m * capM * ig;
-                const float vr = fmaf(nM, apf, a * u), vi = b * u;
-                xm = __builtin_sqrtf(vr * vr + vi * vi) * (0.5f / (float)M);   // (-1)^M = +1
-            }
-
-            hermitian_merge<P>(xr, xi, xm, lane, ws_c, ws_s);
-            wave_fft<P, +1>(xr, xi, tw, xbuf, lane);
-
-            // ---- anti-ringing window (magphase.py:969-973, Q14): centred asymmetric Hann, zero outside
-            const int wl = tb.win_l[fi], wr = tb.win_r[fi];
-            const float inv_wl = (wl > 0) ? 1.0f / (float)wl : 1.0f;
-            const float inv_wr = (wr > 0) ? 1.0f / (float)wr : 0.0f;
-            const int kadd = (wl == 0) ? 1 : 0;
-            const int n_lo = N / 2 - wl, n_hi = N / 2 + wr;   // support [n_lo, n_hi]
-
-            const int x = tb.pm_rel[fi] - cd.x0;
-            const int target = x & ~63;
-            if (flushed < target) {
-                flush_ring<R>(ring, strip, flushed, target, strip_len, lane);
-                flushed = target;
-            }
-            wave_sync();
-            {
-                constexpr int RH = R / 2;
-                const int kap = kappa<P>(lane);
-                const int odd = x & 1;
-                float* r0p = ring + (odd ? RH : 0);
-                float* r1p = ring + (odd ? 0 : RH);
-                const int c0 = ((x >> 1) % RH) + kap;
-                const int c1 = (((x + 1) >> 1) % RH) + kap;
-#pragma unroll
-                for (int i = 0; i < P; ++i) {
-                    const int q = brev(i, LB);
-                    // samples n = 2*(kap + 64 q) + e; skip register rows entirely outside the window support
-                    if (128 * q + 127 < n_lo || 128 * q > n_hi) continue;
-                    const int n0 = 2 * (kap + 64 * q);
-                    const int ks0 = n0 - n_lo, ks1 = n0 + 1 - n_lo;
-                    const float w0 = (ks0 >= 0 && n0 <= n_hi) ? half_window(ks0, wl, wl + wr, kadd, inv_wl, inv_wr, 0) : 0.0f;
-                    const float w1 = (ks1 >= 0 && n0 + 1 <= n_hi) ? half_window(ks1, wl, wl + wr, kadd, inv_wl, inv_wr, 0) : 0.0f;
-                    int s0 = c0 + 64 * q;
-                    s0 = (s0 >= RH) ? s0 - RH : s0;
-                    int s1 = c1 + 64 * q;
-                    s1 = (s1 >= RH) ? s1 - RH : s1;
-                    r0p[s0] += xr[i] * w0;
-                    r1p[s1] += xi[i] * w1;
-                }
-            }
-            wave_sync();
-        }
-        flush_ring<R>(ring, strip, flushed, strip_len, strip_len, lane_id);
-        wave_sync();
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
 // Compressed-feature synthesis + PSOLA, pair form: two waves share one LDS ring and alternate over the frames of the
-// pair's chunks (tickets in LDS, exactly as k_synth_ola_pair), 8 waves per CU.  The single-wave form above holds both
-// feature rows, the per-bin curves and the noise FFT at once (466 VGPRs, ONE wave per SIMD: at one instruction per
-// ~5.4 cycles and wave its ~7.5 k instructions per frame are the whole run time).  Here the noise spectrum is
+// pair's chunks (tickets in LDS, exactly as k_synth_ola_pair), 8 waves per CU.  The single-wave form it replaced (git
+// history) held both feature rows, the per-bin curves and the noise FFT at once (466 VGPRs, ONE wave per SIMD: at one
+// instruction per ~5.4 cycles and wave its ~7.5 k instructions per frame were the whole 1.35 ms).  Here the noise spectrum is
 // computed first and the features are folded into it in place, half a spectrum (16 register rows) at a time:
 // 64 + 128 live registers instead of 64 + 262, so two waves fit a SIMD.
 // ---------------------------------------------------------------------------------------------
@@ -1288,11 +1119,7 @@ int mpx_noise_stats(void* stream, int fft_len, const void* tables, const float* 
     return MPX_OK;
 }
 
-#ifdef MPX_COMP_NO_PAIR
-int mpx_synth_comp_slots(void) { return device_cus() * kCompWaves; }
-#else
 int mpx_synth_comp_slots(void) { return device_cus() * kCompPairs; }
-#endif
 
 int mpx_synthesis_compressed_ola(void* stream, int fft_len, const void* tables, const float* mag, const float* real,
                                  const float* imag, const float* noise, const int64_t* noise_pos,
@@ -1315,9 +1142,7 @@ int mpx_synthesis_compressed_ola(void* stream, int fft_len, const void* tables, 
         return fail(MPX_ERR_ARG, "mpx_synthesis_compressed_ola: null pointer%s");
     CompFrameTabs tb{(const long long*)noise_pos, noise_left, noise_right, noise_wtype, voiced, inv_gain,
                      row0, row1, row_t, win_left, win_right, pm_rel};
-    const dim3 grid((n_slots + kCompWaves - 1) / kCompWaves), block(kCompWaves * 64);
     hipStream_t s = (hipStream_t)stream;
-#ifndef MPX_COMP_NO_PAIR
     {
         const dim3 pgrid((n_slots + kCompPairs - 1) / kCompPairs), pblock(kCompPairWaves * 64);
         if (P == 32) {
@@ -1334,20 +1159,6 @@ int mpx_synthesis_compressed_ola(void* stream, int fft_len, const void* tables, 
         MPX_HIP_CHECK(hipGetLastError());
         return MPX_OK;
     }
-#endif
-    if (P == 32) {
-        if (int rc = set_lds(k_synth_comp_ola<32>, lds_bytes_comp<32>())) return rc;
-        hipLaunchKernelGGL(k_synth_comp_ola<32>, grid, block, lds_bytes_comp<32>(), s, mag, real, imag, noise, tb,
-                           per_v, ap_v, ap_u, (const ChunkDesc*)chunks, slot_off, slot_chunks, (int)n_slots,
-                           (int)territory, (const float2*)tables, strips, (long long)ld);
-    } else {
-        if (int rc = set_lds(k_synth_comp_ola<16>, lds_bytes_comp<16>())) return rc;
-        hipLaunchKernelGGL(k_synth_comp_ola<16>, grid, block, lds_bytes_comp<16>(), s, mag, real, imag, noise, tb,
-                           per_v, ap_v, ap_u, (const ChunkDesc*)chunks, slot_off, slot_chunks, (int)n_slots,
-                           (int)territory, (const float2*)tables, strips, (long long)ld);
-    }
-    MPX_HIP_CHECK(hipGetLastError());
-    return MPX_OK;
 }
 
 int mpx_mel_warp(void* stream, int64_t n_frames, int32_t n_bins, const float* mag, const float* real, const float* imag,
