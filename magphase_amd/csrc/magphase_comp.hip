@@ -90,8 +90,8 @@ __global__ __launch_bounds__(256) void k_mel_warp(WarpJobs jobs, long long F, in
                                                   long long ld) {
     __shared__ __attribute__((aligned(16))) float As[kWarpTile][kWarpStride];   // As[kk][f]
     __shared__ __attribute__((aligned(16))) float Ws[kWarpTile][kWarpStride];   // Ws[kk][i]
-    const WarpJob job = jobs.j[blockIdx.z];
-    const long long f0 = (long long)blockIdx.y * kWarpTile;
+    const WarpJob job = jobs.j[blockIdx.y];
+    const long long f0 = (long long)blockIdx.x * kWarpTile;   // row tiles on x: no 65535 limit on the frame count
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const int kk = threadIdx.x & 63, fq = threadIdx.x >> 6;   // staging roles
     float acc[4][4];
@@ -857,8 +857,8 @@ __global__ __launch_bounds__(256) void k_mel_warp_mfma(WarpJobs jobs, int job0, 
     __shared__ __attribute__((aligned(16))) float Ws[kWarpTile][kWarpStride];   // Ws[i][k]
     __shared__ long long s_o0[kWarpTile], s_o1[kWarpTile];   // element offsets of the two input rows of a frame
     __shared__ float s_rt[kWarpTile];
-    const WarpJob job = jobs.j[job0 + blockIdx.z];
-    const long long f0 = (long long)blockIdx.y * kWarpTile;
+    const WarpJob job = jobs.j[job0 + blockIdx.y];
+    const long long f0 = (long long)blockIdx.x * kWarpTile;   // row tiles on x: no 65535 limit on the frame count
     const int kk = threadIdx.x & 63, fq = threadIdx.x >> 6;   // staging roles: bin within the chunk, frame quarter
     const int wave = rfl((int)(threadIdx.x >> 6));
     const int li = kk & 15, g = kk >> 4;                      // fragment roles
@@ -1177,8 +1177,7 @@ int mpx_mel_warp(void* stream, int64_t n_frames, int32_t n_bins, const float* ma
     jobs.j[0] = {mag, w_mag, out_mag, nullptr, (int)mag_dim, 0};
     jobs.j[1] = {real, w_phase, out_real, voiced, (int)phase_dim, 1};
     jobs.j[2] = {imag, w_phase, out_imag, voiced, (int)phase_dim, 1};
-    const dim3 grid(1, (unsigned)((n_frames + kWarpTile - 1) / kWarpTile), 3);
-    if (grid.y > 65535) return fail(MPX_ERR_ARG, "mpx_mel_warp: too many frames per call (max 4194240)%s");
+    const dim3 grid((unsigned)((n_frames + kWarpTile - 1) / kWarpTile), 3);
 #ifdef MPX_WARP_VALU
     hipLaunchKernelGGL(k_mel_warp, grid, dim3(256), 0, (hipStream_t)stream, jobs, (long long)n_frames, (int)n_bins,
                        row0, row1, row_t, (long long)ld);
@@ -1187,7 +1186,7 @@ int mpx_mel_warp(void* stream, int64_t n_frames, int32_t n_bins, const float* ma
     // column-tile count is a template parameter, so it is sized for the wider job.
     {
         const int job0 = 0;
-        const dim3 g2(1, grid.y, 3);
+        const dim3 g2(grid.x, 3);
 #define MPX_WARP_LAUNCH(NT)                                                                                        \
     hipLaunchKernelGGL(k_mel_warp_mfma<NT>, g2, dim3(256), 0, (hipStream_t)stream, jobs, job0, (long long)n_frames, \
                        (int)n_bins, row0, row1, row_t, (long long)ld)
