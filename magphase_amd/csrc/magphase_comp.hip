@@ -848,7 +848,7 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_synth_comp_pair(const f
 // ---------------------------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int NT>   // 16-wide column tiles in use: ceil(nout / 16)
+template <int NT, bool INTERP>   // NT: 16-wide column tiles in use, ceil(nout / 16); INTERP: rows interpolated (row0 given)
 __attribute__((amdgpu_waves_per_eu(4, 4)))   // <= 128 VGPRs: four workgroups (35 KB of LDS each) per CU, measured -5 %
 __global__ __launch_bounds__(256) void k_mel_warp_mfma(WarpJobs jobs, int job0, long long F, int H,
                                                        const int* __restrict__ row0, const int* __restrict__ row1,
@@ -884,7 +884,7 @@ __global__ __launch_bounds__(256) void k_mel_warp_mfma(WarpJobs jobs, int job0, 
         for (int p = 0; p < 16; ++p) {
             const int fl = fq + 4 * p;
             xv[p] = job.x[s_o0[fl] + kc];
-            xw[p] = job.x[s_o1[fl] + kc];
+            if (INTERP) xw[p] = job.x[s_o1[fl] + kc];   // variable-rate input: one row per frame, a third fewer loads
             wv16[p] = job.W[(long long)min(fl, job.nout - 1) * H + kc];
         }
     };
@@ -894,7 +894,7 @@ __global__ __launch_bounds__(256) void k_mel_warp_mfma(WarpJobs jobs, int job0, 
 #pragma unroll
         for (int p = 0; p < 16; ++p) {
             const int fl = fq + 4 * p;
-            const float x = fmaf(xw[p] - xv[p], s_rt[fl], xv[p]);
+            const float x = INTERP ? fmaf(xw[p] - xv[p], s_rt[fl], xv[p]) : xv[p];
             // hardware exp2/log2 (v_exp_f32 / v_log_f32, ~1 ulp): the 1e-7 error is far below the stated tolerance
             // of this (ill-conditioned, unpinned) stage
             const float e = (job.mode == 0) ? x : __expf(x);
@@ -1188,8 +1188,14 @@ int mpx_mel_warp(void* stream, int64_t n_frames, int32_t n_bins, const float* ma
         const int job0 = 0;
         const dim3 g2(grid.x, 3);
 #define MPX_WARP_LAUNCH(NT)                                                                                        \
-    hipLaunchKernelGGL(k_mel_warp_mfma<NT>, g2, dim3(256), 0, (hipStream_t)stream, jobs, job0, (long long)n_frames, \
-                       (int)n_bins, row0, row1, row_t, (long long)ld)
+    do {                                                                                                           \
+        if (row0)                                                                                                  \
+            hipLaunchKernelGGL((k_mel_warp_mfma<NT, true>), g2, dim3(256), 0, (hipStream_t)stream, jobs, job0,     \
+                               (long long)n_frames, (int)n_bins, row0, row1, row_t, (long long)ld);                \
+        else                                                                                                       \
+            hipLaunchKernelGGL((k_mel_warp_mfma<NT, false>), g2, dim3(256), 0, (hipStream_t)stream, jobs, job0,    \
+                               (long long)n_frames, (int)n_bins, row0, row1, row_t, (long long)ld);                \
+    } while (0)
         switch ((std::max(mag_dim, phase_dim) + 15) / 16) {
             case 1: MPX_WARP_LAUNCH(1); break;
             case 2: MPX_WARP_LAUNCH(2); break;
