@@ -849,15 +849,10 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_synth_comp_pair(const f
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int NT, bool INTERP>   // NT: 16-wide column tiles in use, ceil(nout / 16); INTERP: rows interpolated (row0 given)
-__attribute__((amdgpu_waves_per_eu(4, 4)))   // <= 128 VGPRs: four workgroups (35 KB of LDS each) per CU, measured -5 %
-__global__ __launch_bounds__(256) void k_mel_warp_mfma(WarpJobs jobs, int job0, long long F, int H,
-                                                       const int* __restrict__ row0, const int* __restrict__ row1,
-                                                       const float* __restrict__ rowt, long long ld) {
-    __shared__ __attribute__((aligned(16))) float As[kWarpTile][kWarpStride];   // As[f][k]
-    __shared__ __attribute__((aligned(16))) float Ws[kWarpTile][kWarpStride];   // Ws[i][k]
-    __shared__ long long s_o0[kWarpTile], s_o1[kWarpTile];   // element offsets of the two input rows of a frame
-    __shared__ float s_rt[kWarpTile];
-    const WarpJob job = jobs.j[job0 + blockIdx.y];
+__device__ __forceinline__ void mel_warp_block(const WarpJob& job, float (*As)[kWarpStride], float (*Ws)[kWarpStride],
+                                               long long* s_o0, long long* s_o1, float* s_rt, long long F, int H,
+                                               const int* __restrict__ row0, const int* __restrict__ row1,
+                                               const float* __restrict__ rowt, long long ld) {
     const long long f0 = (long long)blockIdx.x * kWarpTile;   // row tiles on x: no 65535 limit on the frame count
     const int kk = threadIdx.x & 63, fq = threadIdx.x >> 6;   // staging roles: bin within the chunk, frame quarter
     const int wave = rfl((int)(threadIdx.x >> 6));
@@ -937,6 +932,22 @@ __global__ __launch_bounds__(256) void k_mel_warp_mfma(WarpJobs jobs, int job0, 
             job.out[f * job.nout + i] = y;
         }
     }
+}
+
+// One launch for the three jobs (separate launches end in a half-empty last round of workgroups); the magnitude job
+// (blockIdx.y == 0) and the two phase jobs get their own column-tile count (60 outputs -> 4 tiles, 45 -> 3: a quarter
+// fewer MFMAs on two thirds of the workgroups).
+template <int NTM, int NTP, bool INTERP>
+__attribute__((amdgpu_waves_per_eu(4, 4)))   // <= 128 VGPRs: four workgroups (35 KB of LDS each) per CU, measured -5 %
+__global__ __launch_bounds__(256) void k_mel_warp_mfma(WarpJobs jobs, long long F, int H, const int* __restrict__ row0,
+                                                       const int* __restrict__ row1, const float* __restrict__ rowt,
+                                                       long long ld) {
+    __shared__ __attribute__((aligned(16))) float As[kWarpTile][kWarpStride];   // As[f][k]
+    __shared__ __attribute__((aligned(16))) float Ws[kWarpTile][kWarpStride];   // Ws[i][k]
+    __shared__ long long s_o0[kWarpTile], s_o1[kWarpTile];   // element offsets of the two input rows of a frame
+    __shared__ float s_rt[kWarpTile];
+    if (blockIdx.y == 0) mel_warp_block<NTM, INTERP>(jobs.j[0], As, Ws, s_o0, s_o1, s_rt, F, H, row0, row1, rowt, ld);
+    else mel_warp_block<NTP, INTERP>(jobs.j[blockIdx.y], As, Ws, s_o0, s_o1, s_rt, F, H, row0, row1, rowt, ld);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1182,26 +1193,32 @@ int mpx_mel_warp(void* stream, int64_t n_frames, int32_t n_bins, const float* ma
     hipLaunchKernelGGL(k_mel_warp, grid, dim3(256), 0, (hipStream_t)stream, jobs, (long long)n_frames, (int)n_bins,
                        row0, row1, row_t, (long long)ld);
 #else
-    // ONE launch for the three jobs (separate launches end in a half-empty last round of workgroups); the
-    // column-tile count is a template parameter, so it is sized for the wider job.
     {
-        const int job0 = 0;
         const dim3 g2(grid.x, 3);
-#define MPX_WARP_LAUNCH(NT)                                                                                        \
+        const int ntm = ((int)mag_dim + 15) / 16, ntp = ((int)phase_dim + 15) / 16;
+#define MPX_WARP_LAUNCH(NTM, NTP)                                                                                  \
     do {                                                                                                           \
         if (row0)                                                                                                  \
-            hipLaunchKernelGGL((k_mel_warp_mfma<NT, true>), g2, dim3(256), 0, (hipStream_t)stream, jobs, job0,     \
+            hipLaunchKernelGGL((k_mel_warp_mfma<NTM, NTP, true>), g2, dim3(256), 0, (hipStream_t)stream, jobs,     \
                                (long long)n_frames, (int)n_bins, row0, row1, row_t, (long long)ld);                \
         else                                                                                                       \
-            hipLaunchKernelGGL((k_mel_warp_mfma<NT, false>), g2, dim3(256), 0, (hipStream_t)stream, jobs, job0,    \
+            hipLaunchKernelGGL((k_mel_warp_mfma<NTM, NTP, false>), g2, dim3(256), 0, (hipStream_t)stream, jobs,    \
                                (long long)n_frames, (int)n_bins, row0, row1, row_t, (long long)ld);                \
     } while (0)
-        switch ((std::max(mag_dim, phase_dim) + 15) / 16) {
-            case 1: MPX_WARP_LAUNCH(1); break;
-            case 2: MPX_WARP_LAUNCH(2); break;
-            case 3: MPX_WARP_LAUNCH(3); break;
-            default: MPX_WARP_LAUNCH(4); break;
+#define MPX_WARP_ROW(NTM)                       \
+    switch (ntp) {                              \
+        case 1: MPX_WARP_LAUNCH(NTM, 1); break; \
+        case 2: MPX_WARP_LAUNCH(NTM, 2); break; \
+        case 3: MPX_WARP_LAUNCH(NTM, 3); break; \
+        default: MPX_WARP_LAUNCH(NTM, 4); break; \
+    }
+        switch (ntm) {
+            case 1: MPX_WARP_ROW(1) break;
+            case 2: MPX_WARP_ROW(2) break;
+            case 3: MPX_WARP_ROW(3) break;
+            default: MPX_WARP_ROW(4) break;
         }
+#undef MPX_WARP_ROW
 #undef MPX_WARP_LAUNCH
     }
 #endif
