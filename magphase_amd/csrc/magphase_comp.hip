@@ -880,7 +880,7 @@ __device__ __forceinline__ void mel_warp_block(const WarpJob& job, float (*As)[k
             const int fl = fq + 4 * p;
             xv[p] = job.x[s_o0[fl] + kc];
             if (INTERP) xw[p] = job.x[s_o1[fl] + kc];   // variable-rate input: one row per frame, a third fewer loads
-            wv16[p] = job.W[(long long)min(fl, job.nout - 1) * H + kc];
+            if (p < 4 * NT) wv16[p] = job.W[(long long)min(fl, job.nout - 1) * H + kc];   // W rows of the tiles in use
         }
     };
     fetch(0);
@@ -895,7 +895,7 @@ __device__ __forceinline__ void mel_warp_block(const WarpJob& job, float (*As)[k
             const float e = (job.mode == 0) ? x : __expf(x);
             const float v = __logf(fmaf(e, e, 1.0e-8f));
             As[fl][kk] = (kok && f0 + fl < F) ? v : 0.0f;
-            Ws[fl][kk] = (kok && fl < job.nout) ? wv16[p] : 0.0f;
+            if (p < 4 * NT) Ws[fl][kk] = (kok && fl < job.nout) ? wv16[p] : 0.0f;
         }
         __syncthreads();
         if (k0 + kWarpTile < H) fetch(k0 + kWarpTile);
