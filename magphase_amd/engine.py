@@ -104,6 +104,22 @@ class Engine:
                 drain(i)
         return out
 
+    def host_staging(self, n_floats):
+        """float32 numpy view [n_floats] of a page-locked staging buffer (grown on demand, reused by every plan)."""
+        torch = _torch()
+        cur = getattr(self, "_stage_up", None)
+        if cur is None or cur.numel() < n_floats:
+            self._stage_up = cur = torch.empty(max(int(n_floats), 1), dtype=torch.float32).pin_memory()
+        return cur.numpy()[:int(n_floats)]
+
+    def upload_staged(self, n_floats):
+        """The first n_floats of the staging buffer -> a fresh device tensor (one DMA from pinned memory)."""
+        torch = _torch()
+        with torch.cuda.device(self.device):
+            t = self._stage_up[:int(n_floats)].to(self.device, non_blocking=True)
+            torch.cuda.current_stream(self.device).synchronize()   # the buffer is free for the next plan
+        return t
+
     def to_device_pinned(self, arr, dtype):
         """Host array -> device tensor through a page-locked copy (async H2D on the current stream)."""
         torch = _torch()
@@ -339,14 +355,21 @@ class LosslessAnalysisPlan:
 
     def __init__(self, engine, utts, fft_len=None):
         self.engine = engine
-        sigs, pos, left, right = [], [], [], []
+        pos, left, right = [], [], []
         self.v_shift, self.v_f0, self.fs, self.n_frames, self.n_smpls, self.v_pm = [], [], [], [], [], []
+        # the samples of all utterances go straight into ONE float32 buffer (page-locked when the engine has one):
+        # int16 PCM * 2^-15 and float64 -> float32 are each a single pass, no per-utterance temporaries, no concatenate
+        total = int(sum(np.shape(u[0])[0] for u in utts))
+        staged = hasattr(engine, "host_staging")
+        buf = engine.host_staging(total) if staged else np.empty(total, dtype=np.float32)
         off = 0
         for (v_sig, fs, v_pm_sec, v_voi) in utts:
             v_sig = np.asarray(v_sig)
-            if v_sig.dtype == np.int16:
-                v_sig = v_sig.astype(np.float32) / np.float32(32768.0)
             n = v_sig.shape[0]
+            if v_sig.dtype == np.int16:
+                np.multiply(v_sig, np.float32(1.0 / 32768.0), out=buf[off:off + n])   # exact: == astype(f32) / 32768
+            else:
+                buf[off:off + n] = v_sig
             N = fft_len if fft_len is not None else hm.define_fft_len(fs)
             if not hasattr(self, "fft_len"):
                 self.fft_len = N
@@ -354,7 +377,6 @@ class LosslessAnalysisPlan:
                 raise ValueError("all utterances of a plan must share fft_len (bucket by sample rate)")
             pm_sec, voi = hm.clean_epochs(v_pm_sec, v_voi, check_len_smpls=n, fs=fs)
             pm, lft, rgt = hm.frame_bounds(pm_sec * fs, n)
-            sigs.append(v_sig.astype(np.float32, copy=False))
             pos.append(pm + off)
             left.append(lft)
             right.append(rgt)
@@ -369,7 +391,7 @@ class LosslessAnalysisPlan:
         self.frame_off = np.concatenate(([0], np.cumsum(self.n_frames))).astype(np.int64)
         self.long_frame_lens = [(l + r + 1)[(l + r + 1) > self.fft_len].tolist() for l, r in zip(left, right)]
         e = engine
-        self.sig = e.to_device(np.concatenate(sigs) if sigs else np.zeros(0), np.float32)
+        self.sig = e.upload_staged(total) if staged else e.to_device(buf, np.float32)
         self.pos = e.to_device(np.concatenate(pos) if pos else np.zeros(0), np.int64)
         self.left = e.to_device(np.concatenate(left) if left else np.zeros(0), np.int32)
         self.right = e.to_device(np.concatenate(right) if right else np.zeros(0), np.int32)
