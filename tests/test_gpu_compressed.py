@@ -218,3 +218,29 @@ def test_device_output_hpf_matches_lfilter(mp):
         for u, x in enumerate(sigs):
             ref = signal.lfilter(b_, a_, x.astype(np.float64))
             assert np.max(np.abs(y[off[u]:off[u + 1]] - ref)) <= 1e-6 * max(1.0, np.max(np.abs(ref)))
+
+
+@pytest.mark.parametrize("fs", [44100, 22050])
+def test_other_sample_rates_match_oracle(mp, orc, fs):
+    """fs = 44.1 / 22.05 kHz (alpha 0.76 / 0.65, FFT 4096 / 2048, the reference's 'untuned crossfade' warning): lossless
+    and low-dimensional paths against the oracle."""
+    from magphase_amd import synthetic as syn
+    pcm, pm, voi = syn.make_utterance(90 + fs % 7, dur_s=0.8, fs=fs)
+    x = syn.pcm_to_float(pcm)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        al = mp.analysis_lossless_from_epochs(x, fs, pm, voi)
+        ol = orc.analysis_lossless_from_epochs(x, fs, pm, voi)
+        assert np.array_equal(al[5], ol[5]) and np.array_equal(al[3], ol[3], equal_nan=True)
+        peak = np.max(ol[0], axis=1, keepdims=True)
+        assert np.max(np.abs(al[0] - ol[0]) / peak) <= 4e-6
+        a = mp.analysis_compressed_batch([(x, fs, pm, voi)], mag_dim=60, phase_dim=45)[0]
+        o = orc.analysis_compressed_from_epochs(x, fs, pm, voi, mag_dim=60, phase_dim=45)
+        for k in range(3):
+            assert a[k].shape == o[k].shape and np.max(np.abs(a[k] - o[k])) < WARP_TOL
+        assert a[6] == o[6] == (4096 if fs == 44100 else 2048)
+        np.random.seed(5)
+        v = mp.synthesis_from_compressed(o[0], o[1], o[2], o[3], fs)
+        np.random.seed(5)
+        ref = orc.synthesis_from_compressed(o[0], o[1], o[2], o[3], fs)
+    assert v.shape == ref.shape and np.max(np.abs(v - ref)) <= COMP_PCM_TOL * max(1.0, np.max(np.abs(ref)))
