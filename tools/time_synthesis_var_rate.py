@@ -18,7 +18,9 @@ with warnings.catch_warnings():
     warnings.simplefilter("ignore")
     res = mp.analysis_compressed_batch(utts, mag_dim=60, phase_dim=45, b_const_rate=False)
 np.random.seed(0)
-plan = CompressedSynthesisPlan(eng, [(r[0], r[1], r[2], r[3]) for r in res], 48000, b_const_rate=False, post_filter=True)
+ppt = os.environ.get("PER_PHASE", "magphase")   # magphase | min_phase | linear
+plan = CompressedSynthesisPlan(eng, [(r[0], r[1], r[2], r[3]) for r in res], 48000, b_const_rate=False, post_filter=True,
+                               per_phase_type=ppt)
 for _ in range(3):
     plan.run()
 torch.cuda.synchronize()
@@ -28,5 +30,5 @@ for _ in range(20):
     plan.run()
 ev[1].record()
 torch.cuda.synchronize()
-print("variable-rate synthesis_from_compressed (+ post-filter), %d frames: %.3f ms per batch" %
-      (plan.total_frames, ev[0].elapsed_time(ev[1]) / 20))
+print("variable-rate synthesis_from_compressed (+ post-filter, per_phase_type=%s), %d frames: %.3f ms per batch" %
+      (ppt, plan.total_frames, ev[0].elapsed_time(ev[1]) / 20))
