@@ -14,6 +14,11 @@ from oracle.gen_golden import proj
 from magphase_amd import synthetic as syn
 
 TOL = 1e-12
+# Synthesised WAVEFORMS: bit-identical on the machine that generated the goldens (the build container); on another CPU
+# the BLAS / FFT builds pick different SIMD kernels, and the last-bit differences of the unwarp matrix products are
+# amplified by exp(), the gain normalisation and the recursive output high-pass: 2.3e-8 of peak was observed on the
+# MI355X box's host.  Still 3 orders tighter than the fp32 device tolerances these waveforms are the oracle for.
+WAVE_TOL = 1e-6
 
 
 def _close(a, b, tol=TOL):
@@ -113,13 +118,13 @@ def test_g5_generation_from_predicted(golden_dir):
         np.random.seed(seed)
         v, dbg = orc.synthesis_from_compressed(pf, m_real, m_imag, v_lf0, 48000, b_out_hpf=hpf, return_debug=True)
         assert np.array_equal(dbg["v_shift"], g["v_shift"])
-        _close(v, g["syn_pf_hpf%d" % int(hpf)])
+        _close(v, g["syn_pf_hpf%d" % int(hpf)], WAVE_TOL)
     np.random.seed(seed)
     _close(orc.synthesis_from_compressed(m_mag, m_real, m_imag, v_lf0, 48000, per_phase_type="min_phase"),
-           g["syn_nopf_minphase"])
+           g["syn_nopf_minphase"], WAVE_TOL)
     np.random.seed(seed)
     _close(orc.synthesis_from_compressed(m_mag, m_real, m_imag, v_lf0, 48000, b_voi_ap_win=False),
-           g["syn_nopf_novoiwin"])
+           g["syn_nopf_novoiwin"], WAVE_TOL)
 
 
 def test_g7_const_rate_tables(golden_dir):
@@ -157,4 +162,4 @@ def test_g8_compressed_analysis_unpinned_mcep(golden_dir):
         if tag == "cr45":
             np.random.seed(int(g["cr45_seed"]))
             v = orc.synthesis_from_compressed(r[0], r[1], r[2], r[3], fs, b_const_rate=True, b_out_hpf=False)
-            _close(v, g["cr45_syn"])
+            _close(v, g["cr45_syn"], WAVE_TOL)
