@@ -52,9 +52,13 @@ def test_shard_by_cost_partitions_and_balances():
 def test_two_rank_gloo_run_matches_single_process(tmp_path):
     script = tmp_path / "worker.py"
     script.write_text(WORKER % {"root": ROOT})
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29617", OMP_NUM_THREADS="1")
+    import socket
+    with socket.socket() as sk:   # a free rendezvous port (a fixed one can be taken by a parallel run)
+        sk.bind(("127.0.0.1", 0))
+        port = str(sk.getsockname()[1])
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, OMP_NUM_THREADS="1")
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                          "--master-addr", "127.0.0.1", "--master-port", "29617", str(script)],
+                          "--master-addr", "127.0.0.1", "--master-port", port, str(script)],
                          capture_output=True, text=True, env=env, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     import json
