@@ -87,8 +87,8 @@ def cpu_baseline(utts, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", default="lossless", choices=["lossless", "lowdim"],
                     help="lossless = BASELINE configs[1] (the metric; default); lowdim = configs[2]: compressed "
