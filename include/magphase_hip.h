@@ -10,7 +10,7 @@
  *   - every pointer is a DEVICE pointer unless the name ends in _host; the caller owns all buffers
  *     (PyTorch-ROCm tensors are only the allocator); nothing is allocated or freed here;
  *   - `stream` is a hipStream_t (passed as void*); all work is enqueued on it, nothing synchronises;
- *   - fft_len N is 4096 or 2048; H = N/2+1; feature matrices are row-major float32 [F x H];
+ *   - fft_len N is 4096, 2048 or 1024; H = N/2+1; feature matrices are row-major float32 [F x H];
  *   - return 0 on success, <0 on error (text via mpx_last_error()); re-entrant per stream.
  */
 #ifndef MAGPHASE_HIP_H

@@ -498,7 +498,7 @@ __global__ __launch_bounds__(kThreads) void k_min_phase(const float* __restrict_
             re[brev(i, LB)] = xr[i];
             im[brev(i, LB)] = xi[i];
         }
-        if (P == 16) {
+        if (P != 32) {
             const int src = kappa<P>(lane);
 #pragma unroll
             for (int j = 0; j < P; ++j) {
@@ -680,7 +680,7 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_synth_comp_pair(const f
         {
             staged_wait<0>();
             noise_spectrum<P, true>(g, tb.wtype[fi], tw, xbuf, xbuf_byte, lane, wa_c, wa_s, xr, xi, nM);
-            if (P == 16) {   // FFT output lanes hold bins kappa(lane)+64j; everything below wants bins lane+64j
+            if (P != 32) {   // FFT output lanes hold bins kappa(lane)+64j; everything below wants bins lane+64j
                 const int src = kappa<P>(lane);
 #pragma unroll
                 for (int j = 0; j < P; ++j) {
@@ -1120,7 +1120,7 @@ int mpx_noise_stats(void* stream, int fft_len, const void* tables, const float* 
                     const int32_t* frame_left, const int32_t* frame_right, const int32_t* frame_wtype,
                     int64_t n_frames, float* out_sum) {
     const int P = p_of(fft_len);
-    if (!P) return fail(MPX_ERR_ARG, "mpx_noise_stats: fft_len must be 2048 or 4096%s");
+    if (!P) return fail(MPX_ERR_ARG, "mpx_noise_stats: fft_len must be 1024, 2048 or 4096%s");
     if (n_frames < 0) return fail(MPX_ERR_ARG, "mpx_noise_stats: negative n_frames%s");
     if (n_frames == 0) return MPX_OK;
     if (!tables || !noise || !frame_pos || !frame_left || !frame_right || !frame_wtype || !out_sum)
@@ -1131,9 +1131,13 @@ int mpx_noise_stats(void* stream, int fft_len, const void* tables, const float* 
         if (int rc = set_lds(k_noise_stats<32>, lds_bytes_ana<32>())) return rc;
         hipLaunchKernelGGL(k_noise_stats<32>, grid, block, lds_bytes_ana<32>(), s, noise, (const long long*)frame_pos,
                            frame_left, frame_right, frame_wtype, (long long)n_frames, (const float2*)tables, out_sum);
-    } else {
+    } else if (P == 16) {
         if (int rc = set_lds(k_noise_stats<16>, lds_bytes_ana<16>())) return rc;
         hipLaunchKernelGGL(k_noise_stats<16>, grid, block, lds_bytes_ana<16>(), s, noise, (const long long*)frame_pos,
+                           frame_left, frame_right, frame_wtype, (long long)n_frames, (const float2*)tables, out_sum);
+    } else {
+        if (int rc = set_lds(k_noise_stats<8>, lds_bytes_ana<8>())) return rc;
+        hipLaunchKernelGGL(k_noise_stats<8>, grid, block, lds_bytes_ana<8>(), s, noise, (const long long*)frame_pos,
                            frame_left, frame_right, frame_wtype, (long long)n_frames, (const float2*)tables, out_sum);
     }
     MPX_HIP_CHECK(hipGetLastError());
@@ -1152,7 +1156,7 @@ int mpx_synthesis_compressed_ola(void* stream, int fft_len, const void* tables, 
                                  const int32_t* slot_off, const int32_t* slot_chunks, int32_t n_slots,
                                  int32_t territory, float* strips, int64_t ld) {
     const int P = p_of(fft_len);
-    if (!P) return fail(MPX_ERR_ARG, "mpx_synthesis_compressed_ola: fft_len must be 2048 or 4096%s");
+    if (!P) return fail(MPX_ERR_ARG, "mpx_synthesis_compressed_ola: fft_len must be 1024, 2048 or 4096%s");
     if (n_chunks < 0 || n_slots < 0) return fail(MPX_ERR_ARG, "mpx_synthesis_compressed_ola: negative count%s");
     if (territory < fft_len / 2 || (territory % 64) != 0)
         return fail(MPX_ERR_ARG, "mpx_synthesis_compressed_ola: territory must be a multiple of 64 and >= fft_len/2%s");
@@ -1171,9 +1175,14 @@ int mpx_synthesis_compressed_ola(void* stream, int fft_len, const void* tables, 
             hipLaunchKernelGGL(k_synth_comp_pair<32>, pgrid, pblock, lds_bytes_comp_pair<32>(), s, mag, real, imag, noise,
                                tb, per_v, ap_v, ap_u, (const ChunkDesc*)chunks, slot_off, slot_chunks, (int)n_slots,
                                (int)territory, (const float2*)tables, strips, (long long)ld);
-        } else {
+        } else if (P == 16) {
             if (int rc = set_lds(k_synth_comp_pair<16>, lds_bytes_comp_pair<16>())) return rc;
             hipLaunchKernelGGL(k_synth_comp_pair<16>, pgrid, pblock, lds_bytes_comp_pair<16>(), s, mag, real, imag, noise,
+                               tb, per_v, ap_v, ap_u, (const ChunkDesc*)chunks, slot_off, slot_chunks, (int)n_slots,
+                               (int)territory, (const float2*)tables, strips, (long long)ld);
+        } else {
+            if (int rc = set_lds(k_synth_comp_pair<8>, lds_bytes_comp_pair<8>())) return rc;
+            hipLaunchKernelGGL(k_synth_comp_pair<8>, pgrid, pblock, lds_bytes_comp_pair<8>(), s, mag, real, imag, noise,
                                tb, per_v, ap_v, ap_u, (const ChunkDesc*)chunks, slot_off, slot_chunks, (int)n_slots,
                                (int)territory, (const float2*)tables, strips, (long long)ld);
         }
@@ -1240,7 +1249,7 @@ int mpx_min_phase(void* stream, int fft_len, const void* tables, const float* ma
                   const int32_t* row1, const float* row_t, int64_t n_frames, float* out_mag, float* out_real,
                   float* out_imag, int64_t ld) {
     const int P = p_of(fft_len);
-    if (!P) return fail(MPX_ERR_ARG, "mpx_min_phase: fft_len must be 2048 or 4096%s");
+    if (!P) return fail(MPX_ERR_ARG, "mpx_min_phase: fft_len must be 1024, 2048 or 4096%s");
     if (n_frames < 0) return fail(MPX_ERR_ARG, "mpx_min_phase: negative n_frames%s");
     if (n_frames == 0) return MPX_OK;
     if (!tables || !mag || !row0 || !row1 || !row_t || !out_mag || !out_real || !out_imag)
@@ -1251,9 +1260,13 @@ int mpx_min_phase(void* stream, int fft_len, const void* tables, const float* ma
         if (int rc = set_lds(k_min_phase<32>, lds_bytes<32>())) return rc;
         hipLaunchKernelGGL(k_min_phase<32>, grid, block, lds_bytes<32>(), s, mag, row0, row1, row_t,
                            (long long)n_frames, (const float2*)tables, out_mag, out_real, out_imag, (long long)ld);
-    } else {
+    } else if (P == 16) {
         if (int rc = set_lds(k_min_phase<16>, lds_bytes<16>())) return rc;
         hipLaunchKernelGGL(k_min_phase<16>, grid, block, lds_bytes<16>(), s, mag, row0, row1, row_t,
+                           (long long)n_frames, (const float2*)tables, out_mag, out_real, out_imag, (long long)ld);
+    } else {
+        if (int rc = set_lds(k_min_phase<8>, lds_bytes<8>())) return rc;
+        hipLaunchKernelGGL(k_min_phase<8>, grid, block, lds_bytes<8>(), s, mag, row0, row1, row_t,
                            (long long)n_frames, (const float2*)tables, out_mag, out_real, out_imag, (long long)ld);
     }
     MPX_HIP_CHECK(hipGetLastError());

@@ -529,7 +529,7 @@ size_t mpx_tables_bytes(int fft_len) {
 
 int mpx_tables_init(void* stream, int fft_len, void* tables) {
     const int P = p_of(fft_len);
-    if (!P) return fail(MPX_ERR_ARG, "mpx_tables_init: fft_len must be 2048 or 4096%s");
+    if (!P) return fail(MPX_ERR_ARG, "mpx_tables_init: fft_len must be 1024, 2048 or 4096%s");
     if (!tables) return fail(MPX_ERR_ARG, "mpx_tables_init: null tables%s");
     const int M = 64 * P;
     std::vector<float> h(2 * 64 * (size_t)P);
@@ -555,7 +555,7 @@ int mpx_analysis_frames(void* stream, int fft_len, const void* tables, const flo
                         const int32_t* frame_left, const int32_t* frame_right, int64_t n_frames, float* out_mag,
                         float* out_real, float* out_imag, int64_t ld) {
     const int P = p_of(fft_len);
-    if (!P) return fail(MPX_ERR_ARG, "mpx_analysis_frames: fft_len must be 2048 or 4096%s");
+    if (!P) return fail(MPX_ERR_ARG, "mpx_analysis_frames: fft_len must be 1024, 2048 or 4096%s");
     if (n_frames < 0) return fail(MPX_ERR_ARG, "mpx_analysis_frames: negative n_frames%s");
     if (ld < fft_len / 2 + 1) return fail(MPX_ERR_ARG, "mpx_analysis_frames: ld < fft_len/2 + 1%s");
     if (n_frames == 0) return MPX_OK;
@@ -568,9 +568,14 @@ int mpx_analysis_frames(void* stream, int fft_len, const void* tables, const flo
         hipLaunchKernelGGL(k_analysis<32>, grid, block, lds_bytes_ana<32>(), s, sig, (const long long*)frame_pos,
                            frame_left, frame_right, (long long)n_frames, (const float2*)tables, out_mag, out_real,
                            out_imag, (long long)ld);
-    } else {
+    } else if (P == 16) {
         if (int rc = set_lds(k_analysis<16>, lds_bytes_ana<16>())) return rc;
         hipLaunchKernelGGL(k_analysis<16>, grid, block, lds_bytes_ana<16>(), s, sig, (const long long*)frame_pos,
+                           frame_left, frame_right, (long long)n_frames, (const float2*)tables, out_mag, out_real,
+                           out_imag, (long long)ld);
+    } else {
+        if (int rc = set_lds(k_analysis<8>, lds_bytes_ana<8>())) return rc;
+        hipLaunchKernelGGL(k_analysis<8>, grid, block, lds_bytes_ana<8>(), s, sig, (const long long*)frame_pos,
                            frame_left, frame_right, (long long)n_frames, (const float2*)tables, out_mag, out_real,
                            out_imag, (long long)ld);
     }
@@ -581,7 +586,7 @@ int mpx_analysis_frames(void* stream, int fft_len, const void* tables, const flo
 int mpx_synthesis_lossless_frames(void* stream, int fft_len, const void* tables, const float* mag, const float* real,
                                   const float* imag, int64_t n_frames, float* frames_out, int64_t ld) {
     const int P = p_of(fft_len);
-    if (!P) return fail(MPX_ERR_ARG, "mpx_synthesis_lossless_frames: fft_len must be 2048 or 4096%s");
+    if (!P) return fail(MPX_ERR_ARG, "mpx_synthesis_lossless_frames: fft_len must be 1024, 2048 or 4096%s");
     if (n_frames < 0) return fail(MPX_ERR_ARG, "mpx_synthesis_lossless_frames: negative n_frames%s");
     if (ld < fft_len / 2 + 1) return fail(MPX_ERR_ARG, "mpx_synthesis_lossless_frames: ld < fft_len/2 + 1%s");
     if (n_frames == 0) return MPX_OK;
@@ -593,9 +598,13 @@ int mpx_synthesis_lossless_frames(void* stream, int fft_len, const void* tables,
         if (int rc = set_lds(k_synth_lossless<32>, lds_bytes<32>())) return rc;
         hipLaunchKernelGGL(k_synth_lossless<32>, grid, block, lds_bytes<32>(), s, mag, real, imag,
                            (long long)n_frames, (const float2*)tables, frames_out, (long long)ld);
-    } else {
+    } else if (P == 16) {
         if (int rc = set_lds(k_synth_lossless<16>, lds_bytes<16>())) return rc;
         hipLaunchKernelGGL(k_synth_lossless<16>, grid, block, lds_bytes<16>(), s, mag, real, imag,
+                           (long long)n_frames, (const float2*)tables, frames_out, (long long)ld);
+    } else {
+        if (int rc = set_lds(k_synth_lossless<8>, lds_bytes<8>())) return rc;
+        hipLaunchKernelGGL(k_synth_lossless<8>, grid, block, lds_bytes<8>(), s, mag, real, imag,
                            (long long)n_frames, (const float2*)tables, frames_out, (long long)ld);
     }
     MPX_HIP_CHECK(hipGetLastError());
@@ -605,7 +614,7 @@ int mpx_synthesis_lossless_frames(void* stream, int fft_len, const void* tables,
 int mpx_ola_gather(void* stream, int fft_len, const float* frames, int32_t n_utts, const int32_t* utt_frame_off,
                    const int32_t* pm_rel, const int32_t* out_start, const int64_t* out_off, int64_t max_out_len,
                    float* pcm_out) {
-    if (!p_of(fft_len)) return fail(MPX_ERR_ARG, "mpx_ola_gather: fft_len must be 2048 or 4096%s");
+    if (!p_of(fft_len)) return fail(MPX_ERR_ARG, "mpx_ola_gather: fft_len must be 1024, 2048 or 4096%s");
     if (n_utts < 0 || max_out_len < 0) return fail(MPX_ERR_ARG, "mpx_ola_gather: negative size%s");
     if (n_utts == 0 || max_out_len == 0) return MPX_OK;
     if (!frames || !utt_frame_off || !pm_rel || !out_start || !out_off || !pcm_out)
@@ -625,7 +634,7 @@ int mpx_synthesis_lossless_ola(void* stream, int fft_len, const void* tables, co
                                const int32_t* slot_chunks, int32_t n_slots, const int32_t* pm_rel,
                                int32_t territory, float* strips, int64_t ld) {
     const int P = p_of(fft_len);
-    if (!P) return fail(MPX_ERR_ARG, "mpx_synthesis_lossless_ola: fft_len must be 2048 or 4096%s");
+    if (!P) return fail(MPX_ERR_ARG, "mpx_synthesis_lossless_ola: fft_len must be 1024, 2048 or 4096%s");
     if (n_chunks < 0 || n_slots < 0) return fail(MPX_ERR_ARG, "mpx_synthesis_lossless_ola: negative count%s");
     if (ld < fft_len / 2 + 1) return fail(MPX_ERR_ARG, "mpx_synthesis_lossless_ola: ld < fft_len/2 + 1%s");
     if (territory < fft_len / 2 || (territory % 64) != 0)
@@ -641,9 +650,14 @@ int mpx_synthesis_lossless_ola(void* stream, int fft_len, const void* tables, co
             hipLaunchKernelGGL(k_synth_ola_pair<32>, grid, block, lds_bytes_pair<32>(), s, mag, real, imag,
                                (const ChunkDesc*)chunks, slot_off, slot_chunks, (int)n_slots, pm_rel, (int)territory,
                                (const float2*)tables, strips, (long long)ld);
-        } else {
+        } else if (P == 16) {
             if (int rc = set_lds(k_synth_ola_pair<16>, lds_bytes_pair<16>())) return rc;
             hipLaunchKernelGGL(k_synth_ola_pair<16>, grid, block, lds_bytes_pair<16>(), s, mag, real, imag,
+                               (const ChunkDesc*)chunks, slot_off, slot_chunks, (int)n_slots, pm_rel, (int)territory,
+                               (const float2*)tables, strips, (long long)ld);
+        } else {
+            if (int rc = set_lds(k_synth_ola_pair<8>, lds_bytes_pair<8>())) return rc;
+            hipLaunchKernelGGL(k_synth_ola_pair<8>, grid, block, lds_bytes_pair<8>(), s, mag, real, imag,
                                (const ChunkDesc*)chunks, slot_off, slot_chunks, (int)n_slots, pm_rel, (int)territory,
                                (const float2*)tables, strips, (long long)ld);
         }
@@ -655,7 +669,7 @@ int mpx_synthesis_lossless_ola(void* stream, int fft_len, const void* tables, co
 int mpx_ola_fixup(void* stream, int fft_len, int32_t territory, const float* strips, int32_t n_utts,
                   const int32_t* utt_chunk_off, const int32_t* strip_id, const int32_t* out_start,
                   const int64_t* out_off, int32_t max_territories, float* pcm_out) {
-    if (!p_of(fft_len)) return fail(MPX_ERR_ARG, "mpx_ola_fixup: fft_len must be 2048 or 4096%s");
+    if (!p_of(fft_len)) return fail(MPX_ERR_ARG, "mpx_ola_fixup: fft_len must be 1024, 2048 or 4096%s");
     if (n_utts < 0 || max_territories < 0) return fail(MPX_ERR_ARG, "mpx_ola_fixup: negative size%s");
     if (territory < fft_len / 2 || (territory % 64) != 0)
         return fail(MPX_ERR_ARG, "mpx_ola_fixup: territory must be a multiple of 64 and >= fft_len/2%s");

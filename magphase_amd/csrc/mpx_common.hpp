@@ -259,7 +259,7 @@ struct ChunkDesc {
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
-inline int p_of(int fft_len) { return fft_len == 4096 ? 32 : (fft_len == 2048 ? 16 : 0); }
+inline int p_of(int fft_len) { return fft_len == 4096 ? 32 : (fft_len == 2048 ? 16 : (fft_len == 1024 ? 8 : 0)); }
 
 // Compute units of the current device (cached per device: hipGetDeviceProperties costs tens of microseconds, and this
 // is asked on every launch).

@@ -1,4 +1,4 @@
-// wave_fft.hpp -- one-wavefront complex FFT for gfx950 (CDNA4), M = 64*P points, P in {16, 32}.
+// wave_fft.hpp -- one-wavefront complex FFT for gfx950 (CDNA4), M = 64*P points, P in {8, 16, 32}.
 //
 // Layout contract (validated against numpy in tests/test_fft_dataflow_model.py):
 //   input : lane l, register j      holds z[l + 64*j]                       (natural order)
@@ -7,7 +7,12 @@
 //           transpose through a per-wave LDS buffer (row stride 65 floats: conflict-free both ways)
 //   pass 2: 64-point FFT over l = radix-(64/P) butterflies ACROSS lanes + P-point DIF in registers
 //   output: lane l, register i      holds Z[kappa(l) + 64*brev(i)]
-//           kappa(l) = l for P=32; for P=16 kappa swaps lane bits 4 and 5 (an involution).
+//           kappa(l) = l with its bits above log2(P) reversed: identity for P=32, bits 4 and 5 swapped for P=16,
+//           bits 3..5 reversed for P=8 (an involution in every case).
+//   pass 2 in full: the 64-point DIF FFT over l = (lane / P) * P + l' has its strides S >= P across lanes (partner =
+//   lane ^ S, S = 32 .. P) and the strides < P in registers.  The upper lane of a stride-S butterfly multiplies by
+//   W_{2S}^(l mod S) = W_{2S}^{l'} (literal, by register) x W_{2S/P}^{e}, e = (lane / P) mod (S / P): nothing for
+//   S == P, (SIGN i)^e for S == 2P ("rot"), a general eighth root for S == 4P (only P = 8, S = 32).
 //
 // No __syncthreads(): every wave owns its LDS buffer; ordering is wave-local (LDS ops of one wave
 // execute in issue order), the fences below only stop the compiler from reordering.
@@ -67,9 +72,9 @@ __device__ __forceinline__ constexpr float s64(int k) {
 
 // e^{SIGN * 2*pi*i * q / (2P)}: register part of the real-FFT split twiddle W_N^{64 q}, N = 128 P.
 template <int P>
-__device__ __forceinline__ constexpr float cos2p(int q) { return P == 32 ? c64(q) : c32(q); }
+__device__ __forceinline__ constexpr float cos2p(int q) { return P == 32 ? c64(q) : (P == 16 ? c32(q) : c32(2 * q)); }
 template <int P>
-__device__ __forceinline__ constexpr float sin2p(int q) { return P == 32 ? s64(q) : s32(q); }
+__device__ __forceinline__ constexpr float sin2p(int q) { return P == 32 ? s64(q) : (P == 16 ? s32(q) : s32(2 * q)); }
 
 __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -130,7 +135,7 @@ __device__ __forceinline__ void lds_transpose(float (&x)[P], float* xbuf, int la
 // The twiddle multiply sits in ONE exec-masked region with literal constants: selecting the constants per
 // lane instead makes them loop-invariant VGPRs that LICM hoists out of the frame loop (64 registers).
 template <int P, int SIGN, int PARTNER, int TWN>
-__device__ __forceinline__ void cross_lane_stage(float (&re)[P], float (&im)[P], bool upper, bool rot) {
+__device__ __forceinline__ void cross_lane_stage(float (&re)[P], float (&im)[P], bool upper, bool rot, int lane) {
     const float sg = upper ? -1.0f : 1.0f;
     float orr[P], oii[P];   // all 2P lane exchanges in flight together, then the butterflies
 #pragma unroll
@@ -146,8 +151,8 @@ __device__ __forceinline__ void cross_lane_stage(float (&re)[P], float (&im)[P],
     if (upper) {
 #pragma unroll
         for (int lp = 1; lp < P; ++lp) {
-            const float cw = (TWN == 64) ? c64(lp) : c32(lp);
-            const float sw0 = (TWN == 64) ? s64(lp) : s32(lp);
+            const float cw = (TWN == 64) ? c64(lp) : ((TWN == 32) ? c32(lp) : c32(2 * lp));
+            const float sw0 = (TWN == 64) ? s64(lp) : ((TWN == 32) ? s32(lp) : s32(2 * lp));
             const float sw = (SIGN < 0) ? -sw0 : sw0;
             const float xr = re[lp] * cw - im[lp] * sw;
             const float xi = re[lp] * sw + im[lp] * cw;
@@ -155,8 +160,24 @@ __device__ __forceinline__ void cross_lane_stage(float (&re)[P], float (&im)[P],
             im[lp] = xi;
         }
     }
-    if (PARTNER == 32 && P == 16) {
-        if (rot) {  // W_4^{c0}: multiply by SIGN*i
+    if (PARTNER == 4 * P) {   // P = 8, stride 32: W_8^e, e = (lane / P) & 3, on the upper lanes
+        const int e = (lane >> 3) & 3;
+        constexpr float kR2 = 7.071067691e-01f;
+        const float fc = (e == 0) ? 1.0f : ((e == 1) ? kR2 : ((e == 2) ? 0.0f : -kR2));
+        const float fs0 = (e == 0) ? 0.0f : ((e == 1) ? kR2 : ((e == 2) ? 1.0f : kR2));
+        const float fs = (SIGN < 0) ? -fs0 : fs0;
+        if (upper) {
+#pragma unroll
+            for (int lp = 0; lp < P; ++lp) {
+                const float xr = re[lp] * fc - im[lp] * fs;
+                const float xi = re[lp] * fs + im[lp] * fc;
+                re[lp] = xr;
+                im[lp] = xi;
+            }
+        }
+    }
+    if (PARTNER == 2 * P) {
+        if (rot) {  // W_4^{e}: multiply by SIGN*i
 #pragma unroll
             for (int lp = 0; lp < P; ++lp) {
                 const float xr = re[lp], xi = im[lp];
@@ -171,7 +192,8 @@ __device__ __forceinline__ void cross_lane_stage(float (&re)[P], float (&im)[P],
 template <int P>
 __device__ __forceinline__ int kappa(int lane) {
     if (P == 32) return lane;
-    return (lane & 15) | (((lane >> 5) & 1) << 4) | (((lane >> 4) & 1) << 5);
+    if (P == 16) return (lane & 15) | (((lane >> 5) & 1) << 4) | (((lane >> 4) & 1) << 5);
+    return (lane & 7) | (((lane >> 5) & 1) << 3) | (lane & 16) | (((lane >> 3) & 1) << 5);   // P == 8: bits 3..5 reversed
 }
 
 // Full M = 64*P point FFT of one wave, in two halves so that a caller can place independent work
@@ -193,10 +215,14 @@ __device__ __forceinline__ void wave_fft_front(float (&re)[P], float (&im)[P], c
     lds_transpose<P>(re, xbuf, lane);
     lds_transpose<P>(im, xbuf, lane);
     if (P == 32) {
-        cross_lane_stage<P, SIGN, 32, 64>(re, im, (lane & 32) != 0, false);
+        cross_lane_stage<P, SIGN, 32, 64>(re, im, (lane & 32) != 0, false, lane);
+    } else if (P == 16) {
+        cross_lane_stage<P, SIGN, 32, 64>(re, im, (lane & 32) != 0, (lane & 48) == 48, lane);
+        cross_lane_stage<P, SIGN, 16, 32>(re, im, (lane & 16) != 0, false, lane);
     } else {
-        cross_lane_stage<P, SIGN, 32, 64>(re, im, (lane & 32) != 0, (lane & 48) == 48);
-        cross_lane_stage<P, SIGN, 16, 32>(re, im, (lane & 16) != 0, false);
+        cross_lane_stage<P, SIGN, 32, 64>(re, im, (lane & 32) != 0, false, lane);
+        cross_lane_stage<P, SIGN, 16, 32>(re, im, (lane & 16) != 0, (lane & 24) == 24, lane);
+        cross_lane_stage<P, SIGN, 8, 16>(re, im, (lane & 8) != 0, false, lane);
     }
 }
 

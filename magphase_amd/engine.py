@@ -181,7 +181,7 @@ class Engine:
             torch = _torch()
             nbytes = self.lib.mpx_tables_bytes(int(fft_len))
             if nbytes == 0:
-                raise ValueError("fft_len %r not supported by the HIP path (2048 or 4096)" % (fft_len,))
+                raise ValueError("fft_len %r not supported by the HIP path (1024, 2048 or 4096)" % (fft_len,))
             t = torch.empty(nbytes // 4, dtype=torch.float32, device=self.device)
             with torch.cuda.device(self.device):
                 _lib.check(self.lib.mpx_tables_init(self.stream_ptr(), int(fft_len), t.data_ptr()), "mpx_tables_init")

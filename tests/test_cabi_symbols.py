@@ -29,6 +29,7 @@ def test_library_loads_and_exports_all_symbols():
     assert l2.mpx_version() == 1
     assert l2.mpx_tables_bytes(4096) == 2 * 64 * 32 * 4
     assert l2.mpx_tables_bytes(2048) == 2 * 64 * 16 * 4
+    assert l2.mpx_tables_bytes(1024) == 2 * 64 * 8 * 4
     assert l2.mpx_tables_bytes(1000) == 0
 
 

@@ -32,9 +32,9 @@ def fft_inreg(x, sign):
 
 
 def kappa(lane, P):
-    if P == 32:
-        return lane
-    return (lane & 15) | (((lane >> 5) & 1) << 4) | (((lane >> 4) & 1) << 5)
+    """lane bits above log2(P) reversed: identity (P=32), bits 4<->5 (P=16), bits 3..5 reversed (P=8)."""
+    lp = int(np.log2(P))
+    return (lane & (P - 1)) | (brev(lane >> lp, 6 - lp) << lp)
 
 
 def wave_fft(x, sign):
@@ -53,28 +53,26 @@ def wave_fft(x, sign):
     for lam in range(64):
         v[lam] = lds[lam % P, (lam // P) * P:(lam // P) * P + P]
 
-    def stage(v, partner, twn, rot_mask):
+    # 64-point DIF over l = (lane // P) * P + l': strides S >= P across lanes.  Upper lane of a stride-S butterfly:
+    # (oth - own) * W_{2S}^{l'} (by register) * W_{2S/P}^{e}, e = (lane // P) mod (S // P):
+    #   S == P: nothing, S == 2P: (sign i)^e (the "rot" of the HIP code), S == 4P (P = 8, S = 32): an eighth root.
+    S = 32
+    while S >= P:
         out = np.zeros_like(v)
         for lam in range(64):
-            upper = (lam & partner) != 0
-            own, oth = v[lam], v[lam ^ partner]
-            u = (oth - own) if upper else (own + oth)
-            if upper:
-                u = u * np.exp(sign * 2j * np.pi * np.arange(P) / twn)
-            if rot_mask is not None and (lam & rot_mask) == rot_mask:
-                u = u * (sign * 1j)
-            out[lam] = u
-        return out
-
-    if P == 32:
-        v = stage(v, 32, 64, None)
-    else:
-        v = stage(v, 32, 64, 48)
-        v = stage(v, 16, 32, None)
+            own, oth = v[lam], v[lam ^ S]
+            if lam & S:
+                e = (lam // P) % (S // P)
+                out[lam] = (oth - own) * np.exp(sign * 2j * np.pi * np.arange(P) / (2 * S)) \
+                    * np.exp(sign * 2j * np.pi * e * P / (2 * S))
+            else:
+                out[lam] = own + oth
+        v = out
+        S //= 2
     return fft_inreg(v, sign)
 
 
-@pytest.mark.parametrize("P", [32, 16])
+@pytest.mark.parametrize("P", [32, 16, 8])
 @pytest.mark.parametrize("sign", [-1, 1])
 def test_wave_fft_layout(P, sign):
     rng = np.random.RandomState(P + sign)
@@ -88,7 +86,7 @@ def test_wave_fft_layout(P, sign):
             assert abs(out[lam, i] - Z[kappa(lam, P) + 64 * brev(i, LB)]) < 1e-9
 
 
-@pytest.mark.parametrize("P", [32, 16])
+@pytest.mark.parametrize("P", [32, 16, 8])
 def test_real_fft_split_with_partner_lane(P):
     """analysis epilogue: X[k] = E + W_N^k O from Z[k] and Z[M-k] fetched from lane kappa^-1((64-kappa)&63)."""
     rng = np.random.RandomState(7)
@@ -114,7 +112,7 @@ def test_real_fft_split_with_partner_lane(P):
     assert abs((Zl[0, 0].real - Zl[0, 0].imag) - R[M].real) < 1e-9
 
 
-@pytest.mark.parametrize("P", [32, 16])
+@pytest.mark.parametrize("P", [32, 16, 8])
 def test_real_ifft_merge_with_partner_lane(P):
     """synthesis prologue: Z[k] = E + iO from X[k], X[M-k]; fftshift folded in as (-1)^k; DC/Nyquist imag dropped."""
     rng = np.random.RandomState(8)

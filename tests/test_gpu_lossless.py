@@ -334,3 +334,31 @@ def test_random_epoch_patterns_match_oracle(mp, orc, seed):
             s_got = mp.synthesis_from_lossless(a[0], a[1], a[2], a[3], fs)
             assert s_got.shape == s_ref.shape
             assert np.max(np.abs(s_got - s_ref)) <= PCM_TOL * max(1.0, np.max(np.abs(s_ref)))
+
+
+def test_fft_1024_at_8khz(mp, orc):
+    """fs = 8 kHz -> fft_len 1024 (define_fft_len): the P = 8 instantiation of the wave FFT (three cross-lane stages)."""
+    import torch
+    from magphase_amd import synthetic as syn
+    from magphase_amd.engine import get_engine, LosslessAnalysisPlan, LosslessSynthesisPlan
+    fs = 8000
+    utts = []
+    for u in range(3):
+        pcm, pm, voi = syn.make_utterance(60 + u, dur_s=1.2, fs=fs)
+        utts.append((syn.pcm_to_float(pcm), fs, pm, voi))
+    got = mp.analysis_lossless_batch(utts)
+    for (x, _fs, pm, voi), a in zip(utts, got):
+        o = orc.analysis_lossless_from_epochs(x, fs, pm, voi)
+        assert a[0].shape[1] == 513 and np.array_equal(a[5], o[5]) and np.array_equal(a[3], o[3], equal_nan=True)
+        _check_feats(a[:3], o[:3])
+        s_ref = orc.synthesis_from_lossless(o[0], o[1], o[2], o[3], fs)
+        s_got = mp.synthesis_from_lossless(a[0], a[1], a[2], a[3], fs)
+        assert s_got.shape == s_ref.shape
+        assert np.max(np.abs(s_got - s_ref)) <= PCM_TOL * max(1.0, np.max(np.abs(s_ref)))
+    eng = get_engine()
+    plan = LosslessAnalysisPlan(eng, utts)
+    assert plan.fft_len == 1024
+    feats = plan.run()
+    splan = LosslessSynthesisPlan(eng, plan.v_f0, plan.fs, plan.fft_len)
+    a, b = splan.run(*feats), splan.run_unfused(*feats)          # fused ring form vs frames + gather
+    assert float((a - b).abs().max()) <= 1e-6 * max(1.0, float(b.abs().max()))
