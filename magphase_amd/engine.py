@@ -483,7 +483,7 @@ class CompressedSynthesisPlan:
     """
 
     def __init__(self, engine, utts, fs, fft_len=None, b_voi_ap_win=True, b_const_rate=False, alpha_phase=None,
-                 noise=None, territory=None, per_phase_type="magphase", post_filter=False):
+                 noise=None, territory=None, per_phase_type="magphase", post_filter=False, b_fbank_mel=False):
         from scipy import interpolate
 
         self.apply_post_filter = bool(post_filter)
@@ -588,8 +588,12 @@ class CompressedSynthesisPlan:
         # constants: unwarp matrices and per-bin curves (float64 -> float32)
         # (resident on the device per configuration: rebuilding them costs 7 ms on the host, as much as the rest of a
         # single-utterance call -- tools/latency_probe.py)
-        self.u_mag = e.constant(("u_mag", self.mag_dim, H, float(alpha)),
-                                lambda: hm.unwarp_matrix(self.mag_dim, H, alpha))
+        if b_fbank_mel:   # magphase.py:851-852: filter-bank unwarp = a different [mag_dim x H] matrix, same kernel
+            self.u_mag = e.constant(("u_mag_fbank", self.mag_dim, H, float(alpha)),
+                                    lambda: hm.unwarp_fbank_matrix(self.mag_dim, H, alpha))
+        else:
+            self.u_mag = e.constant(("u_mag", self.mag_dim, H, float(alpha)),
+                                    lambda: hm.unwarp_matrix(self.mag_dim, H, alpha))
         self.u_phase = e.constant(("u_phase", self.phase_dim, N, int(fs), float(self.alpha_phase)),
                                   lambda: hm.phase_unwarp_matrix(self.phase_dim, N, fs, self.alpha_phase))
         self.per_v, self.ap_v, self.ap_u = (

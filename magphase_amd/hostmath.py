@@ -195,6 +195,29 @@ def unwarp_matrix(ncoeffs, nbins_out, alpha):
     return ceps @ cosm
 
 
+def fbank_centres(n_melbands, nbins, alpha):
+    """Band centres (linear-frequency bins) of the mel filter bank, libaudio.py:839-846 / :730-736."""
+    from scipy import interpolate
+
+    v_bins_warp = build_mel_curve(alpha, nbins, amp=np.pi)
+    v_cntrs_mel = np.linspace(0, v_bins_warp[-1], n_melbands)
+    f_interp = interpolate.interp1d(v_bins_warp, np.arange(nbins), kind="quadratic")
+    return round_to_int(f_interp(v_cntrs_mel))
+
+
+def unwarp_fbank_matrix(n_melbands, nbins, alpha):
+    """
+    la.sp_mel_unwarp_fbank (libaudio.py:815-864): per frame, a quadratic spline (scipy interp1d) through the band
+    centres, evaluated on every bin.  For fixed knots that is linear in the frame, so it is the matrix
+    U[n_melbands x nbins] = the spline of each unit vector (same scipy call as the reference).
+    """
+    from scipy import interpolate
+
+    v_cntrs = fbank_centres(n_melbands, nbins, alpha)
+    f_interp = interpolate.interp1d(v_cntrs, np.eye(n_melbands), kind="quadratic", axis=0)
+    return f_interp(np.arange(nbins)).T.copy()
+
+
 def get_num_full_mel_coeffs_from_num_phase_coeffs(freq_hz, phase_dim, alpha, fs):
     """magphase.py:2479-2487."""
     cw = 2 * np.pi * freq_hz / float(fs)

@@ -251,13 +251,13 @@ def _output_hpf(v_syn_sig, fs):
 
 def synthesis_from_compressed_batch(utts, fs, fft_len=None, b_voi_ap_win=True, b_const_rate=False, alpha_phase=None,
                                     b_out_hpf=True, noise=None, engine=None, per_phase_type='magphase',
-                                    b_post_filter=False):
+                                    b_post_filter=False, b_fbank_mel=False):
     """Batched synthesis_from_compressed; utts: list of (m_mag_mel_log, m_real_mel, m_imag_mel, v_lf0).
     b_post_filter: apply the MagPhase post-filter to the log-mel magnitudes on the device first (pf_type='magphase')."""
     engine = engine or get_engine()
     plan = CompressedSynthesisPlan(engine, utts, fs, fft_len=fft_len, b_voi_ap_win=b_voi_ap_win,
                                    b_const_rate=b_const_rate, alpha_phase=alpha_phase, noise=noise,
-                                   per_phase_type=per_phase_type, post_filter=b_post_filter)
+                                   per_phase_type=per_phase_type, post_filter=b_post_filter, b_fbank_mel=b_fbank_mel)
     pcm_dev = plan.run()
     if b_out_hpf:   # magphase.py:981-995, float64 on the device (engine.output_hpf); _output_hpf is the host form
         pcm = engine.output_hpf(pcm_dev, plan.out_off_host, fs).cpu().numpy()
@@ -269,14 +269,12 @@ def synthesis_from_compressed_batch(utts, fs, fft_len=None, b_voi_ap_win=True, b
 def synthesis_from_compressed(m_mag_mel_log, m_real_mel, m_imag_mel, v_lf0, fs, fft_len=None, b_voi_ap_win=True,
                               b_fbank_mel=False, b_const_rate=False, per_phase_type='magphase', alpha_phase=None,
                               b_out_hpf=True):
-    """magphase.py:825-997, per_phase_type in {'magphase', 'min_phase', 'linear'}.  b_fbank_mel (experimental
-    filter-bank warping built on helpers outside the live path) is not provided."""
-    if b_fbank_mel:
-        raise NotImplementedError("b_fbank_mel=True (experimental filter-bank warping) is outside the hot path")
+    """magphase.py:825-997, per_phase_type in {'magphase', 'min_phase', 'linear'}; b_fbank_mel: magnitudes unwarped by
+    the filter-bank interpolation (la.sp_mel_unwarp_fbank) instead of the cepstral cosine matrix."""
     return synthesis_from_compressed_batch([(m_mag_mel_log, m_real_mel, m_imag_mel, v_lf0)], fs, fft_len=fft_len,
                                            b_voi_ap_win=b_voi_ap_win, b_const_rate=b_const_rate,
                                            alpha_phase=alpha_phase, b_out_hpf=b_out_hpf,
-                                           per_phase_type=per_phase_type)[0]
+                                           per_phase_type=per_phase_type, b_fbank_mel=b_fbank_mel)[0]
 
 
 def synthesis_from_acoustic_modelling(in_feats_dir, filename_token, out_syn_dir, mag_dim, phase_dim, fs,

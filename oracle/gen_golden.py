@@ -182,6 +182,27 @@ def _py3_loadtxt(orig):
     return f
 
 
+def gen_fbank(mp, la, lu):
+    """G10: filter-bank mel unwarp (la.sp_mel_unwarp_fbank) and synthesis_from_compressed(b_fbank_mel=True)."""
+    rng = np.random.RandomState(123)
+    out = {}
+    for nb, nbins, alpha in ((60, 2049, 0.77), (60, 1025, 0.58), (40, 2049, 0.77)):
+        x = rng.randn(5, nb) * 0.5 - 3.0
+        y = la.sp_mel_unwarp_fbank(x, nbins, alpha=alpha)
+        out["x_%d_%d" % (nb, nbins)] = x
+        out["y_%d_%d" % (nb, nbins)] = y
+    d = os.path.join(ref_shim.REF_ROOT if hasattr(ref_shim, "REF_ROOT") else "/root/reference", "demos", "data_48k",
+                     "params_predicted")
+    m_mag = lu.read_binfile(os.path.join(d, "hvd_704.mag"), dim=60)
+    m_real = lu.read_binfile(os.path.join(d, "hvd_704.real"), dim=45)
+    m_imag = lu.read_binfile(os.path.join(d, "hvd_704.imag"), dim=45)
+    v_lf0 = lu.read_binfile(os.path.join(d, "hvd_704.lf0"), dim=1)
+    np.random.seed(77)
+    out["seed"] = 77
+    out["syn_fbank"] = mp.synthesis_from_compressed(m_mag, m_real, m_imag, v_lf0, 48000, b_fbank_mel=True)
+    np.savez_compressed(os.path.join(OUT, "g10_fbank.npz"), **out)
+
+
 def gen_labels(mp, la):
     """G9: HTS state-aligned labels -> frames per state -> variable-frame-rate labels (magphase.py:2111-2150,
     libaudio.py:687-708).  The label text is synthetic (5 states per phone, 5 ms grid)."""
@@ -241,6 +262,7 @@ def main():
             gen_compressed_synthesis(mp, lu)
             gen_const_rate(mp, la)
             gen_labels(mp, la)
+            gen_fbank(mp, la, lu)
         finally:
             os.chdir(cwd)
     for f in sorted(os.listdir(OUT)):

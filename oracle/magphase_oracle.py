@@ -636,11 +636,29 @@ def build_min_phase_from_mag_spec(m_mag):
     return np.exp(np.fft.fft(ceps)[:, :half])
 
 
+def sp_mel_unwarp_fbank(m_mag_mel, nbins, alpha=0.77, interp_kind="quadratic"):
+    """libaudio.py:815-864 (sp_mel_unwarp_fbank -> unwarp_from_fbank): per-frame interp1d through the band centres."""
+    from scipy import interpolate
+
+    m_mag_mel = np.asarray(m_mag_mel, dtype=np.float64)
+    nfrms, n_melbands = m_mag_mel.shape
+    v_bins_warp = build_mel_curve(alpha, nbins, amp=np.pi)
+    v_cntrs_mel = np.linspace(0, v_bins_warp[-1], n_melbands)
+    f_interp = interpolate.interp1d(v_bins_warp, np.arange(nbins), kind=interp_kind)
+    v_cntrs = round_to_int(f_interp(v_cntrs_mel))
+    v_bins = np.arange(nbins)
+    m_mag = np.zeros((nfrms, nbins))
+    for nxf in range(nfrms):
+        m_mag[nxf, :] = interpolate.interp1d(v_cntrs, m_mag_mel[nxf, :], kind=interp_kind)(v_bins)
+    return m_mag
+
+
 def synthesis_from_compressed(m_mag_mel_log, m_real_mel, m_imag_mel, v_lf0, fs, fft_len=None, b_voi_ap_win=True,
                               b_const_rate=False, per_phase_type="magphase", alpha_phase=None, b_out_hpf=True,
-                              v_noise=None, return_debug=False):
+                              v_noise=None, return_debug=False, b_fbank_mel=False):
     """
-    magphase.py:825-997 (b_fbank_mel=False).  ``v_noise``: if given, used instead of the
+    magphase.py:825-997.  b_fbank_mel: magnitudes unwarped by la.sp_mel_unwarp_fbank (magphase.py:851-852).
+    ``v_noise``: if given, used instead of the
     ``np.random.uniform(-1, 1, ns_len)`` draw of magphase.py:883 (must have length ns_len).
     """
     cf, bw = define_crossfade_params(fs)
@@ -653,7 +671,10 @@ def synthesis_from_compressed(m_mag_mel_log, m_real_mel, m_imag_mel, v_lf0, fs, 
     v_f0 = np.exp(v_lf0)
     v_voi = v_f0 > 1.0
     v_shift = f0_to_shift(v_f0, fs)
-    m_mag = np.exp(sp_mel_unwarp(m_mag_mel_log, half, alpha=alpha, in_type="log"))
+    if b_fbank_mel:
+        m_mag = np.exp(sp_mel_unwarp_fbank(m_mag_mel_log, half, alpha=alpha))
+    else:
+        m_mag = np.exp(sp_mel_unwarp(m_mag_mel_log, half, alpha=alpha, in_type="log"))
     if alpha_phase is None:
         alpha_phase = alpha
     m_real, m_imag = phase_uncompress_type1_mcep(m_real_mel, m_imag_mel, alpha_phase, fft_len, fs)

@@ -134,8 +134,6 @@ def test_min_phase_and_linear_branches(mp, orc, golden_dir):
 
 def test_unsupported_branches_and_errors(mp, golden_dir):
     g, mm, rr, ii, lf = _hvd704(golden_dir)
-    with pytest.raises(NotImplementedError):
-        mp.synthesis_from_compressed(mm, rr, ii, lf, 48000, b_fbank_mel=True)
     with pytest.raises(ValueError):
         mp.synthesis_from_compressed(mm, rr, ii, lf, 44100 + 1)   # define_alpha: unsupported rate
 
@@ -243,4 +241,16 @@ def test_other_sample_rates_match_oracle(mp, orc, fs):
         v = mp.synthesis_from_compressed(o[0], o[1], o[2], o[3], fs)
         np.random.seed(5)
         ref = orc.synthesis_from_compressed(o[0], o[1], o[2], o[3], fs)
+    assert v.shape == ref.shape and np.max(np.abs(v - ref)) <= COMP_PCM_TOL * max(1.0, np.max(np.abs(ref)))
+
+
+def test_fbank_unwarp_generation_matches_reference(mp, golden_dir):
+    """synthesis_from_compressed(b_fbank_mel=True) on the bundled predicted features vs the reference's own output (G10)."""
+    g10 = np.load(os.path.join(golden_dir, "g10_fbank.npz"))
+    g, mm, rr, ii, lf = _hvd704(golden_dir)
+    np.random.seed(int(g10["seed"]))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        v = mp.synthesis_from_compressed(mm, rr, ii, lf, 48000, b_fbank_mel=True)
+    ref = g10["syn_fbank"]
     assert v.shape == ref.shape and np.max(np.abs(v - ref)) <= COMP_PCM_TOL * max(1.0, np.max(np.abs(ref)))

@@ -163,3 +163,13 @@ def test_g8_compressed_analysis_unpinned_mcep(golden_dir):
             np.random.seed(int(g["cr45_seed"]))
             v = orc.synthesis_from_compressed(r[0], r[1], r[2], r[3], fs, b_const_rate=True, b_out_hpf=False)
             _close(v, g["cr45_syn"], WAVE_TOL)
+
+
+def test_g10_fbank_unwarp_and_synthesis(golden_dir):
+    """b_fbank_mel=True branch: la.sp_mel_unwarp_fbank restated (oracle) and as the matrix the device multiplies by."""
+    from magphase_amd import hostmath as hm
+    g = _load(golden_dir, "g10_fbank.npz")
+    for nb, nbins, alpha in ((60, 2049, 0.77), (60, 1025, 0.58), (40, 2049, 0.77)):
+        x, y = g["x_%d_%d" % (nb, nbins)], g["y_%d_%d" % (nb, nbins)]
+        _close(orc.sp_mel_unwarp_fbank(x, nbins, alpha=alpha), y)
+        _close(x @ hm.unwarp_fbank_matrix(nb, nbins, alpha), y, 1e-11)
