@@ -285,6 +285,62 @@ class Engine:
                        "mpx_output_hpf")
         return y[:total]
 
+    def mel_unwarp_single(self, m_x, n_bins, alpha, exp_out=False):
+        """la.sp_mel_unwarp for one [F x n] host matrix through mpx_mel_unwarp (the phase jobs run on a 1-frame dummy)."""
+        torch = _torch()
+        m_x = np.atleast_2d(np.asarray(m_x, dtype=np.float64))
+        F, n = m_x.shape
+        u = self.constant(("u_mag", int(n), int(n_bins), float(alpha)), lambda: hm.unwarp_matrix(n, n_bins, alpha))
+        ld = int(self.lib.mpx_spec_ld(int(n_bins)))
+        a = self.to_device(m_x, np.float32)
+        o_exp, o_lin, o_dummy = (self.empty((F, ld)) for _ in range(3))
+        with torch.cuda.device(self.device):   # magnitude job: exp(x U); "real" job: x U; "imag" job: scratch
+            _lib.check(self.lib.mpx_mel_unwarp(self.stream_ptr(), F, int(n_bins), a.data_ptr(), n, u.data_ptr(),
+                                               o_exp.data_ptr(), a.data_ptr(), a.data_ptr(), n, u.data_ptr(),
+                                               o_lin.data_ptr(), o_dummy.data_ptr(), ld), "mpx_mel_unwarp")
+        return self.to_host_f64((o_exp if exp_out else o_lin)[:, :int(n_bins)])
+
+    def min_phase_single(self, m_mag):
+        """la.build_min_phase_from_mag_spec for one [F x H] host matrix through mpx_min_phase."""
+        torch = _torch()
+        m_mag = np.atleast_2d(m_mag)
+        F, H = m_mag.shape
+        N = 2 * (H - 1)
+        tab = self.tables(N)
+        ld = int(self.lib.mpx_spec_ld(H))
+        mag = self.empty((F, ld))
+        mag[:, :H].copy_(torch.from_numpy(np.ascontiguousarray(m_mag, dtype=np.float32)))
+        ident = torch.arange(F, dtype=torch.int32, device=self.device)
+        zeros_t = torch.zeros(F, dtype=torch.float32, device=self.device)
+        o_m, o_r, o_i = (self.empty((F, ld)) for _ in range(3))
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.mpx_min_phase(self.stream_ptr(), N, tab.data_ptr(), mag.data_ptr(), ident.data_ptr(),
+                                              ident.data_ptr(), zeros_t.data_ptr(), F, o_m.data_ptr(), o_r.data_ptr(),
+                                              o_i.data_ptr(), ld), "mpx_min_phase")
+        m = self.to_host_f64(o_m[:, :H])
+        return m * (self.to_host_f64(o_r[:, :H]) + 1j * self.to_host_f64(o_i[:, :H]))
+
+    def mel_warp_feats(self, mag, real, imag, voi_host, fs, mag_dim, phase_dim, alpha_phase=None):
+        """format_for_modelling's two warps (magphase.py:2504-2529) on device feature matrices [F x H] -> three device
+        matrices [F x mag_dim], [F x phase_dim], [F x phase_dim]."""
+        torch = _torch()
+        F, H = int(mag.shape[0]), int(mag.shape[1])
+        alpha = hm.define_alpha(fs)
+        a_ph = alpha if alpha_phase is None else alpha_phase
+        cf, _ = hm.define_crossfade_params(fs)
+        k_full = hm.get_num_full_mel_coeffs_from_num_phase_coeffs(cf, phase_dim, a_ph, fs)
+        w_mag = self.constant(("w_mag", int(mag_dim), H, float(alpha)), lambda: hm.warp_matrix(mag_dim, H, alpha))
+        w_ph = self.constant(("w_ph", int(k_full), H, float(a_ph), int(phase_dim)),
+                             lambda: hm.warp_matrix(k_full, H, a_ph, nrows=phase_dim))
+        voi = self.to_device(np.asarray(voi_host, dtype=np.float64), np.float32)
+        out = (self.empty((F, int(mag_dim))), self.empty((F, int(phase_dim))), self.empty((F, int(phase_dim))))
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.mpx_mel_warp(self.stream_ptr(), F, H, mag.data_ptr(), real.data_ptr(), imag.data_ptr(),
+                                             None, None, None, w_mag.data_ptr(), int(mag_dim), w_ph.data_ptr(),
+                                             int(phase_dim), voi.data_ptr(), out[0].data_ptr(), out[1].data_ptr(),
+                                             out[2].data_ptr(), self.feat_ld(mag, real, imag)), "mpx_mel_warp")
+        return out
+
     def synth_comp_slots(self):
         torch = _torch()
         with torch.cuda.device(self.device):

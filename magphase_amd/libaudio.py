@@ -128,3 +128,62 @@ def convert_label_state_align_to_var_frame_rate(in_lab_st_file, v_dur_state, out
     with open(out_lab_st_file, "w") as f:
         for i, name in enumerate(l_names):
             f.write("%d %d %s\n" % (v_edges[i], v_edges[i + 1], name))
+
+
+# ---- helpers of the reference's libaudio that the live path is built from, for callers that use them directly
+read_est_file = read_reaper_est_file      # libaudio.py:421 under its older name
+build_mel_curve = hm.build_mel_curve      # libaudio.py:711-718
+
+
+def hz_to_bin(v_hz, nFFT, fs):
+    """libaudio.py:151-152."""
+    return v_hz * nFFT / float(fs)
+
+
+def bin_to_hz(v_bin, nFFT, fs):
+    """libaudio.py:154-155."""
+    return v_bin * fs / float(nFFT)
+
+
+def add_hermitian_half(m_data, data_type="mag"):
+    """libaudio.py:369-388: [F x H] half spectra -> [F x 2(H-1)] ('phase' zeroes DC/Nyquist IN PLACE like the reference)."""
+    if data_type in ("mag", "magnitude"):
+        return np.hstack((m_data, np.fliplr(m_data[:, 1:-1])))
+    if data_type == "phase":
+        m_data[:, 0] = 0
+        m_data[:, -1] = 0
+        return np.hstack((m_data, -np.fliplr(m_data[:, 1:-1])))
+    if data_type == "zeros":
+        return np.hstack((m_data, np.zeros((m_data.shape[0], m_data.shape[1] - 2))))
+    if data_type == "complex":
+        return add_hermitian_half(m_data.real) + 1j * add_hermitian_half(m_data.imag, data_type="phase")
+    return m_data
+
+
+def remove_hermitian_half(m_data):
+    """libaudio.py:392-400."""
+    m_data = np.asarray(m_data)
+    if m_data.ndim == 1:
+        return m_data[:m_data.size // 2 + 1].copy()
+    return m_data[:, :m_data.shape[1] // 2 + 1].copy()
+
+
+def sp_mel_unwarp(m_sp_mel, nbins_out, alpha=0.77, in_type="log"):
+    """
+    libaudio.py:667-684 on the device (mpx_mel_unwarp, the GEMM against hostmath.unwarp_matrix): [F x n] mel-warped
+    log (or 'abs') spectra -> [F x nbins_out], float64 like the reference's.
+    """
+    from .engine import get_engine
+    e = get_engine()
+    x = np.log(m_sp_mel) if in_type == "abs" else np.asarray(m_sp_mel, dtype=np.float64)
+    out = e.mel_unwarp_single(x, int(nbins_out), float(alpha), exp_out=(in_type == "abs"))
+    return out
+
+
+def build_min_phase_from_mag_spec(m_mag):
+    """
+    libaudio.py:920-934 on the device (mpx_min_phase: complex cepstrum, causal fold): [F x H] magnitudes -> complex
+    [F x H] minimum-phase spectra |X| e^{j phi}.  H - 1 must be 512, 1024 or 2048.
+    """
+    from .engine import get_engine
+    return get_engine().min_phase_single(np.asarray(m_mag, dtype=np.float64))

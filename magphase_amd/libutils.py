@@ -70,3 +70,51 @@ def run_multithreaded(*args):
     jobs = [tuple([func] + [a[i] if type(a) is list else a for a in args[1:]]) for i in range(nruns)]
     with Pool() as pool:
         return pool.map(_func_wrapper, jobs)
+
+
+# ---- small helpers of the reference's libutils kept for scripts that import them (libutils.py:23-30, 66-95, 129-203)
+def fileparts(fullpath):
+    """libutils.py:135-139 -> [directory, file token, extension, path without extension]."""
+    path_no_ext, ext = os.path.splitext(fullpath)
+    return [os.path.dirname(fullpath), os.path.basename(path_no_ext), ext, path_no_ext]
+
+
+def get_file_list(files_path):
+    """libutils.py:106-109: glob pattern -> (list, count)."""
+    import glob
+    files = glob.glob(files_path)
+    return files, len(files)
+
+
+def gen_list_of_file_paths(files_dir, v_file_tkns, suffix):
+    """libutils.py:66-77."""
+    return [files_dir + "/" + str(t) + suffix for t in v_file_tkns]
+
+
+def indexes_to_one_zero_vector(v_nxs, length):
+    """libutils.py:82-91."""
+    v = np.zeros(length)
+    v[np.asarray(v_nxs).astype(int)] = 1
+    return v
+
+
+def is_mutable(data):
+    return hasattr(data, "__setitem__")
+
+
+def add_rel_path(rel_path):
+    """libutils.py:175-180: appends <directory of the calling file> + rel_path to sys.path."""
+    import inspect
+    import sys
+    caller_dir = os.path.dirname(inspect.stack()[1][1])
+    sys.path.append(os.path.realpath(caller_dir + rel_path))
+
+
+def ins_date_time(filepath, prefix=""):
+    """libutils.py:197-203: path/file.ext -> path/file_<prefix>_<YYYYmmdd_HHMM>.ext."""
+    import time
+    name, ext = os.path.splitext(filepath)
+    return "%s_%s_%s%s" % (name, prefix, time.strftime("%Y%m%d_%H%M"), ext)
+
+
+func_wrapper = _func_wrapper

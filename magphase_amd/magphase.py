@@ -329,6 +329,30 @@ def analysis_compressed_batch(utts, fft_len=None, mag_dim=60, phase_dim=10, b_co
     return res
 
 
+def format_for_modelling(m_mag, m_real, m_imag, v_f0, fs, mag_dim=60, phase_dim=45, b_mag_fbank_mel=False,
+                         alpha_phase=None):
+    """
+    magphase.py:2490-2544 for lossless features that are already in host arrays: f0 smoothing / lf0 on the host (fp64),
+    the two mel warps on the device (mpx_mel_warp).  Returns (m_mag_mel_log, m_real_mel, m_imag_mel, v_lf0_smth).
+    b_mag_fbank_mel=True (the analysis-side filter bank) is not built: it is unreachable through analysis_compressed /
+    analysis_for_acoustic_modelling in the reference (Q7).
+    """
+    from scipy import signal
+    if b_mag_fbank_mel:
+        raise NotImplementedError("format_for_modelling(b_mag_fbank_mel=True): analysis-side filter bank not built")
+    engine = get_engine()
+    v_f0 = np.asarray(v_f0, dtype=np.float64)
+    v_voi = (v_f0 > 0).astype('float')                                       # magphase.py:2497
+    v_lf0_smth = la.f0_to_lf0(v_voi * signal.medfilt(v_f0))                  # :2499-2501
+    mag, real, imag = (engine.feats_to_device(x) for x in (m_mag, m_real, m_imag))
+    out = engine.mel_warp_feats(mag, real, imag, v_voi, fs, mag_dim, phase_dim, alpha_phase=alpha_phase)
+    return tuple(engine.to_host_f64(t) for t in out) + (v_lf0_smth,)
+
+
+shift_to_f0 = hm.shift_to_f0
+get_num_full_mel_coeffs_from_num_phase_coeffs = hm.get_num_full_mel_coeffs_from_num_phase_coeffs
+
+
 def analysis_compressed(wav_file, fft_len=None, mag_dim=60, phase_dim=10, b_const_rate=False, b_mag_fbank_mel=False,
                         alpha_phase=None):
     """magphase.py:2947-2988 (b_mag_fbank_mel is accepted and, as in the reference, never forwarded)."""

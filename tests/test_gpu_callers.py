@@ -135,3 +135,30 @@ def test_builtin_epoch_tracker_end_to_end(tmp_path):
     err = v_syn[n0:n1] - x[n0:n1]
     snr = 10 * np.log10(np.sum(x[n0:n1] ** 2) / np.sum(err ** 2))
     assert snr > 80.0, snr
+
+
+def test_library_helpers_on_the_device():
+    """la.sp_mel_unwarp / la.build_min_phase_from_mag_spec / mp.format_for_modelling (names the reference exposes) run the
+    same kernels as the main path; checked against the oracle / against analysis_compressed."""
+    from magphase_amd import libaudio as la, magphase as mp, synthetic as syn
+    from oracle import magphase_oracle as orc
+    rng = np.random.RandomState(4)
+    x = rng.randn(37, 60) * 0.7 - 2.0
+    for in_type in ("log", "abs"):
+        got = la.sp_mel_unwarp(np.exp(x) if in_type == "abs" else x, 2049, alpha=0.77, in_type=in_type)
+        ref = orc.sp_mel_unwarp(np.exp(x) if in_type == "abs" else x, 2049, alpha=0.77, in_type=in_type)
+        assert got.shape == ref.shape == (37, 2049)
+        assert np.max(np.abs(got - ref)) <= 5e-6 * max(1.0, np.max(np.abs(ref)))
+    pcm, pm, voi = syn.make_utterance(31, dur_s=0.6)
+    sig = syn.pcm_to_float(pcm)
+    a = mp.analysis_lossless_from_epochs(sig, 48000, pm, voi)
+    mph = la.build_min_phase_from_mag_spec(a[0][:20] + 1e-4)
+    ref = orc.build_min_phase_from_mag_spec(a[0][:20] + 1e-4)
+    assert mph.shape == ref.shape and np.max(np.abs(np.abs(mph) - np.abs(ref))) <= 1e-5 * np.max(np.abs(ref))
+    big = np.abs(ref) > 1e-2 * np.max(np.abs(ref), axis=1, keepdims=True)
+    assert np.max(np.abs(mph - ref)[big] / np.abs(ref)[big]) < 2e-3
+    f = mp.format_for_modelling(a[0], a[1], a[2], a[3], 48000, mag_dim=60, phase_dim=45)
+    c = mp.analysis_compressed_batch([(sig, 48000, pm, voi)], mag_dim=60, phase_dim=45)[0]
+    for k in range(3):
+        assert f[k].shape == c[k].shape and np.max(np.abs(f[k] - c[k])) < 2e-3   # float64 -> float32 re-quantised input
+    assert np.array_equal(f[3], c[3])
