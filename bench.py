@@ -132,7 +132,7 @@ def main():
     H = N // 2 + 1
     F = aplan.total_frames
     feats = tuple(eng.empty_feats(F, H) for _ in range(3))
-    strips = eng.empty((splan.strip_floats,))
+    strips = eng.empty((max(splan.strip_floats, 1),))
     pcm_out = eng.empty((splan.total_out,))
 
     def step():
@@ -171,10 +171,9 @@ def main():
         ev[0].record()
         aplan.run(out=feats)
         ev[1].record()
-        eng.synthesis_lossless_ola(N, feats[0], feats[1], feats[2], splan, strips)
+        eng.synthesis_lossless_ola(N, feats[0], feats[1], feats[2], splan, strips, pcm_out)
         ev[2].record()
-        eng.ola_fixup(N, splan.territory, strips, splan.utt_chunk_off, splan.strip_id, splan.out_start,
-                      splan.out_off, splan.max_territories, splan.total_out, out=pcm_out)
+        eng.ola_fixup(N, splan, strips, pcm_out)
         ev[3].record()
         torch.cuda.synchronize()
         for k in range(3):
@@ -220,7 +219,7 @@ def main():
                        "frames_per_gpu": F, "audio_s_per_gpu": UTTS_PER_GPU * DUR_S,
                        "x_realtime": round(UTTS_PER_GPU * DUR_S * world / (dt / args.steps), 1),
                        "parallelism": "utterance-sharded x%d, no collective" % world,
-                       "ola_territory": splan.territory, "ola_chunks": splan.n_chunks,
+                       "ola_runs": splan.n_runs,
                        "host_plan_build_s": round(t_plan, 3)},
             "roofline": roof,
         }

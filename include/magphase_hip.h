@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MPX_ABI_VERSION 1
+#define MPX_ABI_VERSION 2
 
 #define MPX_OK 0
 #define MPX_ERR_ARG (-1)     /* bad argument (unsupported fft_len, null pointer, negative count) */
@@ -32,9 +32,9 @@ extern "C" {
 int mpx_version(void);
 const char* mpx_last_error(void);
 
-/* Number of bytes of the per-fft_len twiddle table, and its initialisation (host computes the table in
- * float64, rounds to float32 and enqueues an H2D copy on `stream`).  The table is read-only afterwards
- * and may be shared by every stream of the device. */
+/* Number of bytes of the per-fft_len twiddle table, and its initialisation (a small kernel enqueued on `stream`
+ * evaluates it in float64 and rounds to float32: no host copy, no synchronisation).  The table is read-only
+ * afterwards and may be shared by every stream of the device. */
 size_t mpx_tables_bytes(int fft_len);
 int mpx_tables_init(void* stream, int fft_len, void* tables);
 
@@ -91,28 +91,43 @@ int mpx_ola_gather(void* stream, int fft_len, const float* frames, int32_t n_utt
 
 /*
  * Fused lossless synthesis + PSOLA (the production path; the two calls above stay as the reference form).
- * The OLA buffer of every utterance (magphase.py:38) is cut into territories of `territory` samples
- * (multiple of 64, >= N/2); a CHUNK is the run of consecutive frames of one utterance whose centre
- * pm_rel + N/2 falls in one territory.  mpx_synthesis_lossless_ola overlap-adds each chunk's frames, in
- * ascending frame order, into the chunk's strip (territory + N floats: N/2 of halo on each side);
- * mpx_ola_fixup sums, for every output sample, the strips of territories c-1, c, c+1 in that fixed order
- * (deterministic; differs from the reference's single ascending sum only by fp32 re-association).
- * chunks        : n_chunks x {int32 frame_begin, frame_end, x0, pad}; x0 = c*territory - N/2
- * slot_off      : int32[n_slots+1], slot_chunks : int32[n_chunks] -- work list: wave slot s processes chunks
- *                 slot_chunks[slot_off[s] .. slot_off[s+1]) in that order (one wavefront per slot; the host
- *                 balances the lists, longest-processing-time first, for mpx_synth_ola_slots() slots)
- * strips        : float32 [n_chunks x (territory + N)], strip i belongs to chunk i
- * utt_chunk_off : int32[n_utts+1] territory range of each utterance in strip_id
- * strip_id      : int32[sum of territories]  chunk index owning the territory, or -1 if it has no frame
+ * Replaces magphase.py:1759-1776 (synthesis_from_lossless) + :34-62 (ola) for a batch.
+ * The frames of every utterance are cut into RUNS of consecutive frames (host: hostmath.ola_runs).  A run is
+ * overlap-added, in ascending frame order, in an on-chip ring buffer by one wavefront pair; finished samples go
+ * straight to pcm_out, except the first head_end elements of a run that has a predecessor in its utterance -- those
+ * positions also receive the predecessor's last frames -- which go to the run's head strip and are added to pcm_out by
+ * mpx_ola_fixup afterwards (predecessor's sum + head strip: a fixed order, so the result is deterministic; it differs
+ * from the reference's single ascending sum only by fp32 re-association).  Runs of one utterance must be long
+ * enough that only ADJACENT runs overlap: pm_rel[frame_end] - pm_rel[frame_begin - 1] >= N for every run that has
+ * both neighbours (hostmath.ola_runs guarantees it).
+ * Element coordinates e of a run are OLA-buffer positions (magphase.py:38) minus x0.
  */
-int mpx_synth_ola_slots(void); /* wave slots the current device runs concurrently (CUs x waves per block) */
+typedef struct mpx_ola_run {
+    int32_t frame_begin, frame_end; /* global frame indices: rows of mag/real/imag, entries of pm_rel */
+    int32_t x0;                     /* OLA-buffer position of element 0; chosen so that out_base is a multiple of 64 */
+    int32_t head_end;               /* elements e < head_end go to the head strip (0: first run of its utterance) */
+    int32_t out_lo, out_hi;         /* elements out_lo <= e < out_hi are written to pcm_out[out_base + e] */
+    int32_t flush_end;              /* the ring is streamed out and cleared up to this element when the run ends */
+    int32_t fix_lo, fix_hi;         /* mpx_ola_fixup: pcm_out[out_base + e] += strip[e] for fix_lo <= e < fix_hi */
+    int32_t pad;
+    int64_t out_base;               /* pcm_out index of element 0 (may be negative) */
+    int64_t strip_off;              /* float offset of the head strip in `strips`; head_end <= mpx_ola_strip_floats() */
+} mpx_ola_run;
+
+/* slot_off : int32[n_slots+1], slot_runs : int32[n_runs] -- work list: pair slot s processes the runs
+ *            slot_runs[slot_off[s] .. slot_off[s+1]) in that order (the host balances the lists for
+ *            mpx_synth_ola_slots() slots; with runs of equal length every slot gets one)
+ * pm_rel   : int32[n_frames]  pm_i - pm_0 within the utterance (as mpx_ola_gather)
+ * strips   : float32 [n_runs x mpx_ola_strip_floats(fft_len)]
+ * pcm_out  : float32, the utterances' outputs concatenated (every kept sample is written exactly once by
+ *            mpx_synthesis_lossless_ola; mpx_ola_fixup then adds the head strips) */
+int mpx_synth_ola_slots(void); /* pair slots the current device runs concurrently (CUs x pairs per workgroup) */
+int64_t mpx_ola_strip_floats(int fft_len); /* floats per head strip: fft_len + 64 */
 int mpx_synthesis_lossless_ola(void* stream, int fft_len, const void* tables, const float* mag, const float* real,
-                               const float* imag, const void* chunks, int32_t n_chunks, const int32_t* slot_off,
-                               const int32_t* slot_chunks, int32_t n_slots, const int32_t* pm_rel,
-                               int32_t territory, float* strips, int64_t ld /* row pitch of mag/real/imag */);
-int mpx_ola_fixup(void* stream, int fft_len, int32_t territory, const float* strips, int32_t n_utts,
-                  const int32_t* utt_chunk_off, const int32_t* strip_id, const int32_t* out_start,
-                  const int64_t* out_off, int32_t max_territories /* max over utterances of their territory count */,
+                               const float* imag, const mpx_ola_run* runs, int32_t n_runs, const int32_t* slot_off,
+                               const int32_t* slot_runs, int32_t n_slots, const int32_t* pm_rel, float* strips,
+                               float* pcm_out, int64_t ld /* row pitch of mag/real/imag */);
+int mpx_ola_fixup(void* stream, int fft_len, const mpx_ola_run* runs, int32_t n_runs, const float* strips,
                   float* pcm_out);
 
 /* ------------------------------------------------------------------------------------------------------------------
@@ -152,7 +167,7 @@ int mpx_noise_stats(void* stream, int fft_len, const void* tables, const float* 
 
 /*
  * Spectrum assembly + inverse FFT + anti-ringing window + PSOLA for compressed-feature synthesis
- * (magphase.py:908-976; chunk / slot / strip tables exactly as mpx_synthesis_lossless_ola, output through mpx_ola_fixup).
+ * (magphase.py:908-976; run / slot / strip tables and pcm_out exactly as mpx_synthesis_lossless_ola, followed by mpx_ola_fixup).
  * Per frame f (all arrays int32/float32[n_frames] unless noted):
  *   noise_pos(int64)/noise_left/noise_right/noise_wtype : this frame's noise frame (recomputed here)
  *   voiced, inv_gain                                    : class flag and 1/gain of its class
@@ -168,9 +183,9 @@ int mpx_synthesis_compressed_ola(void* stream, int fft_len, const void* tables, 
                                  const int32_t* voiced, const float* inv_gain, const int32_t* row0,
                                  const int32_t* row1, const float* row_t, const int32_t* win_left,
                                  const int32_t* win_right, const int32_t* pm_rel, const float* per_v,
-                                 const float* ap_v, const float* ap_u, const void* chunks, int32_t n_chunks,
-                                 const int32_t* slot_off, const int32_t* slot_chunks, int32_t n_slots,
-                                 int32_t territory, float* strips,
+                                 const float* ap_v, const float* ap_u, const mpx_ola_run* runs, int32_t n_runs,
+                                 const int32_t* slot_off, const int32_t* slot_runs, int32_t n_slots,
+                                 float* strips, float* pcm_out,
                                  int64_t ld /* row pitch of mag/real/imag in floats, >= fft_len/2 + 1 */);
 
 /* ------------------------------------------------------------------------------------------------------------------

@@ -20,6 +20,7 @@ SYMBOLS = (
     "mpx_synthesis_lossless_frames",
     "mpx_ola_gather",
     "mpx_synth_ola_slots",
+    "mpx_ola_strip_floats",
     "mpx_synthesis_lossless_ola",
     "mpx_ola_fixup",
     "mpx_mel_unwarp",
@@ -73,9 +74,11 @@ def load():
     lib.mpx_synthesis_lossless_ola.restype = ctypes.c_int
     lib.mpx_synth_ola_slots.restype = ctypes.c_int
     lib.mpx_synth_ola_slots.argtypes = []
-    lib.mpx_synthesis_lossless_ola.argtypes = [vp, ctypes.c_int, vp, vp, vp, vp, vp, i32, vp, vp, i32, vp, i32, vp, i64]
+    lib.mpx_ola_strip_floats.restype = i64
+    lib.mpx_ola_strip_floats.argtypes = [ctypes.c_int]
+    lib.mpx_synthesis_lossless_ola.argtypes = [vp, ctypes.c_int, vp, vp, vp, vp, vp, i32, vp, vp, i32, vp, vp, vp, i64]
     lib.mpx_ola_fixup.restype = ctypes.c_int
-    lib.mpx_ola_fixup.argtypes = [vp, ctypes.c_int, i32, vp, i32, vp, vp, vp, vp, i32, vp]
+    lib.mpx_ola_fixup.argtypes = [vp, ctypes.c_int, vp, i32, vp, vp]
     lib.mpx_mel_unwarp.restype = ctypes.c_int
     lib.mpx_mel_unwarp.argtypes = [vp, i64, i32, vp, i32, vp, vp, vp, vp, i32, vp, vp, vp, i64]
     lib.mpx_spec_ld.restype = i64
@@ -85,7 +88,7 @@ def load():
     lib.mpx_synth_comp_slots.restype = ctypes.c_int
     lib.mpx_synth_comp_slots.argtypes = []
     lib.mpx_synthesis_compressed_ola.restype = ctypes.c_int
-    lib.mpx_synthesis_compressed_ola.argtypes = [vp, ctypes.c_int, vp] + [vp] * 19 + [vp, i32, vp, vp, i32, i32, vp, i64]
+    lib.mpx_synthesis_compressed_ola.argtypes = [vp, ctypes.c_int, vp] + [vp] * 19 + [vp, i32, vp, vp, i32, vp, vp, i64]
     lib.mpx_mel_warp.restype = ctypes.c_int
     lib.mpx_mel_warp.argtypes = [vp, i64, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, vp, vp, vp, vp, i64]
     lib.mpx_min_phase.restype = ctypes.c_int

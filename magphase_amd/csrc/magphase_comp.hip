@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256) void k_mel_warp(WarpJobs jobs, long long F, in
 // frm_list_to_matrix + fftshift) -> N-point real FFT -> Ns[k] for the bins kappa(lane) + 64 j, j = 0..P-1
 // (natural j), plus the Nyquist bin (real) on the lane with kappa == 0.  Synchronous staging (no prefetch).
 template <int P, bool PRESTAGED = false>   // PRESTAGED: the caller already copied tile 0 into xbuf and waited for it
-__device__ __forceinline__ void noise_spectrum(const FrameGeom& g, int wtype, const float2* tw, float* xbuf,
+__device__ __forceinline__ void noise_spectrum(const FrameGeom& g, int wtype, const float* tw, float* xbuf,
                                                unsigned xbuf_byte, int lane, float wl_c, float wl_s,
                                                float (&nr)[P], float (&ni)[P], float& nM) {
     constexpr int M = 64 * P, N = 2 * M, LB = ilog2(P), kTile = 64 * P;
@@ -244,16 +244,16 @@ __global__ __launch_bounds__(kAnaThreads) void k_noise_stats(const float* __rest
                                                           const int* __restrict__ nleft,
                                                           const int* __restrict__ nright,
                                                           const int* __restrict__ wtype, long long nframes,
-                                                          const float2* __restrict__ tw_g,
+                                                          const float* __restrict__ tw_g,
                                                           float* __restrict__ out_sum) {
     constexpr int M = 64 * P, N = 2 * M;
-    extern __shared__ float smem[];
-    float2* tw = reinterpret_cast<float2*>(smem);
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* tw = smem;
     const int lane_id = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    float* xbuf = smem + P * 64 * 2 + wave * (P * kXStride);
-    const unsigned xbuf_byte = 4u * (unsigned)(P * 64 * 2 + rfl(wave) * (P * kXStride));
-    for (int i = threadIdx.x; i < P * 64; i += kAnaThreads) tw[i] = tw_g[i];
+    float* xbuf = smem + tw_floats<P>() + wave * (P * kXStride);
+    const unsigned xbuf_byte = 4u * (unsigned)(tw_floats<P>() + rfl(wave) * (P * kXStride));
+    for (int i = threadIdx.x; i < tw_floats<P>(); i += kAnaThreads) tw[i] = tw_g[i];
     __syncthreads();
     float wl_s0, wl_c0;
     sincospif(-2.0f * (float)kappa<P>(lane_id) / (float)N, &wl_s0, &wl_c0);
@@ -436,16 +436,16 @@ template <int P>
 __global__ __launch_bounds__(kThreads) void k_min_phase(const float* __restrict__ mag, const int* __restrict__ row0,
                                                         const int* __restrict__ row1,
                                                         const float* __restrict__ rowt, long long nframes,
-                                                        const float2* __restrict__ tw_g, float* __restrict__ omag,
+                                                        const float* __restrict__ tw_g, float* __restrict__ omag,
                                                         float* __restrict__ oreal, float* __restrict__ oimag,
                                                         long long ld) {
     constexpr int M = 64 * P, N = 2 * M, H = M + 1, LB = ilog2(P);
-    extern __shared__ float smem[];
-    float2* tw = reinterpret_cast<float2*>(smem);
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* tw = smem;
     const int lane_id = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    float* xbuf = smem + P * 64 * 2 + wave * (P * kXStride);
-    for (int i = threadIdx.x; i < P * 64; i += kThreads) tw[i] = tw_g[i];
+    float* xbuf = smem + tw_floats<P>() + wave * (P * kXStride);
+    for (int i = threadIdx.x; i < tw_floats<P>(); i += kThreads) tw[i] = tw_g[i];
     __syncthreads();
     float wa_s0, wa_c0, ws_s0, ws_c0;
     sincospif(-2.0f * (float)kappa<P>(lane_id) / (float)N, &wa_s0, &wa_c0);
@@ -584,7 +584,7 @@ constexpr int kCompPairWaves = 8;
 constexpr int kCompPairs = kCompPairWaves / 2;
 template <int P>
 constexpr size_t lds_bytes_comp_pair() {
-    return sizeof(float) * (size_t)(P * 64 * 2 + kCompPairWaves * (P * kXStride) + kCompPairs * ring_len<P>() + 16);
+    return sizeof(float) * (size_t)(tw_floats<P>() + kCompPairWaves * (P * kXStride) + kCompPairs * ring_len<P>() + 16);
 }
 
 template <int P>
@@ -596,32 +596,33 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_synth_comp_pair(const f
                                                                         const float* __restrict__ per_v,
                                                                         const float* __restrict__ ap_v,
                                                                         const float* __restrict__ ap_u,
-                                                                        const ChunkDesc* __restrict__ chunks,
+                                                                        const RunDesc* __restrict__ runs,
                                                                         const int* __restrict__ slot_off,
-                                                                        const int* __restrict__ slot_chunks,
-                                                                        int nslots, int T,
-                                                                        const float2* __restrict__ tw_g,
-                                                                        float* __restrict__ strips, long long ld) {
-    constexpr int M = 64 * P, N = 2 * M, LB = ilog2(P), R = ring_len<P>(), RH = R / 2;
-    extern __shared__ float smem[];
-    float2* tw = reinterpret_cast<float2*>(smem);
+                                                                        const int* __restrict__ slot_runs,
+                                                                        int nslots,
+                                                                        const float* __restrict__ tw_g,
+                                                                        float* __restrict__ strips,
+                                                                        float* __restrict__ pcm, long long ld) {
+    constexpr int M = 64 * P, N = 2 * M, R = ring_len<P>();
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* tw = smem;
     const int lane_id = threadIdx.x & 63;
     const int wave = rfl((int)(threadIdx.x >> 6));
     const int pair = wave >> 1, half = wave & 1;
-    float* xbuf = smem + P * 64 * 2 + wave * (P * kXStride);
-    const unsigned xbuf_byte = 4u * (unsigned)(P * 64 * 2 + wave * (P * kXStride));
-    float* ring = smem + P * 64 * 2 + kCompPairWaves * (P * kXStride) + pair * R;
-    int* turn = reinterpret_cast<int*>(smem + P * 64 * 2 + kCompPairWaves * (P * kXStride) + kCompPairs * R) + pair;
-    for (int i = threadIdx.x; i < P * 64; i += kCompPairWaves * 64) tw[i] = tw_g[i];
-    for (int i = threadIdx.x; i < kCompPairs * R; i += kCompPairWaves * 64)
-        smem[P * 64 * 2 + kCompPairWaves * (P * kXStride) + i] = 0.0f;
+    float* xbuf = smem + tw_floats<P>() + wave * (P * kXStride);
+    const unsigned xbuf_byte = 4u * (unsigned)(tw_floats<P>() + wave * (P * kXStride));
+    constexpr int kRing0 = tw_floats<P>() + kCompPairWaves * (P * kXStride);
+    float* ring = smem + kRing0 + pair * R;
+    const unsigned ring_byte = 4u * (unsigned)(kRing0 + pair * R);
+    int* turn = reinterpret_cast<int*>(smem + kRing0 + kCompPairs * R) + pair;
+    for (int i = threadIdx.x; i < tw_floats<P>(); i += kCompPairWaves * 64) tw[i] = tw_g[i];
+    for (int i = threadIdx.x; i < kCompPairs * R; i += kCompPairWaves * 64) smem[kRing0 + i] = 0.0f;
     if (threadIdx.x < kCompPairs) turn[threadIdx.x - pair] = 0;   // thread t < kCompPairs has pair == 0
     __syncthreads();
 
     float wa_s0, wa_c0, ws_s0, ws_c0;   // analysis-side lane twiddle W_N^kappa and synthesis-side conj(W_N^lane)
     sincospif(-2.0f * (float)kappa<P>(lane_id) / (float)N, &wa_s0, &wa_c0);
     sincospif(2.0f * (float)lane_id / (float)N, &ws_s0, &ws_c0);
-    const int strip_len = T + N;
     const int slot = blockIdx.x * kCompPairs + pair;
     if (slot >= nslots) return;
 
@@ -632,11 +633,10 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_synth_comp_pair(const f
     const int wi_end = slot_off[slot + 1];
     auto settle = [&](Cursor& c) {
         while (c.wi < wi_end) {
-            c.ci = slot_chunks[c.wi];
-            const ChunkDesc cd = chunks[c.ci];
-            c.fb = cd.frame_begin;
-            c.fe = cd.frame_end;
-            c.x0 = cd.x0;
+            c.ci = slot_runs[c.wi];
+            c.fb = runs[c.ci].frame_begin;
+            c.fe = runs[c.ci].frame_end;
+            c.x0 = runs[c.ci].x0;
             c.fi = c.fb + half;
             if (c.fi < c.fe) {
                 c.valid = 1;
@@ -787,58 +787,30 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_synth_comp_pair(const f
         const int n_lo = N / 2 - wl, n_hi = N / 2 + wr;   // support [n_lo, n_hi]
 
         // ---- ordered section: wait for this frame's ticket
-        float* strip = strips + (long long)cur.ci * strip_len;
+        const RunDesc rd = runs[cur.ci];
+        float* strip = strips + rd.strip_off;
+        float* pcm0 = pcm + rd.out_base;
         const int ticket = cur.ticket_base + (fi - cur.fb);
-        const int x = tb.pm_rel[fi] - cur.x0;   // in [0, T)
+        const int x = tb.pm_rel[fi] - cur.x0;   // strip position of the frame's first sample
         const int target = x & ~63;
         const int flushed = (fi == cur.fb) ? 0 : ((tb.pm_rel[fi - 1] - cur.x0) & ~63);
-        asm volatile("" ::"s"(x), "s"(flushed));
+        asm volatile("" ::"s"(x), "s"(flushed), "s"(rd.head_end), "s"(rd.out_lo), "s"(rd.out_hi), "s"(rd.flush_end));
         while (__hip_atomic_load(turn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != ticket)
             __builtin_amdgcn_s_sleep(1);
         asm volatile("" ::: "memory");
-        if (flushed < target) flush_ring<R>(ring, strip, flushed, target, strip_len, lane);
+        if (flushed < target) flush_ring<R>(ring, strip, pcm0, rd.head_end, rd.out_lo, rd.out_hi, flushed, target, lane);
         wave_sync();
-        {
-            const int kap = kappa<P>(lane);
-            const int odd = x & 1;
-            float* r0p = ring + (odd ? RH : 0);
-            float* r1p = ring + (odd ? 0 : RH);
-            const int c0 = ((x >> 1) % RH) + kap;
-            const int c1 = (((x + 1) >> 1) % RH) + kap;
-            float* pA0 = r0p + c0;
-            float* pB0 = pA0 - RH;
-            float* pA1 = r1p + c1;
-            float* pB1 = pA1 - RH;
-            const int w0i = (RH - c0 + 63) >> 6;   // first q with c0 + 64 q >= RH
-            const int w1i = (RH - c1 + 63) >> 6;
-            // register rows whose samples all lie outside the window support add nothing: skipped (wave-uniform).
-            // Reads of all active rows first, then window + add + write: one LDS latency per frame.
-            float o0[P], o1[P];
-#pragma unroll
-            for (int i = 0; i < P; ++i) {
-                const int q = brev(i, LB);
-                o0[i] = o1[i] = 0.0f;
-                if (128 * q + 127 < n_lo || 128 * q > n_hi) continue;
-                o0[i] = ((q >= w0i) ? pB0 : pA0)[64 * q];
-                o1[i] = ((q >= w1i) ? pB1 : pA1)[64 * q];
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int i = 0; i < P; ++i) {
-                const int q = brev(i, LB);
-                if (128 * q + 127 < n_lo || 128 * q > n_hi) continue;
-                // samples n = 2*(kap + 64 q) + e
-                const int n0 = 2 * (kap + 64 * q);
-                const int ks0 = n0 - n_lo, ks1 = n0 + 1 - n_lo;
-                const float w0 = (ks0 >= 0 && n0 <= n_hi) ? half_window(ks0, wl, wl + wr, kadd, inv_wl, inv_wr, 0) : 0.0f;
-                const float w1 = (ks1 >= 0 && n0 + 1 <= n_hi) ? half_window(ks1, wl, wl + wr, kadd, inv_wl, inv_wr, 0) : 0.0f;
-                ((q >= w0i) ? pB0 : pA0)[64 * q] = fmaf(xr[i], w0, o0[i]);
-                ((q >= w1i) ? pB1 : pA1)[64 * q] = fmaf(xi[i], w1, o1[i]);
-            }
-        }
+        // register rows whose samples all lie outside the window support add nothing: skipped (wave-uniform)
+        ring_add<P>(smem, ring_byte, x, xr, xi, lane,
+                    [&](float o, float v, int n) {
+                        const int ks = n - n_lo;
+                        const float w = (ks >= 0 && n <= n_hi) ? half_window(ks, wl, wl + wr, kadd, inv_wl, inv_wr, 0) : 0.0f;
+                        return fmaf(v, w, o);
+                    },
+                    [&](int q) { return !(128 * q + 127 < n_lo || 128 * q > n_hi); });
         wave_sync();
-        if (fi == cur.fe - 1) {   // last frame of the chunk: stream out the rest, leave the ring cleared
-            flush_ring<R>(ring, strip, target, strip_len, strip_len, lane);
+        if (fi == cur.fe - 1) {   // last frame of the run: stream out the rest, leave the ring cleared
+            flush_ring<R>(ring, strip, pcm0, rd.head_end, rd.out_lo, rd.out_hi, target, rd.flush_end, lane);
             wave_sync();
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1130,15 +1102,15 @@ int mpx_noise_stats(void* stream, int fft_len, const void* tables, const float* 
     if (P == 32) {
         if (int rc = set_lds(k_noise_stats<32>, lds_bytes_ana<32>())) return rc;
         hipLaunchKernelGGL(k_noise_stats<32>, grid, block, lds_bytes_ana<32>(), s, noise, (const long long*)frame_pos,
-                           frame_left, frame_right, frame_wtype, (long long)n_frames, (const float2*)tables, out_sum);
+                           frame_left, frame_right, frame_wtype, (long long)n_frames, (const float*)tables, out_sum);
     } else if (P == 16) {
         if (int rc = set_lds(k_noise_stats<16>, lds_bytes_ana<16>())) return rc;
         hipLaunchKernelGGL(k_noise_stats<16>, grid, block, lds_bytes_ana<16>(), s, noise, (const long long*)frame_pos,
-                           frame_left, frame_right, frame_wtype, (long long)n_frames, (const float2*)tables, out_sum);
+                           frame_left, frame_right, frame_wtype, (long long)n_frames, (const float*)tables, out_sum);
     } else {
         if (int rc = set_lds(k_noise_stats<8>, lds_bytes_ana<8>())) return rc;
         hipLaunchKernelGGL(k_noise_stats<8>, grid, block, lds_bytes_ana<8>(), s, noise, (const long long*)frame_pos,
-                           frame_left, frame_right, frame_wtype, (long long)n_frames, (const float2*)tables, out_sum);
+                           frame_left, frame_right, frame_wtype, (long long)n_frames, (const float*)tables, out_sum);
     }
     MPX_HIP_CHECK(hipGetLastError());
     return MPX_OK;
@@ -1152,43 +1124,34 @@ int mpx_synthesis_compressed_ola(void* stream, int fft_len, const void* tables, 
                                  const int32_t* voiced, const float* inv_gain, const int32_t* row0,
                                  const int32_t* row1, const float* row_t, const int32_t* win_left,
                                  const int32_t* win_right, const int32_t* pm_rel, const float* per_v,
-                                 const float* ap_v, const float* ap_u, const void* chunks, int32_t n_chunks,
-                                 const int32_t* slot_off, const int32_t* slot_chunks, int32_t n_slots,
-                                 int32_t territory, float* strips, int64_t ld) {
+                                 const float* ap_v, const float* ap_u, const mpx_ola_run* runs, int32_t n_runs,
+                                 const int32_t* slot_off, const int32_t* slot_runs, int32_t n_slots,
+                                 float* strips, float* pcm_out, int64_t ld) {
     const int P = p_of(fft_len);
     if (!P) return fail(MPX_ERR_ARG, "mpx_synthesis_compressed_ola: fft_len must be 1024, 2048 or 4096%s");
-    if (n_chunks < 0 || n_slots < 0) return fail(MPX_ERR_ARG, "mpx_synthesis_compressed_ola: negative count%s");
-    if (territory < fft_len / 2 || (territory % 64) != 0)
-        return fail(MPX_ERR_ARG, "mpx_synthesis_compressed_ola: territory must be a multiple of 64 and >= fft_len/2%s");
-    if (n_chunks == 0 || n_slots == 0) return MPX_OK;
+    if (n_runs < 0 || n_slots < 0) return fail(MPX_ERR_ARG, "mpx_synthesis_compressed_ola: negative count%s");
+    if (n_runs == 0 || n_slots == 0) return MPX_OK;
     if (!tables || !mag || !real || !imag || !noise || !noise_pos || !noise_left || !noise_right || !noise_wtype ||
         !voiced || !inv_gain || !row0 || !row1 || !row_t || !win_left || !win_right || !pm_rel || !per_v || !ap_v ||
-        !ap_u || !chunks || !slot_off || !slot_chunks || !strips)
+        !ap_u || !runs || !slot_off || !slot_runs || !strips || !pcm_out)
         return fail(MPX_ERR_ARG, "mpx_synthesis_compressed_ola: null pointer%s");
     CompFrameTabs tb{(const long long*)noise_pos, noise_left, noise_right, noise_wtype, voiced, inv_gain,
                      row0, row1, row_t, win_left, win_right, pm_rel};
     hipStream_t s = (hipStream_t)stream;
-    {
-        const dim3 pgrid((n_slots + kCompPairs - 1) / kCompPairs), pblock(kCompPairWaves * 64);
-        if (P == 32) {
-            if (int rc = set_lds(k_synth_comp_pair<32>, lds_bytes_comp_pair<32>())) return rc;
-            hipLaunchKernelGGL(k_synth_comp_pair<32>, pgrid, pblock, lds_bytes_comp_pair<32>(), s, mag, real, imag, noise,
-                               tb, per_v, ap_v, ap_u, (const ChunkDesc*)chunks, slot_off, slot_chunks, (int)n_slots,
-                               (int)territory, (const float2*)tables, strips, (long long)ld);
-        } else if (P == 16) {
-            if (int rc = set_lds(k_synth_comp_pair<16>, lds_bytes_comp_pair<16>())) return rc;
-            hipLaunchKernelGGL(k_synth_comp_pair<16>, pgrid, pblock, lds_bytes_comp_pair<16>(), s, mag, real, imag, noise,
-                               tb, per_v, ap_v, ap_u, (const ChunkDesc*)chunks, slot_off, slot_chunks, (int)n_slots,
-                               (int)territory, (const float2*)tables, strips, (long long)ld);
-        } else {
-            if (int rc = set_lds(k_synth_comp_pair<8>, lds_bytes_comp_pair<8>())) return rc;
-            hipLaunchKernelGGL(k_synth_comp_pair<8>, pgrid, pblock, lds_bytes_comp_pair<8>(), s, mag, real, imag, noise,
-                               tb, per_v, ap_v, ap_u, (const ChunkDesc*)chunks, slot_off, slot_chunks, (int)n_slots,
-                               (int)territory, (const float2*)tables, strips, (long long)ld);
-        }
-        MPX_HIP_CHECK(hipGetLastError());
-        return MPX_OK;
-    }
+    const dim3 pgrid((n_slots + kCompPairs - 1) / kCompPairs), pblock(kCompPairWaves * 64);
+#define MPX_LAUNCH_COMP(PP)                                                                                          \
+    do {                                                                                                             \
+        if (int rc = set_lds(k_synth_comp_pair<PP>, lds_bytes_comp_pair<PP>())) return rc;                           \
+        hipLaunchKernelGGL(k_synth_comp_pair<PP>, pgrid, pblock, lds_bytes_comp_pair<PP>(), s, mag, real, imag,      \
+                           noise, tb, per_v, ap_v, ap_u, (const RunDesc*)runs, slot_off, slot_runs, (int)n_slots,    \
+                           (const float*)tables, strips, pcm_out, (long long)ld);                                    \
+    } while (0)
+    if (P == 32) MPX_LAUNCH_COMP(32);
+    else if (P == 16) MPX_LAUNCH_COMP(16);
+    else MPX_LAUNCH_COMP(8);
+#undef MPX_LAUNCH_COMP
+    MPX_HIP_CHECK(hipGetLastError());
+    return MPX_OK;
 }
 
 int mpx_mel_warp(void* stream, int64_t n_frames, int32_t n_bins, const float* mag, const float* real, const float* imag,
@@ -1259,15 +1222,15 @@ int mpx_min_phase(void* stream, int fft_len, const void* tables, const float* ma
     if (P == 32) {
         if (int rc = set_lds(k_min_phase<32>, lds_bytes<32>())) return rc;
         hipLaunchKernelGGL(k_min_phase<32>, grid, block, lds_bytes<32>(), s, mag, row0, row1, row_t,
-                           (long long)n_frames, (const float2*)tables, out_mag, out_real, out_imag, (long long)ld);
+                           (long long)n_frames, (const float*)tables, out_mag, out_real, out_imag, (long long)ld);
     } else if (P == 16) {
         if (int rc = set_lds(k_min_phase<16>, lds_bytes<16>())) return rc;
         hipLaunchKernelGGL(k_min_phase<16>, grid, block, lds_bytes<16>(), s, mag, row0, row1, row_t,
-                           (long long)n_frames, (const float2*)tables, out_mag, out_real, out_imag, (long long)ld);
+                           (long long)n_frames, (const float*)tables, out_mag, out_real, out_imag, (long long)ld);
     } else {
         if (int rc = set_lds(k_min_phase<8>, lds_bytes<8>())) return rc;
         hipLaunchKernelGGL(k_min_phase<8>, grid, block, lds_bytes<8>(), s, mag, row0, row1, row_t,
-                           (long long)n_frames, (const float2*)tables, out_mag, out_real, out_imag, (long long)ld);
+                           (long long)n_frames, (const float*)tables, out_mag, out_real, out_imag, (long long)ld);
     }
     MPX_HIP_CHECK(hipGetLastError());
     return MPX_OK;

@@ -7,6 +7,7 @@
 //   k_synth_lossless<P>     one wavefront per frame: 3 x H coalesced loads -> unit-phase spectrum ->
 //                           Hermitian merge -> inverse FFT -> epoch-centred frame.      HBM-read bound.
 //   k_ola_gather            one thread per output sample, ascending-frame gather (deterministic PSOLA).
+//   k_synth_ola_pair<P>     the production form: synthesis + PSOLA fused, one LDS ring per wave pair (below).
 // No MFMA in this file: nothing on the lossless path is a dense contraction; the mel
 // warp / unwarp GEMMs of the compressed path (magphase_comp.hip) run on the fp32 MFMA.
 #include "mpx_common.hpp"
@@ -18,18 +19,18 @@ __global__ __launch_bounds__(kAnaThreads) void k_analysis(const float* __restric
                                                           const long long* __restrict__ fpos,
                                                           const int* __restrict__ fleft,
                                                           const int* __restrict__ fright, long long nframes,
-                                                          const float2* __restrict__ tw_g, float* __restrict__ omag,
+                                                          const float* __restrict__ tw_g, float* __restrict__ omag,
                                                           float* __restrict__ oreal, float* __restrict__ oimag,
                                                           long long ld) {
     constexpr int M = 64 * P, N = 2 * M, LB = ilog2(P), kTile = 64 * P;
-    extern __shared__ float smem[];
-    float2* tw = reinterpret_cast<float2*>(smem);
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* tw = smem;
     const int lane_id = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    float* xbuf = smem + P * 64 * 2 + wave * (P * kXStride);
+    float* xbuf = smem + tw_floats<P>() + wave * (P * kXStride);
     // byte address of xbuf in LDS (the dynamic segment starts at 0: the kernel has no static __shared__)
-    const unsigned xbuf_byte = 4u * (unsigned)(P * 64 * 2 + rfl(wave) * (P * kXStride));
-    for (int i = threadIdx.x; i < P * 64; i += kAnaThreads) tw[i] = tw_g[i];
+    const unsigned xbuf_byte = 4u * (unsigned)(tw_floats<P>() + rfl(wave) * (P * kXStride));
+    for (int i = threadIdx.x; i < tw_floats<P>(); i += kAnaThreads) tw[i] = tw_g[i];
     __syncthreads();
 
     // lane part of the split twiddle W_N^kappa = e^{-2 pi i kappa / N}
@@ -208,7 +209,14 @@ __global__ __launch_bounds__(kAnaThreads) void k_analysis(const float* __restric
 #endif
         }
         g = gn;
-        if (fn < nframes) staged_wait<63>();   // >= 63 stores were issued after the copy: it has landed
+        // The epilogue issued 3P + 3 stores after the copy's loads (3 per step q for X[k], 3 for bin M or a mirror block,
+        // 3 for the last block): at most that many operations outstanding <=> the copy has landed.  (P = 32: 99 > 63,
+        // the counter's range; P = 16 / 8: 51 / 27 -- a fixed 63 would not wait at all there.)
+#ifdef MPX_PROBE_NOSTORE
+        if (fn < nframes) staged_wait<0>();
+#else
+        if (fn < nframes) staged_wait<3 * P + 3>();
+#endif
     }
 }
 
@@ -219,15 +227,15 @@ template <int P>
 __global__ __launch_bounds__(kThreads) void k_synth_lossless(const float* __restrict__ mag,
                                                              const float* __restrict__ real,
                                                              const float* __restrict__ imag, long long nframes,
-                                                             const float2* __restrict__ tw_g,
+                                                             const float* __restrict__ tw_g,
                                                              float* __restrict__ frames, long long ld) {
     constexpr int M = 64 * P, N = 2 * M, H = M + 1, LB = ilog2(P);
-    extern __shared__ float smem[];
-    float2* tw = reinterpret_cast<float2*>(smem);
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* tw = smem;
     const int lane_id = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    float* xbuf = smem + P * 64 * 2 + wave * (P * kXStride);
-    for (int i = threadIdx.x; i < P * 64; i += kThreads) tw[i] = tw_g[i];
+    float* xbuf = smem + tw_floats<P>() + wave * (P * kXStride);
+    for (int i = threadIdx.x; i < tw_floats<P>(); i += kThreads) tw[i] = tw_g[i];
     __syncthreads();
 
     // input layout is natural (k = lane + 64 j): lane twiddle conj(W_N^lane) = e^{+2 pi i lane/N}
@@ -256,24 +264,18 @@ __global__ __launch_bounds__(kThreads) void k_synth_lossless(const float* __rest
 }
 
 // ---------------------------------------------------------------------------------------------
-// fused lossless synthesis + PSOLA.  One wavefront owns one CHUNK = the consecutive frames of one
-// utterance whose centres fall in a territory of T samples of the reference's OLA buffer; a PAIR of wavefronts owns a
-// work list of chunks and alternates over their frames (k_synth_ola_pair below; the single-wave form it replaced is
-// in the history: 5 waves per CU, 0.53 ms); each frame is rebuilt
-// each frame (as k_synth_lossless) and overlap-adds it, in ascending frame order, into a ring buffer in
-// LDS, streaming the finished part out to the chunk's private strip (T + N floats: the territory plus
-// N/2 of halo on each side).  k_ola_fixup then sums the <= 3 strips covering each output sample.
-// HBM traffic: features read once, (T+N)/T * 4 B per output sample written -- the [F x N] frame
-// scratch of the two-kernel path (16 KB per frame written + read) is gone.
-// ---------------------------------------------------------------------------------------------
-
-// ---------------------------------------------------------------------------------------------
-// k_synth_ola_pair: same work as k_synth_ola, but TWO wavefronts share one chunk and one LDS ring: they take
-// alternate frames, rebuild them concurrently, and enter the overlap-add strictly in frame order (a ticket word
-// in LDS; LDS serves one CU's waves in order, so "ticket seen" implies the partner's ring writes are done).
-// Why: the ring (16.5 KB) limits k_synth_ola to 5 waves per CU = 1.25 per SIMD, and a lone wave cannot hide its own
-// LDS / memory latencies (measured 53 % issue-active).  Sharing the ring gives 8 waves per CU in the same LDS.
-// Summation order is unchanged (ascending frames), so results are bit-identical to k_synth_ola.
+// Fused lossless synthesis + PSOLA.  The frames of every utterance are cut into RUNS of consecutive frames (host:
+// hostmath.ola_runs -- about total_frames / wave-pair-slots frames each, so every slot gets one run of equal length);
+// a PAIR of wavefronts owns a run: the two waves rebuild alternate frames concurrently (as k_synth_lossless) and enter
+// the overlap-add strictly in frame order (a ticket word in LDS; LDS serves one CU's waves in order, so "ticket seen"
+// implies the partner's ring writes are done).  The sum lives in a ring buffer in LDS; what no later frame of the run
+// can reach any more streams out -- straight to pcm_out for the positions only this run (or this run first) contributes
+// to, to a small head strip for the first <= N positions, which the previous run's last frames also reach;
+// k_ola_fixup adds those strips afterwards (previous run's sum + head strip: fixed order, deterministic).
+// Why pairs: one ring per wave (16.5 KB) would cap the kernel at 5 waves per CU, and a lone wave cannot hide its own LDS /
+// memory latencies.  HBM traffic: features read once, every output sample written once, + (N + 64) floats written and
+// read once more per run boundary (the [F x N] frame scratch of the two-kernel form, 16 KB per frame each way, and the
+// territory strips of the first fused form, T + N floats per T output samples each way, are gone).
 // ---------------------------------------------------------------------------------------------
 #ifndef MPX_SYN_PAIR_WAVES
 #define MPX_SYN_PAIR_WAVES 8
@@ -289,53 +291,52 @@ constexpr int kPairs = kPairWaves / kGroup;      // rings (= work-list slots) pe
 static_assert(kPairWaves % kGroup == 0, "waves per workgroup must be a multiple of the group size");
 template <int P>
 constexpr size_t lds_bytes_pair() {
-    return sizeof(float) * (size_t)(P * 64 * 2 + kPairWaves * (P * kXStride) + kPairs * ring_len<P>() + 16);
+    return sizeof(float) * (size_t)(tw_floats<P>() + kPairWaves * (P * kXStride) + kPairs * ring_len<P>() + 16);
 }
 
 template <int P>
 __global__ __launch_bounds__(kPairWaves * 64) void k_synth_ola_pair(const float* __restrict__ mag,
                                                                     const float* __restrict__ real,
                                                                     const float* __restrict__ imag,
-                                                                    const ChunkDesc* __restrict__ chunks,
+                                                                    const RunDesc* __restrict__ runs,
                                                                     const int* __restrict__ slot_off,
-                                                                    const int* __restrict__ slot_chunks, int nslots,
-                                                                    const int* __restrict__ pm_rel, int T,
-                                                                    const float2* __restrict__ tw_g,
-                                                                    float* __restrict__ strips, long long ld) {
-    constexpr int M = 64 * P, N = 2 * M, H = M + 1, LB = ilog2(P), R = ring_len<P>();
-    extern __shared__ float smem[];
-    float2* tw = reinterpret_cast<float2*>(smem);
+                                                                    const int* __restrict__ slot_runs, int nslots,
+                                                                    const int* __restrict__ pm_rel,
+                                                                    const float* __restrict__ tw_g,
+                                                                    float* __restrict__ strips,
+                                                                    float* __restrict__ pcm, long long ld) {
+    constexpr int M = 64 * P, N = 2 * M, R = ring_len<P>();
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* tw = smem;
     const int lane_id = threadIdx.x & 63;
     const int wave = rfl(threadIdx.x >> 6);
     const int pair = wave / kGroup, half = wave % kGroup;   // ring, member index
-    float* xbuf = smem + P * 64 * 2 + wave * (P * kXStride);
-    float* ring = smem + P * 64 * 2 + kPairWaves * (P * kXStride) + pair * R;
-    int* turn = reinterpret_cast<int*>(smem + P * 64 * 2 + kPairWaves * (P * kXStride) + kPairs * R) + pair;
-    for (int i = threadIdx.x; i < P * 64; i += kPairWaves * 64) tw[i] = tw_g[i];
-    for (int i = threadIdx.x; i < kPairs * R; i += kPairWaves * 64)
-        smem[P * 64 * 2 + kPairWaves * (P * kXStride) + i] = 0.0f;
+    float* xbuf = smem + tw_floats<P>() + wave * (P * kXStride);
+    constexpr int kRing0 = tw_floats<P>() + kPairWaves * (P * kXStride);   // first ring (floats from the LDS base)
+    float* ring = smem + kRing0 + pair * R;
+    const unsigned ring_byte = 4u * (unsigned)(kRing0 + pair * R);
+    int* turn = reinterpret_cast<int*>(smem + kRing0 + kPairs * R) + pair;
+    for (int i = threadIdx.x; i < tw_floats<P>(); i += kPairWaves * 64) tw[i] = tw_g[i];
+    for (int i = threadIdx.x; i < kPairs * R; i += kPairWaves * 64) smem[kRing0 + i] = 0.0f;
     if (threadIdx.x < kPairs) turn[threadIdx.x - pair] = 0;   // thread t < kPairs has pair == 0
     __syncthreads();
 
     float wl_s0, wl_c0;
     sincospif(2.0f * (float)lane_id / (float)N, &wl_s0, &wl_c0);
-    const int strip_len = T + N;
     const int slot = blockIdx.x * kPairs + pair;
     if (slot >= nslots) return;
 
-    // Cursor over this wave's frames: every second frame of every chunk of the pair's work list, as ONE stream, so
-    // that the feature prefetch runs across chunk boundaries (no per-chunk start-up bubble).
+    // Cursor over this wave's frames: every second frame of every run of the pair's work list, as ONE stream.
     struct Cursor {   // plain ints only: a bool member made the struct copies go through scratch (VMEM -> vmcnt waits)
         int wi, fi, ci, ticket_base, fb, fe, x0, valid;
     };
     const int wi_end = slot_off[slot + 1];
-    auto settle = [&](Cursor& c) {   // move to the first chunk (from c.wi on) that has a frame for this wave
+    auto settle = [&](Cursor& c) {   // move to the first run (from c.wi on) that has a frame for this wave
         while (c.wi < wi_end) {
-            c.ci = slot_chunks[c.wi];
-            const ChunkDesc cd = chunks[c.ci];
-            c.fb = cd.frame_begin;
-            c.fe = cd.frame_end;
-            c.x0 = cd.x0;
+            c.ci = slot_runs[c.wi];
+            c.fb = runs[c.ci].frame_begin;
+            c.fe = runs[c.ci].frame_end;
+            c.x0 = runs[c.ci].x0;
             c.fi = c.fb + half;
             if (c.fi < c.fe) {
                 c.valid = 1;
@@ -369,73 +370,39 @@ __global__ __launch_bounds__(kPairWaves * 64) void k_synth_ola_pair(const float*
 
         // Features are loaded right where they are used: no register prefetch.  With two waves per SIMD the partner
         // wave covers the memory latency (a prefetch behind the FFT measured 4 % SLOWER), and the 99 registers are
-        // worth more as room to keep many LDS operations in flight -- this kernel's stalls are LDS latency
-        // (bpermutes of the merge, the exchange, the ring's read-add-write), not HBM.
-        FrameFeat<P> ff;
+        // worth more as room to keep many LDS operations in flight.
+        PairFeat<P> ff;
         {
             const long long f = cur.fi;
-            feat_load<P>(ff, mag + f * ld, real + f * ld, imag + f * ld, lane);
+            feat_load_paired<P>(ff, mag + f * ld, real + f * ld, imag + f * ld, lane);
         }
-        float xr[P], xi[P], xm;
-        feat_convert<P>(ff, xr, xi, xm, lane);
-        hermitian_merge<P>(xr, xi, xm, lane, wl_c, wl_s);
+        float xr[P], xi[P];
+        feat_merge_paired<P>(ff, xr, xi, lane, wl_c, wl_s);
         wave_fft<P, +1>(xr, xi, tw, xbuf, lane);
 
         // ---- ordered section: wait for this frame's ticket
         const int fi = cur.fi;
-        float* strip = strips + (long long)cur.ci * strip_len;
         const int ticket = cur.ticket_base + (fi - cur.fb);
-        // frame positions first: their (scalar) loads must not sit behind the ticket inside the ordered section
-        const int x = pm_rel[fi] - cur.x0;   // in [0, T)
+        // run geometry and frame positions first: their (scalar) loads must not sit behind the ticket
+        const RunDesc rd = runs[cur.ci];
+        float* strip = strips + rd.strip_off;
+        float* pcm0 = pcm + rd.out_base;
+        const int x = pm_rel[fi] - cur.x0;   // strip position of the frame's first sample
         const int target = x & ~63;
         const int flushed = (fi == cur.fb) ? 0 : ((pm_rel[fi - 1] - cur.x0) & ~63);
-        asm volatile("" ::"s"(x), "s"(flushed));
+        asm volatile("" ::"s"(x), "s"(flushed), "s"(rd.head_end), "s"(rd.out_lo), "s"(rd.out_hi), "s"(rd.flush_end));
 #ifndef MPX_PROBE_NOTICKET
         while (__hip_atomic_load(turn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != ticket)
             __builtin_amdgcn_s_sleep(1);
 #endif
         asm volatile("" ::: "memory");
-        if (flushed < target) flush_ring<R>(ring, strip, flushed, target, strip_len, lane);
+        if (flushed < target) flush_ring<R>(ring, strip, pcm0, rd.head_end, rd.out_lo, rd.out_hi, flushed, target, lane);
         wave_sync();
-        {
-            constexpr int RH = R / 2;
-            const int kap = kappa<P>(lane);
-            const int odd = x & 1;
-            float* r0 = ring + (odd ? RH : 0);
-            float* r1 = ring + (odd ? 0 : RH);
-            // element i of a plane sits at ring index (c + 64 b) mod RH, b = brev(i), c = cb + kappa: no index arrays --
-            // the un-wrapped / wrapped base pointers pA / pB = pA - RH are selected per element (the wrap point differs
-            // by at most one b between lanes) and 64 b goes into the instruction's immediate offset.
-            const int c0 = ((x >> 1) % RH) + kap;
-            const int c1 = (((x + 1) >> 1) % RH) + kap;
-            float* pA0 = r0 + c0;
-            float* pB0 = pA0 - RH;
-            float* pA1 = r1 + c1;
-            float* pB1 = pA1 - RH;
-            const int w0 = (RH - c0 + 63) >> 6;   // first b with c0 + 64 b >= RH
-            const int w1 = (RH - c1 + 63) >> 6;
-            // read all ring values first, then add, then write: one LDS latency instead of 2P dependent chains
-            constexpr int kRingBatch = P;
-#pragma unroll
-            for (int i0 = 0; i0 < P; i0 += kRingBatch) {
-                float o0[kRingBatch], o1[kRingBatch];
-#pragma unroll
-                for (int i = 0; i < kRingBatch; ++i) {
-                    const int bq = brev(i0 + i, LB);
-                    o0[i] = ((bq >= w0) ? pB0 : pA0)[64 * bq];
-                    o1[i] = ((bq >= w1) ? pB1 : pA1)[64 * bq];
-                }
-#pragma unroll
-                for (int i = 0; i < kRingBatch; ++i) {
-                    const int bq = brev(i0 + i, LB);
-                    ((bq >= w0) ? pB0 : pA0)[64 * bq] = o0[i] + xr[i0 + i];
-                    ((bq >= w1) ? pB1 : pA1)[64 * bq] = o1[i] + xi[i0 + i];
-                }
-            }
-        }
+        ring_add<P>(smem, ring_byte, x, xr, xi, lane, [](float o, float v, int) { return o + v; },
+                    [](int) { return true; });
         wave_sync();
-        if (fi == cur.fe - 1) {   // last frame of the chunk: stream out the rest, leave the ring cleared
-            flush_ring<R>(ring, strip, target, strip_len, strip_len, lane);
+        if (fi == cur.fe - 1) {   // last frame of the run: stream out the rest, leave the ring cleared
+            flush_ring<R>(ring, strip, pcm0, rd.head_end, rd.out_lo, rd.out_hi, target, rd.flush_end, lane);
             wave_sync();
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -444,39 +411,19 @@ __global__ __launch_bounds__(kPairWaves * 64) void k_synth_ola_pair(const float*
     }
 }
 
-// out[t] = sum over the strips of chunks c-1, c, c+1 (c = territory of b = t + out_start) -- fixed order.
-__global__ __launch_bounds__(256) void k_ola_fixup(const float* __restrict__ strips, int N, int T,
-                                                   const int* __restrict__ utt_chunk_off,
-                                                   const int* __restrict__ strip_id,
-                                                   const int* __restrict__ out_start,
-                                                   const long long* __restrict__ out_off,
+// pcm_out[out_base + e] += head strip[e], fix_lo <= e < fix_hi, for every run that has a predecessor in its utterance:
+// the predecessor's tail sum (already in pcm_out) + this run's head sum, in that order.  One block per (run, 1024 elements).
+__global__ __launch_bounds__(256) void k_ola_fixup(const RunDesc* __restrict__ runs, const float* __restrict__ strips,
                                                    float* __restrict__ pcm) {
-    // One block per (utterance, territory): the three strip ids are block-uniform, every load is independent.
-    const int u = blockIdx.y;
-    const int c = blockIdx.x;
-    const int c0 = utt_chunk_off[u], nc = utt_chunk_off[u + 1] - c0;
-    const long long o0 = out_off[u];
-    const long long len = out_off[u + 1] - o0;
-    const long long start = out_start[u];
-    if ((long long)c * T >= start + len) return;   // no output sample in this territory
-    const int strip_len = T + N;
-    // territories at or beyond nc hold no frame: their output samples (the reference's zero tail) are written as 0
-    const int sid_p = (c > 0 && c - 1 < nc) ? strip_id[c0 + c - 1] : -1;
-    const int sid_o = (c < nc) ? strip_id[c0 + c] : -1;
-    const int sid_n = (c + 1 < nc) ? strip_id[c0 + c + 1] : -1;
-    const float* sp = strips + (long long)max(sid_p, 0) * strip_len;
-    const float* so = strips + (long long)max(sid_o, 0) * strip_len;
-    const float* sn = strips + (long long)max(sid_n, 0) * strip_len;
-    // territory sample r = b - c*T in [0, T): strip indices  prev: r + T + N/2 (valid r < N/2),  own: r + N/2,
-    // next: r - T + N/2 (valid r >= T - N/2); summed in the order prev, own, next (fixed -> deterministic)
-    for (int r = threadIdx.x; r < T; r += 256) {
-        const long long t = (long long)c * T + r - start;   // output index of buffer position b = c*T + r
-        if (t < 0 || t >= len) continue;
-        float acc = 0.0f;
-        if (sid_p >= 0 && r < N / 2) acc += sp[r + T + N / 2];
-        if (sid_o >= 0) acc += so[r + N / 2];
-        if (sid_n >= 0 && r >= T - N / 2) acc += sn[r - T + N / 2];
-        pcm[o0 + t] = acc;
+    const RunDesc rd = runs[blockIdx.x];
+    const int e0 = (rd.fix_lo & ~63) + (int)blockIdx.y * 1024;
+    if (e0 >= rd.fix_hi) return;
+    const float* strip = strips + rd.strip_off;
+    float* out = pcm + rd.out_base;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int e = e0 + 256 * r + (int)threadIdx.x;
+        if (e >= rd.fix_lo && e < rd.fix_hi) out[e] += strip[e];
     }
 }
 
@@ -512,6 +459,27 @@ __global__ __launch_bounds__(256) void k_ola_gather(const float* __restrict__ fr
     pcm[o0 + t] = acc;
 }
 
+// First-pass twiddle table (layout: wave_fft.hpp): row = lane l, entry i = e^{2 pi i l brev(i) / M} as (cos, sin), rows
+// padded to 2P + 4 floats (pad zeroed).  One block per lane, one thread per entry.
+__global__ void k_tables_init(int P, float* __restrict__ tab) {
+    const int l = blockIdx.x, i = threadIdx.x;
+    const int M = 64 * P, stride = 2 * P + 4;
+    int lb = 0;
+    while ((1 << lb) < P) ++lb;
+    if (i < P) {
+        int k1 = 0;
+        for (int b = 0; b < lb; ++b) k1 |= ((i >> b) & 1) << (lb - 1 - b);
+        const int r = (int)(((long long)l * k1) % M);
+        double sn, cs;
+        sincospi(2.0 * (double)r / (double)M, &sn, &cs);
+        tab[l * stride + 2 * i + 0] = (float)cs;
+        tab[l * stride + 2 * i + 1] = (float)sn;
+    } else if (i < P + 2) {
+        tab[l * stride + 2 * i + 0] = 0.0f;
+        tab[l * stride + 2 * i + 1] = 0.0f;
+    }
+}
+
 }  // namespace mpx
 
 using namespace mpx;
@@ -524,25 +492,16 @@ const char* mpx_last_error(void) { return g_err; }
 
 size_t mpx_tables_bytes(int fft_len) {
     const int P = p_of(fft_len);
-    return P ? sizeof(float) * 2 * 64 * (size_t)P : 0;
+    return P ? sizeof(float) * 64 * (size_t)(2 * P + 4) : 0;
 }
 
 int mpx_tables_init(void* stream, int fft_len, void* tables) {
     const int P = p_of(fft_len);
     if (!P) return fail(MPX_ERR_ARG, "mpx_tables_init: fft_len must be 1024, 2048 or 4096%s");
     if (!tables) return fail(MPX_ERR_ARG, "mpx_tables_init: null tables%s");
-    const int M = 64 * P;
-    std::vector<float> h(2 * 64 * (size_t)P);
-    for (int k1 = 0; k1 < P; ++k1)
-        for (int l = 0; l < 64; ++l) {
-            const double a = 2.0 * M_PI * (double)((long long)l * k1 % M) / (double)M;
-            h[2 * (k1 * 64 + l) + 0] = (float)std::cos(a);
-            h[2 * (k1 * 64 + l) + 1] = (float)std::sin(a);
-        }
-    // pageable source: hipMemcpyAsync stages it before returning, so the local vector may die
-    MPX_HIP_CHECK(hipMemcpyAsync(tables, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice,
-                                 (hipStream_t)stream));
-    MPX_HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+    // built on the device (float64 sincospi, rounded once): nothing is copied from the host, nothing synchronises
+    hipLaunchKernelGGL(k_tables_init, dim3(64), dim3(64), 0, (hipStream_t)stream, P, (float*)tables);
+    MPX_HIP_CHECK(hipGetLastError());
     return MPX_OK;
 }
 
@@ -566,17 +525,17 @@ int mpx_analysis_frames(void* stream, int fft_len, const void* tables, const flo
     if (P == 32) {
         if (int rc = set_lds(k_analysis<32>, lds_bytes_ana<32>())) return rc;
         hipLaunchKernelGGL(k_analysis<32>, grid, block, lds_bytes_ana<32>(), s, sig, (const long long*)frame_pos,
-                           frame_left, frame_right, (long long)n_frames, (const float2*)tables, out_mag, out_real,
+                           frame_left, frame_right, (long long)n_frames, (const float*)tables, out_mag, out_real,
                            out_imag, (long long)ld);
     } else if (P == 16) {
         if (int rc = set_lds(k_analysis<16>, lds_bytes_ana<16>())) return rc;
         hipLaunchKernelGGL(k_analysis<16>, grid, block, lds_bytes_ana<16>(), s, sig, (const long long*)frame_pos,
-                           frame_left, frame_right, (long long)n_frames, (const float2*)tables, out_mag, out_real,
+                           frame_left, frame_right, (long long)n_frames, (const float*)tables, out_mag, out_real,
                            out_imag, (long long)ld);
     } else {
         if (int rc = set_lds(k_analysis<8>, lds_bytes_ana<8>())) return rc;
         hipLaunchKernelGGL(k_analysis<8>, grid, block, lds_bytes_ana<8>(), s, sig, (const long long*)frame_pos,
-                           frame_left, frame_right, (long long)n_frames, (const float2*)tables, out_mag, out_real,
+                           frame_left, frame_right, (long long)n_frames, (const float*)tables, out_mag, out_real,
                            out_imag, (long long)ld);
     }
     MPX_HIP_CHECK(hipGetLastError());
@@ -597,15 +556,15 @@ int mpx_synthesis_lossless_frames(void* stream, int fft_len, const void* tables,
     if (P == 32) {
         if (int rc = set_lds(k_synth_lossless<32>, lds_bytes<32>())) return rc;
         hipLaunchKernelGGL(k_synth_lossless<32>, grid, block, lds_bytes<32>(), s, mag, real, imag,
-                           (long long)n_frames, (const float2*)tables, frames_out, (long long)ld);
+                           (long long)n_frames, (const float*)tables, frames_out, (long long)ld);
     } else if (P == 16) {
         if (int rc = set_lds(k_synth_lossless<16>, lds_bytes<16>())) return rc;
         hipLaunchKernelGGL(k_synth_lossless<16>, grid, block, lds_bytes<16>(), s, mag, real, imag,
-                           (long long)n_frames, (const float2*)tables, frames_out, (long long)ld);
+                           (long long)n_frames, (const float*)tables, frames_out, (long long)ld);
     } else {
         if (int rc = set_lds(k_synth_lossless<8>, lds_bytes<8>())) return rc;
         hipLaunchKernelGGL(k_synth_lossless<8>, grid, block, lds_bytes<8>(), s, mag, real, imag,
-                           (long long)n_frames, (const float2*)tables, frames_out, (long long)ld);
+                           (long long)n_frames, (const float*)tables, frames_out, (long long)ld);
     }
     MPX_HIP_CHECK(hipGetLastError());
     return MPX_OK;
@@ -629,57 +588,46 @@ int mpx_ola_gather(void* stream, int fft_len, const float* frames, int32_t n_utt
 
 int mpx_synth_ola_slots(void) { return device_cus() * kPairs; }
 
+int64_t mpx_ola_strip_floats(int fft_len) { return p_of(fft_len) ? (int64_t)fft_len + 64 : 0; }
+
 int mpx_synthesis_lossless_ola(void* stream, int fft_len, const void* tables, const float* mag, const float* real,
-                               const float* imag, const void* chunks, int32_t n_chunks, const int32_t* slot_off,
-                               const int32_t* slot_chunks, int32_t n_slots, const int32_t* pm_rel,
-                               int32_t territory, float* strips, int64_t ld) {
+                               const float* imag, const mpx_ola_run* runs, int32_t n_runs, const int32_t* slot_off,
+                               const int32_t* slot_runs, int32_t n_slots, const int32_t* pm_rel, float* strips,
+                               float* pcm_out, int64_t ld) {
     const int P = p_of(fft_len);
     if (!P) return fail(MPX_ERR_ARG, "mpx_synthesis_lossless_ola: fft_len must be 1024, 2048 or 4096%s");
-    if (n_chunks < 0 || n_slots < 0) return fail(MPX_ERR_ARG, "mpx_synthesis_lossless_ola: negative count%s");
+    if (n_runs < 0 || n_slots < 0) return fail(MPX_ERR_ARG, "mpx_synthesis_lossless_ola: negative count%s");
     if (ld < fft_len / 2 + 1) return fail(MPX_ERR_ARG, "mpx_synthesis_lossless_ola: ld < fft_len/2 + 1%s");
-    if (territory < fft_len / 2 || (territory % 64) != 0)
-        return fail(MPX_ERR_ARG, "mpx_synthesis_lossless_ola: territory must be a multiple of 64 and >= fft_len/2%s");
-    if (n_chunks == 0 || n_slots == 0) return MPX_OK;
-    if (!tables || !mag || !real || !imag || !chunks || !slot_off || !slot_chunks || !pm_rel || !strips)
+    if (n_runs == 0 || n_slots == 0) return MPX_OK;
+    if (!tables || !mag || !real || !imag || !runs || !slot_off || !slot_runs || !pm_rel || !strips || !pcm_out)
         return fail(MPX_ERR_ARG, "mpx_synthesis_lossless_ola: null pointer%s");
     hipStream_t s = (hipStream_t)stream;
-    {
-        const dim3 grid((n_slots + kPairs - 1) / kPairs), block(kPairWaves * 64);
-        if (P == 32) {
-            if (int rc = set_lds(k_synth_ola_pair<32>, lds_bytes_pair<32>())) return rc;
-            hipLaunchKernelGGL(k_synth_ola_pair<32>, grid, block, lds_bytes_pair<32>(), s, mag, real, imag,
-                               (const ChunkDesc*)chunks, slot_off, slot_chunks, (int)n_slots, pm_rel, (int)territory,
-                               (const float2*)tables, strips, (long long)ld);
-        } else if (P == 16) {
-            if (int rc = set_lds(k_synth_ola_pair<16>, lds_bytes_pair<16>())) return rc;
-            hipLaunchKernelGGL(k_synth_ola_pair<16>, grid, block, lds_bytes_pair<16>(), s, mag, real, imag,
-                               (const ChunkDesc*)chunks, slot_off, slot_chunks, (int)n_slots, pm_rel, (int)territory,
-                               (const float2*)tables, strips, (long long)ld);
-        } else {
-            if (int rc = set_lds(k_synth_ola_pair<8>, lds_bytes_pair<8>())) return rc;
-            hipLaunchKernelGGL(k_synth_ola_pair<8>, grid, block, lds_bytes_pair<8>(), s, mag, real, imag,
-                               (const ChunkDesc*)chunks, slot_off, slot_chunks, (int)n_slots, pm_rel, (int)territory,
-                               (const float2*)tables, strips, (long long)ld);
-        }
-        MPX_HIP_CHECK(hipGetLastError());
-        return MPX_OK;
-    }
+    const dim3 grid((n_slots + kPairs - 1) / kPairs), block(kPairWaves * 64);
+#define MPX_LAUNCH_PAIR(PP)                                                                                          \
+    do {                                                                                                             \
+        if (int rc = set_lds(k_synth_ola_pair<PP>, lds_bytes_pair<PP>())) return rc;                                 \
+        hipLaunchKernelGGL(k_synth_ola_pair<PP>, grid, block, lds_bytes_pair<PP>(), s, mag, real, imag,              \
+                           (const RunDesc*)runs, slot_off, slot_runs, (int)n_slots, pm_rel, (const float*)tables,    \
+                           strips, pcm_out, (long long)ld);                                                          \
+    } while (0)
+    if (P == 32) MPX_LAUNCH_PAIR(32);
+    else if (P == 16) MPX_LAUNCH_PAIR(16);
+    else MPX_LAUNCH_PAIR(8);
+#undef MPX_LAUNCH_PAIR
+    MPX_HIP_CHECK(hipGetLastError());
+    return MPX_OK;
 }
 
-int mpx_ola_fixup(void* stream, int fft_len, int32_t territory, const float* strips, int32_t n_utts,
-                  const int32_t* utt_chunk_off, const int32_t* strip_id, const int32_t* out_start,
-                  const int64_t* out_off, int32_t max_territories, float* pcm_out) {
+int mpx_ola_fixup(void* stream, int fft_len, const mpx_ola_run* runs, int32_t n_runs, const float* strips,
+                  float* pcm_out) {
     if (!p_of(fft_len)) return fail(MPX_ERR_ARG, "mpx_ola_fixup: fft_len must be 1024, 2048 or 4096%s");
-    if (n_utts < 0 || max_territories < 0) return fail(MPX_ERR_ARG, "mpx_ola_fixup: negative size%s");
-    if (territory < fft_len / 2 || (territory % 64) != 0)
-        return fail(MPX_ERR_ARG, "mpx_ola_fixup: territory must be a multiple of 64 and >= fft_len/2%s");
-    if (n_utts == 0 || max_territories == 0) return MPX_OK;
-    if (!strips || !utt_chunk_off || !strip_id || !out_start || !out_off || !pcm_out)
-        return fail(MPX_ERR_ARG, "mpx_ola_fixup: null pointer%s");
-    if (n_utts > 65535) return fail(MPX_ERR_ARG, "mpx_ola_fixup: at most 65535 utterances per call%s");
-    const dim3 block(256), grid((unsigned)max_territories, (unsigned)n_utts);
-    hipLaunchKernelGGL(k_ola_fixup, grid, block, 0, (hipStream_t)stream, strips, fft_len, (int)territory,
-                       utt_chunk_off, strip_id, out_start, (const long long*)out_off, pcm_out);
+    if (n_runs < 0) return fail(MPX_ERR_ARG, "mpx_ola_fixup: negative count%s");
+    if (n_runs == 0) return MPX_OK;
+    if (!runs || !strips || !pcm_out) return fail(MPX_ERR_ARG, "mpx_ola_fixup: null pointer%s");
+    if (n_runs > 2147483647 / 2) return fail(MPX_ERR_ARG, "mpx_ola_fixup: too many runs%s");
+    // a head strip holds at most fft_len + 64 elements: ceil((N + 64 + 63) / 1024) column blocks cover any fix range
+    const dim3 block(256), grid((unsigned)n_runs, (unsigned)((fft_len + 127 + 1023) / 1024));
+    hipLaunchKernelGGL(k_ola_fixup, grid, block, 0, (hipStream_t)stream, (const RunDesc*)runs, strips, pcm_out);
     MPX_HIP_CHECK(hipGetLastError());
     return MPX_OK;
 }

@@ -35,7 +35,7 @@ constexpr int kThreads = kWavesPerBlock * 64;
 
 template <int P>
 constexpr size_t lds_bytes() {
-    return sizeof(float) * (size_t)(P * 64 * 2 + kWavesPerBlock * P * kXStride);
+    return sizeof(float) * (size_t)(tw_floats<P>() + kWavesPerBlock * P * kXStride);
 }
 
 #ifndef MPX_ANA_WAVES
@@ -49,7 +49,7 @@ constexpr int kAnaWaves = MPX_ANA_WAVES;
 constexpr int kAnaThreads = kAnaWaves * 64;
 template <int P>
 constexpr size_t lds_bytes_ana() {
-    return sizeof(float) * (size_t)(P * 64 * 2 + kAnaWaves * P * kXStride);
+    return sizeof(float) * (size_t)(tw_floats<P>() + kAnaWaves * P * kXStride);
 }
 
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
@@ -120,10 +120,14 @@ __device__ __forceinline__ void stage_samples_async(const FrameGeom& g, int tile
     }
 }
 
+// Waits until at most N vector-memory operations of this wave are outstanding (gfx9: ONE in-order counter for loads and
+// stores, 6 bits).  After a staged copy, N = the number of VMEM operations issued SINCE the copy's last load: the copy
+// has then landed.  N >= 63 saturates the counter field (63 is the most that can be asked for).
 template <int N>
 __device__ __forceinline__ void staged_wait() {
-    if (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
+    static_assert(N >= 0, "staged_wait: negative count");
+    constexpr int kCnt = N > 63 ? 63 : N;
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kCnt) : "memory");
 }
 
 // Hermitian merge Z[k] = E[k] + i O[k] of the half spectrum held as lane l, register j <-> bin l + 64 j
@@ -211,19 +215,131 @@ __device__ __forceinline__ void feat_convert(const FrameFeat<P>& ff, float (&xr)
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Paired form of feat_load / feat_convert / hermitian_merge (k_synth_ola_pair).  The Hermitian merge works on bin
+// pairs (k, M - k): Z[k] = E + iO and Z[M - k] = conj(E) + i conj(O) come from ONE E / O evaluation.  So lane l loads
+// its bins k = l + 64 j for j < P/2 only, plus their mirrors M - k straight from memory (descending addresses: still
+// one contiguous 256-byte block per instruction), computes both outputs, keeps Z[k] in register j and hands Z[M - k]
+// to the lane that owns it: bin M - k = (64 - l) + 64 (P-1-j) is register P-1-j of lane 64 - l (lane 0: its own
+// register P - j; bin M, the Nyquist bin, is the mirror of bin 0 and has no register; bin M/2 = register P/2 of lane 0
+// is its own mirror: Z = 2 conj(X), one extra single-lane load per stream).
+// Against the per-bin form: half the merge arithmetic (16 instead of 32 E/O evaluations per lane), P instead of 2P
+// lane exchanges, the same 3P + 3 loads.
+// ---------------------------------------------------------------------------------------------
+template <int P>
+struct PairFeat {
+    float m[P / 2], a[P / 2], b[P / 2];      // own bins k = lane + 64 j
+    float mq[P / 2], aq[P / 2], bq[P / 2];   // mirrors M - k
+    float mH, aH, bH;                        // bin M/2 (lane 0)
+};
+
+template <int P>
+__device__ __forceinline__ void feat_load_paired(PairFeat<P>& ff, const float* __restrict__ mrow,
+                                                 const float* __restrict__ rrow, const float* __restrict__ irow,
+                                                 int lane) {
+    constexpr int M = 64 * P;
+    const float* mlo = mrow + lane;
+    const float* rlo = rrow + lane;
+    const float* ilo = irow + lane;
+    const float* mhi = mrow + (M - lane);
+    const float* rhi = rrow + (M - lane);
+    const float* ihi = irow + (M - lane);
+#pragma unroll
+    for (int j = 0; j < P / 2; ++j) {
+        ff.m[j] = mlo[64 * j];
+        ff.a[j] = rlo[64 * j];
+        ff.b[j] = ilo[64 * j];
+        ff.mq[j] = mhi[-64 * j];
+        ff.aq[j] = rhi[-64 * j];
+        ff.bq[j] = ihi[-64 * j];
+    }
+    ff.mH = ff.aH = ff.bH = 0.0f;
+    if (lane == 0) {
+        ff.mH = mrow[M / 2];
+        ff.aH = rrow[M / 2];
+        ff.bH = irow[M / 2];
+    }
+}
+
+template <int P>
+__device__ __forceinline__ void feat_merge_paired(const PairFeat<P>& ff, float (&xr)[P], float (&xi)[P], int lane,
+                                                  float wl_c, float wl_s) {
+    constexpr int M = 64 * P, HP = P / 2;
+    const float sgn_scale = ((lane & 1) ? -1.0f : 1.0f) * (0.5f / (float)M);   // (-1)^k fftshift sign, IFFT scale
+    const bool lane0 = (lane == 0);
+    float zr[HP], zi[HP];   // Z[M - k]
+#pragma unroll
+    for (int j = 0; j < HP; ++j) {
+        // X = mag (R + jI) / |R + jI|, 0 where |R + jI| == 0 (magphase.py:1761-1766)
+        const float s = ff.a[j] * ff.a[j] + ff.b[j] * ff.b[j];
+        const float g = ff.m[j] * sgn_scale * __builtin_amdgcn_rsqf(fmaxf(s, 1.0e-37f));
+        const float sq_ = ff.aq[j] * ff.aq[j] + ff.bq[j] * ff.bq[j];
+        const float gq = ff.mq[j] * sgn_scale * __builtin_amdgcn_rsqf(fmaxf(sq_, 1.0e-37f));
+        const float x_r = ff.a[j] * g, p_r = ff.aq[j] * gq;
+        float x_i = ff.b[j] * g, p_i = ff.bq[j] * gq;
+        if (j == 0) {   // DC and Nyquist: imaginary parts dropped (Q5)
+            x_i = lane0 ? 0.0f : x_i;
+            p_i = lane0 ? 0.0f : p_i;
+        }
+        // E = X + conj(Xp), T = X - conj(Xp), O = conj(W_N^k) T   (conj(W_N^k) = e^{+2 pi i (lane/N + j/2P)})
+        const float er = x_r + p_r, ei = x_i - p_i, tr = x_r - p_r, ti = x_i + p_i;
+        const float cq = cos2p<P>(j), sq = sin2p<P>(j);
+        const float wr = wl_c * cq - wl_s * sq, wi = wl_c * sq + wl_s * cq;
+        const float orr = wr * tr - wi * ti, oi = wr * ti + wi * tr;
+        xr[j] = er - oi;
+        xi[j] = ei + orr;
+        zr[j] = er + oi;
+        zi[j] = orr - ei;
+    }
+    // bin M/2 (lane 0): Z = 2 conj(X); M/2 is even and so is lane 0: sgn_scale is +0.5/M there
+    const float sH = ff.aH * ff.aH + ff.bH * ff.bH;
+    const float gH = 2.0f * ff.mH * sgn_scale * __builtin_amdgcn_rsqf(fmaxf(sH, 1.0e-37f));
+    const float hr = ff.aH * gH, hi = -ff.bH * gH;
+    // hand-over: register r >= P/2 of lane l' comes from lane (64 - l') & 63, which publishes Z[M - k] of its
+    // j = P-1-r; lane 0 serves itself: register P/2 = bin M/2, register r > P/2 = mirror of its j = P - r.
+    const int src_lane = (64 - lane) & 63;
+#pragma unroll
+    for (int r = HP; r < P; ++r) {
+        const float pr = lane0 ? ((r == HP) ? hr : zr[P - r]) : zr[P - 1 - r];
+        const float pi = lane0 ? ((r == HP) ? hi : zi[P - r]) : zi[P - 1 - r];
+        xr[r] = __shfl(pr, src_lane);
+        xi[r] = __shfl(pi, src_lane);
+    }
+}
+
 // Ring of R strip elements, stored as two halves: even strip positions b in ringE[b/2 mod R/2], odd ones in
 // ringO.  A lane's two samples (2m, 2m+1) of a frame then hit ringE/ringO[c + m] with m consecutive across
-// lanes: conflict-free 4-byte accesses whatever the parity of the frame position.  (LDS float atomics
-// -- ds_add_f32 -- measured ~190 LDS cycles per wave instruction on gfx950: plain read/add/write instead.)
+// lanes: conflict-free 4-byte accesses whatever the parity of the frame position (ring_add below).
 template <int P>
 constexpr int ring_len() { return 128 * P + 128; }
 
-// Streams strip elements [from, to) out of the ring (to global) and clears their slots.  from is a multiple of 64.
-// Four 64-element blocks per step: their LDS reads are in flight together (one LDS latency per 256 elements instead
-// of one per 64 -- this runs inside the ordered section of the ring, where every cycle is serial).
+// One RUN of consecutive frames of one utterance, overlap-added by one wave pair in an LDS ring (host planner:
+// hostmath.ola_runs; C ABI: mpx_ola_run).  Coordinates e are "strip elements": e = OLA-buffer position - x0.
+//   e <  head_end           : positions the previous run's last frames reach too -> stored in this run's head strip,
+//                             added to the output by k_ola_fixup (previous run's sum first: fixed order)
+//   out_lo <= e < out_hi    : final for this run (its frames are the only or the first contributors) -> written
+//                             straight to pcm_out[out_base + e]   (out_base is a multiple of 64: aligned 256-byte blocks)
+//   everything else         : outside the kept part of the reference's OLA buffer (magphase.py:59-61), or owned by the
+//                             next run -> dropped
+struct RunDesc {
+    int frame_begin, frame_end;   // global frame indices (rows of mag/real/imag, entries of pm_rel)
+    int x0;                       // OLA-buffer position of element 0
+    int head_end;
+    int out_lo, out_hi;
+    int flush_end;                // the ring is streamed out and cleared up to here when the run ends
+    int fix_lo, fix_hi;           // k_ola_fixup: pcm_out[out_base + e] += head strip[e] for fix_lo <= e < fix_hi
+    int pad;
+    long long out_base;           // pcm_out index of element 0
+    long long strip_off;          // float offset of the head strip in `strips`
+};
+static_assert(sizeof(RunDesc) == 56, "RunDesc must match mpx_ola_run");
+
+// Streams elements [from, to) out of the ring (head strip / pcm_out / nowhere, see RunDesc) and clears their slots.
+// from is a multiple of 64.  Four 64-element blocks per step: their LDS reads are in flight together (one LDS latency
+// per 256 elements instead of one per 64 -- this runs inside the ordered section of the ring, where every cycle is serial).
 template <int R>
-__device__ __forceinline__ void flush_ring(float* ring, float* __restrict__ strip, int from, int to, int strip_len,
-                                           int lane) {
+__device__ __forceinline__ void flush_ring(float* ring, float* __restrict__ strip, float* __restrict__ pcm0,
+                                           int head_end, int out_lo, int out_hi, int from, int to, int lane) {
     constexpr int RH = R / 2;
     // element b = b0 + lane: half = b & 1 (b0 even => lane parity), index (b >> 1) mod RH
     float* half = ring + ((lane & 1) ? RH : 0);
@@ -241,20 +357,69 @@ __device__ __forceinline__ void flush_ring(float* ring, float* __restrict__ stri
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int b = b0 + 64 * r + lane;
-            if (b0 + 64 * r < to) {
-                if (b < strip_len) strip[b] = v[r];
+            const int blk = b0 + 64 * r;
+            if (blk < to) {
+                const int b = blk + lane;
+                if (blk < head_end) {            // wave-uniform: only the first blocks of a run
+                    if (b < head_end) strip[b] = v[r];
+                }
+                if (blk + 64 > out_lo && blk < out_hi) {
+                    if (b >= out_lo && b < out_hi) pcm0[b] = v[r];
+                }
                 half[id[r]] = 0.0f;
             }
         }
     }
 }
 
-struct ChunkDesc {
-    int frame_begin, frame_end;  // global frame indices (rows of mag/real/imag, entries of pm_rel)
-    int x0;                      // OLA-buffer coordinate of strip element 0 (= c*T - N/2, may be negative)
-    int pad;
-};
+// Overlap-add of one frame held as lane l, register i <-> samples 2n, 2n + 1 with n = kappa(l) + 64 brev(i) (the
+// inverse wave FFT's output) at strip position x into the ring.  Even strip positions live in ring[0, RH), odd ones in
+// ring[RH, 2RH) (index b/2 mod RH): a lane's two samples hit the two halves at consecutive indices across lanes --
+// conflict-free 4-byte accesses whatever the parity of x.  Element i of a plane sits at index (c + 64 q) mod RH,
+// q = brev(i), c = c_base + kappa: 64 q goes into the instruction's immediate offset, the wrap (-RH once the index
+// passes the end; the wrap point differs by at most one q between lanes) is a per-lane bit mask: bit q set <=>
+// wrapped, one v_bfe_i32 + v_bfi_b32 per access instead of compare / select pairs (and their hazard nops).
+// All reads first, then the adds, then the writes: one LDS latency per frame.  combine(old, value, n): new ring value
+// for sample n of the frame (plain sum, or windowed sum); live(q): false for register rows that add nothing.
+// (LDS float atomics -- ds_add_f32 -- measured ~190 LDS cycles per wave instruction on gfx950: plain read/add/write.)
+template <int P, typename CFn, typename LFn>
+__device__ __forceinline__ void ring_add(float* smem_base, unsigned ring_byte, int x, const float (&xr)[P],
+                                         const float (&xi)[P], int lane, CFn combine, LFn live) {
+    constexpr int LB = ilog2(P), R = ring_len<P>(), RH = R / 2;
+    const int kap = kappa<P>(lane);
+    const int odd = x & 1;
+    const int c0 = ((x >> 1) % RH) + kap;          // plane 0 (samples 2n): half `odd`
+    const int c1 = (((x + 1) >> 1) % RH) + kap;    // plane 1 (samples 2n + 1): the other half
+    const unsigned a0 = ring_byte + 4u * (unsigned)((odd ? RH : 0) + c0);
+    const unsigned a1 = ring_byte + 4u * (unsigned)((odd ? 0 : RH) + c1);
+    const unsigned b0 = a0 - 4u * RH, b1 = a1 - 4u * RH;
+    const int w0 = (RH - c0 + 63) >> 6;            // first q with c0 + 64 q >= RH (may be > P - 1: never wraps)
+    const int w1 = (RH - c1 + 63) >> 6;
+    const unsigned m0 = (w0 >= 32) ? 0u : (~0u << w0);
+    const unsigned m1 = (w1 >= 32) ? 0u : (~0u << w1);
+    char* base = reinterpret_cast<char*>(smem_base);
+    auto at = [&](unsigned a, unsigned b, unsigned m, int q) -> float* {
+        const unsigned sel = (unsigned)__builtin_amdgcn_sbfe((int)m, q, 1);   // 0 or ~0
+        return reinterpret_cast<float*>(base + ((sel & b) | (~sel & a)) + 256 * q);
+    };
+    float o0[P], o1[P];
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        const int q = brev(i, LB);
+        o0[i] = o1[i] = 0.0f;
+        if (!live(q)) continue;
+        o0[i] = *at(a0, b0, m0, q);
+        o1[i] = *at(a1, b1, m1, q);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        const int q = brev(i, LB);
+        if (!live(q)) continue;
+        *at(a0, b0, m0, q) = combine(o0[i], xr[i], 2 * (kap + 64 * q));
+        *at(a1, b1, m1, q) = combine(o1[i], xi[i], 2 * (kap + 64 * q) + 1);
+    }
+}
 
 // ---------------------------------------------------------------------------------------------
 // host side

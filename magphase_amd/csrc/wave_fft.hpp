@@ -3,14 +3,18 @@
 // Layout contract (validated against numpy in tests/test_fft_dataflow_model.py):
 //   input : lane l, register j      holds z[l + 64*j]                       (natural order)
 //   pass 1: P-point DIF FFT in registers over j            -> register i holds k1 = brev(i)
-//           multiply by W_M^(l*k1)  (table in LDS, shared by the workgroup)
-//           transpose through a per-wave LDS buffer (row stride 65 floats: conflict-free both ways)
+//           multiply by W_M^(l*k1)  (table in LDS, shared by the workgroup, one padded row per lane in register
+//           order: two twiddles per ds_read_b128)
+//           transpose through a per-wave LDS buffer (row stride 68 floats: conflict-free dword writes with the lane
+//           along a row, 16-byte aligned rows so that a lane reads its P consecutive floats as P/4 ds_read_b128 --
+//           a quarter of the LDS instructions of the dword form; bank model in tests/test_fft_dataflow_model.py)
 //   pass 2: 64-point FFT over l = radix-(64/P) butterflies ACROSS lanes + P-point DIF in registers
 //   output: lane l, register i      holds Z[kappa(l) + 64*brev(i)]
 //           kappa(l) = l with its bits above log2(P) reversed: identity for P=32, bits 4 and 5 swapped for P=16,
 //           bits 3..5 reversed for P=8 (an involution in every case).
 //   pass 2 in full: the 64-point DIF FFT over l = (lane / P) * P + l' has its strides S >= P across lanes (partner =
-//   lane ^ S, S = 32 .. P) and the strides < P in registers.  The upper lane of a stride-S butterfly multiplies by
+//   lane ^ S, S = 32 .. P; exchanged with v_permlane32_swap / v_permlane16_swap / DPP row_ror:8 -- VALU lane
+//   crossbars, no LDS round trip) and the strides < P in registers.  The upper lane of a stride-S butterfly multiplies by
 //   W_{2S}^(l mod S) = W_{2S}^{l'} (literal, by register) x W_{2S/P}^{e}, e = (lane / P) mod (S / P): nothing for
 //   S == P, (SIGN i)^e for S == 2P ("rot"), a general eighth root for S == 4P (only P = 8, S = 32).
 //
@@ -21,7 +25,14 @@
 
 namespace mpx {
 
-constexpr int kXStride = 65;  // floats per k1 row of the per-wave transpose buffer
+constexpr int kXStride = 68;  // floats per k1 row of the per-wave transpose buffer (16-byte aligned rows)
+
+// Twiddle table of the first pass: one row per lane, entry i = (cos, sin)(2 pi lane brev(i) / M) in REGISTER order,
+// rows padded to 2P + 4 floats (16-byte aligned, conflict-free ds_read_b128 across lanes).
+template <int P>
+__host__ __device__ constexpr int tw_stride() { return 2 * P + 4; }
+template <int P>
+__host__ __device__ constexpr int tw_floats() { return 64 * tw_stride<P>(); }
 
 __host__ __device__ constexpr int ilog2(int v) { return v <= 1 ? 0 : 1 + ilog2(v >> 1); }
 
@@ -124,10 +135,37 @@ __device__ __forceinline__ void lds_transpose(float (&x)[P], float* xbuf, int la
 #pragma unroll
     for (int i = 0; i < P; ++i) xbuf[brev(i, LB) * kXStride + lane] = x[i];
     wave_sync();
-    const float* src = xbuf + (lane % P) * kXStride + (lane / P) * P;
+    const float4* src = reinterpret_cast<const float4*>(xbuf + (lane % P) * kXStride + (lane / P) * P);
 #pragma unroll
-    for (int lp = 0; lp < P; ++lp) x[lp] = src[lp];
+    for (int q = 0; q < P / 4; ++q) {
+        const float4 v = src[q];
+        x[4 * q + 0] = v.x;
+        x[4 * q + 1] = v.y;
+        x[4 * q + 2] = v.z;
+        x[4 * q + 3] = v.w;
+    }
     wave_sync();
+}
+
+// value of lane ^ PARTNER for the two registers (a, b) at once.  PARTNER 32 / 16: a swap instruction exchanges the
+// upper half (odd 16-lane rows) of one register with the lower half (even rows) of the other: two swaps around the
+// add / subtract give both butterflies with no LDS traffic.
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+// (the elements are copied to scalars before the bit cast: __builtin_bit_cast straight from a vector element reads
+// element 0 for both under hipcc / ROCm 7.2)
+__device__ __forceinline__ void swap32(float& a, float& b) {
+    const u32x2 r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b),
+                                                     false, false);
+    const unsigned r0 = r.x, r1 = r.y;
+    a = __builtin_bit_cast(float, r0);
+    b = __builtin_bit_cast(float, r1);
+}
+__device__ __forceinline__ void swap16(float& a, float& b) {
+    const u32x2 r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b),
+                                                     false, false);
+    const unsigned r0 = r.x, r1 = r.y;
+    a = __builtin_bit_cast(float, r0);
+    b = __builtin_bit_cast(float, r1);
 }
 
 // Radix-2 DIF butterflies across lanes (partner = lane ^ PARTNER).  Lower lane: own + oth; upper lane:
@@ -136,17 +174,38 @@ __device__ __forceinline__ void lds_transpose(float (&x)[P], float* xbuf, int la
 // lane instead makes them loop-invariant VGPRs that LICM hoists out of the frame loop (64 registers).
 template <int P, int SIGN, int PARTNER, int TWN>
 __device__ __forceinline__ void cross_lane_stage(float (&re)[P], float (&im)[P], bool upper, bool rot, int lane) {
-    const float sg = upper ? -1.0f : 1.0f;
-    float orr[P], oii[P];   // all 2P lane exchanges in flight together, then the butterflies
+    if (PARTNER >= 16) {
+        // registers in pairs (lp, lp + 1): after the first swap a = [lower halves of both], b = [upper halves of both];
+        // a + b / a - b are the lower / upper outputs of both registers; the second swap sorts them back.
+        // Three batches (swap / add-subtract / swap): a swap must not read a register written by one of the two VALU
+        // instructions before it (the compiler pads with s_nop otherwise); batched, every operand is older than that.
 #pragma unroll
-    for (int lp = 0; lp < P; ++lp) {
-        orr[lp] = __shfl_xor(re[lp], PARTNER);
-        oii[lp] = __shfl_xor(im[lp], PARTNER);
-    }
+        for (int lp = 0; lp < P; lp += 2) {
+            if (PARTNER == 32) { swap32(re[lp], re[lp + 1]); swap32(im[lp], im[lp + 1]); }
+            else { swap16(re[lp], re[lp + 1]); swap16(im[lp], im[lp + 1]); }
+        }
 #pragma unroll
-    for (int lp = 0; lp < P; ++lp) {
-        re[lp] = fmaf(re[lp], sg, orr[lp]);
-        im[lp] = fmaf(im[lp], sg, oii[lp]);
+        for (int lp = 0; lp < P; lp += 2) {
+            const float a = re[lp], b = re[lp + 1], c = im[lp], d = im[lp + 1];
+            re[lp] = a + b;
+            re[lp + 1] = a - b;
+            im[lp] = c + d;
+            im[lp + 1] = c - d;
+        }
+#pragma unroll
+        for (int lp = 0; lp < P; lp += 2) {
+            if (PARTNER == 32) { swap32(re[lp], re[lp + 1]); swap32(im[lp], im[lp + 1]); }
+            else { swap16(re[lp], re[lp + 1]); swap16(im[lp], im[lp + 1]); }
+        }
+    } else {   // PARTNER == 8 (only P = 8): rotation by 8 inside each 16-lane row (DPP row_ror:8)
+        const float sg = upper ? -1.0f : 1.0f;
+#pragma unroll
+        for (int lp = 0; lp < P; ++lp) {
+            const float orr = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, re[lp]), 0x128, 0xf, 0xf, false));
+            const float oii = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, im[lp]), 0x128, 0xf, 0xf, false));
+            re[lp] = fmaf(re[lp], sg, orr);
+            im[lp] = fmaf(im[lp], sg, oii);
+        }
     }
     if (upper) {
 #pragma unroll
@@ -197,20 +256,25 @@ __device__ __forceinline__ int kappa(int lane) {
 }
 
 // Full M = 64*P point FFT of one wave, in two halves so that a caller can place independent work
-// (e.g. the next frame's global loads) between them.  tw: LDS table [P][64] float2 = (cos, sin)(2 pi l k1 / M)
-// (sign applied here).  xbuf: this wave's P*65-float LDS buffer.
+// (e.g. the next frame's global loads) between them.  tw: LDS twiddle table (tw_floats<P>() floats, layout above; sign
+// applied here).  xbuf: this wave's P * kXStride float LDS buffer.
 template <int P, int SIGN>
-__device__ __forceinline__ void wave_fft_front(float (&re)[P], float (&im)[P], const float2* tw, float* xbuf, int lane) {
-    constexpr int LB = ilog2(P);
+__device__ __forceinline__ void wave_fft_front(float (&re)[P], float (&im)[P], const float* tw, float* xbuf, int lane) {
     fft_inreg<P, SIGN>(re, im);
+    const float4* trow = reinterpret_cast<const float4*>(tw + lane * tw_stride<P>());
 #pragma unroll
-    for (int i = 0; i < P; ++i) {
-        const float2 w = tw[brev(i, LB) * 64 + lane];
-        const float ws = (SIGN < 0) ? -w.y : w.y;
-        const float xr = re[i] * w.x - im[i] * ws;
-        const float xi = re[i] * ws + im[i] * w.x;
-        re[i] = xr;
-        im[i] = xi;
+    for (int q = 0; q < P / 2; ++q) {
+        const float4 w = trow[q];   // twiddles of registers 2q, 2q + 1
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int i = 2 * q + e;
+            const float wc = e ? w.z : w.x;
+            const float ws = (SIGN < 0) ? -(e ? w.w : w.y) : (e ? w.w : w.y);
+            const float xr = re[i] * wc - im[i] * ws;
+            const float xi = re[i] * ws + im[i] * wc;
+            re[i] = xr;
+            im[i] = xi;
+        }
     }
     lds_transpose<P>(re, xbuf, lane);
     lds_transpose<P>(im, xbuf, lane);
@@ -227,7 +291,7 @@ __device__ __forceinline__ void wave_fft_front(float (&re)[P], float (&im)[P], c
 }
 
 template <int P, int SIGN>
-__device__ __forceinline__ void wave_fft(float (&re)[P], float (&im)[P], const float2* tw, float* xbuf, int lane) {
+__device__ __forceinline__ void wave_fft(float (&re)[P], float (&im)[P], const float* tw, float* xbuf, int lane) {
     wave_fft_front<P, SIGN>(re, im, tw, xbuf, lane);
     fft_inreg<P, SIGN>(re, im);
 }

@@ -151,7 +151,7 @@ class Engine:
         """
         torch = _torch()
         tmap = {np.dtype(np.float32): torch.float32, np.dtype(np.float64): torch.float64,
-                np.dtype(np.int32): torch.int32, np.dtype(np.int64): torch.int64}
+                np.dtype(np.int32): torch.int32, np.dtype(np.int64): torch.int64, np.dtype(np.uint8): torch.uint8}
         prepared, offs, total = [], [], 0
         for _name, arr, dt in items:
             a = np.ascontiguousarray(arr, dtype=dt)
@@ -346,42 +346,42 @@ class Engine:
         with torch.cuda.device(self.device):
             return int(self.lib.mpx_synth_comp_slots())
 
-    def synthesis_lossless_ola(self, fft_len, mag, real, imag, plan, strips):
-        """plan: LosslessSynthesisPlan (chunk + slot tables resident on this device)."""
+    def synthesis_lossless_ola(self, fft_len, mag, real, imag, plan, strips, pcm_out):
+        """plan: LosslessSynthesisPlan (run + slot tables resident on this device).  Writes every output sample of
+        pcm_out once and the runs' head strips; ola_fixup(plan, strips, pcm_out) completes the run boundaries."""
         torch = _torch()
         tab = self.tables(fft_len)
         with torch.cuda.device(self.device):
             _lib.check(
                 self.lib.mpx_synthesis_lossless_ola(self.stream_ptr(), int(fft_len), tab.data_ptr(), mag.data_ptr(),
-                                                    real.data_ptr(), imag.data_ptr(), plan.chunks.data_ptr(),
-                                                    int(plan.n_chunks), plan.slot_off.data_ptr(),
-                                                    plan.slot_chunks.data_ptr(), int(plan.n_slots),
-                                                    plan.pm_rel.data_ptr(), int(plan.territory), strips.data_ptr(),
+                                                    real.data_ptr(), imag.data_ptr(), plan.runs.data_ptr(),
+                                                    int(plan.n_runs), plan.slot_off.data_ptr(),
+                                                    plan.slot_runs.data_ptr(), int(plan.n_slots),
+                                                    plan.pm_rel.data_ptr(), strips.data_ptr(), pcm_out.data_ptr(),
                                                     self.feat_ld(mag, real, imag)),
                 "mpx_synthesis_lossless_ola")
-        return strips
+        return pcm_out
 
-    def ola_fixup(self, fft_len, territory, strips, utt_chunk_off, strip_id, out_start, out_off, max_territories,
-                  total_out, out=None):
+    def ola_fixup(self, fft_len, plan, strips, pcm_out):
         torch = _torch()
-        if out is None:
-            out = self.empty((int(total_out),))
-        n_utts = int(out_start.numel())
         with torch.cuda.device(self.device):
-            _lib.check(
-                self.lib.mpx_ola_fixup(self.stream_ptr(), int(fft_len), int(territory), strips.data_ptr(), n_utts,
-                                       utt_chunk_off.data_ptr(), strip_id.data_ptr(), out_start.data_ptr(),
-                                       out_off.data_ptr(), int(max_territories), out.data_ptr()),
-                "mpx_ola_fixup")
-        return out
+            _lib.check(self.lib.mpx_ola_fixup(self.stream_ptr(), int(fft_len), plan.runs.data_ptr(), int(plan.n_runs),
+                                              strips.data_ptr(), pcm_out.data_ptr()), "mpx_ola_fixup")
+        return pcm_out
 
 
-def _max_territories(terr_off, starts, out_lens, territory):
-    """grid.x of k_ola_fixup: territories holding frames, or output samples of the zero tail, whichever is more."""
-    terr_off = np.asarray(terr_off)
-    n_frames_terr = np.diff(terr_off) if terr_off.size > 1 else np.zeros(0, dtype=np.int64)
-    n_out_terr = [-(-(int(s_) + int(l_)) // int(territory)) for s_, l_ in zip(starts, out_lens)]
-    return int(max([0] + list(n_frames_terr) + n_out_terr))
+def _plan_ola_runs(plan, pm_rel_list, starts, out_lens, out_off_host, fft_len, n_slots, frames_per_run, up):
+    """Shared by the two synthesis plans: runs + slot work lists (hostmath.ola_runs / balance_chunks) -> upload list."""
+    fpr = frames_per_run or int(os.environ.get("MAGPHASE_OLA_FRAMES_PER_RUN", 0)) or None
+    runs = hm.ola_runs(pm_rel_list, starts, out_lens, out_off_host, fft_len, n_slots, frames_per_run=fpr)
+    plan.n_runs = int(runs.size)
+    plan.runs_host = runs
+    plan.strip_floats = plan.n_runs * (int(fft_len) + 64)
+    slot_off, slot_runs = hm.balance_chunks(runs["frame_end"] - runs["frame_begin"], n_slots)
+    plan.n_slots = int(slot_off.size - 1)
+    up.append(("runs", runs.view(np.uint8), np.uint8))
+    up.append(("slot_off", slot_off, np.int32))
+    up.append(("slot_runs", slot_runs, np.int32))
 
 
 _ENGINES = {}
@@ -460,13 +460,13 @@ class LosslessAnalysisPlan:
 class LosslessSynthesisPlan:
     """
     PSOLA bookkeeping for a batch: per utterance v_f0 (float64) -> shift -> pm (magphase.py:1771-1772, Q2/Q3)
-    -> ola() offsets and trimming (magphase.py:34-62).  All float64/int host math; device gets int tables.
+    -> ola() offsets and trimming (magphase.py:34-62) -> runs of frames for the fused overlap-add (hostmath.ola_runs).
+    All float64/int host math; device gets int tables.
     """
 
-    def __init__(self, engine, f0_list, fs_list, fft_len, territory=None):
+    def __init__(self, engine, f0_list, fs_list, fft_len, frames_per_run=None):
         self.engine = engine
         self.fft_len = fft_len
-        self.territory = int(territory) if territory else int(os.environ.get("MAGPHASE_OLA_TERRITORY", fft_len))
         pm_rel, starts, lens, nfr = [], [], [], []
         self.v_pm = []
         for v_f0, fs in zip(f0_list, fs_list):
@@ -483,41 +483,25 @@ class LosslessSynthesisPlan:
         self.max_out_len = int(max(lens)) if lens else 0
         self.total_frames = int(sum(nfr))
         e = engine
-        _up = self._up = []   # (attribute, host array, dtype): uploaded together (Engine.to_device_packed)
+        _up = []   # (attribute, host array, dtype): uploaded together (Engine.to_device_packed)
         _up.append(("utt_frame_off", np.concatenate(([0], np.cumsum(nfr))), np.int32))
         _up.append(("pm_rel", np.concatenate(pm_rel) if pm_rel else np.zeros(0), np.int32))
         _up.append(("out_start", np.asarray(starts), np.int32))
-        self._starts_host = [int(x) for x in starts]
         _up.append(("out_off", self.out_off_host, np.int64))
-        self._build_chunks(pm_rel, nfr)
+        n_slots = e.synth_ola_slots() if hasattr(e, "synth_ola_slots") else 1024
+        _plan_ola_runs(self, pm_rel, starts, lens, self.out_off_host, fft_len, n_slots, frames_per_run, _up)
         for _k, _t in e.to_device_packed(_up).items():
             setattr(self, _k, _t)
-        del self._up
-
-    def _build_chunks(self, pm_rel_list, nfr):
-        """Territories of the OLA buffer -> chunks (include/magphase_hip.h: mpx_synthesis_lossless_ola)."""
-        rows, terr_off, owner_all = hm.ola_chunks(pm_rel_list, self.fft_len, self.territory)
-        e = self.engine
-        self.n_chunks = int(rows.shape[0])
-        self._up.append(("chunks", rows, np.int32))
-        self._up.append(("utt_chunk_off", np.asarray(terr_off), np.int32))
-        self.max_territories = _max_territories(terr_off, self._starts_host, self.out_len, self.territory)
-        self._up.append(("strip_id", owner_all, np.int32))
-        self.strip_floats = self.n_chunks * (self.territory + self.fft_len)
-        n_slots = e.synth_ola_slots() if hasattr(e, "synth_ola_slots") else 1280
-        slot_off, slot_chunks = hm.balance_chunks(rows[:, 1] - rows[:, 0], n_slots)
-        self.n_slots = int(slot_off.size - 1)
-        self._up.append(("slot_off", slot_off, np.int32))
-        self._up.append(("slot_chunks", slot_chunks, np.int32))
 
     def run(self, mag, real, imag, strips=None, out=None):
-        """Fused path: k_synth_ola (per-chunk LDS overlap-add) + k_ola_fixup."""
+        """Fused path: k_synth_ola_pair (per-run LDS overlap-add, output written in place) + k_ola_fixup (run boundaries)."""
         e = self.engine
         if strips is None:
-            strips = e.empty((self.strip_floats,))
-        e.synthesis_lossless_ola(self.fft_len, mag, real, imag, self, strips)
-        return e.ola_fixup(self.fft_len, self.territory, strips, self.utt_chunk_off, self.strip_id, self.out_start,
-                           self.out_off, self.max_territories, self.total_out, out=out)
+            strips = e.empty((max(self.strip_floats, 1),))
+        if out is None:
+            out = e.empty((self.total_out,))
+        e.synthesis_lossless_ola(self.fft_len, mag, real, imag, self, strips, out)
+        return e.ola_fixup(self.fft_len, self, strips, out)
 
     def run_unfused(self, mag, real, imag, frames=None, out=None):
         """Two-kernel form: frames to HBM, then the ascending-order gather (bit-for-bit the reference's sum order)."""
@@ -539,7 +523,7 @@ class CompressedSynthesisPlan:
     """
 
     def __init__(self, engine, utts, fs, fft_len=None, b_voi_ap_win=True, b_const_rate=False, alpha_phase=None,
-                 noise=None, territory=None, per_phase_type="magphase", post_filter=False, b_fbank_mel=False):
+                 noise=None, frames_per_run=None, per_phase_type="magphase", post_filter=False, b_fbank_mel=False):
         from scipy import interpolate
 
         self.apply_post_filter = bool(post_filter)
@@ -553,7 +537,6 @@ class CompressedSynthesisPlan:
         self.fs = fs
         N = self.fft_len = int(fft_len) if fft_len else hm.define_fft_len(fs)
         H = N // 2 + 1
-        self.territory = int(territory) if territory else int(os.environ.get("MAGPHASE_OLA_TERRITORY", N))
         alpha = hm.define_alpha(fs)
         self.alpha_phase = alpha if alpha_phase is None else alpha_phase
         self.mag_dim = int(np.shape(utts[0][0])[1])
@@ -654,19 +637,9 @@ class CompressedSynthesisPlan:
                                   lambda: hm.phase_unwarp_matrix(self.phase_dim, N, fs, self.alpha_phase))
         self.per_v, self.ap_v, self.ap_u = (
             e.constant(("bin_curve", k, int(fs), N), lambda k=k: hm.synthesis_bin_curves(fs, N)[k]) for k in range(3))
-        # OLA chunks
-        rows, terr_off, owner_all = hm.ola_chunks(pm_rel, N, self.territory)
-        self.n_chunks = int(rows.shape[0])
-        _up.append(("chunks", rows, np.int32))
-        _up.append(("utt_chunk_off", terr_off, np.int32))
-        self.max_territories = _max_territories(terr_off, starts, self.out_len, self.territory)
-        _up.append(("strip_id", owner_all, np.int32))
-        self.strip_floats = self.n_chunks * (self.territory + N)
+        # OLA runs
         n_slots = e.synth_comp_slots() if hasattr(e, "synth_comp_slots") else 1024
-        slot_off, slot_chunks = hm.balance_chunks(rows[:, 1] - rows[:, 0], n_slots)
-        self.n_slots = int(slot_off.size - 1)
-        _up.append(("slot_off", slot_off, np.int32))
-        _up.append(("slot_chunks", slot_chunks, np.int32))
+        _plan_ola_runs(self, pm_rel, starts, self.out_len, self.out_off_host, N, n_slots, frames_per_run, _up)
         self._gains_dev = None
         for _k, _t in e.to_device_packed(_up).items():
             setattr(self, _k, _t)
@@ -706,7 +679,8 @@ class CompressedSynthesisPlan:
         ld = int(lib.mpx_spec_ld(H))
         mag, real, imag = (e.empty((self.n_rows, ld))[:, :H] for _ in range(3))
         sums = e.empty((self.total_frames,))
-        strips = e.empty((self.strip_floats,))
+        strips = e.empty((max(self.strip_floats, 1),))
+        pcm = out if out is not None else e.empty((self.total_out,))
         with torch.cuda.device(e.device):
             st = e.stream_ptr()
             a_mag = e.post_filter(self.a_mag, self.fs) if self.apply_post_filter else self.a_mag   # magphase.py:3259-3261
@@ -746,11 +720,10 @@ class CompressedSynthesisPlan:
                 self.npos.data_ptr(), self.nleft.data_ptr(), self.nright.data_ptr(), self.wtype.data_ptr(),
                 self.voiced.data_ptr(), inv_gain.data_ptr(), row0.data_ptr(), row1.data_ptr(),
                 rowt.data_ptr(), self.win_l.data_ptr(), self.win_r.data_ptr(), self.pm_rel.data_ptr(),
-                self.per_v.data_ptr(), self.ap_v.data_ptr(), self.ap_u.data_ptr(), self.chunks.data_ptr(),
-                self.n_chunks, self.slot_off.data_ptr(), self.slot_chunks.data_ptr(), self.n_slots, self.territory,
-                strips.data_ptr(), ld), "mpx_synthesis_compressed_ola")
-        pcm = e.ola_fixup(N, self.territory, strips, self.utt_chunk_off, self.strip_id, self.out_start, self.out_off,
-                          self.max_territories, self.total_out, out=out)
+                self.per_v.data_ptr(), self.ap_v.data_ptr(), self.ap_u.data_ptr(), self.runs.data_ptr(),
+                self.n_runs, self.slot_off.data_ptr(), self.slot_runs.data_ptr(), self.n_slots,
+                strips.data_ptr(), pcm.data_ptr(), ld), "mpx_synthesis_compressed_ola")
+        e.ola_fixup(N, self, strips, pcm)
         if keep:
             self.debug = dict(mag=mag, real=real, imag=imag, sums=sums)
         return pcm

@@ -106,42 +106,126 @@ def ola_plan(v_pm, frmlen):
     return (v_pm - v_pm[0]).astype(np.int64), int(start), int(out_len)
 
 
-def ola_chunks(pm_rel_list, fft_len, territory):
+# numpy record layout of the C struct mpx_ola_run (include/magphase_hip.h), 56 bytes
+OLA_RUN_DTYPE = np.dtype([("frame_begin", "<i4"), ("frame_end", "<i4"), ("x0", "<i4"), ("head_end", "<i4"),
+                          ("out_lo", "<i4"), ("out_hi", "<i4"), ("flush_end", "<i4"), ("fix_lo", "<i4"),
+                          ("fix_hi", "<i4"), ("pad", "<i4"), ("out_base", "<i8"), ("strip_off", "<i8")])
+
+
+def _runs_per_utterance(n_frames, n_slots):
     """
-    Cuts every utterance's OLA buffer (magphase.py:38) into territories of ``territory`` samples and groups the
-    frames by the territory their centre pm_rel + N/2 falls in (include/magphase_hip.h:
-    mpx_synthesis_lossless_ola).  Returns
-      rows      int64[n_chunks x 4]  (frame_begin, frame_end, x0 = c*T - N/2, 0), longest chunk first,
-      terr_off  int64[U+1]           territory range of each utterance in ``owner``,
-      owner     int64[sum territories] chunk (row) index owning the territory, -1 if it holds no frame centre.
+    How many runs each utterance gets so that sum(k_u) == n_slots (one run per pair slot) and the longest run,
+    max ceil(F_u / k_u), is as short as possible: floor shares first, the left-over slots to the utterances whose runs
+    are longest (largest-remainder apportionment).  Fewer frames than slots: one frame per run.
     """
-    N, T = int(fft_len), int(territory)
-    if T % 64 != 0 or T < N // 2:
-        raise ValueError("territory must be a multiple of 64 and >= fft_len/2")
-    chunk_rows, terr_off, terr_owner = [], [0], []
+    n_frames = np.asarray(n_frames, dtype=np.int64)
+    total = int(n_frames.sum())
+    if total <= n_slots:
+        return np.maximum(n_frames, 1)
+    k = np.maximum(1, (n_frames * n_slots) // total)
+    left = int(n_slots - k.sum())
+    while left > 0:
+        per = n_frames / k
+        order = np.argsort(-per, kind="stable")[:left]
+        k[order] += 1
+        left = int(n_slots - k.sum())
+    return k
+
+
+def _run_cuts(rel, N, target, k=None):
+    """
+    Frame indices at which one utterance's frames are cut into k runs (default: runs of about ``target`` frames), such
+    that only ADJACENT runs overlap in the OLA buffer: rel[cut_{k+1}] - rel[cut_k - 1] >= N for every run k with both
+    neighbours (a frame covers [rel, rel + N)).  Returns int64 cuts, cuts[0] == 0, cuts[-1] == n.
+    """
+    n = int(rel.size)
+    k = int(k) if k else max(1, int(round(n / float(max(1, target)))))
+    k = max(1, min(k, n))
+    target = max(1, n // k)
+    cuts = np.round(np.linspace(0, n, k + 1)).astype(np.int64)
+    if k > 2:
+        inner = cuts[1:-1]   # runs 1 .. k-2 have both neighbours: span from the frame before their first to the next run's first
+        ok = np.all(rel[inner[1:]] - rel[inner[:-1] - 1] >= N)
+    else:
+        ok = True
+    if ok and (k < 2 or np.all(np.diff(cuts) > 0)):
+        return cuts
+    # rare (tiny utterances, tiny targets): greedy left-to-right
+    out = [0]
+    fb = 0
+    while True:
+        fe = min(n, fb + max(1, int(target)))
+        if fb > 0:
+            while fe < n and rel[fe] - rel[fb - 1] < N:
+                fe += 1
+        if fe >= n:
+            break
+        out.append(fe)
+        fb = fe
+    out.append(n)
+    return np.asarray(out, dtype=np.int64)
+
+
+def ola_runs(pm_rel_list, starts, out_lens, out_offs, fft_len, n_slots, frames_per_run=None):
+    """
+    Plans the fused overlap-add (include/magphase_hip.h: mpx_synthesis_lossless_ola).  Every utterance's frames are cut
+    into runs of consecutive frames, about total_frames / n_slots each (``frames_per_run`` overrides the target), so
+    that each pair slot of the device gets one run of nearly equal length; per run the positions are classified as
+    head strip / final output / dropped (see mpx_ola_run) in the coordinates of the reference's OLA buffer
+    (magphase.py:38-61): frame i covers [pm_rel[i], pm_rel[i] + N), the kept part is [start, start + out_len).
+
+    pm_rel_list: per utterance int64[F_u]; starts / out_lens: ola_plan's (out_start, out_len) per utterance;
+    out_offs: int64[U+1] offsets of the utterances in pcm_out.
+    Returns a structured array (OLA_RUN_DTYPE) of the runs in utterance / frame order.
+    """
+    N = int(fft_len)
+    strip_floats = N + 64
+    total = int(sum(int(np.size(r)) for r in pm_rel_list))
+    target = int(frames_per_run) if frames_per_run else max(1, -(-total // max(1, int(n_slots))))
+    k_utt = None if frames_per_run else _runs_per_utterance([int(np.size(r)) for r in pm_rel_list], max(1, int(n_slots)))
+    recs = []
     f_base = 0
-    for rel in pm_rel_list:
+    for u, rel in enumerate(pm_rel_list):
         rel = np.asarray(rel, dtype=np.int64)
-        n = rel.size
-        n_terr = int((rel[-1] + N - 1) // T) + 1
-        c = (rel + N // 2) // T  # non-decreasing
-        cut = np.flatnonzero(np.diff(c)) + 1
-        begins = np.concatenate(([0], cut))
-        ends = np.concatenate((cut, [n]))
-        owner = np.full(n_terr, -1, dtype=np.int64)
-        for b, e_ in zip(begins, ends):
-            owner[int(c[b])] = len(chunk_rows)
-            chunk_rows.append((f_base + int(b), f_base + int(e_), int(c[b]) * T - N // 2, 0))
-        terr_owner.append(owner)
-        terr_off.append(terr_off[-1] + n_terr)
+        n = int(rel.size)
+        if n == 0:
+            continue
+        start, out_len, o0 = int(starts[u]), int(out_lens[u]), int(out_offs[u])
+        cuts = _run_cuts(rel, N, target, None if k_utt is None else k_utt[u])
+        fb, fe = cuts[:-1], cuts[1:]
+        k = fb.size
+        hi = rel[fe - 1] + N                          # end of the run's last frame
+        prev_hi = np.concatenate(([0], hi[:-1]))      # positions < prev_hi also get the previous run's frames
+        # first position the run is responsible for: its first frame, or the end of the previous run's last frame if
+        # that comes first (consecutive frames further apart than N leave a gap of zeros, which this run writes)
+        lo = np.minimum(rel[fb], prev_hi)
+        # element 0 at a position whose pcm_out index is a multiple of 64 (aligned 256-byte output blocks)
+        x0 = lo - ((lo - start + o0) % 64)
+        head_end = np.where(np.arange(k) > 0, prev_hi - x0, 0)
+        if np.any(head_end > strip_floats):
+            raise ValueError("ola_runs: a run's head overlap exceeds the strip (frames not in ascending position order?)")
+        # final positions of run k: [prev_hi (0 for the first run), hi_k), the last run up to the end of the kept part
+        own_lo = np.where(np.arange(k) > 0, prev_hi, 0)
+        own_hi = hi.copy()
+        own_hi[-1] = max(int(hi[-1]), start + out_len)
+        out_lo = np.maximum(own_lo, start) - x0
+        out_hi = np.minimum(own_hi, start + out_len) - x0
+        out_hi = np.maximum(out_hi, out_lo)
+        flush_end = np.maximum(hi, own_hi) - x0
+        fix_lo = np.maximum(lo, start) - x0
+        fix_hi = np.minimum(prev_hi, start + out_len) - x0
+        fix_hi = np.where(np.arange(k) > 0, np.maximum(fix_hi, fix_lo), fix_lo)
+        r = np.zeros(k, dtype=OLA_RUN_DTYPE)
+        r["frame_begin"], r["frame_end"] = fb + f_base, fe + f_base
+        r["x0"], r["head_end"] = x0, head_end
+        r["out_lo"], r["out_hi"], r["flush_end"] = out_lo, out_hi, flush_end
+        r["fix_lo"], r["fix_hi"] = fix_lo, fix_hi
+        r["out_base"] = o0 + x0 - start
+        recs.append(r)
         f_base += n
-    rows = np.asarray(chunk_rows, dtype=np.int64).reshape(-1, 4)
-    order = np.argsort(-(rows[:, 1] - rows[:, 0]), kind="stable")  # longest chunks first (load balance)
-    rank = np.empty_like(order)
-    rank[order] = np.arange(order.size)
-    owner_all = np.concatenate(terr_owner) if terr_owner else np.zeros(0, dtype=np.int64)
-    owner_all = np.where(owner_all >= 0, rank[np.maximum(owner_all, 0)], -1)
-    return rows[order], np.asarray(terr_off, dtype=np.int64), owner_all
+    runs = np.concatenate(recs) if recs else np.zeros(0, dtype=OLA_RUN_DTYPE)
+    runs["strip_off"] = np.arange(runs.size, dtype=np.int64) * strip_floats
+    return runs
 
 
 def balance_chunks(n_frames_per_chunk, n_slots, overhead=2):

@@ -26,10 +26,10 @@ def test_library_loads_and_exports_all_symbols():
     for name in _declared():
         assert hasattr(lib, name), name
     l2 = _lib.load()
-    assert l2.mpx_version() == 1
-    assert l2.mpx_tables_bytes(4096) == 2 * 64 * 32 * 4
-    assert l2.mpx_tables_bytes(2048) == 2 * 64 * 16 * 4
-    assert l2.mpx_tables_bytes(1024) == 2 * 64 * 8 * 4
+    assert l2.mpx_version() == 2
+    assert l2.mpx_tables_bytes(4096) == 64 * (2 * 32 + 4) * 4   # one padded row per lane (wave_fft.hpp)
+    assert l2.mpx_tables_bytes(2048) == 64 * (2 * 16 + 4) * 4
+    assert l2.mpx_tables_bytes(1024) == 64 * (2 * 8 + 4) * 4
     assert l2.mpx_tables_bytes(1000) == 0
 
 

@@ -205,9 +205,10 @@ def test_full_size_config2_roundtrip_property(mp, orc):
         assert np.max(np.abs(y - ref)) <= 2 * PCM_TOL * np.max(np.abs(ref))
 
 
-@pytest.mark.parametrize("fs,terr", [(48000, 4096), (48000, 2048), (48000, 8192), (16000, 2048), (16000, 1024)])
-def test_fused_ola_equals_two_kernel_form(mp, fs, terr):
-    """k_synth_ola + k_ola_fixup (any territory size) vs frames-to-HBM + ascending gather: same sums up to fp32 re-association."""
+@pytest.mark.parametrize("fs,fpr", [(48000, None), (48000, 1), (48000, 7), (48000, 1000), (16000, None), (16000, 40)])
+def test_fused_ola_equals_two_kernel_form(mp, fs, fpr):
+    """k_synth_ola_pair + k_ola_fixup (any run length: one frame per run ... one run per utterance) vs frames-to-HBM +
+    ascending gather: same sums up to fp32 re-association."""
     import torch
     from magphase_amd import synthetic as syn
     from magphase_amd.engine import LosslessAnalysisPlan, LosslessSynthesisPlan, get_engine
@@ -219,8 +220,9 @@ def test_fused_ola_equals_two_kernel_form(mp, fs, terr):
     plan = LosslessAnalysisPlan(eng, utts)
     mag, real, imag = plan.run()
     f0 = [f.copy() for f in plan.v_f0]
-    f0[2][0] = 15.0 if fs == 48000 else 6.0   # first epoch beyond N/2: negative python slice start + empty territories
-    splan = LosslessSynthesisPlan(eng, f0, plan.fs, plan.fft_len, territory=terr)
+    f0[2][0] = 15.0 if fs == 48000 else 6.0   # first epoch beyond N/2: negative python slice start
+    f0[3][5] = 9.0 if fs == 48000 else 5.0    # two frames further apart than N: a gap of zeros inside the utterance
+    splan = LosslessSynthesisPlan(eng, f0, plan.fs, plan.fft_len, frames_per_run=fpr)
     a = splan.run(mag, real, imag).cpu().numpy()
     b = splan.run_unfused(mag, real, imag).cpu().numpy()
     a2 = splan.run(mag, real, imag).cpu().numpy()

@@ -38,49 +38,90 @@ def test_ola_plan_single_frame():
     assert np.array_equal(_emulate_ola(frames, rel, start, out_len, v_pm[0]), ref)
 
 
-@pytest.mark.parametrize("N,T", [(4096, 4096), (4096, 2048), (4096, 8192), (2048, 1024), (2048, 2048 + 64)])
-def test_ola_chunks_cover_every_frame_once_and_strips_cover_the_buffer(N, T):
-    rng = np.random.RandomState(N + T)
-    rels = []
-    for u in range(4):
-        sh = rng.randint(60, 1000, size=rng.randint(3, 200))
-        sh[rng.randint(0, len(sh))] = 7000  # a gap: empty territories
-        rel = np.cumsum(sh) - sh[0]
-        rels.append(rel.astype(np.int64))
-    rows, terr_off, owner = hm.ola_chunks(rels, N, T)
+def _emulate_runs(runs, rels, frames, N, total_out):
+    """numpy model of k_synth_ola_pair's flush rules + k_ola_fixup on the planner's runs (include/magphase_hip.h)."""
+    allrel = np.concatenate(rels)
+    pcm = np.full(total_out, np.nan)
+    writes = np.zeros(total_out, dtype=int)
+    strips = np.zeros((len(runs), N + 64))
+    for ri, r in enumerate(runs):
+        fb, fe, x0 = int(r["frame_begin"]), int(r["frame_end"]), int(r["x0"])
+        span = max(int(r["flush_end"]), int(allrel[fe - 1]) - x0 + N)
+        acc = np.zeros(span + 64)
+        for f in range(fb, fe):
+            x = int(allrel[f]) - x0
+            assert x >= 0
+            acc[x:x + N] += frames[f]
+        assert int(r["flush_end"]) >= int(allrel[fe - 1]) - x0 + N      # the ring ends up cleared
+        he, lo, hi = int(r["head_end"]), int(r["out_lo"]), int(r["out_hi"])
+        assert 0 <= he <= N + 64 and int(r["out_base"]) % 64 == 0
+        strips[ri, :he] = acc[:he]
+        if hi > lo:
+            assert lo >= he or he == 0 or lo >= 0
+            idx = int(r["out_base"]) + np.arange(lo, hi)
+            pcm[idx] = acc[lo:hi]
+            writes[idx] += 1
+    assert np.all(writes == 1)          # every kept sample written exactly once by the main kernel
+    for ri, r in enumerate(runs):       # fix-up: predecessor's sum (in pcm) + head strip
+        lo, hi = int(r["fix_lo"]), int(r["fix_hi"])
+        if hi > lo:
+            assert hi <= int(r["head_end"])
+            pcm[int(r["out_base"]) + np.arange(lo, hi)] += strips[ri, lo:hi]
+    return pcm
+
+
+@pytest.mark.parametrize("N,fpr,n_slots", [(4096, None, 1024), (4096, 7, 8), (4096, 1, 4), (2048, None, 16),
+                                           (2048, 3, 2), (1024, None, 4096), (4096, 1000, 1)])
+def test_ola_runs_write_every_sample_once_and_sum_to_plain_ola(N, fpr, n_slots):
+    rng = np.random.RandomState(N + (fpr or 0) + n_slots)
+    rels, starts, lens, v_pms = [], [], [], []
+    for u in range(5):
+        sh = rng.randint(60, 1000, size=rng.randint(2, 200))
+        if u != 1:
+            sh[rng.randint(0, len(sh))] = 7000                   # consecutive frames further apart than N: a gap of zeros
+        sh[0] = [150, N // 2 + 700, 90, 9000, N // 2][u]           # incl. first epoch beyond N/2 (negative slice start)
+        v_pm = np.cumsum(sh)
+        rel, start, out_len = hm.ola_plan(v_pm, N)
+        rels.append(rel), starts.append(start), lens.append(out_len), v_pms.append(v_pm)
+    out_off = np.concatenate(([0], np.cumsum(lens))).astype(np.int64)
+    runs = hm.ola_runs(rels, starts, lens, out_off, N, n_slots, frames_per_run=fpr)
     nfr_total = sum(len(r) for r in rels)
     seen = np.zeros(nfr_total, dtype=int)
-    for fb, fe, x0, _ in rows:
-        seen[fb:fe] += 1
-        assert (x0 + N // 2) % T == 0
-    assert np.all(seen == 1)
-    assert np.all(np.diff(rows[:, 1] - rows[:, 0]) <= 0)  # longest first
-    # emulate: strips + 3-neighbour fixup == plain OLA
+    for r in runs:
+        seen[int(r["frame_begin"]):int(r["frame_end"])] += 1
+    assert np.all(seen == 1) and np.all(np.diff(runs["frame_begin"]) > 0)
     frames = rng.randn(nfr_total, N)
-    strips = np.zeros((len(rows), T + N))
-    allrel = np.concatenate(rels)
-    for ci, (fb, fe, x0, _) in enumerate(rows):
-        for f in range(fb, fe):
-            x = allrel[f] - x0
-            assert 0 <= x < T + 0 * N and x + N <= T + N
-            strips[ci, x:x + N] += frames[f]
+    got = _emulate_runs(runs, rels, frames, N, int(out_off[-1]))
     f0 = 0
     for u, rel in enumerate(rels):
-        n = len(rel)
-        ref = np.zeros(rel[-1] + N)
-        for i in range(n):
-            ref[rel[i]:rel[i] + N] += frames[f0 + i]
-        got = np.zeros_like(ref)
-        nc = terr_off[u + 1] - terr_off[u]
-        for b in range(len(ref)):
-            c = b // T
-            for cc in (c - 1, c, c + 1):
-                if 0 <= cc < nc and owner[terr_off[u] + cc] >= 0:
-                    idx = b - (cc * T - N // 2)
-                    if 0 <= idx < T + N:
-                        got[b] += strips[owner[terr_off[u] + cc], idx]
-        assert np.max(np.abs(got - ref)) < 1e-12
-        f0 += n
+        ref = _emulate_ola(frames[f0:f0 + len(rel)], rel, starts[u], lens[u], v_pms[u][0])
+        assert len(ref) == lens[u]
+        assert np.max(np.abs(got[out_off[u]:out_off[u + 1]] - ref)) < 1e-12 if lens[u] else True
+        f0 += len(rel)
+    # only adjacent runs of an utterance overlap
+    f0 = 0
+    allrel = np.concatenate(rels)
+    for u, rel in enumerate(rels):
+        mine = [r for r in runs if f0 <= int(r["frame_begin"]) < f0 + len(rel)]
+        for a, c in zip(mine[:-2], mine[2:]):
+            assert allrel[int(a["frame_end"]) - 1] + N <= allrel[int(c["frame_begin"])]
+        f0 += len(rel)
+
+
+def test_ola_runs_balance_for_the_bench_shape():
+    """64 utterances x ~890 frames over 1024 slots: exactly one run per slot, the longest within 5 % of the mean."""
+    rng = np.random.RandomState(5)
+    rels, starts, lens = [], [], []
+    for u in range(64):
+        v_pm = np.cumsum(rng.randint(200, 350, size=rng.randint(860, 920)))
+        rel, start, out_len = hm.ola_plan(v_pm, 4096)
+        rels.append(rel), starts.append(start), lens.append(out_len)
+    out_off = np.concatenate(([0], np.cumsum(lens))).astype(np.int64)
+    runs = hm.ola_runs(rels, starts, lens, out_off, 4096, 1024)
+    n = runs["frame_end"] - runs["frame_begin"]
+    assert runs.size == 1024 and n.max() <= 1.05 * n.mean() + 1
+    slot_off, slot_runs = hm.balance_chunks(n, 1024)
+    assert np.all(np.diff(slot_off) == 1)
 
 
 class _FakeEngine:
@@ -115,5 +156,5 @@ def test_plans_build_without_gpu_and_match_oracle_indices():
         assert sp.out_len[u] == len(ref)
         off += len(x)
     assert sp.total_frames == ap.total_frames
-    assert sp.strip_floats == sp.n_chunks * (sp.territory + sp.fft_len)
-    assert sp.chunks.shape == (sp.n_chunks, 4)
+    assert sp.strip_floats == sp.n_runs * (sp.fft_len + 64)
+    assert sp.runs.dtype == np.uint8 and sp.runs.size == sp.n_runs * 56

@@ -1,79 +1,119 @@
 #!/usr/bin/env python
 """
-Within-process A/B timing of kernel build variants (guide rule: perf deltas < 10 % need interleaved rounds in ONE
-process).  Builds libmagphase_hip variants with extra -D flags into gpurun_out/ab/, loads each with ctypes and
-times the three hot-path launches on the bench workload, interleaved, reporting median / min per variant.
+Within-process A/B timing of kernel / planner versions (guide rule: perf deltas < 10 % need interleaved rounds in ONE
+process).  A variant is a complete copy of the package (python + csrc + include) plus extra hipcc flags:
 
-    python tools/ab_bench.py base: nostore:-DMPX_PROBE_NOSTORE w8:-DMPX_WAVES_PER_BLOCK=8
+    NAME             the working tree
+    NAME:-DFOO,-DBAR the working tree built with extra flags
+    NAME@REF         the tree of git ref REF (e.g. prev@HEAD~2), optionally NAME@REF:-DFOO
+
+    python tools/ab_bench.py --prepare prev@HEAD cur        # HERE (needs git + hipcc): snapshots + builds under tools/_ab/
+    python tools/ab_bench.py prev@HEAD cur                  # on the GPU box: loads tools/_ab/*, times interleaved
+
+Timed per variant and round, each bracketed by HIP events on the launch stream: the lossless analysis launch
+(aplan.run), the fused synthesis (splan.run = k_synth_ola_pair + k_ola_fixup) -- the bench.py workload.  Reports
+median / min per variant.  AB_WORKLOAD=lowdim times the configs[2] analysis (k_analysis + warp) and synthesis instead.
 """
-import ctypes
+import importlib
+import importlib.util
 import os
+import shutil
 import statistics
 import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-
-import torch  # noqa: E402
-
-import bench  # noqa: E402
-from magphase_amd import _lib, build  # noqa: E402
-from magphase_amd.engine import Engine, LosslessAnalysisPlan, LosslessSynthesisPlan  # noqa: E402
+AB = os.path.join(ROOT, "tools", "_ab")
 
 
-def build_variant(name, flags):
-    out_dir = os.path.join(ROOT, "gpurun_out", "ab")
-    os.makedirs(out_dir, exist_ok=True)
-    lib = os.path.join(out_dir, "libmagphase_hip_%s.so" % name)
-    srcs = build.SRCS
-    if "PREV" in flags:   # build the snapshot of the previous kernel sources kept (untracked) under tools/_ab_prev
-        flags = [f for f in flags if f != "PREV"]
-        srcs = [s.replace(ROOT, os.path.join(ROOT, "tools", "_ab_prev")) for s in build.SRCS]
-    cmd = [build.hipcc_path()] + build.FLAGS + flags + srcs + ["-o", lib]
+def parse(spec):
+    flags = []
+    if ":" in spec:
+        spec, fl = spec.split(":", 1)
+        flags = [f for f in fl.split(",") if f]
+    name, ref = (spec.split("@", 1) + [None])[:2]
+    return name, ref, flags
+
+
+def prepare(name, ref, flags):
+    dst = os.path.join(AB, name)
+    shutil.rmtree(dst, ignore_errors=True)
+    os.makedirs(dst)
+    if ref:
+        tar = subprocess.Popen(["git", "-C", ROOT, "archive", ref, "magphase_amd", "include"], stdout=subprocess.PIPE)
+        subprocess.check_call(["tar", "-x", "-C", dst], stdin=tar.stdout)
+        tar.wait()
+    else:
+        for d in ("magphase_amd", "include"):
+            shutil.copytree(os.path.join(ROOT, d), os.path.join(dst, d),
+                            ignore=shutil.ignore_patterns("__pycache__", "*.so", "*.pyc"))
+    csrc = os.path.join(dst, "magphase_amd", "csrc")
+    srcs = [os.path.join(csrc, f) for f in sorted(os.listdir(csrc)) if f.endswith(".hip")]
+    from magphase_amd import build
+
+    cmd = [build.hipcc_path()] + build.FLAGS + flags + srcs + ["-o", os.path.join(dst, "magphase_amd", "libmagphase_hip.so")]
+    print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    return lib
+
+
+def load(name):
+    pkg_dir = os.path.join(AB, name, "magphase_amd")
+    alias = "mpa_" + name
+    spec = importlib.util.spec_from_file_location(alias, os.path.join(pkg_dir, "__init__.py"),
+                                                  submodule_search_locations=[pkg_dir])
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[alias] = mod
+    spec.loader.exec_module(mod)
+    return importlib.import_module(alias + ".engine")
 
 
 def main():
-    specs = [a.split(":", 1) for a in sys.argv[1:]] or [["base", ""]]
+    args = sys.argv[1:]
+    if args and args[0] == "--prepare":
+        for spec in args[1:]:
+            prepare(*parse(spec))
+        return
+    import torch
+
+    import bench
+
+    names = [parse(a)[0] for a in args] or ["cur"]
     rounds = int(os.environ.get("AB_ROUNDS", "15"))
+    lowdim = os.environ.get("AB_WORKLOAD", "lossless") == "lowdim"
     torch.cuda.set_device(0)
-    engines = {}
-    for name, fl in specs:
-        path = build_variant(name, [f for f in fl.split(",") if f])
-        _lib._lib = None
-        _lib.LIB_PATH = path
-        engines[name] = Engine()
     utts = bench.make_batch(0)
-    first = engines[specs[0][0]]
-    aplan = LosslessAnalysisPlan(first, utts)
-    terr = int(os.environ.get("MAGPHASE_OLA_TERRITORY", aplan.fft_len))
-    splan = LosslessSynthesisPlan(first, aplan.v_f0, aplan.fs, aplan.fft_len, territory=terr)
-    splans = {n: LosslessSynthesisPlan(engines[n], aplan.v_f0, aplan.fs, aplan.fft_len, territory=terr) for n, _ in specs}
-    N, H, F = aplan.fft_len, aplan.fft_len // 2 + 1, aplan.total_frames
-    feats = tuple(first.empty_feats(F, H) for _ in range(3))
-    strips = first.empty((splan.strip_floats,))
-    pcm = first.empty((splan.total_out,))
-    times = {n: ([], [], []) for n, _ in specs}
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    steps = {}
+    for name in names:
+        em = load(name)
+        eng = em.Engine()
+        if not lowdim:
+            aplan = em.LosslessAnalysisPlan(eng, utts)
+            splan = em.LosslessSynthesisPlan(eng, aplan.v_f0, aplan.fs, aplan.fft_len)
+            H, F = aplan.fft_len // 2 + 1, aplan.total_frames
+            feats = tuple(eng.empty_feats(F, H) for _ in range(3))
+            strips = eng.empty((max(splan.strip_floats, 1),))
+            pcm = eng.empty((splan.total_out,))
+            steps[name] = (lambda aplan=aplan, feats=feats: aplan.run(out=feats),
+                           lambda splan=splan, feats=feats, strips=strips, pcm=pcm: splan.run(feats[0], feats[1], feats[2], strips=strips, out=pcm))
+        else:
+            sa, ss = bench.lowdim_plans(em, eng, utts)
+            steps[name] = (sa, ss)
+    times = {n: ([], []) for n in names}
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
     for r in range(rounds + 2):
-        for name, _ in specs:
-            e = engines[name]
+        for name in names:
             ev[0].record()
-            e.analysis_frames(N, aplan.sig, aplan.pos, aplan.left, aplan.right, out=feats)
+            steps[name][0]()
             ev[1].record()
-            e.synthesis_lossless_ola(N, feats[0], feats[1], feats[2], splans[name], strips)
+            steps[name][1]()
             ev[2].record()
-            e.ola_fixup(N, splan.territory, strips, splan.utt_chunk_off, splan.strip_id, splan.out_start,
-                        splan.out_off, splan.max_territories, splan.total_out, out=pcm)
-            ev[3].record()
             torch.cuda.synchronize()
             if r >= 2:
-                for k in range(3):
+                for k in range(2):
                     times[name][k].append(ev[k].elapsed_time(ev[k + 1]))
-    print("%-14s %22s %22s %22s   (ms: median / min over %d interleaved rounds)" % ("variant", "k_analysis", "k_synth_ola", "k_ola_fixup", rounds))
-    for name, _ in specs:
+    print("%-14s %22s %22s   (ms: median / min over %d interleaved rounds)" % ("variant", "analysis", "synthesis (+fixup)", rounds))
+    for name in names:
         t = times[name]
         print("%-14s " % name + " ".join("%10.4f /%9.4f" % (statistics.median(x), min(x)) for x in t))
 

@@ -13,7 +13,7 @@ for u in range(40):
 utts = [base[i % 40] for i in range(2400)]          # 2400 utterances x 3 s = 2 h of audio in ONE launch
 t = time.time(); ap = LosslessAnalysisPlan(eng, utts); print("analysis plan %.2fs, frames %d" % (time.time()-t, ap.total_frames))
 t = time.time(); mag, real, imag = ap.run(); torch.cuda.synchronize(); print("analysis %.1f ms, feats %.1f GB" % ((time.time()-t)*1e3, 3*mag.numel()*4/1e9))
-t = time.time(); sp = LosslessSynthesisPlan(eng, ap.v_f0, ap.fs, ap.fft_len); print("synthesis plan %.2fs, chunks %d" % (time.time()-t, sp.n_chunks))
+t = time.time(); sp = LosslessSynthesisPlan(eng, ap.v_f0, ap.fs, ap.fft_len); print("synthesis plan %.2fs, runs %d" % (time.time()-t, sp.n_runs))
 t = time.time(); pcm = sp.run(mag, real, imag); torch.cuda.synchronize(); print("synthesis %.1f ms" % ((time.time()-t)*1e3))
 # round trip on first / last utterance
 for u in (0, 2399):
