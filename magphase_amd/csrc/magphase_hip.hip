@@ -14,6 +14,14 @@
 
 namespace mpx {
 
+// Feature stores of k_analysis: plain by default; MPX_ANA_NT makes them non-temporal (streaming: the rows are not
+// read again by this kernel) -- an A/B knob, see DESIGN.md for what was measured.
+#ifdef MPX_ANA_NT
+#define MPX_ST(dst, val) __builtin_nontemporal_store((val), &(dst))
+#else
+#define MPX_ST(dst, val) ((dst) = (val))
+#endif
+
 template <int P>
 __global__ __launch_bounds__(kAnaThreads) void k_analysis(const float* __restrict__ sig,
                                                           const long long* __restrict__ fpos,
@@ -166,9 +174,9 @@ __global__ __launch_bounds__(kAnaThreads) void k_analysis(const float* __restric
 #ifdef MPX_PROBE_NOSTORE
                 asm volatile("" ::"v"(s2 * r), "v"(xr * r), "v"(xi * r));
 #else
-                mlo[64 * q] = s2 * r;
-                rlo[64 * q] = xr * r;
-                ilo[64 * q] = xi * r;
+                MPX_ST(mlo[64 * q], s2 * r);
+                MPX_ST(rlo[64 * q], xr * r);
+                MPX_ST(ilo[64 * q], xi * r);
 #endif
             }
             {
@@ -181,14 +189,14 @@ __global__ __launch_bounds__(kAnaThreads) void k_analysis(const float* __restric
 #else
                 if (q == 0) {
                     if (lane0) {                      // bin M
-                        row_m[M] = cm;
-                        row_r[M] = cr;
-                        row_i[M] = ci;
+                        MPX_ST(row_m[M], cm);
+                        MPX_ST(row_r[M], cr);
+                        MPX_ST(row_i[M], ci);
                     }
                 } else {                              // block S_{q-1}
-                    mhi[-64 * (q - 1)] = lane0 ? cm : hm;
-                    rhi[-64 * (q - 1)] = lane0 ? cr : hr;
-                    ihi[-64 * (q - 1)] = lane0 ? ci : hi_;
+                    MPX_ST(mhi[-64 * (q - 1)], lane0 ? cm : hm);
+                    MPX_ST(rhi[-64 * (q - 1)], lane0 ? cr : hr);
+                    MPX_ST(ihi[-64 * (q - 1)], lane0 ? ci : hi_);
                 }
 #endif
                 hm = cm;
@@ -203,9 +211,9 @@ __global__ __launch_bounds__(kAnaThreads) void k_analysis(const float* __restric
 #ifdef MPX_PROBE_NOSTORE
             asm volatile("" ::"v"(s2 * r), "v"(xr * r), "v"(xi * r), "v"(hm), "v"(hr), "v"(hi_));
 #else
-            mhi[-64 * (P / 2 - 1)] = lane0 ? s2 * r : hm;
-            rhi[-64 * (P / 2 - 1)] = lane0 ? xr * r : hr;
-            ihi[-64 * (P / 2 - 1)] = lane0 ? xi * r : hi_;
+            MPX_ST(mhi[-64 * (P / 2 - 1)], lane0 ? s2 * r : hm);
+            MPX_ST(rhi[-64 * (P / 2 - 1)], lane0 ? xr * r : hr);
+            MPX_ST(ihi[-64 * (P / 2 - 1)], lane0 ? xi * r : hi_);
 #endif
         }
         g = gn;
@@ -289,6 +297,22 @@ constexpr int kGroup = MPX_SYN_GROUP;            // waves sharing one ring (2: t
                                                  // waves of a group, so more waves only pay with their own rings -- no LDS left)
 constexpr int kPairs = kPairWaves / kGroup;      // rings (= work-list slots) per workgroup
 static_assert(kPairWaves % kGroup == 0, "waves per workgroup must be a multiple of the group size");
+#ifdef MPX_PROBE_TIMING
+// Timing probe build (tools/probe_timing.py): per-phase s_memtime deltas of every wave, summed into g_probe.  The time
+// reads wait for lgkmcnt(0), which also drains the wave's LDS queue: the phases are serialised a little more than in
+// the production build (the guide quotes ~+11 % wave cycles for this kind of instrumentation).
+__device__ unsigned long long g_probe[16];
+#define MPX_T(idx, ...)                                                                                       \
+    do {                                                                                                      \
+        unsigned long long t__;                                                                               \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__) : __VA_ARGS__ : "memory");            \
+        pr_acc[idx] += t__ - pr_last;                                                                         \
+        pr_last = t__;                                                                                        \
+    } while (0)
+#else
+#define MPX_T(idx, ...) do { } while (0)
+#endif
+
 template <int P>
 constexpr size_t lds_bytes_pair() {
     return sizeof(float) * (size_t)(tw_floats<P>() + kPairWaves * (P * kXStride) + kPairs * ring_len<P>() + 16);
@@ -361,24 +385,92 @@ __global__ __launch_bounds__(kPairWaves * 64) void k_synth_ola_pair(const float*
     settle(cur);
     if (!cur.valid) return;
 
+#ifdef MPX_PROBE_TIMING
+    unsigned long long pr_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pr_last;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pr_last)::"memory");
+#endif
+    // Software pipeline over the wave's frames: the features of the wave's NEXT frame are loaded (3P + 3 registers)
+    // right after this frame's inverse FFT -- when the transform's temporaries are dead -- and land while the wave waits
+    // for its ticket and overlap-adds; convert + merge of the next iteration then starts on data that is there
+    // (tools/probe_timing.py: loading at the point of use cost 23 % of a wave's time in exposed memory latency).
+    // Ablation builds (tools/ab_bench.py): MPX_PROBE_NOLOAD -- features faked from the lane id (no HBM reads: the
+    // compute + LDS floor); MPX_PROBE_NOFFT -- features loaded and summed, no transform (the memory floor);
+    // MPX_PROBE_NOOLA -- no ordered section (no ticket, flush or overlap-add).
+    PairFeat<P> ff;
+#ifdef MPX_PROBE_NOLOAD
+#define MPX_FEAT_LOAD(ff, f, ln)                                                                  \
+    do {                                                                                          \
+        _Pragma("unroll") for (int j_ = 0; j_ < P / 2; ++j_) {                                    \
+            ff.m[j_] = ff.mq[j_] = 1.0f + 0.001f * (float)(ln + j_);                              \
+            ff.a[j_] = ff.bq[j_] = 0.6f;                                                          \
+            ff.b[j_] = ff.aq[j_] = 0.8f;                                                          \
+        }                                                                                         \
+        ff.mH = 1.0f; ff.aH = 0.6f; ff.bH = 0.8f;                                                 \
+        asm volatile("" : "+v"(ff.m[0]), "+v"(ff.a[0]), "+v"(ff.b[0]), "+v"(ff.mq[1]));           \
+    } while (0)
+#elif defined(MPX_PROBE_WIDELOAD)   // with MPX_PROBE_NOFFT only: the same bytes as 16-byte loads (layout ignored)
+#define MPX_FEAT_LOAD(ff, f, ln)                                                                  \
+    do {                                                                                          \
+        const float* rows_[3] = {mag + (f) * ld, real + (f) * ld, imag + (f) * ld};               \
+        float* dst_[3][2] = {{ff.m, ff.mq}, {ff.a, ff.aq}, {ff.b, ff.bq}};                        \
+        _Pragma("unroll") for (int s_ = 0; s_ < 3; ++s_) {                                        \
+            _Pragma("unroll") for (int q_ = 0; q_ < P / 4; ++q_) {                                \
+                float4 v_;                                                                        \
+                __builtin_memcpy(&v_, rows_[s_] + 256 * q_ + 4 * (ln), 16);                       \
+                float* d_ = dst_[s_][q_ / (P / 8)] + 4 * (q_ % (P / 8));                          \
+                d_[0] = v_.x; d_[1] = v_.y; d_[2] = v_.z; d_[3] = v_.w;                           \
+            }                                                                                     \
+        }                                                                                         \
+        ff.mH = rows_[0][64 * P - (ln)]; ff.aH = rows_[1][64 * P - (ln)]; ff.bH = rows_[2][64 * P - (ln)]; \
+    } while (0)
+#else
+#define MPX_FEAT_LOAD(ff, f, ln) feat_load_paired<P>(ff, mag + (f) * ld, real + (f) * ld, imag + (f) * ld, ln)
+#endif
+#ifdef MPX_PROBE_STAGGER
+    for (int i = 0; i < wave * MPX_PROBE_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);   // ~8k cycles per step
+#endif
+    MPX_FEAT_LOAD(ff, (long long)cur.fi, lane_id);
     while (cur.valid) {
         int lane = lane_id;  // laundered per frame (see k_analysis)
         float wl_s = wl_s0, wl_c = wl_c0;
         asm volatile("" : "+v"(lane), "+v"(wl_s), "+v"(wl_c));
         Cursor nxt = cur;
         advance(nxt);
-
-        // Features are loaded right where they are used: no register prefetch.  With two waves per SIMD the partner
-        // wave covers the memory latency (a prefetch behind the FFT measured 4 % SLOWER), and the 99 registers are
-        // worth more as room to keep many LDS operations in flight.
-        PairFeat<P> ff;
-        {
-            const long long f = cur.fi;
-            feat_load_paired<P>(ff, mag + f * ld, real + f * ld, imag + f * ld, lane);
-        }
+        MPX_T(0, "v"(lane));
+        MPX_T(1, "v"(ff.m[0]), "v"(ff.bq[P / 2 - 1]), "v"(ff.bH));      // features landed
         float xr[P], xi[P];
+#ifdef MPX_PROBE_NOFFT
+        {
+            float acc = ff.mH + ff.aH + ff.bH;
+#pragma unroll
+            for (int j = 0; j < P / 2; ++j) acc += ff.m[j] + ff.a[j] + ff.b[j] + ff.mq[j] + ff.aq[j] + ff.bq[j];
+#pragma unroll
+            for (int j = 0; j < P; ++j) xr[j] = xi[j] = acc;
+        }
+#else
         feat_merge_paired<P>(ff, xr, xi, lane, wl_c, wl_s);
+        MPX_T(2, "v"(xr[0]), "v"(xi[0]), "v"(xr[P - 1]), "v"(xi[P - 1]), "v"(xr[P / 2]), "v"(xi[P / 2 - 1]));
         wave_fft<P, +1>(xr, xi, tw, xbuf, lane);
+#endif
+        MPX_T(3, "v"(xr[0]), "v"(xi[0]), "v"(xr[P - 1]), "v"(xi[P - 1]), "v"(xr[P / 2]), "v"(xi[P / 2 - 1]));
+        if (nxt.valid) {   // (issuing these before the transform instead -- 239 VGPRs, no spill -- measured the same time)
+            const long long f = nxt.fi;
+            MPX_FEAT_LOAD(ff, f, lane);
+        }
+#ifdef MPX_PROBE_LATENCY   // with MPX_PROBE_TIMING: phase 4 = issue of the prefetch + its full round trip, nothing hidden
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        MPX_T(4, "v"(lane));
+#endif
+#ifdef MPX_PROBE_NOOLA
+        {
+            float acc = 0.0f;
+#pragma unroll
+            for (int j = 0; j < P; ++j) acc += xr[j] * xi[j];
+            if (acc == 12345.678f) strips[lane] = acc;   // keeps the transform alive
+            cur = nxt;
+            continue;
+        }
+#endif
 
         // ---- ordered section: wait for this frame's ticket
         const int fi = cur.fi;
@@ -396,19 +488,31 @@ __global__ __launch_bounds__(kPairWaves * 64) void k_synth_ola_pair(const float*
             __builtin_amdgcn_s_sleep(1);
 #endif
         asm volatile("" ::: "memory");
+#ifdef MPX_PROBE_LATENCY
+        MPX_T(0, "s"(x));      // ticket wait booked under phase 0 in this build
+#else
+        MPX_T(4, "s"(x));
+#endif
         if (flushed < target) flush_ring<R>(ring, strip, pcm0, rd.head_end, rd.out_lo, rd.out_hi, flushed, target, lane);
         wave_sync();
+        MPX_T(5, "s"(x));
         ring_add<P>(smem, ring_byte, x, xr, xi, lane, [](float o, float v, int) { return o + v; },
                     [](int) { return true; });
         wave_sync();
+        MPX_T(6, "s"(x));
         if (fi == cur.fe - 1) {   // last frame of the run: stream out the rest, leave the ring cleared
             flush_ring<R>(ring, strip, pcm0, rd.head_end, rd.out_lo, rd.out_hi, target, rd.flush_end, lane);
             wave_sync();
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __hip_atomic_store(turn, ticket + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        MPX_T(7, "s"(x));
         cur = nxt;
     }
+#ifdef MPX_PROBE_TIMING
+    if (lane_id == 0)
+        for (int k = 0; k < 8; ++k) atomicAdd(&g_probe[k], pr_acc[k]);
+#endif
 }
 
 // pcm_out[out_base + e] += head strip[e], fix_lo <= e < fix_hi, for every run that has a predecessor in its utterance:
@@ -585,6 +689,18 @@ int mpx_ola_gather(void* stream, int fft_len, const float* frames, int32_t n_utt
     MPX_HIP_CHECK(hipGetLastError());
     return MPX_OK;
 }
+
+#ifdef MPX_PROBE_TIMING
+int mpx_probe_read(unsigned long long* host16, int reset) {   // probe builds only (not part of the ABI)
+    MPX_HIP_CHECK(hipDeviceSynchronize());
+    MPX_HIP_CHECK(hipMemcpyFromSymbol(host16, HIP_SYMBOL(g_probe), sizeof(unsigned long long) * 16));
+    if (reset) {
+        unsigned long long z[16] = {0};
+        MPX_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_probe), z, sizeof(z)));
+    }
+    return MPX_OK;
+}
+#endif
 
 int mpx_synth_ola_slots(void) { return device_cus() * kPairs; }
 

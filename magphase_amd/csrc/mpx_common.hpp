@@ -230,7 +230,7 @@ template <int P>
 struct PairFeat {
     float m[P / 2], a[P / 2], b[P / 2];      // own bins k = lane + 64 j
     float mq[P / 2], aq[P / 2], bq[P / 2];   // mirrors M - k
-    float mH, aH, bH;                        // bin M/2 (lane 0)
+    float mH, aH, bH;                        // bin M/2 + lane (used on lane 0: bin M/2)
 };
 
 template <int P>
@@ -244,21 +244,26 @@ __device__ __forceinline__ void feat_load_paired(PairFeat<P>& ff, const float* _
     const float* mhi = mrow + (M - lane);
     const float* rhi = rrow + (M - lane);
     const float* ihi = irow + (M - lane);
+#ifdef MPX_FEAT_NT
+#define MPX_LD(p) __builtin_nontemporal_load(p)
+#else
+#define MPX_LD(p) (*(p))
+#endif
 #pragma unroll
     for (int j = 0; j < P / 2; ++j) {
-        ff.m[j] = mlo[64 * j];
-        ff.a[j] = rlo[64 * j];
-        ff.b[j] = ilo[64 * j];
-        ff.mq[j] = mhi[-64 * j];
-        ff.aq[j] = rhi[-64 * j];
-        ff.bq[j] = ihi[-64 * j];
+        ff.m[j] = MPX_LD(mlo + 64 * j);
+        ff.a[j] = MPX_LD(rlo + 64 * j);
+        ff.b[j] = MPX_LD(ilo + 64 * j);
+        ff.mq[j] = MPX_LD(mhi - 64 * j);
+        ff.aq[j] = MPX_LD(rhi - 64 * j);
+        ff.bq[j] = MPX_LD(ihi - 64 * j);
     }
-    ff.mH = ff.aH = ff.bH = 0.0f;
-    if (lane == 0) {
-        ff.mH = mrow[M / 2];
-        ff.aH = rrow[M / 2];
-        ff.bH = irow[M / 2];
-    }
+    // bin M/2 is needed on lane 0 only; every lane loads "its" bin M/2 + lane instead (in range, one more coalesced
+    // vector load per stream): a lane-0-only load has a wave-uniform address, which the compiler turns into a SCALAR
+    // load followed by an immediate lgkmcnt(0) wait -- a full memory round trip in the middle of the prefetch.
+    ff.mH = mlo[M / 2];
+    ff.aH = rlo[M / 2];
+    ff.bH = ilo[M / 2];
 }
 
 template <int P>
@@ -335,40 +340,45 @@ struct RunDesc {
 static_assert(sizeof(RunDesc) == 56, "RunDesc must match mpx_ola_run");
 
 // Streams elements [from, to) out of the ring (head strip / pcm_out / nowhere, see RunDesc) and clears their slots.
-// from is a multiple of 64.  Four 64-element blocks per step: their LDS reads are in flight together (one LDS latency
-// per 256 elements instead of one per 64 -- this runs inside the ordered section of the ring, where every cycle is serial).
+// from is a multiple of 64.  One step = 256 elements, FOUR consecutive elements b .. b+3 per lane (b = b0 + 4 lane):
+// elements 2j / 2j+1 live in the even / odd half of the ring at index j, so a lane's quad is one 8-byte read from each
+// half (index b/2 is even and RH is even: aligned, and a pair never straddles the wrap), interleaved into ONE 16-byte
+// global store (1 KB per wave instruction; out_base is a multiple of 64 elements, so the stores are aligned) and cleared
+// by two 8-byte LDS writes -- 5 memory instructions per 256 elements instead of 12 with one element per lane.  Blocks
+// that touch a region boundary (head_end / out_lo / out_hi: at most a handful per run) take the per-element path.
+// This runs inside the ordered section of the ring, where every cycle is serial.
 template <int R>
 __device__ __forceinline__ void flush_ring(float* ring, float* __restrict__ strip, float* __restrict__ pcm0,
                                            int head_end, int out_lo, int out_hi, int from, int to, int lane) {
     constexpr int RH = R / 2;
-    // element b = b0 + lane: half = b & 1 (b0 even => lane parity), index (b >> 1) mod RH
-    float* half = ring + ((lane & 1) ? RH : 0);
-    int idx = ((from >> 1) % RH) + (lane >> 1);
-    idx = (idx >= RH) ? idx - RH : idx;
+    int j = ((from >> 1) % RH) + 2 * lane;      // index of the lane's first pair in each half
+    j = (j >= RH) ? j - RH : j;
     for (int b0 = from; b0 < to; b0 += 256) {
-        int id[4];
-        float v[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            id[r] = idx;
-            v[r] = half[idx];          // blocks past `to` are read but neither stored nor cleared
-            idx += 32;
-            idx = (idx >= RH) ? idx - RH : idx;
+        const int b = b0 + 4 * lane;
+        const bool act = b < to;
+        float2 ev = make_float2(0.0f, 0.0f), od = ev;
+        if (act) {
+            ev = *reinterpret_cast<const float2*>(ring + j);
+            od = *reinterpret_cast<const float2*>(ring + RH + j);
         }
+        const int bend = (min(b0 + 256, to) + 3) & ~3;   // end of the last active quad (to need not be a multiple of 4)
+        const bool whole_out = (b0 >= out_lo) && (bend <= out_hi) && (b0 >= head_end);   // wave-uniform
+        if (whole_out) {
+            if (act) *reinterpret_cast<float4*>(pcm0 + b) = make_float4(ev.x, od.x, ev.y, od.y);
+        } else if (act) {
+            const float v[4] = {ev.x, od.x, ev.y, od.y};
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int blk = b0 + 64 * r;
-            if (blk < to) {
-                const int b = blk + lane;
-                if (blk < head_end) {            // wave-uniform: only the first blocks of a run
-                    if (b < head_end) strip[b] = v[r];
-                }
-                if (blk + 64 > out_lo && blk < out_hi) {
-                    if (b >= out_lo && b < out_hi) pcm0[b] = v[r];
-                }
-                half[id[r]] = 0.0f;
+            for (int e = 0; e < 4; ++e) {
+                if (b + e < head_end) strip[b + e] = v[e];
+                if (b + e >= out_lo && b + e < out_hi) pcm0[b + e] = v[e];
             }
         }
+        if (act) {
+            *reinterpret_cast<float2*>(ring + j) = make_float2(0.0f, 0.0f);
+            *reinterpret_cast<float2*>(ring + RH + j) = make_float2(0.0f, 0.0f);
+        }
+        j += 128;
+        j = (j >= RH) ? j - RH : j;
     }
 }
 
@@ -379,7 +389,7 @@ __device__ __forceinline__ void flush_ring(float* ring, float* __restrict__ stri
 // q = brev(i), c = c_base + kappa: 64 q goes into the instruction's immediate offset, the wrap (-RH once the index
 // passes the end; the wrap point differs by at most one q between lanes) is a per-lane bit mask: bit q set <=>
 // wrapped, one v_bfe_i32 + v_bfi_b32 per access instead of compare / select pairs (and their hazard nops).
-// All reads first, then the adds, then the writes: one LDS latency per frame.  combine(old, value, n): new ring value
+// All reads of a plane first, then the adds, then the writes: one LDS latency per plane.  combine(old, value, n): new ring value
 // for sample n of the frame (plain sum, or windowed sum); live(q): false for register rows that add nothing.
 // (LDS float atomics -- ds_add_f32 -- measured ~190 LDS cycles per wave instruction on gfx950: plain read/add/write.)
 template <int P, typename CFn, typename LFn>
@@ -402,22 +412,24 @@ __device__ __forceinline__ void ring_add(float* smem_base, unsigned ring_byte, i
         const unsigned sel = (unsigned)__builtin_amdgcn_sbfe((int)m, q, 1);   // 0 or ~0
         return reinterpret_cast<float*>(base + ((sel & b) | (~sel & a)) + 256 * q);
     };
-    float o0[P], o1[P];
+    // plane by plane: P ring values in registers at a time (two LDS round trips per frame; all 2P at once cost P more
+    // registers, which the feature prefetch of the next frame needs)
 #pragma unroll
-    for (int i = 0; i < P; ++i) {
-        const int q = brev(i, LB);
-        o0[i] = o1[i] = 0.0f;
-        if (!live(q)) continue;
-        o0[i] = *at(a0, b0, m0, q);
-        o1[i] = *at(a1, b1, m1, q);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    for (int pl = 0; pl < 2; ++pl) {
+        const unsigned a = pl ? a1 : a0, b = pl ? b1 : b0, m = pl ? m1 : m0;
+        float o[P];
 #pragma unroll
-    for (int i = 0; i < P; ++i) {
-        const int q = brev(i, LB);
-        if (!live(q)) continue;
-        *at(a0, b0, m0, q) = combine(o0[i], xr[i], 2 * (kap + 64 * q));
-        *at(a1, b1, m1, q) = combine(o1[i], xi[i], 2 * (kap + 64 * q) + 1);
+        for (int i = 0; i < P; ++i) {
+            const int q = brev(i, LB);
+            o[i] = 0.0f;
+            if (live(q)) o[i] = *at(a, b, m, q);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            const int q = brev(i, LB);
+            if (live(q)) *at(a, b, m, q) = combine(o[i], pl ? xi[i] : xr[i], 2 * (kap + 64 * q) + pl);
+        }
     }
 }
 

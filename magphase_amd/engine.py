@@ -373,11 +373,11 @@ class Engine:
 def _plan_ola_runs(plan, pm_rel_list, starts, out_lens, out_off_host, fft_len, n_slots, frames_per_run, up):
     """Shared by the two synthesis plans: runs + slot work lists (hostmath.ola_runs / balance_chunks) -> upload list."""
     fpr = frames_per_run or int(os.environ.get("MAGPHASE_OLA_FRAMES_PER_RUN", 0)) or None
-    runs = hm.ola_runs(pm_rel_list, starts, out_lens, out_off_host, fft_len, n_slots, frames_per_run=fpr)
+    runs, slot_off, slot_runs = hm.ola_runs(pm_rel_list, starts, out_lens, out_off_host, fft_len, n_slots,
+                                            frames_per_run=fpr)
     plan.n_runs = int(runs.size)
     plan.runs_host = runs
     plan.strip_floats = plan.n_runs * (int(fft_len) + 64)
-    slot_off, slot_runs = hm.balance_chunks(runs["frame_end"] - runs["frame_begin"], n_slots)
     plan.n_slots = int(slot_off.size - 1)
     up.append(("runs", runs.view(np.uint8), np.uint8))
     up.append(("slot_off", slot_off, np.int32))

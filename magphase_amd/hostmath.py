@@ -112,36 +112,14 @@ OLA_RUN_DTYPE = np.dtype([("frame_begin", "<i4"), ("frame_end", "<i4"), ("x0", "
                           ("fix_hi", "<i4"), ("pad", "<i4"), ("out_base", "<i8"), ("strip_off", "<i8")])
 
 
-def _runs_per_utterance(n_frames, n_slots):
+def _run_cuts(rel, N, target):
     """
-    How many runs each utterance gets so that sum(k_u) == n_slots (one run per pair slot) and the longest run,
-    max ceil(F_u / k_u), is as short as possible: floor shares first, the left-over slots to the utterances whose runs
-    are longest (largest-remainder apportionment).  Fewer frames than slots: one frame per run.
-    """
-    n_frames = np.asarray(n_frames, dtype=np.int64)
-    total = int(n_frames.sum())
-    if total <= n_slots:
-        return np.maximum(n_frames, 1)
-    k = np.maximum(1, (n_frames * n_slots) // total)
-    left = int(n_slots - k.sum())
-    while left > 0:
-        per = n_frames / k
-        order = np.argsort(-per, kind="stable")[:left]
-        k[order] += 1
-        left = int(n_slots - k.sum())
-    return k
-
-
-def _run_cuts(rel, N, target, k=None):
-    """
-    Frame indices at which one utterance's frames are cut into k runs (default: runs of about ``target`` frames), such
-    that only ADJACENT runs overlap in the OLA buffer: rel[cut_{k+1}] - rel[cut_k - 1] >= N for every run k with both
-    neighbours (a frame covers [rel, rel + N)).  Returns int64 cuts, cuts[0] == 0, cuts[-1] == n.
+    Frame indices at which one utterance's frames are cut into runs of about ``target`` frames, such that only ADJACENT
+    runs overlap in the OLA buffer: rel[cut_{k+1}] - rel[cut_k - 1] >= N for every run k with both neighbours
+    (a frame covers [rel, rel + N)).  Returns int64 cuts, cuts[0] == 0, cuts[-1] == n.
     """
     n = int(rel.size)
-    k = int(k) if k else max(1, int(round(n / float(max(1, target)))))
-    k = max(1, min(k, n))
-    target = max(1, n // k)
+    k = max(1, min(n, int(round(n / float(max(1, target))))))
     cuts = np.round(np.linspace(0, n, k + 1)).astype(np.int64)
     if k > 2:
         inner = cuts[1:-1]   # runs 1 .. k-2 have both neighbours: span from the frame before their first to the next run's first
@@ -166,23 +144,46 @@ def _run_cuts(rel, N, target, k=None):
     return np.asarray(out, dtype=np.int64)
 
 
+def _enforce_span(rel, N, cuts):
+    """Drops cuts until every run with both neighbours satisfies rel[next run's first] - rel[own first - 1] >= N."""
+    cuts = [int(c) for c in cuts]
+    k = 1
+    while k < len(cuts) - 2:
+        if rel[cuts[k + 1]] - rel[cuts[k] - 1] < N:
+            del cuts[k + 1]          # the run grows into its successor
+        else:
+            k += 1
+    return np.asarray(cuts, dtype=np.int64)
+
+
 def ola_runs(pm_rel_list, starts, out_lens, out_offs, fft_len, n_slots, frames_per_run=None):
     """
-    Plans the fused overlap-add (include/magphase_hip.h: mpx_synthesis_lossless_ola).  Every utterance's frames are cut
-    into runs of consecutive frames, about total_frames / n_slots each (``frames_per_run`` overrides the target), so
-    that each pair slot of the device gets one run of nearly equal length; per run the positions are classified as
-    head strip / final output / dropped (see mpx_ola_run) in the coordinates of the reference's OLA buffer
-    (magphase.py:38-61): frame i covers [pm_rel[i], pm_rel[i] + N), the kept part is [start, start + out_len).
+    Plans the fused overlap-add (include/magphase_hip.h: mpx_synthesis_lossless_ola).  The batch's frames, in utterance
+    order, are dealt to the device's pair slots in equal shares: slot s gets the frames
+    [round(s F / n_slots), round((s+1) F / n_slots)) of the concatenated sequence (every slot the same number +- 1: the
+    kernel ends when the slowest slot does).  A share that crosses an utterance boundary is two (or more) RUNS -- the end
+    of one utterance and the beginning of the next; runs never cross utterances.  ``frames_per_run`` instead cuts every
+    utterance on its own into runs of about that many frames and balances the slots longest-run-first (tests, tuning).
+    Per run the positions are classified as head strip / final output / dropped (see mpx_ola_run) in the coordinates
+    of the reference's OLA buffer (magphase.py:38-61): frame i covers [pm_rel[i], pm_rel[i] + N), the kept part is
+    [start, start + out_len).  Only ADJACENT runs of an utterance may overlap: rel[next run's first frame] -
+    rel[own first frame - 1] >= N for every run with both neighbours (cuts violating it are dropped).
 
     pm_rel_list: per utterance int64[F_u]; starts / out_lens: ola_plan's (out_start, out_len) per utterance;
     out_offs: int64[U+1] offsets of the utterances in pcm_out.
-    Returns a structured array (OLA_RUN_DTYPE) of the runs in utterance / frame order.
+    Returns (runs, slot_off, slot_runs): a structured array (OLA_RUN_DTYPE) of the runs in utterance / frame order and
+    the slots' work lists (slot s processes runs slot_runs[slot_off[s] : slot_off[s+1]] in that order).
     """
     N = int(fft_len)
     strip_floats = N + 64
-    total = int(sum(int(np.size(r)) for r in pm_rel_list))
-    target = int(frames_per_run) if frames_per_run else max(1, -(-total // max(1, int(n_slots))))
-    k_utt = None if frames_per_run else _runs_per_utterance([int(np.size(r)) for r in pm_rel_list], max(1, int(n_slots)))
+    n_frames = np.asarray([int(np.size(r)) for r in pm_rel_list], dtype=np.int64)
+    total = int(n_frames.sum())
+    n_slots = max(1, int(n_slots))
+    if frames_per_run:
+        target, gcuts = int(frames_per_run), None
+    else:
+        target = max(1, -(-total // n_slots))
+        gcuts = np.round(np.linspace(0, total, min(n_slots, max(total, 1)) + 1)).astype(np.int64)
     recs = []
     f_base = 0
     for u, rel in enumerate(pm_rel_list):
@@ -191,7 +192,11 @@ def ola_runs(pm_rel_list, starts, out_lens, out_offs, fft_len, n_slots, frames_p
         if n == 0:
             continue
         start, out_len, o0 = int(starts[u]), int(out_lens[u]), int(out_offs[u])
-        cuts = _run_cuts(rel, N, target, None if k_utt is None else k_utt[u])
+        if gcuts is None:
+            cuts = _run_cuts(rel, N, target)
+        else:   # the global cuts that fall inside this utterance
+            inner = gcuts[(gcuts > f_base) & (gcuts < f_base + n)] - f_base
+            cuts = _enforce_span(rel, N, np.concatenate(([0], inner, [n])))
         fb, fe = cuts[:-1], cuts[1:]
         k = fb.size
         hi = rel[fe - 1] + N                          # end of the run's last frame
@@ -225,7 +230,14 @@ def ola_runs(pm_rel_list, starts, out_lens, out_offs, fft_len, n_slots, frames_p
         f_base += n
     runs = np.concatenate(recs) if recs else np.zeros(0, dtype=OLA_RUN_DTYPE)
     runs["strip_off"] = np.arange(runs.size, dtype=np.int64) * strip_floats
-    return runs
+    if gcuts is None:
+        slot_off, slot_runs = balance_chunks(runs["frame_end"] - runs["frame_begin"], n_slots)
+    else:   # a run belongs to the share its first frame lies in; shares are consecutive, so are their runs
+        ns = gcuts.size - 1
+        slot_of = np.clip(np.searchsorted(gcuts, runs["frame_begin"], side="right") - 1, 0, ns - 1)
+        slot_off = np.searchsorted(slot_of, np.arange(ns + 1), side="left").astype(np.int64)
+        slot_runs = np.arange(runs.size, dtype=np.int64)
+    return runs, slot_off, slot_runs
 
 
 def balance_chunks(n_frames_per_chunk, n_slots, overhead=2):
