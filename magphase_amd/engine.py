@@ -448,9 +448,10 @@ class LosslessAnalysisPlan:
         self.long_frame_lens = [(l + r + 1)[(l + r + 1) > self.fft_len].tolist() for l, r in zip(left, right)]
         e = engine
         self.sig = e.upload_staged(total) if staged else e.to_device(buf, np.float32)
-        self.pos = e.to_device(np.concatenate(pos) if pos else np.zeros(0), np.int64)
-        self.left = e.to_device(np.concatenate(left) if left else np.zeros(0), np.int32)
-        self.right = e.to_device(np.concatenate(right) if right else np.zeros(0), np.int32)
+        desc = e.to_device_packed([("pos", np.concatenate(pos) if pos else np.zeros(0), np.int64),     # one H2D copy
+                                   ("left", np.concatenate(left) if left else np.zeros(0), np.int32),
+                                   ("right", np.concatenate(right) if right else np.zeros(0), np.int32)])
+        self.pos, self.left, self.right = desc["pos"], desc["left"], desc["right"]
         self.total_smpls = int(off)
 
     def run(self, out=None):
@@ -670,46 +671,77 @@ class CompressedSynthesisPlan:
             gains.append(tuple(g))
         return inv
 
-    def run(self, out=None, keep=False):
+    def _buffers(self):
+        """Work buffers of run(), allocated once per plan (the caching allocator makes a re-allocation per call cheap
+        but not free: ~1.6 GB of spectra + strips + per-frame scalars)."""
+        b = getattr(self, "_buf", None)
+        if b is None:
+            e, torch = self.engine, _torch()
+            H = self.fft_len // 2 + 1
+            ld = int(e.lib.mpx_spec_ld(H))
+            b = self._buf = dict(
+                ld=ld,
+                spec=tuple(e.empty((self.n_rows, ld))[:, :H] for _ in range(3)),
+                sums=e.empty((self.total_frames,)),
+                inv_gain=e.empty((self.total_frames,)),
+                gains=torch.empty((self.n_utts, 2), dtype=torch.float64, device=e.device),
+                strips=e.empty((max(self.strip_floats, 1),)),
+            )
+            if self.per_phase_type != "magphase":
+                F = self.total_frames
+                b["ident"] = torch.arange(F, dtype=torch.int32, device=e.device)
+                b["zeros_t"] = torch.zeros(F, dtype=torch.float32, device=e.device)
+                b["spec_v"] = tuple(e.empty((F, ld))[:, :H] for _ in range(3))
+        return b
+
+    def run(self, out=None, keep=False, mark=None):
+        """mark: optional callable(name), called after every kernel launch has been enqueued (bench.py: HIP events)."""
         e, lib, N = self.engine, self.engine.lib, self.fft_len
         torch = _torch()
         H = N // 2 + 1
         tab = e.tables(N)
+        mark = mark or (lambda name: None)
+        buf = self._buffers()
         # unwarped spectra: internal matrices, rows 128-byte aligned (mpx_spec_ld: full-line stores of the MFMA unwarp)
-        ld = int(lib.mpx_spec_ld(H))
-        mag, real, imag = (e.empty((self.n_rows, ld))[:, :H] for _ in range(3))
-        sums = e.empty((self.total_frames,))
-        strips = e.empty((max(self.strip_floats, 1),))
+        ld = buf["ld"]
+        mag, real, imag = buf["spec"]
+        sums, strips, inv_gain = buf["sums"], buf["strips"], buf["inv_gain"]
         pcm = out if out is not None else e.empty((self.total_out,))
         with torch.cuda.device(e.device):
             st = e.stream_ptr()
-            a_mag = e.post_filter(self.a_mag, self.fs) if self.apply_post_filter else self.a_mag   # magphase.py:3259-3261
+            mark("start")
+            a_mag = self.a_mag
+            if self.apply_post_filter:   # magphase.py:3259-3261
+                a_mag = e.post_filter(self.a_mag, self.fs)
+                mark("k_post_filter")
             _lib.check(lib.mpx_mel_unwarp(st, self.n_rows, H, a_mag.data_ptr(), self.mag_dim, self.u_mag.data_ptr(),
                                           mag.data_ptr(), self.a_real.data_ptr(), self.a_imag.data_ptr(),
                                           self.phase_dim, self.u_phase.data_ptr(), real.data_ptr(), imag.data_ptr(), ld),
                        "mpx_mel_unwarp")
+            mark("k_mel_unwarp_mfma")
             _lib.check(lib.mpx_noise_stats(st, N, tab.data_ptr(), self.noise.data_ptr(), self.npos.data_ptr(),
                                            self.nleft.data_ptr(), self.nright.data_ptr(), self.wtype.data_ptr(),
                                            self.total_frames, sums.data_ptr()), "mpx_noise_stats")
+            mark("k_noise_stats")
             # two gains per utterance (Q10): float64 reduction on the device, no host round trip
-            inv_gain = e.empty((self.total_frames,))
-            self._gains_dev = torch.empty((self.n_utts, 2), dtype=torch.float64, device=e.device)
+            self._gains_dev = buf["gains"]
             _lib.check(lib.mpx_noise_gains(st, sums.data_ptr(), self.voiced.data_ptr(), self.utt_frame_off.data_ptr(),
                                            self.n_utts, H - 2, inv_gain.data_ptr(), self._gains_dev.data_ptr()),
                        "mpx_noise_gains")
+            mark("k_noise_gains")
             row0, row1, rowt = self.row0, self.row1, self.rowt
             if self.per_phase_type != "magphase":
                 # periodic component's phase is not the transmitted one (magphase.py:933-938):
                 #   'min_phase': complex-cepstrum minimum phase of the (row-interpolated) magnitude, per frame
                 #   'linear'   : zero phase
                 F = self.total_frames
-                ident = torch.arange(F, dtype=torch.int32, device=e.device)
-                zeros_t = torch.zeros(F, dtype=torch.float32, device=e.device)
-                mag_v, real_v, imag_v = (e.empty((F, ld))[:, :H] for _ in range(3))
+                ident, zeros_t = buf["ident"], buf["zeros_t"]
                 if self.per_phase_type == "min_phase":
+                    mag_v, real_v, imag_v = buf["spec_v"]
                     _lib.check(lib.mpx_min_phase(st, N, tab.data_ptr(), mag.data_ptr(), row0.data_ptr(),
                                                  row1.data_ptr(), rowt.data_ptr(), F, mag_v.data_ptr(),
                                                  real_v.data_ptr(), imag_v.data_ptr(), ld), "mpx_min_phase")
+                    mark("k_min_phase")
                     mag, real, imag = mag_v, real_v, imag_v
                     row0, row1, rowt = ident, ident, zeros_t
                 else:
@@ -723,7 +755,9 @@ class CompressedSynthesisPlan:
                 self.per_v.data_ptr(), self.ap_v.data_ptr(), self.ap_u.data_ptr(), self.runs.data_ptr(),
                 self.n_runs, self.slot_off.data_ptr(), self.slot_runs.data_ptr(), self.n_slots,
                 strips.data_ptr(), pcm.data_ptr(), ld), "mpx_synthesis_compressed_ola")
+            mark("k_synth_comp_pair")
         e.ola_fixup(N, self, strips, pcm)
+        mark("k_ola_fixup")
         if keep:
             self.debug = dict(mag=mag, real=real, imag=imag, sums=sums)
         return pcm
@@ -794,18 +828,21 @@ class CompressedAnalysisPlan:
             row0.append(lo + base), row1.append(hi + base), rowt.append(t), self.f0_out.append(v_f0)
         self.out_off = np.concatenate(([0], np.cumsum([len(f) for f in self.f0_out]))).astype(np.int64)
         self.total_out_frames = int(self.out_off[-1])
-        self.voi = e.to_device(np.concatenate([(f > 0).astype(np.float64) for f in self.f0_out]), np.float32)
+        items = [("voi", np.concatenate([(f > 0).astype(np.float64) for f in self.f0_out]), np.float32)]
         if b_const_rate:
-            self.row0 = e.to_device(np.concatenate(row0), np.int32)
-            self.row1 = e.to_device(np.concatenate(row1), np.int32)
-            self.rowt = e.to_device(np.concatenate(rowt), np.float32)
-        else:
-            self.row0 = self.row1 = self.rowt = None
+            items += [("row0", np.concatenate(row0), np.int32), ("row1", np.concatenate(row1), np.int32),
+                      ("rowt", np.concatenate(rowt), np.float32)]
+        desc = e.to_device_packed(items)   # one H2D copy
+        self.voi = desc["voi"]
+        self.row0, self.row1, self.rowt = (desc.get(k) for k in ("row0", "row1", "rowt"))
 
-    def run(self, feats=None, out=None):
+    def run(self, feats=None, out=None, mark=None):
         e, torch = self.engine, _torch()
         H = self.fft_len // 2 + 1
+        mark = mark or (lambda name: None)
+        mark("start")
         mag, real, imag = self.lossless.run(out=feats)
+        mark("k_analysis")
         if out is None:
             out = (e.empty((self.total_out_frames, self.mag_dim)), e.empty((self.total_out_frames, self.phase_dim)),
                    e.empty((self.total_out_frames, self.phase_dim)))
@@ -816,6 +853,7 @@ class CompressedAnalysisPlan:
                                           self.w_mag.data_ptr(), self.mag_dim, self.w_ph.data_ptr(), self.phase_dim,
                                           self.voi.data_ptr(), out[0].data_ptr(), out[1].data_ptr(),
                                           out[2].data_ptr(), e.feat_ld(mag, real, imag)), "mpx_mel_warp")
+        mark("k_mel_warp_mfma")
         return out
 
 

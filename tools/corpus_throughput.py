@@ -3,6 +3,9 @@
 End-to-end corpus throughput through the file interface: wav + .est files on disk ->
 iobatch.extract_features_corpus (reader thread, batched kernels, writer thread) -> feature files ->
 iobatch.generate_waveforms_corpus -> wav files.  Everything the reference's two batch scripts do, timed wall-clock.
+
+    python tools/corpus_throughput.py            # N_UTT=128 utterances of 5 s
+bench.py imports run() for its "e2e" block.
 """
 import os
 import shutil
@@ -15,38 +18,52 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "demos"))
 import numpy as np  # noqa: E402
 
-import make_demo_data  # noqa: E402
-from magphase_amd import iobatch, libaudio as la, synthetic as syn  # noqa: E402
 
-N_UTT, DUR = int(os.environ.get("N_UTT", 128)), 5.0
-tmp = tempfile.mkdtemp(prefix="mpx_corpus_")
-try:
-    wav_dir = os.path.join(tmp, "wavs")
-    os.makedirs(wav_dir)
-    toks = []
-    for u in range(N_UTT):
-        pcm, pm, voi = syn.make_utterance(3000 + u, dur_s=DUR)
-        tok = "u%04d" % u
-        la.write_audio_file(os.path.join(wav_dir, tok + ".wav"), pcm / 32768.0, 48000, norm=None)
-        make_demo_data.write_est(os.path.join(wav_dir, tok + ".est"), pm, voi)
-        toks.append(tok)
-    wavs = [os.path.join(wav_dir, t + ".wav") for t in toks]
-    feats = os.path.join(tmp, "feats")
-    iobatch.extract_features_corpus(wavs[:8], os.path.join(tmp, "warm"), batch_utts=8, phase_dim=45, verbose=False)
-    t = time.time()
-    iobatch.extract_features_corpus(wavs, feats, batch_utts=32, phase_dim=45, verbose=False)
-    t_ext = time.time() - t
-    np.random.seed(1)
-    iobatch.generate_waveforms_corpus(feats, toks[:8], os.path.join(tmp, "warm_syn"), 60, 45, 48000, pf_type="magphase",
-                                      batch_utts=8, verbose=False)
-    t = time.time()
-    iobatch.generate_waveforms_corpus(feats, toks, os.path.join(tmp, "syn"), 60, 45, 48000, pf_type="magphase",
-                                      batch_utts=32, verbose=False)
-    t_gen = time.time() - t
-    audio = N_UTT * DUR
-    print("feature extraction (wav+est -> .mag/.real/.imag/.lf0/.shift): %d utterances, %.0f s of audio in %.2f s = %.0f x real time"
-          % (N_UTT, audio, t_ext, audio / t_ext))
-    print("waveform generation (features -> post-filter -> wav):          %d utterances, %.0f s of audio in %.2f s = %.0f x real time"
-          % (N_UTT, audio, t_gen, audio / t_gen))
-finally:
-    shutil.rmtree(tmp, ignore_errors=True)
+def run(n_utt=128, dur=5.0, batch_utts=32, noise_mode=None):
+    """Returns a dict with the two rates (x real time) and the wall times; files live in a temporary directory."""
+    import make_demo_data
+    from magphase_amd import iobatch, libaudio as la, synthetic as syn
+
+    tmp = tempfile.mkdtemp(prefix="mpx_corpus_")
+    try:
+        wav_dir = os.path.join(tmp, "wavs")
+        os.makedirs(wav_dir)
+        toks = []
+        for u in range(n_utt):
+            pcm, pm, voi = syn.make_utterance(3000 + u, dur_s=dur)
+            tok = "u%04d" % u
+            la.write_audio_file(os.path.join(wav_dir, tok + ".wav"), pcm / 32768.0, 48000, norm=None)
+            make_demo_data.write_est(os.path.join(wav_dir, tok + ".est"), pm, voi)
+            toks.append(tok)
+        wavs = [os.path.join(wav_dir, t + ".wav") for t in toks]
+        feats = os.path.join(tmp, "feats")
+        iobatch.extract_features_corpus(wavs[:8], os.path.join(tmp, "warm"), batch_utts=8, phase_dim=45, verbose=False)
+        t = time.time()
+        iobatch.extract_features_corpus(wavs, feats, batch_utts=batch_utts, phase_dim=45, verbose=False)
+        t_ext = time.time() - t
+        kw = {} if noise_mode is None else {"noise_mode": noise_mode}
+        np.random.seed(1)
+        iobatch.generate_waveforms_corpus(feats, toks[:8], os.path.join(tmp, "warm_syn"), 60, 45, 48000,
+                                          pf_type="magphase", batch_utts=8, verbose=False, **kw)
+        t = time.time()
+        iobatch.generate_waveforms_corpus(feats, toks, os.path.join(tmp, "syn"), 60, 45, 48000, pf_type="magphase",
+                                          batch_utts=batch_utts, verbose=False, **kw)
+        t_gen = time.time() - t
+        audio = n_utt * dur
+        return {"what": "%d wav + .est files of %.0f s @48 kHz on local disk, one process, one GPU, iobatch reader / "
+                        "compute / writer pipeline, %d utterances per launch: extraction = analysis_for_acoustic_modelling "
+                        "(60 + 45 + 45 + lf0 + shift files), generation = post-filter + synthesis_from_compressed + "
+                        "16-bit wav" % (n_utt, dur, batch_utts),
+                "audio_s": audio, "extraction_s": round(t_ext, 3), "generation_s": round(t_gen, 3),
+                "extraction_x_realtime": round(audio / t_ext, 1), "generation_x_realtime": round(audio / t_gen, 1),
+                "generation_noise": noise_mode or "reference (numpy global RNG)"}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+if __name__ == "__main__":
+    r = run(n_utt=int(os.environ.get("N_UTT", 128)), noise_mode=os.environ.get("NOISE_MODE"))
+    print("feature extraction (wav+est -> .mag/.real/.imag/.lf0/.shift): %.0f s of audio in %.2f s = %.0f x real time"
+          % (r["audio_s"], r["extraction_s"], r["extraction_x_realtime"]))
+    print("waveform generation (features -> post-filter -> wav):          %.0f s of audio in %.2f s = %.0f x real time"
+          % (r["audio_s"], r["generation_s"], r["generation_x_realtime"]))
