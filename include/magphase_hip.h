@@ -156,6 +156,18 @@ int mpx_mel_unwarp(void* stream, int64_t n_frames, int32_t n_bins, const float* 
 int64_t mpx_spec_ld(int32_t n_bins);
 
 /*
+ * Device noise source -- OPT-IN replacement of np.random.uniform(-1, 1, n) (magphase.py:883; the reference draws the
+ * aperiodic excitation from numpy's global Mersenne twister on the host).  out[offsets[u] + i] = sample i of utterance
+ * u = word (i & 3) of Philox4x32-10(counter = i >> 2, key = seeds[u]) mapped to (w >> 8) * 2^-23 - 1 in [-1, 1).
+ * A sample depends on (seed, i) only: the result is independent of batching and sharding (bit-identical files from 1 or
+ * 8 GPUs).  Same distribution as the reference's source, NOT its sample values; the default mode of the Python layer
+ * keeps drawing on the host so that a seeded run reproduces the reference sample for sample.
+ * seeds: uint64[n_utts]; offsets: int64[n_utts+1]; max_len: longest utterance (grid sizing).
+ */
+int mpx_noise_uniform(void* stream, int32_t n_utts, const uint64_t* seeds, const int64_t* offsets, int64_t max_len,
+                      float* out);
+
+/*
  * Noise-gain statistics (magphase.py:886-903, Q10/Q11): for every frame, the windowed noise frame
  * (frame_wtype 0: Hann halves, 1: np.bartlett**2.5 halves; epoch at index 0) is transformed and
  * out_sum[f] = sum_{k=1}^{N/2-1} (ln|Ns[k]|)^2.  The host turns the per-class means into the two gains per utterance.

@@ -25,6 +25,7 @@ SYMBOLS = (
     "mpx_ola_fixup",
     "mpx_mel_unwarp",
     "mpx_spec_ld",
+    "mpx_noise_uniform",
     "mpx_noise_stats",
     "mpx_synth_comp_slots",
     "mpx_synthesis_compressed_ola",
@@ -83,6 +84,8 @@ def load():
     lib.mpx_mel_unwarp.argtypes = [vp, i64, i32, vp, i32, vp, vp, vp, vp, i32, vp, vp, vp, i64]
     lib.mpx_spec_ld.restype = i64
     lib.mpx_spec_ld.argtypes = [i32]
+    lib.mpx_noise_uniform.restype = ctypes.c_int
+    lib.mpx_noise_uniform.argtypes = [vp, i32, vp, vp, i64, vp]
     lib.mpx_noise_stats.restype = ctypes.c_int
     lib.mpx_noise_stats.argtypes = [vp, ctypes.c_int, vp, vp, vp, vp, vp, vp, i64, vp]
     lib.mpx_synth_comp_slots.restype = ctypes.c_int

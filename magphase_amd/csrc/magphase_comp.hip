@@ -284,6 +284,43 @@ __global__ __launch_bounds__(kAnaThreads) void k_noise_stats(const float* __rest
 }
 
 // ---------------------------------------------------------------------------------------------
+// Device noise source (opt-in replacement of the reference's np.random.uniform(-1, 1, n), magphase.py:883, which draws
+// from numpy's global Mersenne twister on the host: 31 M draws per 128 utterances, the largest host cost of waveform
+// generation).  Counter-based Philox4x32-10 (Salmon et al., SC'11): sample i of utterance u is word i & 3 of
+// philox(counter = (i >> 2, 0, 0, 0) as 64 + 64 bits, key = seed_u), mapped to (u32 >> 8) * 2^-23 - 1 in [-1, 1).
+// The value of a sample depends on (seed, i) only -- not on batching, sharding or launch geometry -- so a corpus
+// generated on 1 or 8 GPUs, 1 or 64 utterances per launch, is bit-identical.  Integer arithmetic: the numpy restatement
+// in tests/test_noise_rng.py must agree bit for bit.  NOT the reference's sample values (same distribution).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(unsigned (&c)[4], unsigned k0, unsigned k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned long long p0 = (unsigned long long)0xD2511F53u * c[0];
+        const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c[2];
+        const unsigned n0 = (unsigned)(p1 >> 32) ^ c[1] ^ k0, n1 = (unsigned)p1;
+        const unsigned n2 = (unsigned)(p0 >> 32) ^ c[3] ^ k1, n3 = (unsigned)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_noise_uniform(const unsigned long long* __restrict__ seeds,
+                                                       const long long* __restrict__ off, float* __restrict__ out) {
+    const int u = blockIdx.y;
+    const long long n = off[u + 1] - off[u];
+    const long long q = (long long)blockIdx.x * 256 + threadIdx.x;   // group of 4 samples
+    if (4 * q >= n) return;
+    const unsigned long long seed = seeds[u];
+    unsigned c[4] = {(unsigned)q, (unsigned)((unsigned long long)q >> 32), 0u, 0u};
+    philox4x32_10(c, (unsigned)seed, (unsigned)(seed >> 32));
+    float* o = out + off[u] + 4 * q;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (4 * q + e < n) o[e] = (float)(c[e] >> 8) * (1.0f / 8388608.0f) - 1.0f;
+}
+
+// ---------------------------------------------------------------------------------------------
 // noise gains (magphase.py:902-906, Q10): per utterance and class (voiced / unvoiced)
 //   g = sqrt(exp(mean over the class's frames and bins 1..N/2-1 of (ln|Ns|)^2)),  inv_gain[f] = 1 / g(class of f)
 // from the per-frame sums of k_noise_stats.  One block per utterance, float64 accumulation; an empty class gives
@@ -1232,6 +1269,19 @@ int mpx_min_phase(void* stream, int fft_len, const void* tables, const float* ma
         hipLaunchKernelGGL(k_min_phase<8>, grid, block, lds_bytes<8>(), s, mag, row0, row1, row_t,
                            (long long)n_frames, (const float*)tables, out_mag, out_real, out_imag, (long long)ld);
     }
+    MPX_HIP_CHECK(hipGetLastError());
+    return MPX_OK;
+}
+
+int mpx_noise_uniform(void* stream, int32_t n_utts, const uint64_t* seeds, const int64_t* offsets, int64_t max_len,
+                      float* out) {
+    if (n_utts < 0 || max_len < 0) return fail(MPX_ERR_ARG, "mpx_noise_uniform: negative size%s");
+    if (n_utts == 0 || max_len == 0) return MPX_OK;
+    if (!seeds || !offsets || !out) return fail(MPX_ERR_ARG, "mpx_noise_uniform: null pointer%s");
+    if (n_utts > 65535) return fail(MPX_ERR_ARG, "mpx_noise_uniform: at most 65535 utterances per call%s");
+    const dim3 grid((unsigned)((max_len + 1023) / 1024), (unsigned)n_utts);
+    hipLaunchKernelGGL(k_noise_uniform, grid, dim3(256), 0, (hipStream_t)stream, (const unsigned long long*)seeds,
+                       (const long long*)offsets, out);
     MPX_HIP_CHECK(hipGetLastError());
     return MPX_OK;
 }

@@ -524,10 +524,16 @@ class CompressedSynthesisPlan:
     """
 
     def __init__(self, engine, utts, fs, fft_len=None, b_voi_ap_win=True, b_const_rate=False, alpha_phase=None,
-                 noise=None, frames_per_run=None, per_phase_type="magphase", post_filter=False, b_fbank_mel=False):
+                 noise=None, frames_per_run=None, per_phase_type="magphase", post_filter=False, b_fbank_mel=False,
+                 noise_mode="reference", noise_seeds=None):
         from scipy import interpolate
 
         self.apply_post_filter = bool(post_filter)
+        if noise_mode not in ("reference", "device"):
+            raise ValueError("noise_mode must be 'reference' (numpy global RNG, magphase.py:883) or 'device' (Philox on the GPU)")
+        self.noise_mode = noise_mode
+        if noise_mode == "device" and noise is not None:
+            raise ValueError("noise_mode='device' generates the source itself: do not pass noise")
 
         if per_phase_type not in ("magphase", "min_phase", "linear"):
             raise ValueError("per_phase_type must be 'magphase', 'min_phase' or 'linear'")
@@ -554,6 +560,11 @@ class CompressedSynthesisPlan:
             im = np.atleast_2d(np.asarray(im, dtype=np.float64))
             lf0 = np.atleast_1d(np.asarray(lf0, dtype=np.float64))
             n_rows = mml.shape[0]
+            if rm.shape[0] != n_rows or im.shape[0] != n_rows or lf0.shape[0] != n_rows:
+                raise ValueError("utterance %d: mag / real / imag / lf0 have %d / %d / %d / %d frames"
+                                 % (ui, n_rows, rm.shape[0], im.shape[0], lf0.shape[0]))
+            if rm.shape[1] != im.shape[1]:
+                raise ValueError("utterance %d: real and imag have different dimensions" % ui)
             v_f0 = np.exp(lf0)                                         # magphase.py:846
             v_voi = v_f0 > 1.0                                         # :847
             v_shift = hm.f0_to_shift(v_f0, fs)                         # :848
@@ -584,6 +595,8 @@ class CompressedSynthesisPlan:
                 v_ns = np.asarray(noise[ui], dtype=np.float64)
                 if v_ns.size != ns_len:
                     raise ValueError("noise length %d != ns_len %d" % (v_ns.size, ns_len))
+            elif noise_mode == "device":
+                v_ns = None                                            # generated on the GPU (mpx_noise_uniform)
             else:
                 v_ns = np.random.uniform(-1, 1, ns_len)                # :883 (global numpy RNG, as the reference)
             a_mag.append(mml), a_real.append(rm), a_imag.append(im)
@@ -611,7 +624,16 @@ class CompressedSynthesisPlan:
         _up.append(("a_mag", cat(a_mag), np.float32))
         _up.append(("a_real", cat(a_real), np.float32))
         _up.append(("a_imag", cat(a_imag), np.float32))
-        _up.append(("noise", cat(noises), np.float32))
+        if noise_mode == "device":
+            seeds = np.arange(len(nfr), dtype=np.uint64) if noise_seeds is None else np.asarray(noise_seeds).astype(np.uint64)
+            if seeds.size != len(nfr):
+                raise ValueError("noise_seeds: one per utterance")
+            self.noise_seeds = seeds
+            self.noise_off_host = cat(([0], np.cumsum(self.ns_len))).astype(np.int64)
+            _up.append(("noise_seeds_dev", seeds.view(np.int64), np.int64))
+            _up.append(("noise_off_dev", self.noise_off_host, np.int64))
+        else:
+            _up.append(("noise", cat(noises), np.float32))
         _up.append(("npos", cat(npos), np.int64))
         _up.append(("nleft", cat(nleft), np.int32))
         _up.append(("nright", cat(nright), np.int32))
@@ -644,6 +666,13 @@ class CompressedSynthesisPlan:
         self._gains_dev = None
         for _k, _t in e.to_device_packed(_up).items():
             setattr(self, _k, _t)
+        if noise_mode == "device":
+            torch = _torch()
+            self.noise = e.empty((max(int(self.noise_off_host[-1]), 1),))
+            with torch.cuda.device(e.device):
+                _lib.check(e.lib.mpx_noise_uniform(e.stream_ptr(), len(nfr), self.noise_seeds_dev.data_ptr(),
+                                                   self.noise_off_dev.data_ptr(), int(max(self.ns_len)),
+                                                   self.noise.data_ptr()), "mpx_noise_uniform")
 
     @property
     def gains(self):

@@ -25,28 +25,38 @@ from . import libutils as lu
 
 
 class _Stage(threading.Thread):
-    """Runs fn(item) for every item of an input queue in order, pushes results to an output queue; None ends it."""
+    """Runs fn(item) for every item of an input queue in order, pushes results to an output queue; None ends it.
+    stop: threading.Event -- once set, remaining items are dropped and blocking puts give up (abnormal shutdown)."""
 
-    def __init__(self, fn, q_in, q_out=None):
+    def __init__(self, fn, q_in, q_out=None, stop=None):
         super().__init__(daemon=True)
         self.fn, self.q_in, self.q_out, self.error = fn, q_in, q_out, None
+        self.stop = stop or threading.Event()
+
+    def _put(self, item):
+        while not self.stop.is_set():
+            try:
+                self.q_out.put(item, timeout=0.2)
+                return
+            except queue.Full:
+                continue
 
     def run(self):
         while True:
             item = self.q_in.get()
-            if item is None:
+            if item is None or self.stop.is_set():
                 break
             if self.error is None:
                 try:
                     res = self.fn(item)
                     if self.q_out is not None:
-                        self.q_out.put(res)
+                        self._put(res)
                 except BaseException as e:   # re-raised by pipeline() in the caller's thread
                     self.error = e
                     if self.q_out is not None:
-                        self.q_out.put(_Failed(e))
+                        self._put(_Failed(e))
         if self.q_out is not None:
-            self.q_out.put(None)
+            self._put(None)
 
 
 class _Failed:
@@ -63,17 +73,20 @@ def pipeline(work, load, compute, store, depth=2):
     """
     Three-stage pipeline over the list `work`: load(w) in a reader thread (at most `depth` results ahead),
     compute(loaded) in the calling thread, store(result) in a writer thread.  Order is preserved; an exception in
-    any stage is re-raised here after the threads have been shut down.  Returns the number of items completed.
+    any stage is re-raised here after the threads have been shut down (a KeyboardInterrupt in the calling thread too:
+    the stages are told to stop and never block on a full queue, so Ctrl-C does not hang).
+    Returns the number of items completed.
     """
     q_work, q_loaded, q_store = queue.Queue(), queue.Queue(maxsize=depth), queue.Queue(maxsize=depth)
-    reader = _Stage(load, q_work, q_loaded)
-    writer = _Stage(store, q_store)
+    stop = threading.Event()
+    reader = _Stage(load, q_work, q_loaded, stop)
+    writer = _Stage(store, q_store, None, stop)
     reader.start()
     writer.start()
     for w in work:
         q_work.put(w)
     q_work.put(None)
-    done, err = 0, None
+    done, err, clean = 0, None, False
     try:
         while True:
             item = q_loaded.get()
@@ -86,55 +99,121 @@ def pipeline(work, load, compute, store, depth=2):
                 try:
                     q_store.put(compute(item))
                     done += 1
-                except BaseException as e:
+                except Exception as e:
                     err = e
+        clean = True
     finally:
-        q_store.put(None)
-        writer.join()
-        reader.join()
+        if not clean:                 # interrupted: nobody will drain the queues any more
+            stop.set()
+            q_work.put(None)
+        try:
+            q_store.put(None, timeout=1.0 if not clean else None)
+        except queue.Full:
+            pass
+        writer.join(timeout=None if clean else 2.0)
+        reader.join(timeout=None if clean else 2.0)
     err = err or reader.error or writer.error
     if err is not None:
         raise err
     return done
 
 
+class CorpusReport(dict):
+    """Filled by the two corpus functions: done (utterances written), failed [(token, 'ExcType: message')], crash_list
+    (path of the crash_file_list_<host>_<pid>.scp the failed tokens were appended to, or None)."""
+
+
+def _record_failures(report, out_dir, failed):
+    """The reference's crash-list convention (scripts/batch_convert_label_state_aligned_to_variable_frame_rate.py:48,
+    59-70): tokens that raised are appended to crash_file_list_<host>_<pid>.scp and the run goes on."""
+    if not failed:
+        return
+    path = lu.ins_pid(os.path.join(out_dir, "crash_file_list.scp"))
+    with open(path, "a") as fh:
+        for tok, _msg in failed:
+            fh.write(tok + "\n")
+    if report is not None:
+        report.setdefault("failed", []).extend(failed)
+        report["crash_list"] = path
+
+
+def _isolate(items, fn_batch):
+    """fn_batch(list) -> list of results.  If the whole batch raises, every item is retried on its own so that one bad
+    utterance costs one utterance: returns (results, failed) with failed = [(index, exception)]."""
+    try:
+        return list(zip(range(len(items)), fn_batch(items))), []
+    except (KeyboardInterrupt, SystemExit):
+        raise
+    except Exception:
+        ok, failed = [], []
+        for i, it in enumerate(items):
+            try:
+                ok.append((i, fn_batch([it])[0]))
+            except (KeyboardInterrupt, SystemExit):
+                raise
+            except Exception as e:
+                failed.append((i, e))
+        return ok, failed
+
+
+def _tok(path):
+    return os.path.basename(path).split(".")[0]
+
+
+def token_seed(token):
+    """64-bit noise seed of an utterance for noise_mode='device': FNV-1a of the token's UTF-8 bytes."""
+    h = 0xCBF29CE484222325
+    for b in str(token).encode("utf-8"):
+        h = ((h ^ b) * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
 # ----------------------------------------------------------------------------------------------------
 # feature extraction (scripts/batch_feature_extraction_for_tts.py)
 # ----------------------------------------------------------------------------------------------------
 def extract_features_corpus(wav_files, out_dir, batch_utts=16, fft_len=None, mag_dim=60, phase_dim=10,
-                            b_const_rate=False, engine=None, verbose=True):
+                            b_const_rate=False, engine=None, verbose=True, report=None):
     """
     mp.analysis_for_acoustic_modelling (magphase.py:2992-3022) for a list of wav files, `batch_utts` per launch.
-    All files of one call must share the sample rate (as every corpus the reference's script handles does); a batch
-    with mixed rates is split.  Writes <token>.mag/.real/.imag/.lf0 (+ .shift for variable rate) into out_dir.
+    Sample rates may be mixed: every batch is split by rate (one launch per rate).  Writes <token>.mag/.real/.imag/.lf0
+    (+ .shift for variable rate) into out_dir.  A file that cannot be read or analysed does not stop the corpus: its
+    token goes to crash_file_list_<host>_<pid>.scp in out_dir (report, a CorpusReport / dict, gets the details).
+    Returns the number of batches completed.
     """
     from . import magphase as mp
 
     lu.mkdir(out_dir)
 
     def load(files):
-        utts = []
+        utts, failed = [], []
         for f in files:
-            v_sig, fs = la.read_audio_file(f)
-            v_pm_sec, v_voi = mp._epochs_for(f)
-            utts.append((v_sig, fs, v_pm_sec, v_voi))
-        return files, utts
+            try:
+                v_sig, fs = la.read_audio_file(f)
+                v_pm_sec, v_voi = mp._epochs_for(f)
+                utts.append((f, (v_sig, fs, v_pm_sec, v_voi)))
+            except (KeyboardInterrupt, SystemExit):
+                raise
+            except Exception as e:
+                failed.append((_tok(f), "%s: %s" % (type(e).__name__, e)))
+        return utts, failed
 
     def compute(loaded):
-        files, utts = loaded
+        utts, failed = loaded
         out = []
-        for fs in sorted(set(u[1] for u in utts)):
-            idx = [i for i, u in enumerate(utts) if u[1] == fs]
+        for fs in sorted(set(u[1][1] for u in utts)):
+            group = [u for u in utts if u[1][1] == fs]
             # Q7: the reference forwards alpha_phase=b_mag_fbank_mel (False) -- see mp.analysis_for_acoustic_modelling
-            res = mp.analysis_compressed_batch([utts[i] for i in idx], fft_len=fft_len, mag_dim=mag_dim,
-                                               phase_dim=phase_dim, b_const_rate=b_const_rate, alpha_phase=False,
-                                               engine=engine)
-            out.extend((files[i], r) for i, r in zip(idx, res))
-        return out
+            ok, bad = _isolate(group, lambda g: mp.analysis_compressed_batch(
+                [u[1] for u in g], fft_len=fft_len, mag_dim=mag_dim, phase_dim=phase_dim, b_const_rate=b_const_rate,
+                alpha_phase=False, engine=engine))
+            out.extend((group[i][0], r) for i, r in ok)
+            failed = failed + [(_tok(group[i][0]), "%s: %s" % (type(e).__name__, e)) for i, e in bad]
+        return out, failed
 
-    def store(results):
+    def store(res):
+        results, failed = res
         for f, (m_mag, m_real, m_imag, v_lf0, v_shift, _fs, _n) in results:
-            tok = os.path.basename(f).split(".")[0]
+            tok = _tok(f)
             mp.write_featfile(m_mag, out_dir, tok + ".mag")
             mp.write_featfile(m_real, out_dir, tok + ".real")
             mp.write_featfile(m_imag, out_dir, tok + ".imag")
@@ -143,6 +222,11 @@ def extract_features_corpus(wav_files, out_dir, batch_utts=16, fft_len=None, mag
                 mp.write_featfile(v_shift, out_dir, tok + ".shift")
             if verbose:
                 print("extracted " + tok)
+        if report is not None:
+            report["done"] = report.get("done", 0) + len(results)
+        _record_failures(report, out_dir, failed)
+        for tok, msg in failed:
+            print("FAILED " + tok + " (" + msg + ")")
 
     return pipeline(batches(wav_files, batch_utts), load, compute, store)
 
@@ -151,39 +235,75 @@ def extract_features_corpus(wav_files, out_dir, batch_utts=16, fft_len=None, mag
 # waveform generation (scripts/batch_waveform_generation.py)
 # ----------------------------------------------------------------------------------------------------
 def generate_waveforms_corpus(in_feats_dir, tokens, out_syn_dir, mag_dim, phase_dim, fs, fft_len=None, pf_type="no",
-                              b_const_rate=False, batch_utts=16, engine=None, verbose=True):
+                              b_const_rate=False, batch_utts=16, engine=None, verbose=True, report=None,
+                              noise_mode="reference"):
     """
     mp.synthesis_from_acoustic_modelling (magphase.py:3229-3275) for a list of tokens, `batch_utts` per launch:
     reads <token>.mag/.real/.imag/.lf0, post-filters (pf_type 'magphase' on the device, 'merlin' on the host, 'no'),
     synthesises and writes <token>.wav.
+    fs: one sample rate for all tokens (the reference's script), or a dict / callable token -> fs for corpora that mix
+    rates (feature files carry no rate): every batch is split by rate, one launch per rate.
+    noise_mode: 'reference' draws the aperiodic source from numpy's global RNG exactly like magphase.py:883 (seed it
+    and the output is the reference's); 'device' lets the GPU generate it (counter-based, per-utterance seed: not the
+    reference's sample values, same statistics; removes the largest host cost of generation).
+    A token whose files are missing or malformed does not stop the corpus: crash_file_list_<host>_<pid>.scp.
+    Returns the number of batches completed.
     """
     from . import magphase as mp
 
     lu.mkdir(out_syn_dir)
     if pf_type not in ("no", "magphase", "merlin"):
         raise ValueError("pf_type must be 'no', 'magphase' or 'merlin'")
+    fs_of = (lambda t: int(fs[t])) if isinstance(fs, dict) else ((lambda t: int(fs(t))) if callable(fs) else (lambda t: int(fs)))
 
     def load(toks):
-        utts = []
+        utts, failed = [], []
         for t in toks:
-            base = os.path.join(in_feats_dir, t)
-            m_mag = lu.read_binfile(base + ".mag", dim=mag_dim)
-            if pf_type == "merlin":
-                m_mag = mp.post_filter_merlin(m_mag, fs)       # host arithmetic: done in the reader thread
-            utts.append((m_mag, lu.read_binfile(base + ".real", dim=phase_dim),
-                         lu.read_binfile(base + ".imag", dim=phase_dim), lu.read_binfile(base + ".lf0", dim=1)))
-        return toks, utts
+            try:
+                base = os.path.join(in_feats_dir, t)
+                rate = fs_of(t)
+                m_mag = lu.read_binfile(base + ".mag", dim=mag_dim)
+                if pf_type == "merlin":
+                    m_mag = mp.post_filter_merlin(m_mag, rate)       # host arithmetic: done in the reader thread
+                utts.append((t, rate, (m_mag, lu.read_binfile(base + ".real", dim=phase_dim),
+                                       lu.read_binfile(base + ".imag", dim=phase_dim),
+                                       lu.read_binfile(base + ".lf0", dim=1))))
+            except (KeyboardInterrupt, SystemExit):
+                raise
+            except Exception as e:
+                failed.append((t, "%s: %s" % (type(e).__name__, e)))
+        return utts, failed
 
     def compute(loaded):
-        toks, utts = loaded
-        sigs = mp.synthesis_from_compressed_batch(utts, fs, fft_len=fft_len, b_const_rate=b_const_rate,
-                                                  b_post_filter=(pf_type == "magphase"), engine=engine)
-        return list(zip(toks, sigs))
+        utts, failed = loaded
+        out = []
+        for rate in sorted(set(u[1] for u in utts)):
+            group = [u for u in utts if u[1] == rate]
+            def synth(g):
+                kw = {}
+                if noise_mode != "reference":   # seed = a hash of the token: the same wav whatever the batching / sharding
+                    kw = {"noise_mode": noise_mode, "noise_seeds": [token_seed(u[0]) for u in g]}
+                return mp.synthesis_from_compressed_batch([u[2] for u in g], rate, fft_len=fft_len,
+                                                          b_const_rate=b_const_rate,
+                                                          b_post_filter=(pf_type == "magphase"), engine=engine, **kw)
 
-    def store(results):
-        for t, v_sig in results:
-            la.write_audio_file(os.path.join(out_syn_dir, t + ".wav"), v_sig, fs)
+            ok, bad = _isolate(group, synth)
+            out.extend((group[i][0], rate, sig) for i, sig in ok)
+            failed = failed + [(group[i][0], "%s: %s" % (type(e).__name__, e)) for i, e in bad]
+        order = {u[0]: k for k, u in enumerate(utts)}
+        out.sort(key=lambda r: order[r[0]])
+        return out, failed
+
+    def store(res):
+        results, failed = res
+        for t, rate, v_sig in results:
+            la.write_audio_file(os.path.join(out_syn_dir, t + ".wav"), v_sig, rate)
             if verbose:
                 print("synthesised " + t)
+        if report is not None:
+            report["done"] = report.get("done", 0) + len(results)
+        _record_failures(report, out_syn_dir, failed)
+        for tok, msg in failed:
+            print("FAILED " + tok + " (" + msg + ")")
 
     return pipeline(batches(tokens, batch_utts), load, compute, store)

@@ -8,7 +8,8 @@ epoch/index arithmetic stays on the host (hostmath.py).  There is no CPU fallbac
 
 Epochs: the reference shells out to the REAPER binary (magphase.py:2875-2876).  REAPER is outside the hot path
 (SURVEY.md section 8f #1); epochs come, in this order, from a provider set with ``set_epoch_provider``,
-from ``<wav stem>.est`` next to the wav (REAPER text format), or from a REAPER binary if one is installed.
+from ``<wav stem>.est`` next to the wav (REAPER text format), from the built-in tracker if MAGPHASE_EPOCHS=builtin
+is set (explicit opt-in: it is not REAPER), or from a REAPER binary if one is installed; otherwise RuntimeError.
 """
 import os
 import warnings
@@ -40,7 +41,9 @@ def use_builtin_epoch_tracker(device=None):
 
     def provider(wav_file):
         v_sig, fs = la.read_audio_file(wav_file)
-        return epochs.track_epochs(v_sig, fs, device=device)
+        # the engine's device, named explicitly: torch's "current device" is thread-local and iobatch calls this from
+        # its reader thread, where it would be device 0 on every rank
+        return epochs.track_epochs(v_sig, fs, device=device if device is not None else get_engine().device)
 
     set_epoch_provider(provider)
 
@@ -54,14 +57,19 @@ def _epochs_for(wav_file):
     if os.path.isfile(est):
         m = np.atleast_2d(np.loadtxt(est, skiprows=7, usecols=[0, 1]))
         return m[:, 0], m[:, 1]
-    if la.find_reaper() is None and os.environ.get("MAGPHASE_EPOCHS", "builtin") == "builtin":
-        # no REAPER binary: the built-in zero-frequency-filtering tracker (magphase_amd/epochs.py).  Not REAPER: the
-        # epochs differ, hence so do the (pitch-synchronous) features -- parity unpinned for this front end.
-        warnings.warn("REAPER not found: epochs of %s from the built-in ZFF tracker (set MAGPHASE_EPOCHS=reaper to "
-                      "make this an error)" % wav_file)
+    if os.environ.get("MAGPHASE_EPOCHS", "") == "builtin":
+        # explicit opt-in (or use_builtin_epoch_tracker()): the built-in zero-frequency-filtering tracker
+        # (magphase_amd/epochs.py).  Not REAPER: the epochs differ, hence so do the pitch-synchronous features --
+        # parity unpinned for this front end, so it is never substituted silently.
         from . import epochs
         v_sig, fs = la.read_audio_file(wav_file)
-        return epochs.track_epochs(v_sig, fs)
+        return epochs.track_epochs(v_sig, fs, device=get_engine().device)
+    if la.find_reaper() is None:
+        raise RuntimeError(
+            "no epochs for %s: neither an epoch provider (set_epoch_provider), nor %s, nor a REAPER binary.  Features "
+            "are pitch-synchronous, so the epoch source is part of the result: opt into the built-in tracker "
+            "explicitly with MAGPHASE_EPOCHS=builtin or magphase.use_builtin_epoch_tracker() (not REAPER: parity "
+            "unpinned)." % (wav_file, est))
     est_tmp = lu.ins_pid("temp.est")
     la.reaper(wav_file, est_tmp)
     try:
@@ -251,13 +259,17 @@ def _output_hpf(v_syn_sig, fs):
 
 def synthesis_from_compressed_batch(utts, fs, fft_len=None, b_voi_ap_win=True, b_const_rate=False, alpha_phase=None,
                                     b_out_hpf=True, noise=None, engine=None, per_phase_type='magphase',
-                                    b_post_filter=False, b_fbank_mel=False):
+                                    b_post_filter=False, b_fbank_mel=False, noise_mode='reference', noise_seeds=None):
     """Batched synthesis_from_compressed; utts: list of (m_mag_mel_log, m_real_mel, m_imag_mel, v_lf0).
-    b_post_filter: apply the MagPhase post-filter to the log-mel magnitudes on the device first (pf_type='magphase')."""
+    b_post_filter: apply the MagPhase post-filter to the log-mel magnitudes on the device first (pf_type='magphase').
+    noise_mode: 'reference' (default) draws the aperiodic source from numpy's global RNG like magphase.py:883;
+    'device' generates it on the GPU (Philox, one uint64 seed per utterance in noise_seeds, default 0, 1, ...): same
+    distribution, not the reference's sample values, independent of batching and sharding."""
     engine = engine or get_engine()
     plan = CompressedSynthesisPlan(engine, utts, fs, fft_len=fft_len, b_voi_ap_win=b_voi_ap_win,
                                    b_const_rate=b_const_rate, alpha_phase=alpha_phase, noise=noise,
-                                   per_phase_type=per_phase_type, post_filter=b_post_filter, b_fbank_mel=b_fbank_mel)
+                                   per_phase_type=per_phase_type, post_filter=b_post_filter, b_fbank_mel=b_fbank_mel,
+                                   noise_mode=noise_mode, noise_seeds=noise_seeds)
     pcm_dev = plan.run()
     if b_out_hpf:   # magphase.py:981-995, float64 on the device (engine.output_hpf); _output_hpf is the host form
         pcm = engine.output_hpf(pcm_dev, plan.out_off_host, fs).cpu().numpy()

@@ -36,6 +36,14 @@ def dist_env():
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
+def local_device_index():
+    """GPU of this rank: LOCAL_RANK, or 0 for every rank when MAGPHASE_SHARE_DEVICE=1 (exercising the N > 1 code paths
+    on a box with one GPU: tests, bench.py's BENCH_SHARE_DEVICE)."""
+    if os.environ.get("MAGPHASE_SHARE_DEVICE") or os.environ.get("BENCH_SHARE_DEVICE"):
+        return 0
+    return dist_env()[1]
+
+
 def init_process_group(backend=None):
     """Rendezvous on 127.0.0.1 (the container hostname may not resolve).  backend: 'nccl' (= RCCL) on GPUs, 'gloo' on CPU."""
     import torch
@@ -49,8 +57,8 @@ def init_process_group(backend=None):
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
     if backend == "nccl":
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(local_device_index())
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_device_index()))
     else:
         dist.init_process_group(backend=backend)
     return dist

@@ -35,13 +35,17 @@ def main():
     rank, local_rank, world = sharding.dist_env()
     if world > 1:
         import torch
-        torch.cuda.set_device(local_rank)
-    sizes = [os.path.getsize(os.path.join(args.wav_dir, t + ".wav")) for t in tokens]
+        torch.cuda.set_device(sharding.local_device_index())
+    sizes = [os.path.getsize(os.path.join(args.wav_dir, t + ".wav")) if os.path.isfile(os.path.join(args.wav_dir, t + ".wav"))
+             else 0 for t in tokens]
     mine = sharding.shard_by_cost(sizes, world)[rank]
     if args.batch > 0:   # reader thread / kernels / writer thread overlapped, args.batch utterances per launch
+        rep = iobatch.CorpusReport()
         n = iobatch.extract_features_corpus([os.path.join(args.wav_dir, tokens[i] + ".wav") for i in mine], args.out_dir,
-                                            batch_utts=args.batch)
-        print("[rank %d] %d files analysed in %d batches" % (rank, len(mine), n))
+                                            batch_utts=args.batch, report=rep)
+        print("[rank %d] %d of %d files analysed in %d batches" % (rank, rep.get("done", 0), len(mine), n))
+        if rep.get("failed"):
+            print("[rank %d] %d files failed, listed in %s" % (rank, len(rep["failed"]), rep["crash_list"]))
     else:
         for i in mine:
             print("[rank %d] analysing %s.wav" % (rank, tokens[i]))

@@ -1,0 +1,134 @@
+"""
+N > 1 code paths executed on ONE GPU (-m gpu): two ranks under torch.distributed.run share device 0 (gloo for the
+barrier / reductions, BENCH_SHARE_DEVICE / MAGPHASE_SHARE_DEVICE for the device index).  What 8-GPU runs rely on:
+bench.py's weak-scaling bookkeeping, the batch scripts' utterance sharding (files byte-identical to a single-process
+run, nothing exchanged), mixed sample rates in one generation run, and per-utterance failure isolation.
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+import wave
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return str(sk.getsockname()[1])
+
+
+def _torchrun(nproc, script_args, extra_env, timeout=900):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=_free_port(), OMP_NUM_THREADS="4",
+               HSA_ENABLE_IPC_MODE_LEGACY="0", **extra_env)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % nproc,
+           "--master-addr", "127.0.0.1", "--master-port", env["MASTER_PORT"]] + script_args
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    return r.stdout
+
+
+def test_bench_two_ranks_on_one_device():
+    one = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--steps", "5", "--warmup", "2", "--quick"], cwd=ROOT,
+                         capture_output=True, text=True, timeout=900)
+    assert one.returncode == 0, one.stderr[-2000:]
+    j1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    out = _torchrun(2, ["bench.py", "--gpus", "2", "--steps", "5", "--warmup", "2"],
+                    {"BENCH_DIST_BACKEND": "gloo", "BENCH_SHARE_DEVICE": "1"})
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                             # rank 0 only
+    j2 = json.loads(lines[0])
+    assert j1["n_gpus"] == 1 and j2["n_gpus"] == 2 and j2["scaling"] == "weak"
+    assert j2["config"]["frames_per_gpu"] > 0.9 * j1["config"]["frames_per_gpu"]
+    # whole-job value = frames of BOTH ranks / max-over-ranks time: value * time == 2 ranks' frames
+    f1 = j1["value"] * j1["ms_per_step"] * 1e-3
+    f2 = j2["value"] * j2["ms_per_step"] * 1e-3
+    assert abs(f1 - j1["config"]["frames_per_gpu"]) < 1e-3 * f1
+    assert 1.9 * j1["config"]["frames_per_gpu"] < f2 < 2.1 * j1["config"]["frames_per_gpu"]
+    assert "cpu_baseline" not in j2 and "roofline" in j2
+
+
+def _make_corpus(tmp_path, n, fs_list):
+    sys.path.insert(0, os.path.join(ROOT, "demos"))
+    import make_demo_data
+    from magphase_amd import libaudio as la, synthetic as syn
+    wav_dir = tmp_path / "wavs"
+    os.makedirs(str(wav_dir), exist_ok=True)
+    toks = []
+    for u in range(n):
+        fs = fs_list[u % len(fs_list)]
+        pcm, pm, voi = syn.make_utterance(500 + u, dur_s=0.6 + 0.1 * (u % 3), fs=fs)
+        tok = "m%02d" % u
+        la.write_audio_file(str(wav_dir / (tok + ".wav")), pcm / 32768.0, fs, norm=None)
+        make_demo_data.write_est(str(wav_dir / (tok + ".est")), pm, voi)
+        toks.append((tok, fs))
+    scp = tmp_path / "list.scp"
+    scp.write_text("\n".join(t for t, _ in toks) + "\n")
+    return str(wav_dir), str(scp), toks
+
+
+def _same_files(d1, d2, names):
+    for n in names:
+        a, b = open(os.path.join(d1, n), "rb").read(), open(os.path.join(d2, n), "rb").read()
+        assert len(a) > 0 and a == b, n
+
+
+def test_batch_scripts_two_ranks_write_the_same_files_as_one_process(tmp_path):
+    wav_dir, scp, toks = _make_corpus(tmp_path, 7, [48000])
+    ext = os.path.join(ROOT, "scripts", "batch_feature_extraction_for_tts.py")
+    gen = os.path.join(ROOT, "scripts", "batch_waveform_generation.py")
+    p1, p2, g1, g2 = (str(tmp_path / d) for d in ("p1", "p2", "g1", "g2"))
+    env = dict(os.environ)
+    r = subprocess.run([sys.executable, ext, "--scp", scp, "--wav-dir", wav_dir, "--out-dir", p1, "--batch", "3"], cwd=ROOT,
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    _torchrun(2, [ext, "--scp", scp, "--wav-dir", wav_dir, "--out-dir", p2, "--batch", "2"], {"MAGPHASE_SHARE_DEVICE": "1"})
+    feat_names = [t + e for t, _ in toks for e in (".mag", ".real", ".imag", ".lf0", ".shift")]
+    _same_files(p1, p2, feat_names)                        # batching and sharding do not change a bit of the features
+    common = ["--scp", scp, "--feats-dir", p1, "--mag-dim", "60", "--phase-dim", "10", "--pf-type", "magphase", "--noise", "device"]
+    r = subprocess.run([sys.executable, gen] + common + ["--out-dir", g1, "--batch", "4"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    _torchrun(2, [gen] + common + ["--out-dir", g2, "--batch", "2"], {"MAGPHASE_SHARE_DEVICE": "1"})
+    for t, _fs in toks:   # device noise is seeded by the token: same wav up to 1 LSB (run partition differs with the batch)
+        with wave.open(os.path.join(g1, t + ".wav"), "rb") as w1, wave.open(os.path.join(g2, t + ".wav"), "rb") as w2:
+            a = np.frombuffer(w1.readframes(w1.getnframes()), dtype=np.int16).astype(np.int32)
+            b = np.frombuffer(w2.readframes(w2.getnframes()), dtype=np.int16).astype(np.int32)
+        assert a.size == b.size and a.size > 20000 and np.max(np.abs(a - b)) <= 1, t
+
+
+def test_mixed_sample_rates_and_failure_isolation(tmp_path):
+    """configs[4]: 16 kHz and 48 kHz tokens in one generation run; a token with a truncated file and a missing wav do
+    not stop the corpus and land in crash_file_list_<host>_<pid>.scp."""
+    from magphase_amd import iobatch
+    wav_dir, _scp, toks = _make_corpus(tmp_path, 6, [48000, 16000])
+    wavs = [os.path.join(wav_dir, t + ".wav") for t, _ in toks]
+    with open(os.path.join(wav_dir, "broken.wav"), "wb") as fh:
+        fh.write(b"RIFF not a wav")
+    feats = str(tmp_path / "feats")
+    rep = iobatch.CorpusReport()
+    iobatch.extract_features_corpus(wavs[:3] + [os.path.join(wav_dir, "broken.wav"), os.path.join(wav_dir, "absent.wav")] + wavs[3:],
+                                    feats, batch_utts=4, phase_dim=45, verbose=False, report=rep)
+    assert rep["done"] == 6 and sorted(t for t, _m in rep["failed"]) == ["absent", "broken"]
+    assert open(rep["crash_list"]).read().split() == ["broken", "absent"]
+    for t, _fs in toks:
+        assert os.path.getsize(os.path.join(feats, t + ".mag")) > 0
+    # generation with a token -> fs map; one token has a truncated .real file
+    with open(os.path.join(feats, toks[1][0] + ".real"), "r+b") as fh:
+        fh.truncate(45 * 4 * 3 + 2)
+    out = str(tmp_path / "syn")
+    rep2 = iobatch.CorpusReport()
+    iobatch.generate_waveforms_corpus(feats, [t for t, _ in toks], out, 60, 45, dict(toks), pf_type="no", batch_utts=6,
+                                      verbose=False, report=rep2, noise_mode="device")
+    assert [t for t, _m in rep2["failed"]] == [toks[1][0]] and rep2["done"] == 5
+    for t, fs in toks:
+        if t == toks[1][0]:
+            continue
+        with wave.open(os.path.join(out, t + ".wav"), "rb") as w:
+            assert w.getframerate() == fs and w.getnframes() > 0.4 * fs

@@ -63,3 +63,39 @@ def test_reader_runs_ahead_of_compute():
 
     iobatch.pipeline(list(range(5)), load, compute, lambda r: None, depth=2)
     assert all(loaded_at[w + 1] < computed_at[w] for w in range(4))
+
+
+def test_keyboard_interrupt_in_compute_does_not_hang():
+    """Ctrl-C in the calling thread: the stages are told to stop and never block on a full queue."""
+    def load(w):
+        return w
+
+    def compute(w):
+        if w == 2:
+            raise KeyboardInterrupt
+        return w
+
+    t0 = time.time()
+    with pytest.raises(KeyboardInterrupt):
+        iobatch.pipeline(list(range(50)), load, compute, lambda r: time.sleep(0.01), depth=2)
+    assert time.time() - t0 < 5.0
+
+
+def test_isolate_retries_one_by_one_and_crash_list(tmp_path):
+    def fn(batch):
+        if any(x == 3 for x in batch):
+            raise ValueError("bad item")
+        return [x * 2 for x in batch]
+
+    ok, failed = iobatch._isolate([1, 2, 3, 4], fn)
+    assert ok == [(0, 2), (1, 4), (3, 8)] and [i for i, _e in failed] == [2]
+    ok, failed = iobatch._isolate([1, 2], fn)
+    assert ok == [(0, 2), (1, 4)] and failed == []
+    rep = iobatch.CorpusReport()
+    iobatch._record_failures(rep, str(tmp_path), [("tok_a", "ValueError: x"), ("tok_b", "IOError: y")])
+    iobatch._record_failures(rep, str(tmp_path), [])
+    path = rep["crash_list"]
+    import os
+    import socket
+    assert os.path.basename(path) == "crash_file_list_%s_%d.scp" % (socket.gethostname(), os.getpid())
+    assert open(path).read().split() == ["tok_a", "tok_b"] and len(rep["failed"]) == 2
