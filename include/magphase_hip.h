@@ -56,6 +56,20 @@ int mpx_analysis_frames(void* stream, int fft_len, const void* tables, const flo
                         int64_t n_frames, float* out_mag, float* out_real, float* out_imag, int64_t ld);
 
 /*
+ * The same analysis with the window, the transform and the epilogue in float64 (features still float32: correctly
+ * rounded values of the reference's float64 features instead of values carrying the fp32 FFT's ~1e-6-of-peak noise).
+ * For callers whose next step amplifies that noise on weak bins -- the compressed analysis takes ln(mag^2 + 1e-8)
+ * and uses Re X/|X| of bins 60-80 dB below the frame peak (magphase.py:2508-2521, libaudio.py:575-601).  About twice
+ * the time of mpx_analysis_frames (float64 vector rate, 8 waves per CU).  tables_f64: mpx_tables_f64_bytes() bytes
+ * initialised by mpx_tables_f64_init() (float64 twiddles; same life cycle as mpx_tables_init's table).
+ */
+size_t mpx_tables_f64_bytes(int fft_len);
+int mpx_tables_f64_init(void* stream, int fft_len, void* tables);
+int mpx_analysis_frames_f64(void* stream, int fft_len, const void* tables_f64, const float* sig,
+                            const int64_t* frame_pos, const int32_t* frame_left, const int32_t* frame_right,
+                            int64_t n_frames, float* out_mag, float* out_real, float* out_imag, int64_t ld);
+
+/*
  * Row pitch (in floats) the lossless feature matrices should be allocated with.  Any ld >= H is CORRECT for every
  * entry point that takes `ld` (so the matrices may live inside wider buffers); mpx_feat_ld() returns the pitch
  * measured fastest on MI355X, which is the reference's dense [F x H] layout, ld == H: padding the rows to a

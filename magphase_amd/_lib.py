@@ -17,6 +17,9 @@ SYMBOLS = (
     "mpx_tables_init",
     "mpx_feat_ld",
     "mpx_analysis_frames",
+    "mpx_tables_f64_bytes",
+    "mpx_tables_f64_init",
+    "mpx_analysis_frames_f64",
     "mpx_synthesis_lossless_frames",
     "mpx_ola_gather",
     "mpx_synth_ola_slots",
@@ -66,6 +69,12 @@ def load():
     lib.mpx_tables_init.argtypes = [vp, ctypes.c_int, vp]
     lib.mpx_analysis_frames.restype = ctypes.c_int
     lib.mpx_analysis_frames.argtypes = [vp, ctypes.c_int, vp, vp, vp, vp, vp, i64, vp, vp, vp, i64]
+    lib.mpx_tables_f64_bytes.restype = sz
+    lib.mpx_tables_f64_bytes.argtypes = [ctypes.c_int]
+    lib.mpx_tables_f64_init.restype = ctypes.c_int
+    lib.mpx_tables_f64_init.argtypes = [vp, ctypes.c_int, vp]
+    lib.mpx_analysis_frames_f64.restype = ctypes.c_int
+    lib.mpx_analysis_frames_f64.argtypes = [vp, ctypes.c_int, vp, vp, vp, vp, vp, i64, vp, vp, vp, i64]
     lib.mpx_feat_ld.restype = i64
     lib.mpx_feat_ld.argtypes = [ctypes.c_int]
     lib.mpx_synthesis_lossless_frames.restype = ctypes.c_int

@@ -1,0 +1,244 @@
+// magphase_f64.hip -- analysis of pitch-synchronous frames with a float64 transform (features still float32).
+//
+// Same operation as k_analysis (magphase_hip.hip; magphase.py:74-119, 309-325, 457-476), for the callers whose next step
+// amplifies the transform's round-off: the compressed analysis takes ln(mag^2 + 1e-8) and divides by |X|
+// (magphase.py:2508-2521, libaudio.py:575-601), and speech frames have bins 60-80 dB below the frame's peak.  An fp32
+// FFT leaves an absolute error of ~1e-6 of the peak on every bin -- 1e-3 .. 1e-2 relative on those bins, 7e-4 on the
+// mel-warped outputs; with the window, the transform and the epilogue in float64 the features are correctly rounded
+// float32 values of the reference's float64 ones (a few 1e-8 relative), and the warp's error falls to the fp32 GEMM's.
+// Cost: float64 vector rate is half the fp32 rate and the 64 complex registers of a frame take 128 VGPRs, so 8 waves
+// per CU; the kernel is compute-bound at ~2x the fp32 kernel's time (profiles/), which the compressed path can afford:
+// it is not bandwidth-bound.
+#include "mpx_common.hpp"
+#include "wave_fft_f64.hpp"
+
+namespace mpx {
+
+constexpr int kAna64Waves = 8;
+template <int P>
+constexpr size_t lds_bytes_ana64() {
+    return sizeof(double) * (size_t)tw64_doubles<P>() + sizeof(float) * (size_t)(kAna64Waves * P * kXStride);
+}
+
+// sin(x), |x| <= pi/2: Taylor polynomial to x^17 (remainder (pi/2)^19 / 19! = 4e-14)
+__device__ __forceinline__ double sin_halfpi_range(double x) {
+    const double x2 = x * x;
+    double p = 1.0 / 355687428096000.0;
+    p = fma(x2, p, -1.0 / 1307674368000.0);
+    p = fma(x2, p, 1.0 / 6227020800.0);
+    p = fma(x2, p, -1.0 / 39916800.0);
+    p = fma(x2, p, 1.0 / 362880.0);
+    p = fma(x2, p, -1.0 / 5040.0);
+    p = fma(x2, p, 1.0 / 120.0);
+    p = fma(x2, p, -1.0 / 6.0);
+    return fma(x * x2, p, x);
+}
+
+// np.hanning(1 + 2L)[k] on the rising half (t = k/L; L == 0: weight 1) and np.hanning(1 + 2R) on the falling half
+// (t = (L + R - k)/R): 0.5 - 0.5 cos(pi t) = 0.5 + 0.5 sin(pi (t - 0.5))      (libaudio.py:70-84)
+__device__ __forceinline__ double hann_half_f64(int k, int L, int LR, int kadd, double invL, double invR) {
+    const bool rising = k <= L;
+    const int num = rising ? k + kadd : LR - k;
+    const double t = (double)num * (rising ? invL : invR);
+    return fma(0.5, sin_halfpi_range(3.14159265358979323846 * (t - 0.5)), 0.5);
+}
+
+// 1/sqrt(s) in double from the fp32 hardware estimate and two Newton steps (s > 0)
+__device__ __forceinline__ double rsqrt_f64(double s) {
+    double r = (double)__builtin_amdgcn_rsqf((float)s);
+    r = r * fma(-0.5 * s, r * r, 1.5);
+    r = r * fma(-0.5 * s, r * r, 1.5);
+    return r;
+}
+
+// |X|, Re X / |X|, Im X / |X| as float32 (0, 0, 0 where X == 0: magphase.py:466-472)
+__device__ __forceinline__ void feat_store(double xr, double xi, float* pm, float* pr, float* pi) {
+    const double s = xr * xr + xi * xi;
+    // the fp32 estimate needs a normal float: |X|^2 below 1e-38 is zero for the float32 features anyway
+    const bool nz = s > 1.0e-36;
+    const double r = nz ? rsqrt_f64(s) : 0.0;
+    *pm = (float)(s * r);
+    *pr = (float)(xr * r);
+    *pi = (float)(xi * r);
+}
+
+template <int P>
+__global__ __launch_bounds__(kAna64Waves * 64) void k_analysis_f64(const float* __restrict__ sig,
+                                                                  const long long* __restrict__ fpos,
+                                                                  const int* __restrict__ fleft,
+                                                                  const int* __restrict__ fright, long long nframes,
+                                                                  const double* __restrict__ tw_g,
+                                                                  float* __restrict__ omag, float* __restrict__ oreal,
+                                                                  float* __restrict__ oimag, long long ld) {
+    constexpr int M = 64 * P, N = 2 * M, LB = ilog2(P), kTile = 64 * P;
+    extern __shared__ __attribute__((aligned(16))) double smem64[];
+    double* tw = smem64;
+    float* xbase = reinterpret_cast<float*>(smem64 + tw64_doubles<P>());
+    const int lane_id = threadIdx.x & 63;
+    const int wave = rfl((int)(threadIdx.x >> 6));
+    float* xbuf = xbase + wave * (P * kXStride);
+    const unsigned xbuf_byte = 8u * (unsigned)tw64_doubles<P>() + 4u * (unsigned)(wave * (P * kXStride));
+    for (int i = threadIdx.x; i < tw64_doubles<P>(); i += kAna64Waves * 64) tw[i] = tw_g[i];
+    __syncthreads();
+
+    // lane part of the split twiddle W_N^kappa = e^{-2 pi i kappa / N}
+    double wl_s0, wl_c0;
+    sincospi(-2.0 * (double)kappa<P>(lane_id) / (double)N, &wl_s0, &wl_c0);
+
+    for (long long f = (long long)blockIdx.x * kAna64Waves + wave; f < nframes; f += (long long)gridDim.x * kAna64Waves) {
+        int lane = lane_id;   // laundered per frame: keeps per-lane products out of loop-invariant registers
+        double wl_s = wl_s0, wl_c = wl_c0;
+        asm volatile("" : "+v"(lane), "+v"(wl_s), "+v"(wl_c));
+        const int kap = kappa<P>(lane);
+        const int src_lane = kappa<P>((64 - kap) & 63);
+        const bool lane0 = (kap == 0);
+        const FrameGeom g = frame_geom(sig, fpos[f], fleft[f], fright[f], N);
+        const double invL = (g.L > 0) ? 1.0 / (double)g.L : 1.0;
+        const double invR = (g.LR > g.L) ? 1.0 / (double)(g.LR - g.L) : 0.0;
+
+        // ---- samples HBM -> LDS (fp32: the PCM is exact in float32), window in float64 while gathering in FFT order
+        double re[P], im[P];
+#pragma unroll
+        for (int j = 0; j < P; ++j) re[j] = im[j] = 0.0;
+        const int ntiles = (g.len + kTile - 1) / kTile;   // 1 except for frames longer than 64 P samples (Q19)
+        for (int t = 0; t < ntiles; ++t) {
+            const int tile0 = t * kTile;
+            const int hi = min(g.len, tile0 + kTile);
+            stage_samples_async(g, tile0, kTile, xbuf_byte, lane);
+            staged_wait<0>();
+            wave_sync();
+            // the window weights depend on this copy of the lane id: the compiler cannot evaluate them (2 x 64 doubles)
+            // ahead of the copy and spill them
+            int lane_g = lane;
+            asm volatile("" : "+v"(lane_g));
+#pragma unroll
+            for (int j = 0; j < P; ++j) {
+                const int m0 = 128 * j;
+                // buffer index m holds windowed sample k = (m + rot) mod N, valid iff k < len
+                const bool any = (m0 < g.len - g.rot) || (m0 + 127 >= N - g.rot);
+                if (any) {
+                    const int m = m0 + 2 * lane_g;
+                    int k0 = m + g.rot;
+                    k0 = (k0 >= N) ? k0 - N : k0;
+                    int k1 = m + 1 + g.rot;
+                    k1 = (k1 >= N) ? k1 - N : k1;
+                    if (k0 >= tile0 && k0 < hi)
+                        re[j] = (double)xbuf[k0 - tile0] * hann_half_f64(k0, g.L, g.LR, g.kadd, invL, invR);
+                    if (k1 >= tile0 && k1 < hi)
+                        im[j] = (double)xbuf[k1 - tile0] * hann_half_f64(k1, g.L, g.LR, g.kadd, invL, invR);
+                }
+            }
+            wave_sync();
+        }
+
+        wave_fft_f64<P, -1>(re, im, tw, xbuf, lane);
+
+        // ---- real-FFT split, one (k, M-k) bin pair per step q (see k_analysis): lane kappa owns k = kappa + 64 q
+        // (register brev(q)); Z[M-k] lives in lane (64-kappa)&63, register P-1-i (kappa == 0: own register of bin
+        // (P-q)%P).  X[k] = E + T, X[M-k] = conj(E - T).  Bin M/2 is its own mirror (kappa == 0, register 1).
+        float* row_m = omag + f * ld;
+        float* row_r = oreal + f * ld;
+        float* row_i = oimag + f * ld;
+#pragma unroll
+        for (int qb = 0; qb < P / 2; qb += 4) {
+            double zpr[4], zpi[4];   // four partner bins per batch: 16 lane exchanges in flight
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = brev(qb + u, LB);
+                unsigned a, b, c, d;
+                split64(re[P - 1 - i], a, b);
+                split64(im[P - 1 - i], c, d);
+                zpr[u] = join64((unsigned)__shfl((int)a, src_lane), (unsigned)__shfl((int)b, src_lane));
+                zpi[u] = join64((unsigned)__shfl((int)c, src_lane), (unsigned)__shfl((int)d, src_lane));
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int q = qb + u;
+                const int i = brev(q, LB);
+                const int i0 = brev((P - q) % P, LB);
+                const double pr = lane0 ? re[i0] : zpr[u];
+                const double pi = lane0 ? im[i0] : zpi[u];
+                const double er = 0.5 * (re[i] + pr), ei = 0.5 * (im[i] - pi);
+                const double orr = 0.5 * (im[i] + pi), oi = -0.5 * (re[i] - pr);
+                constexpr int kq = 64 / (2 * P);   // e^{-2 pi i q / (2P)} = W_64^{q kq}
+                const double cq = dc64(q * kq), sq = -ds64(q * kq);
+                const double wr = wl_c * cq - wl_s * sq, wi = wl_c * sq + wl_s * cq;
+                const double tr = wr * orr - wi * oi, ti = wr * oi + wi * orr;
+                const int k = kap + 64 * q;
+                feat_store(er + tr, ei + ti, row_m + k, row_r + k, row_i + k);
+                const int km = M - k;              // kappa == 0, q == 0: bin M
+                feat_store(er - tr, ti - ei, row_m + km, row_r + km, row_i + km);
+            }
+        }
+        if (lane0) feat_store(re[1], -im[1], row_m + M / 2, row_r + M / 2, row_i + M / 2);
+    }
+}
+
+// First-pass twiddle table in double (layout: wave_fft_f64.hpp).  One block per lane row, one thread per entry.
+__global__ void k_tables_init_f64(int P, double* __restrict__ tab) {
+    const int l = blockIdx.x, i = threadIdx.x;
+    const int M = 64 * P, stride = 2 * P + 2;
+    int lb = 0;
+    while ((1 << lb) < P) ++lb;
+    if (i < P) {
+        int k1 = 0;
+        for (int b = 0; b < lb; ++b) k1 |= ((i >> b) & 1) << (lb - 1 - b);
+        const int r = (int)(((long long)l * k1) % M);
+        double sn, cs;
+        sincospi(2.0 * (double)r / (double)M, &sn, &cs);
+        tab[l * stride + 2 * i + 0] = cs;
+        tab[l * stride + 2 * i + 1] = sn;
+    } else if (i == P) {
+        tab[l * stride + 2 * i + 0] = 0.0;
+        tab[l * stride + 2 * i + 1] = 0.0;
+    }
+}
+
+}  // namespace mpx
+
+using namespace mpx;
+
+extern "C" {
+
+size_t mpx_tables_f64_bytes(int fft_len) {
+    const int P = p_of(fft_len);
+    return P ? sizeof(double) * 64 * (size_t)(2 * P + 2) : 0;
+}
+
+int mpx_tables_f64_init(void* stream, int fft_len, void* tables) {
+    const int P = p_of(fft_len);
+    if (!P) return fail(MPX_ERR_ARG, "mpx_tables_f64_init: fft_len must be 1024, 2048 or 4096%s");
+    if (!tables) return fail(MPX_ERR_ARG, "mpx_tables_f64_init: null tables%s");
+    hipLaunchKernelGGL(k_tables_init_f64, dim3(64), dim3(64), 0, (hipStream_t)stream, P, (double*)tables);
+    MPX_HIP_CHECK(hipGetLastError());
+    return MPX_OK;
+}
+
+int mpx_analysis_frames_f64(void* stream, int fft_len, const void* tables_f64, const float* sig, const int64_t* frame_pos,
+                            const int32_t* frame_left, const int32_t* frame_right, int64_t n_frames, float* out_mag,
+                            float* out_real, float* out_imag, int64_t ld) {
+    const int P = p_of(fft_len);
+    if (!P) return fail(MPX_ERR_ARG, "mpx_analysis_frames_f64: fft_len must be 1024, 2048 or 4096%s");
+    if (n_frames < 0) return fail(MPX_ERR_ARG, "mpx_analysis_frames_f64: negative n_frames%s");
+    if (ld < fft_len / 2 + 1) return fail(MPX_ERR_ARG, "mpx_analysis_frames_f64: ld < fft_len/2 + 1%s");
+    if (n_frames == 0) return MPX_OK;
+    if (!tables_f64 || !sig || !frame_pos || !frame_left || !frame_right || !out_mag || !out_real || !out_imag)
+        return fail(MPX_ERR_ARG, "mpx_analysis_frames_f64: null pointer%s");
+    const dim3 grid(grid_for(n_frames, kAna64Waves)), block(kAna64Waves * 64);
+    hipStream_t s = (hipStream_t)stream;
+#define MPX_LAUNCH_A64(PP)                                                                                        \
+    do {                                                                                                          \
+        if (int rc = set_lds(k_analysis_f64<PP>, lds_bytes_ana64<PP>())) return rc;                               \
+        hipLaunchKernelGGL(k_analysis_f64<PP>, grid, block, lds_bytes_ana64<PP>(), s, sig,                        \
+                           (const long long*)frame_pos, frame_left, frame_right, (long long)n_frames,             \
+                           (const double*)tables_f64, out_mag, out_real, out_imag, (long long)ld);                \
+    } while (0)
+    if (P == 32) MPX_LAUNCH_A64(32);
+    else if (P == 16) MPX_LAUNCH_A64(16);
+    else MPX_LAUNCH_A64(8);
+#undef MPX_LAUNCH_A64
+    MPX_HIP_CHECK(hipGetLastError());
+    return MPX_OK;
+}
+
+}  // extern "C"

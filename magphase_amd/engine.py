@@ -188,22 +188,35 @@ class Engine:
             self._tables[fft_len] = t
         return self._tables[fft_len]
 
+    def tables_f64(self, fft_len):
+        key = ("f64", fft_len)
+        if key not in self._tables:
+            torch = _torch()
+            nbytes = self.lib.mpx_tables_f64_bytes(int(fft_len))
+            if nbytes == 0:
+                raise ValueError("fft_len %r not supported by the HIP path (1024, 2048 or 4096)" % (fft_len,))
+            t = torch.empty(nbytes // 8, dtype=torch.float64, device=self.device)
+            with torch.cuda.device(self.device):
+                _lib.check(self.lib.mpx_tables_f64_init(self.stream_ptr(), int(fft_len), t.data_ptr()), "mpx_tables_f64_init")
+            self._tables[key] = t
+        return self._tables[key]
+
     # ------------------------------------------------------------------ kernels
-    def analysis_frames(self, fft_len, sig, pos, left, right, out=None):
-        """sig f32[n], pos i64[F], left/right i32[F] (device) -> (mag, real, imag) f32[F x H] (device)."""
+    def analysis_frames(self, fft_len, sig, pos, left, right, out=None, precise=False):
+        """sig f32[n], pos i64[F], left/right i32[F] (device) -> (mag, real, imag) f32[F x H] (device).
+        precise: window / transform / epilogue in float64 (mpx_analysis_frames_f64): the compressed analysis' choice."""
         torch = _torch()
         nfr = int(pos.numel())
         H = fft_len // 2 + 1
         if out is None:
             out = tuple(self.empty_feats(nfr, H) for _ in range(3))
         ld = self.feat_ld(*out)
-        tab = self.tables(fft_len)
+        tab = self.tables_f64(fft_len) if precise else self.tables(fft_len)
+        fn = self.lib.mpx_analysis_frames_f64 if precise else self.lib.mpx_analysis_frames
         with torch.cuda.device(self.device):
-            _lib.check(
-                self.lib.mpx_analysis_frames(self.stream_ptr(), int(fft_len), tab.data_ptr(), sig.data_ptr(),
-                                             pos.data_ptr(), left.data_ptr(), right.data_ptr(), nfr,
-                                             out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), ld),
-                "mpx_analysis_frames")
+            _lib.check(fn(self.stream_ptr(), int(fft_len), tab.data_ptr(), sig.data_ptr(), pos.data_ptr(), left.data_ptr(),
+                          right.data_ptr(), nfr, out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), ld),
+                       "mpx_analysis_frames_f64" if precise else "mpx_analysis_frames")
         return out
 
     def synthesis_lossless_frames(self, fft_len, mag, real, imag, out=None):
@@ -454,8 +467,9 @@ class LosslessAnalysisPlan:
         self.pos, self.left, self.right = desc["pos"], desc["left"], desc["right"]
         self.total_smpls = int(off)
 
-    def run(self, out=None):
-        return self.engine.analysis_frames(self.fft_len, self.sig, self.pos, self.left, self.right, out=out)
+    def run(self, out=None, precise=False):
+        return self.engine.analysis_frames(self.fft_len, self.sig, self.pos, self.left, self.right, out=out,
+                                           precise=precise)
 
 
 class LosslessSynthesisPlan:
@@ -870,8 +884,10 @@ class CompressedAnalysisPlan:
         H = self.fft_len // 2 + 1
         mark = mark or (lambda name: None)
         mark("start")
-        mag, real, imag = self.lossless.run(out=feats)
-        mark("k_analysis")
+        # float64 transform: the warp's log / division amplify an fp32 FFT's noise on weak bins (magphase_f64.hip)
+        precise = os.environ.get("MAGPHASE_COMP_ANALYSIS", "f64") != "f32"
+        mag, real, imag = self.lossless.run(out=feats, precise=precise)
+        mark("k_analysis_f64" if precise else "k_analysis")
         if out is None:
             out = (e.empty((self.total_out_frames, self.mag_dim)), e.empty((self.total_out_frames, self.phase_dim)),
                    e.empty((self.total_out_frames, self.phase_dim)))
