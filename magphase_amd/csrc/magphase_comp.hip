@@ -129,8 +129,7 @@ __global__ __launch_bounds__(256) void k_mel_warp(WarpJobs jobs, long long F, in
             const float x = fmaf(xw[p] - xv[p], s_rt[fl], xv[p]);
             // hardware exp2/log2 (v_exp_f32 / v_log_f32, ~1 ulp): the 1e-7 error is far below the stated tolerance
             // of this (ill-conditioned, unpinned) stage
-            const float e = (job.mode == 0) ? x : __expf(x);
-            const float v = __logf(fmaf(e, e, 1.0e-8f));
+            const float v = (job.mode == 0) ? __logf(fmaf(x, x, 1.0e-8f)) : fmaf(1.0e-8f, __expf(-2.0f * x), 2.0f * x);
             As[kk][fl] = (kok && f0 + fl < F) ? v : 0.0f;
             Ws[kk][fl] = (kok && fl < job.nout) ? wv16[p] : 0.0f;
         }
@@ -883,9 +882,15 @@ __device__ __forceinline__ void mel_warp_block(const WarpJob& job, float (*As)[k
         s_rt[threadIdx.x] = row0 ? rowt[f] : 0.0f;
     }
     __syncthreads();
-    f32x4 acc[NT];
+    // Two-level accumulation over the H bins.  The operands are log spectra (|v| ~ 10): one fp32 chain over 2049 terms
+    // carries partial sums of that size and loses ~sqrt(2049) * 6e-7 = 3e-5 -- measured 4e-5 against a float64 product of
+    // the same device features, the whole residual error of the compressed analysis once its FFT is float64.  So every
+    // 64-bin chunk is summed in a fresh MFMA accumulator (small partial sums) and the 33 chunk sums are added up
+    // separately: ~sqrt(33) * 6e-7.  (An error-free TwoSum of the totals costs 16 more registers: the kernel, capped at
+    // 128 VGPRs for four workgroups per CU, spills.)
+    f32x4 tot[NT];
 #pragma unroll
-    for (int jt = 0; jt < NT; ++jt) acc[jt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    for (int jt = 0; jt < NT; ++jt) tot[jt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
     // Every load is unconditional (clamped bin): the 48 loads of a chunk are in flight together, and the NEXT chunk's
     // are issued right after this chunk's values are in LDS, so they fly behind the fragment reads and the MFMAs.
@@ -909,16 +914,19 @@ __device__ __forceinline__ void mel_warp_block(const WarpJob& job, float (*As)[k
         for (int p = 0; p < 16; ++p) {
             const int fl = fq + 4 * p;
             const float x = INTERP ? fmaf(xw[p] - xv[p], s_rt[fl], xv[p]) : xv[p];
-            // hardware exp2/log2 (v_exp_f32 / v_log_f32, ~1 ulp): the 1e-7 error is far below the stated tolerance
-            // of this (ill-conditioned, unpinned) stage
-            const float e = (job.mode == 0) ? x : __expf(x);
-            const float v = __logf(fmaf(e, e, 1.0e-8f));
+            // magnitudes: ln(x^2 + 1e-8) with the hardware log2 (v_log_f32, ~1 ulp of log2).  Phase streams (mcep -q 2 on
+            // exp(x), |x| <= 1): ln(e^{2x} + 1e-8) = 2x + ln(1 + 1e-8 e^{-2x}) = 2x + 1e-8 e^{-2x} (the next term is
+            // 5e-17): exact to the rounding of the sum, where exp-then-log in fp32 lost ~1e-6
+            const float v = (job.mode == 0) ? __logf(fmaf(x, x, 1.0e-8f)) : fmaf(1.0e-8f, __expf(-2.0f * x), 2.0f * x);
             As[fl][kk] = (kok && f0 + fl < F) ? v : 0.0f;
             if (p < 4 * NT) Ws[fl][kk] = (kok && fl < job.nout) ? wv16[p] : 0.0f;
         }
         __syncthreads();
         if (k0 + kWarpTile < H) fetch(k0 + kWarpTile);
         const float* arow = &As[16 * wave + li][16 * g];
+        f32x4 acc[NT];
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt) acc[jt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int q = 0; q < 4; ++q) {   // 4 k per lane group and step: one 16-byte read per fragment
             const float4 aq = *reinterpret_cast<const float4*>(arow + 4 * q);
@@ -934,6 +942,8 @@ __device__ __forceinline__ void mel_warp_block(const WarpJob& job, float (*As)[k
 #pragma unroll
             for (int jt = 0; jt < NT; ++jt) acc[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.w, bq[jt].w, acc[jt], 0, 0, 0);
         }
+#pragma unroll
+        for (int jt = 0; jt < NT; ++jt) tot[jt] += acc[jt];
         __syncthreads();
     }
     // C: column li of tile jt, row 4 g + r of this wave's 16 frames
@@ -946,7 +956,7 @@ __device__ __forceinline__ void mel_warp_block(const WarpJob& job, float (*As)[k
         for (int jt = 0; jt < NT; ++jt) {
             const int i = 16 * jt + li;
             if (i >= job.nout) continue;
-            float y = acc[jt][r];
+            float y = tot[jt][r];
             if (job.mode == 1) y = fminf(fmaxf(y * vo, -1.0f), 1.0f);
             job.out[f * job.nout + i] = y;
         }

@@ -256,9 +256,11 @@ class Engine:
         """Device MagPhase post-filter (mpx_post_filter) of a float32 [F x D] tensor; kw as magphase.post_filter."""
         torch = _torch()
         F, D = int(mag_mel_log.shape[0]), int(mag_mel_log.shape[1])
-        nx0, nx1, half, tilt = hm.post_filter_tables(D, fs, **kw)
-        d_half = self.to_device(half, np.int32)
-        d_tilt = self.to_device(tilt, np.float32)
+        key = ("post_filter", D, int(fs)) + tuple(sorted(kw.items()))
+        if key not in self._tables:   # device-resident per configuration (two small uploads per call otherwise)
+            nx0, nx1, half, tilt = hm.post_filter_tables(D, fs, **kw)
+            self._tables[key] = (nx0, nx1, self.to_device(half, np.int32), self.to_device(tilt, np.float32))
+        nx0, nx1, d_half, d_tilt = self._tables[key]
         out = self.empty((F, D))
         with torch.cuda.device(self.device):
             _lib.check(self.lib.mpx_post_filter(self.stream_ptr(), mag_mel_log.data_ptr(), F, D, d_half.data_ptr(),

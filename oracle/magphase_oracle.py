@@ -12,8 +12,8 @@ Pinning status
   * Everything except the two external binaries is PINNED: oracle/gen_golden.py imports the
     real reference (oracle/ref_shim.py) in the build container and tests/test_oracle_vs_golden.py
     compares this restatement with the committed outputs of the reference itself
-    (tests/golden/*.npz); tests/test_oracle_vs_reference.py re-checks live when
-    /root/reference is present.
+    (tests/golden/*.npz; re-running oracle/gen_golden.py where /root/reference exists
+    regenerates them bit for bit).
   * ``sptk_mcep`` / ``freqt`` restate SPTK-3.9 ``mcep -j 0`` (an external C binary fetched by
     the reference's tools/download_and_compile_tools.sh:5,36; source absent from
     /root/reference): PARITY UNPINNED.  Pinned only by self-consistency KATs
