@@ -214,6 +214,16 @@ int mpx_synthesis_compressed_ola(void* stream, int fft_len, const void* tables, 
                                  float* strips, float* pcm_out,
                                  int64_t ld /* row pitch of mag/real/imag in floats, >= fft_len/2 + 1 */);
 
+/*
+ * HOST function (no device work, no stream): the serial constant -> variable frame-rate scan of
+ * magphase.py:1426-1449 (get_shifts_and_frm_locs_from_const_shifts, Q16) in the reference's float64 operation
+ * sequence (scipy interp1d's linear formula, no FMA): bit-identical shifts / frame locations, ~100x faster than one
+ * scipy call per step.  centres, shift_c: HOST float64[n] (centres ascending); shifts_out, locs_out: HOST float64[2n].
+ * Returns the index `start` of the first valid element (results are out[start .. 2n)), or -1 on bad arguments.
+ */
+int64_t mpx_host_const_to_var_scan(const double* centres, const double* shift_c, int64_t n, double* shifts_out,
+                                   double* locs_out);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * Compressed-feature analysis (magphase.py:2490-2544 format_for_modelling, :2947-2988 analysis_compressed)
  * ------------------------------------------------------------------------------------------------------------------ */
@@ -275,6 +285,16 @@ int mpx_hpf_block(void);
 int mpx_output_hpf(void* stream, const float* pcm, const int64_t* out_off, const int32_t* blk_off, int32_t n_utts,
                    int64_t max_len, const double* sos_host, const double* pmat, const double* gtab, double* zend,
                    double* zstart, double* y_tmp, double* y);
+
+/*
+ * 16-bit PCM of the synthesised utterances for the wav writer (libaudio.py:352-365 write_audio_file, Q17): per
+ * utterance v = norm * y / max|y| in float64 (skipped when norm <= 0), then lrint(v * 0x7FFF) as libsndfile converts
+ * floats to PCM_16 -- the host form's IEEE operations in the same order, so the samples are bit-identical to
+ * la.write_audio_file's.  y: float64 (y_is_f64 != 0; the output of mpx_output_hpf) or float32 samples, utterances
+ * concatenated at out_off (int64[n_utts+1]); peaks: float64[n_utts] scratch (receives max|y|); out: int16, same layout.
+ */
+int mpx_pcm16(void* stream, const void* y, int32_t y_is_f64, const int64_t* out_off, int32_t n_utts, int64_t max_len,
+              double norm, double* peaks, int16_t* out);
 
 #ifdef __cplusplus
 }

@@ -32,10 +32,12 @@ SYMBOLS = (
     "mpx_noise_stats",
     "mpx_synth_comp_slots",
     "mpx_synthesis_compressed_ola",
+    "mpx_host_const_to_var_scan",
     "mpx_mel_warp",
     "mpx_min_phase",
     "mpx_noise_gains",
     "mpx_post_filter",
+    "mpx_pcm16",
     "mpx_hpf_block",
     "mpx_output_hpf",
 )
@@ -101,6 +103,8 @@ def load():
     lib.mpx_synth_comp_slots.argtypes = []
     lib.mpx_synthesis_compressed_ola.restype = ctypes.c_int
     lib.mpx_synthesis_compressed_ola.argtypes = [vp, ctypes.c_int, vp] + [vp] * 19 + [vp, i32, vp, vp, i32, vp, vp, i64]
+    lib.mpx_host_const_to_var_scan.restype = i64
+    lib.mpx_host_const_to_var_scan.argtypes = [vp, vp, i64, vp, vp]
     lib.mpx_mel_warp.restype = ctypes.c_int
     lib.mpx_mel_warp.argtypes = [vp, i64, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, vp, vp, vp, vp, i64]
     lib.mpx_min_phase.restype = ctypes.c_int
@@ -109,6 +113,8 @@ def load():
     lib.mpx_noise_gains.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp]
     lib.mpx_post_filter.restype = ctypes.c_int
     lib.mpx_post_filter.argtypes = [vp, vp, i64, i32, vp, i32, i32, vp, vp]
+    lib.mpx_pcm16.restype = ctypes.c_int
+    lib.mpx_pcm16.argtypes = [vp, vp, i32, vp, i32, i64, ctypes.c_double, vp, vp]
     lib.mpx_hpf_block.restype = ctypes.c_int
     lib.mpx_hpf_block.argtypes = []
     lib.mpx_output_hpf.restype = ctypes.c_int

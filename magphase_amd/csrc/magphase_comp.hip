@@ -462,6 +462,41 @@ __global__ __launch_bounds__(256) void k_hpf_apply(const long long* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------
+// 16-bit PCM for the wav writer (libaudio.py:352-365, Q17, as soundfile / libsndfile writes it): per utterance
+// v = norm * y / max|y| in float64, then lrint(v * 0x7FFF) (round half to even; no clipping of in-range input).  Same
+// IEEE operations in the same order as the host form (la.write_audio_file) -- __dmul_rn / __ddiv_rn keep the compiler
+// from fusing them -- so the samples are bit-identical; the device hands the writer thread ready int16 samples and the
+// D2H copy is a quarter of the float64 one.  k_peak_abs: one block per utterance; k_pcm16: one thread per sample.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_peak_abs(const T* __restrict__ y, const long long* __restrict__ off,
+                                                  double* __restrict__ peak) {
+    __shared__ double s_max[256];
+    const int u = blockIdx.x;
+    double m = 0.0;
+    for (long long i = off[u] + threadIdx.x; i < off[u + 1]; i += 256) m = fmax(m, fabs((double)y[i]));
+    s_max[threadIdx.x] = m;
+    __syncthreads();
+    for (int k = 128; k >= 1; k >>= 1) {
+        if (threadIdx.x < k) s_max[threadIdx.x] = fmax(s_max[threadIdx.x], s_max[threadIdx.x + k]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) peak[u] = s_max[0];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_pcm16(const T* __restrict__ y, const long long* __restrict__ off,
+                                               const double* __restrict__ peak, double norm, short* __restrict__ out) {
+    const int u = blockIdx.y;
+    const long long i = off[u] + (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= off[u + 1]) return;
+    double v = (double)y[i];
+    if (norm > 0.0) v = __ddiv_rn(__dmul_rn(norm, v), peak[u]);
+    const double r = rint(__dmul_rn(v, 32767.0));
+    out[i] = (short)fmin(fmax(r, -32768.0), 32767.0);   // NaN (silent utterance: 0 / 0) -> fmax/fmin pick the bound
+}
+
+// ---------------------------------------------------------------------------------------------
 // minimum-phase spectrum from a magnitude spectrum (complex cepstrum), la.build_min_phase_from_mag_spec
 // (libaudio.py:920-934): ln|X| -> even extension -> real IFFT (cepstrum c) -> causal fold (c[1..N/2-1] *= 2,
 // c[N/2+1..] = 0) -> FFT -> exp.  Since Re FFT(fold c) == ln|X|, only the phase phi = Im FFT(fold c) is new: the
@@ -1317,6 +1352,25 @@ int mpx_post_filter(void* stream, const float* mag_mel_log, int64_t n_frames, in
     const dim3 grid((unsigned)((n_frames + rows - 1) / rows)), block(256);
     hipLaunchKernelGGL(k_post_filter, grid, block, sizeof(float) * (size_t)rows * dim, (hipStream_t)stream,
                        mag_mel_log, (long long)n_frames, (int)dim, half_len, (int)nx_first, (int)nx_last, tilt, out);
+    MPX_HIP_CHECK(hipGetLastError());
+    return MPX_OK;
+}
+
+int mpx_pcm16(void* stream, const void* y, int32_t y_is_f64, const int64_t* out_off, int32_t n_utts, int64_t max_len,
+              double norm, double* peaks, int16_t* out) {
+    if (n_utts < 0 || max_len < 0) return fail(MPX_ERR_ARG, "mpx_pcm16: negative size%s");
+    if (n_utts == 0 || max_len == 0) return MPX_OK;
+    if (!y || !out_off || !peaks || !out) return fail(MPX_ERR_ARG, "mpx_pcm16: null pointer%s");
+    if (n_utts > 65535) return fail(MPX_ERR_ARG, "mpx_pcm16: at most 65535 utterances per call%s");
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 g2((unsigned)((max_len + 255) / 256), (unsigned)n_utts);
+    if (y_is_f64) {
+        hipLaunchKernelGGL(k_peak_abs<double>, dim3((unsigned)n_utts), dim3(256), 0, s, (const double*)y, (const long long*)out_off, peaks);
+        hipLaunchKernelGGL(k_pcm16<double>, g2, dim3(256), 0, s, (const double*)y, (const long long*)out_off, peaks, norm, (short*)out);
+    } else {
+        hipLaunchKernelGGL(k_peak_abs<float>, dim3((unsigned)n_utts), dim3(256), 0, s, (const float*)y, (const long long*)out_off, peaks);
+        hipLaunchKernelGGL(k_pcm16<float>, g2, dim3(256), 0, s, (const float*)y, (const long long*)out_off, peaks, norm, (short*)out);
+    }
     MPX_HIP_CHECK(hipGetLastError());
     return MPX_OK;
 }

@@ -690,6 +690,41 @@ int mpx_ola_gather(void* stream, int fft_len, const float* frames, int32_t n_utt
     return MPX_OK;
 }
 
+/*
+ * Host-side planner (no device work): the reference's serial constant -> variable frame-rate scan
+ * (magphase.py:1426-1449, Q16), pos_{k-1} = pos_k - lerp(shift)(pos_k) from the last constant-rate centre backwards
+ * until the position leaves the grid.  The reference evaluates scipy.interpolate.interp1d once per step from a Python
+ * loop (8 us per step, ~1000 steps per utterance); this is the same float64 operation sequence -- searchsorted (left),
+ * indices clipped to [1, n-1], slope = (y_hi - y_lo) / (x_hi - x_lo), y = slope * (x_new - x_lo) + y_lo, no fused
+ * multiply-add -- so the shifts and locations are bit-identical (golden G7, tests/test_host_plans.py).
+ * centres: float64[n] ascending (step * (1 .. n)); shift_c: float64[n]; shifts_out / locs_out: float64[2n].
+ * Returns the index of the first valid element of the two outputs (the result is out[start : 2n]).
+ */
+int64_t mpx_host_const_to_var_scan(const double* centres, const double* shift_c, int64_t n, double* shifts_out,
+                                   double* locs_out) {
+#pragma clang fp contract(off)
+    if (!centres || !shift_c || !shifts_out || !locs_out || n < 2) return -1;
+    for (int64_t i = 0; i < 2 * n; ++i) shifts_out[i] = locs_out[i] = 0.0;
+    double pos = centres[n - 1];
+    for (int64_t i = 2 * n - 1; i >= 1; --i) {
+        locs_out[i] = pos;
+        if (!(pos >= centres[0] && pos <= centres[n - 1])) return i + 1;   // interp1d's bounds_error (NaN included)
+        int64_t lo = 0, hi = n;                                            // np.searchsorted(centres, pos, 'left')
+        while (lo < hi) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (centres[mid] < pos) lo = mid + 1; else hi = mid;
+        }
+        int64_t idx = lo < 1 ? 1 : (lo > n - 1 ? n - 1 : lo);
+        const double x_lo = centres[idx - 1], x_hi = centres[idx], y_lo = shift_c[idx - 1], y_hi = shift_c[idx];
+        const double slope = (y_hi - y_lo) / (x_hi - x_lo);
+        const double prod = slope * (pos - x_lo);
+        const double y = prod + y_lo;
+        shifts_out[i] = y;
+        pos = pos - y;
+    }
+    return 0;
+}
+
 #ifdef MPX_PROBE_TIMING
 int mpx_probe_read(unsigned long long* host16, int reset) {   // probe builds only (not part of the ABI)
     MPX_HIP_CHECK(hipDeviceSynchronize());

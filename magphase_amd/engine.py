@@ -64,8 +64,9 @@ class Engine:
         """Two page-locked float32 staging buffers of at least n_floats elements (grown on demand, kept)."""
         torch = _torch()
         cur = getattr(self, "_pinned", None)
-        if cur is None or cur[0].numel() < n_floats:
-            self._pinned = tuple(torch.empty(int(n_floats), dtype=torch.float32).pin_memory() for _ in range(2))
+        if cur is None or cur[0].numel() < n_floats:   # grown with headroom: page-locking costs milliseconds per 10 MB
+            n_alloc = max(int(n_floats * 1.5), 1 << 20)
+            self._pinned = tuple(torch.empty(n_alloc, dtype=torch.float32).pin_memory() for _ in range(2))
         return self._pinned
 
     def to_host_f64(self, t, chunk_bytes=64 << 20):
@@ -104,12 +105,48 @@ class Engine:
                 drain(i)
         return out
 
+    def to_host_f32(self, t):
+        """Device float32 tensor (rows may be pitched) -> fresh float32 numpy array (one D2H copy into a new pageable
+        array: for the megabyte-sized compressed features that beats staging + a second host copy)."""
+        torch = _torch()
+        dst = torch.empty(tuple(int(x) for x in t.shape), dtype=torch.float32)
+        if dst.numel():
+            with torch.cuda.device(self.device):
+                dst.copy_(t)
+        return dst.numpy()
+
+    def output_pcm16(self, y, out_off_host, norm=0.98):
+        """
+        libaudio.py:352-365 on the device (mpx_pcm16): y float64 or float32 [total] (utterances at out_off_host) ->
+        int16 numpy [total], each utterance peak-normalised to `norm` (None: no normalisation) and rounded like
+        libsndfile's PCM_16 conversion -- bit-identical to la.write_audio_file's samples.
+        """
+        torch = _torch()
+        out_off_host = np.asarray(out_off_host, dtype=np.int64)
+        lens = np.diff(out_off_host)
+        total = int(out_off_host[-1])
+        d_off = self.to_device(out_off_host, np.int64)
+        peaks = torch.empty(max(lens.size, 1), dtype=torch.float64, device=self.device)
+        out = torch.empty(max(total, 1), dtype=torch.int16, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.mpx_pcm16(self.stream_ptr(), y.data_ptr(), 1 if y.dtype == torch.float64 else 0,
+                                          d_off.data_ptr(), int(lens.size), int(lens.max()) if lens.size else 0,
+                                          float(norm) if norm is not None else 0.0, peaks.data_ptr(), out.data_ptr()),
+                       "mpx_pcm16")
+            host = torch.empty(max(total, 1), dtype=torch.int16).pin_memory() if total > (1 << 16) else None
+            if host is not None:
+                host.copy_(out, non_blocking=True)
+                torch.cuda.current_stream(self.device).synchronize()
+                return host[:total].numpy()
+        return out[:total].cpu().numpy()
+
     def host_staging(self, n_floats):
         """float32 numpy view [n_floats] of a page-locked staging buffer (grown on demand, reused by every plan)."""
         torch = _torch()
         cur = getattr(self, "_stage_up", None)
-        if cur is None or cur.numel() < n_floats:
-            self._stage_up = cur = torch.empty(max(int(n_floats), 1), dtype=torch.float32).pin_memory()
+        if cur is None or cur.numel() < n_floats:   # grown with headroom (batches of a corpus differ a little in length:
+            # re-pinning 30 MB for every slightly longer batch cost 40 ms each)
+            self._stage_up = cur = torch.empty(max(int(n_floats * 1.5), 1 << 22), dtype=torch.float32).pin_memory()
         return cur.numpy()[:int(n_floats)]
 
     def upload_staged(self, n_floats):
@@ -811,9 +848,24 @@ class CompressedSynthesisPlan:
 def _const_to_variable_scan(v_shift_c_rate, frm_rate_ms, fs):
     """
     magphase.py:1426-1449 (Q16): serial backward scan pos_{k-1} = pos_k - lerp(shift)(pos_k) from the last
-    constant-rate centre until the position leaves the grid; same scipy interp1d call as the reference, so the float64
-    results (and the integer shifts cast from them) are bit-identical.
+    constant-rate centre until the position leaves the grid.  Runs in the library's host function
+    mpx_host_const_to_var_scan (scipy interp1d's float64 operation sequence without the per-step Python / scipy call:
+    bit-identical results, golden G7; _const_to_variable_scan_scipy is the literal form the tests compare it with).
     """
+    v = np.ascontiguousarray(v_shift_c_rate, dtype=np.float64)
+    n = int(v.shape[0])
+    step = fs * frm_rate_ms / 1000
+    centres = np.ascontiguousarray(step * np.arange(1, n + 1), dtype=np.float64)
+    shifts, locs = np.empty(2 * n), np.empty(2 * n)
+    start = int(_lib.load().mpx_host_const_to_var_scan(centres.ctypes.data, v.ctypes.data, n, shifts.ctypes.data,
+                                                       locs.ctypes.data))
+    if start < 0:
+        return _const_to_variable_scan_scipy(v_shift_c_rate, frm_rate_ms, fs)
+    return shifts[start:], locs[start:]
+
+
+def _const_to_variable_scan_scipy(v_shift_c_rate, frm_rate_ms, fs):
+    """The same scan written like the reference: one scipy interp1d call per step (8 us each)."""
     from scipy import interpolate
 
     n = np.size(v_shift_c_rate, 0)

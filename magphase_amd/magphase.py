@@ -55,8 +55,7 @@ def _epochs_for(wav_file):
             return np.asarray(r[0], dtype=np.float64), np.asarray(r[1], dtype=np.float64)
     est = os.path.splitext(wav_file)[0] + ".est"
     if os.path.isfile(est):
-        m = np.atleast_2d(np.loadtxt(est, skiprows=7, usecols=[0, 1]))
-        return m[:, 0], m[:, 1]
+        return la.read_est_fast(est)      # == np.loadtxt(est, skiprows=7, usecols=[0, 1]) columns, 5x faster
     if os.environ.get("MAGPHASE_EPOCHS", "") == "builtin":
         # explicit opt-in (or use_builtin_epoch_tracker()): the built-in zero-frequency-filtering tracker
         # (magphase_amd/epochs.py).  Not REAPER: the epochs differ, hence so do the pitch-synchronous features --
@@ -259,12 +258,15 @@ def _output_hpf(v_syn_sig, fs):
 
 def synthesis_from_compressed_batch(utts, fs, fft_len=None, b_voi_ap_win=True, b_const_rate=False, alpha_phase=None,
                                     b_out_hpf=True, noise=None, engine=None, per_phase_type='magphase',
-                                    b_post_filter=False, b_fbank_mel=False, noise_mode='reference', noise_seeds=None):
+                                    b_post_filter=False, b_fbank_mel=False, noise_mode='reference', noise_seeds=None,
+                                    pcm16_norm=False):
     """Batched synthesis_from_compressed; utts: list of (m_mag_mel_log, m_real_mel, m_imag_mel, v_lf0).
     b_post_filter: apply the MagPhase post-filter to the log-mel magnitudes on the device first (pf_type='magphase').
     noise_mode: 'reference' (default) draws the aperiodic source from numpy's global RNG like magphase.py:883;
     'device' generates it on the GPU (Philox, one uint64 seed per utterance in noise_seeds, default 0, 1, ...): same
-    distribution, not the reference's sample values, independent of batching and sharding."""
+    distribution, not the reference's sample values, independent of batching and sharding.
+    pcm16_norm: False (default) returns float64 signals; a number (la.write_audio_file's norm, 0.98) or None returns
+    the int16 samples la.write_audio_file(..., norm=pcm16_norm) would store, converted on the device (mpx_pcm16)."""
     engine = engine or get_engine()
     plan = CompressedSynthesisPlan(engine, utts, fs, fft_len=fft_len, b_voi_ap_win=b_voi_ap_win,
                                    b_const_rate=b_const_rate, alpha_phase=alpha_phase, noise=noise,
@@ -272,7 +274,11 @@ def synthesis_from_compressed_batch(utts, fs, fft_len=None, b_voi_ap_win=True, b
                                    noise_mode=noise_mode, noise_seeds=noise_seeds)
     pcm_dev = plan.run()
     if b_out_hpf:   # magphase.py:981-995, float64 on the device (engine.output_hpf); _output_hpf is the host form
-        pcm = engine.output_hpf(pcm_dev, plan.out_off_host, fs).cpu().numpy()
+        pcm_dev = engine.output_hpf(pcm_dev, plan.out_off_host, fs)
+    if pcm16_norm is not False:
+        pcm = engine.output_pcm16(pcm_dev, plan.out_off_host, norm=pcm16_norm)
+    elif b_out_hpf:
+        pcm = pcm_dev.cpu().numpy()
     else:
         pcm = engine.to_host_f64(pcm_dev)
     return [pcm[plan.out_off_host[u]:plan.out_off_host[u + 1]] for u in range(len(utts))]
@@ -315,7 +321,7 @@ def synthesis_from_acoustic_modelling(in_feats_dir, filename_token, out_syn_dir,
 # compressed-feature analysis
 # ======================================================================================================
 def analysis_compressed_batch(utts, fft_len=None, mag_dim=60, phase_dim=10, b_const_rate=False, alpha_phase=None,
-                              engine=None):
+                              engine=None, as_float32=False):
     """
     Batched magphase.py:2947-2988 for utterances with epochs: utts = list of (v_sig, fs, v_pm_sec, v_voi), one
     sample rate per call.  Lossless analysis (k_analysis) stays on the device; the mel warp runs on it directly.
@@ -329,7 +335,8 @@ def analysis_compressed_batch(utts, fft_len=None, mag_dim=60, phase_dim=10, b_co
     for lens in plan.lossless.long_frame_lens:
         for n in lens:
             warnings.warn(_WARN_LONG % (plan.fft_len, n))
-    h_mag, h_real, h_imag = (engine.to_host_f64(t_) for t_ in plan.run())
+    # as_float32: the device's float32 values as they are (what the feature files store), no widening to float64
+    h_mag, h_real, h_imag = ((engine.to_host_f32 if as_float32 else engine.to_host_f64)(t_) for t_ in plan.run())
     res = []
     for u in range(len(utts)):
         a, b = int(plan.out_off[u]), int(plan.out_off[u + 1])

@@ -162,3 +162,29 @@ def test_library_helpers_on_the_device():
     for k in range(3):
         assert f[k].shape == c[k].shape and np.max(np.abs(f[k] - c[k])) < 2e-3   # float64 -> float32 re-quantised input
     assert np.array_equal(f[3], c[3])
+
+
+def test_device_pcm16_equals_the_host_wav_conversion(tmp_path):
+    """mpx_pcm16 (peak normalisation + libsndfile-style rounding on the device) gives exactly the samples
+    la.write_audio_file stores -- with and without the output high-pass (float64 / float32 device input)."""
+    import wave
+    from magphase_amd import libaudio as la, libutils as lu, magphase as mp
+    d = os.path.join(ROOT, "demos", "data_48k", "params_predicted")
+    utts = [tuple(lu.read_binfile(os.path.join(d, t + e), dim=k) for e, k in ((".mag", 60), (".real", 45), (".imag", 45), (".lf0", 1)))
+            for t in ("hvd_704", "hvd_706")]
+    for hpf in (True, False):
+        np.random.seed(5)
+        sigs = mp.synthesis_from_compressed_batch(utts, 48000, b_out_hpf=hpf)
+        np.random.seed(5)
+        pcm = mp.synthesis_from_compressed_batch(utts, 48000, b_out_hpf=hpf, pcm16_norm=0.98)
+        for u in range(2):
+            path = str(tmp_path / ("h%d_%d.wav" % (hpf, u)))
+            la.write_audio_file(path, sigs[u], 48000)
+            with wave.open(path, "rb") as w:
+                ref = np.frombuffer(w.readframes(w.getnframes()), dtype=np.int16)
+            assert pcm[u].dtype == np.int16 and pcm[u].size == ref.size
+            if hpf:      # float64 on both sides: bit-identical
+                assert np.array_equal(pcm[u], ref)
+            else:        # the host widens the device's float32 PCM first: same values, same result
+                assert np.array_equal(pcm[u], ref)
+            assert 32000 < int(np.max(np.abs(ref.astype(np.int32)))) <= 32112      # 0.98 * 32767

@@ -159,3 +159,28 @@ def test_plans_build_without_gpu_and_match_oracle_indices():
     assert sp.total_frames == ap.total_frames
     assert sp.strip_floats == sp.n_runs * (sp.fft_len + 64)
     assert sp.runs.dtype == np.uint8 and sp.runs.size == sp.n_runs * 56
+
+
+def test_native_const_to_variable_scan_is_bit_identical_to_the_scipy_form(golden_dir):
+    """mpx_host_const_to_var_scan (host C++ in the library) vs one scipy interp1d call per step, and vs the reference's
+    own output (golden G7)."""
+    import os
+    import time
+    from magphase_amd import engine
+    rng = np.random.RandomState(3)
+    for n, fs in ((997, 48000), (400, 16000), (2, 48000), (57, 48000)):
+        f0 = np.where(rng.rand(n) < 0.3, 0.0, rng.uniform(60, 400, n))
+        sh = hm.f0_to_shift(f0, fs)
+        a = engine._const_to_variable_scan(sh, 5.0, fs)
+        b = engine._const_to_variable_scan_scipy(sh, 5.0, fs)
+        assert a[0].shape == b[0].shape and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    g = np.load(os.path.join(golden_dir, "g7_const_rate.npz"))
+    shifts, locs = engine._const_to_variable_scan(hm.f0_to_shift(g["v_f0_c"], int(g["fs"])), 5.0, int(g["fs"]))
+    assert np.array_equal(shifts, g["v_shift_vr"]) and np.array_equal(locs, g["v_locs"])
+    sh = hm.f0_to_shift(rng.uniform(80, 300, 1000), 48000)
+    t0 = time.perf_counter()
+    engine._const_to_variable_scan(sh, 5.0, 48000)
+    t1 = time.perf_counter()
+    engine._const_to_variable_scan_scipy(sh, 5.0, 48000)
+    t2 = time.perf_counter()
+    assert (t1 - t0) * 20 < (t2 - t1)

@@ -38,8 +38,9 @@ def run(n_utt=128, dur=5.0, batch_utts=32, noise_mode=None):
         wavs = [os.path.join(wav_dir, t + ".wav") for t in toks]
         feats = os.path.join(tmp, "feats")
         iobatch.extract_features_corpus(wavs[:8], os.path.join(tmp, "warm"), batch_utts=8, phase_dim=45, verbose=False)
+        rep_e, rep_g = iobatch.CorpusReport(), iobatch.CorpusReport()
         t = time.time()
-        iobatch.extract_features_corpus(wavs, feats, batch_utts=batch_utts, phase_dim=45, verbose=False)
+        iobatch.extract_features_corpus(wavs, feats, batch_utts=batch_utts, phase_dim=45, verbose=False, report=rep_e)
         t_ext = time.time() - t
         kw = {} if noise_mode is None else {"noise_mode": noise_mode}
         np.random.seed(1)
@@ -47,7 +48,7 @@ def run(n_utt=128, dur=5.0, batch_utts=32, noise_mode=None):
                                           pf_type="magphase", batch_utts=8, verbose=False, **kw)
         t = time.time()
         iobatch.generate_waveforms_corpus(feats, toks, os.path.join(tmp, "syn"), 60, 45, 48000, pf_type="magphase",
-                                          batch_utts=batch_utts, verbose=False, **kw)
+                                          batch_utts=batch_utts, verbose=False, report=rep_g, **kw)
         t_gen = time.time() - t
         audio = n_utt * dur
         return {"what": "%d wav + .est files of %.0f s @48 kHz on local disk, one process, one GPU, iobatch reader / "
@@ -56,7 +57,9 @@ def run(n_utt=128, dur=5.0, batch_utts=32, noise_mode=None):
                         "16-bit wav" % (n_utt, dur, batch_utts),
                 "audio_s": audio, "extraction_s": round(t_ext, 3), "generation_s": round(t_gen, 3),
                 "extraction_x_realtime": round(audio / t_ext, 1), "generation_x_realtime": round(audio / t_gen, 1),
-                "generation_noise": noise_mode or "reference (numpy global RNG)"}
+                "generation_noise": noise_mode or "reference (numpy global RNG)",
+                "stage_busy_s": {"extraction": {k: round(v, 3) for k, v in rep_e.items() if k.endswith("_s")},
+                                 "generation": {k: round(v, 3) for k, v in rep_g.items() if k.endswith("_s")}}}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 
@@ -67,3 +70,4 @@ if __name__ == "__main__":
           % (r["audio_s"], r["extraction_s"], r["extraction_x_realtime"]))
     print("waveform generation (features -> post-filter -> wav):          %.0f s of audio in %.2f s = %.0f x real time"
           % (r["audio_s"], r["generation_s"], r["generation_x_realtime"]))
+    print("stage busy seconds (reader / compute / writer threads overlap):", r["stage_busy_s"])
