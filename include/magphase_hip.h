@@ -286,6 +286,36 @@ int mpx_output_hpf(void* stream, const float* pcm, const int64_t* out_off, const
                    int64_t max_len, const double* sos_host, const double* pmat, const double* gtab, double* zend,
                    double* zstart, double* y_tmp, double* y);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Built-in epoch / voicing front end.  NOT REAPER (libaudio.py:450-455 shells out to it): parity
+ * unpinned, opt-in (magphase_amd/epochs.py documents the algorithm and its quality checks).  Batched over utterances.
+ * ------------------------------------------------------------------------------------------------------------------ */
+
+/*
+ * F0 / voicing candidates: box-decimation by `dec` (to ~4 kHz), then per 5 ms frame the normalised cross-correlation
+ * for n_lags lags starting at l_min; the shortest lag within 0.06 of the best is refined by a parabola.
+ * sig: float32 PCM, utterances at off[0..n_utts]; dec_off / frame_off: int64[n_utts+1] offsets of the decimated
+ * signals (scratch xd, float64) and of the frames in the outputs; means: float64[2 n_utts] scratch.
+ * Outputs per frame: f0 (fs_d / lag), peak (NCCF at the chosen lag), energy (sum of squares of the frame's window).
+ */
+int mpx_epoch_f0_track(void* stream, const float* sig, const int64_t* off, int32_t n_utts, int32_t dec,
+                       const int64_t* dec_off, int64_t max_dec_len, double* xd, double* means, const int64_t* frame_off,
+                       int64_t max_frames, int32_t hop, int32_t win, int32_t l_min, int32_t n_lags, double fs_d,
+                       float* f0, float* peak, float* energy);
+
+/*
+ * Epoch candidates by zero-frequency filtering: x differenced, through two zero-frequency resonators (cumulative
+ * sums, float64) with the local mean over 2 half_win[u] + 1 samples removed after the first and three times after the
+ * second; then the zero crossings of both directions of the result.  List p of utterance u (p = 0: negative-going,
+ * 1: positive-going) holds counts[2u + p] entries at [(2u + p) * cap ...): sample index, |slope|, and the excitation
+ * energy of the w_score samples after the crossing minus the w_score before it (which direction carries the epochs
+ * depends on the recording's polarity: the host keeps the one with the larger mean score).  Entries are unordered.
+ * buf_a/b/c: float64 scratch of the total sample count each.
+ */
+int mpx_epoch_zff(void* stream, const float* sig, const int64_t* off, int32_t n_utts, int64_t max_len,
+                  const int32_t* half_win, int32_t w_score, double* buf_a, double* buf_b, double* buf_c, int32_t cap,
+                  int32_t* counts, int32_t* cross_idx, float* cross_slope, float* cross_score);
+
 /*
  * 16-bit PCM of the synthesised utterances for the wav writer (libaudio.py:352-365 write_audio_file, Q17): per
  * utterance v = norm * y / max|y| in float64 (skipped when norm <= 0), then lrint(v * 0x7FFF) as libsndfile converts

@@ -37,6 +37,8 @@ SYMBOLS = (
     "mpx_min_phase",
     "mpx_noise_gains",
     "mpx_post_filter",
+    "mpx_epoch_f0_track",
+    "mpx_epoch_zff",
     "mpx_pcm16",
     "mpx_hpf_block",
     "mpx_output_hpf",
@@ -113,6 +115,11 @@ def load():
     lib.mpx_noise_gains.argtypes = [vp, vp, vp, vp, i32, i32, vp, vp]
     lib.mpx_post_filter.restype = ctypes.c_int
     lib.mpx_post_filter.argtypes = [vp, vp, i64, i32, vp, i32, i32, vp, vp]
+    lib.mpx_epoch_f0_track.restype = ctypes.c_int
+    lib.mpx_epoch_f0_track.argtypes = [vp, vp, vp, i32, i32, vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, ctypes.c_double,
+                                       vp, vp, vp]
+    lib.mpx_epoch_zff.restype = ctypes.c_int
+    lib.mpx_epoch_zff.argtypes = [vp, vp, vp, i32, i64, vp, i32, vp, vp, vp, i32, vp, vp, vp, vp]
     lib.mpx_pcm16.restype = ctypes.c_int
     lib.mpx_pcm16.argtypes = [vp, vp, i32, vp, i32, i64, ctypes.c_double, vp, vp]
     lib.mpx_hpf_block.restype = ctypes.c_int

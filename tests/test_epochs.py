@@ -1,15 +1,16 @@
 """
-Built-in epoch / voicing front end (magphase_amd/epochs.py).  PARITY UNPINNED (REAPER is an external
-binary that is not available): quality is measured on synthetic utterances whose epochs are known exactly.
+Built-in epoch / voicing front end (magphase_amd/epochs.py + csrc/magphase_epochs.hip).  PARITY
+UNPINNED (REAPER is an external binary that is not available): quality is measured on synthetic utterances whose epochs
+are known exactly, and on two of the reference's bundled natural recordings (sanity ranges + copy synthesis).
+Device kernels: -m gpu.
 """
+import os
+
 import numpy as np
 import pytest
-import torch
 
-from magphase_amd import epochs
-from magphase_amd import synthetic as syn
-
-CPU = torch.device("cpu")
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _score(pm, voi, e_pm, e_voi):
@@ -20,29 +21,74 @@ def _score(pm, voi, e_pm, e_voi):
     return hit, fa, float(np.median(err))
 
 
-@pytest.mark.parametrize("u,fs", [(0, 48000), (2, 48000), (3, 48000), (5, 16000), (6, 16000)])
-def test_epochs_of_synthetic_utterances(u, fs):
-    pcm, pm, voi = syn.make_utterance(u, dur_s=2.5, fs=fs)
-    e_pm, e_voi = epochs.track_epochs(pcm, fs, device=CPU)
-    assert np.all(np.diff(e_pm) > 0) and set(np.unique(e_voi)) <= {0.0, 1.0}
-    assert e_pm[0] > 0 and e_pm[-1] * fs < pcm.size - 1
-    hit, fa, med = _score(pm, voi, e_pm, e_voi)
-    assert hit > 0.85 and fa < 0.08 and abs(med) < 0.0002, (hit, fa, med)
-    # unvoiced marks every 5 ms, about as many as the generator placed
-    n_unv, n_unv_true = int((e_voi == 0).sum()), int((voi == 0).sum())
-    assert abs(n_unv - n_unv_true) < 0.25 * n_unv_true + 10
+def test_epochs_of_synthetic_utterances_batched():
+    from magphase_amd import epochs, synthetic as syn
+    for fs, us in ((48000, (0, 2, 3)), (16000, (5, 6))):
+        data = [syn.make_utterance(u, dur_s=2.5, fs=fs) for u in us]
+        res = epochs.track_epochs_batch([d[0] for d in data], fs)
+        for (pcm, pm, voi), (e_pm, e_voi) in zip(data, res):
+            assert np.all(np.diff(e_pm) > 0) and set(np.unique(e_voi)) <= {0.0, 1.0}
+            assert e_pm[0] > 0 and e_pm[-1] * fs < pcm.size - 1
+            hit, fa, med = _score(pm, voi, e_pm, e_voi)
+            assert hit > 0.85 and fa < 0.08 and abs(med) < 0.0002, (hit, fa, med)
+            # unvoiced marks every 5 ms, about as many as the generator placed
+            n_unv, n_unv_true = int((e_voi == 0).sum()), int((voi == 0).sum())
+            assert abs(n_unv - n_unv_true) < 0.25 * n_unv_true + 10
+        one = epochs.track_epochs(data[1][0], fs)                     # batching does not change the result
+        assert np.array_equal(one[0], res[1][0]) and np.array_equal(one[1], res[1][1])
 
 
 def test_polarity_does_not_matter():
+    from magphase_amd import epochs, synthetic as syn
     pcm, _pm, _voi = syn.make_utterance(1, dur_s=2.0)
-    a = epochs.track_epochs(pcm.astype(np.float64) / 32768.0, 48000, device=CPU)
-    b = epochs.track_epochs(-pcm.astype(np.float64) / 32768.0, 48000, device=CPU)
+    a = epochs.track_epochs(pcm.astype(np.float64) / 32768.0, 48000)
+    b = epochs.track_epochs(-pcm.astype(np.float64) / 32768.0, 48000)
     assert a[0].size == b[0].size and np.allclose(a[0], b[0], atol=1.0 / 48000) and np.array_equal(a[1], b[1])
 
 
 def test_noise_and_silence_are_unvoiced():
+    from magphase_amd import epochs
     rng = np.random.RandomState(0)
     for sig in (0.1 * rng.randn(32000), np.zeros(32000)):
-        pm, voi = epochs.track_epochs(sig, 16000, device=CPU)
+        pm, voi = epochs.track_epochs(sig, 16000)
         assert voi.sum() <= 0.02 * voi.size
         assert np.allclose(np.diff(pm)[voi[1:] + voi[:-1] == 0], 0.005, atol=1e-6)
+
+
+@pytest.mark.parametrize("tok", ["hvd_593", "hvd_577"])
+def test_natural_recordings_copy_synthesis(tok, tmp_path):
+    """BASELINE configs[0] on the reference's own demo recordings (bundled as data): built-in epochs (opt-in), lossless
+    copy synthesis reproduces the waveform, the low-dimensional copy synthesis runs, the voicing track is sane."""
+    import warnings
+    from magphase_amd import epochs, libaudio as la, magphase as mp
+    wav = os.path.join(ROOT, "demos", "data_48k", "wavs_nat", tok + ".wav")
+    x, fs = la.read_audio_file(wav)
+    assert fs == 48000 and x.size > 100000
+    pm, voi = epochs.track_epochs(x, fs)
+    dur = x.size / fs
+    v_frac = float(np.sum(np.diff(pm)[voi[1:] > 0]) / dur)
+    f0 = 1.0 / np.diff(pm)[(voi[1:] > 0) & (voi[:-1] > 0)]
+    assert 0.25 < v_frac < 0.85, v_frac                             # read speech: roughly half of the time is voiced
+    assert 70.0 < np.median(f0) < 350.0 and np.mean((f0 > 60) & (f0 < 420)) > 0.97
+    assert np.std(np.diff(np.log(f0))) < 0.15                       # consecutive periods agree (no octave hopping)
+    mp.use_builtin_epoch_tracker()
+    try:
+        m_mag, m_real, m_imag, v_f0, fs2, v_shift = mp.analysis_lossless(wav)
+        v_syn = mp.synthesis_from_lossless(m_mag, m_real, m_imag, v_f0, fs)
+        n = min(x.size, v_syn.size)
+        a, b = int(0.05 * n), int(0.95 * n)
+        # Q2: cumsum(fs / f0) re-times ~0.01 % of the epochs by one sample; everywhere else the half windows sum to one
+        err = v_syn[a:b] - x[a:b]
+        assert np.median(np.abs(err)) < 1e-6 * np.max(np.abs(x))
+        snr = 10 * np.log10(np.sum(x[a:b] ** 2) / np.sum(err ** 2))
+        assert snr > 30.0, snr
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            c = mp.analysis_compressed(wav, mag_dim=60, phase_dim=45)
+            np.random.seed(0)
+            y = mp.synthesis_from_compressed(c[0], c[1], c[2], c[3], fs)
+        assert np.all(np.isfinite(y)) and abs(y.size - x.size) < 0.02 * x.size
+        r = np.sqrt(np.mean(y ** 2)) / np.sqrt(np.mean(x ** 2))
+        assert 0.5 < r < 2.0, r
+    finally:
+        mp.set_epoch_provider(None)

@@ -114,15 +114,15 @@ def test_pinned_d2h_matches_plain_copy():
 def test_builtin_epoch_tracker_end_to_end(tmp_path):
     """wav without epochs -> built-in ZFF tracker on the device -> lossless analysis -> synthesis reproduces the signal
     (the half-window pairs of consecutive frames sum to one whatever the epochs are)."""
-    import torch
     from magphase_amd import epochs, libaudio as la, magphase as mp, synthetic as syn
     pcm, pm, voi = syn.make_utterance(7, dur_s=1.5)
-    e_dev = epochs.track_epochs(pcm, 48000)                          # current ROCm device
-    e_cpu = epochs.track_epochs(pcm, 48000, device=torch.device("cpu"))
-    # same algorithm, float64 on both; the device's parallel prefix sums round differently, a borderline voicing
-    # frame may flip
-    assert abs(e_dev[0].size - e_cpu[0].size) <= max(3, int(0.03 * e_cpu[0].size))
+    e_dev = epochs.track_epochs(pcm, 48000)                          # batched HIP kernels (csrc/magphase_epochs.hip)
+    assert abs(int(e_dev[1].sum()) - int(voi.sum())) <= max(5, int(0.1 * voi.sum()))
     wav = str(tmp_path / "x.wav")
+    la.write_audio_file(wav, pcm / 32768.0, 48000, norm=None)
+    if la.find_reaper() is None and os.environ.get("MAGPHASE_EPOCHS", "") != "builtin":
+        with pytest.raises(RuntimeError):        # no .est, no REAPER, no opt-in: an error, never a silent substitution
+            mp.analysis_lossless(wav)
     la.write_audio_file(wav, pcm / 32768.0, 48000, norm=None)
     mp.use_builtin_epoch_tracker()
     try:
