@@ -132,6 +132,12 @@ __global__ __launch_bounds__(kAna64Waves * 64) void k_analysis_f64(const float* 
         }
 
         wave_fft_f64<P, -1>(re, im, tw, xbuf, lane);
+        // scheduling fence: left alone, the last butterfly stage is interleaved with the split below and its inputs AND
+        // outputs are live together (16 doubles spilled: 1 GB of scratch traffic per launch)
+#pragma unroll
+        for (int j = 0; j < P; j += 4)
+            asm volatile("" : "+v"(re[j]), "+v"(re[j + 1]), "+v"(re[j + 2]), "+v"(re[j + 3]), "+v"(im[j]), "+v"(im[j + 1]),
+                              "+v"(im[j + 2]), "+v"(im[j + 3]));
 
         // ---- real-FFT split, one (k, M-k) bin pair per step q (see k_analysis): lane kappa owns k = kappa + 64 q
         // (register brev(q)); Z[M-k] lives in lane (64-kappa)&63, register P-1-i (kappa == 0: own register of bin
@@ -139,11 +145,15 @@ __global__ __launch_bounds__(kAna64Waves * 64) void k_analysis_f64(const float* 
         float* row_m = omag + f * ld;
         float* row_r = oreal + f * ld;
         float* row_i = oimag + f * ld;
+#ifndef MPX_F64_EPI_BATCH
+#define MPX_F64_EPI_BATCH 4
+#endif
+        constexpr int EB = MPX_F64_EPI_BATCH;
 #pragma unroll
-        for (int qb = 0; qb < P / 2; qb += 4) {
-            double zpr[4], zpi[4];   // four partner bins per batch: 16 lane exchanges in flight
+        for (int qb = 0; qb < P / 2; qb += EB) {
+            double zpr[EB], zpi[EB];   // EB partner bins per batch: 4 EB lane exchanges in flight
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < EB; ++u) {
                 const int i = brev(qb + u, LB);
                 unsigned a, b, c, d;
                 split64(re[P - 1 - i], a, b);
@@ -152,7 +162,7 @@ __global__ __launch_bounds__(kAna64Waves * 64) void k_analysis_f64(const float* 
                 zpi[u] = join64((unsigned)__shfl((int)c, src_lane), (unsigned)__shfl((int)d, src_lane));
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < EB; ++u) {
                 const int q = qb + u;
                 const int i = brev(q, LB);
                 const int i0 = brev((P - q) % P, LB);
