@@ -304,7 +304,7 @@ def measure_e2e(utts):
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import corpus_throughput
 
-        out["file_interface"] = corpus_throughput.run(n_utt=int(os.environ.get("BENCH_E2E_UTTS", 64)))
+        out["file_interface"] = corpus_throughput.run(n_utt=int(os.environ.get("BENCH_E2E_UTTS", 128)))
     except Exception as e:
         out["file_interface"] = {"error": "%s: %s" % (type(e).__name__, e)}
     return out

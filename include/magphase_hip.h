@@ -326,6 +326,45 @@ int mpx_epoch_zff(void* stream, const float* sig, const int64_t* off, int32_t n_
 int mpx_pcm16(void* stream, const void* y, int32_t y_is_f64, const int64_t* out_off, int32_t n_utts, int64_t max_len,
               double norm, double* peaks, int16_t* out);
 
+/*
+ * int16 PCM -> float32 samples in [-1, 1) (x / 32768, exact): the conversion la.read_audio_file's caller needs
+ * (libaudio.py:369-377 returns float64 in [-1, 1); the analysis reads float32, magphase.py:2869-2879), done on the
+ * device so that 16-bit wavs cross PCIe as int16.  pcm: DEVICE int16[n], 8-byte aligned; out: DEVICE float32[n],
+ * 16-byte aligned.
+ */
+int mpx_pcm16_to_f32(void* stream, const int16_t* pcm, int64_t n, float* out);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Host-side file helpers of the batch scripts (csrc/magphase_host.cpp; no device work, no stream).  Called from the
+ * reader / writer threads of iobatch.py: the FFI call drops the interpreter lock, so reading, computing and writing overlap.
+ * ------------------------------------------------------------------------------------------------------------------ */
+
+/* sizes[i] = size of paths[i] in bytes, or -errno. */
+int32_t mpx_host_file_sizes(int32_t n, const char* const* paths, int64_t* sizes);
+
+/*
+ * np.loadtxt(est_file, skiprows=skiprows, usecols=[0, 1]) for n files at once (libaudio.py:421-447 read_reaper_est_file's
+ * read): the first two whitespace-separated columns of every non-blank line after `skiprows` lines, as float64 (correctly
+ * rounded decimal -> binary, the values strtod gives).  File i writes its rows to col0 / col1 [row_off[i], row_off[i+1])
+ * (HOST float64); counts[i] = rows, or -errno (-EINVAL: a row with one column, -ENOSPC: more rows than its slice holds;
+ * a file has at most size / 4 + 1 rows).  n_threads <= 1: in the calling thread.
+ */
+int32_t mpx_host_read_est_batch(int32_t n, const char* const* paths, int32_t skiprows, const int64_t* row_off,
+                                double* col0, double* col1, int64_t* counts, int32_t n_threads);
+
+/*
+ * n files written at once: headers[i] (header_bytes[i] bytes; headers may be NULL) followed by bodies[i]
+ * (body_bytes[i] bytes) -- lu.write_binfile (libutils.py:193-199) for the feature files, the RIFF header + samples of
+ * la.write_audio_file (libaudio.py:352-365) for wavs.  status[i] = 0 or errno.
+ */
+int32_t mpx_host_write_files(int32_t n, const char* const* paths, const void* const* headers, const int64_t* header_bytes,
+                             const void* const* bodies, const int64_t* body_bytes, int32_t* status, int32_t n_threads);
+
+/* n files read at once into bufs[i] (at most cap[i] bytes): got[i] = bytes read or -errno (lu.read_binfile's np.fromfile). */
+int32_t mpx_host_read_files(int32_t n, const char* const* paths, void* const* bufs, const int64_t* cap, int64_t* got,
+                            int32_t n_threads);
+
+
 #ifdef __cplusplus
 }
 #endif

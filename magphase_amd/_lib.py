@@ -4,6 +4,7 @@ ctypes binding of libmagphase_hip.so (C ABI: include/magphase_hip.h).
 There is NO CPU fallback: if the library is missing or no ROCm device is visible the product raises.
 """
 import ctypes
+import threading
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -33,6 +34,10 @@ SYMBOLS = (
     "mpx_synth_comp_slots",
     "mpx_synthesis_compressed_ola",
     "mpx_host_const_to_var_scan",
+    "mpx_host_file_sizes",
+    "mpx_host_read_est_batch",
+    "mpx_host_write_files",
+    "mpx_host_read_files",
     "mpx_mel_warp",
     "mpx_min_phase",
     "mpx_noise_gains",
@@ -40,6 +45,7 @@ SYMBOLS = (
     "mpx_epoch_f0_track",
     "mpx_epoch_zff",
     "mpx_pcm16",
+    "mpx_pcm16_to_f32",
     "mpx_hpf_block",
     "mpx_output_hpf",
 )
@@ -51,11 +57,26 @@ class MagphaseHipError(RuntimeError):
     pass
 
 
+_load_lock = threading.Lock()
+
+
 def load():
     """Loads the shared library (once) and declares the prototypes."""
     global _lib
     if _lib is not None:
         return _lib
+    with _load_lock:   # the reader / writer threads of iobatch call the host helpers: one loader at a time
+        return _load_locked()
+
+
+def _load_locked():
+    global _lib
+    if _lib is not None:
+        return _lib
+    # PyTorch first: it brings the process's HIP runtime (its own libamdhip64).  Loading this library before it binds
+    # the kernels to a second copy of the runtime from /opt/rocm, which torch never initialises ("no ROCm-capable
+    # device is detected" at the first launch).
+    import torch  # noqa: F401
     if not os.path.isfile(LIB_PATH):
         raise MagphaseHipError(
             "libmagphase_hip.so not found at %s -- build it with `python -m magphase_amd.build` "
@@ -107,6 +128,14 @@ def load():
     lib.mpx_synthesis_compressed_ola.argtypes = [vp, ctypes.c_int, vp] + [vp] * 19 + [vp, i32, vp, vp, i32, vp, vp, i64]
     lib.mpx_host_const_to_var_scan.restype = i64
     lib.mpx_host_const_to_var_scan.argtypes = [vp, vp, i64, vp, vp]
+    lib.mpx_host_file_sizes.restype = i32
+    lib.mpx_host_file_sizes.argtypes = [i32, vp, vp]
+    lib.mpx_host_read_est_batch.restype = i32
+    lib.mpx_host_read_est_batch.argtypes = [i32, vp, i32, vp, vp, vp, vp, i32]
+    lib.mpx_host_write_files.restype = i32
+    lib.mpx_host_write_files.argtypes = [i32, vp, vp, vp, vp, vp, vp, i32]
+    lib.mpx_host_read_files.restype = i32
+    lib.mpx_host_read_files.argtypes = [i32, vp, vp, vp, vp, i32]
     lib.mpx_mel_warp.restype = ctypes.c_int
     lib.mpx_mel_warp.argtypes = [vp, i64, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, vp, vp, vp, vp, i64]
     lib.mpx_min_phase.restype = ctypes.c_int
@@ -122,6 +151,8 @@ def load():
     lib.mpx_epoch_zff.argtypes = [vp, vp, vp, i32, i64, vp, i32, vp, vp, vp, i32, vp, vp, vp, vp]
     lib.mpx_pcm16.restype = ctypes.c_int
     lib.mpx_pcm16.argtypes = [vp, vp, i32, vp, i32, i64, ctypes.c_double, vp, vp]
+    lib.mpx_pcm16_to_f32.restype = ctypes.c_int
+    lib.mpx_pcm16_to_f32.argtypes = [vp, vp, i64, vp]
     lib.mpx_hpf_block.restype = ctypes.c_int
     lib.mpx_hpf_block.argtypes = []
     lib.mpx_output_hpf.restype = ctypes.c_int

@@ -496,6 +496,19 @@ __global__ __launch_bounds__(256) void k_pcm16(const T* __restrict__ y, const lo
     out[i] = (short)fmin(fmax(r, -32768.0), 32767.0);   // NaN (silent utterance: 0 / 0) -> fmax/fmin pick the bound
 }
 
+// int16 PCM -> float32 in [-1, 1): x * 2^-15, exact (what the host did with np.multiply before uploading float32 --
+// the int16 samples cross PCIe at half the bytes and the host pass is gone).  4 samples per thread.
+__global__ __launch_bounds__(256) void k_pcm16_to_f32(const short* __restrict__ in, long long n, float* __restrict__ out) {
+    const long long i = 4 * ((long long)blockIdx.x * 256 + threadIdx.x);
+    if (i + 3 < n) {
+        const short4 v = *reinterpret_cast<const short4*>(in + i);
+        *reinterpret_cast<float4*>(out + i) = make_float4((float)v.x * (1.0f / 32768.0f), (float)v.y * (1.0f / 32768.0f),
+                                                          (float)v.z * (1.0f / 32768.0f), (float)v.w * (1.0f / 32768.0f));
+    } else {
+        for (long long k = i; k < n; ++k) out[k] = (float)in[k] * (1.0f / 32768.0f);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // minimum-phase spectrum from a magnitude spectrum (complex cepstrum), la.build_min_phase_from_mag_spec
 // (libaudio.py:920-934): ln|X| -> even extension -> real IFFT (cepstrum c) -> causal fold (c[1..N/2-1] *= 2,
@@ -1371,6 +1384,18 @@ int mpx_pcm16(void* stream, const void* y, int32_t y_is_f64, const int64_t* out_
         hipLaunchKernelGGL(k_peak_abs<float>, dim3((unsigned)n_utts), dim3(256), 0, s, (const float*)y, (const long long*)out_off, peaks);
         hipLaunchKernelGGL(k_pcm16<float>, g2, dim3(256), 0, s, (const float*)y, (const long long*)out_off, peaks, norm, (short*)out);
     }
+    MPX_HIP_CHECK(hipGetLastError());
+    return MPX_OK;
+}
+
+int mpx_pcm16_to_f32(void* stream, const int16_t* pcm, int64_t n, float* out) {
+    if (n < 0) return fail(MPX_ERR_ARG, "mpx_pcm16_to_f32: negative size%s");
+    if (n == 0) return MPX_OK;
+    if (!pcm || !out) return fail(MPX_ERR_ARG, "mpx_pcm16_to_f32: null pointer%s");
+    if (((uintptr_t)pcm & 7) || ((uintptr_t)out & 15)) return fail(MPX_ERR_ARG, "mpx_pcm16_to_f32: pcm must be 8-byte, out 16-byte aligned%s");
+    const long long blocks = (n + 1023) / 1024;
+    hipLaunchKernelGGL(k_pcm16_to_f32, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const short*)pcm,
+                       (long long)n, out);
     MPX_HIP_CHECK(hipGetLastError());
     return MPX_OK;
 }

@@ -1,0 +1,253 @@
+// Host-side file helpers of the batch scripts (the file interface either side of the hot path).
+// Plain C++ (no device code): epoch-track parsing and many-file reads / writes with a few threads, called through the C
+// ABI from the reader / writer threads of iobatch.py -- ctypes drops the GIL for the duration of the call, so the
+// stages of the corpus pipeline really overlap (numpy.fromstring / ndarray.tofile hold it).
+//
+// Reference behaviour restated here:
+//   mpx_host_read_est_batch   np.loadtxt(est_file, skiprows=7, usecols=[0, 1])        (libaudio.py:421-447)
+//   mpx_host_write_files      lu.write_binfile / ndarray.tofile, la.write_audio_file's file write
+//                                                                                      (libutils.py:193-199, libaudio.py:352-365)
+//   mpx_host_read_files       lu.read_binfile's np.fromfile                            (libutils.py:201-211)
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <cerrno>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/magphase_hip.h"
+
+namespace {
+
+// Runs fn(i) for i in [0, n) on up to n_threads threads (work stealing through one atomic counter).
+template <typename F>
+void parallel_for(int n, int n_threads, F fn) {
+    if (n <= 0) return;
+    const int nt = n_threads <= 1 ? 1 : (n_threads < n ? n_threads : n);
+    if (nt == 1) {
+        for (int i = 0; i < n; ++i) fn(i);
+        return;
+    }
+    std::atomic<int> next(0);
+    auto worker = [&] {
+        for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) fn(i);
+    };
+    std::vector<std::thread> th;
+    th.reserve(nt - 1);
+    for (int t = 1; t < nt; ++t) th.emplace_back(worker);
+    worker();
+    for (auto& t : th) t.join();
+}
+
+bool read_whole(const char* path, std::string& out, int* err) {
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) {
+        *err = errno;
+        return false;
+    }
+    struct stat st;
+    if (fstat(fd, &st) != 0) {
+        *err = errno;
+        close(fd);
+        return false;
+    }
+    out.resize((size_t)st.st_size);
+    size_t got = 0;
+    while (got < out.size()) {
+        const ssize_t r = read(fd, &out[got], out.size() - got);
+        if (r < 0) {
+            if (errno == EINTR) continue;
+            *err = errno;
+            close(fd);
+            return false;
+        }
+        if (r == 0) break;
+        got += (size_t)r;
+    }
+    out.resize(got);
+    close(fd);
+    return true;
+}
+
+// One decimal number at p (leading blanks skipped) -> value, end pointer; nullptr when there is no number.
+// Plain decimals with <= 15 significant digits and <= 22 fractional digits are mantissa / 10^k with both operands exact
+// in float64, and the IEEE division rounds correctly: the value strtod returns (Clinger's fast path).  Everything else
+// (exponents, long mantissas, inf / nan) goes to strtod itself.
+const double kPow10[23] = {1e0,  1e1,  1e2,  1e3,  1e4,  1e5,  1e6,  1e7,  1e8,  1e9,  1e10, 1e11,
+                           1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+
+const char* parse_double(const char* p, const char* end, double* v) {
+    while (p < end && (*p == ' ' || *p == '\t' || *p == '\r')) ++p;
+    if (p >= end || *p == '\n') return nullptr;
+    const char* s = p;
+    bool neg = false;
+    if (*p == '-' || *p == '+') {
+        neg = (*p == '-');
+        ++p;
+    }
+    uint64_t mant = 0;
+    int digits = 0, frac = 0;
+    bool any = false;
+    while (p < end && *p >= '0' && *p <= '9') {
+        if (digits < 19) {
+            mant = mant * 10 + (uint64_t)(*p - '0');
+            if (mant) ++digits;
+        } else {
+            digits = 99;
+        }
+        any = true;
+        ++p;
+    }
+    if (p < end && *p == '.') {
+        ++p;
+        while (p < end && *p >= '0' && *p <= '9') {
+            if (digits < 19) {
+                mant = mant * 10 + (uint64_t)(*p - '0');
+                if (mant) ++digits;
+                ++frac;
+            } else {
+                digits = 99;
+            }
+            any = true;
+            ++p;
+        }
+    }
+    const bool plain = any && (p >= end || *p == ' ' || *p == '\t' || *p == '\n' || *p == '\r');
+    if (plain && digits <= 15 && frac <= 22) {
+        const double x = (double)mant / kPow10[frac];
+        *v = neg ? -x : x;
+        return p;
+    }
+    char* e = nullptr;
+    const double x = strtod(s, &e);   // the buffer is NUL-terminated by the caller
+    if (e == s) return nullptr;
+    *v = x;
+    return e;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t mpx_host_file_sizes(int32_t n, const char* const* paths, int64_t* sizes) {
+    if (n < 0 || (n > 0 && (!paths || !sizes))) return MPX_ERR_ARG;
+    for (int i = 0; i < n; ++i) {
+        struct stat st;
+        sizes[i] = (stat(paths[i], &st) == 0) ? (int64_t)st.st_size : -(int64_t)errno;
+    }
+    return MPX_OK;
+}
+
+int32_t mpx_host_read_est_batch(int32_t n, const char* const* paths, int32_t skiprows, const int64_t* row_off,
+                                double* col0, double* col1, int64_t* counts, int32_t n_threads) {
+    if (n < 0 || skiprows < 0 || (n > 0 && (!paths || !row_off || !col0 || !col1 || !counts))) return MPX_ERR_ARG;
+    parallel_for(n, n_threads, [&](int i) {
+        std::string txt;
+        int err = 0;
+        if (!read_whole(paths[i], txt, &err)) {
+            counts[i] = -(int64_t)(err ? err : EIO);
+            return;
+        }
+        const char* p = txt.c_str();          // NUL-terminated: strtod cannot run past the end
+        const char* end = p + txt.size();
+        for (int r = 0; r < skiprows && p < end; ++r) {
+            const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p));
+            p = nl ? nl + 1 : end;
+        }
+        const int64_t cap = row_off[i + 1] - row_off[i];
+        double* o0 = col0 + row_off[i];
+        double* o1 = col1 + row_off[i];
+        int64_t rows = 0;
+        while (p < end) {
+            const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p));
+            const char* le = nl ? nl : end;
+            double a, b;
+            const char* q = parse_double(p, le, &a);
+            if (q) {                          // blank lines are skipped, as np.loadtxt does
+                q = parse_double(q, le, &b);
+                if (!q) {
+                    counts[i] = -(int64_t)EINVAL;   // a row with fewer than two columns: np.loadtxt raises
+                    return;
+                }
+                if (rows >= cap) {
+                    counts[i] = -(int64_t)ENOSPC;
+                    return;
+                }
+                o0[rows] = a;
+                o1[rows] = b;
+                ++rows;
+            }
+            p = nl ? nl + 1 : end;
+        }
+        counts[i] = rows;
+    });
+    return MPX_OK;
+}
+
+int32_t mpx_host_write_files(int32_t n, const char* const* paths, const void* const* headers, const int64_t* header_bytes,
+                             const void* const* bodies, const int64_t* body_bytes, int32_t* status, int32_t n_threads) {
+    if (n < 0 || (n > 0 && (!paths || !bodies || !body_bytes || !status))) return MPX_ERR_ARG;
+    parallel_for(n, n_threads, [&](int i) {
+        status[i] = 0;
+        const int fd = open(paths[i], O_WRONLY | O_CREAT | O_TRUNC, 0666);
+        if (fd < 0) {
+            status[i] = errno;
+            return;
+        }
+        auto put = [&](const void* buf, int64_t len) {
+            const char* p = (const char*)buf;
+            while (len > 0) {
+                const ssize_t w = write(fd, p, (size_t)len);
+                if (w < 0) {
+                    if (errno == EINTR) continue;
+                    status[i] = errno;
+                    return false;
+                }
+                p += w;
+                len -= w;
+            }
+            return true;
+        };
+        bool ok = true;
+        if (headers && header_bytes && headers[i] && header_bytes[i] > 0) ok = put(headers[i], header_bytes[i]);
+        if (ok && body_bytes[i] > 0) put(bodies[i], body_bytes[i]);
+        if (close(fd) != 0 && status[i] == 0) status[i] = errno;
+    });
+    return MPX_OK;
+}
+
+int32_t mpx_host_read_files(int32_t n, const char* const* paths, void* const* bufs, const int64_t* cap, int64_t* got,
+                            int32_t n_threads) {
+    if (n < 0 || (n > 0 && (!paths || !bufs || !cap || !got))) return MPX_ERR_ARG;
+    parallel_for(n, n_threads, [&](int i) {
+        const int fd = open(paths[i], O_RDONLY);
+        if (fd < 0) {
+            got[i] = -(int64_t)errno;
+            return;
+        }
+        int64_t total = 0;
+        char* p = (char*)bufs[i];
+        while (total < cap[i]) {
+            const ssize_t r = read(fd, p + total, (size_t)(cap[i] - total));
+            if (r < 0) {
+                if (errno == EINTR) continue;
+                total = -(int64_t)errno;
+                break;
+            }
+            if (r == 0) break;
+            total += r;
+        }
+        close(fd);
+        got[i] = total;
+    });
+    return MPX_OK;
+}
+
+}  // extern "C"

@@ -93,15 +93,20 @@ def write_audio_file(filepath, v_signal, fs, norm=0.98):
     write_pcm16_file(filepath, pcm.astype("<i2"), fs)
 
 
-def write_pcm16_file(filepath, pcm, fs):
-    """int16 samples -> mono 16-bit RIFF wav (44-byte header + the samples)."""
+def wav_header_pcm16(n_samples, fs):
+    """The 44-byte RIFF header of a mono 16-bit wav with n_samples samples."""
     import struct
 
+    n = int(n_samples) * 2
+    return struct.pack("<4sI4s4sIHHIIHH4sI", b"RIFF", 36 + n, b"WAVE", b"fmt ", 16, 1, 1, int(fs), int(fs) * 2, 2, 16,
+                       b"data", n)
+
+
+def write_pcm16_file(filepath, pcm, fs):
+    """int16 samples -> mono 16-bit RIFF wav (44-byte header + the samples)."""
     pcm = np.ascontiguousarray(pcm, dtype="<i2")
-    n = pcm.size * 2
     with open(filepath, "wb") as fh:
-        fh.write(struct.pack("<4sI4s4sIHHIIHH4sI", b"RIFF", 36 + n, b"WAVE", b"fmt ", 16, 1, 1, int(fs), int(fs) * 2, 2, 16,
-                             b"data", n))
+        fh.write(wav_header_pcm16(pcm.size, fs))
         fh.write(memoryview(pcm))
 
 
@@ -118,6 +123,107 @@ def read_est_fast(est_file, skiprows=7):
     vals = np.fromstring(body, dtype=np.float64, sep=" ")   # C strtod: correctly rounded, the values np.loadtxt gives
     m = vals.reshape(-1, max(len(first), 1))
     return m[:, 0], m[:, 1]
+
+
+# ----------------------------------------------------------------------------------------------------
+# many files at once through the library's host helpers (csrc/magphase_host.cpp): a few native threads, no GIL held
+# ----------------------------------------------------------------------------------------------------
+def _io_threads():
+    return max(1, int(os.environ.get("MAGPHASE_IO_NATIVE_THREADS", "8")))
+
+
+def _c_paths(paths):
+    import ctypes
+
+    return (ctypes.c_char_p * len(paths))(*[os.fsencode(p) for p in paths])
+
+
+def read_est_batch(est_files, skiprows=7):
+    """read_est_fast for a list of files in one native call: [(v_time, v_voi) | Exception] in input order."""
+    import ctypes
+
+    from . import _lib
+
+    lib, n = _lib.load(), len(est_files)
+    if n == 0:
+        return []
+    cp = _c_paths(est_files)
+    sizes = np.empty(n, dtype=np.int64)
+    lib.mpx_host_file_sizes(n, cp, sizes.ctypes.data)
+    rows = np.where(sizes > 0, sizes // 4 + 1, 1)          # a row is at least "0 0\n"
+    off = np.concatenate(([0], np.cumsum(rows))).astype(np.int64)
+    c0, c1 = np.empty(int(off[-1])), np.empty(int(off[-1]))
+    counts = np.empty(n, dtype=np.int64)
+    rc = lib.mpx_host_read_est_batch(n, cp, int(skiprows), off.ctypes.data, c0.ctypes.data, c1.ctypes.data,
+                                     counts.ctypes.data, _io_threads())
+    if rc != 0:
+        raise RuntimeError("mpx_host_read_est_batch: error %d" % rc)
+    out = []
+    for i, f in enumerate(est_files):
+        k = int(counts[i])
+        if k < 0:
+            out.append(OSError(-k, os.strerror(-k), f) if -k != 22 else ValueError("%s: malformed epoch file" % f))
+        else:
+            a = int(off[i])
+            out.append((c0[a:a + k].copy(), c1[a:a + k].copy()))
+    return out
+
+
+def write_files_batch(paths, bodies, headers=None):
+    """bodies[i] (C-contiguous numpy array or bytes) -> paths[i], optionally preceded by headers[i] (bytes), all in one
+    native call.  Returns [None | OSError] in input order."""
+    import ctypes
+
+    from . import _lib
+
+    lib, n = _lib.load(), len(paths)
+    if n == 0:
+        return []
+    keep = [np.ascontiguousarray(b) if isinstance(b, np.ndarray) else np.frombuffer(b, dtype=np.uint8) for b in bodies]
+    bp = (ctypes.c_void_p * n)(*[k.ctypes.data if k.size else None for k in keep])
+    bn = np.array([k.nbytes for k in keep], dtype=np.int64)
+    if headers is not None:
+        hk = [np.frombuffer(h, dtype=np.uint8) for h in headers]
+        hp = (ctypes.c_void_p * n)(*[k.ctypes.data for k in hk])
+        hn = np.array([k.nbytes for k in hk], dtype=np.int64)
+        hp_arg, hn_arg = hp, hn.ctypes.data
+    else:
+        hp_arg, hn_arg = None, None
+    status = np.zeros(n, dtype=np.int32)
+    rc = lib.mpx_host_write_files(n, _c_paths(paths), hp_arg, hn_arg, bp, bn.ctypes.data, status.ctypes.data, _io_threads())
+    if rc != 0:
+        raise RuntimeError("mpx_host_write_files: error %d" % rc)
+    return [None if s == 0 else OSError(int(s), os.strerror(int(s)), p) for s, p in zip(status, paths)]
+
+
+def read_files_batch(paths, dtype=np.float32):
+    """np.fromfile(path, dtype) for a list of files in one native call: [array | OSError] in input order."""
+    import ctypes
+
+    from . import _lib
+
+    lib, n = _lib.load(), len(paths)
+    if n == 0:
+        return []
+    cp = _c_paths(paths)
+    sizes = np.empty(n, dtype=np.int64)
+    lib.mpx_host_file_sizes(n, cp, sizes.ctypes.data)
+    item = np.dtype(dtype).itemsize
+    bufs = [np.empty(max(int(s), 0) // item, dtype=dtype) for s in sizes]
+    bp = (ctypes.c_void_p * n)(*[b.ctypes.data if b.size else None for b in bufs])
+    cap = np.array([b.nbytes for b in bufs], dtype=np.int64)
+    got = np.empty(n, dtype=np.int64)
+    rc = lib.mpx_host_read_files(n, cp, bp, cap.ctypes.data, got.ctypes.data, _io_threads())
+    if rc != 0:
+        raise RuntimeError("mpx_host_read_files: error %d" % rc)
+    out = []
+    for i, p in enumerate(paths):
+        if sizes[i] < 0 or got[i] < 0:
+            e = int(-sizes[i]) if sizes[i] < 0 else int(-got[i])
+            out.append(OSError(e, os.strerror(e), p))
+        else:
+            out.append(bufs[i][:int(got[i]) // item])
+    return out
 
 
 def read_reaper_est_file(est_file, check_len_smpls=-1, fs=-1, skiprows=7, usecols=[0, 1]):

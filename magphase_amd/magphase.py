@@ -79,6 +79,26 @@ def _epochs_for(wav_file):
     return m[:, 0], m[:, 1]
 
 
+def _epochs_for_batch(wav_files):
+    """_epochs_for over a list: [(v_pm_sec, v_voi) | Exception].  Without an epoch provider the .est files next to the
+    wavs are parsed in one native call (la.read_est_batch); a wav without one takes _epochs_for's remaining routes."""
+    if _epoch_provider is None:
+        res = la.read_est_batch([os.path.splitext(f)[0] + ".est" for f in wav_files])
+    else:
+        res = [FileNotFoundError()] * len(wav_files)
+    out = []
+    for f, r in zip(wav_files, res):
+        if isinstance(r, FileNotFoundError):
+            try:
+                r = _epochs_for(f)
+            except (KeyboardInterrupt, SystemExit):
+                raise
+            except Exception as e:
+                r = e
+        out.append(r)
+    return out
+
+
 # constants (magphase.py:3279-3317)
 define_alpha = hm.define_alpha
 define_fft_len = hm.define_fft_len
