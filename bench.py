@@ -228,10 +228,10 @@ def measure_lowdim(eng, utts, steps, warmup):
         "k_analysis_f64": ("hbm", 12.0 * H * Fv + 4.0 * n_in),
         "k_mel_warp_mfma": ("mfma", 2.0 * H * dims * Fc),
         "k_post_filter": ("hbm", 8.0 * aplan.mag_dim * Fc),
-        "k_mel_unwarp_mfma": ("mfma", 2.0 * H * dims * splan.n_rows),
+        "k_mel_unwarp_mfma": ("mfma", 2.0 * H * (dims + aplan.mag_dim) * Fs),   # variable-rate rows; the magnitude product twice
         "k_noise_stats": ("hbm", 4.0 * n_noise + 4.0 * Fs),
         "k_noise_gains": ("hbm", 12.0 * Fs),
-        "k_synth_comp_pair": ("hbm", 24.0 * H * Fs + 4.0 * n_noise + 4.0 * n_out),   # two unwarped rows per frame (lerp)
+        "k_synth_comp_pair": ("hbm", 12.0 * H * Fs + 4.0 * n_noise + 4.0 * n_out),   # one unwarped row per frame
         "k_ola_fixup": ("hbm", 12.0 * splan.n_runs * N),
     }
     kern = []

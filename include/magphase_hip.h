@@ -161,6 +161,19 @@ int mpx_mel_unwarp(void* stream, int64_t n_frames, int32_t n_bins, const float* 
                    int64_t ld /* row pitch of the three outputs in floats, >= n_bins; see mpx_spec_ld */);
 
 /*
+ * mpx_mel_unwarp with the constant -> variable frame-rate interpolation of synthesis_from_compressed folded in
+ * (magphase.py:861-868, interp_from_const_to_variable_rate :2242-2252): output row f (n_frames = VARIABLE-rate frames) is
+ * the linear interpolation, weight row_t[f], between the unwarped rows row0[f] and row1[f] of the constant-rate
+ * coefficient matrices -- out_mag = lerp(exp(U a[row0]), exp(U a[row1])), out_real / out_imag = U lerp(a[row0], a[row1])
+ * (the phase unwarp is linear).  The [rows x n_bins] spectra are written once, at the variable rate, and the synthesis
+ * kernel reads one row per frame.  row0, row1: DEVICE int32[n_frames]; row_t: DEVICE float32[n_frames].
+ */
+int mpx_mel_unwarp_rows(void* stream, int64_t n_frames, int32_t n_bins, const float* a_mag, int32_t k_mag,
+                        const float* u_mag, float* out_mag, const float* a_real, const float* a_imag, int32_t k_phase,
+                        const float* u_phase, float* out_real, float* out_imag, int64_t ld, const int32_t* row0,
+                        const int32_t* row1, const float* row_t);
+
+/*
  * Row pitch the unwarped spectra (outputs of mpx_mel_unwarp / mpx_min_phase, inputs of mpx_synthesis_compressed_ola)
  * should be allocated with: n_bins rounded up to a multiple of 32 floats.  mpx_mel_unwarp runs on the matrix cores
  * (v_mfma_f32_32x32x2_f32) and a wave stores 32-float row segments; with 128-byte aligned rows every segment is one
@@ -198,7 +211,9 @@ int mpx_noise_stats(void* stream, int fft_len, const void* tables, const float* 
  *   noise_pos(int64)/noise_left/noise_right/noise_wtype : this frame's noise frame (recomputed here)
  *   voiced, inv_gain                                    : class flag and 1/gain of its class
  *   row0,row1,row_t : the frame's mag/real/imag row = (1-row_t)*row[row0] + row_t*row[row1] of the [rows x H] matrices
- *                     (constant -> variable frame rate, magphase.py:2242-2252; row0 == row1 for variable-rate input)
+ *                     (constant -> variable frame rate, magphase.py:2242-2252; row0 == row1 for variable-rate input);
+ *                     all three NULL: one row per frame, row index = frame index (variable-rate input, or rows already
+ *                     interpolated by mpx_mel_unwarp_rows -- half the feature loads)
  *   win_left, win_right : anti-ringing window half lengths (Q14);  pm_rel : as mpx_ola_gather
  * per_v, ap_v, ap_u : float32[H] per-bin constants (hostmath.synthesis_bin_curves: tilt x sqrt(mask) etc., Q12/Q13)
  */

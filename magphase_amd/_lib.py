@@ -28,6 +28,7 @@ SYMBOLS = (
     "mpx_synthesis_lossless_ola",
     "mpx_ola_fixup",
     "mpx_mel_unwarp",
+    "mpx_mel_unwarp_rows",
     "mpx_spec_ld",
     "mpx_noise_uniform",
     "mpx_noise_stats",
@@ -116,6 +117,8 @@ def _load_locked():
     lib.mpx_ola_fixup.argtypes = [vp, ctypes.c_int, vp, i32, vp, vp]
     lib.mpx_mel_unwarp.restype = ctypes.c_int
     lib.mpx_mel_unwarp.argtypes = [vp, i64, i32, vp, i32, vp, vp, vp, vp, i32, vp, vp, vp, i64]
+    lib.mpx_mel_unwarp_rows.restype = ctypes.c_int
+    lib.mpx_mel_unwarp_rows.argtypes = [vp, i64, i32, vp, i32, vp, vp, vp, vp, i32, vp, vp, vp, i64, vp, vp, vp]
     lib.mpx_spec_ld.restype = i64
     lib.mpx_spec_ld.argtypes = [i32]
     lib.mpx_noise_uniform.restype = ctypes.c_int

@@ -671,7 +671,9 @@ constexpr size_t lds_bytes_comp_pair() {
     return sizeof(float) * (size_t)(tw_floats<P>() + kCompPairWaves * (P * kXStride) + kCompPairs * ring_len<P>() + 16);
 }
 
-template <int P>
+// LERP: every frame interpolates between two spectrum rows (row0 / row1 / rowt tables); false: one row per frame, row
+// index = frame index (variable-rate input, or rows already interpolated by mpx_mel_unwarp_rows) -- half the feature loads.
+template <int P, bool LERP>
 __global__ __launch_bounds__(kCompPairWaves * 64) void k_synth_comp_pair(const float* __restrict__ mag,
                                                                         const float* __restrict__ real,
                                                                         const float* __restrict__ imag,
@@ -779,8 +781,8 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_synth_comp_pair(const f
         // issued together and branch-free (one memory latency per batch)
         const int voiced = tb.voiced[fi];
         const float ig = tb.inv_gain[fi];
-        const int r0 = tb.row0[fi], r1 = tb.row1[fi];
-        const float rt = tb.rowt[fi];               // 0 when r0 == r1: the lerp below is then exact
+        const int r0 = LERP ? tb.row0[fi] : fi, r1 = LERP ? tb.row1[fi] : fi;
+        const float rt = LERP ? tb.rowt[fi] : 0.0f;   // 0 when r0 == r1: the lerp below is then exact
         const float* apc = voiced ? ap_v : ap_u;    // aperiodic curve of the frame's class (uniform select)
         const float pvs = voiced ? 1.0f : 0.0f;     // periodic component only in voiced frames
         const float sgn_scale = ((lane & 1) ? -1.0f : 1.0f) * (0.5f / (float)M);
@@ -818,9 +820,11 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_synth_comp_pair(const f
                 m0[jj] = m0p[lo + k];
                 a0[jj] = a0p[lo + k];
                 b0[jj] = b0p[lo + k];
-                m1[jj] = m1p[lo + k];
-                a1[jj] = a1p[lo + k];
-                b1[jj] = b1p[lo + k];
+                if (LERP) {
+                    m1[jj] = m1p[lo + k];
+                    a1[jj] = a1p[lo + k];
+                    b1[jj] = b1p[lo + k];
+                }
                 cpv[jj] = per_v[lo + k];
                 cap[jj] = apc[lo + k];
             }
@@ -828,9 +832,9 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_synth_comp_pair(const f
             for (int jj = 0; jj < HB; ++jj) {
                 const int j = h * HB + jj;
                 // linear interpolation between constant-rate rows (magphase.py:2242-2252); rt == 0 for variable-rate input
-                const float m = fmaf(m1[jj] - m0[jj], rt, m0[jj]);
-                const float a = fmaf(a1[jj] - a0[jj], rt, a0[jj]);
-                const float b = fmaf(b1[jj] - b0[jj], rt, b0[jj]);
+                const float m = LERP ? fmaf(m1[jj] - m0[jj], rt, m0[jj]) : m0[jj];
+                const float a = LERP ? fmaf(a1[jj] - a0[jj], rt, a0[jj]) : a0[jj];
+                const float b = LERP ? fmaf(b1[jj] - b0[jj], rt, b0[jj]) : b0[jj];
                 const float s = a * a + b * b;
                 const float u = (s > 0.0f) ? m * cpv[jj] * pvs * __builtin_amdgcn_rsqf(s) : 0.0f;
                 const float apf = m * cap[jj] * ig;
@@ -844,9 +848,9 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_synth_comp_pair(const f
             }
         }
         if (lane == 0) {   // Nyquist bin: the noise spectrum is real there; X = |X|
-            const float m = fmaf(m1p[M] - m0p[M], rt, m0p[M]);
-            const float a = fmaf(a1p[M] - a0p[M], rt, a0p[M]);
-            const float b = fmaf(b1p[M] - b0p[M], rt, b0p[M]);
+            const float m = LERP ? fmaf(m1p[M] - m0p[M], rt, m0p[M]) : m0p[M];
+            const float a = LERP ? fmaf(a1p[M] - a0p[M], rt, a0p[M]) : a0p[M];
+            const float b = LERP ? fmaf(b1p[M] - b0p[M], rt, b0p[M]) : b0p[M];
             const float s = a * a + b * b;
             const float u = (s > 0.0f) ? m * per_v[M] * pvs * __builtin_amdgcn_rsqf(s) : 0.0f;
             const float apf = m * apc[M] * ig;
@@ -1039,9 +1043,18 @@ __global__ __launch_bounds__(256) void k_mel_warp_mfma(WarpJobs jobs, long long 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int kUnwarpColTiles = 16;   // 512 bins per task
 
-template <int KH>
+// MODE 0: one output row per row of A.  MODE 1 / 2 (constant -> variable frame rate, magphase.py:2242-2252 folded in):
+// output row f is the interpolation between rows row0[f] and row1[f] of the unwarped A with weight rowt[f] --
+//   MODE 1 (linear maps, op 0): the coefficient rows are interpolated, out = U . lerp(A[r0], A[r1]) (the unwarp is
+//          linear: equal to lerp(U A[r0], U A[r1]) up to rounding);
+//   MODE 2 (op 1, exp): both products are formed (the A fragments of r0 and r1 share every B fragment) and the
+//          interpolation runs on the exponentials, lerp(exp(U A[r0]), exp(U A[r1])), as the reference does on m_mag.
+// The synthesis kernel then reads ONE row per frame instead of two, and the spectra are written at the variable rate only.
+template <int KH, int MODE>
 __global__ __launch_bounds__(256) void k_mel_unwarp_mfma(UnwarpJobs jobs, int job0, long long F, int H,
-                                                         int col_parts, long long n_tasks, int ld) {
+                                                         int col_parts, long long n_tasks, int ld,
+                                                         const int* __restrict__ row0, const int* __restrict__ row1,
+                                                         const float* __restrict__ rowt) {
     const UnwarpJob job = jobs.j[job0 + blockIdx.y];
     const int lane = threadIdx.x & 63;
     const long long task = (long long)blockIdx.x * 4 + rfl((int)(threadIdx.x >> 6));   // wave-uniform, and known to be
@@ -1056,14 +1069,28 @@ __global__ __launch_bounds__(256) void k_mel_unwarp_mfma(UnwarpJobs jobs, int jo
     const int kk = lane >> 5, li = lane & 31;
 
     float a[KH];
+    float a1[MODE == 2 ? KH : 1];   // MODE 2: fragment of the second row
+    float tr[MODE == 2 ? 16 : 1];   // MODE 2: interpolation weight of the output row of accumulator register r
     {
         const long long f = min(f0 + li, F - 1);   // rows past F are computed on a copy of the last row, never stored
-        const float* arow = job.A + f * K;
+        const float* arow = job.A + (MODE == 0 ? f : (long long)row0[f]) * K;
+        const float* arow1 = (MODE == 0) ? arow : job.A + (long long)row1[f] * K;
+        const float wt = (MODE == 0) ? 0.0f : rowt[f];
 #pragma unroll
         for (int t = 0; t < KH; ++t) {
             const int k = 2 * t + kk;
             a[t] = arow[min(k, K - 1)];
             a[t] = (k < K) ? a[t] : 0.0f;
+            if (MODE != 0) {
+                float x1 = arow1[min(k, K - 1)];
+                x1 = (k < K) ? x1 : 0.0f;
+                if (MODE == 1) a[t] = fmaf(x1 - a[t], wt, a[t]);
+                else a1[t] = x1;
+            }
+        }
+        if (MODE == 2) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) tr[r] = rowt[min(f0 + (r & 3) + 8 * (r >> 2) + 4 * kk, F - 1)];
         }
     }
     const int jbeg = cp * (kUnwarpColTiles * 32);
@@ -1097,13 +1124,17 @@ __global__ __launch_bounds__(256) void k_mel_unwarp_mfma(UnwarpJobs jobs, int jo
     const bool full_rows = nrows == 32;
     for (int j0 = jbeg; j0 < jend; j0 += 64) {
         const int vn0 = 4 * (kk * H + j0 + 64 + li), vn0e = 4 * (j0 + 64 + li);
-        f32x16 acc0, acc1;
+        f32x16 acc0, acc1, acc2, acc3;   // acc2 / acc3: the second row's products (MODE 2)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.0f;
+        for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = acc2[r] = acc3[r] = 0.0f;
 #pragma unroll
         for (int t = 0; t < KH; ++t) {
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b0[t], acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b1[t], acc1, 0, 0, 0);
+            if (MODE == 2) {
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[t], b0[t], acc2, 0, 0, 0);
+                acc3 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[t], b1[t], acc3, 0, 0, 0);
+            }
             const int v = (2 * t + 1 == K) ? vn0e : vn0;
             b0[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(urs, v, soff(t), 0));
             b1[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(urs, v + 128, soff(t), 0));
@@ -1120,27 +1151,48 @@ __global__ __launch_bounds__(256) void k_mel_unwarp_mfma(UnwarpJobs jobs, int jo
             const int row = (r & 3) + 8 * (r >> 2);
             const int so = row * (4 * HO);
             const bool ok = full_rows || (row + 4 * kk < nrows);
-            const float v0 = op_exp ? __expf(acc0[r]) : acc0[r];
-            const float v1 = op_exp ? __expf(acc1[r]) : acc1[r];
+            float v0 = op_exp ? __expf(acc0[r]) : acc0[r];
+            float v1 = op_exp ? __expf(acc1[r]) : acc1[r];
+            if (MODE == 2) {   // fmaf(m1 - m0, t, m0): the form the synthesis kernel used on the two rows
+                const float w0 = op_exp ? __expf(acc2[r]) : acc2[r];
+                const float w1 = op_exp ? __expf(acc3[r]) : acc3[r];
+                v0 = fmaf(w0 - v0, tr[r], v0);
+                v1 = fmaf(w1 - v1, tr[r], v1);
+            }
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v0), ors, ok ? vo0 : 0x7ffffff0, so, 0);
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v1), ors, ok ? vo1 : 0x7ffffff0, so, 0);
         }
     }
 }
 
+struct UnwarpRows {   // constant -> variable rate interpolation tables (all null: one output row per input row)
+    const int* row0;
+    const int* row1;
+    const float* rowt;
+};
+
 template <int KH>
-static int launch_unwarp_mfma(hipStream_t s, const UnwarpJobs& jobs, int job0, int njobs, long long F, int H, int ld) {
+static int launch_unwarp_mfma(hipStream_t s, const UnwarpJobs& jobs, int job0, int njobs, long long F, int H, int ld,
+                              const UnwarpRows& rw) {
     const int col_parts = (H + kUnwarpColTiles * 32 - 1) / (kUnwarpColTiles * 32);
     const long long n_tasks = ((F + 31) / 32) * col_parts;
     const dim3 grid((unsigned)((n_tasks + 3) / 4), (unsigned)njobs);
-    hipLaunchKernelGGL(k_mel_unwarp_mfma<KH>, grid, dim3(256), 0, s, jobs, job0, F, H, col_parts, n_tasks, ld);
+    if (!rw.row0)
+        hipLaunchKernelGGL((k_mel_unwarp_mfma<KH, 0>), grid, dim3(256), 0, s, jobs, job0, F, H, col_parts, n_tasks, ld,
+                           rw.row0, rw.row1, rw.rowt);
+    else if (jobs.j[job0].op == 0)
+        hipLaunchKernelGGL((k_mel_unwarp_mfma<KH, 1>), grid, dim3(256), 0, s, jobs, job0, F, H, col_parts, n_tasks, ld,
+                           rw.row0, rw.row1, rw.rowt);
+    else
+        hipLaunchKernelGGL((k_mel_unwarp_mfma<KH, 2>), grid, dim3(256), 0, s, jobs, job0, F, H, col_parts, n_tasks, ld,
+                           rw.row0, rw.row1, rw.rowt);
     return MPX_OK;
 }
 
 static int dispatch_unwarp_mfma(hipStream_t s, const UnwarpJobs& jobs, int job0, int njobs, int K, long long F, int H,
-                                int ld) {
+                                int ld, const UnwarpRows& rw) {
     switch ((K + 3) / 4) {   // KH = K/2 rounded up to even: 16 instantiations cover K <= 64
-#define MPX_UNWARP_CASE(q) case q: return launch_unwarp_mfma<2 * q>(s, jobs, job0, njobs, F, H, ld);
+#define MPX_UNWARP_CASE(q) case q: return launch_unwarp_mfma<2 * q>(s, jobs, job0, njobs, F, H, ld, rw);
         MPX_UNWARP_CASE(1) MPX_UNWARP_CASE(2) MPX_UNWARP_CASE(3) MPX_UNWARP_CASE(4) MPX_UNWARP_CASE(5) MPX_UNWARP_CASE(6)
         MPX_UNWARP_CASE(7) MPX_UNWARP_CASE(8) MPX_UNWARP_CASE(9) MPX_UNWARP_CASE(10) MPX_UNWARP_CASE(11) MPX_UNWARP_CASE(12)
         MPX_UNWARP_CASE(13) MPX_UNWARP_CASE(14) MPX_UNWARP_CASE(15) MPX_UNWARP_CASE(16)
@@ -1157,9 +1209,9 @@ extern "C" {
 
 int64_t mpx_spec_ld(int32_t n_bins) { return n_bins <= 0 ? 0 : ((int64_t)n_bins + 31) / 32 * 32; }
 
-int mpx_mel_unwarp(void* stream, int64_t n_frames, int32_t n_bins, const float* a_mag, int32_t k_mag,
-                   const float* u_mag, float* out_mag, const float* a_real, const float* a_imag, int32_t k_phase,
-                   const float* u_phase, float* out_real, float* out_imag, int64_t ld) {
+static int mel_unwarp_impl(void* stream, int64_t n_frames, int32_t n_bins, const float* a_mag, int32_t k_mag,
+                           const float* u_mag, float* out_mag, const float* a_real, const float* a_imag, int32_t k_phase,
+                           const float* u_phase, float* out_real, float* out_imag, int64_t ld, const UnwarpRows& rw) {
     if (n_frames < 0 || n_bins <= 0 || ld < n_bins || ld > (1 << 20)) return fail(MPX_ERR_ARG, "mpx_mel_unwarp: bad size%s");
     if (k_mag <= 0 || k_mag > kGemmKMax || k_phase <= 0 || k_phase > kGemmKMax)
         return fail(MPX_ERR_ARG, "mpx_mel_unwarp: coefficient count must be in 1..64%s");
@@ -1171,16 +1223,33 @@ int mpx_mel_unwarp(void* stream, int64_t n_frames, int32_t n_bins, const float* 
     jobs.j[1] = {a_real, u_phase, out_real, (int)k_phase, 0};
     jobs.j[2] = {a_imag, u_phase, out_imag, (int)k_phase, 0};
 #ifdef MPX_UNWARP_VALU
+    if (rw.row0) return fail(MPX_ERR_ARG, "mpx_mel_unwarp_rows: not available in the VALU build%s");
     const dim3 grid((unsigned)((n_bins + 255) / 256), (unsigned)((n_frames + kGemmFrames - 1) / kGemmFrames), 3);
     if (grid.y > 65535) return fail(MPX_ERR_ARG, "mpx_mel_unwarp: too many frames per call (max 4194240)%s");
     hipLaunchKernelGGL(k_mel_unwarp, grid, dim3(256), 0, (hipStream_t)stream, jobs, (long long)n_frames, (int)n_bins,
                        (long long)ld);
 #else
-    if (int rc = dispatch_unwarp_mfma((hipStream_t)stream, jobs, 0, 1, (int)k_mag, (long long)n_frames, (int)n_bins, (int)ld)) return rc;
-    if (int rc = dispatch_unwarp_mfma((hipStream_t)stream, jobs, 1, 2, (int)k_phase, (long long)n_frames, (int)n_bins, (int)ld)) return rc;
+    if (int rc = dispatch_unwarp_mfma((hipStream_t)stream, jobs, 0, 1, (int)k_mag, (long long)n_frames, (int)n_bins, (int)ld, rw)) return rc;
+    if (int rc = dispatch_unwarp_mfma((hipStream_t)stream, jobs, 1, 2, (int)k_phase, (long long)n_frames, (int)n_bins, (int)ld, rw)) return rc;
 #endif
     MPX_HIP_CHECK(hipGetLastError());
     return MPX_OK;
+}
+
+int mpx_mel_unwarp(void* stream, int64_t n_frames, int32_t n_bins, const float* a_mag, int32_t k_mag,
+                   const float* u_mag, float* out_mag, const float* a_real, const float* a_imag, int32_t k_phase,
+                   const float* u_phase, float* out_real, float* out_imag, int64_t ld) {
+    return mel_unwarp_impl(stream, n_frames, n_bins, a_mag, k_mag, u_mag, out_mag, a_real, a_imag, k_phase, u_phase,
+                           out_real, out_imag, ld, UnwarpRows{nullptr, nullptr, nullptr});
+}
+
+int mpx_mel_unwarp_rows(void* stream, int64_t n_frames, int32_t n_bins, const float* a_mag, int32_t k_mag,
+                        const float* u_mag, float* out_mag, const float* a_real, const float* a_imag, int32_t k_phase,
+                        const float* u_phase, float* out_real, float* out_imag, int64_t ld, const int32_t* row0,
+                        const int32_t* row1, const float* row_t) {
+    if (!row0 || !row1 || !row_t) return fail(MPX_ERR_ARG, "mpx_mel_unwarp_rows: null row table%s");
+    return mel_unwarp_impl(stream, n_frames, n_bins, a_mag, k_mag, u_mag, out_mag, a_real, a_imag, k_phase, u_phase,
+                           out_real, out_imag, ld, UnwarpRows{row0, row1, row_t});
 }
 
 int mpx_noise_stats(void* stream, int fft_len, const void* tables, const float* noise, const int64_t* frame_pos,
@@ -1227,23 +1296,32 @@ int mpx_synthesis_compressed_ola(void* stream, int fft_len, const void* tables, 
     if (n_runs < 0 || n_slots < 0) return fail(MPX_ERR_ARG, "mpx_synthesis_compressed_ola: negative count%s");
     if (n_runs == 0 || n_slots == 0) return MPX_OK;
     if (!tables || !mag || !real || !imag || !noise || !noise_pos || !noise_left || !noise_right || !noise_wtype ||
-        !voiced || !inv_gain || !row0 || !row1 || !row_t || !win_left || !win_right || !pm_rel || !per_v || !ap_v ||
+        !voiced || !inv_gain || !win_left || !win_right || !pm_rel || !per_v || !ap_v ||
         !ap_u || !runs || !slot_off || !slot_runs || !strips || !pcm_out)
         return fail(MPX_ERR_ARG, "mpx_synthesis_compressed_ola: null pointer%s");
+    const bool lerp = row0 || row1 || row_t;   // all three null: one spectrum row per frame, row index = frame index
+    if (lerp && (!row0 || !row1 || !row_t))
+        return fail(MPX_ERR_ARG, "mpx_synthesis_compressed_ola: row0 / row1 / row_t must be given together%s");
     CompFrameTabs tb{(const long long*)noise_pos, noise_left, noise_right, noise_wtype, voiced, inv_gain,
                      row0, row1, row_t, win_left, win_right, pm_rel};
     hipStream_t s = (hipStream_t)stream;
     const dim3 pgrid((n_slots + kCompPairs - 1) / kCompPairs), pblock(kCompPairWaves * 64);
-#define MPX_LAUNCH_COMP(PP)                                                                                          \
+#define MPX_LAUNCH_COMP(PP, LL)                                                                                        \
     do {                                                                                                             \
-        if (int rc = set_lds(k_synth_comp_pair<PP>, lds_bytes_comp_pair<PP>())) return rc;                           \
-        hipLaunchKernelGGL(k_synth_comp_pair<PP>, pgrid, pblock, lds_bytes_comp_pair<PP>(), s, mag, real, imag,      \
+        if (int rc = set_lds(k_synth_comp_pair<PP, LL>, lds_bytes_comp_pair<PP>())) return rc;                       \
+        hipLaunchKernelGGL((k_synth_comp_pair<PP, LL>), pgrid, pblock, lds_bytes_comp_pair<PP>(), s, mag, real, imag, \
                            noise, tb, per_v, ap_v, ap_u, (const RunDesc*)runs, slot_off, slot_runs, (int)n_slots,    \
                            (const float*)tables, strips, pcm_out, (long long)ld);                                    \
     } while (0)
-    if (P == 32) MPX_LAUNCH_COMP(32);
-    else if (P == 16) MPX_LAUNCH_COMP(16);
-    else MPX_LAUNCH_COMP(8);
+    if (lerp) {
+        if (P == 32) MPX_LAUNCH_COMP(32, true);
+        else if (P == 16) MPX_LAUNCH_COMP(16, true);
+        else MPX_LAUNCH_COMP(8, true);
+    } else {
+        if (P == 32) MPX_LAUNCH_COMP(32, false);
+        else if (P == 16) MPX_LAUNCH_COMP(16, false);
+        else MPX_LAUNCH_COMP(8, false);
+    }
 #undef MPX_LAUNCH_COMP
     MPX_HIP_CHECK(hipGetLastError());
     return MPX_OK;

@@ -596,6 +596,7 @@ class CompressedSynthesisPlan:
         from scipy import interpolate
 
         self.apply_post_filter = bool(post_filter)
+        self.b_const_rate = bool(b_const_rate)
         if noise_mode not in ("reference", "device"):
             raise ValueError("noise_mode must be 'reference' (numpy global RNG, magphase.py:883) or 'device' (Philox on the GPU)")
         self.noise_mode = noise_mode
@@ -783,7 +784,8 @@ class CompressedSynthesisPlan:
             ld = int(e.lib.mpx_spec_ld(H))
             b = self._buf = dict(
                 ld=ld,
-                spec=tuple(e.empty((self.n_rows, ld))[:, :H] for _ in range(3)),
+                # unwarped spectra at the VARIABLE rate: one row per synthesis frame (mpx_mel_unwarp_rows interpolates)
+                spec=tuple(e.empty((self.total_frames, ld))[:, :H] for _ in range(3)),
                 sums=e.empty((self.total_frames,)),
                 inv_gain=e.empty((self.total_frames,)),
                 gains=torch.empty((self.n_utts, 2), dtype=torch.float64, device=e.device),
@@ -816,10 +818,17 @@ class CompressedSynthesisPlan:
             if self.apply_post_filter:   # magphase.py:3259-3261
                 a_mag = e.post_filter(self.a_mag, self.fs)
                 mark("k_post_filter")
-            _lib.check(lib.mpx_mel_unwarp(st, self.n_rows, H, a_mag.data_ptr(), self.mag_dim, self.u_mag.data_ptr(),
-                                          mag.data_ptr(), self.a_real.data_ptr(), self.a_imag.data_ptr(),
-                                          self.phase_dim, self.u_phase.data_ptr(), real.data_ptr(), imag.data_ptr(), ld),
-                       "mpx_mel_unwarp")
+            if self.b_const_rate:   # constant -> variable rate inside the unwarp: one spectrum row per synthesis frame
+                _lib.check(lib.mpx_mel_unwarp_rows(
+                    st, self.total_frames, H, a_mag.data_ptr(), self.mag_dim, self.u_mag.data_ptr(), mag.data_ptr(),
+                    self.a_real.data_ptr(), self.a_imag.data_ptr(), self.phase_dim, self.u_phase.data_ptr(),
+                    real.data_ptr(), imag.data_ptr(), ld, self.row0.data_ptr(), self.row1.data_ptr(),
+                    self.rowt.data_ptr()), "mpx_mel_unwarp_rows")
+            else:                   # variable-rate features: rows == frames
+                _lib.check(lib.mpx_mel_unwarp(st, self.n_rows, H, a_mag.data_ptr(), self.mag_dim, self.u_mag.data_ptr(),
+                                              mag.data_ptr(), self.a_real.data_ptr(), self.a_imag.data_ptr(),
+                                              self.phase_dim, self.u_phase.data_ptr(), real.data_ptr(), imag.data_ptr(),
+                                              ld), "mpx_mel_unwarp")
             mark("k_mel_unwarp_mfma")
             # (the noise chain is independent of the unwarp, but a second HIP stream does not help: measured 3.13 vs
             # 3.18 ms per step with 12-wave and 3.15 vs 3.16 with 8-wave noise workgroups -- the two grids do not co-run)
@@ -833,29 +842,27 @@ class CompressedSynthesisPlan:
                                            self.n_utts, H - 2, inv_gain.data_ptr(), self._gains_dev.data_ptr()),
                        "mpx_noise_gains")
             mark("k_noise_gains")
-            row0, row1, rowt = self.row0, self.row1, self.rowt
             if self.per_phase_type != "magphase":
                 # periodic component's phase is not the transmitted one (magphase.py:933-938):
-                #   'min_phase': complex-cepstrum minimum phase of the (row-interpolated) magnitude, per frame
+                #   'min_phase': complex-cepstrum minimum phase of the magnitude, per frame
                 #   'linear'   : zero phase
                 F = self.total_frames
                 ident, zeros_t = buf["ident"], buf["zeros_t"]
                 if self.per_phase_type == "min_phase":
                     mag_v, real_v, imag_v = buf["spec_v"]
-                    _lib.check(lib.mpx_min_phase(st, N, tab.data_ptr(), mag.data_ptr(), row0.data_ptr(),
-                                                 row1.data_ptr(), rowt.data_ptr(), F, mag_v.data_ptr(),
+                    _lib.check(lib.mpx_min_phase(st, N, tab.data_ptr(), mag.data_ptr(), ident.data_ptr(),
+                                                 ident.data_ptr(), zeros_t.data_ptr(), F, mag_v.data_ptr(),
                                                  real_v.data_ptr(), imag_v.data_ptr(), ld), "mpx_min_phase")
                     mark("k_min_phase")
                     mag, real, imag = mag_v, real_v, imag_v
-                    row0, row1, rowt = ident, ident, zeros_t
                 else:
                     real.fill_(1.0)
                     imag.fill_(0.0)
             _lib.check(lib.mpx_synthesis_compressed_ola(
                 st, N, tab.data_ptr(), mag.data_ptr(), real.data_ptr(), imag.data_ptr(), self.noise.data_ptr(),
                 self.npos.data_ptr(), self.nleft.data_ptr(), self.nright.data_ptr(), self.wtype.data_ptr(),
-                self.voiced.data_ptr(), inv_gain.data_ptr(), row0.data_ptr(), row1.data_ptr(),
-                rowt.data_ptr(), self.win_l.data_ptr(), self.win_r.data_ptr(), self.pm_rel.data_ptr(),
+                self.voiced.data_ptr(), inv_gain.data_ptr(), None, None, None,
+                self.win_l.data_ptr(), self.win_r.data_ptr(), self.pm_rel.data_ptr(),
                 self.per_v.data_ptr(), self.ap_v.data_ptr(), self.ap_u.data_ptr(), self.runs.data_ptr(),
                 self.n_runs, self.slot_off.data_ptr(), self.slot_runs.data_ptr(), self.n_slots,
                 strips.data_ptr(), pcm.data_ptr(), ld), "mpx_synthesis_compressed_ola")

@@ -57,6 +57,41 @@ def test_unwarp_and_noise_gains_match_oracle(orc, golden_dir):
     assert abs(g_unv - dbg["g_unv"]) < 1e-6 * dbg["g_unv"]
 
 
+def test_unwarp_rows_equals_unwarp_then_interpolation(golden_dir):
+    """mpx_mel_unwarp_rows (constant -> variable rate folded into the GEMM: two magnitude products interpolated after
+    the exp, coefficient rows of the linear phase unwarp interpolated before it) against the plain unwarp of the
+    constant-rate rows followed by interp_from_const_to_variable_rate's lerp (magphase.py:2242-2252) in float64."""
+    import torch
+    from magphase_amd import _lib
+    from magphase_amd.engine import CompressedSynthesisPlan, get_engine
+    g = np.load(os.path.join(golden_dir, "g8_compressed_analysis.npz"))
+    e = get_engine()
+    np.random.seed(3)
+    plan = CompressedSynthesisPlan(e, [(g["cr45_mag"], g["cr45_real"], g["cr45_imag"], g["cr45_lf0"])], int(g["fs"]),
+                                   b_const_rate=True)
+    plan.run(keep=True)
+    H = plan.fft_len // 2 + 1
+    ld = int(e.lib.mpx_spec_ld(H))
+    full = [e.empty((plan.n_rows, ld))[:, :H] for _ in range(3)]
+    _lib.check(e.lib.mpx_mel_unwarp(e.stream_ptr(), plan.n_rows, H, plan.a_mag.data_ptr(), plan.mag_dim,
+                                    plan.u_mag.data_ptr(), full[0].data_ptr(), plan.a_real.data_ptr(),
+                                    plan.a_imag.data_ptr(), plan.phase_dim, plan.u_phase.data_ptr(), full[1].data_ptr(),
+                                    full[2].data_ptr(), ld), "mpx_mel_unwarp")
+    torch.cuda.synchronize()
+    r0, r1 = plan.row0.cpu().numpy(), plan.row1.cpu().numpy()
+    t = plan.rowt.cpu().numpy().astype(np.float64)[:, None]
+    assert plan.total_frames != plan.n_rows and np.any(t > 0)
+    for k, name in enumerate(("mag", "real", "imag")):
+        x = full[k].cpu().numpy().astype(np.float64)
+        want = x[r0] + (x[r1] - x[r0]) * t
+        got = plan.debug[name].cpu().numpy().astype(np.float64)
+        assert got.shape == want.shape
+        if name == "mag":
+            assert np.max(np.abs(got - want) / want) < 3e-7          # one fp32 rounding of the lerp
+        else:
+            assert np.max(np.abs(got - want)) < 2e-6                 # 45-term fp32 sums in a different association
+
+
 def test_generation_from_predicted_features_matches_reference_golden(mp, golden_dir):
     g, mm, rr, ii, lf = _hvd704(golden_dir)
     seed = int(g["seed"])
