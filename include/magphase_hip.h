@@ -259,6 +259,17 @@ int mpx_mel_warp(void* stream, int64_t n_frames, int32_t n_bins, const float* ma
                  float* out_imag, int64_t ld /* row pitch of mag/real/imag in floats, >= n_bins */);
 
 /*
+ * mpx_mel_warp with the magnitudes compressed by the mel FILTER BANK instead of the cepstral warp
+ * (format_for_modelling(b_mag_fbank_mel=True), magphase.py:2504-2510; la.sp_mel_warp_fbank / apply_fbank 'average',
+ * libaudio.py:721-769): out_mag = la.log(exp(W_fbank . la.log(mag))), la.log's floor (-1e10 for mag == 0, and where the
+ * exp underflows) included.  w_fbank: [mag_dim x n_bins] (hostmath.warp_fbank_matrix).  The phase streams are unchanged.
+ */
+int mpx_mel_warp_fbank(void* stream, int64_t n_frames, int32_t n_bins, const float* mag, const float* real,
+                       const float* imag, const int32_t* row0, const int32_t* row1, const float* row_t,
+                       const float* w_fbank, int32_t mag_dim, const float* w_phase, int32_t phase_dim, const float* voiced,
+                       float* out_mag, float* out_real, float* out_imag, int64_t ld);
+
+/*
  * Minimum-phase spectrum of a magnitude spectrum by the complex cepstrum (la.build_min_phase_from_mag_spec,
  * libaudio.py:920-934; synthesis_from_compressed(per_phase_type='min_phase'), magphase.py:937-938).
  * For output frame f: m = (1-row_t)*mag[row0] + row_t*mag[row1] ([rows x H]); out_mag[f] = m and

@@ -82,6 +82,24 @@ struct WarpJobs {
     WarpJob j[3];
 };
 
+// Prologue of the mel warp's operand (WarpJob::mode) and the matching epilogue:
+//   0  magnitudes, cepstral warp: ln(x^2 + 1e-8)                                   (mcep -q 3 -e 1e-8 on x, libaudio.py:575-661)
+//   1  phase streams (mcep -q 2 on exp(x), |x| <= 1): ln(e^{2x} + 1e-8) = 2x + 1e-8 e^{-2x} (the next term is 5e-17);
+//      epilogue voicing mask + clip
+//   2  magnitudes, filter bank: la.log(x) = ln x with -1e10 for x == 0 (libaudio.py:241-248, :763-769); the reference then
+//      takes exp and la.log again (magphase.py:2505-2510): the identity unless the exp underflows to 0 (sum < ln of the
+//      smallest float64, -745.13), which comes back as -1e10
+__device__ __forceinline__ float warp_prologue(int mode, float x) {
+    if (mode == 0) return __logf(fmaf(x, x, 1.0e-8f));
+    if (mode == 1) return fmaf(1.0e-8f, __expf(-2.0f * x), 2.0f * x);
+    return (x > 0.0f) ? __logf(x) : -1.0e10f;
+}
+__device__ __forceinline__ float warp_epilogue(int mode, float y, float vo) {
+    if (mode == 1) return fminf(fmaxf(y * vo, -1.0f), 1.0f);
+    if (mode == 2) return (y < -745.13321f) ? -1.0e10f : y;
+    return y;
+}
+
 constexpr int kWarpTile = 64;
 constexpr int kWarpStride = 68;   // floats per LDS row (multiple of 4 for float4 reads)
 
@@ -129,7 +147,7 @@ __global__ __launch_bounds__(256) void k_mel_warp(WarpJobs jobs, long long F, in
             const float x = fmaf(xw[p] - xv[p], s_rt[fl], xv[p]);
             // hardware exp2/log2 (v_exp_f32 / v_log_f32, ~1 ulp): the 1e-7 error is far below the stated tolerance
             // of this (ill-conditioned, unpinned) stage
-            const float v = (job.mode == 0) ? __logf(fmaf(x, x, 1.0e-8f)) : fmaf(1.0e-8f, __expf(-2.0f * x), 2.0f * x);
+            const float v = warp_prologue(job.mode, x);
             As[kk][fl] = (kok && f0 + fl < F) ? v : 0.0f;
             Ws[kk][fl] = (kok && fl < job.nout) ? wv16[p] : 0.0f;
         }
@@ -157,7 +175,7 @@ __global__ __launch_bounds__(256) void k_mel_warp(WarpJobs jobs, long long F, in
             const int i = 4 * tx + c;
             if (i >= job.nout) continue;
             float y = acc[r][c];
-            if (job.mode == 1) y = fminf(fmaxf(y * vo, -1.0f), 1.0f);
+            y = warp_epilogue(job.mode, y, vo);
             job.out[f * job.nout + i] = y;
         }
     }
@@ -969,7 +987,7 @@ __device__ __forceinline__ void mel_warp_block(const WarpJob& job, float (*As)[k
             // magnitudes: ln(x^2 + 1e-8) with the hardware log2 (v_log_f32, ~1 ulp of log2).  Phase streams (mcep -q 2 on
             // exp(x), |x| <= 1): ln(e^{2x} + 1e-8) = 2x + ln(1 + 1e-8 e^{-2x}) = 2x + 1e-8 e^{-2x} (the next term is
             // 5e-17): exact to the rounding of the sum, where exp-then-log in fp32 lost ~1e-6
-            const float v = (job.mode == 0) ? __logf(fmaf(x, x, 1.0e-8f)) : fmaf(1.0e-8f, __expf(-2.0f * x), 2.0f * x);
+            const float v = warp_prologue(job.mode, x);
             As[fl][kk] = (kok && f0 + fl < F) ? v : 0.0f;
             if (p < 4 * NT) Ws[fl][kk] = (kok && fl < job.nout) ? wv16[p] : 0.0f;
         }
@@ -1009,7 +1027,7 @@ __device__ __forceinline__ void mel_warp_block(const WarpJob& job, float (*As)[k
             const int i = 16 * jt + li;
             if (i >= job.nout) continue;
             float y = tot[jt][r];
-            if (job.mode == 1) y = fminf(fmaxf(y * vo, -1.0f), 1.0f);
+            y = warp_epilogue(job.mode, y, vo);
             job.out[f * job.nout + i] = y;
         }
     }
@@ -1327,10 +1345,10 @@ int mpx_synthesis_compressed_ola(void* stream, int fft_len, const void* tables, 
     return MPX_OK;
 }
 
-int mpx_mel_warp(void* stream, int64_t n_frames, int32_t n_bins, const float* mag, const float* real, const float* imag,
-                 const int32_t* row0, const int32_t* row1, const float* row_t, const float* w_mag, int32_t mag_dim,
-                 const float* w_phase, int32_t phase_dim, const float* voiced, float* out_mag, float* out_real,
-                 float* out_imag, int64_t ld) {
+static int mel_warp_impl(void* stream, int64_t n_frames, int32_t n_bins, const float* mag, const float* real,
+                         const float* imag, const int32_t* row0, const int32_t* row1, const float* row_t,
+                         const float* w_mag, int32_t mag_dim, const float* w_phase, int32_t phase_dim, const float* voiced,
+                         float* out_mag, float* out_real, float* out_imag, int64_t ld, int mag_mode) {
     if (n_frames < 0 || n_bins <= 0 || ld < n_bins) return fail(MPX_ERR_ARG, "mpx_mel_warp: bad size%s");
     if (mag_dim <= 0 || mag_dim > kWarpTile || phase_dim <= 0 || phase_dim > kWarpTile)
         return fail(MPX_ERR_ARG, "mpx_mel_warp: output dimension must be in 1..64%s");
@@ -1340,7 +1358,7 @@ int mpx_mel_warp(void* stream, int64_t n_frames, int32_t n_bins, const float* ma
     if ((row0 == nullptr) != (row1 == nullptr) || (row0 == nullptr) != (row_t == nullptr))
         return fail(MPX_ERR_ARG, "mpx_mel_warp: row0/row1/row_t must be all null or all given%s");
     WarpJobs jobs;
-    jobs.j[0] = {mag, w_mag, out_mag, nullptr, (int)mag_dim, 0};
+    jobs.j[0] = {mag, w_mag, out_mag, nullptr, (int)mag_dim, mag_mode};
     jobs.j[1] = {real, w_phase, out_real, voiced, (int)phase_dim, 1};
     jobs.j[2] = {imag, w_phase, out_imag, voiced, (int)phase_dim, 1};
     const dim3 grid((unsigned)((n_frames + kWarpTile - 1) / kWarpTile), 3);
@@ -1379,6 +1397,22 @@ int mpx_mel_warp(void* stream, int64_t n_frames, int32_t n_bins, const float* ma
 #endif
     MPX_HIP_CHECK(hipGetLastError());
     return MPX_OK;
+}
+
+int mpx_mel_warp(void* stream, int64_t n_frames, int32_t n_bins, const float* mag, const float* real, const float* imag,
+                 const int32_t* row0, const int32_t* row1, const float* row_t, const float* w_mag, int32_t mag_dim,
+                 const float* w_phase, int32_t phase_dim, const float* voiced, float* out_mag, float* out_real,
+                 float* out_imag, int64_t ld) {
+    return mel_warp_impl(stream, n_frames, n_bins, mag, real, imag, row0, row1, row_t, w_mag, mag_dim, w_phase, phase_dim,
+                         voiced, out_mag, out_real, out_imag, ld, 0);
+}
+
+int mpx_mel_warp_fbank(void* stream, int64_t n_frames, int32_t n_bins, const float* mag, const float* real,
+                       const float* imag, const int32_t* row0, const int32_t* row1, const float* row_t,
+                       const float* w_fbank, int32_t mag_dim, const float* w_phase, int32_t phase_dim, const float* voiced,
+                       float* out_mag, float* out_real, float* out_imag, int64_t ld) {
+    return mel_warp_impl(stream, n_frames, n_bins, mag, real, imag, row0, row1, row_t, w_fbank, mag_dim, w_phase,
+                         phase_dim, voiced, out_mag, out_real, out_imag, ld, 2);
 }
 
 int mpx_min_phase(void* stream, int fft_len, const void* tables, const float* mag, const int32_t* row0,

@@ -370,7 +370,18 @@ class Engine:
         m = self.to_host_f64(o_m[:, :H])
         return m * (self.to_host_f64(o_r[:, :H]) + 1j * self.to_host_f64(o_i[:, :H]))
 
-    def mel_warp_feats(self, mag, real, imag, voi_host, fs, mag_dim, phase_dim, alpha_phase=None):
+    def warp_mag_matrix(self, mag_dim, H, alpha, b_mag_fbank_mel=False):
+        """Device-resident [mag_dim x H] matrix of the magnitude compression and the C entry point that goes with it:
+        the cepstral mel warp (la.sp_mel_warp, mpx_mel_warp) or the mel filter bank (la.sp_mel_warp_fbank,
+        mpx_mel_warp_fbank)."""
+        if b_mag_fbank_mel:
+            return (self.constant(("w_fbank", int(mag_dim), H, float(alpha)),
+                                  lambda: hm.warp_fbank_matrix(mag_dim, H, alpha)), self.lib.mpx_mel_warp_fbank,
+                    "mpx_mel_warp_fbank")
+        return (self.constant(("w_mag", int(mag_dim), H, float(alpha)), lambda: hm.warp_matrix(mag_dim, H, alpha)),
+                self.lib.mpx_mel_warp, "mpx_mel_warp")
+
+    def mel_warp_feats(self, mag, real, imag, voi_host, fs, mag_dim, phase_dim, alpha_phase=None, b_mag_fbank_mel=False):
         """format_for_modelling's two warps (magphase.py:2504-2529) on device feature matrices [F x H] -> three device
         matrices [F x mag_dim], [F x phase_dim], [F x phase_dim]."""
         torch = _torch()
@@ -379,16 +390,16 @@ class Engine:
         a_ph = alpha if alpha_phase is None else alpha_phase
         cf, _ = hm.define_crossfade_params(fs)
         k_full = hm.get_num_full_mel_coeffs_from_num_phase_coeffs(cf, phase_dim, a_ph, fs)
-        w_mag = self.constant(("w_mag", int(mag_dim), H, float(alpha)), lambda: hm.warp_matrix(mag_dim, H, alpha))
+        w_mag, warp_fn, warp_name = self.warp_mag_matrix(mag_dim, H, alpha, b_mag_fbank_mel)
         w_ph = self.constant(("w_ph", int(k_full), H, float(a_ph), int(phase_dim)),
                              lambda: hm.warp_matrix(k_full, H, a_ph, nrows=phase_dim))
         voi = self.to_device(np.asarray(voi_host, dtype=np.float64), np.float32)
         out = (self.empty((F, int(mag_dim))), self.empty((F, int(phase_dim))), self.empty((F, int(phase_dim))))
         with torch.cuda.device(self.device):
-            _lib.check(self.lib.mpx_mel_warp(self.stream_ptr(), F, H, mag.data_ptr(), real.data_ptr(), imag.data_ptr(),
-                                             None, None, None, w_mag.data_ptr(), int(mag_dim), w_ph.data_ptr(),
-                                             int(phase_dim), voi.data_ptr(), out[0].data_ptr(), out[1].data_ptr(),
-                                             out[2].data_ptr(), self.feat_ld(mag, real, imag)), "mpx_mel_warp")
+            _lib.check(warp_fn(self.stream_ptr(), F, H, mag.data_ptr(), real.data_ptr(), imag.data_ptr(),
+                               None, None, None, w_mag.data_ptr(), int(mag_dim), w_ph.data_ptr(),
+                               int(phase_dim), voi.data_ptr(), out[0].data_ptr(), out[1].data_ptr(),
+                               out[2].data_ptr(), self.feat_ld(mag, real, imag)), warp_name)
         return out
 
     def synth_comp_slots(self):
@@ -924,7 +935,8 @@ class CompressedAnalysisPlan:
     k_mel_warp, everything resident on the device; host fp64 does f0 / lf0 / constant-rate tables only.
     """
 
-    def __init__(self, engine, utts, fft_len=None, mag_dim=60, phase_dim=10, b_const_rate=False, alpha_phase=None):
+    def __init__(self, engine, utts, fft_len=None, mag_dim=60, phase_dim=10, b_const_rate=False, alpha_phase=None,
+                 b_mag_fbank_mel=False):
         self.engine = e = engine
         self.lossless = plan = LosslessAnalysisPlan(engine, utts, fft_len=fft_len)
         fs = self.fs = plan.fs[0]
@@ -937,7 +949,7 @@ class CompressedAnalysisPlan:
         a_ph = alpha if alpha_phase is None else alpha_phase
         cf, _ = hm.define_crossfade_params(fs)
         k_full = hm.get_num_full_mel_coeffs_from_num_phase_coeffs(cf, phase_dim, a_ph, fs)
-        self.w_mag = e.constant(("w_mag", int(mag_dim), H, float(alpha)), lambda: hm.warp_matrix(mag_dim, H, alpha))
+        self.w_mag, self._warp_fn, self._warp_name = e.warp_mag_matrix(mag_dim, H, alpha, b_mag_fbank_mel)
         self.w_ph = e.constant(("w_ph", int(k_full), H, float(a_ph), int(phase_dim)),
                                lambda: hm.warp_matrix(k_full, H, a_ph, nrows=phase_dim))
         row0, row1, rowt, self.f0_out = [], [], [], []
@@ -976,11 +988,11 @@ class CompressedAnalysisPlan:
                    e.empty((self.total_out_frames, self.phase_dim)))
         ptr = (lambda t: t.data_ptr() if t is not None else None)
         with torch.cuda.device(e.device):
-            _lib.check(e.lib.mpx_mel_warp(e.stream_ptr(), self.total_out_frames, H, mag.data_ptr(), real.data_ptr(),
-                                          imag.data_ptr(), ptr(self.row0), ptr(self.row1), ptr(self.rowt),
-                                          self.w_mag.data_ptr(), self.mag_dim, self.w_ph.data_ptr(), self.phase_dim,
-                                          self.voi.data_ptr(), out[0].data_ptr(), out[1].data_ptr(),
-                                          out[2].data_ptr(), e.feat_ld(mag, real, imag)), "mpx_mel_warp")
+            _lib.check(self._warp_fn(e.stream_ptr(), self.total_out_frames, H, mag.data_ptr(), real.data_ptr(),
+                                     imag.data_ptr(), ptr(self.row0), ptr(self.row1), ptr(self.rowt),
+                                     self.w_mag.data_ptr(), self.mag_dim, self.w_ph.data_ptr(), self.phase_dim,
+                                     self.voi.data_ptr(), out[0].data_ptr(), out[1].data_ptr(),
+                                     out[2].data_ptr(), e.feat_ld(mag, real, imag)), self._warp_name)
         mark("k_mel_warp_mfma")
         return out
 

@@ -301,6 +301,24 @@ def fbank_centres(n_melbands, nbins, alpha):
     return round_to_int(f_interp(v_cntrs_mel))
 
 
+def warp_fbank_matrix(n_melbands, nbins, alpha):
+    """
+    la.sp_mel_warp_fbank / apply_fbank(mode='average') (libaudio.py:721-769) as W[n_melbands x nbins] acting on
+    ln(mag): band b = the asymmetric Hann window (rising half of np.hanning(1 + 2 l), falling half of
+    np.hanning(1 + 2 r), l / r = distances to the neighbouring band centres, first and last centre repeated)
+    normalised to unit sum, placed from centre b-1 on.  Same float64 construction as the reference.
+    """
+    v_cntrs = fbank_centres(n_melbands, nbins, alpha)
+    ext = np.r_[v_cntrs[0], v_cntrs, v_cntrs[-1]]
+    w = np.zeros((n_melbands, nbins))
+    for b in range(1, n_melbands + 1):
+        ll, rr = int(ext[b] - ext[b - 1]), int(ext[b + 1] - ext[b])
+        win = np.hstack((np.hanning(1 + 2 * ll)[:ll + 1], np.flipud(np.hanning(1 + 2 * rr)[:rr + 1])[1:]))
+        win = win / np.sum(win)
+        w[b - 1, ext[b - 1]:ext[b - 1] + win.size] = win
+    return w
+
+
 def unwarp_fbank_matrix(n_melbands, nbins, alpha):
     """
     la.sp_mel_unwarp_fbank (libaudio.py:815-864): per frame, a quadratic spline (scipy interp1d) through the band

@@ -373,18 +373,18 @@ def format_for_modelling(m_mag, m_real, m_imag, v_f0, fs, mag_dim=60, phase_dim=
     """
     magphase.py:2490-2544 for lossless features that are already in host arrays: f0 smoothing / lf0 on the host (fp64),
     the two mel warps on the device (mpx_mel_warp).  Returns (m_mag_mel_log, m_real_mel, m_imag_mel, v_lf0_smth).
-    b_mag_fbank_mel=True (the analysis-side filter bank) is not built: it is unreachable through analysis_compressed /
-    analysis_for_acoustic_modelling in the reference (Q7).
+    b_mag_fbank_mel=True: the magnitudes go through the mel filter bank (la.sp_mel_warp_fbank, magphase.py:2504-2505;
+    mpx_mel_warp_fbank) instead of the cepstral warp.  In the reference this branch is reachable only through this
+    function (analysis_compressed never forwards the flag, Q7).
     """
     from scipy import signal
-    if b_mag_fbank_mel:
-        raise NotImplementedError("format_for_modelling(b_mag_fbank_mel=True): analysis-side filter bank not built")
     engine = get_engine()
     v_f0 = np.asarray(v_f0, dtype=np.float64)
     v_voi = (v_f0 > 0).astype('float')                                       # magphase.py:2497
     v_lf0_smth = la.f0_to_lf0(v_voi * signal.medfilt(v_f0))                  # :2499-2501
     mag, real, imag = (engine.feats_to_device(x) for x in (m_mag, m_real, m_imag))
-    out = engine.mel_warp_feats(mag, real, imag, v_voi, fs, mag_dim, phase_dim, alpha_phase=alpha_phase)
+    out = engine.mel_warp_feats(mag, real, imag, v_voi, fs, mag_dim, phase_dim, alpha_phase=alpha_phase,
+                                b_mag_fbank_mel=bool(b_mag_fbank_mel))
     return tuple(engine.to_host_f64(t) for t in out) + (v_lf0_smth,)
 
 

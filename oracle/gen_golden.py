@@ -203,6 +203,26 @@ def gen_fbank(mp, la, lu):
     np.savez_compressed(os.path.join(OUT, "g10_fbank.npz"), **out)
 
 
+def gen_fbank_warp(mp, la):
+    """G11: analysis-side filter bank (la.sp_mel_warp_fbank, libaudio.py:721-769 -- pure numpy, so this vector is
+    PINNED) and format_for_modelling(b_mag_fbank_mel=True)'s magnitude stream on the G8 lossless features."""
+    rng = np.random.RandomState(321)
+    out = {}
+    for nb, nbins, alpha in ((60, 2049, 0.77), (60, 1025, 0.58), (40, 2049, 0.77)):
+        x = np.exp(rng.randn(6, nbins) * 1.5 - 2.0)
+        x[4, 100:140] = 0.0                      # exact zeros: la.log's MAGIC floor, exp underflow, MAGIC again
+        x[5, :] = 0.0                            # a silent frame
+        y = la.log(la.sp_mel_warp_fbank(x, nb, alpha=alpha))
+        out["x_%d_%d" % (nb, nbins)] = x
+        out["y_%d_%d" % (nb, nbins)] = y
+    g = np.load(os.path.join(OUT, "g2_lossless_48k.npz"))
+    m_mag, m_real, m_imag = (g[k].astype(np.float64) for k in ("mag32", "real32", "imag32"))   # inputs = the fixture's
+    r = mp.format_for_modelling(m_mag, m_real, m_imag, g["v_f0"], 48000, mag_dim=60, phase_dim=45, b_mag_fbank_mel=True)
+    out["ffm_mag_mel_log"] = r[0]
+    out["ffm_lf0"] = r[3]
+    np.savez_compressed(os.path.join(OUT, "g11_fbank_warp.npz"), **out)
+
+
 def gen_labels(mp, la):
     """G9: HTS state-aligned labels -> frames per state -> variable-frame-rate labels (magphase.py:2111-2150,
     libaudio.py:687-708).  The label text is synthetic (5 states per phone, 5 ms grid)."""
@@ -263,6 +283,7 @@ def main():
             gen_const_rate(mp, la)
             gen_labels(mp, la)
             gen_fbank(mp, la, lu)
+            gen_fbank_warp(mp, la)
         finally:
             os.chdir(cwd)
     for f in sorted(os.listdir(OUT)):

@@ -525,15 +525,45 @@ def interp_from_const_to_variable_rate(m_data, v_frm_locs_smpls, frm_rate_ms, fs
     return interpolate.interp1d(centres, m_data, axis=0, kind="linear")(v_frm_locs_smpls)
 
 
+def fbank_matrix(v_bins_warp, nbands, win_func=np.hanning):
+    """
+    libaudio.py:721-749 (apply_fbank, the filter-bank construction): band centres equally spaced on the warped axis,
+    mapped back to bins through a quadratic interp1d and rounded; band b is the normalised asymmetric window
+    (half_windows) from centre b-1 to centre b+1.  Returns m_fbank [nbins x nbands].
+    """
+    nbins = v_bins_warp.size
+    v_cntrs_mel = np.linspace(0, v_bins_warp[-1], nbands)
+    v_cntrs = round_to_int(interpolate.interp1d(v_bins_warp, np.arange(nbins), kind="quadratic")(v_cntrs_mel))
+    m_fbank = np.zeros((nbins, nbands))
+    ext = np.r_[v_cntrs[0], v_cntrs, v_cntrs[-1]]
+    for b in range(1, nbands + 1):
+        v_win = half_windows(ext[b] - ext[b - 1], ext[b + 1] - ext[b])
+        v_win = v_win / np.sum(v_win)
+        m_fbank[ext[b - 1]:ext[b - 1] + v_win.size, b - 1] = v_win
+    return m_fbank
+
+
+def sp_mel_warp_fbank(m_mag, n_melbands, alpha=0.77):
+    """libaudio.py:763-769: exp(log_protected(m_mag) . fbank) -- 'average' mode of apply_fbank.  PINNED (golden G11)."""
+    m_fbank = fbank_matrix(build_mel_curve(alpha, m_mag.shape[1]), n_melbands)
+    with np.errstate(under="ignore"):
+        return np.exp(np.dot(log_protected(m_mag), m_fbank))
+
+
 # =============================================================================================
 # compressed analysis  (magphase.py:2490-2544, 2947-2988)
 # =============================================================================================
-def format_for_modelling(m_mag, m_real, m_imag, v_f0, fs, mag_dim=60, phase_dim=45, alpha_phase=None):
-    """magphase.py:2490-2544 (b_mag_fbank_mel=False branch).  Passes through the UNPINNED mcep."""
+def format_for_modelling(m_mag, m_real, m_imag, v_f0, fs, mag_dim=60, phase_dim=45, alpha_phase=None,
+                         b_mag_fbank_mel=False):
+    """magphase.py:2490-2544.  The phase streams (and the magnitudes unless b_mag_fbank_mel) pass through the UNPINNED
+    mcep; the filter-bank magnitudes (b_mag_fbank_mel=True, :2504-2505) are pure numpy in the reference: pinned, G11."""
     alpha = define_alpha(fs)
     v_voi = (v_f0 > 0).astype("float")
     v_lf0 = f0_to_lf0(v_voi * signal.medfilt(v_f0))
-    m_mag_mel_log = log_protected(sp_mel_warp(m_mag, mag_dim, alpha=alpha, in_type=3))
+    if b_mag_fbank_mel:
+        m_mag_mel_log = log_protected(sp_mel_warp_fbank(m_mag, mag_dim, alpha=alpha))
+    else:
+        m_mag_mel_log = log_protected(sp_mel_warp(m_mag, mag_dim, alpha=alpha, in_type=3))
     cf, _ = define_crossfade_params(fs)
     if alpha_phase is None:
         alpha_phase = alpha

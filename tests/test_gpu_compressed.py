@@ -314,6 +314,30 @@ def test_fbank_unwarp_generation_matches_reference(mp, golden_dir):
     assert v.shape == ref.shape and np.max(np.abs(v - ref)) <= COMP_PCM_TOL * max(1.0, np.max(np.abs(ref)))
 
 
+def test_fbank_warp_analysis_matches_reference(mp, golden_dir):
+    """format_for_modelling(b_mag_fbank_mel=True): the mel filter bank on the device (mpx_mel_warp_fbank) against the
+    reference's own output (G11, pinned); la.log's -1e10 floor for zero magnitudes comes back exactly."""
+    from magphase_amd.engine import get_engine
+    g = np.load(os.path.join(golden_dir, "g11_fbank_warp.npz"))
+    g2 = np.load(os.path.join(golden_dir, "g2_lossless_48k.npz"))
+    r = mp.format_for_modelling(g2["mag32"], g2["real32"], g2["imag32"], g2["v_f0"], 48000, mag_dim=60, phase_dim=45,
+                                b_mag_fbank_mel=True)
+    assert r[0].shape == g["ffm_mag_mel_log"].shape
+    assert np.max(np.abs(r[0] - g["ffm_mag_mel_log"])) < WARP_TOL, np.max(np.abs(r[0] - g["ffm_mag_mel_log"]))
+    assert np.array_equal(r[3], g["ffm_lf0"])
+    plain = mp.format_for_modelling(g2["mag32"], g2["real32"], g2["imag32"], g2["v_f0"], 48000, mag_dim=60, phase_dim=45)
+    assert np.array_equal(r[1], plain[1]) and np.array_equal(r[2], plain[2])      # the phase streams do not change
+    e = get_engine()
+    for nb, nbins, fs in ((60, 2049, 48000), (60, 1025, 16000)):
+        x, y = g["x_%d_%d" % (nb, nbins)], g["y_%d_%d" % (nb, nbins)]
+        dev = [e.feats_to_device(a) for a in (x, np.zeros_like(x), np.zeros_like(x))]
+        out = e.mel_warp_feats(dev[0], dev[1], dev[2], np.ones(x.shape[0]), fs, nb, 10, b_mag_fbank_mel=True)
+        got = e.to_host_f64(out[0])
+        floor = y == -1.0e10
+        assert np.array_equal(got == -1.0e10, floor)
+        assert np.max(np.abs(got[~floor] - y[~floor])) < WARP_TOL, np.max(np.abs(got[~floor] - y[~floor]))
+
+
 def test_full_size_config3_constant_rate_post_filter(mp, orc):
     """
     BASELINE configs[2] at full size on the device-resident batch path: 64 x 5 s @ 48 kHz, analysis_compressed (mag 60,

@@ -173,3 +173,23 @@ def test_g10_fbank_unwarp_and_synthesis(golden_dir):
         x, y = g["x_%d_%d" % (nb, nbins)], g["y_%d_%d" % (nb, nbins)]
         _close(orc.sp_mel_unwarp_fbank(x, nbins, alpha=alpha), y)
         _close(x @ hm.unwarp_fbank_matrix(nb, nbins, alpha), y, 1e-11)
+
+
+def test_g11_fbank_warp_pinned(golden_dir):
+    """Analysis-side filter bank (la.sp_mel_warp_fbank, pure numpy in the reference: PINNED): the oracle restatement is
+    bit-identical to the reference's output, MAGIC floors included; so is the matrix the device multiplies by."""
+    import warnings
+    from magphase_amd import hostmath as hm
+    g = _load(golden_dir, "g11_fbank_warp.npz")
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for nb, nbins, alpha in ((60, 2049, 0.77), (60, 1025, 0.58), (40, 2049, 0.77)):
+            x, y = g["x_%d_%d" % (nb, nbins)], g["y_%d_%d" % (nb, nbins)]
+            assert np.array_equal(orc.log_protected(orc.sp_mel_warp_fbank(x, nb, alpha=alpha)), y)
+            assert np.all(y[5] == orc.MAGIC) and np.any(y[4] == orc.MAGIC) and np.any(y[4] > -100)
+            assert np.array_equal(hm.warp_fbank_matrix(nb, nbins, alpha).T,
+                                  orc.fbank_matrix(orc.build_mel_curve(alpha, nbins), nb))
+        g2 = _load(golden_dir, "g2_lossless_48k.npz")
+        r = orc.format_for_modelling(*(g2[k].astype(np.float64) for k in ("mag32", "real32", "imag32")), g2["v_f0"],
+                                     48000, mag_dim=60, phase_dim=45, b_mag_fbank_mel=True)
+    assert np.array_equal(r[0], g["ffm_mag_mel_log"]) and np.array_equal(r[3], g["ffm_lf0"])
