@@ -962,37 +962,53 @@ __device__ __forceinline__ void mel_warp_block(const WarpJob& job, float (*As)[k
 #pragma unroll
     for (int jt = 0; jt < NT; ++jt) tot[jt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
-    // Every load is unconditional (clamped bin): the 48 loads of a chunk are in flight together, and the NEXT chunk's
-    // are issued right after this chunk's values are in LDS, so they fly behind the fragment reads and the MFMAs.
-    // (Refilling each staging register as soon as it is consumed costs a second register set: 204 VGPRs, 2 workgroups
-    // per CU instead of 3, measured 10 % slower.)
-    float xv[16], xw[16], wv16[16];
+    // Staging roles: thread (c4, rr) handles the 4 consecutive bins k0 + 4 c4 .. + 3 of the rows rr + 16 p, p < 4: one
+    // 16-byte load per row and operand (12 per thread and chunk instead of 48 dword loads: the kernel issued 19 M VMEM
+    // instructions per launch) and one ds_write_b128 per row (16 lanes cover a row's 256 bytes: conflict-free).  Rows
+    // are dense (pitch H floats): the loads are 4-byte aligned only, which global_load_dwordx4 allows.  Every load is
+    // unconditional; the chunk that crosses the end of the row (H = 64 q + 1: the last bin alone) clamps per element.
+    // The NEXT chunk's loads are issued right after this chunk's values are in LDS, so they fly behind the fragment
+    // reads and the MFMAs.
+    const int c4 = threadIdx.x & 15, rr = threadIdx.x >> 4;
+    typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte load from a 4-byte aligned address
+    auto ld4 = [](const float* q) {
+        const f32x4u v = *reinterpret_cast<const f32x4u*>(q);
+        return make_float4(v[0], v[1], v[2], v[3]);
+    };
+    float4 xv[4], xw[4], wv4[4];
     auto fetch = [&](int k0) {
-        const int kc = min(k0 + kk, H - 1);
 #pragma unroll
-        for (int p = 0; p < 16; ++p) {
-            const int fl = fq + 4 * p;
-            xv[p] = job.x[s_o0[fl] + kc];
-            if (INTERP) xw[p] = job.x[s_o1[fl] + kc];   // variable-rate input: one row per frame, a third fewer loads
-            if (p < 4 * NT) wv16[p] = job.W[(long long)min(fl, job.nout - 1) * H + kc];   // W rows of the tiles in use
+        for (int p = 0; p < 4; ++p) {
+            const int fl = rr + 16 * p;
+            const int k = k0 + 4 * c4;
+            xv[p] = ld4(job.x + s_o0[fl] + k);
+            if (INTERP) xw[p] = ld4(job.x + s_o1[fl] + k);
+            if (p < NT) wv4[p] = ld4(job.W + (long long)min(fl, job.nout - 1) * H + k);
         }
     };
-    fetch(0);
-    for (int k0 = 0; k0 < H; k0 += kWarpTile) {
-        const bool kok = k0 + kk < H;
+    const int Hfull = H & ~(kWarpTile - 1);   // bins covered by whole chunks; the rest (one bin for H = 64 q + 1) below
+    if (Hfull > 0) fetch(0);
+    for (int k0 = 0; k0 < Hfull; k0 += kWarpTile) {
 #pragma unroll
-        for (int p = 0; p < 16; ++p) {
-            const int fl = fq + 4 * p;
-            const float x = INTERP ? fmaf(xw[p] - xv[p], s_rt[fl], xv[p]) : xv[p];
-            // magnitudes: ln(x^2 + 1e-8) with the hardware log2 (v_log_f32, ~1 ulp of log2).  Phase streams (mcep -q 2 on
-            // exp(x), |x| <= 1): ln(e^{2x} + 1e-8) = 2x + ln(1 + 1e-8 e^{-2x}) = 2x + 1e-8 e^{-2x} (the next term is
-            // 5e-17): exact to the rounding of the sum, where exp-then-log in fp32 lost ~1e-6
-            const float v = warp_prologue(job.mode, x);
-            As[fl][kk] = (kok && f0 + fl < F) ? v : 0.0f;
-            if (p < 4 * NT) Ws[fl][kk] = (kok && fl < job.nout) ? wv16[p] : 0.0f;
+        for (int p = 0; p < 4; ++p) {
+            const int fl = rr + 16 * p;
+            const float rt = INTERP ? s_rt[fl] : 0.0f;
+            const bool fok = f0 + fl < F;
+            const float xin[4] = {xv[p].x, xv[p].y, xv[p].z, xv[p].w};
+            const float xin1[4] = {xw[p].x, xw[p].y, xw[p].z, xw[p].w};
+            const float win[4] = {wv4[p].x, wv4[p].y, wv4[p].z, wv4[p].w};
+            float av[4], wo[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float x = INTERP ? fmaf(xin1[e] - xin[e], rt, xin[e]) : xin[e];
+                av[e] = fok ? warp_prologue(job.mode, x) : 0.0f;
+                wo[e] = (fl < job.nout) ? win[e] : 0.0f;
+            }
+            *reinterpret_cast<float4*>(&As[fl][4 * c4]) = make_float4(av[0], av[1], av[2], av[3]);
+            if (p < NT) *reinterpret_cast<float4*>(&Ws[fl][4 * c4]) = make_float4(wo[0], wo[1], wo[2], wo[3]);
         }
         __syncthreads();
-        if (k0 + kWarpTile < H) fetch(k0 + kWarpTile);
+        if (k0 + kWarpTile < Hfull) fetch(k0 + kWarpTile);
         const float* arow = &As[16 * wave + li][16 * g];
         f32x4 acc[NT];
 #pragma unroll
@@ -1016,11 +1032,23 @@ __device__ __forceinline__ void mel_warp_block(const WarpJob& job, float (*As)[k
         for (int jt = 0; jt < NT; ++jt) tot[jt] += acc[jt];
         __syncthreads();
     }
-    // C: column li of tile jt, row 4 g + r of this wave's 16 frames
+    // C: column li of tile jt, row 4 g + r of this wave's 16 frames.  The bins past the last whole chunk are added here,
+    // one fmaf per bin and output (H = 64 q + 1 for every transform size: the Nyquist bin).
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const long long f = f0 + 16 * wave + 4 * g + r;
         if (f >= F) continue;
+        const int fl = 16 * wave + 4 * g + r;
+        for (int k = Hfull; k < H; ++k) {
+            const float x0 = job.x[s_o0[fl] + k];
+            const float x = INTERP ? fmaf(job.x[s_o1[fl] + k] - x0, s_rt[fl], x0) : x0;
+            const float v = warp_prologue(job.mode, x);
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt) {
+                const int i = 16 * jt + li;
+                tot[jt][r] = fmaf(v, job.W[(long long)min(i, job.nout - 1) * H + k], tot[jt][r]);
+            }
+        }
         const float vo = job.voi ? job.voi[f] : 1.0f;
 #pragma unroll
         for (int jt = 0; jt < NT; ++jt) {
