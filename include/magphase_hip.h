@@ -365,6 +365,49 @@ int mpx_pcm16_to_f32(void* stream, const int16_t* pcm, int64_t n, float* out);
  * reader / writer threads of iobatch.py: the FFI call drops the interpreter lock, so reading, computing and writing overlap.
  * ------------------------------------------------------------------------------------------------------------------ */
 
+/*
+ * Batch planners (csrc/magphase_plan.cpp): the reference's float64 / integer index arithmetic for all utterances of a
+ * batch in one call, the same IEEE-754 operation sequence as the numpy forms in magphase_amd/hostmath.py / engine.py
+ * (np.round = half to even, astype(int) = truncation, sequential cumsum).  All pointers are HOST memory.  A negative
+ * return value -(u + 2) names utterance u as the one the numpy form would raise on; -1 = bad arguments.
+ *
+ * mpx_host_plan_analysis: libaudio.py:435-447 (epoch clean-up), magphase.py:77-98 (frame bounds), :2198-2207 (f0).
+ *   pm_sec, voi [ep_off[n_utts]]: epochs (seconds) and voicing flags, utterance u at [ep_off[u], ep_off[u+1]);
+ *   n_smpls, fs [n_utts]; sig_off [n_utts]: offset of the utterance's samples in the batch's sample buffer.
+ *   Outputs (capacity = number of epochs): pos = rounded epoch + sig_off, pm = rounded epoch, left / right = distances to
+ *   the neighbouring epochs (0 and n_smpls - 1 at the ends), f0 = voi * fs / left; frame_off [n_utts + 1].
+ *   Returns the total number of frames.
+ */
+int64_t mpx_host_plan_analysis(int32_t n_utts, const double* pm_sec, const double* voi, const int64_t* ep_off,
+                               const int64_t* n_smpls, const double* fs, const int64_t* sig_off, int64_t* pos,
+                               int64_t* pm_out, int64_t* left, int64_t* right, double* f0, int64_t* frame_off);
+
+/*
+ * mpx_host_plan_synthesis: the per-utterance part of synthesis_from_compressed before any spectrum (magphase.py:846-848
+ * f0 -> voicing / shifts, :861-868 constant -> variable rate via mpx_host_const_to_var_scan, :879-882 epochs and noise
+ * length, :77-98 noise frame bounds, :969-973 anti-ringing window lengths, :34-62 OLA offsets).  f0 = exp(lf0) of the
+ * rows [row_off[u], row_off[u+1]) (the caller evaluates the exp).  Per-frame outputs have capacity `cap` (2 x rows is
+ * always enough); row0 / row1 index the batch's coefficient rows; npos is relative to the batch's noise buffer.
+ * Returns the total number of (variable-rate) frames.
+ */
+int64_t mpx_host_plan_synthesis(int32_t n_utts, const double* f0, const int64_t* row_off, double fs, int32_t fft_len,
+                                int32_t b_const_rate, int32_t b_voi_ap_win, int64_t cap, int64_t* v_shift, int64_t* v_pm,
+                                int64_t* npos, int32_t* nleft, int32_t* nright, int32_t* wtype, int32_t* voiced,
+                                int32_t* row0, int32_t* row1, double* rowt, int32_t* win_l, int32_t* win_r,
+                                int64_t* pm_rel, int64_t* frame_off, int64_t* ns_len_out, int64_t* out_start,
+                                int64_t* out_len);
+
+/*
+ * mpx_host_ola_runs: the run planner of mpx_synthesis_lossless_ola / mpx_synthesis_compressed_ola (see mpx_ola_run) in
+ * its default mode: the batch's frames are cut at `gcuts` (equal shares of the frame sequence, one per wave-pair slot)
+ * and at utterance boundaries; cuts that would let non-adjacent runs overlap are dropped.  pm_rel / frame_off: frame
+ * positions relative to each utterance's first frame; starts / out_lens: ola's kept part per utterance; out_offs:
+ * utterance offsets in pcm_out.  Returns the number of runs written (capacity n_utts + n_gcuts is always enough).
+ */
+int64_t mpx_host_ola_runs(int32_t n_utts, const int64_t* pm_rel, const int64_t* frame_off, const int64_t* starts,
+                          const int64_t* out_lens, const int64_t* out_offs, int32_t fft_len, const int64_t* gcuts,
+                          int64_t n_gcuts, mpx_ola_run* runs, int64_t cap_runs);
+
 /* sizes[i] = size of paths[i] in bytes, or -errno. */
 int32_t mpx_host_file_sizes(int32_t n, const char* const* paths, int64_t* sizes);
 

@@ -35,6 +35,9 @@ SYMBOLS = (
     "mpx_synth_comp_slots",
     "mpx_synthesis_compressed_ola",
     "mpx_host_const_to_var_scan",
+    "mpx_host_plan_analysis",
+    "mpx_host_plan_synthesis",
+    "mpx_host_ola_runs",
     "mpx_host_file_sizes",
     "mpx_host_read_est_batch",
     "mpx_host_write_files",
@@ -132,6 +135,12 @@ def _load_locked():
     lib.mpx_synthesis_compressed_ola.argtypes = [vp, ctypes.c_int, vp] + [vp] * 19 + [vp, i32, vp, vp, i32, vp, vp, i64]
     lib.mpx_host_const_to_var_scan.restype = i64
     lib.mpx_host_const_to_var_scan.argtypes = [vp, vp, i64, vp, vp]
+    lib.mpx_host_plan_analysis.restype = i64
+    lib.mpx_host_plan_analysis.argtypes = [i32] + [vp] * 12
+    lib.mpx_host_plan_synthesis.restype = i64
+    lib.mpx_host_plan_synthesis.argtypes = [i32, vp, vp, ctypes.c_double, i32, i32, i32, i64] + [vp] * 17
+    lib.mpx_host_ola_runs.restype = i64
+    lib.mpx_host_ola_runs.argtypes = [i32, vp, vp, vp, vp, vp, i32, vp, i64, vp, i64]
     lib.mpx_host_file_sizes.restype = i32
     lib.mpx_host_file_sizes.argtypes = [i32, vp, vp]
     lib.mpx_host_read_est_batch.restype = i32

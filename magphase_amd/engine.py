@@ -13,7 +13,7 @@ import os
 
 import numpy as np
 
-from . import _lib, hostmath as hm
+from . import _lib, hostmath as hm, hostplan
 
 
 def _torch():
@@ -434,8 +434,16 @@ class Engine:
 def _plan_ola_runs(plan, pm_rel_list, starts, out_lens, out_off_host, fft_len, n_slots, frames_per_run, up):
     """Shared by the two synthesis plans: runs + slot work lists (hostmath.ola_runs / balance_chunks) -> upload list."""
     fpr = frames_per_run or int(os.environ.get("MAGPHASE_OLA_FRAMES_PER_RUN", 0)) or None
-    runs, slot_off, slot_runs = hm.ola_runs(pm_rel_list, starts, out_lens, out_off_host, fft_len, n_slots,
-                                            frames_per_run=fpr)
+    try:
+        if fpr:
+            raise hostplan.PlanFallback()      # per-utterance run lengths (tests, tuning): the numpy planner only
+        sizes = [int(np.size(r)) for r in pm_rel_list]
+        rel_cat = np.concatenate([np.asarray(r, dtype=np.int64) for r in pm_rel_list]) if pm_rel_list else np.zeros(0, np.int64)
+        runs, slot_off, slot_runs = hostplan.ola_runs(rel_cat, np.concatenate(([0], np.cumsum(sizes))), starts, out_lens,
+                                                      np.asarray(out_off_host)[:len(sizes)], fft_len, n_slots)
+    except hostplan.PlanFallback:
+        runs, slot_off, slot_runs = hm.ola_runs(pm_rel_list, starts, out_lens, out_off_host, fft_len, n_slots,
+                                                frames_per_run=fpr)
     plan.n_runs = int(runs.size)
     plan.runs_host = runs
     plan.strip_floats = plan.n_runs * (int(fft_len) + 64)
@@ -500,21 +508,36 @@ class LosslessAnalysisPlan:
                 self.fft_len = N
             elif N != self.fft_len:
                 raise ValueError("all utterances of a plan must share fft_len (bucket by sample rate)")
-            pm_sec, voi = hm.clean_epochs(v_pm_sec, v_voi, check_len_smpls=n, fs=fs)
-            pm, lft, rgt = hm.frame_bounds(pm_sec * fs, n)
-            pos.append(pm + off)
-            left.append(lft)
-            right.append(rgt)
-            self.v_shift.append(lft)
-            self.v_pm.append(pm)
-            self.v_f0.append(hm.shift_to_f0(lft, voi, fs))
             self.fs.append(fs)
-            self.n_frames.append(pm.size)
             self.n_smpls.append(n)
             off += n
+        sig_off = np.concatenate(([0], np.cumsum(self.n_smpls)))[:-1] if utts else np.zeros(0)
+        try:     # the index arithmetic of the whole batch in one native call (hostplan / csrc/magphase_plan.cpp) ...
+            r = hostplan.plan_analysis([u[2] for u in utts], [u[3] for u in utts], self.n_smpls, self.fs, sig_off)
+            fo = r["frame_off"]
+            for u in range(len(utts)):
+                a, b = int(fo[u]), int(fo[u + 1])
+                self.v_shift.append(r["left"][a:b]), self.v_pm.append(r["pm"][a:b]), self.v_f0.append(r["f0"][a:b])
+                self.n_frames.append(b - a)
+            pos, left, right = [r["pos"]], [r["left"]], [r["right"]]
+        except hostplan.PlanFallback:   # ... or utterance by utterance in numpy (same arithmetic; raises what it raises)
+            for (v_sig, fs, v_pm_sec, v_voi), n, o in zip(utts, self.n_smpls, sig_off):
+                pm_sec, voi = hm.clean_epochs(v_pm_sec, v_voi, check_len_smpls=n, fs=fs)
+                pm, lft, rgt = hm.frame_bounds(pm_sec * fs, n)
+                pos.append(pm + int(o))
+                left.append(lft)
+                right.append(rgt)
+                self.v_shift.append(lft)
+                self.v_pm.append(pm)
+                self.v_f0.append(hm.shift_to_f0(lft, voi, fs))
+                self.n_frames.append(pm.size)
         self.total_frames = int(sum(self.n_frames))
         self.frame_off = np.concatenate(([0], np.cumsum(self.n_frames))).astype(np.int64)
-        self.long_frame_lens = [(l + r + 1)[(l + r + 1) > self.fft_len].tolist() for l, r in zip(left, right)]
+        right_cat = np.concatenate(right) if right else np.zeros(0, dtype=np.int64)
+        self.long_frame_lens = []
+        for u, lft in enumerate(self.v_shift):
+            tot = lft + right_cat[int(self.frame_off[u]):int(self.frame_off[u + 1])] + 1
+            self.long_frame_lens.append(tot[tot > self.fft_len].tolist())
         e = engine
         if all_i16:
             raw = e.upload_staged((total + 1) // 2 + 2)
@@ -604,8 +627,6 @@ class CompressedSynthesisPlan:
     def __init__(self, engine, utts, fs, fft_len=None, b_voi_ap_win=True, b_const_rate=False, alpha_phase=None,
                  noise=None, frames_per_run=None, per_phase_type="magphase", post_filter=False, b_fbank_mel=False,
                  noise_mode="reference", noise_seeds=None):
-        from scipy import interpolate
-
         self.apply_post_filter = bool(post_filter)
         self.b_const_rate = bool(b_const_rate)
         if noise_mode not in ("reference", "device"):
@@ -630,9 +651,9 @@ class CompressedSynthesisPlan:
 
         a_mag, a_real, a_imag = [], [], []
         npos, nleft, nright, wtype, voiced, row0, row1, rowt, win_l, win_r = ([] for _ in range(10))
-        pm_rel, starts, lens, nfr, noises = [], [], [], [], []
+        pm_rel, starts, lens, nfr, noises, lf0s = [], [], [], [], [], []
         self.v_shift, self.v_pm, self.v_voi, self.ns_len = [], [], [], []
-        row_base, noise_base = 0, 0
+        row_base = 0
         for ui, (mml, rm, im, lf0) in enumerate(utts):
             # the coefficient matrices go to the device as float32 whatever they arrive as: no float64 round trip here
             mml, rm, im = np.atleast_2d(np.asarray(mml)), np.atleast_2d(np.asarray(rm)), np.atleast_2d(np.asarray(im))
@@ -643,50 +664,33 @@ class CompressedSynthesisPlan:
                                  % (ui, n_rows, rm.shape[0], im.shape[0], lf0.shape[0]))
             if rm.shape[1] != im.shape[1]:
                 raise ValueError("utterance %d: real and imag have different dimensions" % ui)
-            v_f0 = np.exp(lf0)                                         # magphase.py:846
-            v_voi = v_f0 > 1.0                                         # :847
-            v_shift = hm.f0_to_shift(v_f0, fs)                         # :848
-            if b_const_rate:                                           # :861-870
-                v_shift, v_locs = _const_to_variable_scan(v_shift, 5.0, fs)
-                step = fs * 5.0 / 1000
-                centres = step * np.arange(1, n_rows + 1)
-                v_voi = interpolate.interp1d(centres, v_voi, axis=0, kind="linear")(v_locs) > 0.5
-                idx = np.clip(np.searchsorted(centres, v_locs), 1, n_rows - 1)   # scipy's _call_linear bracketing
-                lo, hi = idx - 1, idx
-                t = (v_locs - centres[lo]) / (centres[hi] - centres[lo])
-            else:
-                lo = hi = np.arange(n_rows)
-                t = np.zeros(n_rows)
-            v_shift = v_shift.astype(int)                              # :879
-            v_pm = np.cumsum(v_shift)                                  # :880
-            n = v_pm.size
-            ns_len = int(v_pm[-1] + (v_pm[-1] - v_pm[-2]))             # :882
-            _, lft, rgt = hm.frame_bounds(v_pm, ns_len)                # windowing(v_ns, v_pm): magphase.py:77-98
-            if np.any(lft > N // 2) or np.any(rgt + 1 > N // 2):
-                raise ValueError("negative dimensions are not allowed")   # np.zeros(<0) in la.frm_list_to_matrix
-            se = np.r_[v_shift[0], v_shift, v_shift[-1], v_shift[-1]]   # :969
-            wl, wr = se[:n] + se[1:n + 1], se[2:n + 2] + se[3:n + 3]
-            if np.any(wl > N // 2) or np.any(wr + 1 > N // 2):
-                raise ValueError("could not broadcast input array (anti-ringing window longer than the frame)")
-            rel, start, out_len = hm.ola_plan(v_pm, N)
+            a_mag.append(mml), a_real.append(rm), a_imag.append(im), lf0s.append(lf0)
+            row_base += n_rows
+
+        def noise_for(ui, ns_len):
             if noise is not None:
                 v_ns = np.asarray(noise[ui], dtype=np.float64)
                 if v_ns.size != ns_len:
                     raise ValueError("noise length %d != ns_len %d" % (v_ns.size, ns_len))
-            elif noise_mode == "device":
-                v_ns = None                                            # generated on the GPU (mpx_noise_uniform)
-            else:
-                v_ns = np.random.uniform(-1, 1, ns_len)                # :883 (global numpy RNG, as the reference)
-            a_mag.append(mml), a_real.append(rm), a_imag.append(im)
-            npos.append(v_pm + noise_base), nleft.append(lft), nright.append(rgt)
-            wtype.append((v_voi & bool(b_voi_ap_win)).astype(np.int32))
-            voiced.append(v_voi.astype(np.int32))
-            row0.append(lo + row_base), row1.append(hi + row_base), rowt.append(t)
-            win_l.append(wl), win_r.append(wr)
-            pm_rel.append(rel), starts.append(start), lens.append(out_len), nfr.append(n), noises.append(v_ns)
-            self.v_shift.append(v_shift), self.v_pm.append(v_pm), self.v_voi.append(v_voi), self.ns_len.append(ns_len)
-            row_base += n_rows
-            noise_base += ns_len
+                return v_ns
+            if noise_mode == "device":
+                return None                                            # generated on the GPU (mpx_noise_uniform)
+            return np.random.uniform(-1, 1, ns_len)                    # :883 (global numpy RNG, as the reference)
+
+        try:    # index arithmetic of the whole batch in one native call (hostplan / csrc/magphase_plan.cpp) ...
+            r = hostplan.plan_synthesis([np.exp(l) for l in lf0s], fs, N, b_const_rate, b_voi_ap_win)   # :846
+        except hostplan.PlanFallback:   # ... or utterance by utterance in numpy: the same arithmetic, spelled out
+            r = plan_synthesis_numpy(lf0s, fs, N, b_const_rate, b_voi_ap_win)
+        fo = r["frame_off"]
+        for ui in range(len(utts)):
+            a_, b_ = int(fo[ui]), int(fo[ui + 1])
+            self.v_shift.append(r["v_shift"][a_:b_]), self.v_pm.append(r["v_pm"][a_:b_])
+            self.v_voi.append(r["voiced"][a_:b_].astype(bool)), self.ns_len.append(int(r["ns_len"][ui]))
+            starts.append(int(r["out_start"][ui])), lens.append(int(r["out_len"][ui])), nfr.append(b_ - a_)
+            pm_rel.append(r["pm_rel"][a_:b_])
+            noises.append(noise_for(ui, self.ns_len[-1]))
+        npos, nleft, nright, wtype, voiced = [r["npos"]], [r["nleft"]], [r["nright"]], [r["wtype"]], [r["voiced"]]
+        row0, row1, rowt, win_l, win_r = [r["row0"]], [r["row1"]], [r["rowt"]], [r["win_l"]], [r["win_r"]]
 
         cat = np.concatenate
         self.n_rows = row_base
@@ -883,6 +887,65 @@ class CompressedSynthesisPlan:
         if keep:
             self.debug = dict(mag=mag, real=real, imag=imag, sums=sums)
         return pcm
+
+
+def plan_synthesis_numpy(lf0s, fs, N, b_const_rate, b_voi_ap_win):
+    """
+    The per-utterance index arithmetic of synthesis_from_compressed in numpy, reference line by reference line; returns
+    the batch's tables in hostplan.plan_synthesis' layout.  The native planner (csrc/magphase_plan.cpp) is this, for the
+    whole batch in one call; this form raises what the reference's arithmetic raises and is what the tests compare the
+    native one with.
+    """
+    from scipy import interpolate
+
+    keys = ("v_shift", "v_pm", "npos", "nleft", "nright", "wtype", "voiced", "row0", "row1", "rowt", "win_l", "win_r",
+            "pm_rel")
+    acc = {k: [] for k in keys}
+    ns_lens, starts, lens, nfr = [], [], [], []
+    row_base, noise_base = 0, 0
+    for lf0 in lf0s:
+        lf0 = np.atleast_1d(np.asarray(lf0, dtype=np.float64))
+        n_rows = lf0.shape[0]
+        v_f0 = np.exp(lf0)                                         # magphase.py:846
+        v_voi = v_f0 > 1.0                                         # :847
+        v_shift = hm.f0_to_shift(v_f0, fs)                         # :848
+        if b_const_rate:                                           # :861-870
+            v_shift, v_locs = _const_to_variable_scan(v_shift, 5.0, fs)
+            step = fs * 5.0 / 1000
+            centres = step * np.arange(1, n_rows + 1)
+            v_voi = interpolate.interp1d(centres, v_voi, axis=0, kind="linear")(v_locs) > 0.5
+            idx = np.clip(np.searchsorted(centres, v_locs), 1, n_rows - 1)   # scipy's _call_linear bracketing
+            lo, hi = idx - 1, idx
+            t = (v_locs - centres[lo]) / (centres[hi] - centres[lo])
+        else:
+            lo = hi = np.arange(n_rows)
+            t = np.zeros(n_rows)
+        v_shift = v_shift.astype(int)                              # :879
+        v_pm = np.cumsum(v_shift)                                  # :880
+        n = v_pm.size
+        ns_len = int(v_pm[-1] + (v_pm[-1] - v_pm[-2]))             # :882
+        _, lft, rgt = hm.frame_bounds(v_pm, ns_len)                # windowing(v_ns, v_pm): magphase.py:77-98
+        if np.any(lft > N // 2) or np.any(rgt + 1 > N // 2):
+            raise ValueError("negative dimensions are not allowed")   # np.zeros(<0) in la.frm_list_to_matrix
+        se = np.r_[v_shift[0], v_shift, v_shift[-1], v_shift[-1]]   # :969
+        wl, wr = se[:n] + se[1:n + 1], se[2:n + 2] + se[3:n + 3]
+        if np.any(wl > N // 2) or np.any(wr + 1 > N // 2):
+            raise ValueError("could not broadcast input array (anti-ringing window longer than the frame)")
+        rel, start, out_len = hm.ola_plan(v_pm, N)
+        for k, v in (("v_shift", v_shift), ("v_pm", v_pm), ("npos", v_pm + noise_base), ("nleft", lft), ("nright", rgt),
+                     ("wtype", (v_voi & bool(b_voi_ap_win)).astype(np.int32)), ("voiced", v_voi.astype(np.int32)),
+                     ("row0", lo + row_base), ("row1", hi + row_base), ("rowt", t), ("win_l", wl), ("win_r", wr),
+                     ("pm_rel", rel)):
+            acc[k].append(v)
+        ns_lens.append(ns_len), starts.append(start), lens.append(out_len), nfr.append(n)
+        row_base += n_rows
+        noise_base += ns_len
+    i32 = ("nleft", "nright", "wtype", "voiced", "row0", "row1", "win_l", "win_r")
+    out = {k: (np.concatenate(v).astype(np.int32 if k in i32 else (np.float64 if k == "rowt" else np.int64))
+               if v else np.zeros(0)) for k, v in acc.items()}
+    out.update(frame_off=np.concatenate(([0], np.cumsum(nfr))).astype(np.int64), ns_len=np.asarray(ns_lens, dtype=np.int64),
+               out_start=np.asarray(starts, dtype=np.int64), out_len=np.asarray(lens, dtype=np.int64))
+    return out
 
 
 def _const_to_variable_scan(v_shift_c_rate, frm_rate_ms, fs):

@@ -1,0 +1,108 @@
+"""
+Batch planners in the library (csrc/magphase_plan.cpp) behind numpy-friendly wrappers.  They are the same float64 /
+integer arithmetic as the numpy forms in hostmath.py / engine.py (which remain: they are what a failed native call falls
+back to -- raising the exceptions the reference's arithmetic would -- and what tests/test_host_plans.py compares these
+against, bit for bit), for a whole batch per call instead of ~60 numpy calls per utterance.
+MAGPHASE_NATIVE_PLAN=0 disables them.
+"""
+import os
+
+import numpy as np
+
+from . import _lib
+from .hostmath import OLA_RUN_DTYPE
+
+
+class PlanFallback(Exception):
+    """The native planner declined (an utterance the numpy form raises on, or planners disabled): use the numpy form."""
+
+
+def enabled():
+    return os.environ.get("MAGPHASE_NATIVE_PLAN", "1") != "0"
+
+
+def _cat(arrs, dtype):
+    if len(arrs) == 1:
+        return np.ascontiguousarray(arrs[0], dtype=dtype).reshape(-1)
+    return np.concatenate([np.asarray(a, dtype=dtype).reshape(-1) for a in arrs])
+
+
+def plan_analysis(pm_sec_list, voi_list, n_smpls, fs_list, sig_off):
+    """-> dict(pos, pm, left, right (int64[F]), f0 (float64[F]), frame_off (int64[U+1])) for the batch."""
+    if not enabled():
+        raise PlanFallback()
+    lib = _lib.load()
+    U = len(pm_sec_list)
+    pm_sec = _cat(pm_sec_list, np.float64)
+    voi = _cat(voi_list, np.float64)
+    sizes = [int(np.size(p)) for p in pm_sec_list]
+    if [int(np.size(v)) for v in voi_list] != sizes:
+        raise PlanFallback()
+    ep_off = np.concatenate(([0], np.cumsum(sizes))).astype(np.int64)
+    E = int(ep_off[-1])
+    n_smpls = np.ascontiguousarray(n_smpls, dtype=np.int64)
+    fs = np.ascontiguousarray(fs_list, dtype=np.float64)
+    sig_off = np.ascontiguousarray(sig_off, dtype=np.int64)
+    pos, pm, left, right = (np.empty(max(E, 1), dtype=np.int64) for _ in range(4))
+    f0 = np.empty(max(E, 1), dtype=np.float64)
+    frame_off = np.empty(U + 1, dtype=np.int64)
+    F = int(lib.mpx_host_plan_analysis(U, pm_sec.ctypes.data, voi.ctypes.data, ep_off.ctypes.data, n_smpls.ctypes.data,
+                                       fs.ctypes.data, sig_off.ctypes.data, pos.ctypes.data, pm.ctypes.data,
+                                       left.ctypes.data, right.ctypes.data, f0.ctypes.data, frame_off.ctypes.data))
+    if F < 0:
+        raise PlanFallback()
+    return dict(pos=pos[:F], pm=pm[:F], left=left[:F], right=right[:F], f0=f0[:F], frame_off=frame_off)
+
+
+def plan_synthesis(f0_list, fs, fft_len, b_const_rate, b_voi_ap_win):
+    """f0_list: exp(lf0) per utterance.  -> dict of the per-frame tables of CompressedSynthesisPlan for the batch."""
+    if not enabled():
+        raise PlanFallback()
+    lib = _lib.load()
+    U = len(f0_list)
+    f0 = _cat(f0_list, np.float64)
+    row_off = np.concatenate(([0], np.cumsum([int(np.size(f)) for f in f0_list]))).astype(np.int64)
+    cap = 2 * int(row_off[-1]) + 2
+    i64 = lambda: np.empty(cap, dtype=np.int64)      # noqa: E731
+    i32 = lambda: np.empty(cap, dtype=np.int32)      # noqa: E731
+    o = dict(v_shift=i64(), v_pm=i64(), npos=i64(), nleft=i32(), nright=i32(), wtype=i32(), voiced=i32(), row0=i32(),
+             row1=i32(), rowt=np.empty(cap, dtype=np.float64), win_l=i32(), win_r=i32(), pm_rel=i64())
+    frame_off = np.empty(U + 1, dtype=np.int64)
+    ns_len, out_start, out_len = (np.empty(max(U, 1), dtype=np.int64) for _ in range(3))
+    F = int(lib.mpx_host_plan_synthesis(
+        U, f0.ctypes.data, row_off.ctypes.data, float(fs), int(fft_len), int(bool(b_const_rate)), int(bool(b_voi_ap_win)),
+        cap, o["v_shift"].ctypes.data, o["v_pm"].ctypes.data, o["npos"].ctypes.data, o["nleft"].ctypes.data,
+        o["nright"].ctypes.data, o["wtype"].ctypes.data, o["voiced"].ctypes.data, o["row0"].ctypes.data,
+        o["row1"].ctypes.data, o["rowt"].ctypes.data, o["win_l"].ctypes.data, o["win_r"].ctypes.data,
+        o["pm_rel"].ctypes.data, frame_off.ctypes.data, ns_len.ctypes.data, out_start.ctypes.data, out_len.ctypes.data))
+    if F < 0:
+        raise PlanFallback()
+    o = {k: v[:F] for k, v in o.items()}
+    o.update(frame_off=frame_off, ns_len=ns_len[:U], out_start=out_start[:U], out_len=out_len[:U], row_off=row_off)
+    return o
+
+
+def ola_runs(pm_rel_cat, frame_off, starts, out_lens, out_offs, fft_len, n_slots):
+    """hostmath.ola_runs (default equal-share mode) on the concatenated frame positions -> (runs, slot_off, slot_runs)."""
+    if not enabled():
+        raise PlanFallback()
+    lib = _lib.load()
+    frame_off = np.ascontiguousarray(frame_off, dtype=np.int64)
+    U = int(frame_off.size - 1)
+    total = int(frame_off[-1])
+    n_slots = max(1, int(n_slots))
+    gcuts = np.round(np.linspace(0, total, min(n_slots, max(total, 1)) + 1)).astype(np.int64)
+    pm_rel = np.ascontiguousarray(pm_rel_cat, dtype=np.int64)
+    starts, out_lens, out_offs = (np.ascontiguousarray(a, dtype=np.int64) for a in (starts, out_lens, out_offs))
+    cap = U + int(gcuts.size) + 1
+    runs = np.zeros(cap, dtype=OLA_RUN_DTYPE)
+    n = int(lib.mpx_host_ola_runs(U, pm_rel.ctypes.data, frame_off.ctypes.data, starts.ctypes.data, out_lens.ctypes.data,
+                                  out_offs.ctypes.data, int(fft_len), gcuts.ctypes.data, int(gcuts.size),
+                                  runs.ctypes.data, cap))
+    if n < 0:
+        raise PlanFallback()
+    runs = runs[:n]
+    ns = gcuts.size - 1
+    slot_of = np.clip(np.searchsorted(gcuts, runs["frame_begin"], side="right") - 1, 0, ns - 1)
+    slot_off = np.searchsorted(slot_of, np.arange(ns + 1), side="left").astype(np.int64)
+    return runs, slot_off, np.arange(runs.size, dtype=np.int64)

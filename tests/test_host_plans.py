@@ -184,3 +184,79 @@ def test_native_const_to_variable_scan_is_bit_identical_to_the_scipy_form(golden
     engine._const_to_variable_scan_scipy(sh, 5.0, 48000)
     t2 = time.perf_counter()
     assert (t1 - t0) * 20 < (t2 - t1)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# native batch planners (csrc/magphase_plan.cpp through magphase_amd/hostplan.py) == the numpy forms, bit for bit
+# ----------------------------------------------------------------------------------------------------------------------
+def test_native_analysis_planner_equals_numpy_form():
+    from magphase_amd import hostplan as hp, synthetic as syn
+    rng = np.random.default_rng(0)
+    utts = []
+    for u in range(8):
+        fs = (48000, 16000, 8000)[u % 3]
+        pcm, pm, voi = syn.make_utterance(10 + u, dur_s=0.4 + 0.15 * u, fs=fs)
+        utts.append((len(pcm), fs, pm, voi))
+    n0, fs0, pm0, voi0 = utts[0]
+    utts.append((n0, fs0, np.r_[pm0, pm0[-1], pm0[-1] - 1e-4, n0 / fs0 + 0.01], np.r_[voi0, 1, 0, 1]))   # repeats, past the end
+    utts.append((n0, fs0, np.r_[0.0, pm0], np.r_[1.0, voi0]))                                            # first epoch at sample 0
+    utts.append((n0, fs0, (np.arange(1, 200) + 0.5) / fs0 * 37, rng.integers(0, 2, 199).astype(float)))   # half-even ties
+    sig_off = np.concatenate(([0], np.cumsum([u[0] for u in utts])))[:-1]
+    r = hp.plan_analysis([u[2] for u in utts], [u[3] for u in utts], [u[0] for u in utts], [u[1] for u in utts], sig_off)
+    for i, (n, fs, pm_sec, voi) in enumerate(utts):
+        ps, vv = hm.clean_epochs(pm_sec, voi, check_len_smpls=n, fs=fs)
+        pm, lft, rgt = hm.frame_bounds(ps * fs, n)
+        f0 = hm.shift_to_f0(lft, vv, fs)
+        a, b = int(r["frame_off"][i]), int(r["frame_off"][i + 1])
+        assert np.array_equal(r["pm"][a:b], pm) and np.array_equal(r["pos"][a:b], pm + sig_off[i])
+        assert np.array_equal(r["left"][a:b], lft) and np.array_equal(r["right"][a:b], rgt)
+        assert np.array_equal(r["f0"][a:b], f0, equal_nan=True)
+    with pytest.raises(hp.PlanFallback):       # an utterance without epochs: left to the numpy form (which raises)
+        hp.plan_analysis([np.zeros(0)], [np.zeros(0)], [100], [48000], [0])
+
+
+@pytest.mark.parametrize("b_const_rate", [False, True])
+@pytest.mark.parametrize("fs,N", [(48000, 4096), (16000, 2048)])
+def test_native_synthesis_planner_equals_numpy_form(b_const_rate, fs, N):
+    from magphase_amd import engine, hostplan as hp
+    rng = np.random.RandomState(7 + int(b_const_rate))
+    lf0s = []
+    for u in range(7):
+        n = int(rng.randint(3, 600))
+        f0 = rng.uniform(70, 420, n)
+        seg = rng.rand(n) < 0.35
+        lf0 = np.where(seg, -1.0e10, np.log(f0))                  # la.f0_to_lf0's floor for unvoiced frames
+        lf0s.append(lf0)
+    for b_win in (True, False):
+        a = hp.plan_synthesis([np.exp(l) for l in lf0s], fs, N, b_const_rate, b_win)
+        b = engine.plan_synthesis_numpy(lf0s, fs, N, b_const_rate, b_win)
+        for k in b:
+            assert a[k].dtype == b[k].dtype or k == "rowt", k
+            assert np.array_equal(a[k], b[k]), k
+    # what the reference's arithmetic raises on, the native planner hands back to the numpy form
+    bad = [np.log(np.full(10, 5.0))]                              # f0 = 5 Hz: shifts of fs / 5 samples > N / 2
+    with pytest.raises(hp.PlanFallback):
+        hp.plan_synthesis([np.exp(l) for l in bad], fs, N, b_const_rate, True)
+    with pytest.raises(ValueError):
+        engine.plan_synthesis_numpy(bad, fs, N, False, True)
+
+
+def test_native_ola_runs_equal_numpy_form():
+    from magphase_amd import hostplan as hp
+    rng = np.random.default_rng(1)
+    for trial in range(120):
+        U, N = int(rng.integers(1, 9)), int(rng.choice([1024, 2048, 4096]))
+        n_slots = int(rng.choice([1, 3, 16, 64, 1024]))
+        rels, starts, lens = [], [], []
+        for u in range(U):
+            n = int(rng.integers(2, 400))
+            sh = rng.integers(20, N // 2 - 1, size=n)
+            if rng.random() < 0.15:
+                sh[rng.integers(0, n)] = N + rng.integers(1, 500)   # frames further apart than N: a gap of zeros
+            rel, st, ol = hm.ola_plan(np.cumsum(sh), N)
+            rels.append(rel), starts.append(st), lens.append(ol)
+        offs = np.concatenate(([0], np.cumsum(lens))).astype(np.int64)
+        a = hm.ola_runs(rels, starts, lens, offs, N, n_slots)
+        sizes = [r.size for r in rels]
+        b = hp.ola_runs(np.concatenate(rels), np.concatenate(([0], np.cumsum(sizes))), starts, lens, offs[:U], N, n_slots)
+        assert a[0].tobytes() == b[0].tobytes() and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])

@@ -19,8 +19,10 @@ sys.path.insert(0, os.path.join(ROOT, "demos"))
 import numpy as np  # noqa: E402
 
 
-def run(n_utt=128, dur=5.0, batch_utts=32, noise_mode=None):
-    """Returns a dict with the two rates (x real time) and the wall times; files live in a temporary directory."""
+def run(n_utt=128, dur=5.0, batch_utts=32, noise_mode=None, reps=3):
+    """Returns a dict with the two rates (x real time) and the wall times; files live in a temporary directory.
+    Every timed section runs `reps` times; the MEDIAN is reported (the box's page-cache write-back makes single runs
+    differ by 2-3 x), all samples are listed."""
     import make_demo_data
     from magphase_amd import iobatch, libaudio as la, synthetic as syn
 
@@ -41,23 +43,33 @@ def run(n_utt=128, dur=5.0, batch_utts=32, noise_mode=None):
         # corpus pays for them once
         nw = min(n_utt, batch_utts)
         iobatch.extract_features_corpus(wavs[:nw], os.path.join(tmp, "warm"), batch_utts=batch_utts, phase_dim=45, verbose=False)
-        rep_e = iobatch.CorpusReport()
-        t = time.time()
-        iobatch.extract_features_corpus(wavs, feats, batch_utts=batch_utts, phase_dim=45, verbose=False, report=rep_e)
-        t_ext = time.time() - t
+        ext = []
+        for _ in range(reps):
+            rep_e = iobatch.CorpusReport()
+            t = time.time()
+            iobatch.extract_features_corpus(wavs, feats, batch_utts=batch_utts, phase_dim=45, verbose=False, report=rep_e)
+            ext.append((time.time() - t, rep_e))
+        ext.sort(key=lambda x: x[0])
+        t_ext, rep_e = ext[len(ext) // 2]
         audio = n_utt * dur
         gen = {}
         for mode in ([noise_mode] if noise_mode else ["reference", "device"]):
             np.random.seed(1)
             iobatch.generate_waveforms_corpus(feats, toks[:nw], os.path.join(tmp, "warm_syn"), 60, 45, 48000,
                                               pf_type="magphase", batch_utts=batch_utts, verbose=False, noise_mode=mode)
-            rep_g = iobatch.CorpusReport()
-            t = time.time()
-            iobatch.generate_waveforms_corpus(feats, toks, os.path.join(tmp, "syn_" + mode), 60, 45, 48000,
-                                              pf_type="magphase", batch_utts=batch_utts, verbose=False, report=rep_g,
-                                              noise_mode=mode)
-            t_gen = time.time() - t
+            runs = []
+            for _ in range(reps):
+                rep_g = iobatch.CorpusReport()
+                np.random.seed(1)
+                t = time.time()
+                iobatch.generate_waveforms_corpus(feats, toks, os.path.join(tmp, "syn_" + mode), 60, 45, 48000,
+                                                  pf_type="magphase", batch_utts=batch_utts, verbose=False, report=rep_g,
+                                                  noise_mode=mode)
+                runs.append((time.time() - t, rep_g))
+            runs.sort(key=lambda x: x[0])
+            t_gen, rep_g = runs[len(runs) // 2]
             gen[mode] = {"s": round(t_gen, 3), "x_realtime": round(audio / t_gen, 1),
+                         "samples_s": [round(x[0], 3) for x in runs],
                          "stage_busy_s": {k: round(v, 3) for k, v in rep_g.items() if k.endswith("_s")}}
         first = gen.get("reference") or next(iter(gen.values()))
         return {"what": "%d wav + .est files of %.0f s @48 kHz on local disk, one process, one GPU, iobatch reader / "
@@ -66,6 +78,7 @@ def run(n_utt=128, dur=5.0, batch_utts=32, noise_mode=None):
                         "16-bit wav; noise 'reference' = numpy's global RNG drawn on the host exactly as magphase.py:883 "
                         "(the default), 'device' = counter-based generator on the GPU (opt-in)" % (n_utt, dur, batch_utts),
                 "audio_s": audio, "extraction_s": round(t_ext, 3), "extraction_x_realtime": round(audio / t_ext, 1),
+                "extraction_samples_s": [round(x[0], 3) for x in ext], "timing": "median of %d runs" % reps,
                 "generation_s": first["s"], "generation_x_realtime": first["x_realtime"],
                 "generation": gen,
                 "stage_busy_s": {"extraction": {k: round(v, 3) for k, v in rep_e.items() if k.endswith("_s")}}}
