@@ -398,6 +398,15 @@ int64_t mpx_host_plan_synthesis(int32_t n_utts, const double* f0, const int64_t*
                                 int64_t* out_len);
 
 /*
+ * mpx_host_plan_lossless_synthesis: synthesis_from_lossless's epochs and OLA offsets (magphase.py:1771-1772: v_pm =
+ * cumsum(f0_to_shift(f0, fs)).astype(int) -- float cumsum, then truncation (Q3); :34-62) for the utterances
+ * [frame_off[u], frame_off[u+1]) of f0.  Outputs v_pm, pm_rel [frames], out_start, out_len [n_utts].
+ */
+int64_t mpx_host_plan_lossless_synthesis(int32_t n_utts, const double* f0, const int64_t* frame_off, const double* fs,
+                                         int32_t fft_len, int64_t* v_pm, int64_t* pm_rel, int64_t* out_start,
+                                         int64_t* out_len);
+
+/*
  * mpx_host_ola_runs: the run planner of mpx_synthesis_lossless_ola / mpx_synthesis_compressed_ola (see mpx_ola_run) in
  * its default mode: the batch's frames are cut at `gcuts` (equal shares of the frame sequence, one per wave-pair slot)
  * and at utterance boundaries; cuts that would let non-adjacent runs overlap are dropped.  pm_rel / frame_off: frame

@@ -37,6 +37,7 @@ SYMBOLS = (
     "mpx_host_const_to_var_scan",
     "mpx_host_plan_analysis",
     "mpx_host_plan_synthesis",
+    "mpx_host_plan_lossless_synthesis",
     "mpx_host_ola_runs",
     "mpx_host_file_sizes",
     "mpx_host_read_est_batch",
@@ -139,6 +140,8 @@ def _load_locked():
     lib.mpx_host_plan_analysis.argtypes = [i32] + [vp] * 12
     lib.mpx_host_plan_synthesis.restype = i64
     lib.mpx_host_plan_synthesis.argtypes = [i32, vp, vp, ctypes.c_double, i32, i32, i32, i64] + [vp] * 17
+    lib.mpx_host_plan_lossless_synthesis.restype = i64
+    lib.mpx_host_plan_lossless_synthesis.argtypes = [i32, vp, vp, vp, i32, vp, vp, vp, vp]
     lib.mpx_host_ola_runs.restype = i64
     lib.mpx_host_ola_runs.argtypes = [i32, vp, vp, vp, vp, vp, i32, vp, i64, vp, i64]
     lib.mpx_host_file_sizes.restype = i32

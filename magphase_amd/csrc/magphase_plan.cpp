@@ -205,6 +205,39 @@ int64_t mpx_host_plan_synthesis(int32_t n_utts, const double* f0, const int64_t*
     return w;
 }
 
+// LosslessSynthesisPlan's loop: v_pm = cumsum(f0_to_shift(f0, fs)).astype(int) (float cumsum, then truncation: Q3,
+// magphase.py:1771-1772) and ola's offsets (magphase.py:34-62) per utterance.
+int64_t mpx_host_plan_lossless_synthesis(int32_t n_utts, const double* f0, const int64_t* frame_off, const double* fs,
+                                         int32_t fft_len, int64_t* v_pm, int64_t* pm_rel, int64_t* out_start,
+                                         int64_t* out_len) {
+    if (n_utts < 0 || fft_len <= 0) return -1;
+    if (n_utts > 0 && (!f0 || !frame_off || !fs || !v_pm || !pm_rel || !out_start || !out_len)) return -1;
+    const int64_t N = fft_len, half = N / 2;
+    for (int32_t u = 0; u < n_utts; ++u) {
+        const int64_t a = frame_off[u], n = frame_off[u + 1] - frame_off[u];
+        if (n < 1) return -(int64_t)(u + 2);
+        double acc = 0.0;
+        for (int64_t i = 0; i < n; ++i) {
+            const double f = f0[a + i];
+            acc += fs[u] / ((f == 0) ? 200.0 : f);
+            if (!std::isfinite(acc) || std::fabs(acc) > 1.0e15) return -(int64_t)(u + 2);
+            v_pm[a + i] = (int64_t)acc;
+        }
+        const int64_t first = v_pm[a], last = v_pm[a + n - 1], buf_len = last + N;
+        int64_t start = half - first;
+        if (start < 0) start = (buf_len + start > 0) ? buf_len + start : 0;
+        if (start > buf_len) start = buf_len;
+        const int64_t len1 = buf_len - start;
+        const int64_t last_shift = (n > 1) ? last - v_pm[a + n - 2] : last;
+        int64_t stop = last + last_shift + 1;
+        if (stop < 0) stop = (len1 + stop > 0) ? len1 + stop : 0;
+        for (int64_t i = 0; i < n; ++i) pm_rel[a + i] = v_pm[a + i] - first;
+        out_start[u] = start;
+        out_len[u] = len1 < stop ? len1 : stop;
+    }
+    return n_utts > 0 ? frame_off[n_utts] : 0;
+}
+
 // hostmath.ola_runs in its default mode (global equal shares `gcuts`, computed by the caller).  runs: capacity
 // n_utts + n_gcuts records; returns the number of runs or a negative error.
 int64_t mpx_host_ola_runs(int32_t n_utts, const int64_t* pm_rel, const int64_t* frame_off, const int64_t* starts,

@@ -571,14 +571,22 @@ class LosslessSynthesisPlan:
         self.fft_len = fft_len
         pm_rel, starts, lens, nfr = [], [], [], []
         self.v_pm = []
-        for v_f0, fs in zip(f0_list, fs_list):
-            v_pm = np.cumsum(hm.f0_to_shift(np.asarray(v_f0, dtype=np.float64), fs)).astype(int)
-            rel, start, out_len = hm.ola_plan(v_pm, fft_len)
-            self.v_pm.append(v_pm)
-            pm_rel.append(rel)
-            starts.append(start)
-            lens.append(out_len)
-            nfr.append(v_pm.size)
+        try:
+            r = hostplan.plan_lossless_synthesis(f0_list, fs_list, fft_len)
+            fo = r["frame_off"]
+            for u in range(len(f0_list)):
+                a, b = int(fo[u]), int(fo[u + 1])
+                self.v_pm.append(r["v_pm"][a:b]), pm_rel.append(r["pm_rel"][a:b])
+                starts.append(int(r["out_start"][u])), lens.append(int(r["out_len"][u])), nfr.append(b - a)
+        except hostplan.PlanFallback:
+            for v_f0, fs in zip(f0_list, fs_list):
+                v_pm = np.cumsum(hm.f0_to_shift(np.asarray(v_f0, dtype=np.float64), fs)).astype(int)
+                rel, start, out_len = hm.ola_plan(v_pm, fft_len)
+                self.v_pm.append(v_pm)
+                pm_rel.append(rel)
+                starts.append(start)
+                lens.append(out_len)
+                nfr.append(v_pm.size)
         self.out_len = [int(x) for x in lens]
         self.out_off_host = np.concatenate(([0], np.cumsum(lens))).astype(np.int64)
         self.total_out = int(self.out_off_host[-1])

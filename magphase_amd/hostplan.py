@@ -82,6 +82,28 @@ def plan_synthesis(f0_list, fs, fft_len, b_const_rate, b_voi_ap_win):
     return o
 
 
+def plan_lossless_synthesis(f0_list, fs_list, fft_len):
+    """-> dict(v_pm, pm_rel (int64[F]), frame_off (int64[U+1]), out_start, out_len (int64[U]))."""
+    if not enabled():
+        raise PlanFallback()
+    lib = _lib.load()
+    U = len(f0_list)
+    if U == 0:
+        raise PlanFallback()
+    f0 = _cat(f0_list, np.float64)
+    frame_off = np.concatenate(([0], np.cumsum([int(np.size(f)) for f in f0_list]))).astype(np.int64)
+    fs = np.ascontiguousarray(fs_list, dtype=np.float64)
+    F = int(frame_off[-1])
+    v_pm, pm_rel = np.empty(max(F, 1), dtype=np.int64), np.empty(max(F, 1), dtype=np.int64)
+    out_start, out_len = np.empty(U, dtype=np.int64), np.empty(U, dtype=np.int64)
+    rc = int(lib.mpx_host_plan_lossless_synthesis(U, f0.ctypes.data, frame_off.ctypes.data, fs.ctypes.data, int(fft_len),
+                                                  v_pm.ctypes.data, pm_rel.ctypes.data, out_start.ctypes.data,
+                                                  out_len.ctypes.data))
+    if rc < 0:
+        raise PlanFallback()
+    return dict(v_pm=v_pm[:F], pm_rel=pm_rel[:F], frame_off=frame_off, out_start=out_start, out_len=out_len)
+
+
 def ola_runs(pm_rel_cat, frame_off, starts, out_lens, out_offs, fft_len, n_slots):
     """hostmath.ola_runs (default equal-share mode) on the concatenated frame positions -> (runs, slot_off, slot_runs)."""
     if not enabled():

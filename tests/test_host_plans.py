@@ -260,3 +260,27 @@ def test_native_ola_runs_equal_numpy_form():
         sizes = [r.size for r in rels]
         b = hp.ola_runs(np.concatenate(rels), np.concatenate(([0], np.cumsum(sizes))), starts, lens, offs[:U], N, n_slots)
         assert a[0].tobytes() == b[0].tobytes() and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+
+
+def test_native_lossless_synthesis_planner_equals_numpy_form():
+    from magphase_amd import hostplan as hp
+    rng = np.random.RandomState(11)
+    f0s, fss = [], []
+    for u in range(9):
+        n = int(rng.randint(1, 500))
+        f0 = np.where(rng.rand(n) < 0.3, 0.0, rng.uniform(55, 450, n))
+        if u == 3:
+            f0[0] = np.inf                                  # first epoch at sample 0: L = 0 -> f0 = inf -> shift 0
+        if u == 4:
+            f0[:3] = 20.0                                   # first epoch beyond N / 2: ola's negative slice start
+        f0s.append(f0), fss.append((48000, 16000)[u % 2])
+    for N in (4096, 2048):
+        r = hp.plan_lossless_synthesis(f0s, fss, N)
+        for u, (f0, fs) in enumerate(zip(f0s, fss)):
+            v_pm = np.cumsum(hm.f0_to_shift(f0, fs)).astype(int)
+            rel, start, out_len = hm.ola_plan(v_pm, N)
+            a, b = int(r["frame_off"][u]), int(r["frame_off"][u + 1])
+            assert np.array_equal(r["v_pm"][a:b], v_pm) and np.array_equal(r["pm_rel"][a:b], rel)
+            assert (int(r["out_start"][u]), int(r["out_len"][u])) == (start, out_len)
+    with pytest.raises(hp.PlanFallback):
+        hp.plan_lossless_synthesis([np.array([np.nan, 100.0])], [48000], 4096)
