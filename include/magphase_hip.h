@@ -195,6 +195,17 @@ int mpx_noise_uniform(void* stream, int32_t n_utts, const uint64_t* seeds, const
                       float* out);
 
 /*
+ * The reference's noise source, np.random.uniform(-1, 1, n) drawn from numpy's GLOBAL generator (magphase.py:883), produced
+ * on the device from numpy's own state: key [624] (DEVICE uint32) and pos are np.random.get_state()[1:3]; out [n_samples]
+ * gets float32(-1 + 2 d), d = the 53-bit doubles random_sample() would return (two MT19937 words each) -- bit-identical to
+ * the host draw --, key_out [624] / pos_out [1] (DEVICE) the state numpy is left in after those draws (the caller puts it
+ * back with np.random.set_state).  raw: DEVICE scratch of 2 * n_samples uint32.  One workgroup runs the recurrence
+ * (454 words per barrier), a second kernel converts.
+ */
+int mpx_noise_numpy_mt19937(void* stream, const uint32_t* key, int32_t pos, int64_t n_samples, uint32_t* raw,
+                            float* out, uint32_t* key_out, int32_t* pos_out);
+
+/*
  * Noise-gain statistics (magphase.py:886-903, Q10/Q11): for every frame, the windowed noise frame
  * (frame_wtype 0: Hann halves, 1: np.bartlett**2.5 halves; epoch at index 0) is transformed and
  * out_sum[f] = sum_{k=1}^{N/2-1} (ln|Ns[k]|)^2.  The host turns the per-class means into the two gains per utterance.

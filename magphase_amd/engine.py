@@ -138,6 +138,25 @@ class Engine:
             host.copy_(out)
         return host[:total].numpy()
 
+    def numpy_global_uniform(self, n):
+        """np.random.uniform(-1, 1, n).astype(float32) drawn from numpy's global generator, on the device
+        (mpx_noise_numpy_mt19937): same values, and the global state is left where the host draw would leave it."""
+        torch = _torch()
+        st = np.random.get_state()
+        if st[0] != "MT19937":
+            raise RuntimeError("numpy's global generator is not MT19937")
+        key = torch.from_numpy(np.ascontiguousarray(st[1], dtype=np.uint32).view(np.int32)).to(self.device)
+        out = self.empty((max(int(n), 1),))
+        raw = torch.empty(max(2 * int(n), 1), dtype=torch.int32, device=self.device)
+        state = torch.empty(625, dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.mpx_noise_numpy_mt19937(self.stream_ptr(), key.data_ptr(), int(st[2]), int(n),
+                                                        raw.data_ptr(), out.data_ptr(), state.data_ptr(),
+                                                        state.data_ptr() + 4 * 624), "mpx_noise_numpy_mt19937")
+            h = state.cpu().numpy()          # synchronises: the state goes back before anyone else draws
+        np.random.set_state((st[0], h[:624].view(np.uint32).copy(), int(h[624]), st[3], st[4]))
+        return out[:int(n)]
+
     def host_staging(self, n_floats):
         """float32 numpy view [n_floats] of a page-locked staging buffer (grown on demand, reused by every plan)."""
         torch = _torch()
@@ -681,8 +700,8 @@ class CompressedSynthesisPlan:
                 if v_ns.size != ns_len:
                     raise ValueError("noise length %d != ns_len %d" % (v_ns.size, ns_len))
                 return v_ns
-            if noise_mode == "device":
-                return None                                            # generated on the GPU (mpx_noise_uniform)
+            if noise_mode == "device" or mt_device:
+                return None                                            # generated on the GPU
             return np.random.uniform(-1, 1, ns_len)                    # :883 (global numpy RNG, as the reference)
 
         try:    # index arithmetic of the whole batch in one native call (hostplan / csrc/magphase_plan.cpp) ...
@@ -690,6 +709,12 @@ class CompressedSynthesisPlan:
         except hostplan.PlanFallback:   # ... or utterance by utterance in numpy: the same arithmetic, spelled out
             r = plan_synthesis_numpy(lf0s, fs, N, b_const_rate, b_voi_ap_win)
         fo = r["frame_off"]
+        # Reference noise (np.random.uniform from numpy's GLOBAL generator, magphase.py:883) for more than a few
+        # utterances is continued on the device from numpy's own MT19937 state (mpx_noise_numpy_mt19937: the same
+        # samples, the state put back advanced) -- the host draw is 4 ns per sample, 0.13 s per 128 utterances.
+        mt_total = int(np.sum(r["ns_len"]))
+        mt_device = (noise_mode == "reference" and noise is None and mt_total >= (1 << 18)
+                     and os.environ.get("MAGPHASE_MT_DEVICE", "1") != "0" and np.random.get_state()[0] == "MT19937")
         for ui in range(len(utts)):
             a_, b_ = int(fo[ui]), int(fo[ui + 1])
             self.v_shift.append(r["v_shift"][a_:b_]), self.v_pm.append(r["v_pm"][a_:b_])
@@ -729,7 +754,7 @@ class CompressedSynthesisPlan:
             self.noise_off_host = cat(([0], np.cumsum(self.ns_len))).astype(np.int64)
             _up.append(("noise_seeds_dev", seeds.view(np.int64), np.int64))
             _up.append(("noise_off_dev", self.noise_off_host, np.int64))
-        else:
+        elif not mt_device:
             _up.append(("noise", cat(noises), np.float32))
         _up.append(("npos", cat(npos), np.int64))
         _up.append(("nleft", cat(nleft), np.int32))
@@ -770,6 +795,8 @@ class CompressedSynthesisPlan:
                 _lib.check(e.lib.mpx_noise_uniform(e.stream_ptr(), len(nfr), self.noise_seeds_dev.data_ptr(),
                                                    self.noise_off_dev.data_ptr(), int(max(self.ns_len)),
                                                    self.noise.data_ptr()), "mpx_noise_uniform")
+        elif mt_device:
+            self.noise = e.numpy_global_uniform(mt_total)
 
     @property
     def gains(self):

@@ -93,3 +93,26 @@ def test_device_noise_generation_is_independent_of_batching():
     np.random.seed(3)
     ref = mp.synthesis_from_compressed_batch([utts[0]], 48000)[0]
     assert abs(np.std(ref) / np.std(a[0]) - 1.0) < 0.05
+
+
+@pytest.mark.gpu
+def test_numpy_global_generator_continued_on_the_device():
+    """mpx_noise_numpy_mt19937: np.random.uniform(-1, 1, n) from numpy's GLOBAL MT19937 state, produced on the device --
+    the same float32 samples as the host draw and the same generator state afterwards (any position in the 624-word
+    block, lengths around the block and the 454-word step boundaries)."""
+    from magphase_amd.engine import get_engine
+    e = get_engine()
+    for seed, warm, n in ((1, 0, 5), (2, 311, 700), (3, 1, 1000), (5, 623, 312), (7, 0, 312), (9, 100, 311), (11, 17, 227),
+                          (13, 0, 1), (4, 5, 300001)):
+        np.random.seed(seed)
+        np.random.uniform(size=warm)
+        st = np.random.get_state()
+        want = np.random.uniform(-1, 1, n).astype(np.float32)
+        after = np.random.get_state()
+        nxt = np.random.uniform(-1, 1, 7)
+        np.random.set_state(st)
+        got = e.numpy_global_uniform(n).cpu().numpy()
+        now = np.random.get_state()
+        assert np.array_equal(got, want), (seed, warm, n)
+        assert np.array_equal(now[1], after[1]) and now[2] == after[2] and now[3:] == after[3:]
+        assert np.array_equal(np.random.uniform(-1, 1, 7), nxt)          # and the stream goes on identically
