@@ -251,8 +251,8 @@ def extract_features_corpus(wav_files, out_dir, batch_utts=16, fft_len=None, mag
     lu.mkdir(out_dir)
 
     def load(files):
-        # wav reads are one short read each; the epoch tracks (text) are parsed by the library in one call
-        wavs = _io_map(la.read_audio_file_pcm, files)    # 16-bit PCM stays int16: the plan converts it in one pass
+        # the bytes of the wavs and the parsed epoch tracks (text) each come from one native call (a few threads, no GIL)
+        wavs = la.read_audio_files_pcm_batch(files)      # 16-bit PCM stays int16: the plan converts it in one pass
         eps = mp._epochs_for_batch(files)
         utts, failed = [], []
         for f, w, ep in zip(files, wavs, eps):

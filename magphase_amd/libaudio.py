@@ -17,15 +17,22 @@ MAGIC = hm.MAGIC
 def _read_wav_raw(filepath):
     """(samples as stored, fs, scale): mono PCM 16 / 24 / 32-bit or IEEE float32 RIFF wav, parsed directly (the wave
     module copies the frames twice and knows no float wavs)."""
-    import struct
-
     with open(filepath, "rb") as fh:
         buf = fh.read()
-    if len(buf) < 12 or buf[:4] != b"RIFF" or buf[8:12] != b"WAVE":
+    return _parse_wav(buf, filepath)
+
+
+def _parse_wav(buf, filepath="<buffer>"):
+    """_read_wav_raw on the file's bytes (bytes, or a uint8 numpy array as read_files_batch returns them)."""
+    import struct
+
+    if isinstance(buf, np.ndarray):
+        buf = memoryview(np.ascontiguousarray(buf, dtype=np.uint8)).cast("B")
+    if len(buf) < 12 or bytes(buf[:4]) != b"RIFF" or bytes(buf[8:12]) != b"WAVE":
         raise ValueError("%s: not a RIFF/WAVE file" % filepath)
     pos, fmt, data = 12, None, None
     while pos + 8 <= len(buf):
-        cid, size = buf[pos:pos + 4], struct.unpack_from("<I", buf, pos + 4)[0]
+        cid, size = bytes(buf[pos:pos + 4]), struct.unpack_from("<I", buf, pos + 4)[0]
         if cid == b"fmt ":
             fmt = struct.unpack_from("<HHIIHH", buf, pos + 8)
             if fmt[0] == 0xFFFE and size >= 26:      # WAVE_FORMAT_EXTENSIBLE: the real tag is the sub-format's first word
@@ -72,6 +79,24 @@ def read_audio_file_pcm(filepath):
     if v.dtype == np.dtype("<i2"):
         return v, fs
     return v.astype(np.float64) * scale, fs
+
+
+def read_audio_files_pcm_batch(paths):
+    """read_audio_file_pcm for a list of files: the bytes of all files in one native call (read_files_batch), the RIFF
+    headers parsed here.  [(samples, fs) | Exception] in input order."""
+    out = []
+    for p, raw in zip(paths, read_files_batch(paths, dtype=np.uint8)):
+        if isinstance(raw, Exception):
+            out.append(raw)
+            continue
+        try:
+            v, fs, scale = _parse_wav(raw, p)
+            out.append((v, fs) if v.dtype == np.dtype("<i2") else (v.astype(np.float64) * scale, fs))
+        except (KeyboardInterrupt, SystemExit):
+            raise
+        except Exception as e:
+            out.append(e)
+    return out
 
 
 def write_audio_file(filepath, v_signal, fs, norm=0.98):

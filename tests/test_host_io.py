@@ -88,3 +88,35 @@ def test_wav_written_with_header(tmp_path):
     assert open(p, "rb").read() == open(q, "rb").read()
     sig, fs = la.read_audio_file_pcm(p)
     assert fs == 16000 and np.array_equal(sig, pcm)
+
+
+def test_wav_batch_reader_formats_and_errors(tmp_path):
+    """la.read_audio_files_pcm_batch: the files' bytes in one native call, RIFF parsing as read_audio_file_pcm (16-bit PCM
+    stays int16; 24 / 32-bit PCM and float32 become float64 in [-1, 1)); a bad file costs one entry."""
+    import struct
+    rng = np.random.default_rng(2)
+    pcm = rng.integers(-32768, 32767, 3000).astype(np.int16)
+    la.write_pcm16_file(str(tmp_path / "a.wav"), pcm, 16000)
+    f32 = rng.uniform(-1, 1, 777).astype("<f4")
+    with open(tmp_path / "f.wav", "wb") as fh:
+        fh.write(struct.pack("<4sI4s4sIHHIIHH4sI", b"RIFF", 36 + f32.nbytes, b"WAVE", b"fmt ", 16, 3, 1, 48000, 48000 * 4, 4, 32,
+                             b"data", f32.nbytes))
+        fh.write(f32.tobytes())
+    i24 = rng.integers(-(1 << 23), (1 << 23) - 1, 500)
+    b24 = np.stack([(i24 >> s) & 0xFF for s in (0, 8, 16)], axis=1).astype(np.uint8)
+    with open(tmp_path / "t.wav", "wb") as fh:
+        fh.write(struct.pack("<4sI4s4sIHHIIHH4sI", b"RIFF", 36 + b24.size, b"WAVE", b"fmt ", 16, 1, 1, 22050, 22050 * 3, 3, 24,
+                             b"data", b24.size))
+        fh.write(b24.tobytes())
+    (tmp_path / "junk.wav").write_bytes(b"not a wav at all")
+    paths = [str(tmp_path / n) for n in ("a.wav", "f.wav", "missing.wav", "t.wav", "junk.wav")]
+    r = la.read_audio_files_pcm_batch(paths)
+    assert r[0][1] == 16000 and r[0][0].dtype == np.int16 and np.array_equal(r[0][0], pcm)
+    assert r[1][1] == 48000 and np.array_equal(r[1][0], f32.astype(np.float64))
+    assert isinstance(r[2], FileNotFoundError)
+    assert r[3][1] == 22050 and np.array_equal(r[3][0], i24 / 8388608.0)
+    assert isinstance(r[4], ValueError)
+    for p, got in zip(paths, r):
+        if not isinstance(got, Exception):
+            one = la.read_audio_file_pcm(p)
+            assert one[1] == got[1] and np.array_equal(one[0], got[0])
