@@ -188,11 +188,9 @@ __global__ __launch_bounds__(256) void k_mel_warp(WarpJobs jobs, long long F, in
 // frm_list_to_matrix + fftshift) -> N-point real FFT -> Ns[k] for the bins kappa(lane) + 64 j, j = 0..P-1
 // (natural j), plus the Nyquist bin (real) on the lane with kappa == 0.  Synchronous staging (no prefetch).
 template <int P, bool PRESTAGED = false>   // PRESTAGED: the caller already copied tile 0 into xbuf and waited for it
-__device__ __forceinline__ void noise_spectrum(const FrameGeom& g, int wtype, const float* tw, float* xbuf,
-                                               unsigned xbuf_byte, int lane, float wl_c, float wl_s,
-                                               float (&nr)[P], float (&ni)[P], float& nM) {
-    constexpr int M = 64 * P, N = 2 * M, LB = ilog2(P), kTile = 64 * P;
-    float re[P], im[P];
+__device__ __forceinline__ void noise_fft(const FrameGeom& g, int wtype, const float* tw, float* xbuf,
+                                          unsigned xbuf_byte, int lane, float (&re)[P], float (&im)[P]) {
+    constexpr int M = 64 * P, N = 2 * M, kTile = 64 * P;
 #pragma unroll
     for (int j = 0; j < P; ++j) re[j] = im[j] = 0.0f;
     const int ntiles = (g.len + kTile - 1) / kTile;
@@ -223,7 +221,58 @@ __device__ __forceinline__ void noise_spectrum(const FrameGeom& g, int wtype, co
         wave_sync();
     }
     wave_fft<P, -1>(re, im, tw, xbuf, lane);
+}
 
+// Spectrum of the windowed noise frame in PAIRED layout: lane l (kappa = kappa(l)) gets, for q < P/2, its own bin
+// k = kappa + 64 q (no_*) and the mirrored bin M - k (nm_*) from ONE evaluation of the real-FFT split's E / T terms
+// (X[k] = E + T, X[M-k] = conj(E - T)): P lane exchanges and P/2 split evaluations per lane instead of 2P and P of the
+// per-bin form.  The kappa == 0 lane's q == 0 pair is (DC, Nyquist); bin M/2 is its own mirror and comes out separately
+// (nh_*, meaningful on the kappa == 0 lane).
+template <int P, bool PRESTAGED = false>
+__device__ __forceinline__ void noise_spectrum_paired(const FrameGeom& g, int wtype, const float* tw, float* xbuf,
+                                                      unsigned xbuf_byte, int lane, float wl_c, float wl_s,
+                                                      float (&no_r)[P / 2], float (&no_i)[P / 2], float (&nm_r)[P / 2],
+                                                      float (&nm_i)[P / 2], float& nh_r, float& nh_i) {
+    constexpr int LB = ilog2(P);
+    float re[P], im[P];
+    noise_fft<P, PRESTAGED>(g, wtype, tw, xbuf, xbuf_byte, lane, re, im);
+    const int kap = kappa<P>(lane);
+    const int src_lane = kappa<P>((64 - kap) & 63);
+    const bool lane0 = (kap == 0);
+    float zpr[P / 2], zpi[P / 2];   // all partner bins first: P lane exchanges in flight together
+#pragma unroll
+    for (int q = 0; q < P / 2; ++q) {
+        const int i = brev(q, LB);
+        zpr[q] = __shfl(re[P - 1 - i], src_lane);
+        zpi[q] = __shfl(im[P - 1 - i], src_lane);
+    }
+#pragma unroll
+    for (int q = 0; q < P / 2; ++q) {
+        const int i = brev(q, LB);
+        const int i0 = brev((P - q) % P, LB);
+        const float pr = lane0 ? re[i0] : zpr[q];
+        const float pi = lane0 ? im[i0] : zpi[q];
+        const float er = 0.5f * (re[i] + pr), ei = 0.5f * (im[i] - pi);
+        const float orr = 0.5f * (im[i] + pi), oi = -0.5f * (re[i] - pr);
+        const float cq = cos2p<P>(q), sq = -sin2p<P>(q);   // W_N^k = W_N^kappa * e^{-2 pi i q/(2P)}
+        const float wr = wl_c * cq - wl_s * sq, wi = wl_c * sq + wl_s * cq;
+        const float tr = wr * orr - wi * oi, ti = wr * oi + wi * orr;
+        no_r[q] = er + tr;
+        no_i[q] = ei + ti;
+        nm_r[q] = er - tr;
+        nm_i[q] = ti - ei;
+    }
+    nh_r = re[1];    // bin M/2 = register brev(P/2) = 1 of the kappa == 0 lane: X = conj Z
+    nh_i = -im[1];
+}
+
+template <int P, bool PRESTAGED = false>   // PRESTAGED: the caller already copied tile 0 into xbuf and waited for it
+__device__ __forceinline__ void noise_spectrum(const FrameGeom& g, int wtype, const float* tw, float* xbuf,
+                                               unsigned xbuf_byte, int lane, float wl_c, float wl_s,
+                                               float (&nr)[P], float (&ni)[P], float& nM) {
+    constexpr int LB = ilog2(P);
+    float re[P], im[P];
+    noise_fft<P, PRESTAGED>(g, wtype, tw, xbuf, xbuf_byte, lane, re, im);
     // real-FFT split for every own bin (redundant form: each lane evaluates X[k] for all its bins)
     const int kap = kappa<P>(lane);
     const int src_lane = kappa<P>((64 - kap) & 63);
@@ -282,17 +331,22 @@ __global__ __launch_bounds__(kAnaThreads) void k_noise_stats(const float* __rest
         float wl_s = wl_s0, wl_c = wl_c0;
         asm volatile("" : "+v"(lane), "+v"(wl_s), "+v"(wl_c));
         const FrameGeom g = frame_geom(noise, npos[f], nleft[f], nright[f], N);
-        float nr[P], ni[P], nM;
-        noise_spectrum<P>(g, wtype[f], tw, xbuf, xbuf_byte, lane, wl_c, wl_s, nr, ni, nM);
+        float no_r[P / 2], no_i[P / 2], nm_r[P / 2], nm_i[P / 2], nh_r, nh_i;
+        noise_spectrum_paired<P>(g, wtype[f], tw, xbuf, xbuf_byte, lane, wl_c, wl_s, no_r, no_i, nm_r, nm_i, nh_r, nh_i);
         // sum over bins 1..M-1 of (ln|Ns|)^2 = (0.5 ln |Ns|^2)^2 ; |Ns| == 0 -> protected log MAGIC = -1e10 (libaudio.py:241-248)
+        // paired layout: own bin + mirror per step; the kappa == 0 lane's first pair is (DC, Nyquist), both excluded, and
+        // that lane adds bin M/2
         const bool lane0 = (kappa<P>(lane) == 0);
-        float acc = 0.0f;
+        auto term = [](float xr_, float xi_) {
+            const float s_ = xr_ * xr_ + xi_ * xi_;
+            const float lg = (s_ > 0.0f) ? 0.5f * __logf(s_) : -1.0e10f;
+            return lg * lg;
+        };
+        float acc = lane0 ? term(nh_r, nh_i) : 0.0f;
 #pragma unroll
-        for (int q = 0; q < P; ++q) {
-            const float s = nr[q] * nr[q] + ni[q] * ni[q];
-            const float lg = (s > 0.0f) ? 0.5f * __logf(s) : -1.0e10f;
-            const float term = lg * lg;
-            acc += (q == 0 && lane0) ? 0.0f : term;   // bin 0 excluded
+        for (int q = 0; q < P / 2; ++q) {
+            const float tq = term(no_r[q], no_i[q]) + term(nm_r[q], nm_i[q]);
+            acc += (q == 0 && lane0) ? 0.0f : tq;
         }
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
@@ -854,104 +908,193 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_synth_comp_pair(const f
         advance(nxt);
         const int fi = cur.fi;
 
-        // ---- aperiodic source: spectrum of this frame's windowed noise, bins k = lane + 64 j
-        float xr[P], xi[P], nM;
-        {
-            staged_wait<0>();
-            noise_spectrum<P, true>(g, tb.wtype[fi], tw, xbuf, xbuf_byte, lane, wa_c, wa_s, xr, xi, nM);
-            if (P != 32) {   // FFT output lanes hold bins kappa(lane)+64j; everything below wants bins lane+64j
-                const int src = kappa<P>(lane);
-#pragma unroll
-                for (int j = 0; j < P; ++j) {
-                    xr[j] = __shfl(xr[j], src);
-                    xi[j] = __shfl(xi[j], src);
-                }
-                nM = __shfl(nM, src);
-            }
-        }
-
-        // ---- spectrum assembly (Appendix A2 steps 9-12) in place, HB register rows at a time: all loads of a batch are
-        // issued together and branch-free (one memory latency per batch)
+        float xr[P], xi[P];
         const int voiced = tb.voiced[fi];
         const float ig = tb.inv_gain[fi];
-        const int r0 = LERP ? tb.row0[fi] : fi, r1 = LERP ? tb.row1[fi] : fi;
-        const float rt = LERP ? tb.rowt[fi] : 0.0f;   // 0 when r0 == r1: the lerp below is then exact
         const float* apc = voiced ? ap_v : ap_u;    // aperiodic curve of the frame's class (uniform select)
         const float pvs = voiced ? 1.0f : 0.0f;     // periodic component only in voiced frames
         const float sgn_scale = ((lane & 1) ? -1.0f : 1.0f) * (0.5f / (float)M);
-        const float* m0p = mag + (long long)r0 * ld;
-        const float* a0p = real + (long long)r0 * ld;
-        const float* b0p = imag + (long long)r0 * ld;
-        const float* m1p = mag + (long long)r1 * ld;
-        const float* a1p = real + (long long)r1 * ld;
-        const float* b1p = imag + (long long)r1 * ld;
-        float xm = 0.0f;
-#ifndef MPX_COMP_FEAT_ROWS
-#define MPX_COMP_FEAT_ROWS 16
-#endif
-        constexpr int HB = MPX_COMP_FEAT_ROWS;   // register rows per batch: 8 x HB loads in flight
+        if constexpr (!LERP) {
+            // ---- aperiodic source in PAIRED layout: own bins k = lane + 64 q and their mirrors M - k, q < P/2 (one
+            // evaluation of the split per pair), then the spectrum assembly (Appendix A2 steps 9-12) on the same pairs
+            // with the features loaded ascending / descending, and the Hermitian merge without a second round of lane
+            // exchanges (merge_paired_complex): against the per-bin form 2P fewer lane exchanges and half the split /
+            // merge arithmetic per frame.
+            constexpr int HP = P / 2;
+            float no_r[HP], no_i[HP], nm_r[HP], nm_i[HP], nh_r, nh_i;
+            staged_wait<0>();
+            noise_spectrum_paired<P, true>(g, tb.wtype[fi], tw, xbuf, xbuf_byte, lane, wa_c, wa_s, no_r, no_i, nm_r, nm_i,
+                                           nh_r, nh_i);
+            if (P != 32) {   // FFT output lanes hold bins kappa(lane) + 64 q; everything below wants bins lane + 64 q
+                const int src = kappa<P>(lane);
 #pragma unroll
-        for (int h = 0; h < P / HB; ++h) {
-            float m0[HB], a0[HB], b0[HB], m1[HB], a1[HB], b1[HB], cpv[HB], cap[HB];
-            // keep each half's loads where they are written: hoisted above the noise spectrum (or into the other
-            // half) they cost 190 spilled registers
-            // (the compiler moves loads of read-only memory across plain barriers: the lane offset is laundered with a
-            // fake dependency on the last value produced before this half)
-            int lo = lane;
-            {
-                const int c0 = (h == 0) ? 0 : (h - 1) * HB, c1 = (h == 0) ? P : h * HB;   // everything produced so far
-#pragma unroll
-                for (int c = c0; c < c1; c += 8)
-                    asm volatile("" : "+v"(lo)
-                                 : "v"(xr[c]), "v"(xr[c + 1]), "v"(xr[c + 2]), "v"(xr[c + 3]), "v"(xr[c + 4]), "v"(xr[c + 5]),
-                                   "v"(xr[c + 6]), "v"(xr[c + 7]), "v"(xi[c]), "v"(xi[c + 1]), "v"(xi[c + 2]), "v"(xi[c + 3]),
-                                   "v"(xi[c + 4]), "v"(xi[c + 5]), "v"(xi[c + 6]), "v"(xi[c + 7]));
-            }
-#pragma unroll
-            for (int jj = 0; jj < HB; ++jj) {
-                const int k = 64 * (h * HB + jj);
-                m0[jj] = m0p[lo + k];
-                a0[jj] = a0p[lo + k];
-                b0[jj] = b0p[lo + k];
-                if (LERP) {
-                    m1[jj] = m1p[lo + k];
-                    a1[jj] = a1p[lo + k];
-                    b1[jj] = b1p[lo + k];
+                for (int q = 0; q < HP; ++q) {
+                    no_r[q] = __shfl(no_r[q], src);
+                    no_i[q] = __shfl(no_i[q], src);
+                    nm_r[q] = __shfl(nm_r[q], src);
+                    nm_i[q] = __shfl(nm_i[q], src);
                 }
-                cpv[jj] = per_v[lo + k];
-                cap[jj] = apc[lo + k];
+                nh_r = __shfl(nh_r, src);
+                nh_i = __shfl(nh_i, src);
             }
-#pragma unroll
-            for (int jj = 0; jj < HB; ++jj) {
-                const int j = h * HB + jj;
-                // linear interpolation between constant-rate rows (magphase.py:2242-2252); rt == 0 for variable-rate input
-                const float m = LERP ? fmaf(m1[jj] - m0[jj], rt, m0[jj]) : m0[jj];
-                const float a = LERP ? fmaf(a1[jj] - a0[jj], rt, a0[jj]) : a0[jj];
-                const float b = LERP ? fmaf(b1[jj] - b0[jj], rt, b0[jj]) : b0[jj];
+            const float* mrow = mag + (long long)fi * ld;
+            const float* arow = real + (long long)fi * ld;
+            const float* brow = imag + (long long)fi * ld;
+            auto assemble = [&](float m, float a, float b, float cpv, float cap, float n_r, float n_i, bool real_only,
+                                float& o_r, float& o_i) {
                 const float s = a * a + b * b;
-                const float u = (s > 0.0f) ? m * cpv[jj] * pvs * __builtin_amdgcn_rsqf(s) : 0.0f;
-                const float apf = m * cap[jj] * ig;
-                float vr = fmaf(xr[j], apf, a * u), vi = fmaf(xi[j], apf, b * u);
-                if (j == 0 && lane == 0) {   // DC: X = |X| (magphase.py:958-961)
+                const float u = (s > 0.0f) ? m * cpv * pvs * __builtin_amdgcn_rsqf(s) : 0.0f;
+                const float apf = m * cap * ig;
+                float vr = fmaf(n_r, apf, a * u), vi = fmaf(n_i, apf, b * u);
+                if (real_only) {   // DC and Nyquist: X = |X| (magphase.py:958-961)
                     vr = __builtin_sqrtf(vr * vr + vi * vi);
                     vi = 0.0f;
                 }
-                xr[j] = vr * sgn_scale;
-                xi[j] = vi * sgn_scale;
+                o_r = vr * sgn_scale;
+                o_i = vi * sgn_scale;
+            };
+            constexpr int QB = (HP < 8) ? HP : 8;   // pairs per batch: 10 QB loads in flight
+#pragma unroll
+            for (int h = 0; h < HP / QB; ++h) {
+                float m0[QB], a0[QB], b0[QB], c0[QB], d0[QB], m1[QB], a1[QB], b1[QB], c1[QB], d1[QB];
+                // keep each batch's loads where they are written (the compiler moves loads of read-only memory across plain
+                // barriers; hoisted above the noise spectrum they spill): the lane offset is laundered with a fake
+                // dependency on what has been produced so far
+                int lo = lane;
+                {
+                    const int q0 = (h == 0) ? 0 : (h - 1) * QB, q1 = (h == 0) ? HP : h * QB;
+#pragma unroll
+                    for (int c = q0; c < q1; c += 4)
+                        asm volatile("" : "+v"(lo)
+                                     : "v"(no_r[c]), "v"(no_r[c + 1]), "v"(no_r[c + 2]), "v"(no_r[c + 3]), "v"(no_i[c]),
+                                       "v"(no_i[c + 1]), "v"(no_i[c + 2]), "v"(no_i[c + 3]), "v"(nm_r[c]), "v"(nm_r[c + 1]),
+                                       "v"(nm_r[c + 2]), "v"(nm_r[c + 3]), "v"(nm_i[c]), "v"(nm_i[c + 1]), "v"(nm_i[c + 2]),
+                                       "v"(nm_i[c + 3]));
+                }
+                const int hi_ = M - lo;
+#pragma unroll
+                for (int jj = 0; jj < QB; ++jj) {
+                    const int k = 64 * (h * QB + jj);
+                    m0[jj] = mrow[lo + k];
+                    a0[jj] = arow[lo + k];
+                    b0[jj] = brow[lo + k];
+                    c0[jj] = per_v[lo + k];
+                    d0[jj] = apc[lo + k];
+                    m1[jj] = mrow[hi_ - k];
+                    a1[jj] = arow[hi_ - k];
+                    b1[jj] = brow[hi_ - k];
+                    c1[jj] = per_v[hi_ - k];
+                    d1[jj] = apc[hi_ - k];
+                }
+#pragma unroll
+                for (int jj = 0; jj < QB; ++jj) {
+                    const int q = h * QB + jj;
+                    const bool ends = (q == 0) && (lane == 0);   // the (DC, Nyquist) pair
+                    assemble(m0[jj], a0[jj], b0[jj], c0[jj], d0[jj], no_r[q], no_i[q], ends, no_r[q], no_i[q]);
+                    assemble(m1[jj], a1[jj], b1[jj], c1[jj], d1[jj], nm_r[q], nm_i[q], ends, nm_r[q], nm_i[q]);
+                }
             }
-        }
-        if (lane == 0) {   // Nyquist bin: the noise spectrum is real there; X = |X|
-            const float m = LERP ? fmaf(m1p[M] - m0p[M], rt, m0p[M]) : m0p[M];
-            const float a = LERP ? fmaf(a1p[M] - a0p[M], rt, a0p[M]) : a0p[M];
-            const float b = LERP ? fmaf(b1p[M] - b0p[M], rt, b0p[M]) : b0p[M];
-            const float s = a * a + b * b;
-            const float u = (s > 0.0f) ? m * per_v[M] * pvs * __builtin_amdgcn_rsqf(s) : 0.0f;
-            const float apf = m * apc[M] * ig;
-            const float vr = fmaf(nM, apf, a * u), vi = b * u;
-            xm = __builtin_sqrtf(vr * vr + vi * vi) * (0.5f / (float)M);   // (-1)^M = +1
-        }
+            // bin M/2 (lane 0): every lane loads "its" bin M/2 + lane (a lane-0-only load becomes a scalar load with an
+            // immediate wait, see feat_load_paired); only lane 0's value is used by the merge
+            float xh_r, xh_i;
+            assemble(mrow[M / 2 + lane], arow[M / 2 + lane], brow[M / 2 + lane], per_v[M / 2 + lane], apc[M / 2 + lane], nh_r,
+                     nh_i, false, xh_r, xh_i);
+            merge_paired_complex<P>(no_r, no_i, nm_r, nm_i, xh_r, xh_i, xr, xi, lane, ws_c, ws_s);
+        } else {
+            // ---- aperiodic source: spectrum of this frame's windowed noise, bins k = lane + 64 j
+            float nM;
+            {
+                staged_wait<0>();
+                noise_spectrum<P, true>(g, tb.wtype[fi], tw, xbuf, xbuf_byte, lane, wa_c, wa_s, xr, xi, nM);
+                if (P != 32) {   // FFT output lanes hold bins kappa(lane)+64j; everything below wants bins lane+64j
+                    const int src = kappa<P>(lane);
+    #pragma unroll
+                    for (int j = 0; j < P; ++j) {
+                        xr[j] = __shfl(xr[j], src);
+                        xi[j] = __shfl(xi[j], src);
+                    }
+                    nM = __shfl(nM, src);
+                }
+            }
 
-        hermitian_merge<P>(xr, xi, xm, lane, ws_c, ws_s);
+            // ---- spectrum assembly (Appendix A2 steps 9-12) in place, HB register rows at a time: all loads of a batch are
+            // issued together and branch-free (one memory latency per batch)
+            const int r0 = LERP ? tb.row0[fi] : fi, r1 = LERP ? tb.row1[fi] : fi;
+            const float rt = LERP ? tb.rowt[fi] : 0.0f;   // 0 when r0 == r1: the lerp below is then exact
+            const float* m0p = mag + (long long)r0 * ld;
+            const float* a0p = real + (long long)r0 * ld;
+            const float* b0p = imag + (long long)r0 * ld;
+            const float* m1p = mag + (long long)r1 * ld;
+            const float* a1p = real + (long long)r1 * ld;
+            const float* b1p = imag + (long long)r1 * ld;
+            float xm = 0.0f;
+    #ifndef MPX_COMP_FEAT_ROWS
+    #define MPX_COMP_FEAT_ROWS 16
+    #endif
+            constexpr int HB = MPX_COMP_FEAT_ROWS;   // register rows per batch: 8 x HB loads in flight
+    #pragma unroll
+            for (int h = 0; h < P / HB; ++h) {
+                float m0[HB], a0[HB], b0[HB], m1[HB], a1[HB], b1[HB], cpv[HB], cap[HB];
+                // keep each half's loads where they are written: hoisted above the noise spectrum (or into the other
+                // half) they cost 190 spilled registers
+                // (the compiler moves loads of read-only memory across plain barriers: the lane offset is laundered with a
+                // fake dependency on the last value produced before this half)
+                int lo = lane;
+                {
+                    const int c0 = (h == 0) ? 0 : (h - 1) * HB, c1 = (h == 0) ? P : h * HB;   // everything produced so far
+    #pragma unroll
+                    for (int c = c0; c < c1; c += 8)
+                        asm volatile("" : "+v"(lo)
+                                     : "v"(xr[c]), "v"(xr[c + 1]), "v"(xr[c + 2]), "v"(xr[c + 3]), "v"(xr[c + 4]), "v"(xr[c + 5]),
+                                       "v"(xr[c + 6]), "v"(xr[c + 7]), "v"(xi[c]), "v"(xi[c + 1]), "v"(xi[c + 2]), "v"(xi[c + 3]),
+                                       "v"(xi[c + 4]), "v"(xi[c + 5]), "v"(xi[c + 6]), "v"(xi[c + 7]));
+                }
+    #pragma unroll
+                for (int jj = 0; jj < HB; ++jj) {
+                    const int k = 64 * (h * HB + jj);
+                    m0[jj] = m0p[lo + k];
+                    a0[jj] = a0p[lo + k];
+                    b0[jj] = b0p[lo + k];
+                    if (LERP) {
+                        m1[jj] = m1p[lo + k];
+                        a1[jj] = a1p[lo + k];
+                        b1[jj] = b1p[lo + k];
+                    }
+                    cpv[jj] = per_v[lo + k];
+                    cap[jj] = apc[lo + k];
+                }
+    #pragma unroll
+                for (int jj = 0; jj < HB; ++jj) {
+                    const int j = h * HB + jj;
+                    // linear interpolation between constant-rate rows (magphase.py:2242-2252); rt == 0 for variable-rate input
+                    const float m = LERP ? fmaf(m1[jj] - m0[jj], rt, m0[jj]) : m0[jj];
+                    const float a = LERP ? fmaf(a1[jj] - a0[jj], rt, a0[jj]) : a0[jj];
+                    const float b = LERP ? fmaf(b1[jj] - b0[jj], rt, b0[jj]) : b0[jj];
+                    const float s = a * a + b * b;
+                    const float u = (s > 0.0f) ? m * cpv[jj] * pvs * __builtin_amdgcn_rsqf(s) : 0.0f;
+                    const float apf = m * cap[jj] * ig;
+                    float vr = fmaf(xr[j], apf, a * u), vi = fmaf(xi[j], apf, b * u);
+                    if (j == 0 && lane == 0) {   // DC: X = |X| (magphase.py:958-961)
+                        vr = __builtin_sqrtf(vr * vr + vi * vi);
+                        vi = 0.0f;
+                    }
+                    xr[j] = vr * sgn_scale;
+                    xi[j] = vi * sgn_scale;
+                }
+            }
+            if (lane == 0) {   // Nyquist bin: the noise spectrum is real there; X = |X|
+                const float m = LERP ? fmaf(m1p[M] - m0p[M], rt, m0p[M]) : m0p[M];
+                const float a = LERP ? fmaf(a1p[M] - a0p[M], rt, a0p[M]) : a0p[M];
+                const float b = LERP ? fmaf(b1p[M] - b0p[M], rt, b0p[M]) : b0p[M];
+                const float s = a * a + b * b;
+                const float u = (s > 0.0f) ? m * per_v[M] * pvs * __builtin_amdgcn_rsqf(s) : 0.0f;
+                const float apf = m * apc[M] * ig;
+                const float vr = fmaf(nM, apf, a * u), vi = b * u;
+                xm = __builtin_sqrtf(vr * vr + vi * vi) * (0.5f / (float)M);   // (-1)^M = +1
+            }
+
+            hermitian_merge<P>(xr, xi, xm, lane, ws_c, ws_s);
+        }
         wave_fft_front<P, +1>(xr, xi, tw, xbuf, lane);
         if (nxt.valid) {   // the exchange buffer is idle from here on: start the copy of the next frame's noise
             g = frame_geom(noise, tb.npos[nxt.fi], tb.nleft[nxt.fi], tb.nright[nxt.fi], N);

@@ -312,6 +312,39 @@ __device__ __forceinline__ void feat_merge_paired(const PairFeat<P>& ff, float (
     }
 }
 
+// feat_merge_paired's second half for spectra that are already complex (k_synth_comp_pair): xo = X[k] of the own bins
+// k = lane + 64 j, xm = X[M - k] of their mirrors (j < P/2), xh = X[M/2] (lane 0), all including the (-1)^k / 2M factor.
+template <int P>
+__device__ __forceinline__ void merge_paired_complex(const float (&xo_r)[P / 2], const float (&xo_i)[P / 2],
+                                                     const float (&xm_r)[P / 2], const float (&xm_i)[P / 2], float xh_r,
+                                                     float xh_i, float (&xr)[P], float (&xi)[P], int lane, float wl_c,
+                                                     float wl_s) {
+    constexpr int HP = P / 2;
+    const bool lane0 = (lane == 0);
+    float zr[HP], zi[HP];   // Z[M - k]
+#pragma unroll
+    for (int j = 0; j < HP; ++j) {
+        // E = X + conj(Xp), T = X - conj(Xp), O = conj(W_N^k) T   (conj(W_N^k) = e^{+2 pi i (lane/N + j/2P)})
+        const float er = xo_r[j] + xm_r[j], ei = xo_i[j] - xm_i[j], tr = xo_r[j] - xm_r[j], ti = xo_i[j] + xm_i[j];
+        const float cq = cos2p<P>(j), sq = sin2p<P>(j);
+        const float wr = wl_c * cq - wl_s * sq, wi = wl_c * sq + wl_s * cq;
+        const float orr = wr * tr - wi * ti, oi = wr * ti + wi * tr;
+        xr[j] = er - oi;
+        xi[j] = ei + orr;
+        zr[j] = er + oi;
+        zi[j] = orr - ei;
+    }
+    const float hr = 2.0f * xh_r, hi = -2.0f * xh_i;   // bin M/2 (lane 0): Z = 2 conj(X)
+    const int src_lane = (64 - lane) & 63;
+#pragma unroll
+    for (int r = HP; r < P; ++r) {
+        const float pr = lane0 ? ((r == HP) ? hr : zr[P - r]) : zr[P - 1 - r];
+        const float pi = lane0 ? ((r == HP) ? hi : zi[P - r]) : zi[P - 1 - r];
+        xr[r] = __shfl(pr, src_lane);
+        xi[r] = __shfl(pi, src_lane);
+    }
+}
+
 // Ring of R strip elements, stored as two halves: even strip positions b in ringE[b/2 mod R/2], odd ones in
 // ringO.  A lane's two samples (2m, 2m+1) of a frame then hit ringE/ringO[c + m] with m consecutive across
 // lanes: conflict-free 4-byte accesses whatever the parity of the frame position (ring_add below).
