@@ -428,6 +428,14 @@ int64_t mpx_host_ola_runs(int32_t n_utts, const int64_t* pm_rel, const int64_t* 
                           const int64_t* out_lens, const int64_t* out_offs, int32_t fft_len, const int64_t* gcuts,
                           int64_t n_gcuts, mpx_ola_run* runs, int64_t cap_runs);
 
+/* dst[i] = (double)src[i], i < n, on a few threads: the float32 -> float64 widening of the array API's outputs (the
+ * reference's arrays are float64, magphase.py:457-476; numpy's astype is one thread at ~1.5 GB/s). */
+int32_t mpx_host_widen_f32(const float* src, double* dst, int64_t n, int32_t n_threads);
+
+/* dst[i] = (float)src[i] (round to nearest even, numpy's astype), i < n, on a few threads: the array API's float64 inputs
+ * on their way to the device. */
+int32_t mpx_host_narrow_f64(const double* src, float* dst, int64_t n, int32_t n_threads);
+
 /* sizes[i] = size of paths[i] in bytes, or -errno. */
 int32_t mpx_host_file_sizes(int32_t n, const char* const* paths, int64_t* sizes);
 

@@ -136,6 +136,28 @@ const char* parse_double(const char* p, const char* end, double* v) {
 
 extern "C" {
 
+int32_t mpx_host_widen_f32(const float* src, double* dst, int64_t n, int32_t n_threads) {
+    if (n < 0 || (n > 0 && (!src || !dst))) return MPX_ERR_ARG;
+    const int64_t kBlock = 1 << 18;   // 1 MB of input per task
+    const int nb = (int)((n + kBlock - 1) / kBlock);
+    parallel_for(nb, n_threads, [&](int b) {
+        const int64_t a = (int64_t)b * kBlock, e = (a + kBlock < n) ? a + kBlock : n;
+        for (int64_t i = a; i < e; ++i) dst[i] = (double)src[i];
+    });
+    return MPX_OK;
+}
+
+int32_t mpx_host_narrow_f64(const double* src, float* dst, int64_t n, int32_t n_threads) {
+    if (n < 0 || (n > 0 && (!src || !dst))) return MPX_ERR_ARG;
+    const int64_t kBlock = 1 << 17;   // 1 MB of input per task
+    const int nb = (int)((n + kBlock - 1) / kBlock);
+    parallel_for(nb, n_threads, [&](int b) {
+        const int64_t a = (int64_t)b * kBlock, e = (a + kBlock < n) ? a + kBlock : n;
+        for (int64_t i = a; i < e; ++i) dst[i] = (float)src[i];   // round to nearest even, as numpy's astype
+    });
+    return MPX_OK;
+}
+
 int32_t mpx_host_file_sizes(int32_t n, const char* const* paths, int64_t* sizes) {
     if (n < 0 || (n > 0 && (!paths || !sizes))) return MPX_ERR_ARG;
     for (int i = 0; i < n; ++i) {

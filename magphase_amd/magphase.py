@@ -135,8 +135,9 @@ def analysis_lossless_batch(utts, fft_len=None, engine=None, return_device=False
         if return_device:
             feats = (mag[a:b], real[a:b], imag[a:b])
         else:
-            # fresh arrays owned by the caller, like the reference's (a one-utterance batch already is one)
-            feats = h_feats if len(utts) == 1 else tuple(h[a:b].copy() for h in h_feats)
+            # the utterance's rows of the batch's arrays (disjoint views: no second pass over the 0.7 GB a 16-utterance
+            # batch returns; a one-utterance batch is its own array)
+            feats = h_feats if len(utts) == 1 else tuple(h[a:b] for h in h_feats)
         out.append(feats + (plan.v_f0[u], plan.fs[u], plan.v_shift[u].astype(int)))
     return out
 
@@ -181,6 +182,11 @@ def synthesis_from_lossless_batch(feats, engine=None):
         if len(feats) == 1 and torch.is_tensor(feats[0][k]) and feats[0][k].dtype == torch.float32:
             cat.append(feats[0][k])
             continue
+        if not any(torch.is_tensor(f[k]) for f in feats):   # host arrays: narrowed into pinned staging, one DMA
+            buf = engine.feats_cat_to_device([f[k] for f in feats], H)
+            if buf is not None:
+                cat.append(buf)
+                continue
         buf = engine.empty_feats(int(rows[-1]), H)
         for u, f in enumerate(feats):
             part = f[k] if torch.is_tensor(f[k]) else torch.from_numpy(np.ascontiguousarray(f[k], dtype=np.float32))
