@@ -312,9 +312,13 @@ def measure_e2e(utts):
 
 # ------------------------------------------------------------------------------------------------------------------
 def _kernel_source_hash():
+    """sha1 of the DEVICE sources (csrc/*.hip, *.hpp): what the committed PMC traffic was measured on.  The host-only
+    .cpp files (file helpers, planners) do not change a kernel's traffic."""
     h = hashlib.sha1()
     d = os.path.join(ROOT, "magphase_amd", "csrc")
     for f in sorted(os.listdir(d)):
+        if not f.endswith((".hip", ".hpp")):
+            continue
         with open(os.path.join(d, f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:12]
