@@ -953,7 +953,10 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_synth_comp_pair(const f
                 o_r = vr * sgn_scale;
                 o_i = vi * sgn_scale;
             };
-            constexpr int QB = (HP < 8) ? HP : 8;   // pairs per batch: 10 QB loads in flight
+#ifndef MPX_COMP_QB
+#define MPX_COMP_QB 8
+#endif
+            constexpr int QB = (HP < MPX_COMP_QB) ? HP : MPX_COMP_QB;   // pairs per batch: 10 QB loads in flight
 #pragma unroll
             for (int h = 0; h < HP / QB; ++h) {
                 float m0[QB], a0[QB], b0[QB], c0[QB], d0[QB], m1[QB], a1[QB], b1[QB], c1[QB], d1[QB];
@@ -1305,7 +1308,10 @@ __global__ __launch_bounds__(256) void k_mel_warp_mfma(WarpJobs jobs, long long 
 // tile's KH MFMAs; C: column j0 + (l & 31), row (r & 3) + 8 (r >> 2) + 4 (l >> 5) of register r.
 // ---------------------------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr int kUnwarpColTiles = 16;   // 512 bins per task
+#ifndef MPX_UNWARP_COL_TILES
+#define MPX_UNWARP_COL_TILES 16
+#endif
+constexpr int kUnwarpColTiles = MPX_UNWARP_COL_TILES;   // 512 bins per task
 
 // MODE 0: one output row per row of A.  MODE 1 / 2 (constant -> variable frame rate, magphase.py:2242-2252 folded in):
 // output row f is the interpolation between rows row0[f] and row1[f] of the unwarped A with weight rowt[f] --

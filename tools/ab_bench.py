@@ -49,7 +49,7 @@ def prepare(name, ref, flags):
             shutil.copytree(os.path.join(ROOT, d), os.path.join(dst, d),
                             ignore=shutil.ignore_patterns("__pycache__", "*.so", "*.pyc"))
     csrc = os.path.join(dst, "magphase_amd", "csrc")
-    srcs = [os.path.join(csrc, f) for f in sorted(os.listdir(csrc)) if f.endswith(".hip")]
+    srcs = [os.path.join(csrc, f) for f in sorted(os.listdir(csrc)) if f.endswith((".hip", ".cpp"))]
     from magphase_amd import build
 
     cmd = [build.hipcc_path()] + build.FLAGS + flags + srcs + ["-o", os.path.join(dst, "magphase_amd", "libmagphase_hip.so")]
