@@ -167,11 +167,15 @@ int mpx_mel_unwarp(void* stream, int64_t n_frames, int32_t n_bins, const float* 
  * coefficient matrices -- out_mag = lerp(exp(U a[row0]), exp(U a[row1])), out_real / out_imag = U lerp(a[row0], a[row1])
  * (the phase unwarp is linear).  The [rows x n_bins] spectra are written once, at the variable rate, and the synthesis
  * kernel reads one row per frame.  row0, row1: DEVICE int32[n_frames]; row_t: DEVICE float32[n_frames].
+ * tile_first (optional, with n_rows = number of constant-rate rows): DEVICE int32[ceil(n_rows / 31) + 1], tile_first[T] =
+ * the first frame whose row0 >= 31 T (row0 ascending, row1 - row0 in {0, 1}: what the constant -> variable scan yields);
+ * the magnitudes are then unwarped once per constant-rate ROW and interpolated out of an LDS tile (same values, 44 % fewer
+ * products).  NULL: two products per frame.
  */
 int mpx_mel_unwarp_rows(void* stream, int64_t n_frames, int32_t n_bins, const float* a_mag, int32_t k_mag,
                         const float* u_mag, float* out_mag, const float* a_real, const float* a_imag, int32_t k_phase,
                         const float* u_phase, float* out_real, float* out_imag, int64_t ld, const int32_t* row0,
-                        const int32_t* row1, const float* row_t);
+                        const int32_t* row1, const float* row_t, int64_t n_rows, const int32_t* tile_first);
 
 /*
  * Row pitch the unwarped spectra (outputs of mpx_mel_unwarp / mpx_min_phase, inputs of mpx_synthesis_compressed_ola)

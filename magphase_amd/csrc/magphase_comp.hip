@@ -101,7 +101,10 @@ __device__ __forceinline__ float warp_epilogue(int mode, float y, float vo) {
 }
 
 constexpr int kWarpTile = 64;
-constexpr int kWarpStride = 68;   // floats per LDS row (multiple of 4 for float4 reads)
+#ifndef MPX_WARP_STRIDE
+#define MPX_WARP_STRIDE 68
+#endif
+constexpr int kWarpStride = MPX_WARP_STRIDE;   // floats per LDS row (multiple of 4 for float4 reads)
 
 __global__ __launch_bounds__(256) void k_mel_warp(WarpJobs jobs, long long F, int H, const int* __restrict__ row0,
                                                   const int* __restrict__ row1, const float* __restrict__ rowt,
@@ -1474,6 +1477,138 @@ static int dispatch_unwarp_mfma(hipStream_t s, const UnwarpJobs& jobs, int job0,
     return fail(MPX_ERR_ARG, "mpx_mel_unwarp: coefficient count must be in 1..64%s");
 }
 
+// Magnitude unwarp with the constant -> variable rate interpolation, ONE product per constant-rate row (MODE 2 above
+// forms two per variable-rate frame: adjacent frames share their rows, 44 % of its MFMAs are repeats).  A task = 32
+// constant-rate rows (tiles advance by 31 rows: a frame's two rows are adjacent, so both lie in the tile its row0 falls
+// into) x kUnwarpColTiles column tiles.  Per 64-bin step the exp'd 32 x 64 tile goes through a per-wave LDS buffer
+// (row stride 72 floats: the accumulator's two half-waves write rows a and a + 4, 32 banks apart) and every
+// variable-rate frame of the tile -- [tile_first[T], tile_first[T + 1]), planned on the host -- reads its two rows
+// back (lane = bin: 256 contiguous bytes), interpolates with fmaf(m1 - m0, t, m0) and stores its 256-byte row segment.
+// Same values as MODE 2 (each row's product is the same fmaf chain).
+constexpr int kTileRows = 31;          // new constant-rate rows per tile
+constexpr int kTileStride = 72;        // floats per LDS row
+
+template <int KH>
+__global__ __launch_bounds__(256) void k_mel_unwarp_tiled(UnwarpJob job, long long F, long long n_rows, int H,
+                                                          int col_parts, long long n_tasks, int ld,
+                                                          const int* __restrict__ row0, const int* __restrict__ row1,
+                                                          const float* __restrict__ rowt,
+                                                          const int* __restrict__ tile_first) {
+    __shared__ float tiles[4][32 * kTileStride];
+    const int lane = threadIdx.x & 63;
+    const int wave = rfl((int)(threadIdx.x >> 6));
+    const long long task = (long long)blockIdx.x * 4 + wave;
+    if (task >= n_tasks) return;
+    const long long row_tiles = n_tasks / col_parts;
+    const int cp = (int)(task / row_tiles);
+    const long long T = task - cp * row_tiles;
+    const long long rb = T * kTileRows;
+    const int K = job.K;
+    const int kk = lane >> 5, li = lane & 31;
+    float* tile = tiles[wave];
+
+    float a[KH];
+    {
+        const float* arow = job.A + min(rb + li, n_rows - 1) * K;
+#pragma unroll
+        for (int t = 0; t < KH; ++t) {
+            const int k = 2 * t + kk;
+            a[t] = arow[min(k, K - 1)];
+            a[t] = (k < K) ? a[t] : 0.0f;
+        }
+    }
+    const int fa = rfl(tile_first[T]), fb = rfl(tile_first[T + 1]);
+    const int jbeg = cp * (kUnwarpColTiles * 32);
+    const int jend = min(H, jbeg + kUnwarpColTiles * 32);
+    if (jbeg >= jend || fa >= fb) return;
+    float b0[KH], b1[KH];
+    const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(job.U), 0, K * H * 4, 0x00020000);
+    const int row2 = 8 * H;
+    const bool op_exp = rfl(job.op) != 0;
+    auto soff = [&](int t) { return (2 * t < K) ? t * row2 : 0; };
+    {
+        const int v0 = 4 * (kk * H + jbeg + li), v0e = 4 * (jbeg + li);
+#pragma unroll
+        for (int t = 0; t < KH; ++t) {
+            const int v = (2 * t + 1 == K) ? v0e : v0;
+            b0[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(urs, v, soff(t), 0));
+            b1[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(urs, v + 128, soff(t), 0));
+        }
+    }
+    for (int j0 = jbeg; j0 < jend; j0 += 64) {
+        const int vn0 = 4 * (kk * H + j0 + 64 + li), vn0e = 4 * (j0 + 64 + li);
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.0f;
+#pragma unroll
+        for (int t = 0; t < KH; ++t) {
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b0[t], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b1[t], acc1, 0, 0, 0);
+            const int v = (2 * t + 1 == K) ? vn0e : vn0;
+            b0[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(urs, v, soff(t), 0));
+            b1[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(urs, v + 128, soff(t), 0));
+        }
+        wave_sync();   // the previous step's readers are done with the tile
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * kk;
+            tile[row * kTileStride + li] = op_exp ? __expf(acc0[r]) : acc0[r];
+            tile[row * kTileStride + 32 + li] = op_exp ? __expf(acc1[r]) : acc1[r];
+        }
+        wave_sync();
+        const bool col_ok = j0 + lane < jend;
+        for (int fc = fa; fc < fb; fc += 64) {
+            // lane i holds the tables of frame fc + i; the loop below broadcasts them one frame at a time
+            const int fl = min(fc + lane, fb - 1);
+            const int rv = row0[fl] - (int)rb;
+            const int dv = row1[fl] - row0[fl];
+            const float tv = rowt[fl];
+            const int cnt = min(64, fb - fc);
+            // four frames per iteration: their eight LDS reads are in flight together (one frame at a time the loop is a
+            // chain of LDS round trips)
+            float* orow = job.out + (long long)fc * ld + j0 + lane;
+            for (int i = 0; i < cnt; i += 4) {
+                float m0[4], m1[4], w[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int iu = min(i + u, cnt - 1);
+                    const int r = __builtin_amdgcn_readlane(rv, iu);
+                    const int d = __builtin_amdgcn_readlane(dv, iu);
+                    w[u] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tv), iu));
+                    m0[u] = tile[r * kTileStride + lane];
+                    m1[u] = tile[(r + d) * kTileStride + lane];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (col_ok && i + u < cnt) orow[(long long)(i + u) * ld] = fmaf(m1[u] - m0[u], w[u], m0[u]);
+            }
+        }
+    }
+}
+
+template <int KH>
+static int launch_unwarp_tiled(hipStream_t s, const UnwarpJob& job, long long F, long long n_rows, int H, int ld,
+                               const UnwarpRows& rw, const int* tile_first) {
+    const int col_parts = (H + kUnwarpColTiles * 32 - 1) / (kUnwarpColTiles * 32);
+    const long long row_tiles = (n_rows + kTileRows - 1) / kTileRows;
+    const long long n_tasks = row_tiles * col_parts;
+    hipLaunchKernelGGL((k_mel_unwarp_tiled<KH>), dim3((unsigned)((n_tasks + 3) / 4)), dim3(256), 0, s, job, F, n_rows, H,
+                       col_parts, n_tasks, ld, rw.row0, rw.row1, rw.rowt, tile_first);
+    return MPX_OK;
+}
+
+static int dispatch_unwarp_tiled(hipStream_t s, const UnwarpJob& job, int K, long long F, long long n_rows, int H, int ld,
+                                 const UnwarpRows& rw, const int* tile_first) {
+    switch ((K + 3) / 4) {
+#define MPX_UNWARP_CASE(q) case q: return launch_unwarp_tiled<2 * q>(s, job, F, n_rows, H, ld, rw, tile_first);
+        MPX_UNWARP_CASE(1) MPX_UNWARP_CASE(2) MPX_UNWARP_CASE(3) MPX_UNWARP_CASE(4) MPX_UNWARP_CASE(5) MPX_UNWARP_CASE(6)
+        MPX_UNWARP_CASE(7) MPX_UNWARP_CASE(8) MPX_UNWARP_CASE(9) MPX_UNWARP_CASE(10) MPX_UNWARP_CASE(11) MPX_UNWARP_CASE(12)
+        MPX_UNWARP_CASE(13) MPX_UNWARP_CASE(14) MPX_UNWARP_CASE(15) MPX_UNWARP_CASE(16)
+#undef MPX_UNWARP_CASE
+    }
+    return fail(MPX_ERR_ARG, "mpx_mel_unwarp: coefficient count must be in 1..64%s");
+}
+
 }  // namespace mpx
 
 using namespace mpx;
@@ -1484,7 +1619,8 @@ int64_t mpx_spec_ld(int32_t n_bins) { return n_bins <= 0 ? 0 : ((int64_t)n_bins 
 
 static int mel_unwarp_impl(void* stream, int64_t n_frames, int32_t n_bins, const float* a_mag, int32_t k_mag,
                            const float* u_mag, float* out_mag, const float* a_real, const float* a_imag, int32_t k_phase,
-                           const float* u_phase, float* out_real, float* out_imag, int64_t ld, const UnwarpRows& rw) {
+                           const float* u_phase, float* out_real, float* out_imag, int64_t ld, const UnwarpRows& rw,
+                           int64_t n_rows = 0, const int32_t* tile_first = nullptr) {
     if (n_frames < 0 || n_bins <= 0 || ld < n_bins || ld > (1 << 20)) return fail(MPX_ERR_ARG, "mpx_mel_unwarp: bad size%s");
     if (k_mag <= 0 || k_mag > kGemmKMax || k_phase <= 0 || k_phase > kGemmKMax)
         return fail(MPX_ERR_ARG, "mpx_mel_unwarp: coefficient count must be in 1..64%s");
@@ -1502,7 +1638,12 @@ static int mel_unwarp_impl(void* stream, int64_t n_frames, int32_t n_bins, const
     hipLaunchKernelGGL(k_mel_unwarp, grid, dim3(256), 0, (hipStream_t)stream, jobs, (long long)n_frames, (int)n_bins,
                        (long long)ld);
 #else
-    if (int rc = dispatch_unwarp_mfma((hipStream_t)stream, jobs, 0, 1, (int)k_mag, (long long)n_frames, (int)n_bins, (int)ld, rw)) return rc;
+    if (tile_first) {   // magnitudes: one product per constant-rate row, interpolated out of an LDS tile
+        if (int rc = dispatch_unwarp_tiled((hipStream_t)stream, jobs.j[0], (int)k_mag, (long long)n_frames, (long long)n_rows,
+                                           (int)n_bins, (int)ld, rw, tile_first)) return rc;
+    } else {
+        if (int rc = dispatch_unwarp_mfma((hipStream_t)stream, jobs, 0, 1, (int)k_mag, (long long)n_frames, (int)n_bins, (int)ld, rw)) return rc;
+    }
     if (int rc = dispatch_unwarp_mfma((hipStream_t)stream, jobs, 1, 2, (int)k_phase, (long long)n_frames, (int)n_bins, (int)ld, rw)) return rc;
 #endif
     MPX_HIP_CHECK(hipGetLastError());
@@ -1519,10 +1660,11 @@ int mpx_mel_unwarp(void* stream, int64_t n_frames, int32_t n_bins, const float* 
 int mpx_mel_unwarp_rows(void* stream, int64_t n_frames, int32_t n_bins, const float* a_mag, int32_t k_mag,
                         const float* u_mag, float* out_mag, const float* a_real, const float* a_imag, int32_t k_phase,
                         const float* u_phase, float* out_real, float* out_imag, int64_t ld, const int32_t* row0,
-                        const int32_t* row1, const float* row_t) {
+                        const int32_t* row1, const float* row_t, int64_t n_rows, const int32_t* tile_first) {
     if (!row0 || !row1 || !row_t) return fail(MPX_ERR_ARG, "mpx_mel_unwarp_rows: null row table%s");
+    if (tile_first && n_rows <= 0) return fail(MPX_ERR_ARG, "mpx_mel_unwarp_rows: tile_first needs n_rows%s");
     return mel_unwarp_impl(stream, n_frames, n_bins, a_mag, k_mag, u_mag, out_mag, a_real, a_imag, k_phase, u_phase,
-                           out_real, out_imag, ld, UnwarpRows{row0, row1, row_t});
+                           out_real, out_imag, ld, UnwarpRows{row0, row1, row_t}, n_rows, tile_first);
 }
 
 int mpx_noise_stats(void* stream, int fft_len, const void* tables, const float* noise, const int64_t* frame_pos,

@@ -789,6 +789,11 @@ class CompressedSynthesisPlan:
         _up.append(("nright", cat(nright), np.int32))
         _up.append(("wtype", cat(wtype), np.int32))
         _up.append(("voiced", cat(voiced), np.int32))
+        if self.b_const_rate:   # frames of every 31-row tile of the constant-rate matrix (mpx_mel_unwarp_rows)
+            r0c = cat(row0)
+            self._check_rows_for_tiles(r0c, cat(row1))
+            _up.append(("tile_first", np.searchsorted(r0c, 31 * np.arange((self.n_rows + 30) // 31 + 1), side="left"),
+                        np.int32))
         _up.append(("row0", cat(row0), np.int32))
         _up.append(("row1", cat(row1), np.int32))
         _up.append(("rowt", cat(rowt), np.float32))
@@ -825,6 +830,12 @@ class CompressedSynthesisPlan:
                                                    self.noise.data_ptr()), "mpx_noise_uniform")
         elif mt_device:
             self.noise = e.numpy_global_uniform(mt_total)
+
+    @staticmethod
+    def _check_rows_for_tiles(r0, r1):
+        """What the tiled unwarp relies on: row0 ascending over the batch, row1 - row0 in {0, 1}."""
+        if r0.size and (np.any(np.diff(r0) < 0) or np.any((r1 - r0) < 0) or np.any((r1 - r0) > 1)):
+            raise ValueError("constant -> variable rate tables out of order")
 
     @property
     def gains(self):
@@ -901,7 +912,7 @@ class CompressedSynthesisPlan:
                     st, self.total_frames, H, a_mag.data_ptr(), self.mag_dim, self.u_mag.data_ptr(), mag.data_ptr(),
                     self.a_real.data_ptr(), self.a_imag.data_ptr(), self.phase_dim, self.u_phase.data_ptr(),
                     real.data_ptr(), imag.data_ptr(), ld, self.row0.data_ptr(), self.row1.data_ptr(),
-                    self.rowt.data_ptr()), "mpx_mel_unwarp_rows")
+                    self.rowt.data_ptr(), self.n_rows, self.tile_first.data_ptr()), "mpx_mel_unwarp_rows")
             else:                   # variable-rate features: rows == frames
                 _lib.check(lib.mpx_mel_unwarp(st, self.n_rows, H, a_mag.data_ptr(), self.mag_dim, self.u_mag.data_ptr(),
                                               mag.data_ptr(), self.a_real.data_ptr(), self.a_imag.data_ptr(),

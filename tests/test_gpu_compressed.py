@@ -78,6 +78,16 @@ def test_unwarp_rows_equals_unwarp_then_interpolation(golden_dir):
                                     plan.a_imag.data_ptr(), plan.phase_dim, plan.u_phase.data_ptr(), full[1].data_ptr(),
                                     full[2].data_ptr(), ld), "mpx_mel_unwarp")
     torch.cuda.synchronize()
+    # the same through the two-products-per-frame form (tile_first = NULL): bit-identical magnitudes
+    alt = [e.empty((plan.total_frames, ld))[:, :H] for _ in range(3)]
+    _lib.check(e.lib.mpx_mel_unwarp_rows(e.stream_ptr(), plan.total_frames, H, plan.a_mag.data_ptr(), plan.mag_dim,
+                                         plan.u_mag.data_ptr(), alt[0].data_ptr(), plan.a_real.data_ptr(),
+                                         plan.a_imag.data_ptr(), plan.phase_dim, plan.u_phase.data_ptr(), alt[1].data_ptr(),
+                                         alt[2].data_ptr(), ld, plan.row0.data_ptr(), plan.row1.data_ptr(),
+                                         plan.rowt.data_ptr(), 0, None), "mpx_mel_unwarp_rows")
+    torch.cuda.synchronize()
+    for k, name in enumerate(("mag", "real", "imag")):
+        assert torch.equal(alt[k], plan.debug[name]), name
     r0, r1 = plan.row0.cpu().numpy(), plan.row1.cpu().numpy()
     t = plan.rowt.cpu().numpy().astype(np.float64)[:, None]
     assert plan.total_frames != plan.n_rows and np.any(t > 0)
