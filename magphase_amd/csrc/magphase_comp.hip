@@ -1488,6 +1488,8 @@ static int dispatch_unwarp_mfma(hipStream_t s, const UnwarpJobs& jobs, int job0,
 constexpr int kTileRows = 31;          // new constant-rate rows per tile
 constexpr int kTileStride = 72;        // floats per LDS row
 
+// (Dropping the two special cases for U rows past K when K == 2 KH -- fewer instructions -- made the kernel SLOWER,
+// 271 -> 350 us: the selects space the B-fragment loads out between the MFMAs; without them the compiler batches them.)
 template <int KH>
 __global__ __launch_bounds__(256) void k_mel_unwarp_tiled(UnwarpJob job, long long F, long long n_rows, int H,
                                                           int col_parts, long long n_tasks, int ld,
@@ -1495,6 +1497,7 @@ __global__ __launch_bounds__(256) void k_mel_unwarp_tiled(UnwarpJob job, long lo
                                                           const float* __restrict__ rowt,
                                                           const int* __restrict__ tile_first) {
     __shared__ float tiles[4][32 * kTileStride];
+    __shared__ __attribute__((aligned(16))) float4 tabs[4][64];
     const int lane = threadIdx.x & 63;
     const int wave = rfl((int)(threadIdx.x >> 6));
     const long long task = (long long)blockIdx.x * 4 + wave;
@@ -1506,6 +1509,7 @@ __global__ __launch_bounds__(256) void k_mel_unwarp_tiled(UnwarpJob job, long lo
     const int K = job.K;
     const int kk = lane >> 5, li = lane & 31;
     float* tile = tiles[wave];
+    float4* tab = tabs[wave];
 
     float a[KH];
     {
@@ -1524,7 +1528,7 @@ __global__ __launch_bounds__(256) void k_mel_unwarp_tiled(UnwarpJob job, long lo
     float b0[KH], b1[KH];
     const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(job.U), 0, K * H * 4, 0x00020000);
     const int row2 = 8 * H;
-    const bool op_exp = rfl(job.op) != 0;
+    constexpr bool op_exp = true;   // the tiled form is the magnitudes' (exp epilogue)
     auto soff = [&](int t) { return (2 * t < K) ? t * row2 : 0; };
     {
         const int v0 = 4 * (kk * H + jbeg + li), v0e = 4 * (jbeg + li);
@@ -1558,25 +1562,26 @@ __global__ __launch_bounds__(256) void k_mel_unwarp_tiled(UnwarpJob job, long lo
         wave_sync();
         const bool col_ok = j0 + lane < jend;
         for (int fc = fa; fc < fb; fc += 64) {
-            // lane i holds the tables of frame fc + i; the loop below broadcasts them one frame at a time
+            // lane i writes the tables of frame fc + i (tile offsets of its two rows, weight) into a small per-wave LDS
+            // table; the loop below reads one entry per frame as a broadcast -- no v_readlane / SGPR round trips (that
+            // form spent its time in scalar hazards: 26 M SALU instructions per launch)
             const int fl = min(fc + lane, fb - 1);
-            const int rv = row0[fl] - (int)rb;
-            const int dv = row1[fl] - row0[fl];
-            const float tv = rowt[fl];
+            const int r_ = row0[fl] - (int)rb;
+            const int d_ = row1[fl] - row0[fl];
+            wave_sync();
+            tab[lane] = make_float4(__builtin_bit_cast(float, r_ * kTileStride), __builtin_bit_cast(float, (r_ + d_) * kTileStride),
+                                    rowt[fl], 0.0f);
+            wave_sync();
             const int cnt = min(64, fb - fc);
-            // four frames per iteration: their eight LDS reads are in flight together (one frame at a time the loop is a
-            // chain of LDS round trips)
             float* orow = job.out + (long long)fc * ld + j0 + lane;
-            for (int i = 0; i < cnt; i += 4) {
+            for (int i = 0; i < cnt; i += 4) {   // four frames per iteration: their LDS reads are in flight together
                 float m0[4], m1[4], w[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const int iu = min(i + u, cnt - 1);
-                    const int r = __builtin_amdgcn_readlane(rv, iu);
-                    const int d = __builtin_amdgcn_readlane(dv, iu);
-                    w[u] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tv), iu));
-                    m0[u] = tile[r * kTileStride + lane];
-                    m1[u] = tile[(r + d) * kTileStride + lane];
+                    const float4 e = tab[min(i + u, cnt - 1)];
+                    m0[u] = tile[__builtin_bit_cast(int, e.x) + lane];
+                    m1[u] = tile[__builtin_bit_cast(int, e.y) + lane];
+                    w[u] = e.z;
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u)
@@ -1599,6 +1604,7 @@ static int launch_unwarp_tiled(hipStream_t s, const UnwarpJob& job, long long F,
 
 static int dispatch_unwarp_tiled(hipStream_t s, const UnwarpJob& job, int K, long long F, long long n_rows, int H, int ld,
                                  const UnwarpRows& rw, const int* tile_first) {
+    if (job.op != 1) return fail(MPX_ERR_ARG, "mpx_mel_unwarp_rows: the tiled form is the exp job's%s");
     switch ((K + 3) / 4) {
 #define MPX_UNWARP_CASE(q) case q: return launch_unwarp_tiled<2 * q>(s, job, F, n_rows, H, ld, rw, tile_first);
         MPX_UNWARP_CASE(1) MPX_UNWARP_CASE(2) MPX_UNWARP_CASE(3) MPX_UNWARP_CASE(4) MPX_UNWARP_CASE(5) MPX_UNWARP_CASE(6)
