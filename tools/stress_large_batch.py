@@ -21,9 +21,11 @@ for u in (0, 2399):
     y = pcm[a:b].cpu().numpy(); x = utts[u][0][:y.size]
     n0, n1 = 2400, min(x.size, y.size) - 2400
     err = np.max(np.abs(y[n0:n1]-x[n0:n1])); print("utt", u, "roundtrip max err %.2e" % err); assert err < 2e-5
-# identical utterances give identical outputs wherever they sit in the batch
+# identical utterances give the same output wherever they sit in the batch -- up to the fp32 re-association at the run
+# boundaries (the batch's frames are cut into equal shares, so the cuts fall differently in utterance 0 and 2360)
 a0, b0 = int(sp.out_off_host[0]), int(sp.out_off_host[1]); a1, b1 = int(sp.out_off_host[2360]), int(sp.out_off_host[2361])
-assert torch.equal(pcm[a0:b0], pcm[a1:b1])
+d = (pcm[a0:b0] - pcm[a1:b1]).abs().max().item(); print("position dependence max |d| %.2e" % d)
+assert d <= 2e-6 * pcm[a0:b0].abs().max().item()
 del mag, real, imag, pcm
 cp = CompressedAnalysisPlan(eng, utts, mag_dim=60, phase_dim=45, b_const_rate=True)
 t = time.time(); out = cp.run(); torch.cuda.synchronize(); print("compressed analysis %.1f ms, const-rate frames %d" % ((time.time()-t)*1e3, cp.total_out_frames))
