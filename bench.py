@@ -326,8 +326,11 @@ def _kernel_source_hash():
     for f in sorted(os.listdir(d)):
         if not f.endswith((".hip", ".hpp")):
             continue
-        with open(os.path.join(d, f), "rb") as fh:
-            h.update(fh.read())
+        with open(os.path.join(d, f), "r") as fh:
+            for line in fh:      # the code, not the commentary: // comments and blank lines do not count
+                code = line.split("//", 1)[0].strip()
+                if code:
+                    h.update(code.encode() + b"\n")
     return h.hexdigest()[:12]
 
 

@@ -4,7 +4,7 @@
 //                         linear maps they are, K <= 64.  fp32 VALU GEMM, A tile broadcast from LDS.
 //   k_noise_stats<P>      per frame: windowed noise frame -> FFT -> sum_k (ln|Ns[k]|)^2, k = 1..N/2-1 (Q10 gain statistics)
 //   k_synth_comp_pair<P>  per chunk of frames: noise FFT (recomputed) + periodic/aperiodic spectrum assembly
-//                         (Appendix A2 steps 9-12) + inverse FFT + anti-ringing window + LDS overlap-add (as k_synth_ola)
+//                         (Appendix A2 steps 9-12) + inverse FFT + anti-ringing window + LDS overlap-add (as k_synth_ola_pair)
 #include "mpx_common.hpp"
 
 namespace mpx {
@@ -808,7 +808,7 @@ struct CompFrameTabs {
 // at once (> 256 VGPRs); with 512 registers per wave nothing spills to scratch (scratch = VMEM = vmcnt stalls).
 // ---------------------------------------------------------------------------------------------
 // Compressed-feature synthesis + PSOLA, pair form: two waves share one LDS ring and alternate over the frames of the
-// pair's chunks (tickets in LDS, exactly as k_synth_ola_pair), 8 waves per CU.  The single-wave form it replaced (git
+// pair's runs (tickets in LDS, exactly as k_synth_ola_pair), 8 waves per CU.  The single-wave form it replaced (git
 // history) held both feature rows, the per-bin curves and the noise FFT at once (466 VGPRs, ONE wave per SIMD: at one
 // instruction per ~5.4 cycles and wave its ~7.5 k instructions per frame were the whole 1.35 ms).  Here the noise spectrum is
 // computed first and the features are folded into it in place, half a spectrum (16 register rows) at a time:
@@ -862,7 +862,7 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_synth_comp_pair(const f
     const int slot = blockIdx.x * kCompPairs + pair;
     if (slot >= nslots) return;
 
-    // cursor over this wave's frames: every second frame of every chunk of the pair's work list (see k_synth_ola_pair)
+    // cursor over this wave's frames: every second frame of every run of the pair's work list (see k_synth_ola_pair)
     struct Cursor {
         int wi, fi, ci, ticket_base, fb, fe, x0, valid;
     };
