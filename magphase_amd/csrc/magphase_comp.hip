@@ -90,7 +90,8 @@ struct WarpJobs {
 //      takes exp and la.log again (magphase.py:2505-2510): the identity unless the exp underflows to 0 (sum < ln of the
 //      smallest float64, -745.13), which comes back as -1e10
 __device__ __forceinline__ float warp_prologue(int mode, float x) {
-    if (mode == 0) return __logf(fmaf(x, x, 1.0e-8f));
+    // the argument is >= 1e-8 (never a denormal): the hardware log2 as it is, without __logf's denormal rescaling
+    if (mode == 0) return __builtin_amdgcn_logf(fmaf(x, x, 1.0e-8f)) * 0.69314718055994531f;
     if (mode == 1) return fmaf(1.0e-8f, __expf(-2.0f * x), 2.0f * x);
     return (x > 0.0f) ? __logf(x) : -1.0e10f;
 }
@@ -204,8 +205,14 @@ __device__ __forceinline__ void noise_fft(const FrameGeom& g, int wtype, const f
             staged_wait<0>();
         }
         const int hi = min(g.len, tile0 + kTile);
-        for (int k = tile0 + lane; k < hi; k += 64)
-            xbuf[k - tile0] *= half_window(k, g.L, g.LR, g.kadd, g.invL, g.invR, wtype);
+        // the window type is per frame (wave-uniform): one loop per type, not a select per sample
+        if (wtype == 0) {
+            for (int k = tile0 + lane; k < hi; k += 64)
+                xbuf[k - tile0] *= half_window(k, g.L, g.LR, g.kadd, g.invL, g.invR, 0);
+        } else {
+            for (int k = tile0 + lane; k < hi; k += 64)
+                xbuf[k - tile0] *= half_window(k, g.L, g.LR, g.kadd, g.invL, g.invR, 1);
+        }
         wave_sync();
 #pragma unroll
         for (int j = 0; j < P; ++j) {
@@ -340,16 +347,41 @@ __global__ __launch_bounds__(kAnaThreads) void k_noise_stats(const float* __rest
         // paired layout: own bin + mirror per step; the kappa == 0 lane's first pair is (DC, Nyquist), both excluded, and
         // that lane adds bin M/2
         const bool lane0 = (kappa<P>(lane) == 0);
-        auto term = [](float xr_, float xi_) {
-            const float s_ = xr_ * xr_ + xi_ * xi_;
-            const float lg = (s_ > 0.0f) ? 0.5f * __logf(s_) : -1.0e10f;
-            return lg * lg;
-        };
-        float acc = lane0 ? term(nh_r, nh_i) : 0.0f;
+        // |Ns|^2 of every bin first; the logarithm is the hardware log2 as it is (3 instructions per bin) when no bin of the
+        // frame is zero or a denormal -- always, in practice -- and __logf with its rescaling sequence otherwise (one
+        // wave-uniform branch per frame instead of a select per bin)
+        float so[P / 2], sm[P / 2];
+        const float sh = nh_r * nh_r + nh_i * nh_i;
+        float smin = lane0 ? sh : 1.0f;
 #pragma unroll
         for (int q = 0; q < P / 2; ++q) {
-            const float tq = term(no_r[q], no_i[q]) + term(nm_r[q], nm_i[q]);
-            acc += (q == 0 && lane0) ? 0.0f : tq;
+            so[q] = no_r[q] * no_r[q] + no_i[q] * no_i[q];
+            sm[q] = nm_r[q] * nm_r[q] + nm_i[q] * nm_i[q];
+            smin = fminf(smin, fminf(so[q], sm[q]));
+        }
+        float acc;
+        if (!__any(smin < 1.1754944e-38f)) {
+            auto term = [](float s_) {
+                const float lg = 0.34657359027997264f * __builtin_amdgcn_logf(s_);   // 0.5 ln 2 log2(s)
+                return lg * lg;
+            };
+            acc = lane0 ? term(sh) : 0.0f;
+#pragma unroll
+            for (int q = 0; q < P / 2; ++q) {
+                const float tq = term(so[q]) + term(sm[q]);
+                acc += (q == 0 && lane0) ? 0.0f : tq;
+            }
+        } else {
+            auto term = [](float s_) {
+                const float lg = (s_ > 0.0f) ? 0.5f * __logf(s_) : -1.0e10f;
+                return lg * lg;
+            };
+            acc = lane0 ? term(sh) : 0.0f;
+#pragma unroll
+            for (int q = 0; q < P / 2; ++q) {
+                const float tq = term(so[q]) + term(sm[q]);
+                acc += (q == 0 && lane0) ? 0.0f : tq;
+            }
         }
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) acc += __shfl_xor(acc, off);
@@ -1160,7 +1192,10 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_synth_comp_pair(const f
 // ---------------------------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-template <int NT, bool INTERP>   // NT: 16-wide column tiles in use, ceil(nout / 16); INTERP: rows interpolated (row0 given)
+// NT: 16-wide column tiles in use, ceil(nout / 16); INTERP: rows interpolated (row0 given); MODE: the job's prologue /
+// epilogue at compile time (as a run-time value it was a scalar branch per staged element: a third of the kernel's
+// instructions were SALU, and the kernel is bound by instruction issue)
+template <int NT, bool INTERP, int MODE>
 __device__ __forceinline__ void mel_warp_block(const WarpJob& job, float (*As)[kWarpStride], float (*Ws)[kWarpStride],
                                                long long* s_o0, long long* s_o1, float* s_rt, long long F, int H,
                                                const int* __restrict__ row0, const int* __restrict__ row1,
@@ -1225,7 +1260,7 @@ __device__ __forceinline__ void mel_warp_block(const WarpJob& job, float (*As)[k
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float x = INTERP ? fmaf(xin1[e] - xin[e], rt, xin[e]) : xin[e];
-                av[e] = fok ? warp_prologue(job.mode, x) : 0.0f;
+                av[e] = fok ? warp_prologue(MODE, x) : 0.0f;
                 wo[e] = (fl < job.nout) ? win[e] : 0.0f;
             }
             *reinterpret_cast<float4*>(&As[fl][4 * c4]) = make_float4(av[0], av[1], av[2], av[3]);
@@ -1266,7 +1301,7 @@ __device__ __forceinline__ void mel_warp_block(const WarpJob& job, float (*As)[k
         for (int k = Hfull; k < H; ++k) {
             const float x0 = job.x[s_o0[fl] + k];
             const float x = INTERP ? fmaf(job.x[s_o1[fl] + k] - x0, s_rt[fl], x0) : x0;
-            const float v = warp_prologue(job.mode, x);
+            const float v = warp_prologue(MODE, x);
 #pragma unroll
             for (int jt = 0; jt < NT; ++jt) {
                 const int i = 16 * jt + li;
@@ -1279,7 +1314,7 @@ __device__ __forceinline__ void mel_warp_block(const WarpJob& job, float (*As)[k
             const int i = 16 * jt + li;
             if (i >= job.nout) continue;
             float y = tot[jt][r];
-            y = warp_epilogue(job.mode, y, vo);
+            y = warp_epilogue(MODE, y, vo);
             job.out[f * job.nout + i] = y;
         }
     }
@@ -1288,7 +1323,7 @@ __device__ __forceinline__ void mel_warp_block(const WarpJob& job, float (*As)[k
 // One launch for the three jobs (separate launches end in a half-empty last round of workgroups); the magnitude job
 // (blockIdx.y == 0) and the two phase jobs get their own column-tile count (60 outputs -> 4 tiles, 45 -> 3: a quarter
 // fewer MFMAs on two thirds of the workgroups).
-template <int NTM, int NTP, bool INTERP>
+template <int NTM, int NTP, bool INTERP, int MAGMODE>
 __attribute__((amdgpu_waves_per_eu(4, 4)))   // <= 128 VGPRs: four workgroups (35 KB of LDS each) per CU, measured -5 %
 __global__ __launch_bounds__(256) void k_mel_warp_mfma(WarpJobs jobs, long long F, int H, const int* __restrict__ row0,
                                                        const int* __restrict__ row1, const float* __restrict__ rowt,
@@ -1297,8 +1332,8 @@ __global__ __launch_bounds__(256) void k_mel_warp_mfma(WarpJobs jobs, long long 
     __shared__ __attribute__((aligned(16))) float Ws[kWarpTile][kWarpStride];   // Ws[i][k]
     __shared__ long long s_o0[kWarpTile], s_o1[kWarpTile];   // element offsets of the two input rows of a frame
     __shared__ float s_rt[kWarpTile];
-    if (blockIdx.y == 0) mel_warp_block<NTM, INTERP>(jobs.j[0], As, Ws, s_o0, s_o1, s_rt, F, H, row0, row1, rowt, ld);
-    else mel_warp_block<NTP, INTERP>(jobs.j[blockIdx.y], As, Ws, s_o0, s_o1, s_rt, F, H, row0, row1, rowt, ld);
+    if (blockIdx.y == 0) mel_warp_block<NTM, INTERP, MAGMODE>(jobs.j[0], As, Ws, s_o0, s_o1, s_rt, F, H, row0, row1, rowt, ld);
+    else mel_warp_block<NTP, INTERP, 1>(jobs.j[blockIdx.y], As, Ws, s_o0, s_o1, s_rt, F, H, row0, row1, rowt, ld);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1378,7 +1413,9 @@ __global__ __launch_bounds__(256) void k_mel_unwarp_mfma(UnwarpJobs jobs, int jo
     // is 0 anyway), columns >= H read the next row's start and are never stored.
     const __amdgpu_buffer_rsrc_t urs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(job.U), 0, K * H * 4, 0x00020000);
     const int row2 = 8 * H;   // bytes between rows 2t and 2t + 2
-    const bool op_exp = rfl(job.op) != 0;
+    // MODE 1 is the linear (phase) jobs, MODE 2 the exp (magnitude) job: known at compile time (as a run-time flag both
+    // values are computed and selected for every output element)
+    const bool op_exp = (MODE == 1) ? false : ((MODE == 2) ? true : (rfl(job.op) != 0));
     const int nrows = (int)min((long long)32, F - f0);
     const int HO = ld;   // output row pitch
     const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(job.out + f0 * HO, 0, nrows * HO * 4, 0x00020000);
@@ -1774,11 +1811,17 @@ static int mel_warp_impl(void* stream, int64_t n_frames, int32_t n_bins, const f
         const int ntm = ((int)mag_dim + 15) / 16, ntp = ((int)phase_dim + 15) / 16;
 #define MPX_WARP_LAUNCH(NTM, NTP)                                                                                  \
     do {                                                                                                           \
-        if (row0)                                                                                                  \
-            hipLaunchKernelGGL((k_mel_warp_mfma<NTM, NTP, true>), g2, dim3(256), 0, (hipStream_t)stream, jobs,     \
+        if (row0 && mag_mode == 0)                                                                                 \
+            hipLaunchKernelGGL((k_mel_warp_mfma<NTM, NTP, true, 0>), g2, dim3(256), 0, (hipStream_t)stream, jobs,  \
+                               (long long)n_frames, (int)n_bins, row0, row1, row_t, (long long)ld);                \
+        else if (row0)                                                                                             \
+            hipLaunchKernelGGL((k_mel_warp_mfma<NTM, NTP, true, 2>), g2, dim3(256), 0, (hipStream_t)stream, jobs,  \
+                               (long long)n_frames, (int)n_bins, row0, row1, row_t, (long long)ld);                \
+        else if (mag_mode == 0)                                                                                    \
+            hipLaunchKernelGGL((k_mel_warp_mfma<NTM, NTP, false, 0>), g2, dim3(256), 0, (hipStream_t)stream, jobs, \
                                (long long)n_frames, (int)n_bins, row0, row1, row_t, (long long)ld);                \
         else                                                                                                       \
-            hipLaunchKernelGGL((k_mel_warp_mfma<NTM, NTP, false>), g2, dim3(256), 0, (hipStream_t)stream, jobs,    \
+            hipLaunchKernelGGL((k_mel_warp_mfma<NTM, NTP, false, 2>), g2, dim3(256), 0, (hipStream_t)stream, jobs, \
                                (long long)n_frames, (int)n_bins, row0, row1, row_t, (long long)ld);                \
     } while (0)
 #define MPX_WARP_ROW(NTM)                       \

@@ -79,7 +79,8 @@ __device__ __forceinline__ float half_window(int k, int L, int LR, int kadd, flo
     const int num = rising ? k + kadd : LR - k;
     const float inv = rising ? invL : invR;
     const float t = (float)num * inv;
-    return (wtype == 0) ? sin2_halfpi(t) : t * t * __builtin_sqrtf(t);
+    // t = k / L in [0, 1], never a denormal: the hardware square root as it is (sqrtf adds a rescaling sequence)
+    return (wtype == 0) ? sin2_halfpi(t) : t * t * __builtin_amdgcn_sqrtf(t);
 }
 
 __device__ __forceinline__ float hann_half(int k, int L, int LR, int kadd, float invL, float invR) {
