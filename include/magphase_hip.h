@@ -171,11 +171,14 @@ int mpx_mel_unwarp(void* stream, int64_t n_frames, int32_t n_bins, const float* 
  * the first frame whose row0 >= 31 T (row0 ascending, row1 - row0 in {0, 1}: what the constant -> variable scan yields);
  * the magnitudes are then unwarped once per constant-rate ROW and interpolated out of an LDS tile (same values, 44 % fewer
  * products).  NULL: two products per frame.
+ * voiced (optional): DEVICE int32[n_frames]; the PHASE rows of a 32-frame tile without a voiced frame are not computed (out_real /
+ * out_imag keep their previous content there): mpx_synthesis_compressed_ola never reads the phase rows of unvoiced frames.
  */
 int mpx_mel_unwarp_rows(void* stream, int64_t n_frames, int32_t n_bins, const float* a_mag, int32_t k_mag,
                         const float* u_mag, float* out_mag, const float* a_real, const float* a_imag, int32_t k_phase,
                         const float* u_phase, float* out_real, float* out_imag, int64_t ld, const int32_t* row0,
-                        const int32_t* row1, const float* row_t, int64_t n_rows, const int32_t* tile_first);
+                        const int32_t* row1, const float* row_t, int64_t n_rows, const int32_t* tile_first,
+                        const int32_t* voiced);
 
 /*
  * Row pitch the unwarped spectra (outputs of mpx_mel_unwarp / mpx_min_phase, inputs of mpx_synthesis_compressed_ola)

@@ -126,7 +126,7 @@ def _load_locked():
     lib.mpx_mel_unwarp.restype = ctypes.c_int
     lib.mpx_mel_unwarp.argtypes = [vp, i64, i32, vp, i32, vp, vp, vp, vp, i32, vp, vp, vp, i64]
     lib.mpx_mel_unwarp_rows.restype = ctypes.c_int
-    lib.mpx_mel_unwarp_rows.argtypes = [vp, i64, i32, vp, i32, vp, vp, vp, vp, i32, vp, vp, vp, i64, vp, vp, vp, i64, vp]
+    lib.mpx_mel_unwarp_rows.argtypes = [vp, i64, i32, vp, i32, vp, vp, vp, vp, i32, vp, vp, vp, i64, vp, vp, vp, i64, vp, vp]
     lib.mpx_spec_ld.restype = i64
     lib.mpx_spec_ld.argtypes = [i32]
     lib.mpx_noise_uniform.restype = ctypes.c_int

@@ -5,6 +5,8 @@
 //   k_noise_stats<P>      per frame: windowed noise frame -> FFT -> sum_k (ln|Ns[k]|)^2, k = 1..N/2-1 (Q10 gain statistics)
 //   k_synth_comp_pair<P>  per chunk of frames: noise FFT (recomputed) + periodic/aperiodic spectrum assembly
 //                         (Appendix A2 steps 9-12) + inverse FFT + anti-ringing window + LDS overlap-add (as k_synth_ola_pair)
+#include <type_traits>
+
 #include "mpx_common.hpp"
 
 namespace mpx {
@@ -96,7 +98,7 @@ __device__ __forceinline__ float warp_prologue(int mode, float x) {
     return (x > 0.0f) ? __logf(x) : -1.0e10f;
 }
 __device__ __forceinline__ float warp_epilogue(int mode, float y, float vo) {
-    if (mode == 1) return fminf(fmaxf(y * vo, -1.0f), 1.0f);
+    if (mode == 1) return (vo == 0.0f) ? 0.0f : fminf(fmaxf(y * vo, -1.0f), 1.0f);   // +0 for unvoiced frames, always
     if (mode == 2) return (y < -745.13321f) ? -1.0e10f : y;
     return y;
 }
@@ -975,68 +977,87 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_synth_comp_pair(const f
             const float* mrow = mag + (long long)fi * ld;
             const float* arow = real + (long long)fi * ld;
             const float* brow = imag + (long long)fi * ld;
-            auto assemble = [&](float m, float a, float b, float cpv, float cap, float n_r, float n_i, bool real_only,
-                                float& o_r, float& o_i) {
-                const float s = a * a + b * b;
-                const float u = (s > 0.0f) ? m * cpv * pvs * __builtin_amdgcn_rsqf(s) : 0.0f;
-                const float apf = m * cap * ig;
-                float vr = fmaf(n_r, apf, a * u), vi = fmaf(n_i, apf, b * u);
-                if (real_only) {   // DC and Nyquist: X = |X| (magphase.py:958-961)
-                    vr = __builtin_sqrtf(vr * vr + vi * vi);
-                    vi = 0.0f;
-                }
-                o_r = vr * sgn_scale;
-                o_i = vi * sgn_scale;
-            };
+            // Unvoiced frames have no periodic component (its mask is zero, magphase.py:873-876): the phase features and
+            // the periodic curve are neither loaded nor used -- one wave-uniform branch per frame, 4 instead of 10 loads and
+            // a third of the arithmetic per bin pair for about a third of the frames.
+            float xh_r, xh_i;
+            auto assemble_all = [&](auto voiced_tag) {
+                constexpr bool V = decltype(voiced_tag)::value;
+                auto assemble = [&](float m, float a, float b, float cpv, float cap, float n_r, float n_i, bool real_only,
+                                    float& o_r, float& o_i) {
+                    const float apf = m * cap * ig;
+                    float vr, vi;
+                    if (V) {
+                        const float s = a * a + b * b;
+                        const float u = (s > 0.0f) ? m * cpv * __builtin_amdgcn_rsqf(s) : 0.0f;
+                        vr = fmaf(n_r, apf, a * u);
+                        vi = fmaf(n_i, apf, b * u);
+                    } else {
+                        vr = n_r * apf;
+                        vi = n_i * apf;
+                    }
+                    if (real_only) {   // DC and Nyquist: X = |X| (magphase.py:958-961)
+                        vr = __builtin_sqrtf(vr * vr + vi * vi);
+                        vi = 0.0f;
+                    }
+                    o_r = vr * sgn_scale;
+                    o_i = vi * sgn_scale;
+                };
 #ifndef MPX_COMP_QB
 #define MPX_COMP_QB 8
 #endif
-            constexpr int QB = (HP < MPX_COMP_QB) ? HP : MPX_COMP_QB;   // pairs per batch: 10 QB loads in flight
+                constexpr int QB = (HP < MPX_COMP_QB) ? HP : MPX_COMP_QB;   // pairs per batch: 10 QB loads in flight
 #pragma unroll
-            for (int h = 0; h < HP / QB; ++h) {
-                float m0[QB], a0[QB], b0[QB], c0[QB], d0[QB], m1[QB], a1[QB], b1[QB], c1[QB], d1[QB];
-                // keep each batch's loads where they are written (the compiler moves loads of read-only memory across plain
-                // barriers; hoisted above the noise spectrum they spill): the lane offset is laundered with a fake
-                // dependency on what has been produced so far
-                int lo = lane;
-                {
-                    const int q0 = (h == 0) ? 0 : (h - 1) * QB, q1 = (h == 0) ? HP : h * QB;
+                for (int h = 0; h < HP / QB; ++h) {
+                    float m0[QB], a0[QB], b0[QB], c0[QB], d0[QB], m1[QB], a1[QB], b1[QB], c1[QB], d1[QB];
+                    // keep each batch's loads where they are written (the compiler moves loads of read-only memory across
+                    // plain barriers; hoisted above the noise spectrum they spill): the lane offset is laundered with a fake
+                    // dependency on what has been produced so far
+                    int lo = lane;
+                    {
+                        const int q0 = (h == 0) ? 0 : (h - 1) * QB, q1 = (h == 0) ? HP : h * QB;
 #pragma unroll
-                    for (int c = q0; c < q1; c += 4)
-                        asm volatile("" : "+v"(lo)
-                                     : "v"(no_r[c]), "v"(no_r[c + 1]), "v"(no_r[c + 2]), "v"(no_r[c + 3]), "v"(no_i[c]),
-                                       "v"(no_i[c + 1]), "v"(no_i[c + 2]), "v"(no_i[c + 3]), "v"(nm_r[c]), "v"(nm_r[c + 1]),
-                                       "v"(nm_r[c + 2]), "v"(nm_r[c + 3]), "v"(nm_i[c]), "v"(nm_i[c + 1]), "v"(nm_i[c + 2]),
-                                       "v"(nm_i[c + 3]));
+                        for (int c = q0; c < q1; c += 4)
+                            asm volatile("" : "+v"(lo)
+                                         : "v"(no_r[c]), "v"(no_r[c + 1]), "v"(no_r[c + 2]), "v"(no_r[c + 3]), "v"(no_i[c]),
+                                           "v"(no_i[c + 1]), "v"(no_i[c + 2]), "v"(no_i[c + 3]), "v"(nm_r[c]), "v"(nm_r[c + 1]),
+                                           "v"(nm_r[c + 2]), "v"(nm_r[c + 3]), "v"(nm_i[c]), "v"(nm_i[c + 1]), "v"(nm_i[c + 2]),
+                                           "v"(nm_i[c + 3]));
+                    }
+                    const int hi_ = M - lo;
+#pragma unroll
+                    for (int jj = 0; jj < QB; ++jj) {
+                        const int k = 64 * (h * QB + jj);
+                        m0[jj] = mrow[lo + k];
+                        d0[jj] = apc[lo + k];
+                        m1[jj] = mrow[hi_ - k];
+                        d1[jj] = apc[hi_ - k];
+                        if (V) {
+                            a0[jj] = arow[lo + k];
+                            b0[jj] = brow[lo + k];
+                            c0[jj] = per_v[lo + k];
+                            a1[jj] = arow[hi_ - k];
+                            b1[jj] = brow[hi_ - k];
+                            c1[jj] = per_v[hi_ - k];
+                        } else {
+                            a0[jj] = b0[jj] = c0[jj] = a1[jj] = b1[jj] = c1[jj] = 0.0f;
+                        }
+                    }
+#pragma unroll
+                    for (int jj = 0; jj < QB; ++jj) {
+                        const int q = h * QB + jj;
+                        const bool ends = (q == 0) && (lane == 0);   // the (DC, Nyquist) pair
+                        assemble(m0[jj], a0[jj], b0[jj], c0[jj], d0[jj], no_r[q], no_i[q], ends, no_r[q], no_i[q]);
+                        assemble(m1[jj], a1[jj], b1[jj], c1[jj], d1[jj], nm_r[q], nm_i[q], ends, nm_r[q], nm_i[q]);
+                    }
                 }
-                const int hi_ = M - lo;
-#pragma unroll
-                for (int jj = 0; jj < QB; ++jj) {
-                    const int k = 64 * (h * QB + jj);
-                    m0[jj] = mrow[lo + k];
-                    a0[jj] = arow[lo + k];
-                    b0[jj] = brow[lo + k];
-                    c0[jj] = per_v[lo + k];
-                    d0[jj] = apc[lo + k];
-                    m1[jj] = mrow[hi_ - k];
-                    a1[jj] = arow[hi_ - k];
-                    b1[jj] = brow[hi_ - k];
-                    c1[jj] = per_v[hi_ - k];
-                    d1[jj] = apc[hi_ - k];
-                }
-#pragma unroll
-                for (int jj = 0; jj < QB; ++jj) {
-                    const int q = h * QB + jj;
-                    const bool ends = (q == 0) && (lane == 0);   // the (DC, Nyquist) pair
-                    assemble(m0[jj], a0[jj], b0[jj], c0[jj], d0[jj], no_r[q], no_i[q], ends, no_r[q], no_i[q]);
-                    assemble(m1[jj], a1[jj], b1[jj], c1[jj], d1[jj], nm_r[q], nm_i[q], ends, nm_r[q], nm_i[q]);
-                }
-            }
-            // bin M/2 (lane 0): every lane loads "its" bin M/2 + lane (a lane-0-only load becomes a scalar load with an
-            // immediate wait, see feat_load_paired); only lane 0's value is used by the merge
-            float xh_r, xh_i;
-            assemble(mrow[M / 2 + lane], arow[M / 2 + lane], brow[M / 2 + lane], per_v[M / 2 + lane], apc[M / 2 + lane], nh_r,
-                     nh_i, false, xh_r, xh_i);
+                // bin M/2 (lane 0): every lane loads "its" bin M/2 + lane (a lane-0-only load becomes a scalar load with an
+                // immediate wait, see feat_load_paired); only lane 0's value is used by the merge
+                assemble(mrow[M / 2 + lane], V ? arow[M / 2 + lane] : 0.0f, V ? brow[M / 2 + lane] : 0.0f,
+                         V ? per_v[M / 2 + lane] : 0.0f, apc[M / 2 + lane], nh_r, nh_i, false, xh_r, xh_i);
+            };
+            if (voiced) assemble_all(std::true_type{});
+            else assemble_all(std::false_type{});
             merge_paired_complex<P>(no_r, no_i, nm_r, nm_i, xh_r, xh_i, xr, xi, lane, ws_c, ws_s);
         } else {
             // ---- aperiodic source: spectrum of this frame's windowed noise, bins k = lane + 64 j
@@ -1204,6 +1225,15 @@ __device__ __forceinline__ void mel_warp_block(const WarpJob& job, float (*As)[k
     const int kk = threadIdx.x & 63, fq = threadIdx.x >> 6;   // staging roles: bin within the chunk, frame quarter
     const int wave = rfl((int)(threadIdx.x >> 6));
     const int li = kk & 15, g = kk >> 4;                      // fragment roles
+    if (MODE == 1 && job.voi) {   // phase streams are masked by the voicing (magphase.py:2527-2529): a tile without a
+        // voiced frame is all zeros -- written as such, nothing read
+        const int pred = (threadIdx.x < kWarpTile) && (job.voi[min(f0 + (long long)threadIdx.x, F - 1)] != 0.0f);
+        if (!__syncthreads_or(pred)) {
+            const long long n_el = min((long long)kWarpTile, F - f0) * job.nout;
+            for (long long i = threadIdx.x; i < n_el; i += 256) job.out[f0 * job.nout + i] = 0.0f;
+            return;
+        }
+    }
     if (threadIdx.x < kWarpTile) {
         const long long f = min(f0 + (long long)threadIdx.x, F - 1);
         s_o0[threadIdx.x] = (long long)(row0 ? row0[f] : (int)f) * ld;
@@ -1362,7 +1392,7 @@ template <int KH, int MODE>
 __global__ __launch_bounds__(256) void k_mel_unwarp_mfma(UnwarpJobs jobs, int job0, long long F, int H,
                                                          int col_parts, long long n_tasks, int ld,
                                                          const int* __restrict__ row0, const int* __restrict__ row1,
-                                                         const float* __restrict__ rowt) {
+                                                         const float* __restrict__ rowt, const int* __restrict__ voiced) {
     const UnwarpJob job = jobs.j[job0 + blockIdx.y];
     const int lane = threadIdx.x & 63;
     const long long task = (long long)blockIdx.x * 4 + rfl((int)(threadIdx.x >> 6));   // wave-uniform, and known to be
@@ -1375,6 +1405,9 @@ __global__ __launch_bounds__(256) void k_mel_unwarp_mfma(UnwarpJobs jobs, int jo
     const long long f0 = rt * 32;
     const int K = job.K;
     const int kk = lane >> 5, li = lane & 31;
+    if (MODE == 1 && voiced) {   // phase rows of unvoiced frames are never read: skip tiles without a voiced frame
+        if (!__any(voiced[min(f0 + li, F - 1)] != 0)) return;
+    }
 
     float a[KH];
     float a1[MODE == 2 ? KH : 1];   // MODE 2: fragment of the second row
@@ -1482,6 +1515,8 @@ struct UnwarpRows {   // constant -> variable rate interpolation tables (all nul
     const int* row0;
     const int* row1;
     const float* rowt;
+    const int* voiced;   // optional (MODE 1): a tile of 32 frames none of which is voiced is skipped -- the synthesis does
+                         // not read the phase rows of unvoiced frames
 };
 
 template <int KH>
@@ -1492,13 +1527,13 @@ static int launch_unwarp_mfma(hipStream_t s, const UnwarpJobs& jobs, int job0, i
     const dim3 grid((unsigned)((n_tasks + 3) / 4), (unsigned)njobs);
     if (!rw.row0)
         hipLaunchKernelGGL((k_mel_unwarp_mfma<KH, 0>), grid, dim3(256), 0, s, jobs, job0, F, H, col_parts, n_tasks, ld,
-                           rw.row0, rw.row1, rw.rowt);
+                           rw.row0, rw.row1, rw.rowt, rw.voiced);
     else if (jobs.j[job0].op == 0)
         hipLaunchKernelGGL((k_mel_unwarp_mfma<KH, 1>), grid, dim3(256), 0, s, jobs, job0, F, H, col_parts, n_tasks, ld,
-                           rw.row0, rw.row1, rw.rowt);
+                           rw.row0, rw.row1, rw.rowt, rw.voiced);
     else
         hipLaunchKernelGGL((k_mel_unwarp_mfma<KH, 2>), grid, dim3(256), 0, s, jobs, job0, F, H, col_parts, n_tasks, ld,
-                           rw.row0, rw.row1, rw.rowt);
+                           rw.row0, rw.row1, rw.rowt, rw.voiced);
     return MPX_OK;
 }
 
@@ -1697,17 +1732,18 @@ int mpx_mel_unwarp(void* stream, int64_t n_frames, int32_t n_bins, const float* 
                    const float* u_mag, float* out_mag, const float* a_real, const float* a_imag, int32_t k_phase,
                    const float* u_phase, float* out_real, float* out_imag, int64_t ld) {
     return mel_unwarp_impl(stream, n_frames, n_bins, a_mag, k_mag, u_mag, out_mag, a_real, a_imag, k_phase, u_phase,
-                           out_real, out_imag, ld, UnwarpRows{nullptr, nullptr, nullptr});
+                           out_real, out_imag, ld, UnwarpRows{nullptr, nullptr, nullptr, nullptr});
 }
 
 int mpx_mel_unwarp_rows(void* stream, int64_t n_frames, int32_t n_bins, const float* a_mag, int32_t k_mag,
                         const float* u_mag, float* out_mag, const float* a_real, const float* a_imag, int32_t k_phase,
                         const float* u_phase, float* out_real, float* out_imag, int64_t ld, const int32_t* row0,
-                        const int32_t* row1, const float* row_t, int64_t n_rows, const int32_t* tile_first) {
+                        const int32_t* row1, const float* row_t, int64_t n_rows, const int32_t* tile_first,
+                        const int32_t* voiced) {
     if (!row0 || !row1 || !row_t) return fail(MPX_ERR_ARG, "mpx_mel_unwarp_rows: null row table%s");
     if (tile_first && n_rows <= 0) return fail(MPX_ERR_ARG, "mpx_mel_unwarp_rows: tile_first needs n_rows%s");
     return mel_unwarp_impl(stream, n_frames, n_bins, a_mag, k_mag, u_mag, out_mag, a_real, a_imag, k_phase, u_phase,
-                           out_real, out_imag, ld, UnwarpRows{row0, row1, row_t}, n_rows, tile_first);
+                           out_real, out_imag, ld, UnwarpRows{row0, row1, row_t, voiced}, n_rows, tile_first);
 }
 
 int mpx_noise_stats(void* stream, int fft_len, const void* tables, const float* noise, const int64_t* frame_pos,

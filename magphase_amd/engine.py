@@ -912,7 +912,8 @@ class CompressedSynthesisPlan:
                     st, self.total_frames, H, a_mag.data_ptr(), self.mag_dim, self.u_mag.data_ptr(), mag.data_ptr(),
                     self.a_real.data_ptr(), self.a_imag.data_ptr(), self.phase_dim, self.u_phase.data_ptr(),
                     real.data_ptr(), imag.data_ptr(), ld, self.row0.data_ptr(), self.row1.data_ptr(),
-                    self.rowt.data_ptr(), self.n_rows, self.tile_first.data_ptr()), "mpx_mel_unwarp_rows")
+                    self.rowt.data_ptr(), self.n_rows, self.tile_first.data_ptr(),
+                    self.voiced.data_ptr() if self.per_phase_type == "magphase" else None), "mpx_mel_unwarp_rows")
             else:                   # variable-rate features: rows == frames
                 _lib.check(lib.mpx_mel_unwarp(st, self.n_rows, H, a_mag.data_ptr(), self.mag_dim, self.u_mag.data_ptr(),
                                               mag.data_ptr(), self.a_real.data_ptr(), self.a_imag.data_ptr(),
