@@ -173,12 +173,15 @@ int mpx_mel_unwarp(void* stream, int64_t n_frames, int32_t n_bins, const float* 
  * products).  NULL: two products per frame.
  * voiced (optional): DEVICE int32[n_frames]; the PHASE rows of a 32-frame tile without a voiced frame are not computed (out_real /
  * out_imag keep their previous content there): mpx_synthesis_compressed_ola never reads the phase rows of unvoiced frames.
+ * n_phase_bins: only the first n_phase_bins bins (rounded up to a multiple of 64) of out_real / out_imag are produced (0: all):
+ * above the periodic / aperiodic crossfade (magphase.py:873-876; 6 kHz at 48 kHz = bin 512 of 2049) the periodic curve is
+ * exactly zero and the synthesis (n_per_bins below) does not read them.
  */
 int mpx_mel_unwarp_rows(void* stream, int64_t n_frames, int32_t n_bins, const float* a_mag, int32_t k_mag,
                         const float* u_mag, float* out_mag, const float* a_real, const float* a_imag, int32_t k_phase,
                         const float* u_phase, float* out_real, float* out_imag, int64_t ld, const int32_t* row0,
                         const int32_t* row1, const float* row_t, int64_t n_rows, const int32_t* tile_first,
-                        const int32_t* voiced);
+                        const int32_t* voiced, int32_t n_phase_bins);
 
 /*
  * Row pitch the unwarped spectra (outputs of mpx_mel_unwarp / mpx_min_phase, inputs of mpx_synthesis_compressed_ola)
@@ -234,6 +237,8 @@ int mpx_noise_stats(void* stream, int fft_len, const void* tables, const float* 
  *                     interpolated by mpx_mel_unwarp_rows -- half the feature loads)
  *   win_left, win_right : anti-ringing window half lengths (Q14);  pm_rel : as mpx_ola_gather
  * per_v, ap_v, ap_u : float32[H] per-bin constants (hostmath.synthesis_bin_curves: tilt x sqrt(mask) etc., Q12/Q13)
+ * n_per_bins : per_v[k] == 0 for k >= n_per_bins (the caller's promise; 0 or >= H: no promise): real / imag and per_v of those
+ *              bins are not read (one row per frame form only).
  */
 int mpx_synth_comp_slots(void); /* wave slots of mpx_synthesis_compressed_ola on the current device */
 int mpx_synthesis_compressed_ola(void* stream, int fft_len, const void* tables, const float* mag, const float* real,
@@ -245,7 +250,8 @@ int mpx_synthesis_compressed_ola(void* stream, int fft_len, const void* tables, 
                                  const float* ap_v, const float* ap_u, const mpx_ola_run* runs, int32_t n_runs,
                                  const int32_t* slot_off, const int32_t* slot_runs, int32_t n_slots,
                                  float* strips, float* pcm_out,
-                                 int64_t ld /* row pitch of mag/real/imag in floats, >= fft_len/2 + 1 */);
+                                 int64_t ld /* row pitch of mag/real/imag in floats, >= fft_len/2 + 1 */,
+                                 int32_t n_per_bins);
 
 /*
  * HOST function (no device work, no stream): the serial constant -> variable frame-rate scan of

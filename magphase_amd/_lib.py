@@ -126,7 +126,7 @@ def _load_locked():
     lib.mpx_mel_unwarp.restype = ctypes.c_int
     lib.mpx_mel_unwarp.argtypes = [vp, i64, i32, vp, i32, vp, vp, vp, vp, i32, vp, vp, vp, i64]
     lib.mpx_mel_unwarp_rows.restype = ctypes.c_int
-    lib.mpx_mel_unwarp_rows.argtypes = [vp, i64, i32, vp, i32, vp, vp, vp, vp, i32, vp, vp, vp, i64, vp, vp, vp, i64, vp, vp]
+    lib.mpx_mel_unwarp_rows.argtypes = [vp, i64, i32, vp, i32, vp, vp, vp, vp, i32, vp, vp, vp, i64, vp, vp, vp, i64, vp, vp, i32]
     lib.mpx_spec_ld.restype = i64
     lib.mpx_spec_ld.argtypes = [i32]
     lib.mpx_noise_uniform.restype = ctypes.c_int
@@ -138,7 +138,7 @@ def _load_locked():
     lib.mpx_synth_comp_slots.restype = ctypes.c_int
     lib.mpx_synth_comp_slots.argtypes = []
     lib.mpx_synthesis_compressed_ola.restype = ctypes.c_int
-    lib.mpx_synthesis_compressed_ola.argtypes = [vp, ctypes.c_int, vp] + [vp] * 19 + [vp, i32, vp, vp, i32, vp, vp, i64]
+    lib.mpx_synthesis_compressed_ola.argtypes = [vp, ctypes.c_int, vp] + [vp] * 19 + [vp, i32, vp, vp, i32, vp, vp, i64, i32]
     lib.mpx_host_const_to_var_scan.restype = i64
     lib.mpx_host_const_to_var_scan.argtypes = [vp, vp, i64, vp, vp]
     lib.mpx_host_plan_analysis.restype = i64

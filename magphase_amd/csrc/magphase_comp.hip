@@ -872,7 +872,7 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_synth_comp_pair(const f
                                                                         int nslots,
                                                                         const float* __restrict__ tw_g,
                                                                         float* __restrict__ strips,
-                                                                        float* __restrict__ pcm, long long ld) {
+                                                                        float* __restrict__ pcm, long long ld, int n_per) {
     constexpr int M = 64 * P, N = 2 * M, R = ring_len<P>();
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* tw = smem;
@@ -1032,15 +1032,18 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_synth_comp_pair(const f
                         d0[jj] = apc[lo + k];
                         m1[jj] = mrow[hi_ - k];
                         d1[jj] = apc[hi_ - k];
-                        if (V) {
+                        // the periodic curve is zero from bin n_per on (above the crossfade): the phase rows and the curve
+                        // are read only for the register rows that reach below it (wave-uniform conditions)
+                        a0[jj] = b0[jj] = c0[jj] = a1[jj] = b1[jj] = c1[jj] = 0.0f;
+                        if (V && k < n_per) {               // own bins lane + k
                             a0[jj] = arow[lo + k];
                             b0[jj] = brow[lo + k];
                             c0[jj] = per_v[lo + k];
+                        }
+                        if (V && M - k - 63 < n_per) {      // mirrors M - lane - k
                             a1[jj] = arow[hi_ - k];
                             b1[jj] = brow[hi_ - k];
                             c1[jj] = per_v[hi_ - k];
-                        } else {
-                            a0[jj] = b0[jj] = c0[jj] = a1[jj] = b1[jj] = c1[jj] = 0.0f;
                         }
                     }
 #pragma unroll
@@ -1053,8 +1056,9 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_synth_comp_pair(const f
                 }
                 // bin M/2 (lane 0): every lane loads "its" bin M/2 + lane (a lane-0-only load becomes a scalar load with an
                 // immediate wait, see feat_load_paired); only lane 0's value is used by the merge
-                assemble(mrow[M / 2 + lane], V ? arow[M / 2 + lane] : 0.0f, V ? brow[M / 2 + lane] : 0.0f,
-                         V ? per_v[M / 2 + lane] : 0.0f, apc[M / 2 + lane], nh_r, nh_i, false, xh_r, xh_i);
+                const bool ph = V && M / 2 < n_per;
+                assemble(mrow[M / 2 + lane], ph ? arow[M / 2 + lane] : 0.0f, ph ? brow[M / 2 + lane] : 0.0f,
+                         ph ? per_v[M / 2 + lane] : 0.0f, apc[M / 2 + lane], nh_r, nh_i, false, xh_r, xh_i);
             };
             if (voiced) assemble_all(std::true_type{});
             else assemble_all(std::false_type{});
@@ -1392,7 +1396,8 @@ template <int KH, int MODE>
 __global__ __launch_bounds__(256) void k_mel_unwarp_mfma(UnwarpJobs jobs, int job0, long long F, int H,
                                                          int col_parts, long long n_tasks, int ld,
                                                          const int* __restrict__ row0, const int* __restrict__ row1,
-                                                         const float* __restrict__ rowt, const int* __restrict__ voiced) {
+                                                         const float* __restrict__ rowt, const int* __restrict__ voiced,
+                                                         int Hc) {   // Hc <= H: output columns produced
     const UnwarpJob job = jobs.j[job0 + blockIdx.y];
     const int lane = threadIdx.x & 63;
     const long long task = (long long)blockIdx.x * 4 + rfl((int)(threadIdx.x >> 6));   // wave-uniform, and known to be
@@ -1435,7 +1440,7 @@ __global__ __launch_bounds__(256) void k_mel_unwarp_mfma(UnwarpJobs jobs, int jo
         }
     }
     const int jbeg = cp * (kUnwarpColTiles * 32);
-    const int jend = min(H, jbeg + kUnwarpColTiles * 32);
+    const int jend = min(Hc, jbeg + kUnwarpColTiles * 32);
     if (jbeg >= jend) return;
     // Two column tiles (64 bins) per step: their stores go out back to back, so every row gets 256 contiguous bytes at
     // once.  The B fragments are refilled for the NEXT step right behind the MFMA that consumed them (a whole step of
@@ -1517,23 +1522,27 @@ struct UnwarpRows {   // constant -> variable rate interpolation tables (all nul
     const float* rowt;
     const int* voiced;   // optional (MODE 1): a tile of 32 frames none of which is voiced is skipped -- the synthesis does
                          // not read the phase rows of unvoiced frames
+    int phase_cols;      // MODE 1: only the first phase_cols bins of the phase rows are produced (0: all)
 };
 
 template <int KH>
 static int launch_unwarp_mfma(hipStream_t s, const UnwarpJobs& jobs, int job0, int njobs, long long F, int H, int ld,
                               const UnwarpRows& rw) {
-    const int col_parts = (H + kUnwarpColTiles * 32 - 1) / (kUnwarpColTiles * 32);
+    // the phase rows are only needed below the periodic / aperiodic crossfade (rw.phase_cols, rounded up to a 64-bin step)
+    const bool phase = rw.row0 && jobs.j[job0].op == 0;
+    const int Hc = (phase && rw.phase_cols > 0) ? min(H, (rw.phase_cols + 63) / 64 * 64) : H;
+    const int col_parts = (Hc + kUnwarpColTiles * 32 - 1) / (kUnwarpColTiles * 32);
     const long long n_tasks = ((F + 31) / 32) * col_parts;
     const dim3 grid((unsigned)((n_tasks + 3) / 4), (unsigned)njobs);
     if (!rw.row0)
         hipLaunchKernelGGL((k_mel_unwarp_mfma<KH, 0>), grid, dim3(256), 0, s, jobs, job0, F, H, col_parts, n_tasks, ld,
-                           rw.row0, rw.row1, rw.rowt, rw.voiced);
-    else if (jobs.j[job0].op == 0)
+                           rw.row0, rw.row1, rw.rowt, rw.voiced, Hc);
+    else if (phase)
         hipLaunchKernelGGL((k_mel_unwarp_mfma<KH, 1>), grid, dim3(256), 0, s, jobs, job0, F, H, col_parts, n_tasks, ld,
-                           rw.row0, rw.row1, rw.rowt, rw.voiced);
+                           rw.row0, rw.row1, rw.rowt, rw.voiced, Hc);
     else
         hipLaunchKernelGGL((k_mel_unwarp_mfma<KH, 2>), grid, dim3(256), 0, s, jobs, job0, F, H, col_parts, n_tasks, ld,
-                           rw.row0, rw.row1, rw.rowt, rw.voiced);
+                           rw.row0, rw.row1, rw.rowt, rw.voiced, Hc);
     return MPX_OK;
 }
 
@@ -1732,18 +1741,19 @@ int mpx_mel_unwarp(void* stream, int64_t n_frames, int32_t n_bins, const float* 
                    const float* u_mag, float* out_mag, const float* a_real, const float* a_imag, int32_t k_phase,
                    const float* u_phase, float* out_real, float* out_imag, int64_t ld) {
     return mel_unwarp_impl(stream, n_frames, n_bins, a_mag, k_mag, u_mag, out_mag, a_real, a_imag, k_phase, u_phase,
-                           out_real, out_imag, ld, UnwarpRows{nullptr, nullptr, nullptr, nullptr});
+                           out_real, out_imag, ld, UnwarpRows{nullptr, nullptr, nullptr, nullptr, 0});
 }
 
 int mpx_mel_unwarp_rows(void* stream, int64_t n_frames, int32_t n_bins, const float* a_mag, int32_t k_mag,
                         const float* u_mag, float* out_mag, const float* a_real, const float* a_imag, int32_t k_phase,
                         const float* u_phase, float* out_real, float* out_imag, int64_t ld, const int32_t* row0,
                         const int32_t* row1, const float* row_t, int64_t n_rows, const int32_t* tile_first,
-                        const int32_t* voiced) {
+                        const int32_t* voiced, int32_t n_phase_bins) {
     if (!row0 || !row1 || !row_t) return fail(MPX_ERR_ARG, "mpx_mel_unwarp_rows: null row table%s");
+    if (n_phase_bins < 0) return fail(MPX_ERR_ARG, "mpx_mel_unwarp_rows: negative n_phase_bins%s");
     if (tile_first && n_rows <= 0) return fail(MPX_ERR_ARG, "mpx_mel_unwarp_rows: tile_first needs n_rows%s");
     return mel_unwarp_impl(stream, n_frames, n_bins, a_mag, k_mag, u_mag, out_mag, a_real, a_imag, k_phase, u_phase,
-                           out_real, out_imag, ld, UnwarpRows{row0, row1, row_t, voiced}, n_rows, tile_first);
+                           out_real, out_imag, ld, UnwarpRows{row0, row1, row_t, voiced, (int)n_phase_bins}, n_rows, tile_first);
 }
 
 int mpx_noise_stats(void* stream, int fft_len, const void* tables, const float* noise, const int64_t* frame_pos,
@@ -1784,9 +1794,10 @@ int mpx_synthesis_compressed_ola(void* stream, int fft_len, const void* tables, 
                                  const int32_t* win_right, const int32_t* pm_rel, const float* per_v,
                                  const float* ap_v, const float* ap_u, const mpx_ola_run* runs, int32_t n_runs,
                                  const int32_t* slot_off, const int32_t* slot_runs, int32_t n_slots,
-                                 float* strips, float* pcm_out, int64_t ld) {
+                                 float* strips, float* pcm_out, int64_t ld, int32_t n_per_bins) {
     const int P = p_of(fft_len);
     if (!P) return fail(MPX_ERR_ARG, "mpx_synthesis_compressed_ola: fft_len must be 1024, 2048 or 4096%s");
+    const int n_per = (n_per_bins <= 0 || n_per_bins > fft_len / 2 + 1) ? fft_len / 2 + 1 : (int)n_per_bins;
     if (n_runs < 0 || n_slots < 0) return fail(MPX_ERR_ARG, "mpx_synthesis_compressed_ola: negative count%s");
     if (n_runs == 0 || n_slots == 0) return MPX_OK;
     if (!tables || !mag || !real || !imag || !noise || !noise_pos || !noise_left || !noise_right || !noise_wtype ||
@@ -1805,7 +1816,7 @@ int mpx_synthesis_compressed_ola(void* stream, int fft_len, const void* tables, 
         if (int rc = set_lds(k_synth_comp_pair<PP, LL>, lds_bytes_comp_pair<PP>())) return rc;                       \
         hipLaunchKernelGGL((k_synth_comp_pair<PP, LL>), pgrid, pblock, lds_bytes_comp_pair<PP>(), s, mag, real, imag, \
                            noise, tb, per_v, ap_v, ap_u, (const RunDesc*)runs, slot_off, slot_runs, (int)n_slots,    \
-                           (const float*)tables, strips, pcm_out, (long long)ld);                                    \
+                           (const float*)tables, strips, pcm_out, (long long)ld, n_per);                             \
     } while (0)
     if (lerp) {
         if (P == 32) MPX_LAUNCH_COMP(32, true);

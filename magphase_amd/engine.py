@@ -219,6 +219,12 @@ class Engine:
                 raise ValueError("mag/real/imag must share one row pitch")
         return ld
 
+    def host_constant(self, key, build):
+        """A host value computed once per key."""
+        if key not in self._tables:
+            self._tables[key] = build()
+        return self._tables[key]
+
     def constant(self, key, build, dtype=np.float32):
         """Device-resident constant table, built (float64 on the host) and uploaded once per key."""
         if key not in self._tables:
@@ -815,6 +821,10 @@ class CompressedSynthesisPlan:
                                   lambda: hm.phase_unwarp_matrix(self.phase_dim, N, fs, self.alpha_phase))
         self.per_v, self.ap_v, self.ap_u = (
             e.constant(("bin_curve", k, int(fs), N), lambda k=k: hm.synthesis_bin_curves(fs, N)[k]) for k in range(3))
+        # bins from n_per on have no periodic component (the crossfade mask is exactly zero there): their phase rows are
+        # neither unwarped nor read
+        self.n_per = e.host_constant(("n_per", int(fs), N), lambda: _first_all_zero_from(
+            np.asarray(hm.synthesis_bin_curves(fs, N)[0], dtype=np.float32)))
         # OLA runs
         n_slots = e.synth_comp_slots() if hasattr(e, "synth_comp_slots") else 1024
         _plan_ola_runs(self, pm_rel, starts, self.out_len, self.out_off_host, N, n_slots, frames_per_run, _up)
@@ -913,7 +923,8 @@ class CompressedSynthesisPlan:
                     self.a_real.data_ptr(), self.a_imag.data_ptr(), self.phase_dim, self.u_phase.data_ptr(),
                     real.data_ptr(), imag.data_ptr(), ld, self.row0.data_ptr(), self.row1.data_ptr(),
                     self.rowt.data_ptr(), self.n_rows, self.tile_first.data_ptr(),
-                    self.voiced.data_ptr() if self.per_phase_type == "magphase" else None), "mpx_mel_unwarp_rows")
+                    self.voiced.data_ptr() if self.per_phase_type == "magphase" else None,
+                    self.n_per if self.per_phase_type == "magphase" else 0), "mpx_mel_unwarp_rows")
             else:                   # variable-rate features: rows == frames
                 _lib.check(lib.mpx_mel_unwarp(st, self.n_rows, H, a_mag.data_ptr(), self.mag_dim, self.u_mag.data_ptr(),
                                               mag.data_ptr(), self.a_real.data_ptr(), self.a_imag.data_ptr(),
@@ -955,13 +966,20 @@ class CompressedSynthesisPlan:
                 self.win_l.data_ptr(), self.win_r.data_ptr(), self.pm_rel.data_ptr(),
                 self.per_v.data_ptr(), self.ap_v.data_ptr(), self.ap_u.data_ptr(), self.runs.data_ptr(),
                 self.n_runs, self.slot_off.data_ptr(), self.slot_runs.data_ptr(), self.n_slots,
-                strips.data_ptr(), pcm.data_ptr(), ld), "mpx_synthesis_compressed_ola")
+                strips.data_ptr(), pcm.data_ptr(), ld, self.n_per if self.per_phase_type == "magphase" else 0),
+                "mpx_synthesis_compressed_ola")
             mark("k_synth_comp_pair")
         e.ola_fixup(N, self, strips, pcm)
         mark("k_ola_fixup")
         if keep:
             self.debug = dict(mag=mag, real=real, imag=imag, sums=sums)
         return pcm
+
+
+def _first_all_zero_from(v):
+    """Smallest n with v[k] == 0 for every k >= n."""
+    nz = np.flatnonzero(np.asarray(v) != 0)
+    return int(nz[-1]) + 1 if nz.size else 0
 
 
 def plan_synthesis_numpy(lf0s, fs, N, b_const_rate, b_voi_ap_win):
