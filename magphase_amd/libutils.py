@@ -42,12 +42,16 @@ def get_filename(filepath):
 
 
 def mkdir(l_dir):
-    """libutils.py:146-156."""
+    """libutils.py:146-156.  Several ranks of one batch job call this on the same path at the same moment: creation is
+    race-free (a directory another rank made in between is not an error)."""
     if isinstance(l_dir, str):
         l_dir = [l_dir]
     for directory in l_dir:
-        if not os.path.exists(directory):
+        try:
             os.mkdir(directory)
+        except FileExistsError:
+            if not os.path.isdir(directory):
+                raise
 
 
 def ins_pid(filepath):

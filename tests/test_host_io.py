@@ -120,3 +120,30 @@ def test_wav_batch_reader_formats_and_errors(tmp_path):
         if not isinstance(got, Exception):
             one = la.read_audio_file_pcm(p)
             assert one[1] == got[1] and np.array_equal(one[0], got[0])
+
+
+def test_mkdir_is_race_free_between_ranks(tmp_path):
+    """Two ranks of a batch job create the same output directory at the same moment (libutils.py:146-156 checks and
+    then creates: the loser of that race raised FileExistsError)."""
+    import threading
+    from magphase_amd import libutils as lu
+    errs = []
+    for rep in range(50):
+        d = str(tmp_path / ("out%d" % rep))
+        gate = threading.Barrier(8)
+
+        def work():
+            gate.wait()
+            try:
+                lu.mkdir(d)
+            except Exception as e:  # noqa: BLE001
+                errs.append(e)
+        th = [threading.Thread(target=work) for _ in range(8)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        assert os.path.isdir(d)
+    assert not errs
+    f = tmp_path / "afile"
+    f.write_text("x")
+    with pytest.raises(FileExistsError):
+        lu.mkdir(str(f))
