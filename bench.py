@@ -222,16 +222,21 @@ def measure_lowdim(eng, utts, steps, warmup):
     Fv, Fc, Fs = aplan.lossless.total_frames, aplan.total_out_frames, splan.total_frames
     n_in, n_out, n_noise = aplan.lossless.total_smpls, splan.total_out, int(sum(splan.ns_len))
     dims = aplan.mag_dim + 2 * aplan.phase_dim
+    n_per, n_voiced = int(splan.n_per), int(splan.voiced_host.sum())
     # per-kernel bound.  bytes: what THIS kernel reads + writes as the path is staged today; flops: the GEMM's 2 m n k
     kinfo = {
         "k_analysis": ("hbm", 12.0 * H * Fv + 4.0 * n_in),
         "k_analysis_f64": ("hbm", 12.0 * H * Fv + 4.0 * n_in),
         "k_mel_warp_mfma": ("mfma", 2.0 * H * dims * Fc),
         "k_post_filter": ("hbm", 8.0 * aplan.mag_dim * Fc),
-        "k_mel_unwarp_mfma": ("mfma", 2.0 * H * (dims + aplan.mag_dim) * Fs),   # variable-rate rows; the magnitude product twice
+        # variable-rate rows.  Magnitudes: two products over all H bins (k_mel_unwarp_tiled, timed under this mark too);
+        # phases: real + imaginary, voiced frames only, bins below the periodic / aperiodic crossfade only
+        "k_mel_unwarp_mfma": ("mfma", 2.0 * H * 2 * aplan.mag_dim * Fs
+                              + 2.0 * n_per * 2 * aplan.phase_dim * n_voiced),
         "k_noise_stats": ("hbm", 4.0 * n_noise + 4.0 * Fs),
         "k_noise_gains": ("hbm", 12.0 * Fs),
-        "k_synth_comp_pair": ("hbm", 12.0 * H * Fs + 4.0 * n_noise + 4.0 * n_out),   # one unwarped row per frame
+        # one unwarped magnitude row per frame, the two phase rows of voiced frames below the crossfade
+        "k_synth_comp_pair": ("hbm", 4.0 * H * Fs + 8.0 * n_per * n_voiced + 4.0 * n_noise + 4.0 * n_out),
         "k_ola_fixup": ("hbm", 12.0 * splan.n_runs * N),
     }
     kern = []
@@ -259,6 +264,7 @@ def measure_lowdim(eng, utts, steps, warmup):
         "value": round(Fc / (ms_step * 1e-3), 1), "unit": "5ms-frames/s",
         "x_realtime": round(UTTS_PER_GPU * DUR_S / (ms_step * 1e-3), 1),
         "const_rate_frames": Fc, "variable_rate_frames_analysed": Fv, "variable_rate_frames_resynthesised": Fs,
+        "voiced_frames_resynthesised": n_voiced, "periodic_bins": n_per,
         "kernels": kern,
         "roofline": {"kernel": dom["name"], "bound": dom["bound"], "achieved": dom["achieved"], "unit": dom["unit"],
                      "peak": HBM_PEAK_GBS if dom["bound"] == "hbm" else MFMA_F32_PEAK_TF, "frac": dom["frac"]},

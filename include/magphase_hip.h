@@ -209,11 +209,25 @@ int mpx_noise_uniform(void* stream, int32_t n_utts, const uint64_t* seeds, const
  * on the device from numpy's own state: key [624] (DEVICE uint32) and pos are np.random.get_state()[1:3]; out [n_samples]
  * gets float32(-1 + 2 d), d = the 53-bit doubles random_sample() would return (two MT19937 words each) -- bit-identical to
  * the host draw --, key_out [624] / pos_out [1] (DEVICE) the state numpy is left in after those draws (the caller puts it
- * back with np.random.set_state).  raw: DEVICE scratch of 2 * n_samples uint32.  One workgroup runs the recurrence
- * (454 words per barrier), a second kernel converts.
+ * back with np.random.set_state).  raw: DEVICE scratch of 2 * n_samples uint32.  work: DEVICE scratch of
+ * mpx_noise_numpy_mt19937_work_words() uint32, or NULL.  With work and more than one segment of 319 488 words to draw,
+ * the stream is produced by one workgroup per segment: the 624-word window each segment starts from is a jump-ahead of
+ * the first one (X[n + J] = xor of X[n + i] over the set bits of x^J mod the generator's characteristic polynomial;
+ * log2(segments) rounds of k_mt_jump, polynomials from mpx_host_mt19937_jump_poly).  Without work, or for short draws,
+ * one workgroup runs the recurrence from the key (454 words per barrier).  A second kernel converts.  Bit-identical
+ * either way.
  */
 int mpx_noise_numpy_mt19937(void* stream, const uint32_t* key, int32_t pos, int64_t n_samples, uint32_t* raw,
-                            float* out, uint32_t* key_out, int32_t* pos_out);
+                            float* out, uint32_t* key_out, int32_t* pos_out, uint32_t* work);
+int64_t mpx_noise_numpy_mt19937_work_words(void);
+
+/*
+ * Host helper (no device): out [n_levels x 624] uint32 (HOST), level l = the bits of x^(jump_words * 2^l) mod phi, phi the
+ * characteristic polynomial (degree 19937) of MT19937's word recurrence; bit i of a level = bit (i & 31) of word i >> 5.
+ * For the words X[n] the recurrence produces (n >= 624 counted from a key), X[n + jump] = xor_{i : bit i} X[n + i].
+ * phi is found once per process (Berlekamp-Massey), ladders are cached per jump_words.
+ */
+int32_t mpx_host_mt19937_jump_poly(int64_t jump_words, int32_t n_levels, uint32_t* out);
 
 /*
  * Noise-gain statistics (magphase.py:886-903, Q10/Q11): for every frame, the windowed noise frame

@@ -32,6 +32,8 @@ SYMBOLS = (
     "mpx_spec_ld",
     "mpx_noise_uniform",
     "mpx_noise_numpy_mt19937",
+    "mpx_noise_numpy_mt19937_work_words",
+    "mpx_host_mt19937_jump_poly",
     "mpx_noise_stats",
     "mpx_synth_comp_slots",
     "mpx_synthesis_compressed_ola",
@@ -132,7 +134,11 @@ def _load_locked():
     lib.mpx_noise_uniform.restype = ctypes.c_int
     lib.mpx_noise_uniform.argtypes = [vp, i32, vp, vp, i64, vp]
     lib.mpx_noise_numpy_mt19937.restype = ctypes.c_int
-    lib.mpx_noise_numpy_mt19937.argtypes = [vp, vp, i32, i64, vp, vp, vp, vp]
+    lib.mpx_noise_numpy_mt19937.argtypes = [vp, vp, i32, i64, vp, vp, vp, vp, vp]
+    lib.mpx_noise_numpy_mt19937_work_words.restype = i64
+    lib.mpx_noise_numpy_mt19937_work_words.argtypes = []
+    lib.mpx_host_mt19937_jump_poly.restype = ctypes.c_int
+    lib.mpx_host_mt19937_jump_poly.argtypes = [i64, i32, vp]
     lib.mpx_noise_stats.restype = ctypes.c_int
     lib.mpx_noise_stats.argtypes = [vp, ctypes.c_int, vp, vp, vp, vp, vp, vp, i64, vp]
     lib.mpx_synth_comp_slots.restype = ctypes.c_int

@@ -18,7 +18,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "magphase_hip.hip")
 SRCS = [SRC, os.path.join(HERE, "csrc", "magphase_comp.hip"), os.path.join(HERE, "csrc", "magphase_f64.hip"),
         os.path.join(HERE, "csrc", "magphase_epochs.hip"), os.path.join(HERE, "csrc", "magphase_host.cpp"),
-        os.path.join(HERE, "csrc", "magphase_plan.cpp")]
+        os.path.join(HERE, "csrc", "magphase_plan.cpp"), os.path.join(HERE, "csrc", "magphase_mtjump.cpp")]
 DEPS = SRCS + [os.path.join(HERE, "csrc", "wave_fft.hpp"), os.path.join(HERE, "csrc", "wave_fft_f64.hpp"),
                os.path.join(HERE, "csrc", "mpx_common.hpp"),
                os.path.join(os.path.dirname(HERE), "include", "magphase_hip.h")]

@@ -452,47 +452,121 @@ __device__ __forceinline__ unsigned mt_temper(unsigned y) {
     return y;
 }
 
-__global__ __launch_bounds__(256) void k_mt19937_stream(const unsigned* __restrict__ key_in, int pos, long long n_words,
-                                                        unsigned* __restrict__ raw, unsigned* __restrict__ key_out,
-                                                        int* __restrict__ pos_out) {
-    constexpr int R = 2048;   // ring: X[i] lives in ring[i & (R - 1)]
+// With ``windows`` the stream is cut into segments of J words (J a multiple of 624), one workgroup each: segment k
+// starts from the 624-word window X[624 + k J ..] (k_mt_jump below), emits its own words and stops at the next
+// segment's start; workgroup 0 also emits what is left of numpy's current block (X[pos .. 623], straight from the key)
+// and the last one leaves the state.  Without windows: one segment, from the key.
+__global__ __launch_bounds__(256) void k_mt19937_stream(const unsigned* __restrict__ key_in,
+                                                        const unsigned* __restrict__ windows, long long J, int pos,
+                                                        long long n_words, unsigned* __restrict__ raw,
+                                                        unsigned* __restrict__ key_out, int* __restrict__ pos_out) {
+    constexpr int R = 2048;   // ring: X[c + i] lives in ring[i & (R - 1)]
     __shared__ unsigned ring[R];
     const int t = threadIdx.x;
-    for (int i = t; i < 624; i += 256) ring[i] = key_in[i];
-    __syncthreads();
     const long long end = (long long)pos + n_words;                 // stream indices [pos, end) are emitted
     const long long B = (end > 0) ? (end - 1) / 624 : 0;            // block numpy's state ends in
     const long long gen_end = 624 * (B + 1);                        // that block is produced completely
+    const long long c = windows ? 624 + (long long)blockIdx.x * J : 0;          // stream index of the segment's window
+    const long long seg_end = windows ? min(c + J, gen_end) : gen_end;
+    const unsigned* src = windows ? windows + 624ll * blockIdx.x : key_in;
+    for (int i = t; i < 624; i += 256) ring[i] = src[i];
+    __syncthreads();
     auto emit = [&](long long i, unsigned v) {
-        if (i >= pos && i < end) raw[i - pos] = mt_temper(v);
+        if (i >= pos && i < end && i < seg_end) raw[i - pos] = mt_temper(v);
     };
-    for (int i = t; i < 624; i += 256) emit(i, ring[i]);
-    // Thread t < 227 owns the chain X[624 + 227 j + t], j = 0, 1, ...: each link is the previous one (a register) xor the
-    // twist of two words 624 / 623 places back, which were written at least one barrier ago as long as only TWO links are
-    // made per barrier (the third would read words of this very interval).  Per interval: 4 LDS reads, 2 writes, 2 stores.
-    // (One wavefront running all 227 chains without barriers -- LDS serves a wave in order -- was measured slower: 120 vs
-    // 71 ms per 128 utterances; the four waves overlap their LDS round trips.)
-    unsigned v = (t < 227) ? ring[t + 397] : 0u;                     // X[397 + t]: the "previous link" of the first step
-    const long long n_int = (gen_end > 624) ? (gen_end - 624 + 453) / 454 : 0;
+    for (int i = t; i < 624; i += 256) emit(c + i, ring[i]);
+    if (windows && blockIdx.x == 0)
+        for (int i = t; i < 624; i += 256)
+            if (i >= pos && i < end) raw[i - pos] = mt_temper(key_in[i]);
+    // Thread t < 227 owns the chain X[c + 624 + 227 j + t], j = 0, 1, ...: each link is the previous one (a register) xor
+    // the twist of two words 624 / 623 places back, which were written at least one barrier ago as long as only TWO links
+    // are made per barrier (the third would read words of this very interval).  Per interval: 4 LDS reads, 2 writes, 2
+    // stores.  (One wavefront running all 227 chains without barriers -- LDS serves a wave in order -- was measured
+    // slower: 120 vs 71 ms per 128 utterances; the four waves overlap their LDS round trips.)
+    unsigned v = (t < 227) ? ring[t + 397] : 0u;                     // X[c + 397 + t]: the "previous link" of the first step
+    const long long n_int = (seg_end > c + 624) ? (seg_end - c - 624 + 453) / 454 : 0;
     unsigned k = 0;                                                   // ring offset of the interval's first input word
-    long long o = 624 + t - pos;                                      // raw index of this thread's next output
+    long long o = c + 624 + t;                                        // stream index of this thread's next output
     for (long long it = 0; it < n_int; ++it) {
         if (t < 227) {
             const unsigned x = ring[(k + t) & (R - 1)], y = ring[(k + t + 1) & (R - 1)];
             const unsigned x2 = ring[(k + 227 + t) & (R - 1)], y2 = ring[(k + 228 + t) & (R - 1)];
-            const unsigned v1 = v ^ mt_twist(x, y);                  // X[k + 624 + t]
-            v = v1 ^ mt_twist(x2, y2);                               // X[k + 851 + t]
+            const unsigned v1 = v ^ mt_twist(x, y);                  // X[c + k + 624 + t]
+            v = v1 ^ mt_twist(x2, y2);                               // X[c + k + 851 + t]
             ring[(k + 624 + t) & (R - 1)] = v1;
             ring[(k + 851 + t) & (R - 1)] = v;
-            if (o >= 0 && o < n_words) raw[o] = mt_temper(v1);
-            if (o + 227 >= 0 && o + 227 < n_words) raw[o + 227] = mt_temper(v);
+            emit(o, v1);
+            emit(o + 227, v);
         }
         k = (k + 454) & (R - 1);
         o += 454;
         __syncthreads();
     }
-    for (int i = t; i < 624; i += 256) key_out[i] = ring[(624 * B + i) & (R - 1)];
-    if (t == 0) pos_out[0] = (int)(end - 624 * B);
+    if (blockIdx.x == gridDim.x - 1) {
+        for (int i = t; i < 624; i += 256) key_out[i] = ring[(624 * B - c + i) & (R - 1)];
+        if (t == 0) pos_out[0] = (int)(end - 624 * B);
+    }
+}
+
+// windows[0] = X[624 .. 1247], the first block the recurrence produces from numpy's key: every word of it (and after
+// it) is a linear function of the generator's 19937 state bits, which the low 31 bits of X[0] are not.
+__global__ __launch_bounds__(256) void k_mt_first(const unsigned* __restrict__ key_in, unsigned* __restrict__ windows) {
+    __shared__ unsigned xs[624 + 908];
+    const int t = threadIdx.x;
+    for (int i = t; i < 624; i += 256) xs[i] = key_in[i];
+    __syncthreads();
+    for (int base = 0; base < 624; base += 454) {
+        if (t < 227) {
+            const unsigned v1 = xs[base + 397 + t] ^ mt_twist(xs[base + t], xs[base + t + 1]);
+            xs[base + 624 + t] = v1;
+            xs[base + 851 + t] = v1 ^ mt_twist(xs[base + 227 + t], xs[base + 228 + t]);
+        }
+        __syncthreads();
+    }
+    for (int i = t; i < 624; i += 256) windows[i] = xs[624 + i];
+}
+
+// Jump-ahead: windows[dst_off + w] = the window J' words after windows[w], J' the jump whose polynomial g = x^J' mod phi
+// is given as a 19968-bit mask (magphase_mtjump.cpp):  X[n + J'] = xor_{i : g_i} X[n + i].  kMtJumpSplit workgroups share
+// one jump (the first rounds of the doubling have 1, 2, 4 ... jumps to make: a lone workgroup took 0.48 ms per round):
+// each runs the recurrence for the 19937 + 623 words after the source window (LDS, 85 KB; 13 us) and xors the words
+// i + j of ITS share of the set bits i for three j per thread, then xors the partial window into the (zeroed) result.
+constexpr int kMtJumpWords = 19937 + 624 + 768;   // generated + read-ahead slack of the threads without a third j
+constexpr int kMtJumpSplit = 16;                  // 624 mask words = 16 x 39
+__global__ __launch_bounds__(256) void k_mt_jump(unsigned* __restrict__ windows, const unsigned* __restrict__ poly,
+                                                 int n_src, int dst_off, int n_windows) {
+    extern __shared__ __attribute__((aligned(16))) unsigned mt_xs[];
+    const int t = threadIdx.x, w = blockIdx.x, part = blockIdx.y;
+    if (w >= n_src || dst_off + w >= n_windows) return;
+    for (int i = t; i < 624; i += 256) mt_xs[i] = windows[624ll * w + i];
+    for (int i = 19937 + 624 + t; i < kMtJumpWords; i += 256) mt_xs[i] = 0u;
+    __syncthreads();
+    constexpr int NX = 19937 + 624;
+    for (int base = 0; base + 624 < NX; base += 454) {
+        if (t < 227) {
+            const unsigned v1 = mt_xs[base + 397 + t] ^ mt_twist(mt_xs[base + t], mt_xs[base + t + 1]);
+            const unsigned v2 = v1 ^ mt_twist(mt_xs[base + 227 + t], mt_xs[base + 228 + t]);
+            if (base + 624 + t < NX) mt_xs[base + 624 + t] = v1;
+            if (base + 851 + t < NX) mt_xs[base + 851 + t] = v2;
+        }
+        __syncthreads();
+    }
+    unsigned a0 = 0u, a1 = 0u, a2 = 0u;
+    constexpr int QW = 624 / kMtJumpSplit;
+    for (int q = part * QW; q < (part + 1) * QW; ++q) {
+        unsigned bits = __builtin_amdgcn_readfirstlane(poly[q]);
+        while (bits) {   // wave-uniform: the mask is the same for every lane
+            const int i = 32 * q + __builtin_ctz(bits);
+            bits &= bits - 1u;
+            a0 ^= mt_xs[i + t];
+            a1 ^= mt_xs[i + t + 256];
+            a2 ^= mt_xs[i + t + 512];
+        }
+    }
+    unsigned* dst = windows + 624ll * (dst_off + w);
+    atomicXor(&dst[t], a0);
+    atomicXor(&dst[t + 256], a1);
+    if (t + 512 < 624) atomicXor(&dst[t + 512], a2);
 }
 
 __global__ __launch_bounds__(256) void k_mt_uniform(const unsigned* __restrict__ raw, long long n, float* __restrict__ out) {
@@ -1949,14 +2023,55 @@ int mpx_noise_uniform(void* stream, int32_t n_utts, const uint64_t* seeds, const
     return MPX_OK;
 }
 
+// Segments of the parallel form: kMtSegWords words each (doubled until at most kMtMaxSegs are needed)
+constexpr long long kMtSegWords = 624ll * 512;
+constexpr int kMtMaxSegs = 256, kMtMaxLevels = 8;
+
+int64_t mpx_noise_numpy_mt19937_work_words(void) { return (int64_t)(kMtMaxSegs + kMtMaxLevels) * 624; }
+
 int mpx_noise_numpy_mt19937(void* stream, const uint32_t* key, int32_t pos, int64_t n_samples, uint32_t* raw,
-                            float* out, uint32_t* key_out, int32_t* pos_out) {
+                            float* out, uint32_t* key_out, int32_t* pos_out, uint32_t* work) {
     if (n_samples < 0 || pos < 0 || pos > 624) return fail(MPX_ERR_ARG, "mpx_noise_numpy_mt19937: bad size / position%s");
     if (!key || !key_out || !pos_out || (n_samples > 0 && (!raw || !out)))
         return fail(MPX_ERR_ARG, "mpx_noise_numpy_mt19937: null pointer%s");
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_mt19937_stream, dim3(1), dim3(256), 0, s, (const unsigned*)key, (int)pos,
-                       (long long)(2 * n_samples), (unsigned*)raw, (unsigned*)key_out, (int*)pos_out);
+    const long long n_words = 2 * (long long)n_samples, end = pos + n_words;
+    const long long gen_end = 624 * (((end > 0) ? (end - 1) / 624 : 0) + 1);
+    long long J = kMtSegWords;
+    int shift = 0;
+    while ((gen_end - 624 + J - 1) / J > kMtMaxSegs) {
+        J *= 2;
+        ++shift;
+    }
+    const int K = (int)((gen_end - 624 + J - 1) / J);
+    if (!work || K < 2) {   // short draws: one workgroup, from the key
+        hipLaunchKernelGGL(k_mt19937_stream, dim3(1), dim3(256), 0, s, (const unsigned*)key, (const unsigned*)nullptr, 0ll,
+                           (int)pos, n_words, (unsigned*)raw, (unsigned*)key_out, (int*)pos_out);
+    } else {
+        int levels = 0;
+        while ((1 << levels) < K) ++levels;
+        static thread_local std::vector<uint32_t> polys;
+        polys.resize((size_t)(shift + levels) * 624);
+        if (mpx_host_mt19937_jump_poly(kMtSegWords, shift + levels, polys.data()) != MPX_OK)
+            return fail(MPX_ERR_ARG, "mpx_noise_numpy_mt19937: jump polynomials unavailable%s");
+        unsigned* windows = (unsigned*)work;
+        unsigned* dpoly = windows + 624ll * kMtMaxSegs;
+        MPX_HIP_CHECK(hipMemcpyAsync(dpoly, polys.data() + (size_t)shift * 624, (size_t)levels * 624 * sizeof(uint32_t),
+                                     hipMemcpyHostToDevice, s));
+        MPX_HIP_CHECK(hipStreamSynchronize(s));   // pageable source: the copy has left the host buffer
+        MPX_HIP_CHECK(hipMemsetAsync(windows, 0, (size_t)K * 624 * sizeof(unsigned), s));   // jump results are xor-ed in
+        hipLaunchKernelGGL(k_mt_first, dim3(1), dim3(256), 0, s, (const unsigned*)key, windows);
+        const size_t lds = (size_t)kMtJumpWords * sizeof(unsigned);
+        if (int rc = set_lds(k_mt_jump, lds)) return rc;
+        for (int l = 0; l < levels; ++l) {
+            const int n_src = 1 << l;
+            hipLaunchKernelGGL(k_mt_jump, dim3((unsigned)min(n_src, K - n_src), kMtJumpSplit), dim3(256), lds, s, windows,
+                               (const unsigned*)(dpoly + 624ll * l), n_src, n_src, K);
+        }
+        hipLaunchKernelGGL(k_mt19937_stream, dim3((unsigned)K), dim3(256), 0, s, (const unsigned*)key,
+                           (const unsigned*)windows, J, (int)pos, n_words, (unsigned*)raw, (unsigned*)key_out,
+                           (int*)pos_out);
+    }
     if (n_samples > 0)
         hipLaunchKernelGGL(k_mt_uniform, dim3((unsigned)((n_samples + 255) / 256)), dim3(256), 0, s, (const unsigned*)raw,
                            (long long)n_samples, out);

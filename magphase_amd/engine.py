@@ -177,10 +177,15 @@ class Engine:
         out = self.empty((max(int(n), 1),))
         raw = torch.empty(max(2 * int(n), 1), dtype=torch.int32, device=self.device)
         state = torch.empty(625, dtype=torch.int32, device=self.device)
+        work = getattr(self, "_mt_work", None)
+        if work is None:   # segment windows + jump polynomials of the many-workgroup form
+            work = self._mt_work = torch.empty(int(self.lib.mpx_noise_numpy_mt19937_work_words()), dtype=torch.int32,
+                                               device=self.device)
         with torch.cuda.device(self.device):
             _lib.check(self.lib.mpx_noise_numpy_mt19937(self.stream_ptr(), key.data_ptr(), int(st[2]), int(n),
                                                         raw.data_ptr(), out.data_ptr(), state.data_ptr(),
-                                                        state.data_ptr() + 4 * 624), "mpx_noise_numpy_mt19937")
+                                                        state.data_ptr() + 4 * 624, work.data_ptr()),
+                       "mpx_noise_numpy_mt19937")
             h = state.cpu().numpy()          # synchronises: the state goes back before anyone else draws
         np.random.set_state((st[0], h[:624].view(np.uint32).copy(), int(h[624]), st[3], st[4]))
         return out[:int(n)]

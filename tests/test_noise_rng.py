@@ -103,7 +103,11 @@ def test_numpy_global_generator_continued_on_the_device():
     from magphase_amd.engine import get_engine
     e = get_engine()
     for seed, warm, n in ((1, 0, 5), (2, 311, 700), (3, 1, 1000), (5, 623, 312), (7, 0, 312), (9, 100, 311), (11, 17, 227),
-                          (13, 0, 1), (4, 5, 300001)):
+                          (13, 0, 1), (4, 5, 300001),
+                          # many-workgroup form (segments of 159 744 samples, jump-ahead windows): 2, 3, 20 segments, a
+                          # draw ending exactly on a segment / block boundary, one ending a word after it
+                          (21, 0, 159744 + 312), (22, 77, 400000), (23, 623, 3111111), (24, 0, 2 * 159744 + 312),
+                          (25, 0, 2 * 159744 + 313), (26, 1, 159744 * 9)):
         np.random.seed(seed)
         np.random.uniform(size=warm)
         st = np.random.get_state()
@@ -116,3 +120,45 @@ def test_numpy_global_generator_continued_on_the_device():
         assert np.array_equal(got, want), (seed, warm, n)
         assert np.array_equal(now[1], after[1]) and now[2] == after[2] and now[3:] == after[3:]
         assert np.array_equal(np.random.uniform(-1, 1, 7), nxt)          # and the stream goes on identically
+
+
+def _mt_raw_stream(key, n_words):
+    """Raw (untempered) words X[0 .. n_words) of MT19937 continued from a 624-word key (X[0..623] = key)."""
+    x = np.zeros(n_words + 624, dtype=np.uint32)
+    x[:624] = key
+    up, lo, mag = np.uint32(0x80000000), np.uint32(0x7FFFFFFF), np.uint32(0x9908B0DF)
+    n = 0
+    while n + 624 < x.size:       # 227 new words per step depend on old ones only
+        m = min(227, x.size - 624 - n)
+        y = (x[n:n + m] & up) | (x[n + 1:n + m + 1] & lo)
+        x[n + 624:n + 624 + m] = x[n + 397:n + 397 + m] ^ (y >> np.uint32(1)) ^ np.where(y & np.uint32(1), mag, np.uint32(0))
+        n += m
+    return x[:n_words]
+
+
+def test_mt19937_jump_polynomials_against_the_recurrence():
+    """mpx_host_mt19937_jump_poly (host, no device): X[n + J] == xor of X[n + i] over the set bits i of x^J mod phi, for
+    the words the recurrence produces from one of numpy's own states; the ladder's level l is the jump J 2^l."""
+    import ctypes
+    from magphase_amd import _lib
+    lib = _lib.load()
+    rs = np.random.RandomState(12345)
+    key = rs.get_state()[1].astype(np.uint32)
+    # the key really is numpy's stream: tempering X[0..] gives random_raw's words (pos = 624 after seeding)
+    J, levels = 624 * 40, 3
+    polys = np.zeros((levels, 624), dtype=np.uint32)
+    assert lib.mpx_host_mt19937_jump_poly(J, levels, polys.ctypes.data_as(ctypes.c_void_p)) == 0
+    x = _mt_raw_stream(key, 624 + 19937 + 624 + J * 4 + 700)
+    for l in range(levels):
+        bits = np.unpackbits(polys[l].view(np.uint8), bitorder="little")
+        assert bits.size == 19968 and not bits[19937:].any()
+        idx = np.flatnonzero(bits)
+        assert idx.size > 100
+        for n in (624, 625, 624 + 623, 2000):
+            acc = np.bitwise_xor.reduce(x[n + idx])
+            assert acc == x[n + J * (1 << l)], (l, n)
+    # the same call again (cached ladder) and a longer ladder agree
+    more = np.zeros((levels + 2, 624), dtype=np.uint32)
+    assert lib.mpx_host_mt19937_jump_poly(J, levels + 2, more.ctypes.data_as(ctypes.c_void_p)) == 0
+    assert np.array_equal(more[:levels], polys)
+    assert lib.mpx_host_mt19937_jump_poly(0, 1, more.ctypes.data_as(ctypes.c_void_p)) != 0
