@@ -1,5 +1,9 @@
+#!/usr/bin/env python
+"""Where generation's wall time goes: iobatch.generate_waveforms_corpus on 128 synthetic utterances, both noise modes,
+per-launch duration of mp.synthesis_from_compressed_batch inside the pipeline, then a cProfile of that call."""
 import os, sys, time, tempfile, shutil, threading, cProfile, pstats
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/demos'); sys.path.insert(0, '/root/repo/tools')
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'demos')); sys.path.insert(0, os.path.join(ROOT, 'tools'))
 import numpy as np
 import make_demo_data
 from magphase_amd import iobatch, libaudio as la, synthetic as syn, magphase as mp
