@@ -108,6 +108,11 @@ constexpr int kWarpTile = 64;
 #define MPX_WARP_STRIDE 68
 #endif
 constexpr int kWarpStride = MPX_WARP_STRIDE;   // floats per LDS row (multiple of 4 for float4 reads)
+#ifndef MPX_WARP_KC
+#define MPX_WARP_KC 64
+#endif
+constexpr int kWarpKC = MPX_WARP_KC;                 // bins per staged chunk of the MFMA warp (64 or 128)
+constexpr int kWarpKStride = kWarpKC + (kWarpStride - 64);
 
 __global__ __launch_bounds__(256) void k_mel_warp(WarpJobs jobs, long long F, int H, const int* __restrict__ row0,
                                                   const int* __restrict__ row1, const float* __restrict__ rowt,
@@ -1295,7 +1300,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // epilogue at compile time (as a run-time value it was a scalar branch per staged element: a third of the kernel's
 // instructions were SALU, and the kernel is bound by instruction issue)
 template <int NT, bool INTERP, int MODE>
-__device__ __forceinline__ void mel_warp_block(const WarpJob& job, float (*As)[kWarpStride], float (*Ws)[kWarpStride],
+__device__ __forceinline__ void mel_warp_block(const WarpJob& job, float (*As)[kWarpKStride], float (*Ws)[kWarpKStride],
                                                long long* s_o0, long long* s_o1, float* s_rt, long long F, int H,
                                                const int* __restrict__ row0, const int* __restrict__ row1,
                                                const float* __restrict__ rowt, long long ld) {
@@ -1336,67 +1341,84 @@ __device__ __forceinline__ void mel_warp_block(const WarpJob& job, float (*As)[k
     // unconditional; the chunk that crosses the end of the row (H = 64 q + 1: the last bin alone) clamps per element.
     // The NEXT chunk's loads are issued right after this chunk's values are in LDS, so they fly behind the fragment
     // reads and the MFMAs.
-    const int c4 = threadIdx.x & 15, rr = threadIdx.x >> 4;
+    constexpr int LPR = kWarpKC / 4, RPT = 256 / LPR, NP = kWarpTile / RPT;   // lanes per row, rows per pass, passes
+    constexpr int NPW = (16 * NT + RPT - 1) / RPT;                            // passes that touch a W row in use
+    const int c4 = threadIdx.x % LPR, rr = threadIdx.x / LPR;
     typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte load from a 4-byte aligned address
     auto ld4 = [](const float* q) {
         const f32x4u v = *reinterpret_cast<const f32x4u*>(q);
         return make_float4(v[0], v[1], v[2], v[3]);
     };
-    float4 xv[4], xw[4], wv4[4];
+    float4 xv[NP], xw[NP], wv4[NP];
     auto fetch = [&](int k0) {
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int fl = rr + 16 * p;
+        for (int p = 0; p < NP; ++p) {
+            const int fl = rr + RPT * p;
             const int k = k0 + 4 * c4;
+#ifdef MPX_PROBE_WARP_NOLOAD   // ablation (tools/ab_bench.py): operands faked, no global loads in the chunk loop
+            xv[p] = xw[p] = make_float4(1.0f + 0.001f * (float)(k + fl), 1.1f, 1.2f, 1.3f);
+            wv4[p] = make_float4(0.001f * (float)fl, 0.002f, 0.003f, 0.004f);
+            asm volatile("" : "+v"(xv[p].x), "+v"(xw[p].y), "+v"(wv4[p].z));
+#else
             xv[p] = ld4(job.x + s_o0[fl] + k);
             if (INTERP) xw[p] = ld4(job.x + s_o1[fl] + k);
-            if (p < NT) wv4[p] = ld4(job.W + (long long)min(fl, job.nout - 1) * H + k);
+            if (p < NPW) wv4[p] = ld4(job.W + (long long)min(fl, job.nout - 1) * H + k);
+#endif
         }
     };
-    const int Hfull = H & ~(kWarpTile - 1);   // bins covered by whole chunks; the rest (one bin for H = 64 q + 1) below
+    const int Hfull = H & ~(kWarpKC - 1);   // bins covered by whole chunks; the rest (one bin for H = 64 q + 1) below
     if (Hfull > 0) fetch(0);
-    for (int k0 = 0; k0 < Hfull; k0 += kWarpTile) {
+    for (int k0 = 0; k0 < Hfull; k0 += kWarpKC) {
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int fl = rr + 16 * p;
+        for (int p = 0; p < NP; ++p) {
+            const int fl = rr + RPT * p;
+            // No masking of the padding: frames past F repeat the last frame's rows (s_o0 / s_o1 are clamped) and W rows
+            // past nout repeat the last row -- rows and columns of the product are independent, and the epilogue stores
+            // neither (a select per staged element was 32 of the 180 instructions of this block).
             const float rt = INTERP ? s_rt[fl] : 0.0f;
-            const bool fok = f0 + fl < F;
             const float xin[4] = {xv[p].x, xv[p].y, xv[p].z, xv[p].w};
             const float xin1[4] = {xw[p].x, xw[p].y, xw[p].z, xw[p].w};
-            const float win[4] = {wv4[p].x, wv4[p].y, wv4[p].z, wv4[p].w};
-            float av[4], wo[4];
+            float av[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float x = INTERP ? fmaf(xin1[e] - xin[e], rt, xin[e]) : xin[e];
-                av[e] = fok ? warp_prologue(MODE, x) : 0.0f;
-                wo[e] = (fl < job.nout) ? win[e] : 0.0f;
+                av[e] = warp_prologue(MODE, x);
             }
             *reinterpret_cast<float4*>(&As[fl][4 * c4]) = make_float4(av[0], av[1], av[2], av[3]);
-            if (p < NT) *reinterpret_cast<float4*>(&Ws[fl][4 * c4]) = make_float4(wo[0], wo[1], wo[2], wo[3]);
+            if (p < NPW) *reinterpret_cast<float4*>(&Ws[fl][4 * c4]) = wv4[p];
         }
         __syncthreads();
-        if (k0 + kWarpTile < Hfull) fetch(k0 + kWarpTile);
-        const float* arow = &As[16 * wave + li][16 * g];
-        f32x4 acc[NT];
+        if (k0 + kWarpKC < Hfull) fetch(k0 + kWarpKC);
+#ifdef MPX_PROBE_WARP_NOMFMA   // ablation: staging, barriers and fragment reads only
+#define MPX_WARP_MFMA(a_, b_, c_) ((c_) + f32x4{(a_) * (b_), 0.0f, 0.0f, 0.0f})
+#else
+#define MPX_WARP_MFMA(a_, b_, c_) __builtin_amdgcn_mfma_f32_16x16x4f32((a_), (b_), (c_), 0, 0, 0)
+#endif
 #pragma unroll
-        for (int jt = 0; jt < NT; ++jt) acc[jt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        for (int h = 0; h < kWarpKC / 64; ++h) {   // a fresh accumulator per 64 bins (two-level accumulation, above)
+            const float* arow = &As[16 * wave + li][64 * h + 16 * g];
+            f32x4 acc[NT];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {   // 4 k per lane group and step: one 16-byte read per fragment
-            const float4 aq = *reinterpret_cast<const float4*>(arow + 4 * q);
-            float4 bq[NT];
+            for (int jt = 0; jt < NT; ++jt) acc[jt] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-            for (int jt = 0; jt < NT; ++jt) bq[jt] = *reinterpret_cast<const float4*>(&Ws[16 * jt + li][16 * g + 4 * q]);
+            for (int q = 0; q < 4; ++q) {   // 4 k per lane group and step: one 16-byte read per fragment
+                const float4 aq = *reinterpret_cast<const float4*>(arow + 4 * q);
+                float4 bq[NT];
 #pragma unroll
-            for (int jt = 0; jt < NT; ++jt) acc[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.x, bq[jt].x, acc[jt], 0, 0, 0);
+                for (int jt = 0; jt < NT; ++jt)
+                    bq[jt] = *reinterpret_cast<const float4*>(&Ws[16 * jt + li][64 * h + 16 * g + 4 * q]);
 #pragma unroll
-            for (int jt = 0; jt < NT; ++jt) acc[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.y, bq[jt].y, acc[jt], 0, 0, 0);
+                for (int jt = 0; jt < NT; ++jt) acc[jt] = MPX_WARP_MFMA(aq.x, bq[jt].x, acc[jt]);
 #pragma unroll
-            for (int jt = 0; jt < NT; ++jt) acc[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.z, bq[jt].z, acc[jt], 0, 0, 0);
+                for (int jt = 0; jt < NT; ++jt) acc[jt] = MPX_WARP_MFMA(aq.y, bq[jt].y, acc[jt]);
 #pragma unroll
-            for (int jt = 0; jt < NT; ++jt) acc[jt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq.w, bq[jt].w, acc[jt], 0, 0, 0);
+                for (int jt = 0; jt < NT; ++jt) acc[jt] = MPX_WARP_MFMA(aq.z, bq[jt].z, acc[jt]);
+#pragma unroll
+                for (int jt = 0; jt < NT; ++jt) acc[jt] = MPX_WARP_MFMA(aq.w, bq[jt].w, acc[jt]);
+            }
+#pragma unroll
+            for (int jt = 0; jt < NT; ++jt) tot[jt] += acc[jt];
         }
-#pragma unroll
-        for (int jt = 0; jt < NT; ++jt) tot[jt] += acc[jt];
         __syncthreads();
     }
     // C: column li of tile jt, row 4 g + r of this wave's 16 frames.  The bins past the last whole chunk are added here,
@@ -1432,12 +1454,16 @@ __device__ __forceinline__ void mel_warp_block(const WarpJob& job, float (*As)[k
 // (blockIdx.y == 0) and the two phase jobs get their own column-tile count (60 outputs -> 4 tiles, 45 -> 3: a quarter
 // fewer MFMAs on two thirds of the workgroups).
 template <int NTM, int NTP, bool INTERP, int MAGMODE>
+#if MPX_WARP_KC == 64
 __attribute__((amdgpu_waves_per_eu(4, 4)))   // <= 128 VGPRs: four workgroups (35 KB of LDS each) per CU, measured -5 %
+#else
+__attribute__((amdgpu_waves_per_eu(2, 2)))   // 128-bin chunks: 68 KB of LDS, two workgroups per CU
+#endif
 __global__ __launch_bounds__(256) void k_mel_warp_mfma(WarpJobs jobs, long long F, int H, const int* __restrict__ row0,
                                                        const int* __restrict__ row1, const float* __restrict__ rowt,
                                                        long long ld) {
-    __shared__ __attribute__((aligned(16))) float As[kWarpTile][kWarpStride];   // As[f][k]
-    __shared__ __attribute__((aligned(16))) float Ws[kWarpTile][kWarpStride];   // Ws[i][k]
+    __shared__ __attribute__((aligned(16))) float As[kWarpTile][kWarpKStride];   // As[f][k]
+    __shared__ __attribute__((aligned(16))) float Ws[kWarpTile][kWarpKStride];   // Ws[i][k]
     __shared__ long long s_o0[kWarpTile], s_o1[kWarpTile];   // element offsets of the two input rows of a frame
     __shared__ float s_rt[kWarpTile];
     if (blockIdx.y == 0) mel_warp_block<NTM, INTERP, MAGMODE>(jobs.j[0], As, Ws, s_o0, s_o1, s_rt, F, H, row0, row1, rowt, ld);
