@@ -1729,9 +1729,13 @@ __global__ __launch_bounds__(256) void k_mel_unwarp_tiled(UnwarpJob job, long lo
         for (int t = 0; t < KH; ++t) {
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b0[t], acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b1[t], acc1, 0, 0, 0);
+#ifndef MPX_PROBE_UNWARP_NOBLOAD   // ablation: the first step's U fragments for every step
             const int v = (2 * t + 1 == K) ? vn0e : vn0;
             b0[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(urs, v, soff(t), 0));
             b1[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(urs, v + 128, soff(t), 0));
+#else
+            asm volatile("" : "+v"(b0[t]), "+v"(b1[t]) : "s"(vn0 + vn0e));
+#endif
         }
         wave_sync();   // the previous step's readers are done with the tile
 #pragma unroll
@@ -1765,8 +1769,13 @@ __global__ __launch_bounds__(256) void k_mel_unwarp_tiled(UnwarpJob job, long lo
                     w[u] = e.z;
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
+                for (int u = 0; u < 4; ++u) {
+#ifdef MPX_PROBE_UNWARP_NOSTORE    // ablation: everything but the global stores
+                    asm volatile("" ::"v"(fmaf(m1[u] - m0[u], w[u], m0[u])), "v"(orow));
+#else
                     if (col_ok && i + u < cnt) orow[(long long)(i + u) * ld] = fmaf(m1[u] - m0[u], w[u], m0[u]);
+#endif
+                }
             }
         }
     }
