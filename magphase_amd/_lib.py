@@ -50,6 +50,7 @@ SYMBOLS = (
     "mpx_host_read_files",
     "mpx_mel_warp",
     "mpx_mel_warp_fbank",
+    "mpx_mel_warp_rows",
     "mpx_min_phase",
     "mpx_noise_gains",
     "mpx_post_filter",
@@ -171,6 +172,8 @@ def _load_locked():
     lib.mpx_mel_warp.argtypes = [vp, i64, i32, vp, vp, vp, vp, vp, vp, vp, i32, vp, i32, vp, vp, vp, vp, i64]
     lib.mpx_mel_warp_fbank.restype = ctypes.c_int
     lib.mpx_mel_warp_fbank.argtypes = lib.mpx_mel_warp.argtypes
+    lib.mpx_mel_warp_rows.restype = ctypes.c_int
+    lib.mpx_mel_warp_rows.argtypes = lib.mpx_mel_warp.argtypes + [i32, i64, vp, vp, vp]
     lib.mpx_min_phase.restype = ctypes.c_int
     lib.mpx_min_phase.argtypes = [vp, ctypes.c_int, vp, vp, vp, vp, vp, i64, vp, vp, vp, i64]
     lib.mpx_noise_gains.restype = ctypes.c_int

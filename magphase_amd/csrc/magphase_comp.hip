@@ -79,6 +79,7 @@ struct WarpJob {
     const float* voi;    // [F] or null
     int nout;
     int mode;
+    long long F;         // frames (rows of out) of THIS job: the phase jobs may run on other rows than the magnitudes
 };
 struct WarpJobs {
     WarpJob j[3];
@@ -88,13 +89,15 @@ struct WarpJobs {
 //   0  magnitudes, cepstral warp: ln(x^2 + 1e-8)                                   (mcep -q 3 -e 1e-8 on x, libaudio.py:575-661)
 //   1  phase streams (mcep -q 2 on exp(x), |x| <= 1): ln(e^{2x} + 1e-8) = 2x + 1e-8 e^{-2x} (the next term is 5e-17);
 //      epilogue voicing mask + clip
+//   3  phase streams on the VARIABLE-rate rows (mpx_mel_warp_rows): prologue of mode 1, no epilogue -- the 45 outputs
+//      are interpolated to the constant rate, masked and clipped by k_warp_phase_rows; ``voi`` = the rows in use
 //   2  magnitudes, filter bank: la.log(x) = ln x with -1e10 for x == 0 (libaudio.py:241-248, :763-769); the reference then
 //      takes exp and la.log again (magphase.py:2505-2510): the identity unless the exp underflows to 0 (sum < ln of the
 //      smallest float64, -745.13), which comes back as -1e10
 __device__ __forceinline__ float warp_prologue(int mode, float x) {
     // the argument is >= 1e-8 (never a denormal): the hardware log2 as it is, without __logf's denormal rescaling
     if (mode == 0) return __builtin_amdgcn_logf(fmaf(x, x, 1.0e-8f)) * 0.69314718055994531f;
-    if (mode == 1) return fmaf(1.0e-8f, __expf(-2.0f * x), 2.0f * x);
+    if (mode == 1 || mode == 3) return fmaf(1.0e-8f, __expf(-2.0f * x), 2.0f * x);
     return (x > 0.0f) ? __logf(x) : -1.0e10f;
 }
 __device__ __forceinline__ float warp_epilogue(int mode, float y, float vo) {
@@ -1305,10 +1308,11 @@ __device__ __forceinline__ void mel_warp_block(const WarpJob& job, float (*As)[k
                                                const int* __restrict__ row0, const int* __restrict__ row1,
                                                const float* __restrict__ rowt, long long ld) {
     const long long f0 = (long long)blockIdx.x * kWarpTile;   // row tiles on x: no 65535 limit on the frame count
+    if (f0 >= F) return;                                      // the jobs of a launch need not have the same frame count
     const int kk = threadIdx.x & 63, fq = threadIdx.x >> 6;   // staging roles: bin within the chunk, frame quarter
     const int wave = rfl((int)(threadIdx.x >> 6));
     const int li = kk & 15, g = kk >> 4;                      // fragment roles
-    if (MODE == 1 && job.voi) {   // phase streams are masked by the voicing (magphase.py:2527-2529): a tile without a
+    if ((MODE == 1 || MODE == 3) && job.voi) {   // phase streams are masked by the voicing (magphase.py:2527-2529): a tile without a
         // voiced frame is all zeros -- written as such, nothing read
         const int pred = (threadIdx.x < kWarpTile) && (job.voi[min(f0 + (long long)threadIdx.x, F - 1)] != 0.0f);
         if (!__syncthreads_or(pred)) {
@@ -1438,7 +1442,7 @@ __device__ __forceinline__ void mel_warp_block(const WarpJob& job, float (*As)[k
                 tot[jt][r] = fmaf(v, job.W[(long long)min(i, job.nout - 1) * H + k], tot[jt][r]);
             }
         }
-        const float vo = job.voi ? job.voi[f] : 1.0f;
+        const float vo = (MODE == 1 && job.voi) ? job.voi[f] : 1.0f;
 #pragma unroll
         for (int jt = 0; jt < NT; ++jt) {
             const int i = 16 * jt + li;
@@ -1453,21 +1457,54 @@ __device__ __forceinline__ void mel_warp_block(const WarpJob& job, float (*As)[k
 // One launch for the three jobs (separate launches end in a half-empty last round of workgroups); the magnitude job
 // (blockIdx.y == 0) and the two phase jobs get their own column-tile count (60 outputs -> 4 tiles, 45 -> 3: a quarter
 // fewer MFMAs on two thirds of the workgroups).
-template <int NTM, int NTP, bool INTERP, int MAGMODE>
+// PHV: the phase jobs run on the variable-rate rows themselves (mode 3, no row interpolation, their own frame count);
+// k_warp_phase_rows then interpolates their outputs to the constant rate.
+template <int NTM, int NTP, bool INTERP, int MAGMODE, bool PHV>
 #if MPX_WARP_KC == 64
 __attribute__((amdgpu_waves_per_eu(4, 4)))   // <= 128 VGPRs: four workgroups (35 KB of LDS each) per CU, measured -5 %
 #else
 __attribute__((amdgpu_waves_per_eu(2, 2)))   // 128-bin chunks: 68 KB of LDS, two workgroups per CU
 #endif
-__global__ __launch_bounds__(256) void k_mel_warp_mfma(WarpJobs jobs, long long F, int H, const int* __restrict__ row0,
+__global__ __launch_bounds__(256) void k_mel_warp_mfma(WarpJobs jobs, int H, const int* __restrict__ row0,
                                                        const int* __restrict__ row1, const float* __restrict__ rowt,
                                                        long long ld) {
     __shared__ __attribute__((aligned(16))) float As[kWarpTile][kWarpKStride];   // As[f][k]
     __shared__ __attribute__((aligned(16))) float Ws[kWarpTile][kWarpKStride];   // Ws[i][k]
     __shared__ long long s_o0[kWarpTile], s_o1[kWarpTile];   // element offsets of the two input rows of a frame
     __shared__ float s_rt[kWarpTile];
-    if (blockIdx.y == 0) mel_warp_block<NTM, INTERP, MAGMODE>(jobs.j[0], As, Ws, s_o0, s_o1, s_rt, F, H, row0, row1, rowt, ld);
-    else mel_warp_block<NTP, INTERP, 1>(jobs.j[blockIdx.y], As, Ws, s_o0, s_o1, s_rt, F, H, row0, row1, rowt, ld);
+    if (blockIdx.y == 0)
+        mel_warp_block<NTM, INTERP, MAGMODE>(jobs.j[0], As, Ws, s_o0, s_o1, s_rt, jobs.j[0].F, H, row0, row1, rowt, ld);
+    else if (PHV)
+        mel_warp_block<NTP, false, 3>(jobs.j[blockIdx.y], As, Ws, s_o0, s_o1, s_rt, jobs.j[blockIdx.y].F, H, nullptr, nullptr,
+                                      nullptr, ld);
+    else
+        mel_warp_block<NTP, INTERP, 1>(jobs.j[blockIdx.y], As, Ws, s_o0, s_o1, s_rt, jobs.j[blockIdx.y].F, H, row0, row1, rowt,
+                                       ld);
+}
+
+// Phase streams of the compressed analysis at the constant rate from their variable-rate warp (mode 3): row
+// interpolation of the phase_dim outputs, then the epilogue of mode 1 (voicing mask, clip; magphase.py:2527-2532).
+// The warp is linear up to its 1e-8 e^{-2x} floor term, so interpolating after it instead of before differs by < 1e-8 per
+// bin; rows no voiced frame uses were not computed and are not read (the select discards them).
+__global__ __launch_bounds__(256) void k_warp_phase_rows(const float* __restrict__ tr, const float* __restrict__ ti,
+                                                         const int* __restrict__ row0, const int* __restrict__ row1,
+                                                         const float* __restrict__ rowt, const float* __restrict__ voi,
+                                                         long long F, int nout, float* __restrict__ out_r,
+                                                         float* __restrict__ out_i) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= F * nout) return;
+    const long long f = idx / nout;
+    const int i = (int)(idx - f * nout);
+    const float vo = voi[f];
+    float yr = 0.0f, yi = 0.0f;
+    if (vo != 0.0f) {
+        const long long a = (long long)row0[f] * nout + i, b = (long long)row1[f] * nout + i;
+        const float t = rowt[f];
+        yr = warp_epilogue(1, fmaf(tr[b] - tr[a], t, tr[a]), vo);
+        yi = warp_epilogue(1, fmaf(ti[b] - ti[a], t, ti[a]), vo);
+    }
+    out_r[idx] = yr;
+    out_i[idx] = yi;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1941,10 +1978,13 @@ int mpx_synthesis_compressed_ola(void* stream, int fft_len, const void* tables, 
     return MPX_OK;
 }
 
+// n_var_rows / need / tmp_real / tmp_imag: the phase jobs on the variable-rate rows (mpx_mel_warp_rows), or 0 / null
 static int mel_warp_impl(void* stream, int64_t n_frames, int32_t n_bins, const float* mag, const float* real,
                          const float* imag, const int32_t* row0, const int32_t* row1, const float* row_t,
                          const float* w_mag, int32_t mag_dim, const float* w_phase, int32_t phase_dim, const float* voiced,
-                         float* out_mag, float* out_real, float* out_imag, int64_t ld, int mag_mode) {
+                         float* out_mag, float* out_real, float* out_imag, int64_t ld, int mag_mode,
+                         int64_t n_var_rows = 0, const float* need = nullptr, float* tmp_real = nullptr,
+                         float* tmp_imag = nullptr) {
     if (n_frames < 0 || n_bins <= 0 || ld < n_bins) return fail(MPX_ERR_ARG, "mpx_mel_warp: bad size%s");
     if (mag_dim <= 0 || mag_dim > kWarpTile || phase_dim <= 0 || phase_dim > kWarpTile)
         return fail(MPX_ERR_ARG, "mpx_mel_warp: output dimension must be in 1..64%s");
@@ -1953,32 +1993,39 @@ static int mel_warp_impl(void* stream, int64_t n_frames, int32_t n_bins, const f
         return fail(MPX_ERR_ARG, "mpx_mel_warp: null pointer%s");
     if ((row0 == nullptr) != (row1 == nullptr) || (row0 == nullptr) != (row_t == nullptr))
         return fail(MPX_ERR_ARG, "mpx_mel_warp: row0/row1/row_t must be all null or all given%s");
+    const bool phv = tmp_real != nullptr;
+    if (phv && (!row0 || !tmp_imag || !need || n_var_rows <= 0))
+        return fail(MPX_ERR_ARG, "mpx_mel_warp_rows: the variable-rate phase warp needs row tables, both scratch matrices and the row flags%s");
     WarpJobs jobs;
-    jobs.j[0] = {mag, w_mag, out_mag, nullptr, (int)mag_dim, mag_mode};
-    jobs.j[1] = {real, w_phase, out_real, voiced, (int)phase_dim, 1};
-    jobs.j[2] = {imag, w_phase, out_imag, voiced, (int)phase_dim, 1};
-    const dim3 grid((unsigned)((n_frames + kWarpTile - 1) / kWarpTile), 3);
+    jobs.j[0] = {mag, w_mag, out_mag, nullptr, (int)mag_dim, mag_mode, (long long)n_frames};
+    if (phv) {
+        jobs.j[1] = {real, w_phase, tmp_real, need, (int)phase_dim, 3, (long long)n_var_rows};
+        jobs.j[2] = {imag, w_phase, tmp_imag, need, (int)phase_dim, 3, (long long)n_var_rows};
+    } else {
+        jobs.j[1] = {real, w_phase, out_real, voiced, (int)phase_dim, 1, (long long)n_frames};
+        jobs.j[2] = {imag, w_phase, out_imag, voiced, (int)phase_dim, 1, (long long)n_frames};
+    }
+    const long long max_f = phv ? ((long long)n_frames > (long long)n_var_rows ? (long long)n_frames : (long long)n_var_rows) : (long long)n_frames;
+    const dim3 grid((unsigned)((max_f + kWarpTile - 1) / kWarpTile), 3);
 #ifdef MPX_WARP_VALU
+    if (phv) return fail(MPX_ERR_ARG, "mpx_mel_warp_rows: not in the VALU build%s");
     hipLaunchKernelGGL(k_mel_warp, grid, dim3(256), 0, (hipStream_t)stream, jobs, (long long)n_frames, (int)n_bins,
                        row0, row1, row_t, (long long)ld);
 #else
     {
         const dim3 g2(grid.x, 3);
         const int ntm = ((int)mag_dim + 15) / 16, ntp = ((int)phase_dim + 15) / 16;
-#define MPX_WARP_LAUNCH(NTM, NTP)                                                                                  \
-    do {                                                                                                           \
-        if (row0 && mag_mode == 0)                                                                                 \
-            hipLaunchKernelGGL((k_mel_warp_mfma<NTM, NTP, true, 0>), g2, dim3(256), 0, (hipStream_t)stream, jobs,  \
-                               (long long)n_frames, (int)n_bins, row0, row1, row_t, (long long)ld);                \
-        else if (row0)                                                                                             \
-            hipLaunchKernelGGL((k_mel_warp_mfma<NTM, NTP, true, 2>), g2, dim3(256), 0, (hipStream_t)stream, jobs,  \
-                               (long long)n_frames, (int)n_bins, row0, row1, row_t, (long long)ld);                \
-        else if (mag_mode == 0)                                                                                    \
-            hipLaunchKernelGGL((k_mel_warp_mfma<NTM, NTP, false, 0>), g2, dim3(256), 0, (hipStream_t)stream, jobs, \
-                               (long long)n_frames, (int)n_bins, row0, row1, row_t, (long long)ld);                \
-        else                                                                                                       \
-            hipLaunchKernelGGL((k_mel_warp_mfma<NTM, NTP, false, 2>), g2, dim3(256), 0, (hipStream_t)stream, jobs, \
-                               (long long)n_frames, (int)n_bins, row0, row1, row_t, (long long)ld);                \
+#define MPX_WARP_GO(NTM, NTP, IN, MM, PV)                                                                              \
+    hipLaunchKernelGGL((k_mel_warp_mfma<NTM, NTP, IN, MM, PV>), g2, dim3(256), 0, (hipStream_t)stream, jobs, (int)n_bins, \
+                       row0, row1, row_t, (long long)ld)
+#define MPX_WARP_LAUNCH(NTM, NTP)                                   \
+    do {                                                            \
+        if (phv && mag_mode == 0) MPX_WARP_GO(NTM, NTP, true, 0, true);      \
+        else if (phv) MPX_WARP_GO(NTM, NTP, true, 2, true);         \
+        else if (row0 && mag_mode == 0) MPX_WARP_GO(NTM, NTP, true, 0, false);  \
+        else if (row0) MPX_WARP_GO(NTM, NTP, true, 2, false);       \
+        else if (mag_mode == 0) MPX_WARP_GO(NTM, NTP, false, 0, false);      \
+        else MPX_WARP_GO(NTM, NTP, false, 2, false);                \
     } while (0)
 #define MPX_WARP_ROW(NTM)                       \
     switch (ntp) {                              \
@@ -1995,10 +2042,27 @@ static int mel_warp_impl(void* stream, int64_t n_frames, int32_t n_bins, const f
         }
 #undef MPX_WARP_ROW
 #undef MPX_WARP_LAUNCH
+#undef MPX_WARP_GO
     }
 #endif
+    if (phv) {
+        const long long n_el = (long long)n_frames * phase_dim;
+        hipLaunchKernelGGL(k_warp_phase_rows, dim3((unsigned)((n_el + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                           (const float*)tmp_real, (const float*)tmp_imag, row0, row1, row_t, voiced, (long long)n_frames,
+                           (int)phase_dim, out_real, out_imag);
+    }
     MPX_HIP_CHECK(hipGetLastError());
     return MPX_OK;
+}
+
+int mpx_mel_warp_rows(void* stream, int64_t n_frames, int32_t n_bins, const float* mag, const float* real,
+                      const float* imag, const int32_t* row0, const int32_t* row1, const float* row_t, const float* w_mag,
+                      int32_t mag_dim, const float* w_phase, int32_t phase_dim, const float* voiced, float* out_mag,
+                      float* out_real, float* out_imag, int64_t ld, int32_t mag_fbank, int64_t n_var_rows,
+                      const float* rows_in_use, float* tmp_real, float* tmp_imag) {
+    return mel_warp_impl(stream, n_frames, n_bins, mag, real, imag, row0, row1, row_t, w_mag, mag_dim, w_phase, phase_dim,
+                         voiced, out_mag, out_real, out_imag, ld, mag_fbank ? 2 : 0, n_var_rows, rows_in_use, tmp_real,
+                         tmp_imag);
 }
 
 int mpx_mel_warp(void* stream, int64_t n_frames, int32_t n_bins, const float* mag, const float* real, const float* imag,

@@ -1131,9 +1131,21 @@ class CompressedAnalysisPlan:
         if b_const_rate:
             items += [("row0", np.concatenate(row0), np.int32), ("row1", np.concatenate(row1), np.int32),
                       ("rowt", np.concatenate(rowt), np.float32)]
+        # phase streams warped on the variable-rate rows, their 45 outputs interpolated afterwards (mpx_mel_warp_rows):
+        # the rows a voiced constant-rate frame interpolates from
+        self.phase_on_rows = bool(b_const_rate) and os.environ.get("MAGPHASE_WARP_PHASE_ROWS", "1") != "0"
+        if self.phase_on_rows:
+            voiced = items[0][1] > 0
+            r0, r1 = np.concatenate(row0), np.concatenate(row1)
+            need = np.zeros(plan.total_frames, dtype=np.float32)
+            need[r0[voiced]] = 1.0
+            need[r1[voiced]] = 1.0
+            items.append(("rows_in_use", need, np.float32))
         desc = e.to_device_packed(items)   # one H2D copy
         self.voi = desc["voi"]
         self.row0, self.row1, self.rowt = (desc.get(k) for k in ("row0", "row1", "rowt"))
+        self.rows_in_use = desc.get("rows_in_use")
+        self._phase_tmp = None
 
     def run(self, feats=None, out=None, mark=None):
         e, torch = self.engine, _torch()
@@ -1149,11 +1161,23 @@ class CompressedAnalysisPlan:
                    e.empty((self.total_out_frames, self.phase_dim)))
         ptr = (lambda t: t.data_ptr() if t is not None else None)
         with torch.cuda.device(e.device):
-            _lib.check(self._warp_fn(e.stream_ptr(), self.total_out_frames, H, mag.data_ptr(), real.data_ptr(),
-                                     imag.data_ptr(), ptr(self.row0), ptr(self.row1), ptr(self.rowt),
-                                     self.w_mag.data_ptr(), self.mag_dim, self.w_ph.data_ptr(), self.phase_dim,
-                                     self.voi.data_ptr(), out[0].data_ptr(), out[1].data_ptr(),
-                                     out[2].data_ptr(), e.feat_ld(mag, real, imag)), self._warp_name)
+            if self.phase_on_rows:
+                n_var = self.lossless.total_frames
+                if self._phase_tmp is None:
+                    self._phase_tmp = (e.empty((n_var, self.phase_dim)), e.empty((n_var, self.phase_dim)))
+                _lib.check(e.lib.mpx_mel_warp_rows(
+                    e.stream_ptr(), self.total_out_frames, H, mag.data_ptr(), real.data_ptr(), imag.data_ptr(),
+                    ptr(self.row0), ptr(self.row1), ptr(self.rowt), self.w_mag.data_ptr(), self.mag_dim,
+                    self.w_ph.data_ptr(), self.phase_dim, self.voi.data_ptr(), out[0].data_ptr(), out[1].data_ptr(),
+                    out[2].data_ptr(), e.feat_ld(mag, real, imag), 1 if self._warp_name == "mpx_mel_warp_fbank" else 0,
+                    n_var, self.rows_in_use.data_ptr(), self._phase_tmp[0].data_ptr(), self._phase_tmp[1].data_ptr()),
+                    "mpx_mel_warp_rows")
+            else:
+                _lib.check(self._warp_fn(e.stream_ptr(), self.total_out_frames, H, mag.data_ptr(), real.data_ptr(),
+                                         imag.data_ptr(), ptr(self.row0), ptr(self.row1), ptr(self.rowt),
+                                         self.w_mag.data_ptr(), self.mag_dim, self.w_ph.data_ptr(), self.phase_dim,
+                                         self.voi.data_ptr(), out[0].data_ptr(), out[1].data_ptr(),
+                                         out[2].data_ptr(), e.feat_ld(mag, real, imag)), self._warp_name)
         mark("k_mel_warp_mfma")
         return out
 

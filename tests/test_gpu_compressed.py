@@ -242,6 +242,38 @@ def test_compressed_analysis_matches_golden(mp, golden_dir, tag, kw):
     assert r[5] == fs and r[6] == 4096
 
 
+def test_phase_warp_on_variable_rate_rows_equals_warp_of_interpolated_rows(monkeypatch):
+    """mpx_mel_warp_rows: the phase streams warped once per variable-rate row and interpolated afterwards against the
+    reference's order (rows interpolated, then warped: mpx_mel_warp with row tables).  The warp is linear up to its
+    1e-8 e^{-2x} floor term: the two orders agree to fp32 rounding of sums of 2049 terms (WARP_PHASE_TOL / 7); unvoiced constant-rate frames are
+    +0 in both, the magnitudes are the same launch."""
+    from magphase_amd import synthetic as syn
+    from magphase_amd.engine import CompressedAnalysisPlan, get_engine
+    eng = get_engine()
+    utts = []
+    for u, fs in enumerate((48000, 48000, 48000)):
+        pcm, pm, voi = syn.make_utterance(40 + u, dur_s=1.5 + 0.5 * u, fs=fs)
+        utts.append((pcm, fs, pm, voi))
+    outs = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("MAGPHASE_WARP_PHASE_ROWS", flag)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            plan = CompressedAnalysisPlan(eng, utts, mag_dim=60, phase_dim=45, b_const_rate=True)
+        assert plan.phase_on_rows == (flag == "1")
+        outs[flag] = [t.cpu().numpy() for t in plan.run()]
+        voi = plan.voi.cpu().numpy()
+    assert np.array_equal(outs["1"][0], outs["0"][0])
+    assert 0.2 < voi.mean() < 0.9
+    for k in (1, 2):
+        a, b = outs["1"][k], outs["0"][k]
+        assert np.all(a[voi == 0] == 0.0) and np.all(b[voi == 0] == 0.0)
+        assert np.max(np.abs(a)) <= 1.0
+        # both are fp32 sums of 2049 terms of size ~1 in different association: each is ~1e-6 from the float64 value
+        assert np.max(np.abs(a - b)) < 3e-6, np.max(np.abs(a - b))
+        assert np.sqrt(np.mean((a - b) ** 2)) < 2e-7, np.sqrt(np.mean((a - b) ** 2))
+
+
 def test_low_dim_copy_synthesis_roundtrip(mp, orc):
     """demo_copy_synthesis_low_dim call sequence on the device path vs the same sequence in the oracle."""
     from magphase_amd import synthetic as syn
