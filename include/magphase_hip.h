@@ -62,12 +62,16 @@ int mpx_analysis_frames(void* stream, int fft_len, const void* tables, const flo
  * and uses Re X/|X| of bins 60-80 dB below the frame peak (magphase.py:2508-2521, libaudio.py:575-601).  About twice
  * the time of mpx_analysis_frames (float64 vector rate, 8 waves per CU).  tables_f64: mpx_tables_f64_bytes() bytes
  * initialised by mpx_tables_f64_init() (float64 twiddles; same life cycle as mpx_tables_init's table).
+ * rows_in_use [n_frames] (DEVICE) or NULL: frames with a 0 get their magnitude row only -- out_real / out_imag keep what
+ * they held (the compressed analysis never reads the phase features of rows no voiced frame interpolates from:
+ * mpx_mel_warp_rows' rows_in_use).
  */
 size_t mpx_tables_f64_bytes(int fft_len);
 int mpx_tables_f64_init(void* stream, int fft_len, void* tables);
 int mpx_analysis_frames_f64(void* stream, int fft_len, const void* tables_f64, const float* sig,
                             const int64_t* frame_pos, const int32_t* frame_left, const int32_t* frame_right,
-                            int64_t n_frames, float* out_mag, float* out_real, float* out_imag, int64_t ld);
+                            int64_t n_frames, float* out_mag, float* out_real, float* out_imag, int64_t ld,
+                            const float* rows_in_use);
 
 /*
  * Row pitch (in floats) the lossless feature matrices should be allocated with.  Any ld >= H is CORRECT for every

@@ -111,7 +111,7 @@ def _load_locked():
     lib.mpx_tables_f64_init.restype = ctypes.c_int
     lib.mpx_tables_f64_init.argtypes = [vp, ctypes.c_int, vp]
     lib.mpx_analysis_frames_f64.restype = ctypes.c_int
-    lib.mpx_analysis_frames_f64.argtypes = [vp, ctypes.c_int, vp, vp, vp, vp, vp, i64, vp, vp, vp, i64]
+    lib.mpx_analysis_frames_f64.argtypes = [vp, ctypes.c_int, vp, vp, vp, vp, vp, i64, vp, vp, vp, i64, vp]
     lib.mpx_feat_ld.restype = i64
     lib.mpx_feat_ld.argtypes = [ctypes.c_int]
     lib.mpx_synthesis_lossless_frames.restype = ctypes.c_int

@@ -9,6 +9,8 @@
 // Cost: float64 vector rate is half the fp32 rate and the 64 complex registers of a frame take 128 VGPRs, so 8 waves
 // per CU; the kernel is compute-bound at ~2x the fp32 kernel's time (profiles/), which the compressed path can afford:
 // it is not bandwidth-bound.
+#include <type_traits>
+
 #include "mpx_common.hpp"
 #include "wave_fft_f64.hpp"
 
@@ -51,15 +53,19 @@ __device__ __forceinline__ double rsqrt_f64(double s) {
     return r * fma(-0.5 * s, r * r, 1.5);
 }
 
-// |X|, Re X / |X|, Im X / |X| as float32 (0, 0, 0 where X == 0: magphase.py:466-472)
+// |X|, Re X / |X|, Im X / |X| as float32 (0, 0, 0 where X == 0: magphase.py:466-472).  PH == false: the magnitude only
+// (rows whose phase features nobody reads, mpx_analysis_frames_f64's rows_in_use)
+template <bool PH>
 __device__ __forceinline__ void feat_store(double xr, double xi, float* pm, float* pr, float* pi) {
     const double s = xr * xr + xi * xi;
     // the fp32 estimate needs a normal float: |X|^2 below 1e-38 is zero for the float32 features anyway
     const bool nz = s > 1.0e-36;
     const double r = nz ? rsqrt_f64(s) : 0.0;
     *pm = (float)(s * r);
-    *pr = (float)(xr * r);
-    *pi = (float)(xi * r);
+    if (PH) {
+        *pr = (float)(xr * r);
+        *pi = (float)(xi * r);
+    }
 }
 
 template <int P>
@@ -69,7 +75,8 @@ __global__ __launch_bounds__(kAna64Waves * 64) void k_analysis_f64(const float* 
                                                                   const int* __restrict__ fright, long long nframes,
                                                                   const double* __restrict__ tw_g,
                                                                   float* __restrict__ omag, float* __restrict__ oreal,
-                                                                  float* __restrict__ oimag, long long ld) {
+                                                                  float* __restrict__ oimag, long long ld,
+                                                                  const float* __restrict__ rows_in_use) {
     constexpr int M = 64 * P, N = 2 * M, LB = ilog2(P), kTile = 64 * P;
     extern __shared__ __attribute__((aligned(16))) double smem64[];
     double* tw = smem64;
@@ -149,38 +156,45 @@ __global__ __launch_bounds__(kAna64Waves * 64) void k_analysis_f64(const float* 
 #define MPX_F64_EPI_BATCH 4
 #endif
         constexpr int EB = MPX_F64_EPI_BATCH;
+        auto epilogue = [&](auto ph_tag) {
+            constexpr bool PH = decltype(ph_tag)::value;
 #pragma unroll
-        for (int qb = 0; qb < P / 2; qb += EB) {
-            double zpr[EB], zpi[EB];   // EB partner bins per batch: 4 EB lane exchanges in flight
+            for (int qb = 0; qb < P / 2; qb += EB) {
+                double zpr[EB], zpi[EB];   // EB partner bins per batch: 4 EB lane exchanges in flight
 #pragma unroll
-            for (int u = 0; u < EB; ++u) {
-                const int i = brev(qb + u, LB);
-                unsigned a, b, c, d;
-                split64(re[P - 1 - i], a, b);
-                split64(im[P - 1 - i], c, d);
-                zpr[u] = join64((unsigned)__shfl((int)a, src_lane), (unsigned)__shfl((int)b, src_lane));
-                zpi[u] = join64((unsigned)__shfl((int)c, src_lane), (unsigned)__shfl((int)d, src_lane));
+                for (int u = 0; u < EB; ++u) {
+                    const int i = brev(qb + u, LB);
+                    unsigned a, b, c, d;
+                    split64(re[P - 1 - i], a, b);
+                    split64(im[P - 1 - i], c, d);
+                    zpr[u] = join64((unsigned)__shfl((int)a, src_lane), (unsigned)__shfl((int)b, src_lane));
+                    zpi[u] = join64((unsigned)__shfl((int)c, src_lane), (unsigned)__shfl((int)d, src_lane));
+                }
+#pragma unroll
+                for (int u = 0; u < EB; ++u) {
+                    const int q = qb + u;
+                    const int i = brev(q, LB);
+                    const int i0 = brev((P - q) % P, LB);
+                    const double pr = lane0 ? re[i0] : zpr[u];
+                    const double pi = lane0 ? im[i0] : zpi[u];
+                    const double er = 0.5 * (re[i] + pr), ei = 0.5 * (im[i] - pi);
+                    const double orr = 0.5 * (im[i] + pi), oi = -0.5 * (re[i] - pr);
+                    constexpr int kq = 64 / (2 * P);   // e^{-2 pi i q / (2P)} = W_64^{q kq}
+                    const double cq = dc64(q * kq), sq = -ds64(q * kq);
+                    const double wr = wl_c * cq - wl_s * sq, wi = wl_c * sq + wl_s * cq;
+                    const double tr = wr * orr - wi * oi, ti = wr * oi + wi * orr;
+                    const int k = kap + 64 * q;
+                    feat_store<PH>(er + tr, ei + ti, row_m + k, row_r + k, row_i + k);
+                    const int km = M - k;              // kappa == 0, q == 0: bin M
+                    feat_store<PH>(er - tr, ti - ei, row_m + km, row_r + km, row_i + km);
+                }
             }
-#pragma unroll
-            for (int u = 0; u < EB; ++u) {
-                const int q = qb + u;
-                const int i = brev(q, LB);
-                const int i0 = brev((P - q) % P, LB);
-                const double pr = lane0 ? re[i0] : zpr[u];
-                const double pi = lane0 ? im[i0] : zpi[u];
-                const double er = 0.5 * (re[i] + pr), ei = 0.5 * (im[i] - pi);
-                const double orr = 0.5 * (im[i] + pi), oi = -0.5 * (re[i] - pr);
-                constexpr int kq = 64 / (2 * P);   // e^{-2 pi i q / (2P)} = W_64^{q kq}
-                const double cq = dc64(q * kq), sq = -ds64(q * kq);
-                const double wr = wl_c * cq - wl_s * sq, wi = wl_c * sq + wl_s * cq;
-                const double tr = wr * orr - wi * oi, ti = wr * oi + wi * orr;
-                const int k = kap + 64 * q;
-                feat_store(er + tr, ei + ti, row_m + k, row_r + k, row_i + k);
-                const int km = M - k;              // kappa == 0, q == 0: bin M
-                feat_store(er - tr, ti - ei, row_m + km, row_r + km, row_i + km);
-            }
-        }
-        if (lane0) feat_store(re[1], -im[1], row_m + M / 2, row_r + M / 2, row_i + M / 2);
+            if (lane0) feat_store<PH>(re[1], -im[1], row_m + M / 2, row_r + M / 2, row_i + M / 2);
+        };
+        // rows whose phase features no consumer reads (the compressed analysis: unvoiced stretches) get the magnitude only:
+        // a third of the stores and two conversions per bin less, one wave-uniform branch per frame
+        if (rows_in_use == nullptr || rfl((int)(rows_in_use[f] != 0.0f))) epilogue(std::true_type{});
+        else epilogue(std::false_type{});
     }
 }
 
@@ -226,7 +240,7 @@ int mpx_tables_f64_init(void* stream, int fft_len, void* tables) {
 
 int mpx_analysis_frames_f64(void* stream, int fft_len, const void* tables_f64, const float* sig, const int64_t* frame_pos,
                             const int32_t* frame_left, const int32_t* frame_right, int64_t n_frames, float* out_mag,
-                            float* out_real, float* out_imag, int64_t ld) {
+                            float* out_real, float* out_imag, int64_t ld, const float* rows_in_use) {
     const int P = p_of(fft_len);
     if (!P) return fail(MPX_ERR_ARG, "mpx_analysis_frames_f64: fft_len must be 1024, 2048 or 4096%s");
     if (n_frames < 0) return fail(MPX_ERR_ARG, "mpx_analysis_frames_f64: negative n_frames%s");
@@ -241,7 +255,7 @@ int mpx_analysis_frames_f64(void* stream, int fft_len, const void* tables_f64, c
         if (int rc = set_lds(k_analysis_f64<PP>, lds_bytes_ana64<PP>())) return rc;                               \
         hipLaunchKernelGGL(k_analysis_f64<PP>, grid, block, lds_bytes_ana64<PP>(), s, sig,                        \
                            (const long long*)frame_pos, frame_left, frame_right, (long long)n_frames,             \
-                           (const double*)tables_f64, out_mag, out_real, out_imag, (long long)ld);                \
+                           (const double*)tables_f64, out_mag, out_real, out_imag, (long long)ld, rows_in_use);   \
     } while (0)
     if (P == 32) MPX_LAUNCH_A64(32);
     else if (P == 16) MPX_LAUNCH_A64(16);

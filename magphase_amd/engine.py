@@ -295,9 +295,10 @@ class Engine:
         return self._tables[key]
 
     # ------------------------------------------------------------------ kernels
-    def analysis_frames(self, fft_len, sig, pos, left, right, out=None, precise=False):
+    def analysis_frames(self, fft_len, sig, pos, left, right, out=None, precise=False, rows_in_use=None):
         """sig f32[n], pos i64[F], left/right i32[F] (device) -> (mag, real, imag) f32[F x H] (device).
-        precise: window / transform / epilogue in float64 (mpx_analysis_frames_f64): the compressed analysis' choice."""
+        precise: window / transform / epilogue in float64 (mpx_analysis_frames_f64): the compressed analysis' choice;
+        rows_in_use (precise only): f32[F], 0 = this frame's phase rows are never read, write the magnitudes only."""
         torch = _torch()
         nfr = int(pos.numel())
         H = fft_len // 2 + 1
@@ -306,9 +307,10 @@ class Engine:
         ld = self.feat_ld(*out)
         tab = self.tables_f64(fft_len) if precise else self.tables(fft_len)
         fn = self.lib.mpx_analysis_frames_f64 if precise else self.lib.mpx_analysis_frames
+        extra = ((rows_in_use.data_ptr() if rows_in_use is not None else None),) if precise else ()
         with torch.cuda.device(self.device):
             _lib.check(fn(self.stream_ptr(), int(fft_len), tab.data_ptr(), sig.data_ptr(), pos.data_ptr(), left.data_ptr(),
-                          right.data_ptr(), nfr, out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), ld),
+                          right.data_ptr(), nfr, out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), ld, *extra),
                        "mpx_analysis_frames_f64" if precise else "mpx_analysis_frames")
         return out
 
@@ -612,9 +614,9 @@ class LosslessAnalysisPlan:
         self.pos, self.left, self.right = desc["pos"], desc["left"], desc["right"]
         self.total_smpls = int(off)
 
-    def run(self, out=None, precise=False):
+    def run(self, out=None, precise=False, rows_in_use=None):
         return self.engine.analysis_frames(self.fft_len, self.sig, self.pos, self.left, self.right, out=out,
-                                           precise=precise)
+                                           precise=precise, rows_in_use=rows_in_use if precise else None)
 
 
 class LosslessSynthesisPlan:
@@ -1154,7 +1156,9 @@ class CompressedAnalysisPlan:
         mark("start")
         # float64 transform: the warp's log / division amplify an fp32 FFT's noise on weak bins (magphase_f64.hip)
         precise = os.environ.get("MAGPHASE_COMP_ANALYSIS", "f64") != "f32"
-        mag, real, imag = self.lossless.run(out=feats, precise=precise)
+        # (the phase rows nobody reads -- rows_in_use == 0 -- are not written either)
+        mag, real, imag = self.lossless.run(out=feats, precise=precise,
+                                            rows_in_use=self.rows_in_use if self.phase_on_rows else None)
         mark("k_analysis_f64" if precise else "k_analysis")
         if out is None:
             out = (e.empty((self.total_out_frames, self.mag_dim)), e.empty((self.total_out_frames, self.phase_dim)),

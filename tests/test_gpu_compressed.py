@@ -223,6 +223,27 @@ def test_f64_analysis_features_are_correctly_rounded(orc):
         assert np.array_equal(plan.v_f0[0], o[3])
 
 
+def test_f64_analysis_rows_in_use_skips_only_the_phase_rows():
+    """mpx_analysis_frames_f64(rows_in_use): frames flagged 0 get their magnitude row only -- the real / imag rows keep
+    what the buffers held; everything else is bit-identical to the unflagged launch."""
+    import torch
+    from magphase_amd import synthetic as syn
+    from magphase_amd.engine import LosslessAnalysisPlan, get_engine
+    eng = get_engine()
+    pcm, pm, voi = syn.make_utterance(9, dur_s=1.0, fs=48000)
+    plan = LosslessAnalysisPlan(eng, [(syn.pcm_to_float(pcm), 48000, pm, voi)])
+    full = [t.clone() for t in plan.run(precise=True)]
+    F = plan.total_frames
+    use = (torch.arange(F, device=eng.device) % 3 != 1).float()
+    out = tuple(torch.full_like(t, -7.0) for t in full)
+    got = plan.run(out=out, precise=True, rows_in_use=use)
+    keep = use.bool()
+    assert torch.equal(got[0], full[0])
+    for k in (1, 2):
+        assert torch.equal(got[k][keep], full[k][keep])
+        assert bool((got[k][~keep] == -7.0).all()) and int((~keep).sum()) > 50
+
+
 @pytest.mark.parametrize("tag,kw", [("vr45", dict(phase_dim=45)), ("cr45", dict(phase_dim=45, b_const_rate=True)),
                                      ("q7", dict(phase_dim=10, alpha_phase=False))])
 def test_compressed_analysis_matches_golden(mp, golden_dir, tag, kw):
