@@ -223,10 +223,12 @@ def measure_lowdim(eng, utts, steps, warmup):
     n_in, n_out, n_noise = aplan.lossless.total_smpls, splan.total_out, int(sum(splan.ns_len))
     dims = aplan.mag_dim + 2 * aplan.phase_dim
     n_per, n_voiced = int(splan.n_per), int(splan.voiced_host.sum())
+    n_phase_rows = int(aplan.rows_in_use.sum().item()) if getattr(aplan, "phase_on_rows", False) else Fv
     # per-kernel bound.  bytes: what THIS kernel reads + writes as the path is staged today; flops: the GEMM's 2 m n k
     kinfo = {
         "k_analysis": ("hbm", 12.0 * H * Fv + 4.0 * n_in),
-        "k_analysis_f64": ("hbm", 12.0 * H * Fv + 4.0 * n_in),
+        # magnitude row of every frame, phase rows of the frames a voiced constant-rate frame interpolates from
+        "k_analysis_f64": ("hbm", 4.0 * H * Fv + 8.0 * H * n_phase_rows + 4.0 * n_in),
         "k_mel_warp_mfma": ("mfma", 2.0 * H * dims * Fc),
         "k_post_filter": ("hbm", 8.0 * aplan.mag_dim * Fc),
         # variable-rate rows.  Magnitudes: two products over all H bins (k_mel_unwarp_tiled, timed under this mark too);
@@ -264,7 +266,7 @@ def measure_lowdim(eng, utts, steps, warmup):
         "value": round(Fc / (ms_step * 1e-3), 1), "unit": "5ms-frames/s",
         "x_realtime": round(UTTS_PER_GPU * DUR_S / (ms_step * 1e-3), 1),
         "const_rate_frames": Fc, "variable_rate_frames_analysed": Fv, "variable_rate_frames_resynthesised": Fs,
-        "voiced_frames_resynthesised": n_voiced, "periodic_bins": n_per,
+        "voiced_frames_resynthesised": n_voiced, "periodic_bins": n_per, "analysis_rows_with_phase": n_phase_rows,
         "kernels": kern,
         "roofline": {"kernel": dom["name"], "bound": dom["bound"], "achieved": dom["achieved"], "unit": dom["unit"],
                      "peak": HBM_PEAK_GBS if dom["bound"] == "hbm" else MFMA_F32_PEAK_TF, "frac": dom["frac"]},
