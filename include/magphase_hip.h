@@ -219,7 +219,8 @@ int mpx_noise_uniform(void* stream, int32_t n_utts, const uint64_t* seeds, const
  * the first one (X[n + J] = xor of X[n + i] over the set bits of x^J mod the generator's characteristic polynomial;
  * log2(segments) rounds of k_mt_jump, polynomials from mpx_host_mt19937_jump_poly).  Without work, or for short draws,
  * one workgroup runs the recurrence from the key (454 words per barrier).  A second kernel converts.  Bit-identical
- * either way.
+ * either way.  The many-workgroup form waits for the stream once (the polynomials are uploaded from pageable memory);
+ * its caller reads key_out / pos_out back right afterwards anyway.
  */
 int mpx_noise_numpy_mt19937(void* stream, const uint32_t* key, int32_t pos, int64_t n_samples, uint32_t* raw,
                             float* out, uint32_t* key_out, int32_t* pos_out, uint32_t* work);
