@@ -55,11 +55,15 @@ __device__ __forceinline__ double rsqrt_f64(double s) {
 
 // |X|, Re X / |X|, Im X / |X| as float32 (0, 0, 0 where X == 0: magphase.py:466-472).  PH == false: the magnitude only
 // (rows whose phase features nobody reads, mpx_analysis_frames_f64's rows_in_use)
+// zero2: |X|^2 at or below it is the transform's own rounding noise (k_analysis_f64: (2^-45 sum |windowed samples|)^2,
+// never less than 1e-36) -- an exactly cancelling bin (the Nyquist bin of a frame of two exactly periodic pitch periods,
+// say) comes out of numpy's FFT as 0.0 and the reference stores (0, 0, 0) for it; a residue of 2^-50 normalised to a
+// "phase" of (1, 0) moved the compressed phase features by 6e-5.
 template <bool PH>
-__device__ __forceinline__ void feat_store(double xr, double xi, float* pm, float* pr, float* pi) {
+__device__ __forceinline__ void feat_store(double xr, double xi, double zero2, float* pm, float* pr, float* pi) {
     const double s = xr * xr + xi * xi;
-    // the fp32 estimate needs a normal float: |X|^2 below 1e-38 is zero for the float32 features anyway
-    const bool nz = s > 1.0e-36;
+    // (the fp32 estimate needs a normal float: |X|^2 below 1e-38 is zero for the float32 features anyway)
+    const bool nz = s > zero2;
     const double r = nz ? rsqrt_f64(s) : 0.0;
     *pm = (float)(s * r);
     if (PH) {
@@ -105,6 +109,7 @@ __global__ __launch_bounds__(kAna64Waves * 64) void k_analysis_f64(const float* 
 
         // ---- samples HBM -> LDS (fp32: the PCM is exact in float32), window in float64 while gathering in FFT order
         double re[P], im[P];
+        double s_abs = 0.0;   // this lane's share of sum |windowed sample|: the scale of the transform's rounding noise
 #pragma unroll
         for (int j = 0; j < P; ++j) re[j] = im[j] = 0.0;
         const int ntiles = (g.len + kTile - 1) / kTile;   // 1 except for frames longer than 64 P samples (Q19)
@@ -133,10 +138,16 @@ __global__ __launch_bounds__(kAna64Waves * 64) void k_analysis_f64(const float* 
                         re[j] = (double)xbuf[k0 - tile0] * hann_half_f64(k0, g.L, g.LR, g.kadd, invL, invR);
                     if (k1 >= tile0 && k1 < hi)
                         im[j] = (double)xbuf[k1 - tile0] * hann_half_f64(k1, g.L, g.LR, g.kadd, invL, invR);
+                    s_abs += fabs(re[j]) + fabs(im[j]);
                 }
             }
             wave_sync();
         }
+        float s_all = (float)s_abs;   // a scale: float is plenty
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) s_all += __shfl_xor(s_all, d);
+        const double zt = 2.842170943040401e-14 * (double)s_all;   // 2^-45 * sum: ~20 x the transform's error bound
+        const double zero2 = fmax(zt * zt, 1.0e-36);
 
         wave_fft_f64<P, -1>(re, im, tw, xbuf, lane);
         // scheduling fence: left alone, the last butterfly stage is interleaved with the split below and its inputs AND
@@ -184,12 +195,12 @@ __global__ __launch_bounds__(kAna64Waves * 64) void k_analysis_f64(const float* 
                     const double wr = wl_c * cq - wl_s * sq, wi = wl_c * sq + wl_s * cq;
                     const double tr = wr * orr - wi * oi, ti = wr * oi + wi * orr;
                     const int k = kap + 64 * q;
-                    feat_store<PH>(er + tr, ei + ti, row_m + k, row_r + k, row_i + k);
+                    feat_store<PH>(er + tr, ei + ti, zero2, row_m + k, row_r + k, row_i + k);
                     const int km = M - k;              // kappa == 0, q == 0: bin M
-                    feat_store<PH>(er - tr, ti - ei, row_m + km, row_r + km, row_i + km);
+                    feat_store<PH>(er - tr, ti - ei, zero2, row_m + km, row_r + km, row_i + km);
                 }
             }
-            if (lane0) feat_store<PH>(re[1], -im[1], row_m + M / 2, row_r + M / 2, row_i + M / 2);
+            if (lane0) feat_store<PH>(re[1], -im[1], zero2, row_m + M / 2, row_r + M / 2, row_i + M / 2);
         };
         // rows whose phase features no consumer reads (the compressed analysis: unvoiced stretches) get the magnitude only:
         // a third of the stores and two conversions per bin less, one wave-uniform branch per frame

@@ -223,6 +223,31 @@ def test_f64_analysis_features_are_correctly_rounded(orc):
         assert np.array_equal(plan.v_f0[0], o[3])
 
 
+def test_exactly_cancelling_bins_are_zero_like_the_reference(mp, orc):
+    """Found by tools/fuzz_vs_oracle.py: over a stretch of exactly periodic pitch periods (synthetic utterance 447741 at
+    44.1 kHz, frames 132-138) the Nyquist bin cancels exactly; numpy's FFT returns 0.0 and the reference stores
+    (0, 0, 0) (magphase.py:466-472).  The float64 wave FFT leaves a residue of 2^-50: it must not become a phase of
+    (1, 0) -- that moved the warped phase features by 6e-5."""
+    from magphase_amd import synthetic as syn
+    from magphase_amd.engine import LosslessAnalysisPlan, get_engine
+    fs = 44100
+    pcm, pm, voi = syn.make_utterance(447741, dur_s=0.813, fs=fs)
+    x = syn.pcm_to_float(pcm)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        o = orc.analysis_lossless_from_epochs(x, fs, pm, voi)
+        zero = o[0] == 0.0
+        assert zero.sum() >= 5 and zero[132, 2048]
+        plan = LosslessAnalysisPlan(get_engine(), [(x, fs, pm, voi)])
+        m, r, i = (t.cpu().numpy() for t in plan.run(precise=True))
+        assert np.all(m[zero] == 0.0) and np.all(r[zero] == 0.0) and np.all(i[zero] == 0.0)
+        assert np.count_nonzero(m == 0.0) == zero.sum()              # and nothing else was flushed
+        oc = orc.analysis_compressed_from_epochs(x, fs, pm, voi, mag_dim=60, phase_dim=45)
+        g = mp.analysis_compressed_batch([(x, fs, pm, voi)], mag_dim=60, phase_dim=45)[0]
+    assert np.max(np.abs(g[1] - oc[1])) < WARP_PHASE_TOL and np.max(np.abs(g[2] - oc[2])) < WARP_PHASE_TOL
+    assert np.max(np.abs(g[0] - oc[0])) < WARP_TOL
+
+
 def test_f64_analysis_rows_in_use_skips_only_the_phase_rows():
     """mpx_analysis_frames_f64(rows_in_use): frames flagged 0 get their magnitude row only -- the real / imag rows keep
     what the buffers held; everything else is bit-identical to the unflagged launch."""

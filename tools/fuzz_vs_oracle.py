@@ -1,0 +1,102 @@
+#!/usr/bin/env python
+"""
+Randomised sweep of the device path against the oracle (oracle/magphase_oracle.py, test infrastructure): batches of
+utterances of random length / pitch / voicing at every supported sample rate, variable and constant frame rate,
+analysis_compressed -> synthesis_from_compressed with numpy's noise stream, and the lossless round trip.  Prints the
+worst error per quantity and exits non-zero if a bound of tests/test_gpu_compressed.py is exceeded.
+
+    python tools/fuzz_vs_oracle.py [n_batches] [seed]
+"""
+import os
+import sys
+import warnings
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import magphase_oracle as orc  # noqa: E402
+
+from magphase_amd import magphase as mp, synthetic as syn  # noqa: E402
+
+WARP_TOL, WARP_PHASE_TOL, COMP_PCM_TOL, LOSSLESS_TOL = 1e-4, 2e-5, 2e-5, 2e-6
+
+
+def main():
+    n_batches = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+    rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    worst = {"mag": 0.0, "phase": 0.0, "pcm": 0.0, "lossless_feat": 0.0, "lossless_pcm": 0.0}
+    bad = []
+    for b in range(n_batches):
+        fs = int(rng.choice([8000, 16000, 22050, 44100, 48000]))
+        n_utt = int(rng.randint(1, 5))
+        const = bool(rng.randint(0, 2))
+        utts = []
+        for _ in range(n_utt):
+            pcm, pm, voi = syn.make_utterance(int(rng.randint(0, 10 ** 6)), dur_s=float(rng.uniform(0.25, 1.3)), fs=fs)
+            kind = rng.randint(0, 6)
+            if kind == 0:
+                voi = np.ones_like(voi)               # every epoch voiced
+            elif kind == 1 and voi.sum() > 8:
+                k = np.flatnonzero(voi)[4:]           # a few voiced epochs at the start, the rest unvoiced
+                voi = voi.copy()
+                voi[k] = 0
+            utts.append((syn.pcm_to_float(pcm), fs, pm, voi))
+        tag = "batch %d: fs %d, %d utterances, %s rate" % (b, fs, n_utt, "constant" if const else "variable")
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            if fs == 8000:   # no constants for the compressed path at 8 kHz in the reference: the lossless round trip, N = 1024
+                lo = [orc.analysis_lossless_from_epochs(x, fs, pm, voi, fft_len=1024) for x, _f, pm, voi in utts]
+                lg = mp.analysis_lossless_batch(utts, fft_len=1024)
+                for g, o in zip(lg, lo):
+                    worst["lossless_feat"] = max(worst["lossless_feat"], float(np.max(np.abs(g[0] - o[0])) / np.max(o[0])))
+                    assert np.array_equal(g[3], o[3]), tag
+                sy = mp.synthesis_from_lossless_batch([(o[0], o[1], o[2], o[3], fs) for o in lo])
+                for a, o in zip(sy, lo):
+                    r = orc.synthesis_from_lossless(o[0], o[1], o[2], o[3], fs)
+                    assert len(a) == len(r), tag
+                    worst["lossless_pcm"] = max(worst["lossless_pcm"], float(np.max(np.abs(a - r)) / np.max(np.abs(r))))
+                print(tag + " (lossless only): ok", flush=True)
+                continue
+            try:
+                ref = [orc.analysis_compressed_from_epochs(x, fs, pm, voi, mag_dim=60, phase_dim=45, b_const_rate=const)
+                       for x, _f, pm, voi in utts]
+            except Exception as e:   # the reference's own arithmetic refuses this input (e.g. no voiced frame)
+                print(tag + ": oracle raised %s, skipped" % type(e).__name__)
+                continue
+            got = mp.analysis_compressed_batch(utts, mag_dim=60, phase_dim=45, b_const_rate=const)
+            for g, o in zip(got, ref):
+                assert g[0].shape == o[0].shape and np.array_equal(g[3], o[3]), tag
+                worst["mag"] = max(worst["mag"], float(np.max(np.abs(g[0] - o[0]))))
+                worst["phase"] = max(worst["phase"], float(np.max(np.abs(g[1] - o[1]))), float(np.max(np.abs(g[2] - o[2]))))
+            seed = int(rng.randint(0, 2 ** 31))
+            np.random.seed(seed)
+            v = mp.synthesis_from_compressed_batch([(o[0], o[1], o[2], o[3]) for o in ref], fs, b_const_rate=const)
+            np.random.seed(seed)
+            w = [orc.synthesis_from_compressed(o[0], o[1], o[2], o[3], fs, b_const_rate=const) for o in ref]
+            for a, r in zip(v, w):
+                assert len(a) == len(r), tag
+                e = float(np.max(np.abs(a - r)) / max(np.max(np.abs(r)), 1e-12))
+                worst["pcm"] = max(worst["pcm"], e)
+            lo = [orc.analysis_lossless_from_epochs(x, fs, pm, voi) for x, _f, pm, voi in utts]
+            lg = mp.analysis_lossless_batch(utts)
+            for g, o in zip(lg, lo):
+                peak = np.max(o[0])
+                worst["lossless_feat"] = max(worst["lossless_feat"], float(np.max(np.abs(g[0] - o[0])) / peak))
+                assert np.array_equal(g[3], o[3]), tag
+            sy = mp.synthesis_from_lossless_batch([(o[0], o[1], o[2], o[3], fs) for o in lo])
+            for a, o in zip(sy, lo):
+                r = orc.synthesis_from_lossless(o[0], o[1], o[2], o[3], fs)
+                assert len(a) == len(r), tag
+                worst["lossless_pcm"] = max(worst["lossless_pcm"], float(np.max(np.abs(a - r)) / np.max(np.abs(r))))
+        print(tag + ": ok   " + "  ".join("%s %.2e" % kv for kv in worst.items()), flush=True)
+    lim = {"mag": WARP_TOL, "phase": WARP_PHASE_TOL, "pcm": COMP_PCM_TOL, "lossless_feat": LOSSLESS_TOL,
+           "lossless_pcm": LOSSLESS_TOL}
+    bad = [k for k in worst if worst[k] > lim[k]]
+    print("worst:", worst, "over the bound:", bad)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
