@@ -23,11 +23,37 @@ from magphase_amd import magphase as mp, synthetic as syn  # noqa: E402
 WARP_TOL, WARP_PHASE_TOL, COMP_PCM_TOL, LOSSLESS_TOL = 1e-4, 2e-5, 2e-5, 2e-6
 
 
+def diagnose(utt, const, g, o):
+    """A phase coefficient off by more than the bound: which lossless bins differ between the device's float64 analysis
+    and the oracle's in the frames behind it."""
+    from magphase_amd.engine import LosslessAnalysisPlan, get_engine
+    x, fs, pm, voi = utt
+    lo = orc.analysis_lossless_from_epochs(x, fs, pm, voi)
+    dev = [t.cpu().numpy().astype(np.float64) for t in LosslessAnalysisPlan(get_engine(), [utt]).run(precise=True)]
+    for k in (1, 2):
+        d = np.abs(g[k] - o[k])
+        rows = np.flatnonzero(d.max(axis=1) > WARP_PHASE_TOL)
+        print("   stream %d: %d compressed rows over the bound (max %.2e), first %s" % (k, rows.size, d.max(), rows[:6]))
+    dr = np.abs(dev[1] - lo[1]) + np.abs(dev[2] - lo[2])
+    fr, bn = np.nonzero(dr > 1e-3)
+    print("   lossless (real, imag) differing by > 1e-3: %d bins" % fr.size)
+    for f, b in list(zip(fr, bn))[:8]:
+        print("     frame %d bin %d: oracle mag %.3e (frame sum of mags %.3e) real %.4f imag %.4f | device mag %.3e real %.4f imag %.4f"
+              % (f, b, lo[0][f, b], lo[0][f].sum(), lo[1][f, b], lo[2][f, b], dev[0][f, b], dev[1][f, b], dev[2][f, b]))
+    # Bins that cancel exactly (the Nyquist bin over exactly periodic pitch periods: synthetic signals) come out of
+    # numpy's FFT as 0.0 or as a residue of +-2^-51, by the luck of its summation order; the reference turns the residue
+    # into a "phase" of (+-1, 0).  The device stores (0, 0, 0) for anything below 2^-45 of the frame (DESIGN.md section 2).
+    noise = fr.size > 0 and bool(np.all(lo[0][fr, bn] <= 1e-13 * lo[0][fr].sum(axis=1)))
+    if noise:
+        print("   -> every differing bin is at the reference's own rounding noise (|X| <= 1e-13 of the frame): not counted")
+    return noise
+
+
 def main():
     n_batches = int(sys.argv[1]) if len(sys.argv) > 1 else 12
     rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
     worst = {"mag": 0.0, "phase": 0.0, "pcm": 0.0, "lossless_feat": 0.0, "lossless_pcm": 0.0}
-    bad = []
+    bad, residue = [], 0
     for b in range(n_batches):
         fs = int(rng.choice([8000, 16000, 22050, 44100, 48000]))
         n_utt = int(rng.randint(1, 5))
@@ -66,15 +92,28 @@ def main():
                 print(tag + ": oracle raised %s, skipped" % type(e).__name__)
                 continue
             got = mp.analysis_compressed_batch(utts, mag_dim=60, phase_dim=45, b_const_rate=const)
-            for g, o in zip(got, ref):
+            for u, (g, o) in enumerate(zip(got, ref)):
                 assert g[0].shape == o[0].shape and np.array_equal(g[3], o[3]), tag
                 worst["mag"] = max(worst["mag"], float(np.max(np.abs(g[0] - o[0]))))
-                worst["phase"] = max(worst["phase"], float(np.max(np.abs(g[1] - o[1]))), float(np.max(np.abs(g[2] - o[2]))))
+                e_ph = max(float(np.max(np.abs(g[1] - o[1]))), float(np.max(np.abs(g[2] - o[2]))))
+                if e_ph > WARP_PHASE_TOL and diagnose(utts[u], const, g, o):
+                    residue += 1          # the reference's value there is numpy's rounding residue: not comparable
+                else:
+                    worst["phase"] = max(worst["phase"], e_ph)
             seed = int(rng.randint(0, 2 ** 31))
+            # synthesis options: the phase of the periodic component, the voiced noise window, the output high-pass, the
+            # post-filter ('linear' raises in the reference under numpy 2: oracle only -- it is what the restatement says)
+            ppt = str(rng.choice(["magphase", "magphase", "min_phase", "linear"]))
+            vwin, hpf, pf = bool(rng.randint(0, 2)), bool(rng.randint(0, 2)), bool(rng.randint(0, 2))
+            pf = pf and fs in (16000, 48000)   # the reference's post-filter raises at other rates (magphase.py:2316-2323)
+            tag += ", %s%s%s%s" % (ppt, "" if vwin else ", hann noise window", ", hpf" if hpf else "", ", post-filter" if pf else "")
             np.random.seed(seed)
-            v = mp.synthesis_from_compressed_batch([(o[0], o[1], o[2], o[3]) for o in ref], fs, b_const_rate=const)
+            v = mp.synthesis_from_compressed_batch([(o[0], o[1], o[2], o[3]) for o in ref], fs, b_const_rate=const,
+                                                   per_phase_type=ppt, b_voi_ap_win=vwin, b_out_hpf=hpf, b_post_filter=pf)
             np.random.seed(seed)
-            w = [orc.synthesis_from_compressed(o[0], o[1], o[2], o[3], fs, b_const_rate=const) for o in ref]
+            w = [orc.synthesis_from_compressed(orc.post_filter(o[0], fs) if pf else o[0], o[1], o[2], o[3], fs,
+                                               b_const_rate=const, per_phase_type=ppt, b_voi_ap_win=vwin, b_out_hpf=hpf)
+                 for o in ref]
             for a, r in zip(v, w):
                 assert len(a) == len(r), tag
                 e = float(np.max(np.abs(a - r)) / max(np.max(np.abs(r)), 1e-12))
@@ -94,7 +133,7 @@ def main():
     lim = {"mag": WARP_TOL, "phase": WARP_PHASE_TOL, "pcm": COMP_PCM_TOL, "lossless_feat": LOSSLESS_TOL,
            "lossless_pcm": LOSSLESS_TOL}
     bad = [k for k in worst if worst[k] > lim[k]]
-    print("worst:", worst, "over the bound:", bad)
+    print("worst:", worst, "over the bound:", bad, "| utterances with a bin at numpy's rounding residue:", residue)
     return 1 if bad else 0
 
 
