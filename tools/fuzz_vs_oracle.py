@@ -21,6 +21,8 @@ import magphase_oracle as orc  # noqa: E402
 from magphase_amd import magphase as mp, synthetic as syn  # noqa: E402
 
 WARP_TOL, WARP_PHASE_TOL, COMP_PCM_TOL, LOSSLESS_TOL = 1e-4, 2e-5, 2e-5, 2e-6
+MAX_UTTS = int(os.environ.get("FUZZ_UTTS", "4"))
+DUR = tuple(float(v) for v in os.environ.get("FUZZ_DUR", "0.25,1.3").split(","))   # utterance length range, seconds
 
 
 def diagnose(utt, const, g, o):
@@ -56,11 +58,11 @@ def main():
     bad, residue = [], 0
     for b in range(n_batches):
         fs = int(rng.choice([8000, 16000, 22050, 44100, 48000]))
-        n_utt = int(rng.randint(1, 5))
+        n_utt = int(rng.randint(1, MAX_UTTS + 1))
         const = bool(rng.randint(0, 2))
         utts = []
         for _ in range(n_utt):
-            pcm, pm, voi = syn.make_utterance(int(rng.randint(0, 10 ** 6)), dur_s=float(rng.uniform(0.25, 1.3)), fs=fs)
+            pcm, pm, voi = syn.make_utterance(int(rng.randint(0, 10 ** 6)), dur_s=float(rng.uniform(*DUR)), fs=fs)
             kind = rng.randint(0, 6)
             if kind == 0:
                 voi = np.ones_like(voi)               # every epoch voiced
