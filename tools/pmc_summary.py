@@ -20,8 +20,8 @@ d = sys.argv[1].rstrip("/")
 tag = os.path.basename(d).replace("prof_", "")
 
 # one lowdim step (bench.py measure_lowdim) launches each of these once
-LOWDIM = ("k_analysis_f64", "k_mel_warp_mfma", "k_post_filter", "k_mel_unwarp_tiled", "k_mel_unwarp_mfma", "k_noise_stats",
-          "k_noise_gains", "k_synth_comp_pair")
+LOWDIM = ("k_analysis_f64", "k_mel_warp_mfma", "k_warp_phase_rows", "k_post_filter", "k_mel_unwarp_tiled",
+          "k_mel_unwarp_mfma", "k_noise_stats", "k_noise_gains", "k_synth_comp_pair")
 
 
 def short(k):
