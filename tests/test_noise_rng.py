@@ -107,7 +107,9 @@ def test_numpy_global_generator_continued_on_the_device():
                           # many-workgroup form (segments of 159 744 samples, jump-ahead windows): 2, 3, 20 segments, a
                           # draw ending exactly on a segment / block boundary, one ending a word after it
                           (21, 0, 159744 + 312), (22, 77, 400000), (23, 623, 3111111), (24, 0, 2 * 159744 + 312),
-                          (25, 0, 2 * 159744 + 313), (26, 1, 159744 * 9)):
+                          (25, 0, 2 * 159744 + 313), (26, 1, 159744 * 9),
+                          # 188 segments (the noise of 128 utterances of 5 s), and more than 256: segments of twice the length
+                          (27, 5, 30_000_000), (28, 3, 45_000_000)):
         np.random.seed(seed)
         np.random.uniform(size=warm)
         st = np.random.get_state()
