@@ -142,20 +142,26 @@ def cpu_baseline(utts, fn, what, unit, budget_s=12.0):
 # ------------------------------------------------------------------------------------------------------------------
 # configs[2]: low-dimensional path
 # ------------------------------------------------------------------------------------------------------------------
-def lowdim_plans(em, eng, utts):
-    """(analysis step, synthesis step) closures of configs[2] for engine module `em` (tools/ab_bench.py uses this too)."""
-    state = _lowdim_state(em, eng, utts)
+def lowdim_plans(em, eng, utts, shared=None):
+    """(analysis step, synthesis step) closures of configs[2] for engine module `em` (tools/ab_bench.py uses this too;
+    ``shared``: a dict it passes to every variant so that all of them work in the same large buffers)."""
+    state = _lowdim_state(em, eng, utts, shared)
     return (lambda: state["aplan"].run(feats=state["feats"], out=state["out"]),
             lambda: state["splan"].run(out=state["pcm"]))
 
 
-def _lowdim_state(em, eng, utts):
+def _lowdim_state(em, eng, utts, shared=None):
     import torch
     from scipy import signal
 
     aplan = em.CompressedAnalysisPlan(eng, utts, mag_dim=60, phase_dim=45, b_const_rate=True)
     H = aplan.fft_len // 2 + 1
-    feats = tuple(eng.empty_feats(aplan.lossless.total_frames, H) for _ in range(3))
+    if shared is not None and "feats" in shared:
+        feats = shared["feats"]
+    else:
+        feats = tuple(eng.empty_feats(aplan.lossless.total_frames, H) for _ in range(3))
+        if shared is not None:
+            shared["feats"] = feats
     out = aplan.run(feats=feats)
     torch.cuda.synchronize()
     res = [t.cpu().numpy().astype(np.float64) for t in out]
@@ -172,7 +178,16 @@ def _lowdim_state(em, eng, utts):
         splan = em.CompressedSynthesisPlan(eng, sutts, FS, b_const_rate=True, post_filter=True)
     except TypeError:
         splan = em.CompressedSynthesisPlan(eng, sutts, FS, b_const_rate=True)
-    pcm = eng.empty((splan.total_out,))
+    if shared is not None:   # the unwarped spectra (3 x 0.47 GB) and the output as well
+        if hasattr(splan, "_buffers"):
+            if "splan_buf" in shared:
+                splan._buf = shared["splan_buf"]
+            else:
+                shared["splan_buf"] = splan._buffers()
+        shared.setdefault("pcm", eng.empty((splan.total_out,)))
+        pcm = shared["pcm"]
+    else:
+        pcm = eng.empty((splan.total_out,))
     return dict(aplan=aplan, splan=splan, feats=feats, out=out, pcm=pcm)
 
 
