@@ -71,7 +71,9 @@ def main():
                 voi = voi.copy()
                 voi[k] = 0
             utts.append((syn.pcm_to_float(pcm), fs, pm, voi))
-        tag = "batch %d: fs %d, %d utterances, %s rate" % (b, fs, n_utt, "constant" if const else "variable")
+        mag_dim, phase_dim = int(rng.choice([24, 40, 60, 64])), int(rng.choice([10, 16, 30, 45]))
+        tag = "batch %d: fs %d, %d utterances, %s rate, dims %d/%d" % (b, fs, n_utt, "constant" if const else "variable",
+                                                                     mag_dim, phase_dim)
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
             if fs == 8000:   # no constants for the compressed path at 8 kHz in the reference: the lossless round trip, N = 1024
@@ -88,12 +90,12 @@ def main():
                 print(tag + " (lossless only): ok", flush=True)
                 continue
             try:
-                ref = [orc.analysis_compressed_from_epochs(x, fs, pm, voi, mag_dim=60, phase_dim=45, b_const_rate=const)
+                ref = [orc.analysis_compressed_from_epochs(x, fs, pm, voi, mag_dim=mag_dim, phase_dim=phase_dim, b_const_rate=const)
                        for x, _f, pm, voi in utts]
             except Exception as e:   # the reference's own arithmetic refuses this input (e.g. no voiced frame)
                 print(tag + ": oracle raised %s, skipped" % type(e).__name__)
                 continue
-            got = mp.analysis_compressed_batch(utts, mag_dim=60, phase_dim=45, b_const_rate=const)
+            got = mp.analysis_compressed_batch(utts, mag_dim=mag_dim, phase_dim=phase_dim, b_const_rate=const)
             for u, (g, o) in enumerate(zip(got, ref)):
                 assert g[0].shape == o[0].shape and np.array_equal(g[3], o[3]), tag
                 worst["mag"] = max(worst["mag"], float(np.max(np.abs(g[0] - o[0]))))
@@ -108,13 +110,15 @@ def main():
             ppt = str(rng.choice(["magphase", "magphase", "min_phase", "linear"]))
             vwin, hpf, pf = bool(rng.randint(0, 2)), bool(rng.randint(0, 2)), bool(rng.randint(0, 2))
             pf = pf and fs in (16000, 48000)   # the reference's post-filter raises at other rates (magphase.py:2316-2323)
-            tag += ", %s%s%s%s" % (ppt, "" if vwin else ", hann noise window", ", hpf" if hpf else "", ", post-filter" if pf else "")
+            fb = bool(rng.randint(0, 4) == 0)  # the magnitudes read as mel filter-bank energies (magphase.py:851-852)
+            tag += ", %s%s%s%s%s" % (ppt, "" if vwin else ", hann noise window", ", hpf" if hpf else "",
+                                     ", post-filter" if pf else "", ", fbank" if fb else "")
             np.random.seed(seed)
             v = mp.synthesis_from_compressed_batch([(o[0], o[1], o[2], o[3]) for o in ref], fs, b_const_rate=const,
-                                                   per_phase_type=ppt, b_voi_ap_win=vwin, b_out_hpf=hpf, b_post_filter=pf)
+                                                   per_phase_type=ppt, b_voi_ap_win=vwin, b_out_hpf=hpf, b_post_filter=pf, b_fbank_mel=fb)
             np.random.seed(seed)
             w = [orc.synthesis_from_compressed(orc.post_filter(o[0], fs) if pf else o[0], o[1], o[2], o[3], fs,
-                                               b_const_rate=const, per_phase_type=ppt, b_voi_ap_win=vwin, b_out_hpf=hpf)
+                                               b_const_rate=const, per_phase_type=ppt, b_voi_ap_win=vwin, b_out_hpf=hpf, b_fbank_mel=fb)
                  for o in ref]
             for a, r in zip(v, w):
                 assert len(a) == len(r), tag
