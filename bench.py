@@ -18,7 +18,16 @@ ONE JSON line.  Next to the headline (metric / value / roofline / cpu_baseline) 
               events) with their bound (bytes or fp32-MFMA flops), and its own cpu_baseline;
   "e2e":      what a caller gets -- the numpy-in / numpy-out array API and the file interface (wav + .est files ->
               feature files -> wavs through iobatch), as multiples of real time.
---quick skips configs2 / e2e / the CPU baselines.
+  "corpus_shard": one 1 250-utterance shard of the 8-GPU corpus job (configs[3] extraction + configs[4] mixed-rate
+              generation through the batch API, tools/corpus_workload.py).
+roofline carries, besides the spec-peak fraction: the HBM traffic of the dominant kernel measured IN THIS RUN (two
+rocprofv3 --pmc child passes; --traffic committed|none skips them) and this device's measured streaming read / write /
+copy ceilings (mpx_bw_probe).
+--quick skips configs2 / e2e / corpus_shard / the CPU baselines / the PMC passes.
+
+    python bench.py --workload corpus --utts 10000      BASELINE configs[3] + configs[4] as the whole job: the corpus is
+                                                        LPT-sharded over the ranks (strong scaling), --gpus 1 --utts 1250
+                                                        is one shard
 """
 import argparse
 import hashlib
@@ -97,10 +106,12 @@ def _cpu_warm(_):
 
 def cpu_baseline(utts, fn, what, unit, budget_s=12.0):
     """
-    Same parallel model as the reference (libutils.py:32-63: one utterance per multiprocessing.Pool worker).  The pool
-    is created and warmed (imports, one BLAS thread per worker) BEFORE the clock starts; it has min(cores, 64) workers and
-    every worker gets at least 4 tasks; tasks cycle through the batch's utterances.  Reports the pool rate, the
-    per-worker rate inside the pool and the rate of one process alone (which may use BLAS threads).
+    Same parallel model as the reference (libutils.py:32-63: one utterance per multiprocessing.Pool worker).  A pool
+    is created and warmed (imports, one BLAS thread per worker) BEFORE its clock starts and every worker gets at least 4
+    tasks; tasks cycle through the batch's utterances.  TWO pool sizes are timed: min(cores, 64) workers and
+    Pool(os.cpu_count()) -- what lu.run_multithreaded does -- and `value` is the faster of the two
+    (`pools` lists both).  Also reported: the per-worker rate inside the pool and one process alone (which may use BLAS
+    threads).
     """
     import multiprocessing as mpc
 
@@ -110,32 +121,41 @@ def cpu_baseline(utts, fn, what, unit, budget_s=12.0):
     fn(utts[0])   # untimed: first-call costs (scipy imports, FFT plan caches)
     t0 = time.perf_counter()
     n1, f1 = 0, 0
-    while (time.perf_counter() - t0 < budget_s / 3 and n1 < len(utts)) or n1 == 0:   # one process alone
+    while (time.perf_counter() - t0 < budget_s / 4 and n1 < len(utts)) or n1 == 0:   # one process alone
         f1 += fn(utts[n1])
         n1 += 1
     dt1 = time.perf_counter() - t0
     rate1, t_task = f1 / dt1, dt1 / n1
     what_unit = unit.split("/")[0]
-    workers = max(1, min(ncores, 64))
-    tasks = int(max(4 * workers, min(8 * workers, workers * (budget_s / 2) / t_task)))
-    sample = [utts[i % len(utts)] for i in range(tasks)]
-    out = {"value": round(rate1, 1), "unit": unit, "cores": 1, "kind": "port",
+    out = {"value": round(rate1, 1), "unit": unit, "cores": 1, "kind": "port", "host_cores": ncores,
            "sample": "%s, numpy fp64 oracle, one process: %d utterances (%d %s) in %.1f s" % (what, n1, f1, what_unit, dt1),
-           "value_1core": round(rate1, 1)}
-    try:
-        with mpc.get_context("fork").Pool(workers, initializer=_cpu_init) as pool:
-            pool.map(_cpu_warm, range(4 * workers), chunksize=1)
-            t0 = time.perf_counter()
-            fp = sum(pool.map(fn, sample, chunksize=1))
-            dtp = time.perf_counter() - t0
-        out.update({"value": round(fp / dtp, 1), "cores": workers, "value_per_worker": round(fp / dtp / workers, 1),
-                    "host_cores": ncores,
-                    "sample": "%s, numpy fp64 oracle, Pool(%d of %d cores, created and warmed before timing), %d tasks "
-                              "(%d per worker, cycling through the %d utterances of the batch) = %d %s in %.1f s; one "
-                              "process alone: %.1f %s" % (what, workers, ncores, tasks, tasks // workers, len(utts), fp,
-                                                          what_unit, dtp, rate1, unit)})
-    except Exception as e:   # no fork / no semaphores: the single-process rate stands
-        out["sample"] += " (pool unavailable: %s)" % type(e).__name__
+           "value_1core": round(rate1, 1), "pools": []}
+    sizes = sorted({max(1, min(ncores, 64)), ncores})
+    for workers in sizes:
+        tasks = int(max(4 * workers, min(8 * workers, workers * (budget_s / (2 * len(sizes))) / t_task)))
+        sample = [utts[i % len(utts)] for i in range(tasks)]
+        try:
+            with mpc.get_context("fork").Pool(workers, initializer=_cpu_init) as pool:
+                pool.map(_cpu_warm, range(4 * workers), chunksize=1)
+                t0 = time.perf_counter()
+                fp = sum(pool.map(fn, sample, chunksize=1))
+                dtp = time.perf_counter() - t0
+            out["pools"].append({"workers": workers, "value": round(fp / dtp, 1), "tasks": tasks,
+                                 "value_per_worker": round(fp / dtp / workers, 1), "seconds": round(dtp, 2),
+                                 what_unit: fp})
+        except Exception as e:   # no fork / no semaphores: the single-process rate stands
+            out["pools"].append({"workers": workers, "error": type(e).__name__})
+    ok = [p_ for p_ in out["pools"] if "value" in p_]
+    if ok:
+        best = max(ok, key=lambda p_: p_["value"])
+        out.update({"value": best["value"], "cores": best["workers"], "value_per_worker": best["value_per_worker"],
+                    "sample": "%s, numpy fp64 oracle; pools created and warmed before timing, tasks cycle through the %d "
+                              "utterances of the batch: %s; one process alone: %.1f %s" % (
+                                  what, len(utts), "; ".join("Pool(%d of %d cores) %d tasks = %d %s in %.1f s -> %.1f %s" % (
+                                      p_["workers"], ncores, p_["tasks"], p_[what_unit], what_unit, p_["seconds"],
+                                      p_["value"], unit) for p_ in ok), rate1, unit)})
+    else:
+        out["sample"] += " (pool unavailable)"
     return out
 
 
@@ -204,7 +224,7 @@ class _Marks:
         return [(n1, e0.elapsed_time(e1)) for (_n0, e0), (n1, e1) in zip(self.ev[:-1], self.ev[1:])]
 
 
-def measure_lowdim(eng, utts, steps, warmup):
+def measure_lowdim(eng, utts, steps, warmup, live=None, live_src=None):
     import torch
 
     from magphase_amd import engine as em
@@ -216,15 +236,32 @@ def measure_lowdim(eng, utts, steps, warmup):
         aplan.run(feats=st["feats"], out=st["out"], mark=mark)
         splan.run(out=st["pcm"], mark=mark)
 
-    for _ in range(warmup):
+    # Timing, independent of the headline's --steps / --warmup (round 2's driver run timed 10 steps after 2 warm-ups,
+    # right behind 15 s of GPU idle under the CPU baseline, and got 3.6 x the kernels' own sum): warm up until two
+    # consecutive single steps agree to 3 % (clocks back up, every first-use allocation done), then time a fixed number
+    # of steps with BOTH the host clock around the synchronised loop and a HIP event pair around the same loop.
+    steps, warm_used, last = max(int(steps), 50), 0, None
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    while warm_used < 60:
+        e0.record()
         step()
+        e1.record()
+        torch.cuda.synchronize()
+        warm_used += 1
+        cur = e0.elapsed_time(e1)
+        if warm_used >= max(int(warmup), 3) and last is not None and abs(cur - last) <= 0.03 * min(cur, last):
+            break
+        last = cur
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    e0.record()
     for _ in range(steps):
         step()
+    e1.record()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    acc, reps = {}, max(5, min(steps, 20))
+    dt_events = e0.elapsed_time(e1) * 1e-3
+    acc, reps = {}, 20
     for _ in range(reps):
         m = _Marks(torch)
         step(m)
@@ -273,11 +310,22 @@ def measure_lowdim(eng, utts, steps, warmup):
     # interpolation works on (2 x 12 H per variable-rate frame), which 8(d) allows for this configuration
     alg_fused = (4.0 * n_in + 4.0 * (dims + 2) * Fc) + (4.0 * (dims + 1) * Fc + 4.0 * n_noise + 4.0 * n_out)
     alg_staged = alg_fused + 24.0 * H * Fv
-    traffic, src = _committed_traffic("lowdim_step")
+    if live is not None and "lowdim_step" in live:
+        traffic, src = live["lowdim_step"], live_src
+        for k in kern:
+            if k["name"] in live:
+                k["hbm_traffic"] = round(live[k["name"]], 1)
+    else:
+        traffic, src = _committed_traffic("lowdim_step")
     return {
         "workload": "configs[2]: the same 64 x 5 s @48 kHz; analysis_compressed(mag 60, phase 45, constant 5 ms rate) -> "
                     "post-filter -> synthesis_from_compressed(b_const_rate=True, per_phase_type='magphase')",
-        "ms_per_step": round(ms_step, 4), "steps": steps,
+        "ms_per_step": round(ms_step, 4), "steps": steps, "warmup_steps_used": warm_used,
+        "ms_per_step_hip_events": round(dt_events / steps * 1e3, 4),
+        "kernel_sum_ms": round(sum(k["ms"] for k in kern), 4),
+        "timing": "fixed %d steps after warming up until two consecutive steps agree to 3 %% (%d used); ms_per_step = host "
+                  "clock around the synchronised loop, ms_per_step_hip_events = one event pair around the same loop, "
+                  "kernel_sum_ms = sum of the per-kernel event durations of a separate 20-step loop" % (steps, warm_used),
         "value": round(Fc / (ms_step * 1e-3), 1), "unit": "5ms-frames/s",
         "x_realtime": round(UTTS_PER_GPU * DUR_S / (ms_step * 1e-3), 1),
         "const_rate_frames": Fc, "variable_rate_frames_analysed": Fv, "variable_rate_frames_resynthesised": Fs,
@@ -307,13 +355,13 @@ def measure_e2e(utts):
     audio = len(sub) * DUR_S
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
-        feats = mp.analysis_lossless_batch(sub)                        # warm-up (pinned buffers, tables)
+        feats = mp.analysis_lossless_batch(sub, copy=False)            # warm-up (pinned buffers, tables)
         fin = [(f[0], f[1], f[2], f[3], f[4]) for f in feats]
         mp.synthesis_from_lossless_batch(fin[:2])
         runs = []
         for _ in range(3):                                             # median of three (fresh 0.7 GB of pages per run)
             t0 = time.perf_counter()
-            feats = mp.analysis_lossless_batch(sub)
+            feats = mp.analysis_lossless_batch(sub, copy=False)        # row views of the batch's arrays
             t_a = time.perf_counter() - t0
             fin = [(f[0], f[1], f[2], f[3], f[4]) for f in feats]
             t0 = time.perf_counter()
@@ -338,6 +386,118 @@ def measure_e2e(utts):
     except Exception as e:
         out["file_interface"] = {"error": "%s: %s" % (type(e).__name__, e)}
     return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# measured ceilings and live HBM traffic
+# ------------------------------------------------------------------------------------------------------------------
+def measure_ceilings(eng):
+    """
+    What THIS device sustains for a plain streaming read, fill and copy of 1 GiB (mpx_bw_probe: grid-stride float4
+    kernels), timed with HIP events in this process: the "measured device copy-kernel ceiling" of SURVEY.md 8(d), quoted
+    in the roofline object beside the 8 TB/s spec peak.  Median of 7 launches after 2 warm-ups.
+    """
+    import statistics
+
+    import torch
+
+    from magphase_amd import _lib
+
+    n = 1 << 28
+    a, b = eng.empty((n,)), eng.empty((n,))
+    a.zero_()
+    b.zero_()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    out = {"bytes": 4 * n, "how": "mpx_bw_probe (grid-stride float4 kernels, 2048 x 256 threads) over 1 GiB, HIP events, "
+                                  "median of 7 launches after 2 warm-ups, this process, this device"}
+    with torch.cuda.device(eng.device):
+        for mode, name, nbytes in ((0, "read", 4.0 * n), (1, "write", 4.0 * n), (2, "copy", 8.0 * n)):
+            ts = []
+            for r in range(9):
+                e0.record()
+                _lib.check(eng.lib.mpx_bw_probe(eng.stream_ptr(), mode, a.data_ptr(), b.data_ptr(), n), "mpx_bw_probe")
+                e1.record()
+                torch.cuda.synchronize()
+                if r >= 2:
+                    ts.append(e0.elapsed_time(e1))
+            out[name + "_GBps"] = round(nbytes / (statistics.median(ts) * 1e-3) / 1e9, 1)
+    del a, b
+    torch.cuda.empty_cache()
+    return out
+
+
+# kernels of one configs[2] step (each launched once per step; the unwarp is two launches of different kernels)
+LOWDIM_KERNELS = ("k_analysis_f64", "k_mel_warp_mfma", "k_warp_phase_rows", "k_post_filter", "k_mel_unwarp_tiled",
+                  "k_mel_unwarp_mfma", "k_noise_stats", "k_noise_gains", "k_synth_comp_pair")
+
+
+def _short_kernel_name(k):
+    return k.split("(")[0].split("::")[-1].split("<")[0].replace("void ", "").strip()
+
+
+def live_traffic(timeout_s=170):
+    """
+    HBM bytes per launch measured NOW, on this box: two child runs of this script (``--pmc-child``: 4 lossless steps +
+    3 configs[2] steps, nothing else) under ``rocprofv3 --pmc FETCH_SIZE`` and ``--pmc WRITE_SIZE`` -- separate passes
+    (the two do not fit the TCC's counter slots together), each with --kernel-trace only, as MI355X_MICROARCH.md's
+    rocprofv3 section prescribes.  bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024: both counters are in KiB and gfx950's
+    FETCH_SIZE tallies a coalesced stream's 128-byte requests at 64 bytes (same guide; it self-calibrates here:
+    k_synth_ola_pair must fetch the 1.40 GB k_analysis wrote).  Returns ({kernel: bytes per launch, "lowdim_step": ...},
+    description) or (None, why not).
+    """
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    if os.environ.get("BENCH_PMC_CHILD"):
+        return None, "inside a profiled child"
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.isfile(rocprof):
+        return None, "rocprofv3 not found"
+    tmp = tempfile.mkdtemp(prefix="bench_pmc_", dir="/tmp")
+    env = dict(os.environ, BENCH_PMC_CHILD="1", TMPDIR="/tmp")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    vals, launches = {}, {}
+    t_start = time.perf_counter()
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            left = timeout_s - (time.perf_counter() - t_start)
+            if left < 20:
+                return None, "time budget for the PMC passes used up"
+            d = os.path.join(tmp, ctr)
+            cmd = [rocprof, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "pmc", "--",
+                   sys.executable, os.path.join(ROOT, "bench.py"), "--pmc-child", "--steps", "3", "--warmup", "1"]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=left)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, "rocprofv3 --pmc %s pass failed (rc %d)" % (ctr, r.returncode)
+            for f in files:
+                with open(f) as fh:
+                    for row in csv.DictReader(fh):
+                        if row.get("Counter_Name") != ctr:
+                            continue
+                        k = _short_kernel_name(row["Kernel_Name"])
+                        if k.startswith("k_"):
+                            vals.setdefault(k, {}).setdefault(ctr, []).append(float(row["Counter_Value"]))
+    except Exception as e:   # timeout, no permission for the counters, ...
+        return None, "live PMC passes unavailable: %s" % type(e).__name__
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    out = {}
+    for k, c in vals.items():
+        if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+            f_, w_ = c["FETCH_SIZE"], c["WRITE_SIZE"]
+            out[k] = (2.0 * sum(f_) / len(f_) + sum(w_) / len(w_)) * 1024.0
+            launches[k] = len(f_)
+    if "k_noise_stats" in out:
+        ks = [k for k in LOWDIM_KERNELS if k in out]
+        out["lowdim_step"] = sum(max(1, round(launches[k] / launches["k_noise_stats"])) * out[k] for k in ks)
+    return out, ("measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE child passes of `bench.py --pmc-child` "
+                 "(4 lossless + 3 configs[2] steps) on this box, (2 x FETCH_SIZE + WRITE_SIZE) KiB per launch, %.0f s"
+                 % (time.perf_counter() - t_start))
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -385,6 +545,15 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--quick", action="store_true", help="headline only: no configs2 / e2e / CPU baselines")
     ap.add_argument("--no-e2e", action="store_true", help="skip the array-API / file-interface block (profiling runs)")
+    ap.add_argument("--workload", choices=("configs1", "corpus"), default="configs1",
+                    help="'corpus' = BASELINE configs[3] + configs[4]: a --utts corpus, LPT-sharded over the ranks "
+                         "(tools/corpus_workload.py); the default is the headline configs[1] (+ configs2 / e2e / a corpus shard)")
+    ap.add_argument("--utts", type=int, default=10000, help="corpus size of --workload corpus (whole job, all ranks)")
+    ap.add_argument("--traffic", choices=("live", "committed", "none"), default="live",
+                    help="roofline.traffic: 'live' = rocprofv3 --pmc child passes in this run (falls back to the committed "
+                         "measurement), 'committed' = profiles/traffic.json, 'none'")
+    ap.add_argument("--pmc-child", action="store_true",
+                    help="internal: the short workload the live PMC passes profile (lossless steps + 3 configs[2] steps)")
     args = ap.parse_args()
 
     import torch
@@ -412,6 +581,32 @@ def main():
     from magphase_amd.engine import LosslessAnalysisPlan, LosslessSynthesisPlan, get_engine
 
     eng = get_engine()
+    if args.workload == "corpus":
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import corpus_workload
+
+        def barrier_c():
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
+
+        rep = corpus_workload.run(args.utts, rank=rank, world=world, dist=dist, barrier=barrier_c)
+        if rank == 0:
+            c3, c4 = rep["configs3_extraction"], rep["configs4_generation"]
+            t = c3["seconds_max_over_ranks"] + c4["seconds_max_over_ranks"]
+            print(json.dumps({
+                "metric": "frames/sec corpus feature extraction + waveform generation (BASELINE configs[3] + configs[4])",
+                "value": round((c3["frames"] + c4["frames"]) / t, 1), "unit": "frames/s", "n_gpus": world,
+                "steps": 1, "warmup": 1, "ms_per_step": round(t * 1e3, 2), "higher_is_better": True, "scaling": "strong",
+                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": "configs[3] + configs[4]: %d-utterance corpus, utterance-sharded x%d (LPT), no "
+                                       "collective" % (args.utts, world), "x_realtime": round(
+                                           (c3["audio_s"] + c4["audio_s"]) / t, 1)},
+                "corpus": rep}))
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     utts = make_batch(rank)
     t_plan0 = time.perf_counter()
     aplan = LosslessAnalysisPlan(eng, utts)
@@ -447,6 +642,15 @@ def main():
         step()
     barrier()
     dt = time.perf_counter() - t0
+    if args.pmc_child:      # profiled by live_traffic(): a few configs[2] steps as well, then done (no JSON line)
+        from magphase_amd import engine as em
+
+        st = _lowdim_state(em, eng, utts)
+        for _ in range(3):
+            st["aplan"].run(feats=st["feats"], out=st["out"])
+            st["splan"].run(out=st["pcm"])
+        torch.cuda.synchronize()
+        return
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -482,11 +686,36 @@ def main():
     fix_elems = int(np.sum(np.maximum(splan.runs_host["fix_hi"] - splan.runs_host["fix_lo"], 0)))
     kern[2]["note"] = "run-boundary fix-up: %d floats read twice and written once; not algorithmic traffic" % fix_elems
     dom = int(np.argmax(ms[:2]))
-    traffic, traffic_src = _committed_traffic(names[dom])
+    full = rank == 0 and world == 1 and not args.quick
+    live, live_src = (live_traffic() if (full and args.traffic == "live") else (None, "not requested"))
+    if live is not None and names[dom] in live:
+        traffic, traffic_src = live[names[dom]], live_src
+        for k in kern:
+            if k["name"] in live:
+                k["hbm_traffic"] = round(live[k["name"]], 1)
+    elif args.traffic == "none":
+        traffic, traffic_src = None, "not requested"
+    else:
+        traffic, traffic_src = _committed_traffic(names[dom])
+        if live is None and args.traffic == "live" and full:
+            traffic_src += " (live passes: %s)" % live_src
     roof = {"bound": "hbm", "kernel": names[dom], "achieved": kern[dom]["alg_GBps"], "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(kern[dom]["alg_GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic,
-            "traffic_source": traffic_src, "kernels": kern,
+            "traffic_source": traffic_src,
+            "traffic_over_algorithmic": (round(traffic / alg[dom], 4) if traffic else None),
+            "kernels": kern,
+            "kernel_time_source": "HIP events on the launch stream, mean of %d launches in this process (the rocprofv3 "
+                                  "--kernel-trace --stats summary of this command: profiles/, latest r03_*kernel_stats.csv)" % reps,
             "path_alg_GBps": round(sum(alg) / (sum(ms) * 1e-3) / 1e9, 1)}
+    if full:
+        try:    # what this device sustains for plain streams: the read ceiling bounds k_synth_ola_pair, the write one k_analysis
+            ceil = measure_ceilings(eng)
+            roof["measured_ceilings"] = ceil
+            roof["frac_of_measured_read"] = round(kern[1]["alg_GBps"] / ceil["read_GBps"], 4)
+            kern[0]["frac_of_measured_write"] = round(kern[0]["alg_GBps"] / ceil["write_GBps"], 4)
+            kern[1]["frac_of_measured_read"] = roof["frac_of_measured_read"]
+        except Exception as e:
+            roof["measured_ceilings"] = {"error": "%s: %s" % (type(e).__name__, e)}
 
     if rank == 0:
         ms_step = dt / args.steps * 1e3
@@ -512,13 +741,12 @@ def main():
                        "host_plan_build_s": round(t_plan, 4), "host_plan_build_cold_s": round(t_plan_cold, 3)},
             "roofline": roof,
         }
-        full = world == 1 and not args.quick
         if full and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(utts, _cpu_lossless, "lossless analysis+synthesis of 5 s utterances",
                                                "frames/s")
         if full:
             try:
-                c2 = measure_lowdim(eng, utts, max(10, args.steps // 4), max(2, args.warmup // 2))
+                c2 = measure_lowdim(eng, utts, 50, 3, live=live, live_src=live_src)
                 if not args.no_cpu_baseline:
                     c2["cpu_baseline"] = cpu_baseline(
                         utts, _cpu_lowdim, "configs[2] (analysis_compressed at constant rate -> post_filter -> "
@@ -531,6 +759,13 @@ def main():
                     out["e2e"] = measure_e2e(utts)
                 except Exception as e:
                     out["e2e"] = {"error": "%s: %s" % (type(e).__name__, e)}
+                try:    # one shard of the 8-GPU corpus job (10 000 utterances / 8): `bench.py --workload corpus --utts 1250`
+                    sys.path.insert(0, os.path.join(ROOT, "tools"))
+                    import corpus_workload
+
+                    out["corpus_shard"] = corpus_workload.run(int(os.environ.get("BENCH_CORPUS_UTTS", 1250)))
+                except Exception as e:
+                    out["corpus_shard"] = {"error": "%s: %s" % (type(e).__name__, e)}
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

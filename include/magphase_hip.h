@@ -419,6 +419,14 @@ int mpx_pcm16(void* stream, const void* y, int32_t y_is_f64, const int64_t* out_
  */
 int mpx_pcm16_to_f32(void* stream, const int16_t* pcm, int64_t n, float* out);
 
+/*
+ * Memory-rate probe (csrc/magphase_probe.hip; measurement only, not on the MagPhase path): one grid-stride float4
+ * kernel over n_floats (a multiple of 4) elements -- mode 0 reads `a` (b: one float of scratch), mode 1 fills `a`,
+ * mode 2 copies a -> b.  bench.py times these with HIP events to quote the device's own streaming read / write / copy
+ * ceilings beside the 8 TB/s spec peak in its roofline object.  The reference has no counterpart.
+ */
+int mpx_bw_probe(void* stream, int32_t mode, float* a, float* b, int64_t n_floats);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * Host-side file helpers of the batch scripts (csrc/magphase_host.cpp; no device work, no stream).  Called from the
  * reader / writer threads of iobatch.py: the FFI call drops the interpreter lock, so reading, computing and writing overlap.

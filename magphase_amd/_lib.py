@@ -60,6 +60,7 @@ SYMBOLS = (
     "mpx_pcm16_to_f32",
     "mpx_hpf_block",
     "mpx_output_hpf",
+    "mpx_bw_probe",
 )
 
 _lib = None
@@ -193,6 +194,8 @@ def _load_locked():
     lib.mpx_hpf_block.argtypes = []
     lib.mpx_output_hpf.restype = ctypes.c_int
     lib.mpx_output_hpf.argtypes = [vp, vp, vp, vp, i32, i64, vp, vp, vp, vp, vp, vp, vp]
+    lib.mpx_bw_probe.restype = ctypes.c_int
+    lib.mpx_bw_probe.argtypes = [vp, i32, vp, vp, i64]
     _lib = lib
     return lib
 

@@ -138,6 +138,9 @@ int64_t mpx_host_plan_synthesis(int32_t n_utts, const double* f0, const int64_t*
         for (int64_t i = 0; i < n; ++i) {
             if (b_const_rate) {
                 const double x = loc[(size_t)(s0 + i)];
+                // outside the constant-rate grid scipy's interp1d raises (bounds_error): hand the utterance to the numpy
+                // form, which raises the reference's ValueError, instead of extrapolating silently
+                if (!(x >= centres[0] && x <= centres[(size_t)(n_rows - 1)])) return -(int64_t)(u + 2);
                 int64_t lo = 0, hi = n_rows;   // np.searchsorted(centres, x, 'left')
                 while (lo < hi) {
                     const int64_t mid = (lo + hi) >> 1;

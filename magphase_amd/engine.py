@@ -410,6 +410,25 @@ class Engine:
                                                o_lin.data_ptr(), o_dummy.data_ptr(), ld), "mpx_mel_unwarp")
         return self.to_host_f64((o_exp if exp_out else o_lin)[:, :int(n_bins)])
 
+    def mel_warp_single(self, m_abs, nbins_out, alpha):
+        """la.sp_mel_warp's linear map for one host matrix of MAGNITUDES [F x H] through mpx_mel_warp (the magnitude job:
+        W ln(x^2 + 1e-8) = the warped ln|f| (the one-sided cepstral sum carries the 1/2); the phase jobs run on a 1-row dummy):
+        float64 [F x nbins_out]."""
+        torch = _torch()
+        m_abs = np.atleast_2d(np.asarray(m_abs, dtype=np.float64))
+        F, H = m_abs.shape
+        w = self.constant(("w_mag", int(nbins_out), H, float(alpha)), lambda: hm.warp_matrix(nbins_out, H, alpha))
+        w1 = self.constant(("w_dummy", H), lambda: np.zeros((1, H)))
+        mag = self.feats_to_device(m_abs)
+        voi = torch.zeros(F, dtype=torch.float32, device=self.device)
+        out, d0, d1 = self.empty((F, int(nbins_out))), self.empty((F, 1)), self.empty((F, 1))
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.mpx_mel_warp(self.stream_ptr(), F, H, mag.data_ptr(), mag.data_ptr(), mag.data_ptr(),
+                                             None, None, None, w.data_ptr(), int(nbins_out), w1.data_ptr(), 1,
+                                             voi.data_ptr(), out.data_ptr(), d0.data_ptr(), d1.data_ptr(),
+                                             self.feat_ld(mag, mag, mag)), "mpx_mel_warp")
+        return self.to_host_f64(out)
+
     def min_phase_single(self, m_mag):
         """la.build_min_phase_from_mag_spec for one [F x H] host matrix through mpx_min_phase."""
         torch = _torch()

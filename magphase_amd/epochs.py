@@ -60,14 +60,16 @@ def track_epochs_batch(sigs, fs, engine=None, unvoiced_step_s=0.005, nccf_min=0.
     span = win + l_max
     lens = np.asarray([int(np.shape(s)[0]) for s in sigs], dtype=np.int64)
     off = np.concatenate(([0], np.cumsum(lens))).astype(np.int64)
-    buf = e.host_staging(int(off[-1]))
+    # the tracker's OWN host buffer: iobatch calls this from its reader thread while the compute thread fills and uploads
+    # the engine's shared page-locked staging buffer (Engine.host_staging / upload_staged) -- sharing it corrupted both
+    buf = np.empty(int(off[-1]), dtype=np.float32)
     for u, s in enumerate(sigs):
         s = np.asarray(s)
         if s.dtype.kind in "iu":
             np.multiply(s, np.float32(1.0 / 32768.0), out=buf[off[u]:off[u + 1]])
         else:
             buf[off[u]:off[u + 1]] = s
-    sig = e.upload_staged(int(off[-1]))
+    sig = e.to_device(buf, np.float32)
     nd = np.maximum((lens + 2 * (dec // 2) - 2 * dec) // dec + 1, 0)                 # avg_pool1d(kernel 2 dec, stride dec, pad dec//2)
     T = (np.maximum(nd, span + hop) - span) // hop + 1
     doff = np.concatenate(([0], np.cumsum(nd))).astype(np.int64)
@@ -179,3 +181,53 @@ def track_epochs(v_sig, fs, device=None, unvoiced_step_s=0.005):
     from .engine import get_engine
 
     return track_epochs_batch([v_sig], fs, engine=get_engine(device), unvoiced_step_s=unvoiced_step_s)[0]
+
+
+def accuracy_against_truth(pm_true, voi_true, pm_est, voi_est, max_period_s=0.02):
+    """
+    The usual glottal-closure-instant scores (Naylor et al. 2007) of an estimated (v_pm_sec, v_voi) track against a
+    known one, plus pitch and voicing errors -- what tests/test_epochs.py prints and bounds and tools/epoch_accuracy.py
+    records (the front end is quality-judged, there is no REAPER here to be bit-judged against).
+
+    A larynx cycle is the span around a true voiced epoch t_k bounded by the midpoints to its voiced neighbours (cycles
+    next to a voicing boundary, where a neighbour is further than max_period_s away, are bounded by half that period).
+      identification_rate   cycles with exactly ONE estimated voiced epoch
+      miss_rate / false_alarm_rate   cycles with none / with more than one
+      jitter_us, bias_us    standard deviation / median of (estimate - truth) over the identified cycles, microseconds
+      gross_f0_error_rate   identified consecutive cycle pairs whose estimated period differs from the true one by > 20 %
+      voicing_error_rate    disagreement of the voiced / unvoiced decision on a 5 ms grid
+    """
+    pm_true, voi_true = np.asarray(pm_true, dtype=np.float64), np.asarray(voi_true) > 0
+    pm_est, voi_est = np.asarray(pm_est, dtype=np.float64), np.asarray(voi_est) > 0
+    tv, ev = pm_true[voi_true], np.sort(pm_est[voi_est])
+    out = {"true_voiced_epochs": int(tv.size), "estimated_voiced_epochs": int(ev.size)}
+    if tv.size < 3:
+        return out
+    half = np.minimum(np.diff(tv), max_period_s) / 2.0
+    lo = tv - np.r_[half[0], half]
+    hi = tv + np.r_[half, half[-1]]
+    n_in = np.searchsorted(ev, hi, side="left") - np.searchsorted(ev, lo, side="left")
+    ident = n_in == 1
+    first = np.searchsorted(ev, lo, side="left")
+    err = ev[np.minimum(first[ident], max(ev.size - 1, 0))] - tv[ident] if ev.size else np.zeros(0)
+    out.update(identification_rate=float(ident.mean()), miss_rate=float((n_in == 0).mean()),
+               false_alarm_rate=float((n_in > 1).mean()),
+               jitter_us=float(np.std(err) * 1e6) if err.size else float("nan"),
+               bias_us=float(np.median(err) * 1e6) if err.size else float("nan"))
+    both = ident[1:] & ident[:-1] & (np.diff(tv) < max_period_s)
+    if both.any():
+        e_of = np.full(tv.size, np.nan)
+        e_of[ident] = tv[ident] + err
+        p_true, p_est = np.diff(tv)[both], np.diff(e_of)[both]
+        out["gross_f0_error_rate"] = float((np.abs(p_est / p_true - 1.0) > 0.2).mean())
+        out["f0_fine_error_percent"] = float(np.mean(np.abs(p_est / p_true - 1.0)[np.abs(p_est / p_true - 1.0) <= 0.2]) * 100)
+    dur = max(pm_true[-1], pm_est[-1] if pm_est.size else 0.0)
+    grid = np.arange(0.0025, dur, 0.005)
+
+    def voiced_on(pm, voi):
+        k = np.clip(np.searchsorted(pm, grid), 0, pm.size - 1)
+        return voi[k]
+
+    if pm_est.size:
+        out["voicing_error_rate"] = float((voiced_on(pm_true, voi_true) != voiced_on(pm_est, voi_est)).mean())
+    return out

@@ -277,6 +277,17 @@ def build_mel_curve(alpha, nbins, amp=np.pi):
     return warp_axis(alpha, nbins) * (amp / np.pi)
 
 
+_COS_CACHE = {}
+
+
+def cos_matrix(n_cep, n_spbins, alpha):
+    """libaudio.py:611-619: trans[i, k] = cos(i * warp_alpha(pi k / (n_spbins - 1))), cached per configuration."""
+    key = (int(n_cep), int(n_spbins), float(alpha))
+    if key not in _COS_CACHE:
+        _COS_CACHE[key] = np.cos(np.arange(key[0])[:, None] * warp_axis(key[2], key[1])[None, :])
+    return _COS_CACHE[key]
+
+
 def unwarp_matrix(ncoeffs, nbins_out, alpha):
     """
     la.sp_mel_unwarp(in_type='log') (libaudio.py:667-684) as the matrix it is: out = x @ U,

@@ -172,14 +172,21 @@ def _record_failures(report, out_dir, failed):
         report["crash_list"] = path
 
 
-def _isolate(items, fn_batch):
+def _isolate(items, fn_batch, keep_numpy_rng=False):
     """fn_batch(list) -> list of results.  If the whole batch raises, every item is retried on its own so that one bad
-    utterance costs one utterance: returns (results, failed) with failed = [(index, exception)]."""
+    utterance costs one utterance: returns (results, failed) with failed = [(index, exception)].
+    keep_numpy_rng: the batch draws from numpy's GLOBAL generator (reference noise, magphase.py:883); the failed attempt
+    may already have advanced it, so its state is put back before the retries -- the good utterances then get the noise
+    they would have got without the bad one in the batch (a bad utterance that draws before it fails still shifts the
+    stream for the ones after it, as it would in the reference's own loop)."""
+    state = np.random.get_state() if keep_numpy_rng else None
     try:
         return list(zip(range(len(items)), fn_batch(items))), []
     except (KeyboardInterrupt, SystemExit):
         raise
     except Exception:
+        if state is not None:
+            np.random.set_state(state)
         ok, failed = [], []
         for i, it in enumerate(items):
             try:
@@ -249,11 +256,19 @@ def extract_features_corpus(wav_files, out_dir, batch_utts=16, fft_len=None, mag
     from . import magphase as mp
 
     lu.mkdir(out_dir)
+    # the engine's device, resolved in THIS thread (torch's current device is thread-local: in the reader thread it would
+    # be device 0 on every rank) -- only needed when a wav has no .est and the built-in tracker is the opt-in route
+    tracker_device = None
+    if engine is not None:
+        tracker_device = engine.device
+    elif os.environ.get("MAGPHASE_EPOCHS", "") == "builtin":
+        from .engine import get_engine
+        tracker_device = get_engine().device
 
     def load(files):
         # the bytes of the wavs and the parsed epoch tracks (text) each come from one native call (a few threads, no GIL)
         wavs = la.read_audio_files_pcm_batch(files)      # 16-bit PCM stays int16: the plan converts it in one pass
-        eps = mp._epochs_for_batch(files)
+        eps = mp._epochs_for_batch(files, device=tracker_device)
         utts, failed = [], []
         for f, w, ep in zip(files, wavs, eps):
             bad = w if isinstance(w, Exception) else (ep if isinstance(ep, Exception) else None)
@@ -369,7 +384,7 @@ def generate_waveforms_corpus(in_feats_dir, tokens, out_syn_dir, mag_dim, phase_
                                                           b_post_filter=(pf_type == "magphase"), engine=engine,
                                                           pcm16_norm=0.98, **kw)
 
-            ok, bad = _isolate(group, synth)
+            ok, bad = _isolate(group, synth, keep_numpy_rng=(noise_mode == "reference"))
             out.extend((group[i][0], rate, sig) for i, sig in ok)
             failed = failed + [(group[i][0], "%s: %s" % (type(e).__name__, e)) for i, e in bad]
         order = {u[0]: k for k, u in enumerate(utts)}

@@ -384,3 +384,59 @@ def build_min_phase_from_mag_spec(m_mag):
     """
     from .engine import get_engine
     return get_engine().min_phase_single(np.asarray(m_mag, dtype=np.float64))
+
+
+def gen_non_symmetric_win(left_len, right_len, win_func, b_norm=False):
+    """libaudio.py:70-84: rising half of win_func(1 + 2 left) joined to the falling half of win_func(1 + 2 right)."""
+    left_len, right_len = int(left_len), int(right_len)
+    v_rise = win_func(1 + 2 * left_len)[:left_len + 1]
+    v_fall = win_func(1 + 2 * right_len)[:right_len + 1][::-1]
+    v_win = np.concatenate((v_rise, v_fall[1:]))
+    return v_win / np.sum(v_win) if b_norm else v_win
+
+
+def gen_centr_win(winlen_l, winlen_r, totlen, win_func=None, b_fill_w_bound_val=False):
+    """libaudio.py:90-103: the non-symmetric window placed so that its centre sits at index totlen // 2."""
+    v_short = gen_non_symmetric_win(winlen_l, winlen_r, win_func)
+    first = int(np.floor(totlen / 2.0)) - int(winlen_l)
+    v_win = np.zeros(totlen)
+    if b_fill_w_bound_val:
+        v_win += v_short[0]
+    v_win[first:first + len(v_short)] = v_short
+    return v_win
+
+
+def mcep_to_sp_cosmat(m_mcep, n_spbins, alpha=0.77, out_type="abs"):
+    """
+    libaudio.py:605-631: mel-cepstra -> spectra by the cosine matrix on the all-pass warped axis (the reference fills the
+    [n_cep x n_spbins] matrix in a Python double loop on every call; here it is one outer product, cached per
+    configuration by hostmath).  Host float64 like the reference: out_type 'abs' (exp), 'db', 'log'.
+    """
+    from . import hostmath as hm
+
+    m_mcep = np.asarray(m_mcep, dtype=np.float64)
+    m_sp = np.dot(m_mcep, hm.cos_matrix(m_mcep.shape[1], int(n_spbins), float(alpha)))
+    if out_type == "abs":
+        return np.exp(m_sp)
+    if out_type == "db":
+        return m_sp * (20 / np.log(10))
+    return m_sp
+
+
+def sp_mel_warp(m_sp, nbins_out, alpha=0.77, in_type=3):
+    """
+    libaudio.py:643-661 on the device: SPTK ``mcep -j 0`` followed by the cosine matrix with alpha = 0 is ONE linear
+    map of the log-periodogram (hostmath.warp_matrix; SPTK restated, parity unpinned) -- the GEMM of mpx_mel_warp.
+    m_sp [F x H] with H - 1 in {512, 1024, 2048}; in_type 3: |f(w)|, 2: ln|f(w)|, 1: 20 log10|f(w)|.  Returns float64
+    [F x nbins_out] of the same kind as the input ('abs' / 'log' / 'db').
+    """
+    from .engine import get_engine
+
+    if in_type not in (1, 2, 3):
+        raise ValueError("in_type must be 1, 2 or 3")
+    m_sp = np.atleast_2d(np.asarray(m_sp, dtype=np.float64))
+    x = m_sp if in_type == 3 else np.exp(m_sp if in_type == 2 else m_sp * (np.log(10.0) / 20.0))
+    out = get_engine().mel_warp_single(x, int(nbins_out), float(alpha))      # ln-domain result
+    if in_type == 3:
+        return np.exp(out)
+    return out if in_type == 2 else out * (20 / np.log(10))

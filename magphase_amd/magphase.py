@@ -36,19 +36,23 @@ def set_epoch_provider(fn):
 
 
 def use_builtin_epoch_tracker(device=None):
-    """Installs magphase_amd.epochs.track_epochs as the epoch provider (instead of <wav>.est files / REAPER)."""
+    """Installs magphase_amd.epochs.track_epochs as the epoch provider (instead of <wav>.est files / REAPER).
+    The device is resolved HERE, in the caller's thread: torch's "current device" is thread-local and iobatch calls the
+    provider from its reader thread, where it is device 0 on every rank."""
     from . import epochs
+
+    dev = device if device is not None else get_engine().device
 
     def provider(wav_file):
         v_sig, fs = la.read_audio_file(wav_file)
-        # the engine's device, named explicitly: torch's "current device" is thread-local and iobatch calls this from
-        # its reader thread, where it would be device 0 on every rank
-        return epochs.track_epochs(v_sig, fs, device=device if device is not None else get_engine().device)
+        return epochs.track_epochs(v_sig, fs, device=dev)
 
     set_epoch_provider(provider)
 
 
-def _epochs_for(wav_file):
+def _epochs_for(wav_file, device=None):
+    """device: the engine's device for the built-in tracker (MAGPHASE_EPOCHS=builtin); callers that run this in a worker
+    thread pass it (see use_builtin_epoch_tracker), None = this thread's current device."""
     if _epoch_provider is not None:
         r = _epoch_provider(wav_file)
         if r is not None:
@@ -62,7 +66,7 @@ def _epochs_for(wav_file):
         # parity unpinned for this front end, so it is never substituted silently.
         from . import epochs
         v_sig, fs = la.read_audio_file(wav_file)
-        return epochs.track_epochs(v_sig, fs, device=get_engine().device)
+        return epochs.track_epochs(v_sig, fs, device=device if device is not None else get_engine().device)
     if la.find_reaper() is None:
         raise RuntimeError(
             "no epochs for %s: neither an epoch provider (set_epoch_provider), nor %s, nor a REAPER binary.  Features "
@@ -79,9 +83,10 @@ def _epochs_for(wav_file):
     return m[:, 0], m[:, 1]
 
 
-def _epochs_for_batch(wav_files):
+def _epochs_for_batch(wav_files, device=None):
     """_epochs_for over a list: [(v_pm_sec, v_voi) | Exception].  Without an epoch provider the .est files next to the
-    wavs are parsed in one native call (la.read_est_batch); a wav without one takes _epochs_for's remaining routes."""
+    wavs are parsed in one native call (la.read_est_batch); a wav without one takes _epochs_for's remaining routes
+    (device: see _epochs_for -- iobatch's reader thread passes its engine's device)."""
     if _epoch_provider is None:
         res = la.read_est_batch([os.path.splitext(f)[0] + ".est" for f in wav_files])
     else:
@@ -90,13 +95,101 @@ def _epochs_for_batch(wav_files):
     for f, r in zip(wav_files, res):
         if isinstance(r, FileNotFoundError):
             try:
-                r = _epochs_for(f)
+                r = _epochs_for(f, device=device)
             except (KeyboardInterrupt, SystemExit):
                 raise
             except Exception as e:
                 r = e
         out.append(r)
     return out
+
+
+# ======================================================================================================
+# helper names of the reference's module that Merlin-side callers import (array in, float64 array out)
+# ======================================================================================================
+def windowing(v_sig, v_pm, win_func=np.hanning):
+    """
+    magphase.py:74-119: pitch-synchronous frames sig[pm_{f-1} .. pm_{f+1}] times the non-symmetric window of their two
+    half lengths.  win_func: a window function, a list of them (one per frame, Q11) or None (no window).
+    Returns (l_frames, v_lens, v_pm_plus, v_shift, v_rights) -- float64 frames on the host, like the reference (the
+    batched device form of the same step is the front end of mpx_analysis_frames).
+    """
+    v_sig = np.asarray(v_sig)
+    pm, left, right = hm.frame_bounds(v_pm, np.size(v_sig))
+    v_pm_plus = np.hstack((0, pm, np.size(v_sig) - 1))
+    l_frames = []
+    for f in range(pm.size):
+        v_frm = v_sig[v_pm_plus[f]:v_pm_plus[f + 2] + 1]
+        fn = win_func[f] if isinstance(win_func, list) else win_func
+        if fn is not None:
+            v_frm = v_frm * la.gen_non_symmetric_win(left[f], right[f], fn)
+        l_frames.append(v_frm)
+    v_lens = np.array([len(x) for x in l_frames], dtype=int)
+    return l_frames, v_lens, v_pm_plus, left.astype(int), right.astype(int)
+
+
+def ola(m_frm, v_pm, win_func=None):
+    """
+    magphase.py:34-62 (PSOLA): frame i added at pm[i] - pm[0], head and tail trimmed so that frame centres land on the
+    epochs.  Frames of 1024 / 2048 / 4096 samples without a window go through the device gather (mpx_ola_gather: the
+    reference's ascending summation order, float32); anything else is summed on the host in float64.  With win_func the
+    frames are multiplied by the centred anti-ringing window first -- IN PLACE, like the reference (magphase.py:48).
+    """
+    v_pm = np.asarray(v_pm).astype(int)
+    nfrms, frmlen = np.shape(m_frm)
+    rel, start, out_len = hm.ola_plan(v_pm, frmlen)
+    if win_func is not None:
+        v_shift = np.append(la.pm_to_shift(v_pm), v_pm[-1] - v_pm[-2] if nfrms > 1 else v_pm[-1])
+        for i in range(nfrms):
+            m_frm[i, :] *= la.gen_centr_win(v_shift[i], v_shift[i + 1], frmlen, win_func=win_func)
+    if win_func is None and frmlen in (1024, 2048, 4096) and nfrms > 0 and out_len > 0:
+        e = get_engine()
+        frames = e.to_device(np.ascontiguousarray(m_frm, dtype=np.float32), np.float32)
+        t = e.to_device_packed([("fo", np.array([0, nfrms]), np.int32), ("rel", rel, np.int32),
+                                ("st", np.array([start]), np.int32), ("oo", np.array([0, out_len]), np.int64)])
+        out = e.ola_gather(frmlen, frames, t["fo"], t["rel"], t["st"], t["oo"], out_len, out_len)
+        return e.to_host_f64(out)
+    v_sig = np.zeros(int(v_pm[-1]) + frmlen)
+    for i in range(nfrms):
+        v_sig[rel[i]:rel[i] + frmlen] += m_frm[i, :]
+    return v_sig[start:start + out_len]
+
+
+def get_shifts_and_frm_locs_from_const_shifts(v_shift_c_rate, frm_rate_ms, fs, interp_type='linear'):
+    """magphase.py:1426-1449 (Q16): the serial backward scan from the last constant-rate centre, in the library's host
+    function (scipy interp1d's float64 operation sequence, bit-identical: golden G7)."""
+    from .engine import _const_to_variable_scan, _const_to_variable_scan_scipy
+
+    if interp_type != 'linear':
+        return _const_to_variable_scan_scipy(v_shift_c_rate, frm_rate_ms, fs)
+    return _const_to_variable_scan(v_shift_c_rate, frm_rate_ms, fs)
+
+
+def interp_from_variable_to_const_frm_rate(m_data, v_pm_smpls, const_rate_ms, fs, interp_type='linear'):
+    """magphase.py:2219-2239 (Q15): rows at the epochs -> rows on the constant-rate grid, float64 on the host (scipy's
+    interp1d like the reference; the batched device form is the operand load of mpx_mel_warp)."""
+    from scipy import interpolate
+
+    m_data = np.asarray(m_data, dtype=np.float64)
+    squeeze = m_data.ndim == 1
+    m2 = m_data[:, None] if squeeze else m_data
+    v_pm_smpls = np.asarray(v_pm_smpls)
+    grid = np.arange(fs * const_rate_ms / 1000, v_pm_smpls[-1], fs * const_rate_ms / 1000)
+    if v_pm_smpls[0] > 0:   # the first row is held back to sample 0
+        f = interpolate.interp1d(np.r_[0, v_pm_smpls], np.vstack((m2[0, :], m2)), axis=0, kind=interp_type)
+    else:
+        f = interpolate.interp1d(v_pm_smpls, m2, axis=0, kind=interp_type)
+    out = f(grid)
+    return out[:, 0] if squeeze else out
+
+
+def interp_from_const_to_variable_rate(m_data, v_frm_locs_smpls, frm_rate_ms, fs, interp_type='linear'):
+    """magphase.py:2242-2252: rows on the constant-rate grid -> rows at the frame locations (host float64)."""
+    from scipy import interpolate
+
+    m_data = np.asarray(m_data, dtype=np.float64)
+    centres = (fs * frm_rate_ms / 1000) * np.arange(1, np.size(m_data, 0) + 1)
+    return interpolate.interp1d(centres, m_data, axis=0, kind=interp_type)(v_frm_locs_smpls)
 
 
 # constants (magphase.py:3279-3317)
@@ -115,11 +208,15 @@ def write_featfile(m_data, out_dir, filename):
 # ======================================================================================================
 # lossless analysis
 # ======================================================================================================
-def analysis_lossless_batch(utts, fft_len=None, engine=None, return_device=False):
+def analysis_lossless_batch(utts, fft_len=None, engine=None, return_device=False, copy=True):
     """
     Batched magphase.py:2869-2906 for utterances that already have epochs.
     utts: list of (v_sig, fs, v_pm_sec, v_voi).  Returns a list of
     (m_mag, m_real, m_imag, v_f0, fs, v_shift) in float64 numpy (or device tensors if return_device).
+    copy=True (default): every utterance owns its arrays, like the reference's (independent, freeing one frees its
+    memory).  copy=False: the utterances' matrices are ROW VIEWS of three arrays that hold the whole batch -- no second
+    pass over the data (0.7 GB for 16 utterances), but keeping one utterance alive keeps the batch alive and in-place
+    edits are made in the shared arrays; bench.py and iobatch use it.
     """
     engine = engine or get_engine()
     plan = LosslessAnalysisPlan(engine, utts, fft_len=fft_len)
@@ -137,7 +234,7 @@ def analysis_lossless_batch(utts, fft_len=None, engine=None, return_device=False
         else:
             # the utterance's rows of the batch's arrays (disjoint views: no second pass over the 0.7 GB a 16-utterance
             # batch returns; a one-utterance batch is its own array)
-            feats = h_feats if len(utts) == 1 else tuple(h[a:b] for h in h_feats)
+            feats = h_feats if len(utts) == 1 else tuple((h[a:b].copy() if copy else h[a:b]) for h in h_feats)
         out.append(feats + (plan.v_f0[u], plan.fs[u], plan.v_shift[u].astype(int)))
     return out
 

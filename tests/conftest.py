@@ -17,3 +17,20 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """Measured worst case of every stated tolerance of this session (tests/_tol.py) -> gpurun_out/tolerance_report.json."""
+    try:
+        import json
+
+        from _tol import MEASURED
+    except Exception:
+        return
+    if not MEASURED:
+        return
+    out_dir = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out_dir, exist_ok=True)
+    rows = {k: dict(v, ratio=(round(v["tol"] / v["max"], 2) if v["max"] > 0 else None)) for k, v in sorted(MEASURED.items())}
+    with open(os.path.join(out_dir, "tolerance_report.json"), "w") as fh:
+        json.dump(rows, fh, indent=1)

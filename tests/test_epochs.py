@@ -38,6 +38,56 @@ def test_epochs_of_synthetic_utterances_batched():
         assert np.array_equal(one[0], res[1][0]) and np.array_equal(one[1], res[1][1])
 
 
+def test_accuracy_figures_on_synthetic_truth(capsys):
+    """The figures a reader can see (DESIGN.md section 1 / profiles/r03_epoch_accuracy.json quote them): identification
+    rate, miss / false-alarm rate, timing jitter, gross F0 error and voicing error of the built-in tracker on synthetic
+    utterances whose epochs are known exactly, pooled per sample rate -- printed, and bounded."""
+    from magphase_amd import epochs, synthetic as syn
+    for fs, us in ((48000, range(20, 28)), (16000, range(30, 36))):
+        data = [syn.make_utterance(u, dur_s=3.0, fs=fs) for u in us]
+        res = epochs.track_epochs_batch([d[0] for d in data], fs)
+        rows = [epochs.accuracy_against_truth(pm, voi, e_pm, e_voi) for (_p, pm, voi), (e_pm, e_voi) in zip(data, res)]
+        w = np.array([r["true_voiced_epochs"] for r in rows], dtype=np.float64)
+        pooled = {k: float(np.sum(w * np.array([r[k] for r in rows])) / w.sum())
+                  for k in ("identification_rate", "miss_rate", "false_alarm_rate", "jitter_us", "bias_us",
+                            "gross_f0_error_rate", "voicing_error_rate")}
+        with capsys.disabled():
+            print("\nepoch tracker @ %d Hz, %d utterances, %d true voiced epochs: %s"
+                  % (fs, len(rows), int(w.sum()), ", ".join("%s %.4g" % kv for kv in pooled.items())))
+        assert pooled["identification_rate"] > 0.90 and pooled["miss_rate"] < 0.08 and pooled["false_alarm_rate"] < 0.05
+        assert pooled["jitter_us"] < 250.0 and abs(pooled["bias_us"]) < 150.0
+        assert pooled["gross_f0_error_rate"] < 0.03 and pooled["voicing_error_rate"] < 0.08
+
+
+def test_corpus_pipeline_with_builtin_tracker_matches_sequential(tmp_path, monkeypatch):
+    """the tracker runs in iobatch's READER thread (wavs without .est, MAGPHASE_EPOCHS=builtin) while the
+    compute thread uses the engine's staging buffer.  The threaded corpus run with batches > 1 must write exactly the
+    files a sequential, one-file-at-a-time run writes."""
+    from magphase_amd import iobatch, libaudio as la, magphase as mp, synthetic as syn
+    monkeypatch.setenv("MAGPHASE_EPOCHS", "builtin")
+    wav_dir = tmp_path / "w"
+    os.makedirs(str(wav_dir))
+    wavs = []
+    for u in range(7):
+        pcm, _pm, _voi = syn.make_utterance(800 + u, dur_s=0.7 + 0.15 * (u % 3), fs=48000)
+        f = str(wav_dir / ("t%02d.wav" % u))
+        la.write_audio_file(f, pcm / 32768.0, 48000, norm=None)
+        wavs.append(f)
+    seq, thr = str(tmp_path / "seq"), str(tmp_path / "thr")
+    monkeypatch.setenv("MAGPHASE_IO_PIPELINE", "0")
+    iobatch.extract_features_corpus(wavs, seq, batch_utts=1, phase_dim=45, verbose=False)
+    monkeypatch.setenv("MAGPHASE_IO_PIPELINE", "1")
+    for _rep in range(3):            # a race does not show every time
+        rep = iobatch.CorpusReport()
+        iobatch.extract_features_corpus(wavs, thr, batch_utts=3, phase_dim=45, verbose=False, report=rep)
+        assert rep["done"] == 7 and not rep.get("failed")
+        for f in wavs:
+            tok = os.path.basename(f)[:-4]
+            for ext in (".mag", ".real", ".imag", ".lf0", ".shift"):
+                a, b = open(os.path.join(seq, tok + ext), "rb").read(), open(os.path.join(thr, tok + ext), "rb").read()
+                assert len(a) > 0 and a == b, tok + ext
+
+
 def test_polarity_does_not_matter():
     from magphase_amd import epochs, synthetic as syn
     pcm, _pm, _voi = syn.make_utterance(1, dur_s=2.0)

@@ -13,6 +13,8 @@ import warnings
 import numpy as np
 import pytest
 
+from _tol import within
+
 pytestmark = pytest.mark.gpu
 
 COMP_PCM_TOL = 2e-5
@@ -120,12 +122,12 @@ def test_generation_from_predicted_features_matches_reference_golden(mp, golden_
         v = mp.synthesis_from_compressed(pf, rr, ii, lf, 48000, b_out_hpf=hpf)
         ref = g["syn_pf_hpf%d" % int(hpf)]
         assert len(v) == len(ref)
-        assert np.max(np.abs(v - ref)) <= COMP_PCM_TOL * np.max(np.abs(ref)), np.max(np.abs(v - ref))
+        within((np.max(np.abs(v - ref))) / (np.max(np.abs(ref))), COMP_PCM_TOL, "COMP_PCM_TOL:123")
     np.random.seed(seed)
     v = mp.synthesis_from_compressed(mm, rr, ii, lf, 48000, b_voi_ap_win=False)
     ref = g["syn_nopf_novoiwin"]
     assert len(v) == len(ref)
-    assert np.max(np.abs(v - ref)) <= COMP_PCM_TOL * np.max(np.abs(ref))
+    within((np.max(np.abs(v - ref))) / (np.max(np.abs(ref))), COMP_PCM_TOL, "COMP_PCM_TOL:128")
 
 
 def test_constant_rate_input_matches_reference_golden(mp, golden_dir):
@@ -135,7 +137,7 @@ def test_constant_rate_input_matches_reference_golden(mp, golden_dir):
                                      b_const_rate=True, b_out_hpf=False)
     ref = g["cr45_syn"]
     assert len(v) == len(ref)
-    assert np.max(np.abs(v - ref)) <= COMP_PCM_TOL * np.max(np.abs(ref)), np.max(np.abs(v - ref))
+    within((np.max(np.abs(v - ref))) / (np.max(np.abs(ref))), COMP_PCM_TOL, "COMP_PCM_TOL:138")
 
 
 def test_16k_and_batch_match_oracle(mp, orc):
@@ -155,7 +157,7 @@ def test_16k_and_batch_match_oracle(mp, orc):
         got = mp.synthesis_from_compressed_batch(feats, 16000)
     for v, ref in zip(got, refs):
         assert len(v) == len(ref)
-        assert np.max(np.abs(v - ref)) <= COMP_PCM_TOL * np.max(np.abs(ref)), np.max(np.abs(v - ref))
+        within((np.max(np.abs(v - ref))) / (np.max(np.abs(ref))), COMP_PCM_TOL, "COMP_PCM_TOL:158")
 
 
 def test_min_phase_and_linear_branches(mp, orc, golden_dir):
@@ -166,13 +168,13 @@ def test_min_phase_and_linear_branches(mp, orc, golden_dir):
     v = mp.synthesis_from_compressed(mm, rr, ii, lf, 48000, per_phase_type="min_phase")
     ref = g["syn_nopf_minphase"]
     assert len(v) == len(ref)
-    assert np.max(np.abs(v - ref)) <= COMP_PCM_TOL * np.max(np.abs(ref)), np.max(np.abs(v - ref))   # observed 4e-7
+    within((np.max(np.abs(v - ref))) / (np.max(np.abs(ref))), COMP_PCM_TOL, "COMP_PCM_TOL:169")
     np.random.seed(4)
     v = mp.synthesis_from_compressed(mm, rr, ii, lf, 48000, per_phase_type="linear", b_out_hpf=False)
     np.random.seed(4)
     ref = orc.synthesis_from_compressed(mm, rr, ii, lf, 48000, per_phase_type="linear", b_out_hpf=False)
     assert len(v) == len(ref)
-    assert np.max(np.abs(v - ref)) <= COMP_PCM_TOL * np.max(np.abs(ref))
+    within((np.max(np.abs(v - ref))) / (np.max(np.abs(ref))), COMP_PCM_TOL, "COMP_PCM_TOL:175")
     # constant-rate input: the minimum phase is taken of the row-interpolated magnitude (magphase.py:861-865, 937-938)
     g8 = np.load(os.path.join(golden_dir, "g8_compressed_analysis.npz"))
     np.random.seed(8)
@@ -182,7 +184,7 @@ def test_min_phase_and_linear_branches(mp, orc, golden_dir):
     ref = orc.synthesis_from_compressed(g8["cr45_mag"], g8["cr45_real"], g8["cr45_imag"], g8["cr45_lf0"], 48000,
                                         b_const_rate=True, per_phase_type="min_phase", b_out_hpf=False)
     assert len(v) == len(ref)
-    assert np.max(np.abs(v - ref)) <= COMP_PCM_TOL * np.max(np.abs(ref)), np.max(np.abs(v - ref))   # observed 6e-7
+    within((np.max(np.abs(v - ref))) / (np.max(np.abs(ref))), COMP_PCM_TOL, "COMP_PCM_TOL:185")
 
 
 def test_unsupported_branches_and_errors(mp, golden_dir):
@@ -244,8 +246,9 @@ def test_exactly_cancelling_bins_are_zero_like_the_reference(mp, orc):
         assert np.count_nonzero(m == 0.0) == zero.sum()              # and nothing else was flushed
         oc = orc.analysis_compressed_from_epochs(x, fs, pm, voi, mag_dim=60, phase_dim=45)
         g = mp.analysis_compressed_batch([(x, fs, pm, voi)], mag_dim=60, phase_dim=45)[0]
-    assert np.max(np.abs(g[1] - oc[1])) < WARP_PHASE_TOL and np.max(np.abs(g[2] - oc[2])) < WARP_PHASE_TOL
-    assert np.max(np.abs(g[0] - oc[0])) < WARP_TOL
+    within(np.max(np.abs(g[1] - oc[1])), WARP_PHASE_TOL, "WARP_PHASE_TOL:247r")
+    within(np.max(np.abs(g[2] - oc[2])), WARP_PHASE_TOL, "WARP_PHASE_TOL:247i")
+    within(np.max(np.abs(g[0] - oc[0])), WARP_TOL, "WARP_TOL:248")
 
 
 def test_f64_analysis_rows_in_use_skips_only_the_phase_rows():
@@ -280,9 +283,9 @@ def test_compressed_analysis_matches_golden(mp, golden_dir, tag, kw):
         warnings.simplefilter("ignore")
         r = mp.analysis_compressed_batch([(x, fs, g["pm_sec"], g["voi"])], mag_dim=60, **kw)[0]
     assert r[0].shape == g[tag + "_mag"].shape and r[1].shape == g[tag + "_real"].shape
-    assert np.max(np.abs(r[0] - g[tag + "_mag"])) < WARP_TOL
-    assert np.max(np.abs(r[1] - g[tag + "_real"])) < WARP_PHASE_TOL
-    assert np.max(np.abs(r[2] - g[tag + "_imag"])) < WARP_PHASE_TOL
+    within(np.max(np.abs(r[0] - g[tag + "_mag"])), WARP_TOL, "WARP_TOL:283")
+    within(np.max(np.abs(r[1] - g[tag + "_real"])), WARP_PHASE_TOL, "WARP_PHASE_TOL:284")
+    within(np.max(np.abs(r[2] - g[tag + "_imag"])), WARP_PHASE_TOL, "WARP_PHASE_TOL:285")
     assert np.array_equal(r[3], g[tag + "_lf0"])
     assert np.array_equal(r[4], g[tag + "_shift"])
     assert r[5] == fs and r[6] == 4096
@@ -335,8 +338,9 @@ def test_low_dim_copy_synthesis_roundtrip(mp, orc):
         ref = orc.synthesis_from_compressed(o[0], o[1], o[2], o[3], 48000, b_const_rate=True, b_out_hpf=False)
     assert len(v) == len(ref)
     # features differ by ~3e-5 (fp32 log / GEMM of the warp) -> the waveform by ~2e-6 of peak (observed)
-    assert np.max(np.abs(a[0] - o[0])) < WARP_TOL and np.max(np.abs(a[1] - o[1])) < WARP_PHASE_TOL
-    assert np.max(np.abs(v - ref)) <= COMP_PCM_TOL * np.max(np.abs(ref))
+    within(np.max(np.abs(a[0] - o[0])), WARP_TOL, "WARP_TOL:338")
+    within(np.max(np.abs(a[1] - o[1])), WARP_PHASE_TOL, "WARP_PHASE_TOL:338")
+    within((np.max(np.abs(v - ref))) / (np.max(np.abs(ref))), COMP_PCM_TOL, "COMP_PCM_TOL:339")
 
 
 def test_device_post_filter_and_gains(mp, orc, golden_dir):
@@ -352,7 +356,8 @@ def test_device_post_filter_and_gains(mp, orc, golden_dir):
     np.random.seed(int(g["seed"]))
     v = mp.synthesis_from_compressed_batch([(mm, rr, ii, lf)], 48000, b_post_filter=True)[0]
     ref = g["syn_pf_hpf1"]
-    assert len(v) == len(ref) and np.max(np.abs(v - ref)) <= COMP_PCM_TOL * np.max(np.abs(ref))
+    assert len(v) == len(ref)
+    within(np.max(np.abs(v - ref)) / np.max(np.abs(ref)), COMP_PCM_TOL, "COMP_PCM_TOL:355")
 
 
 def test_device_output_hpf_matches_lfilter(mp):
@@ -389,13 +394,15 @@ def test_other_sample_rates_match_oracle(mp, orc, fs):
         a = mp.analysis_compressed_batch([(x, fs, pm, voi)], mag_dim=60, phase_dim=45)[0]
         o = orc.analysis_compressed_from_epochs(x, fs, pm, voi, mag_dim=60, phase_dim=45)
         for k in range(3):
-            assert a[k].shape == o[k].shape and np.max(np.abs(a[k] - o[k])) < WARP_TOL
+            assert a[k].shape == o[k].shape
+            within(np.max(np.abs(a[k] - o[k])), WARP_TOL if k == 0 else WARP_PHASE_TOL, "WARP_TOL:392/%d" % min(k, 1))
         assert a[6] == o[6] == (4096 if fs == 44100 else 2048)
         np.random.seed(5)
         v = mp.synthesis_from_compressed(o[0], o[1], o[2], o[3], fs)
         np.random.seed(5)
         ref = orc.synthesis_from_compressed(o[0], o[1], o[2], o[3], fs)
-    assert v.shape == ref.shape and np.max(np.abs(v - ref)) <= COMP_PCM_TOL * max(1.0, np.max(np.abs(ref)))
+    assert v.shape == ref.shape
+    within(np.max(np.abs(v - ref)) / max(1.0, np.max(np.abs(ref))), COMP_PCM_TOL, "COMP_PCM_TOL:398")
 
 
 def test_fbank_unwarp_generation_matches_reference(mp, golden_dir):
@@ -407,7 +414,8 @@ def test_fbank_unwarp_generation_matches_reference(mp, golden_dir):
         warnings.simplefilter("ignore")
         v = mp.synthesis_from_compressed(mm, rr, ii, lf, 48000, b_fbank_mel=True)
     ref = g10["syn_fbank"]
-    assert v.shape == ref.shape and np.max(np.abs(v - ref)) <= COMP_PCM_TOL * max(1.0, np.max(np.abs(ref)))
+    assert v.shape == ref.shape
+    within(np.max(np.abs(v - ref)) / max(1.0, np.max(np.abs(ref))), COMP_PCM_TOL, "COMP_PCM_TOL:398")
 
 
 def test_fbank_warp_analysis_matches_reference(mp, golden_dir):
@@ -419,7 +427,7 @@ def test_fbank_warp_analysis_matches_reference(mp, golden_dir):
     r = mp.format_for_modelling(g2["mag32"], g2["real32"], g2["imag32"], g2["v_f0"], 48000, mag_dim=60, phase_dim=45,
                                 b_mag_fbank_mel=True)
     assert r[0].shape == g["ffm_mag_mel_log"].shape
-    assert np.max(np.abs(r[0] - g["ffm_mag_mel_log"])) < WARP_TOL, np.max(np.abs(r[0] - g["ffm_mag_mel_log"]))
+    within(np.max(np.abs(r[0] - g["ffm_mag_mel_log"])), WARP_TOL, "WARP_TOL:422")
     assert np.array_equal(r[3], g["ffm_lf0"])
     plain = mp.format_for_modelling(g2["mag32"], g2["real32"], g2["imag32"], g2["v_f0"], 48000, mag_dim=60, phase_dim=45)
     assert np.array_equal(r[1], plain[1]) and np.array_equal(r[2], plain[2])      # the phase streams do not change
@@ -431,7 +439,7 @@ def test_fbank_warp_analysis_matches_reference(mp, golden_dir):
         got = e.to_host_f64(out[0])
         floor = y == -1.0e10
         assert np.array_equal(got == -1.0e10, floor)
-        assert np.max(np.abs(got[~floor] - y[~floor])) < WARP_TOL, np.max(np.abs(got[~floor] - y[~floor]))
+        within(np.max(np.abs(got[~floor] - y[~floor])), WARP_TOL, "WARP_TOL:434")
 
 
 def test_full_size_config3_constant_rate_post_filter(mp, orc):
@@ -447,6 +455,7 @@ def test_full_size_config3_constant_rate_post_filter(mp, orc):
     import torch
     from scipy import signal
     from magphase_amd import synthetic as syn
+    from magphase_amd import hostmath as hm
     from magphase_amd.engine import CompressedAnalysisPlan, CompressedSynthesisPlan, get_engine
     eng = get_engine()
     fs = 48000
@@ -458,6 +467,7 @@ def test_full_size_config3_constant_rate_post_filter(mp, orc):
         warnings.simplefilter("ignore")
         aplan = CompressedAnalysisPlan(eng, utts, mag_dim=60, phase_dim=45, b_const_rate=True)
         feats = [t.cpu().numpy().astype(np.float64) for t in aplan.run()]
+        lossless_dev = aplan.lossless.run(precise=True)      # every row (the plan's own run skips unread phase rows)
     assert aplan.total_out_frames > 60000 and all(np.all(np.isfinite(f)) for f in feats)
     assert np.max(np.abs(feats[1])) <= 1.0 and np.max(np.abs(feats[2])) <= 1.0
     sutts, lf0s = [], []
@@ -496,14 +506,36 @@ def test_full_size_config3_constant_rate_post_filter(mp, orc):
             o = orc.analysis_compressed_from_epochs(x, fs, pm, voi, mag_dim=60, phase_dim=45, b_const_rate=True)
             a, b = int(aplan.out_off[u]), int(aplan.out_off[u + 1])
             assert o[0].shape == (b - a, 60)
-            assert np.max(np.abs(feats[0][a:b] - o[0])) < WARP_TOL
-            # phase streams: Re X/|X| is ill-conditioned where |X| is at the float64 round-off floor (~1e-13 of the frame
-            # peak) -- the synthetic generator has stretches of exactly constant pitch, whose frames have spectral nulls
-            # between the harmonics; there the reference's own value depends on its FFT's rounding.  Utterance 63 has
-            # eight such frames in a row (3e-5 on their outputs); everything else is below 1e-6.
+            within(np.max(np.abs(feats[0][a:b] - o[0])), WARP_TOL, "WARP_TOL:499")
+            # Phase streams, stage by stage -- no allowance.  Re X/|X| has no well-defined reference value where |X| sits
+            # on the reference FFT's own rounding floor (the synthetic generator has stretches of exactly constant pitch:
+            # frames of two identical periods under a symmetric Hann window have exact spectral nulls between the
+            # harmonics; numpy returns ~1e-13 of the frame peak there and the reference normalises that noise to a unit
+            # phasor).  So: (1) the device's LOSSLESS features are the correctly rounded reference values on every bin
+            # the reference itself determines (|X| > 1e-9 of the frame peak); (2) the compression of those features --
+            # constant-rate interpolation + mel warp + mask + clip -- agrees with the oracle's compression of the SAME
+            # features on every value; (3) end to end against the oracle, every constant-rate frame that does not
+            # interpolate from a frame with such a bin agrees to the phase tolerance.
+            a0, b0 = int(aplan.lossless.frame_off[u]), int(aplan.lossless.frame_off[u + 1])
+            ol = orc.analysis_lossless_from_epochs(x, fs, pm, voi)
+            dl = [t[a0:b0].cpu().numpy().astype(np.float64) for t in lossless_dev]
+            peak = ol[0].max(axis=1, keepdims=True)
+            ok = ol[0] > 1e-9 * peak
+            within(np.max((np.abs(dl[0] - ol[0]) / np.maximum(ol[0], 1e-300))[ok]), 6.5e-8, "F64_MAG_REL:cfg2")
+            within(np.max(np.abs(dl[1] - ol[1])[ok]), 3.5e-8, "F64_PHASE_ABS:cfg2r")
+            within(np.max(np.abs(dl[2] - ol[2])[ok]), 3.5e-8, "F64_PHASE_ABS:cfg2i")
+            oc = orc.to_const_rate(dl[0], dl[1], dl[2], ol[3], ol[5], fs)
+            of = orc.format_for_modelling(oc[0], oc[1], oc[2], oc[3], fs, mag_dim=60, phase_dim=45)
+            within(np.max(np.abs(feats[0][a:b] - of[0])), WARP_TOL, "WARP_TOL:cfg2_same_inputs")
             for k in (1, 2):
-                d = np.abs(feats[k][a:b] - o[k])
-                assert np.max(d) < WARP_TOL and np.mean(d < WARP_PHASE_TOL) > 0.99, (u, k, np.max(d))
+                within(np.max(np.abs(feats[k][a:b] - of[k])), WARP_PHASE_TOL, "WARP_PHASE_TOL:cfg2_same_inputs")
+            lo, hi, _t = hm.var_to_const_rate_table(np.cumsum(ol[5]), 5.0, fs)
+            bad_var = ~ok.all(axis=1)
+            bad_c = bad_var[lo] | bad_var[hi]
+            assert np.mean(bad_c) < 0.05, (u, np.mean(bad_c))
+            for k in (1, 2):
+                d = np.abs(feats[k][a:b] - o[k]).max(axis=1)
+                within(np.max(d[~bad_c]), WARP_PHASE_TOL, "WARP_PHASE_TOL:cfg2_end_to_end")
             assert np.array_equal(lf0s[u], o[3])
             # the oracle on OUR features (so that the waveform check isolates the synthesis side), same noise draw
             np.random.set_state(states[u])
@@ -511,4 +543,4 @@ def test_full_size_config3_constant_rate_post_filter(mp, orc):
                                                 b_const_rate=True, b_out_hpf=False)
         y = pcm1[splan.out_off_host[u]:splan.out_off_host[u + 1]]
         assert len(y) == len(ref)
-        assert np.max(np.abs(y - ref)) <= COMP_PCM_TOL * np.max(np.abs(ref)), (u, np.max(np.abs(y - ref)))
+        within((np.max(np.abs(y - ref))) / (np.max(np.abs(ref))), COMP_PCM_TOL, "COMP_PCM_TOL:514")

@@ -1,0 +1,26 @@
+"""
+-m gpu: a fixed-seed 20-batch slice of tools/fuzz_vs_oracle.py -- random sample rates (8 / 16 / 22.05 / 44.1 / 48 kHz),
+1-4 utterances of random length / pitch / voicing per batch, variable and constant frame rate, random coefficient counts
+(24-64 magnitude, 10-45 phase), all three per_phase_type branches, both noise windows, output high-pass, post-filter,
+filter-bank magnitudes, numpy's noise stream -- the device path against the oracle (the sweep was
+builder-run only).  Bounds: tools/fuzz_vs_oracle.LIMITS.
+"""
+import os
+import sys
+
+import pytest
+
+from _tol import within
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_fixed_seed_fuzz_slice_against_oracle():
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import fuzz_vs_oracle as fz
+
+    worst, bad, residue = fz.run(n_batches=20, seed=20260929, verbose=False)
+    for k, v in worst.items():
+        within(v, fz.LIMITS[k], "FUZZ:" + k)
+    assert not bad and residue <= 2, (worst, bad, residue)

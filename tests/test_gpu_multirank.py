@@ -132,3 +132,27 @@ def test_mixed_sample_rates_and_failure_isolation(tmp_path):
             continue
         with wave.open(os.path.join(out, t + ".wav"), "rb") as w:
             assert w.getframerate() == fs and w.getnframes() > 0.4 * fs
+
+
+def test_corpus_workload_two_ranks_on_one_device():
+    """bench.py --workload corpus (BASELINE configs[3] + configs[4]): the 2-rank job processes exactly the corpus of the
+    1-rank job (same frames, same audio), LPT-sharded, every utterance once; ONE JSON line from rank 0."""
+    n = 96
+    one = subprocess.run([sys.executable, "bench.py", "--gpus", "1", "--workload", "corpus", "--utts", str(n)], cwd=ROOT,
+                         capture_output=True, text=True, timeout=900)
+    assert one.returncode == 0, one.stderr[-3000:]
+    j1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    out = _torchrun(2, ["bench.py", "--gpus", "2", "--workload", "corpus", "--utts", str(n)],
+                    {"BENCH_DIST_BACKEND": "gloo", "BENCH_SHARE_DEVICE": "1"})
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j2 = json.loads(lines[0])
+    assert j1["n_gpus"] == 1 and j2["n_gpus"] == 2 and j2["scaling"] == "strong"
+    for key in ("configs3_extraction", "configs4_generation"):
+        a, b = j1["corpus"][key], j2["corpus"][key]
+        assert sum(b["per_rank_utts"]) == n and a["per_rank_utts"] == [n]
+        assert min(b["per_rank_utts"]) >= n // 2 - 8                       # LPT: both ranks busy
+        assert abs(b["audio_s"] - a["audio_s"]) < 0.2 and b["lpt_cost_imbalance_max_over_mean"] < 1.02
+        # base utterances are seeded per rank, so the frame counts of the two jobs agree to a few percent, not exactly
+        assert abs(b["frames"] - a["frames"]) < 0.05 * a["frames"] and b["frames_per_s"] > 0
+    assert j2["value"] > 0 and j2["config"]["x_realtime"] > 50

@@ -80,3 +80,23 @@ def test_two_rank_gloo_run_matches_single_process(tmp_path):
         checksum += float(np.sum(np.abs(y)))
     assert sum(r["frames"] for r in res) == frames
     assert abs(sum(r["checksum"] for r in res) - checksum) < 1e-9 * checksum
+
+
+def test_corpus_spec_shards_cover_the_10k_corpus_evenly():
+    """bench.py --workload corpus (tools/corpus_workload.py): every rank derives the same corpus and the same LPT shards;
+    at 10 000 utterances / 8 ranks the assigned cost differs by less than 0.1 % between ranks, mixed rates included."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import corpus_workload as cw
+
+    for mixed in (False, True):
+        dur, fs = cw.corpus_spec(10000, mixed)
+        dur2, fs2 = cw.corpus_spec(10000, mixed)
+        assert np.array_equal(dur, dur2) and np.array_equal(fs, fs2)
+        assert 4.9 < dur.mean() < 5.1 and dur.min() >= 2.0 and dur.max() <= 8.0
+        assert set(fs.tolist()) == ({48000, 16000} if mixed else {48000})
+        cost = cw.utterance_cost(dur, fs)
+        shards = sharding.shard_by_cost(cost, 8)
+        assert sorted(np.concatenate(shards).tolist()) == list(range(10000))
+        loads = np.array([cost[s].sum() for s in shards])
+        assert loads.max() / loads.mean() < 1.001

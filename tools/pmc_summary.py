@@ -64,6 +64,6 @@ print(json.dumps({k: (round(v["hbm_bytes_per_launch"] / 1e6, 1) if isinstance(v,
 if "--install" in sys.argv:
     shutil.copy(os.path.join(d, "traffic.json"), os.path.join(ROOT, "profiles", "traffic.json"))
     shutil.copy(os.path.join(d, "pmc_summary.json"), os.path.join(ROOT, "profiles", "%s_pmc_summary.json" % tag))
-    for n in ("kernel_stats.csv", "bench.json"):
+    for n in ("kernel_stats.csv", "bench.json", "bench_profiled.json"):
         if os.path.exists(os.path.join(d, n)):
             shutil.copy(os.path.join(d, n), os.path.join(ROOT, "profiles", "%s_%s" % (tag, n)))
