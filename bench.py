@@ -132,7 +132,10 @@ def cpu_baseline(utts, fn, what, unit, budget_s=12.0):
            "value_1core": round(rate1, 1), "pools": []}
     sizes = sorted({max(1, min(ncores, 64)), ncores})
     for workers in sizes:
-        tasks = int(max(4 * workers, min(8 * workers, workers * (budget_s / (2 * len(sizes))) / t_task)))
+        if workers == sizes[0]:
+            tasks = int(max(4 * workers, min(8 * workers, workers * (budget_s / 2) / t_task)))
+        else:   # Pool(os.cpu_count()): one task per worker (oversubscribed numpy workers run ~4 x slower each)
+            tasks = workers
         sample = [utts[i % len(utts)] for i in range(tasks)]
         try:
             with mpc.get_context("fork").Pool(workers, initializer=_cpu_init) as pool:

@@ -420,6 +420,21 @@ int mpx_pcm16(void* stream, const void* y, int32_t y_is_f64, const int64_t* out_
 int mpx_pcm16_to_f32(void* stream, const int16_t* pcm, int64_t n, float* out);
 
 /*
+ * Merlin / HTS style post-filter of the log mel magnitudes (magphase.py:3375-3465: the reference pipes each utterance
+ * through nine SPTK-3.9 binaries -- x2x | freqt | c2acr, vopr, mc2b | bcp | merge | b2mc -- SPTK restated from its published
+ * algorithms, PARITY UNPINNED) for all frames of a batch (csrc/magphase_merlin.hip):
+ *   mcep = x . c1 (la.rceps 'log' / 'compact' as a matrix);  mcep_w = mcep * lifter (1, 1, pf, pf, ...);
+ *   r0, p_r0 = sum_k wk[k] exp(2 (mcep | mcep_w) . g)[k]   (frame energy: freqt to the linear axis + c2acr -M 0 -l 4096);
+ *   b = mc2b(mcep_w, alpha); b[0] += ln(r0 / p_r0) / 2; mcep_pf = b2mc(b, alpha);  out = mcep_pf . cf, NaN -> magic.
+ * mag_mel_log, out: float32 [n_frames x dim] (3 <= dim <= 64); c1, cf: [dim x dim]; lifter: [dim]; g: [dim x n_bins];
+ * wk: [n_bins] (hostmath.merlin_tables builds them in float64); mcep, mcep_w: scratch [n_frames x dim]; r0, p_r0: scratch
+ * [n_frames].  Deterministic (no atomics).
+ */
+int mpx_post_filter_merlin(void* stream, const float* mag_mel_log, int64_t n_frames, int32_t dim, const float* c1,
+                           const float* lifter, const float* g, const float* wk, int32_t n_bins, double alpha,
+                           const float* cf, double magic, float* mcep, float* mcep_w, float* r0, float* p_r0, float* out);
+
+/*
  * Memory-rate probe (csrc/magphase_probe.hip; measurement only, not on the MagPhase path): one grid-stride float4
  * kernel over n_floats (a multiple of 4) elements -- mode 0 reads `a` (b: one float of scratch), mode 1 fills `a`,
  * mode 2 copies a -> b.  bench.py times these with HIP events to quote the device's own streaming read / write / copy

@@ -61,6 +61,7 @@ SYMBOLS = (
     "mpx_hpf_block",
     "mpx_output_hpf",
     "mpx_bw_probe",
+    "mpx_post_filter_merlin",
 )
 
 _lib = None
@@ -194,6 +195,9 @@ def _load_locked():
     lib.mpx_hpf_block.argtypes = []
     lib.mpx_output_hpf.restype = ctypes.c_int
     lib.mpx_output_hpf.argtypes = [vp, vp, vp, vp, i32, i64, vp, vp, vp, vp, vp, vp, vp]
+    lib.mpx_post_filter_merlin.restype = ctypes.c_int
+    lib.mpx_post_filter_merlin.argtypes = [vp, vp, i64, i32, vp, vp, vp, vp, i32, ctypes.c_double, vp, ctypes.c_double,
+                                           vp, vp, vp, vp, vp]
     lib.mpx_bw_probe.restype = ctypes.c_int
     lib.mpx_bw_probe.argtypes = [vp, i32, vp, vp, i64]
     _lib = lib

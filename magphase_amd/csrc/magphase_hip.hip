@@ -286,36 +286,40 @@ __global__ __launch_bounds__(kThreads) void k_synth_lossless(const float* __rest
 // territory strips of the first fused form, T + N floats per T output samples each way, are gone).
 // ---------------------------------------------------------------------------------------------
 #ifndef MPX_SYN_PAIR_WAVES
-#define MPX_SYN_PAIR_WAVES 8
+#define MPX_SYN_PAIR_WAVES 12
 #endif
 #ifndef MPX_SYN_GROUP
 #define MPX_SYN_GROUP 2
 #endif
+// Waves per workgroup: 12 = 3 per SIMD (<= 168 VGPRs).  A wave issues at most one VALU instruction per ~4-5 cycles while a
+// SIMD can start one every 2: with 2 waves per SIMD (round 2: 243 VGPRs, 8 waves) the kernel ran its VALU 33 % and its
+// memory pipe 47 % busy -- bound by neither, by latency.  The third wave needs (a) the LDS: six rings + twelve transpose
+// buffers + the twiddle table are 223 KB in the round-2 form; P == 32 therefore uses the COMPACT transform front of
+// wave_fft.hpp (half-height transpose buffer, half twiddle table: 162.9 KB), and (b) <= 168 VGPRs: the prefetch of the
+// next frame's 99 feature values is issued in THREE parts as registers come free (after the transform; between the two
+// planes of the overlap-add; after the ordered section) and the overlap-add reads the ring 16 values at a time.
 constexpr int kPairWaves = MPX_SYN_PAIR_WAVES;   // waves per workgroup
 constexpr int kGroup = MPX_SYN_GROUP;            // waves sharing one ring (2: the "pair"; 4 at the same occupancy measured
                                                  // +11 %, 6 with 12 waves per CU +15 %: the in-order ring hand-over couples the
-                                                 // waves of a group, so more waves only pay with their own rings -- no LDS left)
+                                                 // waves of a group, so more waves only pay with their own rings)
 constexpr int kPairs = kPairWaves / kGroup;      // rings (= work-list slots) per workgroup
 static_assert(kPairWaves % kGroup == 0, "waves per workgroup must be a multiple of the group size");
-#ifdef MPX_PROBE_TIMING
-// Timing probe build (tools/probe_timing.py): per-phase s_memtime deltas of every wave, summed into g_probe.  The time
-// reads wait for lgkmcnt(0), which also drains the wave's LDS queue: the phases are serialised a little more than in
-// the production build (the guide quotes ~+11 % wave cycles for this kind of instrumentation).
-__device__ unsigned long long g_probe[16];
-#define MPX_T(idx, ...)                                                                                       \
-    do {                                                                                                      \
-        unsigned long long t__;                                                                               \
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__) : __VA_ARGS__ : "memory");            \
-        pr_acc[idx] += t__ - pr_last;                                                                         \
-        pr_last = t__;                                                                                        \
-    } while (0)
-#else
-#define MPX_T(idx, ...) do { } while (0)
+
+#ifdef MPX_PROBE_ENDTIME
+// Probe build (tools/endtime_probe.py): every wave of k_synth_ola_pair stores the constant-rate clock (100 MHz) when it
+// enters and when it leaves its frame loop, and its frame count -- the spread of the end times is the launch tail.
+__device__ unsigned long long g_endprobe[3 * 8192];
 #endif
 
 template <int P>
+constexpr bool pair_compact() { return P == 32 && kPairWaves > 8; }
+template <int P>
+constexpr int pair_tw_floats() { return pair_compact<P>() ? tw_half_floats<P>() : tw_floats<P>(); }
+template <int P>
+constexpr int pair_xbuf_floats() { return (pair_compact<P>() ? P / 2 : P) * kXStride; }
+template <int P>
 constexpr size_t lds_bytes_pair() {
-    return sizeof(float) * (size_t)(tw_floats<P>() + kPairWaves * (P * kXStride) + kPairs * ring_len<P>() + 16);
+    return sizeof(float) * (size_t)(pair_tw_floats<P>() + kPairWaves * pair_xbuf_floats<P>() + kPairs * ring_len<P>() + 16);
 }
 
 template <int P>
@@ -330,27 +334,50 @@ __global__ __launch_bounds__(kPairWaves * 64) void k_synth_ola_pair(const float*
                                                                     float* __restrict__ strips,
                                                                     float* __restrict__ pcm, long long ld) {
     constexpr int M = 64 * P, N = 2 * M, R = ring_len<P>();
+    constexpr bool kCompact = pair_compact<P>();
+    // feature prefetch in parts (bin pairs j: six values each): j < JA and bin M/2 right after the transform, JA <= j < JB
+    // between the two planes of the overlap-add (the first plane's 32 registers are free then), the rest after the
+    // ordered section.  The short transforms have the registers for one part.  (JA, JB, CH) = (6, 11, 8) is the largest
+    // first part that compiles without a spill at 168 VGPRs (8 / 13 / 16: 20 spilled registers; tools/kres.py).
+#ifndef MPX_JA
+#define MPX_JA 6
+#endif
+#ifndef MPX_JB
+#define MPX_JB 11
+#endif
+#ifndef MPX_CH
+#define MPX_CH 8
+#endif
+    constexpr int JA = kCompact ? MPX_JA : P / 2, JB = kCompact ? MPX_JB : P / 2;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* tw = smem;
     const int lane_id = threadIdx.x & 63;
     const int wave = rfl(threadIdx.x >> 6);
     const int pair = wave / kGroup, half = wave % kGroup;   // ring, member index
-    float* xbuf = smem + tw_floats<P>() + wave * (P * kXStride);
-    constexpr int kRing0 = tw_floats<P>() + kPairWaves * (P * kXStride);   // first ring (floats from the LDS base)
+    float* xbuf = smem + pair_tw_floats<P>() + wave * pair_xbuf_floats<P>();
+    constexpr int kRing0 = pair_tw_floats<P>() + kPairWaves * pair_xbuf_floats<P>();   // first ring (floats from the LDS base)
     float* ring = smem + kRing0 + pair * R;
     const unsigned ring_byte = 4u * (unsigned)(kRing0 + pair * R);
     int* turn = reinterpret_cast<int*>(smem + kRing0 + kPairs * R) + pair;
-    for (int i = threadIdx.x; i < tw_floats<P>(); i += kPairWaves * 64) tw[i] = tw_g[i];
+    if constexpr (kCompact) {   // even registers' twiddles only: row l = (P/2 complex + 4 pad floats) out of the full table's row
+        for (int i = threadIdx.x; i < tw_half_floats<P>(); i += kPairWaves * 64) {
+            const int l = i / tw_half_stride<P>(), c = i % tw_half_stride<P>();
+            tw[i] = (c < P) ? tw_g[l * tw_stride<P>() + 4 * (c >> 1) + (c & 1)] : 0.0f;
+        }
+    } else {
+        for (int i = threadIdx.x; i < tw_floats<P>(); i += kPairWaves * 64) tw[i] = tw_g[i];
+    }
     for (int i = threadIdx.x; i < kPairs * R; i += kPairWaves * 64) smem[kRing0 + i] = 0.0f;
     if (threadIdx.x < kPairs) turn[threadIdx.x - pair] = 0;   // thread t < kPairs has pair == 0
     __syncthreads();
 
-    float wl_s0, wl_c0;
+    float wl_s0, wl_c0, lc0 = 1.0f, ls0 = 0.0f;
     sincospif(2.0f * (float)lane_id / (float)N, &wl_s0, &wl_c0);
+    if constexpr (kCompact) sincospif((float)lane_id / 64.0f, &ls0, &lc0);   // W_128^lane: the odd registers' twiddle factor
     const int slot = blockIdx.x * kPairs + pair;
     if (slot >= nslots) return;
 
-    // Cursor over this wave's frames: every second frame of every run of the pair's work list, as ONE stream.
+    // Cursor over this wave's frames: every kGroup-th frame of every run of the ring's work list, as ONE stream.
     struct Cursor {   // plain ints only: a bool member made the struct copies go through scratch (VMEM -> vmcnt waits)
         int wi, fi, ci, ticket_base, fb, fe, x0, valid;
     };
@@ -385,92 +412,37 @@ __global__ __launch_bounds__(kPairWaves * 64) void k_synth_ola_pair(const float*
     settle(cur);
     if (!cur.valid) return;
 
-#ifdef MPX_PROBE_TIMING
-    unsigned long long pr_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pr_last;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(pr_last)::"memory");
+#ifdef MPX_PROBE_ENDTIME
+    const unsigned long long probe_t0 = wall_clock64();
+    int probe_frames = 0;
 #endif
-    // Software pipeline over the wave's frames: the features of the wave's NEXT frame are loaded (3P + 3 registers)
-    // right after this frame's inverse FFT -- when the transform's temporaries are dead -- and land while the wave waits
-    // for its ticket and overlap-adds; convert + merge of the next iteration then starts on data that is there
-    // (tools/probe_timing.py: loading at the point of use cost 23 % of a wave's time in exposed memory latency).
-    // Ablation builds (tools/ab_bench.py): MPX_PROBE_NOLOAD -- features faked from the lane id (no HBM reads: the
-    // compute + LDS floor); MPX_PROBE_NOFFT -- features loaded and summed, no transform (the memory floor);
-    // MPX_PROBE_NOOLA -- no ordered section (no ticket, flush or overlap-add).
+    // Software pipeline over the wave's frames: the features of the wave's NEXT frame are loaded while this frame waits
+    // for its ticket and overlap-adds; convert + merge of the next iteration then starts on data that is (mostly) there.
     PairFeat<P> ff;
-#ifdef MPX_PROBE_NOLOAD
-#define MPX_FEAT_LOAD(ff, f, ln)                                                                  \
-    do {                                                                                          \
-        _Pragma("unroll") for (int j_ = 0; j_ < P / 2; ++j_) {                                    \
-            ff.m[j_] = ff.mq[j_] = 1.0f + 0.001f * (float)(ln + j_);                              \
-            ff.a[j_] = ff.bq[j_] = 0.6f;                                                          \
-            ff.b[j_] = ff.aq[j_] = 0.8f;                                                          \
-        }                                                                                         \
-        ff.mH = 1.0f; ff.aH = 0.6f; ff.bH = 0.8f;                                                 \
-        asm volatile("" : "+v"(ff.m[0]), "+v"(ff.a[0]), "+v"(ff.b[0]), "+v"(ff.mq[1]));           \
-    } while (0)
-#elif defined(MPX_PROBE_WIDELOAD)   // with MPX_PROBE_NOFFT only: the same bytes as 16-byte loads (layout ignored)
-#define MPX_FEAT_LOAD(ff, f, ln)                                                                  \
-    do {                                                                                          \
-        const float* rows_[3] = {mag + (f) * ld, real + (f) * ld, imag + (f) * ld};               \
-        float* dst_[3][2] = {{ff.m, ff.mq}, {ff.a, ff.aq}, {ff.b, ff.bq}};                        \
-        _Pragma("unroll") for (int s_ = 0; s_ < 3; ++s_) {                                        \
-            _Pragma("unroll") for (int q_ = 0; q_ < P / 4; ++q_) {                                \
-                float4 v_;                                                                        \
-                __builtin_memcpy(&v_, rows_[s_] + 256 * q_ + 4 * (ln), 16);                       \
-                float* d_ = dst_[s_][q_ / (P / 8)] + 4 * (q_ % (P / 8));                          \
-                d_[0] = v_.x; d_[1] = v_.y; d_[2] = v_.z; d_[3] = v_.w;                           \
-            }                                                                                     \
-        }                                                                                         \
-        ff.mH = rows_[0][64 * P - (ln)]; ff.aH = rows_[1][64 * P - (ln)]; ff.bH = rows_[2][64 * P - (ln)]; \
-    } while (0)
-#else
-#define MPX_FEAT_LOAD(ff, f, ln) feat_load_paired<P>(ff, mag + (f) * ld, real + (f) * ld, imag + (f) * ld, ln)
-#endif
-#ifdef MPX_PROBE_STAGGER
-    for (int i = 0; i < wave * MPX_PROBE_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);   // ~8k cycles per step
-#endif
-    MPX_FEAT_LOAD(ff, (long long)cur.fi, lane_id);
+    {
+        const long long f = cur.fi;
+        feat_load_paired_part<P, 0, P / 2, true>(ff, mag + f * ld, real + f * ld, imag + f * ld, lane_id);
+    }
     while (cur.valid) {
         int lane = lane_id;  // laundered per frame (see k_analysis)
-        float wl_s = wl_s0, wl_c = wl_c0;
-        asm volatile("" : "+v"(lane), "+v"(wl_s), "+v"(wl_c));
+        float wl_s = wl_s0, wl_c = wl_c0, lc = lc0, ls = ls0;
+        asm volatile("" : "+v"(lane), "+v"(wl_s), "+v"(wl_c), "+v"(lc), "+v"(ls));
         Cursor nxt = cur;
         advance(nxt);
-        MPX_T(0, "v"(lane));
-        MPX_T(1, "v"(ff.m[0]), "v"(ff.bq[P / 2 - 1]), "v"(ff.bH));      // features landed
         float xr[P], xi[P];
-#ifdef MPX_PROBE_NOFFT
-        {
-            float acc = ff.mH + ff.aH + ff.bH;
-#pragma unroll
-            for (int j = 0; j < P / 2; ++j) acc += ff.m[j] + ff.a[j] + ff.b[j] + ff.mq[j] + ff.aq[j] + ff.bq[j];
-#pragma unroll
-            for (int j = 0; j < P; ++j) xr[j] = xi[j] = acc;
-        }
-#else
         feat_merge_paired<P>(ff, xr, xi, lane, wl_c, wl_s);
-        MPX_T(2, "v"(xr[0]), "v"(xi[0]), "v"(xr[P - 1]), "v"(xi[P - 1]), "v"(xr[P / 2]), "v"(xi[P / 2 - 1]));
-        wave_fft<P, +1>(xr, xi, tw, xbuf, lane);
-#endif
-        MPX_T(3, "v"(xr[0]), "v"(xi[0]), "v"(xr[P - 1]), "v"(xi[P - 1]), "v"(xr[P / 2]), "v"(xi[P / 2 - 1]));
-        if (nxt.valid) {   // (issuing these before the transform instead -- 239 VGPRs, no spill -- measured the same time)
-            const long long f = nxt.fi;
-            MPX_FEAT_LOAD(ff, f, lane);
+        if constexpr (kCompact) {
+            wave_fft_front_compact<P, +1>(xr, xi, tw, xbuf, lane, lc, ls);
+            fft_inreg<P, +1>(xr, xi);
+        } else {
+            wave_fft<P, +1>(xr, xi, tw, xbuf, lane);
         }
-#ifdef MPX_PROBE_LATENCY   // with MPX_PROBE_TIMING: phase 4 = issue of the prefetch + its full round trip, nothing hidden
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        MPX_T(4, "v"(lane));
-#endif
-#ifdef MPX_PROBE_NOOLA
-        {
-            float acc = 0.0f;
-#pragma unroll
-            for (int j = 0; j < P; ++j) acc += xr[j] * xi[j];
-            if (acc == 12345.678f) strips[lane] = acc;   // keeps the transform alive
-            cur = nxt;
-            continue;
-        }
-#endif
+        const long long fnx = nxt.valid ? nxt.fi : cur.fi;   // (an exhausted cursor re-reads this frame: no branch around loads)
+        const float* nm = mag + fnx * ld;
+        const float* nr = real + fnx * ld;
+        const float* ni = imag + fnx * ld;
+        asm volatile("" ::: "memory");
+        feat_load_paired_part<P, 0, JA, true>(ff, nm, nr, ni, lane);
 
         // ---- ordered section: wait for this frame's ticket
         const int fi = cur.fi;
@@ -483,35 +455,43 @@ __global__ __launch_bounds__(kPairWaves * 64) void k_synth_ola_pair(const float*
         const int target = x & ~63;
         const int flushed = (fi == cur.fb) ? 0 : ((pm_rel[fi - 1] - cur.x0) & ~63);
         asm volatile("" ::"s"(x), "s"(flushed), "s"(rd.head_end), "s"(rd.out_lo), "s"(rd.out_hi), "s"(rd.flush_end));
-#ifndef MPX_PROBE_NOTICKET
         while (__hip_atomic_load(turn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != ticket)
             __builtin_amdgcn_s_sleep(1);
-#endif
         asm volatile("" ::: "memory");
-#ifdef MPX_PROBE_LATENCY
-        MPX_T(0, "s"(x));      // ticket wait booked under phase 0 in this build
-#else
-        MPX_T(4, "s"(x));
-#endif
         if (flushed < target) flush_ring<R>(ring, strip, pcm0, rd.head_end, rd.out_lo, rd.out_hi, flushed, target, lane);
         wave_sync();
-        MPX_T(5, "s"(x));
-        ring_add<P>(smem, ring_byte, x, xr, xi, lane, [](float o, float v, int) { return o + v; },
-                    [](int) { return true; });
+        const RingAddr ra = ring_addr<P>(ring_byte, x, lane);
+        ring_add_plane<P, 0, kCompact ? MPX_CH : P>(smem, ra, xr, lane, [](float o, float v, int) { return o + v; },
+                                                [](int) { return true; });
+        if constexpr (JB > JA) {   // the first plane's registers are free: the second part of the prefetch
+            asm volatile("" ::: "memory");
+            feat_load_paired_part<P, JA, JB, false>(ff, nm, nr, ni, lane);
+        }
+        ring_add_plane<P, 1, kCompact ? MPX_CH : P>(smem, ra, xi, lane, [](float o, float v, int) { return o + v; },
+                                                [](int) { return true; });
         wave_sync();
-        MPX_T(6, "s"(x));
         if (fi == cur.fe - 1) {   // last frame of the run: stream out the rest, leave the ring cleared
             flush_ring<R>(ring, strip, pcm0, rd.head_end, rd.out_lo, rd.out_hi, target, rd.flush_end, lane);
             wave_sync();
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __hip_atomic_store(turn, ticket + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        MPX_T(7, "s"(x));
+        if constexpr (JB < P / 2) {
+            asm volatile("" ::: "memory");
+            feat_load_paired_part<P, JB, P / 2, false>(ff, nm, nr, ni, lane);
+        }
         cur = nxt;
+#ifdef MPX_PROBE_ENDTIME
+        ++probe_frames;
+#endif
     }
-#ifdef MPX_PROBE_TIMING
-    if (lane_id == 0)
-        for (int k = 0; k < 8; ++k) atomicAdd(&g_probe[k], pr_acc[k]);
+#ifdef MPX_PROBE_ENDTIME
+    if (lane_id == 0) {
+        const int w = (blockIdx.x * kPairWaves + wave) % 8192;
+        g_endprobe[3 * w + 0] = probe_t0;
+        g_endprobe[3 * w + 1] = wall_clock64();
+        g_endprobe[3 * w + 2] = (unsigned long long)probe_frames;
+    }
 #endif
 }
 
@@ -725,14 +705,11 @@ int64_t mpx_host_const_to_var_scan(const double* centres, const double* shift_c,
     return 0;
 }
 
-#ifdef MPX_PROBE_TIMING
-int mpx_probe_read(unsigned long long* host16, int reset) {   // probe builds only (not part of the ABI)
+
+#ifdef MPX_PROBE_ENDTIME
+int mpx_probe_endtimes(unsigned long long* host, int n_words) {   // probe builds only (not part of the ABI)
     MPX_HIP_CHECK(hipDeviceSynchronize());
-    MPX_HIP_CHECK(hipMemcpyFromSymbol(host16, HIP_SYMBOL(g_probe), sizeof(unsigned long long) * 16));
-    if (reset) {
-        unsigned long long z[16] = {0};
-        MPX_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_probe), z, sizeof(z)));
-    }
+    MPX_HIP_CHECK(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_endprobe), sizeof(unsigned long long) * (size_t)n_words));
     return MPX_OK;
 }
 #endif

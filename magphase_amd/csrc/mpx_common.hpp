@@ -267,6 +267,35 @@ __device__ __forceinline__ void feat_load_paired(PairFeat<P>& ff, const float* _
     ff.bH = ilo[M / 2];
 }
 
+// The same loads for the bin pairs J0 <= j < J1 only (+ bin M/2 + lane if WITH_H): k_synth_ola_pair issues a frame's
+// prefetch in parts, as registers come free.
+template <int P, int J0, int J1, bool WITH_H>
+__device__ __forceinline__ void feat_load_paired_part(PairFeat<P>& ff, const float* __restrict__ mrow,
+                                                      const float* __restrict__ rrow, const float* __restrict__ irow,
+                                                      int lane) {
+    constexpr int M = 64 * P;
+    const float* mlo = mrow + lane;
+    const float* rlo = rrow + lane;
+    const float* ilo = irow + lane;
+    const float* mhi = mrow + (M - lane);
+    const float* rhi = rrow + (M - lane);
+    const float* ihi = irow + (M - lane);
+#pragma unroll
+    for (int j = J0; j < J1; ++j) {
+        ff.m[j] = mlo[64 * j];
+        ff.a[j] = rlo[64 * j];
+        ff.b[j] = ilo[64 * j];
+        ff.mq[j] = mhi[-64 * j];
+        ff.aq[j] = rhi[-64 * j];
+        ff.bq[j] = ihi[-64 * j];
+    }
+    if (WITH_H) {   // every lane loads "its" bin M/2 + lane (see feat_load_paired)
+        ff.mH = mlo[M / 2];
+        ff.aH = rlo[M / 2];
+        ff.bH = ilo[M / 2];
+    }
+}
+
 template <int P>
 __device__ __forceinline__ void feat_merge_paired(const PairFeat<P>& ff, float (&xr)[P], float (&xi)[P], int lane,
                                                   float wl_c, float wl_s) {
@@ -463,6 +492,62 @@ __device__ __forceinline__ void ring_add(float* smem_base, unsigned ring_byte, i
         for (int i = 0; i < P; ++i) {
             const int q = brev(i, LB);
             if (live(q)) *at(a, b, m, q) = combine(o[i], pl ? xi[i] : xr[i], 2 * (kap + 64 * q) + pl);
+        }
+    }
+}
+
+// ring_add one plane at a time, CH ring values in registers at a time (k_synth_ola_pair at 3 waves per SIMD: the caller
+// places the next part of its feature prefetch between the planes).  PL 0: samples 2n (from xv = the real parts),
+// PL 1: samples 2n + 1 (the imaginary parts).
+struct RingAddr {
+    unsigned a0, a1, b0, b1, m0, m1;
+};
+
+template <int P>
+__device__ __forceinline__ RingAddr ring_addr(unsigned ring_byte, int x, int lane) {
+    constexpr int R = ring_len<P>(), RH = R / 2;
+    const int kap = kappa<P>(lane);
+    const int odd = x & 1;
+    const int c0 = ((x >> 1) % RH) + kap;          // plane 0 (samples 2n): half `odd`
+    const int c1 = (((x + 1) >> 1) % RH) + kap;    // plane 1 (samples 2n + 1): the other half
+    RingAddr r;
+    r.a0 = ring_byte + 4u * (unsigned)((odd ? RH : 0) + c0);
+    r.a1 = ring_byte + 4u * (unsigned)((odd ? 0 : RH) + c1);
+    r.b0 = r.a0 - 4u * RH;
+    r.b1 = r.a1 - 4u * RH;
+    const int w0 = (RH - c0 + 63) >> 6;            // first q with c0 + 64 q >= RH (may be > P - 1: never wraps)
+    const int w1 = (RH - c1 + 63) >> 6;
+    r.m0 = (w0 >= 32) ? 0u : (~0u << w0);
+    r.m1 = (w1 >= 32) ? 0u : (~0u << w1);
+    return r;
+}
+
+template <int P, int PL, int CH, typename CFn, typename LFn>
+__device__ __forceinline__ void ring_add_plane(float* smem_base, const RingAddr& ra, const float (&xv)[P], int lane,
+                                               CFn combine, LFn live) {
+    constexpr int LB = ilog2(P);
+    static_assert(P % CH == 0, "chunk size must divide P");
+    const int kap = kappa<P>(lane);
+    const unsigned a = PL ? ra.a1 : ra.a0, b = PL ? ra.b1 : ra.b0, m = PL ? ra.m1 : ra.m0;
+    char* base = reinterpret_cast<char*>(smem_base);
+    auto at = [&](int q) -> float* {
+        const unsigned sel = (unsigned)__builtin_amdgcn_sbfe((int)m, q, 1);   // 0 or ~0
+        return reinterpret_cast<float*>(base + ((sel & b) | (~sel & a)) + 256 * q);
+    };
+#pragma unroll
+    for (int c = 0; c < P; c += CH) {
+        float o[CH];
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int q = brev(c + i, LB);
+            o[i] = 0.0f;
+            if (live(q)) o[i] = *at(q);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int q = brev(c + i, LB);
+            if (live(q)) *at(q) = combine(o[i], xv[c + i], 2 * (kap + 64 * q) + PL);
         }
     }
 }

@@ -296,4 +296,85 @@ __device__ __forceinline__ void wave_fft(float (&re)[P], float (&im)[P], const f
     fft_inreg<P, SIGN>(re, im);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Compact form (P == 32 only) for kernels that need their LDS for something else (k_synth_ola_pair at 12 waves per CU:
+// six overlap-add rings): HALF-height transpose buffer (P/2 rows) and HALF twiddle table, the same data flow.
+//   * twiddles: the table keeps the even registers only (k1 = brev(i) < 16; rows of P floats + 4 pad); register i + 1
+//     holds k1 + 16, its twiddle is the even one times W_M^{16 l} = W_128^l, a per-lane constant (lc, ls): 4 VALU per
+//     odd register instead of 8.7 KB of LDS.
+//   * transpose in two phases, rows k1 < 16 first: all 64 lanes write their 16 registers of the phase; lane lam reads
+//     16 consecutive columns of row lam % 16 -- the 16 x 64 block is read by all 64 lanes, so a lane whose own row
+//     (k1 = lam % 32) belongs to the OTHER phase reads the half of its neighbour lam ^ 16 that the neighbour does not
+//     read itself (columns 16 b .. 16 b + 15, b = bit 4 of the lane).  After both phases every lane holds its own row's
+//     columns [16 b, 16 b + 16) and the other 16 columns of its neighbour's row: one v_permlane16_swap per register
+//     pair (odd 16-lane rows of A <-> even rows of B) sorts them out -- 16 VALU per plane.
+//   Same output as lds_transpose: register l' holds (k1 = lane % P, l = (lane / P) * P + l').
+// ---------------------------------------------------------------------------------------------
+template <int P>
+__host__ __device__ constexpr int tw_half_stride() { return P + 4; }
+template <int P>
+__host__ __device__ constexpr int tw_half_floats() { return 64 * tw_half_stride<P>(); }
+
+template <int P>
+__device__ __forceinline__ void lds_transpose_half(float (&x)[P], float* xbuf, int lane) {
+    static_assert(P == 32, "the half-height transpose pairs lanes lam, lam ^ 16: P == 32 only");
+    constexpr int LB = ilog2(P), HP = P / 2;
+    float t[P];
+    const float4* src = reinterpret_cast<const float4*>(xbuf + (lane & (HP - 1)) * kXStride + (lane / P) * P +
+                                                        ((lane >> (LB - 1)) & 1) * HP);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int i = 0; i < P; ++i) {
+            const int k1 = brev(i, LB);
+            if ((k1 >> (LB - 1)) == h) xbuf[(k1 & (HP - 1)) * kXStride + lane] = x[i];
+        }
+        wave_sync();
+#pragma unroll
+        for (int q = 0; q < HP / 4; ++q) {
+            const float4 v = src[q];
+            t[h * HP + 4 * q + 0] = v.x;
+            t[h * HP + 4 * q + 1] = v.y;
+            t[h * HP + 4 * q + 2] = v.z;
+            t[h * HP + 4 * q + 3] = v.w;
+        }
+        wave_sync();
+    }
+#pragma unroll
+    for (int j = 0; j < HP; ++j) swap16(t[j], t[HP + j]);
+#pragma unroll
+    for (int j = 0; j < P; ++j) x[j] = t[j];
+}
+
+// wave_fft_front with the half table (twh: tw_half_floats<P>() floats) and the half-height buffer (P/2 * kXStride floats).
+// (lc, ls) = (cos, sin)(2 pi lane / 128), the caller's per-lane constant.
+template <int P, int SIGN>
+__device__ __forceinline__ void wave_fft_front_compact(float (&re)[P], float (&im)[P], const float* twh, float* xbuf,
+                                                       int lane, float lc, float ls) {
+    static_assert(P == 32, "compact form: P == 32 only");
+    fft_inreg<P, SIGN>(re, im);
+    const float4* trow = reinterpret_cast<const float4*>(twh + lane * tw_half_stride<P>());
+#pragma unroll
+    for (int q = 0; q < P / 4; ++q) {
+        const float4 w = trow[q];   // twiddles of the even registers 4q, 4q + 2
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int i = 4 * q + 2 * e;
+            const float wc = e ? w.z : w.x;
+            const float ws0 = e ? w.w : w.y;
+            const float wc1 = wc * lc - ws0 * ls, ws1 = wc * ls + ws0 * lc;   // register i + 1: times W_128^lane
+            const float ws = (SIGN < 0) ? -ws0 : ws0, wsb = (SIGN < 0) ? -ws1 : ws1;
+            const float xr = re[i] * wc - im[i] * ws, xi = re[i] * ws + im[i] * wc;
+            const float yr = re[i + 1] * wc1 - im[i + 1] * wsb, yi = re[i + 1] * wsb + im[i + 1] * wc1;
+            re[i] = xr;
+            im[i] = xi;
+            re[i + 1] = yr;
+            im[i + 1] = yi;
+        }
+    }
+    lds_transpose_half<P>(re, xbuf, lane);
+    lds_transpose_half<P>(im, xbuf, lane);
+    cross_lane_stage<P, SIGN, 32, 64>(re, im, (lane & 32) != 0, false, lane);
+}
+
 }  // namespace mpx

@@ -362,6 +362,30 @@ class Engine:
                                                 nx0, nx1, d_tilt.data_ptr(), out.data_ptr()), "mpx_post_filter")
         return out
 
+    def post_filter_merlin(self, mag_mel_log, fs, pf_coef=1.4):
+        """Device Merlin-style post-filter (mpx_post_filter_merlin, magphase.py:3375-3465) of a float32 [F x D] tensor
+        (3 <= D <= 64) -> float32 [F x D].  Tables: hostmath.merlin_tables, resident on the device per configuration."""
+        torch = _torch()
+        from . import libaudio as la
+
+        F, D = int(mag_mel_log.shape[0]), int(mag_mel_log.shape[1])
+        key = ("merlin", D, int(fs), float("%1.2f" % pf_coef))
+        if key not in self._tables:
+            t = hm.merlin_tables(D, fs, pf_coef)
+            self._tables[key] = (t["alpha"], int(t["g"].shape[1])) + tuple(
+                self.to_device(t[k], np.float32) for k in ("c1", "lifter", "g", "wk", "cf"))
+        alpha, nb, c1, lifter, g, wk, cf = self._tables[key]
+        mcep, mcep_w, out = (self.empty((max(F, 1), D)) for _ in range(3))
+        r0, p_r0 = self.empty((max(F, 1),)), self.empty((max(F, 1),))
+        x = mag_mel_log.contiguous()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.mpx_post_filter_merlin(self.stream_ptr(), x.data_ptr(), F, D, c1.data_ptr(),
+                                                       lifter.data_ptr(), g.data_ptr(), wk.data_ptr(), nb, float(alpha),
+                                                       cf.data_ptr(), float(la.MAGIC), mcep.data_ptr(), mcep_w.data_ptr(),
+                                                       r0.data_ptr(), p_r0.data_ptr(), out.data_ptr()),
+                       "mpx_post_filter_merlin")
+        return out[:F]
+
     def output_hpf(self, pcm, out_off_host, fs):
         """
         magphase.py:981-995 on the device: float32 pcm [total] (utterances concatenated at out_off_host) ->
@@ -714,7 +738,8 @@ class CompressedSynthesisPlan:
     def __init__(self, engine, utts, fs, fft_len=None, b_voi_ap_win=True, b_const_rate=False, alpha_phase=None,
                  noise=None, frames_per_run=None, per_phase_type="magphase", post_filter=False, b_fbank_mel=False,
                  noise_mode="reference", noise_seeds=None):
-        self.apply_post_filter = bool(post_filter)
+        # post_filter: False / True ('magphase': mp.post_filter on the device) / 'merlin' (mp.post_filter_merlin on the device)
+        self.apply_post_filter = post_filter if post_filter in ("merlin", "magphase") else bool(post_filter)
         self.b_const_rate = bool(b_const_rate)
         if noise_mode not in ("reference", "device"):
             raise ValueError("noise_mode must be 'reference' (numpy global RNG, magphase.py:883) or 'device' (Philox on the GPU)")
@@ -940,7 +965,10 @@ class CompressedSynthesisPlan:
             st = e.stream_ptr()
             mark("start")
             a_mag = self.a_mag
-            if self.apply_post_filter:   # magphase.py:3259-3261
+            if self.apply_post_filter == "merlin":   # magphase.py:3262-3264
+                a_mag = e.post_filter_merlin(self.a_mag, self.fs)
+                mark("k_post_filter_merlin")
+            elif self.apply_post_filter:   # magphase.py:3259-3261
                 a_mag = e.post_filter(self.a_mag, self.fs)
                 mark("k_post_filter")
             if self.b_const_rate:   # constant -> variable rate inside the unwarp: one spectrum row per synthesis frame

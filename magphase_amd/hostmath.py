@@ -581,3 +581,30 @@ def cos_matrix_log_spectrum(m_mcep, n_spbins):
     v_w = np.linspace(0, np.pi, num=n_spbins)
     m_trans = np.cos(np.outer(np.arange(m_mcep.shape[1]), v_w))
     return np.asarray(m_mcep, dtype=np.float64) @ m_trans
+
+
+_MERLIN_CACHE = {}
+
+
+def merlin_tables(dim, fs, pf_coef=1.4, fft_len=4096):
+    """
+    Constant tables of the device form of the Merlin post-filter (mpx_post_filter_merlin), float64:
+      c1 [dim x dim]   rceps_compact as a matrix (mcep = x @ c1)
+      lifter [dim]     (1, 1, pf, pf, ...) with pf printed with two decimals like the reference's command line
+      g [dim x H]      freqt(alpha -> 0, order fft_len/2 - 1) followed by the real part of the fft_len-point DFT, on the
+                       H = fft_len/2 + 1 distinct bins;  wk [H] = (1, 2, ..., 2, 1) / fft_len  (c2acr -M 0 -l fft_len)
+      cf [dim x dim]   cosine matrix of cos_matrix_log_spectrum (alpha = 0);  alpha = define_alpha(fs)
+    """
+    key = (int(dim), int(fs), float("%1.2f" % pf_coef), int(fft_len))
+    if key not in _MERLIN_CACHE:
+        dim, alpha, half = key[0], define_alpha(fs), fft_len // 2
+        c1 = rceps_compact(np.eye(dim))
+        lifter = np.concatenate(([1.0, 1.0], np.full(dim - 2, key[2])))
+        a = (0.0 - alpha) / (1.0 - alpha * 0.0)
+        fq = freqt_matrix(dim, half - 1, a).T                     # [dim x half] cepstrum on the linear axis
+        dcos = np.cos(2.0 * np.pi * np.outer(np.arange(half), np.arange(half + 1)) / fft_len)   # [half x H]
+        wk = np.full(half + 1, 2.0 / fft_len)
+        wk[0] = wk[-1] = 1.0 / fft_len
+        cf = np.cos(np.outer(np.arange(dim), np.linspace(0, np.pi, num=dim)))
+        _MERLIN_CACHE[key] = dict(c1=c1, lifter=lifter, g=fq @ dcos, wk=wk, cf=cf, alpha=alpha)
+    return _MERLIN_CACHE[key]

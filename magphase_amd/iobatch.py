@@ -328,7 +328,7 @@ def generate_waveforms_corpus(in_feats_dir, tokens, out_syn_dir, mag_dim, phase_
                               noise_mode="reference"):
     """
     mp.synthesis_from_acoustic_modelling (magphase.py:3229-3275) for a list of tokens, `batch_utts` per launch:
-    reads <token>.mag/.real/.imag/.lf0, post-filters (pf_type 'magphase' on the device, 'merlin' on the host, 'no'),
+    reads <token>.mag/.real/.imag/.lf0, post-filters on the device (pf_type 'magphase' / 'merlin', or 'no'),
     synthesises and writes <token>.wav.
     fs: one sample rate for all tokens (the reference's script), or a dict / callable token -> fs for corpora that mix
     rates (feature files carry no rate): every batch is split by rate, one launch per rate.
@@ -360,8 +360,6 @@ def generate_waveforms_corpus(in_feats_dir, tokens, out_syn_dir, mag_dim, phase_
                     if v.size % dim != 0:
                         raise ValueError("Dimension provided not compatible with file size.")
                     mats.append(v.reshape(-1, dim) if dim > 1 else v)
-                if pf_type == "merlin":   # host arithmetic, reader side
-                    mats[0] = mp.post_filter_merlin(mats[0].astype(np.float64), rate)
                 utts.append((t, rate, tuple(mats)))
             except (KeyboardInterrupt, SystemExit):
                 raise
@@ -381,7 +379,8 @@ def generate_waveforms_corpus(in_feats_dir, tokens, out_syn_dir, mag_dim, phase_
                 # pcm16_norm: la.write_audio_file's peak normalisation and 16-bit conversion done on the device
                 return mp.synthesis_from_compressed_batch([u[2] for u in g], rate, fft_len=fft_len,
                                                           b_const_rate=b_const_rate,
-                                                          b_post_filter=(pf_type == "magphase"), engine=engine,
+                                                          b_post_filter=(pf_type if pf_type != "no" else False),
+                                                          engine=engine,
                                                           pcm16_norm=0.98, **kw)
 
             ok, bad = _isolate(group, synth, keep_numpy_rng=(noise_mode == "reference"))

@@ -371,6 +371,15 @@ def post_filter_merlin(m_mag_mel_log, fs, pf_coef=1.4):
     return m_out
 
 
+def post_filter_merlin_device(m_mag_mel_log, fs, pf_coef=1.4, engine=None):
+    """post_filter_merlin on the device (mpx_post_filter_merlin): the same chain in float32 for all frames at once --
+    what iobatch.generate_waveforms_corpus(pf_type='merlin') and synthesis_from_compressed_batch(b_post_filter='merlin')
+    run.  Host array in, float64 array out; differs from the host form by float32 rounding (tests: -m gpu)."""
+    engine = engine or get_engine()
+    x = engine.to_device(np.atleast_2d(np.asarray(m_mag_mel_log)), np.float32)
+    return engine.to_host_f64(engine.post_filter_merlin(x, fs, pf_coef=pf_coef))
+
+
 def _output_hpf(v_syn_sig, fs):
     """magphase.py:981-995: 4th-order Butterworth high-pass at 40 Hz, float64 on the host (poles at |z|~0.997)."""
     from scipy import signal
@@ -384,7 +393,8 @@ def synthesis_from_compressed_batch(utts, fs, fft_len=None, b_voi_ap_win=True, b
                                     b_post_filter=False, b_fbank_mel=False, noise_mode='reference', noise_seeds=None,
                                     pcm16_norm=False):
     """Batched synthesis_from_compressed; utts: list of (m_mag_mel_log, m_real_mel, m_imag_mel, v_lf0).
-    b_post_filter: apply the MagPhase post-filter to the log-mel magnitudes on the device first (pf_type='magphase').
+    b_post_filter: apply a post-filter to the log-mel magnitudes on the device first: True / 'magphase' = the MagPhase
+    post-filter (pf_type='magphase'), 'merlin' = the Merlin-style one (pf_type='merlin', mpx_post_filter_merlin).
     noise_mode: 'reference' (default) draws the aperiodic source from numpy's global RNG like magphase.py:883;
     'device' generates it on the GPU (Philox, one uint64 seed per utterance in noise_seeds, default 0, 1, ...): same
     distribution, not the reference's sample values, independent of batching and sharding.

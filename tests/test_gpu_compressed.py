@@ -17,7 +17,7 @@ from _tol import within
 
 pytestmark = pytest.mark.gpu
 
-COMP_PCM_TOL = 2e-5
+COMP_PCM_TOL = 2e-6   # measured worst case on MI355X 6.0e-7 of the signal peak (profiles/r03_tolerance_report.json)
 
 
 @pytest.fixture(scope="module")
@@ -195,15 +195,16 @@ def test_unsupported_branches_and_errors(mp, golden_dir):
 
 # ---------------------------------------------------------------------------------------------------------------
 # compressed analysis (mel warp).  The SPTK mcep arithmetic is a restatement -> golden G8 is "oracle-with-our-mcep".
-# Tolerances: log-mag mel abs 1e-4 nepers (0.0009 dB), real/imag abs 2e-5, lf0 and shifts exact (host fp64).
+# Tolerances: log-mag mel abs 2e-5 nepers (0.0002 dB), real/imag abs 3e-6, lf0 and shifts exact (host fp64).
 # The lossless features feeding the warp come from the float64-transform analysis kernel (magphase_f64.hip): they are
 # the correctly rounded float32 values of the reference's float64 features (test_f64_analysis_features_are_correctly_
 # rounded below), so what is left is the fp32 log / GEMM of the warp itself: observed 3.3e-5 (mag), 3.7e-6 (real/imag).
 # (With the fp32 transform the same outputs were off by 6.6e-4 / 5.6e-4: ~1e-6 of the frame peak of FFT noise on every
 # bin is a 1e-3..1e-2 relative error on bins 60-80 dB down, which ln() and the division by |X| pass on.)
 # ---------------------------------------------------------------------------------------------------------------
-WARP_TOL = 1e-4
-WARP_PHASE_TOL = 2e-5
+WARP_TOL = 2e-5         # log-mel magnitudes: measured 8.5e-6 on the golden / configs[2] cases (the random sweep of
+                        # tests/test_gpu_fuzz.py keeps 1e-4: worst seen in 340 batches 4.1e-5)
+WARP_PHASE_TOL = 3e-6   # phase coefficients: measured 8.9e-7
 
 
 def test_f64_analysis_features_are_correctly_rounded(orc):

@@ -8,7 +8,8 @@ Tolerances (fp32 device arithmetic vs fp64 reference), written here once:
     (real/imag alone are ill-conditioned where mag ~ 0 -- SURVEY 8c -- so they are compared through X,
      plus directly, per bin, with the frame-peak bound amplified by peak / |X|: see REAL_IMAG_TOL in _check_feats)
   * mag: <= 4e-6 * frame peak
-  * resynthesised PCM: <= 1e-5 of the signal peak (north_star's "stated fp32 tolerance")
+  * resynthesised PCM: <= 1e-6 of the signal peak (north_star's "stated fp32 tolerance"; SURVEY 8c allows 1e-5)
+Every bound is <= ~3 x the worst case measured on MI355X (tests/_tol.py keeps the book: profiles/r03_tolerance_report.json).
 """
 import os
 import warnings
@@ -20,9 +21,9 @@ from _tol import within
 
 pytestmark = pytest.mark.gpu
 
-SPEC_TOL = 4e-6
-PCM_TOL = 1e-5
-REAL_IMAG_TOL = 4e-6  # per bin: |d real| <= REAL_IMAG_TOL * frame peak / |X| (+ 2e-7), bins above 1e-5 of the frame peak
+SPEC_TOL = 4e-6      # measured worst case on MI355X 2.8e-6 (profiles/r03_tolerance_report.json)
+PCM_TOL = 1e-6       # measured 4.8e-7 of the signal peak
+REAL_IMAG_TOL = 3e-6  # measured 8.8e-7; per bin: |d real| <= REAL_IMAG_TOL * frame peak / |X| (+ 2e-7), bins above 1e-5 of the frame peak
 
 
 @pytest.fixture(scope="module")
@@ -132,7 +133,7 @@ def test_synthesis_general_features_and_ola_trimming(mp, orc):
         ref = orc.synthesis_from_lossless(m_mag, m_real, m_imag, v_f0, fs)
         got = mp.synthesis_from_lossless(m_mag, m_real, m_imag, v_f0, fs)
         assert len(got) == len(ref)
-        within((np.max(np.abs(got - ref))) / (np.max(np.abs(ref))), PCM_TOL, "PCM_TOL:129")
+        within(np.max(np.abs(got - ref)) / max(np.max(np.abs(ref)), 1e-30), PCM_TOL, "PCM_TOL:129")
 
 
 def test_batch_equals_single_and_is_deterministic(mp):

@@ -62,3 +62,62 @@ def test_silent_frames_do_not_produce_nans():
     x = np.full((3, 60), -23.0)
     y = mp.post_filter_merlin(x, 16000)
     assert np.all(np.isfinite(y))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# device form (mpx_post_filter_merlin, csrc/magphase_merlin.hip): -m gpu, against the host form above
+# ---------------------------------------------------------------------------------------------------------------------
+import os  # noqa: E402
+
+import pytest  # noqa: E402
+
+from _tol import within  # noqa: E402
+
+
+def test_merlin_tables_reproduce_the_host_chain():
+    """hostmath.merlin_tables (what the device kernels consume) against the host functions they fold together."""
+    x = _log_mel_mags(n_frames=6)
+    t = hm.merlin_tables(60, 48000)
+    mcep = hm.rceps_compact(x)
+    assert np.max(np.abs(x @ t["c1"] - mcep)) < 1e-12
+    r0 = hm.sptk_c2acr_r0(hm.sptk_freqt(mcep, 2047, t["alpha"]), 4096)
+    r0_t = np.exp(2.0 * (mcep @ t["g"])) @ t["wk"]
+    assert np.max(np.abs(r0_t / r0 - 1.0)) < 1e-10
+    assert np.max(np.abs(mcep @ t["cf"] - hm.cos_matrix_log_spectrum(mcep, 60))) < 1e-12
+    assert t["lifter"][0] == t["lifter"][1] == 1.0 and t["lifter"][2] == 1.4
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fs", [48000, 16000])
+def test_device_form_matches_host_form(fs, golden_dir):
+    x = _log_mel_mags(n_frames=300, seed=11)
+    g = np.load(os.path.join(golden_dir, "g5_generation_hvd704.npz"))
+    real = g["in_mag"].reshape(-1, 60).astype(np.float64)          # the reference's bundled predicted features
+    for m in (x, real, np.full((3, 60), -23.0)):
+        want = mp.post_filter_merlin(m, fs)
+        got = mp.post_filter_merlin_device(m, fs)
+        assert got.shape == want.shape and np.all(np.isfinite(got))
+        within(np.max(np.abs(got - want)), 3e-5, "MERLIN_PF_ABS")
+    x24 = _log_mel_mags(n_frames=10, dim=24)
+    within(np.max(np.abs(mp.post_filter_merlin_device(x24, fs) - mp.post_filter_merlin(x24, fs))), 3e-5, "MERLIN_PF_ABS")
+
+
+@pytest.mark.gpu
+def test_batch_synthesis_with_device_merlin_post_filter(golden_dir):
+    """synthesis_from_compressed_batch(b_post_filter='merlin') == synthesis of host-post-filtered magnitudes (same seeded
+    device noise), and a second run is bit-identical (the post-filter kernels use no atomics)."""
+    g = np.load(os.path.join(golden_dir, "g5_generation_hvd704.npz"))
+    mm = g["in_mag"].reshape(-1, 60).astype(np.float64)
+    rr = g["in_real"].reshape(-1, 45).astype(np.float64)
+    ii = g["in_imag"].reshape(-1, 45).astype(np.float64)
+    lf = g["in_lf0"].astype(np.float64)
+    kw = dict(noise_mode="device", noise_seeds=[7, 8])
+    a = mp.synthesis_from_compressed_batch([(mm, rr, ii, lf), (mm[:120], rr[:120], ii[:120], lf[:120])], 48000,
+                                           b_post_filter="merlin", **kw)
+    a2 = mp.synthesis_from_compressed_batch([(mm, rr, ii, lf), (mm[:120], rr[:120], ii[:120], lf[:120])], 48000,
+                                            b_post_filter="merlin", **kw)
+    b = mp.synthesis_from_compressed_batch([(mp.post_filter_merlin(mm, 48000), rr, ii, lf),
+                                            (mp.post_filter_merlin(mm[:120], 48000), rr[:120], ii[:120], lf[:120])], 48000, **kw)
+    for u in range(2):
+        assert np.array_equal(a[u], a2[u]) and a[u].shape == b[u].shape
+        within(np.max(np.abs(a[u] - b[u])) / np.max(np.abs(b[u])), 6e-6, "MERLIN_PF_PCM")

@@ -1,0 +1,53 @@
+#!/usr/bin/env python
+"""
+Launch tail of k_synth_ola_pair: start / end clock of every wave of one launch (a -DMPX_PROBE_ENDTIME build).
+
+    python tools/ab_bench.py --prepare endp:-DMPX_PROBE_ENDTIME        # here
+    python tools/endtime_probe.py [variant]                            # on the GPU box
+
+Prints the distribution of the waves' end times relative to the first start, per XCD (block b runs on XCD b % 8), and
+what the launch would take if every wave ended at the mean.
+"""
+import ctypes
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import ab_bench  # noqa: E402
+import bench  # noqa: E402
+
+name = sys.argv[1] if len(sys.argv) > 1 else "endp"
+em = ab_bench.load(name)
+eng = em.Engine()
+utts = bench.make_batch(0)
+aplan = em.LosslessAnalysisPlan(eng, utts)
+splan = em.LosslessSynthesisPlan(eng, aplan.v_f0, aplan.fs, aplan.fft_len)
+feats = aplan.run()
+strips, pcm = eng.empty((splan.strip_floats,)), eng.empty((splan.total_out,))
+for rep in range(4):
+    aplan.run(out=feats)
+    splan.run(feats[0], feats[1], feats[2], strips=strips, out=pcm)
+torch.cuda.synchronize()
+waves_per_block = 2 * splan.n_slots // 256 if splan.n_slots % 256 == 0 else 12
+n = 256 * waves_per_block
+buf = (ctypes.c_ulonglong * (3 * n))()
+assert eng.lib.mpx_probe_endtimes(buf, 3 * n) == 0
+a = np.frombuffer(buf, dtype=np.uint64).reshape(n, 3).astype(np.float64)
+t0, t1, fr = a[:, 0], a[:, 1], a[:, 2]
+ok = fr > 0
+base = t0[ok].min()
+s, e = (t0[ok] - base) / 100.0, (t1[ok] - base) / 100.0     # microseconds (100 MHz clock)
+print("waves %d (with frames: %d), frames per wave %.1f .. %.1f" % (n, ok.sum(), fr[ok].min(), fr[ok].max()))
+print("start  us: min %.1f  median %.1f  max %.1f" % (s.min(), np.median(s), s.max()))
+print("end    us: min %.1f  p10 %.1f  median %.1f  p90 %.1f  p99 %.1f  max %.1f" % (
+    e.min(), np.percentile(e, 10), np.median(e), np.percentile(e, 90), np.percentile(e, 99), e.max()))
+print("busy   us: mean %.1f  (launch = max end %.1f: %.0f %% of the waves' mean)" % ((e - s).mean(), e.max(), 100 * e.max() / (e - s).mean()))
+blk = np.arange(n)[ok] // waves_per_block
+for x in range(8):
+    m = (blk % 8) == x
+    print("  XCD %d: end median %.1f  max %.1f   us per frame (median) %.2f" % (x, np.median(e[m]), e[m].max(), np.median((e[m] - s[m]) / fr[ok][m])))
