@@ -140,6 +140,10 @@ typedef struct mpx_ola_run {
  * pcm_out  : float32, the utterances' outputs concatenated (every kept sample is written exactly once by
  *            mpx_synthesis_lossless_ola; mpx_ola_fixup then adds the head strips) */
 int mpx_synth_ola_slots(void); /* pair slots the current device runs concurrently (CUs x pairs per workgroup) */
+/* Relative speed of the slots (HOST float32[n_slots], n_slots = mpx_synth_ola_slots()): a SIMD serves its resident waves
+ * by age, so the wave groups of a workgroup run at different, fixed rates; the planner (hostmath.ola_runs) deals the frames
+ * of a batch in proportion to these weights so that all slots finish together. */
+int mpx_synth_ola_slot_weights(float* weights_host, int32_t n_slots);
 int64_t mpx_ola_strip_floats(int fft_len); /* floats per head strip: fft_len + 64 */
 int mpx_synthesis_lossless_ola(void* stream, int fft_len, const void* tables, const float* mag, const float* real,
                                const float* imag, const mpx_ola_run* runs, int32_t n_runs, const int32_t* slot_off,
@@ -260,6 +264,8 @@ int mpx_noise_stats(void* stream, int fft_len, const void* tables, const float* 
  *              bins are not read (one row per frame form only).
  */
 int mpx_synth_comp_slots(void); /* wave slots of mpx_synthesis_compressed_ola on the current device */
+/* Relative speed of the compressed synthesis kernel's slots (see mpx_synth_ola_slot_weights). */
+int mpx_synth_comp_slot_weights(float* weights_host, int32_t n_slots);
 int mpx_synthesis_compressed_ola(void* stream, int fft_len, const void* tables, const float* mag, const float* real,
                                  const float* imag, const float* noise, const int64_t* noise_pos,
                                  const int32_t* noise_left, const int32_t* noise_right, const int32_t* noise_wtype,

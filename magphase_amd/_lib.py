@@ -24,6 +24,7 @@ SYMBOLS = (
     "mpx_synthesis_lossless_frames",
     "mpx_ola_gather",
     "mpx_synth_ola_slots",
+    "mpx_synth_ola_slot_weights",
     "mpx_ola_strip_floats",
     "mpx_synthesis_lossless_ola",
     "mpx_ola_fixup",
@@ -36,6 +37,7 @@ SYMBOLS = (
     "mpx_host_mt19937_jump_poly",
     "mpx_noise_stats",
     "mpx_synth_comp_slots",
+    "mpx_synth_comp_slot_weights",
     "mpx_synthesis_compressed_ola",
     "mpx_host_const_to_var_scan",
     "mpx_host_plan_analysis",
@@ -123,6 +125,10 @@ def _load_locked():
     lib.mpx_synthesis_lossless_ola.restype = ctypes.c_int
     lib.mpx_synth_ola_slots.restype = ctypes.c_int
     lib.mpx_synth_ola_slots.argtypes = []
+    lib.mpx_synth_comp_slot_weights.restype = ctypes.c_int
+    lib.mpx_synth_comp_slot_weights.argtypes = [vp, i32]
+    lib.mpx_synth_ola_slot_weights.restype = ctypes.c_int
+    lib.mpx_synth_ola_slot_weights.argtypes = [vp, i32]
     lib.mpx_ola_strip_floats.restype = i64
     lib.mpx_ola_strip_floats.argtypes = [ctypes.c_int]
     lib.mpx_synthesis_lossless_ola.argtypes = [vp, ctypes.c_int, vp, vp, vp, vp, vp, i32, vp, vp, i32, vp, vp, vp, i64]

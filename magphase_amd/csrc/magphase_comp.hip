@@ -357,13 +357,16 @@ __global__ __launch_bounds__(kAnaThreads) void k_noise_stats(const float* __rest
     float* xbuf = smem + tw_floats<P>() + wave * (P * kXStride);
     const unsigned xbuf_byte = 4u * (unsigned)(tw_floats<P>() + rfl(wave) * (P * kXStride));
     for (int i = threadIdx.x; i < tw_floats<P>(); i += kAnaThreads) tw[i] = tw_g[i];
+    unsigned* queue = reinterpret_cast<unsigned*>(smem + tw_floats<P>() + kAnaWaves * (P * kXStride));
+    if (threadIdx.x == 0) *queue = 0u;
     __syncthreads();
     float wl_s0, wl_c0;
     sincospif(-2.0f * (float)kappa<P>(lane_id) / (float)N, &wl_s0, &wl_c0);
-    const int wave_u = rfl(wave);
-    // compute-only kernel (one float out per frame): 12 waves per CU like k_analysis (3 per SIMD)
-    for (long long f = (long long)blockIdx.x * kAnaWaves + wave_u; f < nframes;
-         f += (long long)gridDim.x * kAnaWaves) {
+    // compute-only kernel (one float out per frame): 12 waves per CU like k_analysis (3 per SIMD); the workgroup's frames
+    // are pulled from its LDS queue (queue_pull, mpx_common.hpp: a SIMD serves its waves by age)
+    long long fb, fe;
+    block_frame_range(nframes, fb, fe);
+    for (long long f = queue_pull(queue, fb); f < fe; f = queue_pull(queue, fb)) {
         int lane = lane_id;
         float wl_s = wl_s0, wl_c = wl_c0;
         asm volatile("" : "+v"(lane), "+v"(wl_s), "+v"(wl_c));
@@ -1953,6 +1956,21 @@ int mpx_noise_stats(void* stream, int fft_len, const void* tables, const float* 
 }
 
 int mpx_synth_comp_slots(void) { return device_cus() * kCompPairs; }
+
+// Relative speed of the slots' wave pairs (see mpx_synth_ola_slot_weights): 8 waves per workgroup = two per SIMD, the
+// pairs 0 and 1 hold the older wave of every SIMD.
+#ifndef MPX_COMP_W0
+#define MPX_COMP_W0 100
+#endif
+#ifndef MPX_COMP_W1
+#define MPX_COMP_W1 80
+#endif
+int mpx_synth_comp_slot_weights(float* weights_host, int32_t n_slots) {
+    if (!weights_host || n_slots < 0) return fail(MPX_ERR_ARG, "mpx_synth_comp_slot_weights: bad arguments%s");
+    for (int s = 0; s < n_slots; ++s)
+        weights_host[s] = (((s % kCompPairs) * 2) / 4 == 0) ? (float)MPX_COMP_W0 : (float)MPX_COMP_W1;
+    return MPX_OK;
+}
 
 int mpx_synthesis_compressed_ola(void* stream, int fft_len, const void* tables, const float* mag, const float* real,
                                  const float* imag, const float* noise, const int64_t* noise_pos,

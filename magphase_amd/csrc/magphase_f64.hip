@@ -19,7 +19,7 @@ namespace mpx {
 constexpr int kAna64Waves = 8;
 template <int P>
 constexpr size_t lds_bytes_ana64() {
-    return sizeof(double) * (size_t)tw64_doubles<P>() + sizeof(float) * (size_t)(kAna64Waves * P * kXStride);
+    return sizeof(double) * (size_t)tw64_doubles<P>() + sizeof(float) * (size_t)(kAna64Waves * P * kXStride + 4);   // + frame queue
 }
 
 // sin(x), |x| <= pi/2: Taylor polynomial to x^17 (remainder (pi/2)^19 / 19! = 4e-14)
@@ -90,13 +90,18 @@ __global__ __launch_bounds__(kAna64Waves * 64) void k_analysis_f64(const float* 
     float* xbuf = xbase + wave * (P * kXStride);
     const unsigned xbuf_byte = 8u * (unsigned)tw64_doubles<P>() + 4u * (unsigned)(wave * (P * kXStride));
     for (int i = threadIdx.x; i < tw64_doubles<P>(); i += kAna64Waves * 64) tw[i] = tw_g[i];
+    unsigned* queue = reinterpret_cast<unsigned*>(xbase + kAna64Waves * (P * kXStride));
+    if (threadIdx.x == 0) *queue = 0u;
     __syncthreads();
 
     // lane part of the split twiddle W_N^kappa = e^{-2 pi i kappa / N}
     double wl_s0, wl_c0;
     sincospi(-2.0 * (double)kappa<P>(lane_id) / (double)N, &wl_s0, &wl_c0);
 
-    for (long long f = (long long)blockIdx.x * kAna64Waves + wave; f < nframes; f += (long long)gridDim.x * kAna64Waves) {
+    // the workgroup's frames are pulled from its LDS queue (queue_pull, mpx_common.hpp: a SIMD serves its waves by age)
+    long long fb, fe;
+    block_frame_range(nframes, fb, fe);
+    for (long long f = queue_pull(queue, fb); f < fe; f = queue_pull(queue, fb)) {
         int lane = lane_id;   // laundered per frame: keeps per-lane products out of loop-invariant registers
         double wl_s = wl_s0, wl_c = wl_c0;
         asm volatile("" : "+v"(lane), "+v"(wl_s), "+v"(wl_c));

@@ -22,6 +22,9 @@ namespace mpx {
 #define MPX_ST(dst, val) ((dst) = (val))
 #endif
 
+#ifndef MPX_ANA_QUEUE
+#define MPX_ANA_QUEUE 0
+#endif
 template <int P>
 __global__ __launch_bounds__(kAnaThreads) void k_analysis(const float* __restrict__ sig,
                                                           const long long* __restrict__ fpos,
@@ -39,16 +42,28 @@ __global__ __launch_bounds__(kAnaThreads) void k_analysis(const float* __restric
     // byte address of xbuf in LDS (the dynamic segment starts at 0: the kernel has no static __shared__)
     const unsigned xbuf_byte = 4u * (unsigned)(tw_floats<P>() + rfl(wave) * (P * kXStride));
     for (int i = threadIdx.x; i < tw_floats<P>(); i += kAnaThreads) tw[i] = tw_g[i];
+    unsigned* queue = reinterpret_cast<unsigned*>(smem + tw_floats<P>() + kAnaWaves * (P * kXStride));
+    if (threadIdx.x == 0) *queue = 0u;
     __syncthreads();
 
     // lane part of the split twiddle W_N^kappa = e^{-2 pi i kappa / N}
     float wl_s0, wl_c0;
     sincospif(-2.0f * (float)kappa<P>(lane_id) / (float)N, &wl_s0, &wl_c0);
 
-    const int wave_u = rfl(wave);
-    const long long fstep = (long long)gridDim.x * kAnaWaves;
-    long long f = (long long)blockIdx.x * kAnaWaves + wave_u;
-    if (f >= nframes) return;
+    // Frames: grid-stride by default (wave w takes frames w, w + W, ...: neighbouring rows of the three feature matrices
+    // are written at the same time); MPX_ANA_QUEUE = 1 gives every workgroup a contiguous range pulled frame by frame
+    // from an LDS counter (queue_pull, mpx_common.hpp) -- what balances the compute-bound frame kernels (k_analysis_f64,
+    // k_noise_stats) measured 3 % SLOWER here (0.3285 vs 0.3183 ms): this kernel runs at the device's store ceiling, and
+    // the store pattern, not the waves' age, is what it is sensitive to.
+#if MPX_ANA_QUEUE
+    long long fb, fe;
+    block_frame_range(nframes, fb, fe);
+    long long f = queue_pull(queue, fb);
+#else
+    const long long fb = 0, fe = nframes, fstep = (long long)gridDim.x * kAnaWaves;
+    long long f = (long long)blockIdx.x * kAnaWaves + rfl(wave);
+#endif
+    if (f >= fe) return;
 
     // Software pipeline: the samples of the wave's next frame are copied HBM -> LDS (into the transpose buffer, idle
     // after the FFT's exchange) while this frame's second FFT pass and epilogue run.  All 99 stores of the epilogue
@@ -57,7 +72,7 @@ __global__ __launch_bounds__(kAnaThreads) void k_analysis(const float* __restric
     stage_samples_async(g, 0, kTile, xbuf_byte, lane_id);
     staged_wait<0>();
 
-    for (; f < nframes; f += fstep) {
+    while (true) {
         // Launder the per-lane invariants once per frame: otherwise LICM hoists every (lane x register)
         // twiddle product out of this loop and the kernel spills.
         int lane = lane_id;
@@ -111,9 +126,13 @@ __global__ __launch_bounds__(kAnaThreads) void k_analysis(const float* __restric
         wave_fft_front<P, -1>(re, im, tw, xbuf, lane);
 
         // ---- the exchange buffer is idle from here on: start the copy of the next frame's samples into it
+#if MPX_ANA_QUEUE
+        const long long fn = queue_pull(queue, fb);
+#else
         const long long fn = f + fstep;
+#endif
         FrameGeom gn = g;
-        if (fn < nframes) {
+        if (fn < fe) {
             gn = frame_geom(sig, fpos[fn], fleft[fn], fright[fn], N);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the exchange's own LDS reads have returned
             stage_samples_async(gn, 0, kTile, xbuf_byte, lane);
@@ -220,11 +239,13 @@ __global__ __launch_bounds__(kAnaThreads) void k_analysis(const float* __restric
         // The epilogue issued 3P + 3 stores after the copy's loads (3 per step q for X[k], 3 for bin M or a mirror block,
         // 3 for the last block): at most that many operations outstanding <=> the copy has landed.  (P = 32: 99 > 63,
         // the counter's range; P = 16 / 8: 51 / 27 -- a fixed 63 would not wait at all there.)
+        if (fn >= fe) break;
 #ifdef MPX_PROBE_NOSTORE
-        if (fn < nframes) staged_wait<0>();
+        staged_wait<0>();
 #else
-        if (fn < nframes) staged_wait<3 * P + 3>();
+        staged_wait<3 * P + 3>();
 #endif
+        f = fn;
     }
 }
 
@@ -305,6 +326,12 @@ constexpr int kGroup = MPX_SYN_GROUP;            // waves sharing one ring (2: t
 constexpr int kPairs = kPairWaves / kGroup;      // rings (= work-list slots) per workgroup
 static_assert(kPairWaves % kGroup == 0, "waves per workgroup must be a multiple of the group size");
 
+#ifndef MPX_PRIO_ROTATE
+#define MPX_PRIO_ROTATE 0
+#endif
+#ifndef MPX_PRIO_SHIFT
+#define MPX_PRIO_SHIFT 10
+#endif
 #ifdef MPX_PROBE_ENDTIME
 // Probe build (tools/endtime_probe.py): every wave of k_synth_ola_pair stores the constant-rate clock (100 MHz) when it
 // enters and when it leaves its frame loop, and its frame count -- the spread of the end times is the launch tail.
@@ -427,6 +454,24 @@ __global__ __launch_bounds__(kPairWaves * 64) void k_synth_ola_pair(const float*
         int lane = lane_id;  // laundered per frame (see k_analysis)
         float wl_s = wl_s0, wl_c = wl_c0, lc = lc0, ls = ls0;
         asm volatile("" : "+v"(lane), "+v"(wl_s), "+v"(wl_c), "+v"(lc), "+v"(ls));
+#if MPX_PRIO_ROTATE
+        // Fair shares of a SIMD.  The waves of a SIMD are arbitrated by priority, then AGE: at equal priority the oldest
+        // wave issues whenever it can and the youngest gets what is left (MI355X_MICROARCH.md, "Two waves per SIMD").
+        // Every wave here has the same static amount of work, so the old waves finished at 220 us, the young ones at
+        // 370-400 us (tools/endtime_probe.py: launch = 126-134 % of the waves' mean busy time) and the SIMDs idled through
+        // the tail.  The priority therefore rotates with the constant-rate clock: the waves w, w + 4, w + 8 of a workgroup
+        // share a SIMD (dispatch order 0 -> 2 -> 1 -> 3) and take the priorities (t + w / 4) mod kPerSimd in turn, t
+        // advancing every 2^MPX_PRIO_SHIFT ticks of 10 ns.
+        {
+            constexpr int kPerSimd = (kPairWaves + 3) / 4;
+            const unsigned t = (unsigned)(wall_clock64() >> MPX_PRIO_SHIFT);
+            const int pr = (int)((t + (unsigned)(wave >> 2)) % (unsigned)kPerSimd);
+            if (pr == 0) __builtin_amdgcn_s_setprio(0);
+            else if (pr == 1) __builtin_amdgcn_s_setprio(1);
+            else if (pr == 2) __builtin_amdgcn_s_setprio(2);
+            else __builtin_amdgcn_s_setprio(3);
+        }
+#endif
         Cursor nxt = cur;
         advance(nxt);
         float xr[P], xi[P];
@@ -715,6 +760,31 @@ int mpx_probe_endtimes(unsigned long long* host, int n_words) {   // probe build
 #endif
 
 int mpx_synth_ola_slots(void) { return device_cus() * kPairs; }
+
+// Relative speed of the slots' wave groups.  The waves i, i + 4, i + 8 of a workgroup share a SIMD, and a SIMD serves its
+// waves by age: measured on MI355X (tools/endtime_probe.py) the first four waves of a 12-wave workgroup take 14.4 us per
+// frame, the next four 17.2, the last four 20.5 while all are resident (18.0 / 23.9 corrected for the time they run
+// without their elders) -- with equal shares the launch lasted 126-134 % of the waves' mean busy time.  The planner
+// therefore deals the frames in proportion to these weights; a rotating s_setprio (MPX_PRIO_ROTATE) narrows the spread
+// only by a third.
+#ifndef MPX_SYN_W0
+#define MPX_SYN_W0 100
+#endif
+#ifndef MPX_SYN_W1
+#define MPX_SYN_W1 80
+#endif
+#ifndef MPX_SYN_W2
+#define MPX_SYN_W2 60
+#endif
+int mpx_synth_ola_slot_weights(float* weights_host, int32_t n_slots) {
+    if (!weights_host || n_slots < 0) return fail(MPX_ERR_ARG, "mpx_synth_ola_slot_weights: bad arguments%s");
+    const float w[4] = {(float)MPX_SYN_W0, (float)MPX_SYN_W1, (float)MPX_SYN_W2, (float)MPX_SYN_W2};
+    for (int s = 0; s < n_slots; ++s) {
+        const int age = ((s % kPairs) * kGroup) / 4;   // first wave of the group: its age rank on its SIMD
+        weights_host[s] = w[age > 3 ? 3 : age];
+    }
+    return MPX_OK;
+}
 
 int64_t mpx_ola_strip_floats(int fft_len) { return p_of(fft_len) ? (int64_t)fft_len + 64 : 0; }
 

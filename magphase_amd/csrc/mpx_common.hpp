@@ -48,11 +48,29 @@ constexpr size_t lds_bytes() {
 constexpr int kAnaWaves = MPX_ANA_WAVES;
 constexpr int kAnaThreads = kAnaWaves * 64;
 template <int P>
-constexpr size_t lds_bytes_ana() {
-    return sizeof(float) * (size_t)(tw_floats<P>() + kAnaWaves * P * kXStride);
+constexpr size_t lds_bytes_ana() {   // twiddles + one transpose buffer per wave + the workgroup's frame queue (4 words)
+    return sizeof(float) * (size_t)(tw_floats<P>() + kAnaWaves * P * kXStride + 4);
 }
 
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// ---------------------------------------------------------------------------------------------
+// Frame queue of a workgroup.  A SIMD serves its resident waves by AGE (MI355X_MICROARCH.md, "Two waves per SIMD"): with
+// a static frame list per wave (grid-stride) the first-dispatched wave of every SIMD ran 14 us per frame, the last one 21
+// (tools/endtime_probe.py), the old waves finished a third earlier and the SIMDs idled through the tail.  The frame-per-
+// wave kernels therefore give every workgroup a contiguous range of the batch's frames and let its waves PULL the next
+// frame from a counter in LDS (one ds_add_rtn_u32 by lane 0 per frame): fast waves simply take more frames, all waves
+// of a workgroup finish together.  Frames are independent, so the order changes nothing in the output.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ long long queue_pull(unsigned* ctr, long long begin) {
+    unsigned v = 0u;
+    if ((threadIdx.x & 63) == 0) v = atomicAdd(ctr, 1u);
+    return begin + (long long)(unsigned)__builtin_amdgcn_readfirstlane((int)v);
+}
+__device__ __forceinline__ void block_frame_range(long long nframes, long long& fb, long long& fe) {
+    fb = (long long)blockIdx.x * nframes / (long long)gridDim.x;
+    fe = (long long)(blockIdx.x + 1) * nframes / (long long)gridDim.x;
+}
 
 // ---------------------------------------------------------------------------------------------
 // analysis

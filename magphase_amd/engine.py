@@ -347,6 +347,20 @@ class Engine:
         with torch.cuda.device(self.device):
             return int(self.lib.mpx_synth_ola_slots())
 
+    def synth_ola_slot_weights(self, comp=False):
+        """Relative speeds of the slots of the lossless (comp=True: the compressed) synthesis kernel
+        (mpx_synth_ola_slot_weights / mpx_synth_comp_slot_weights), cached; MAGPHASE_OLA_WEIGHTS=0 -> None (equal shares)."""
+        if os.environ.get("MAGPHASE_OLA_WEIGHTS", "1") == "0":
+            return None
+        key = "comp_w" if comp else "ola_w"
+        if key not in self._tables:
+            n = self.synth_comp_slots() if comp else self.synth_ola_slots()
+            w = np.zeros(n, dtype=np.float32)
+            fn = self.lib.mpx_synth_comp_slot_weights if comp else self.lib.mpx_synth_ola_slot_weights
+            _lib.check(fn(w.ctypes.data, n), "mpx_synth_*_slot_weights")
+            self._tables[key] = w
+        return self._tables[key]
+
     def post_filter(self, mag_mel_log, fs, **kw):
         """Device MagPhase post-filter (mpx_post_filter) of a float32 [F x D] tensor; kw as magphase.post_filter."""
         torch = _torch()
@@ -534,8 +548,9 @@ class Engine:
         return pcm_out
 
 
-def _plan_ola_runs(plan, pm_rel_list, starts, out_lens, out_off_host, fft_len, n_slots, frames_per_run, up):
-    """Shared by the two synthesis plans: runs + slot work lists (hostmath.ola_runs / balance_chunks) -> upload list."""
+def _plan_ola_runs(plan, pm_rel_list, starts, out_lens, out_off_host, fft_len, n_slots, frames_per_run, up, weights=None):
+    """Shared by the two synthesis plans: runs + slot work lists (hostmath.ola_runs / balance_chunks) -> upload list.
+    weights: the slots' relative speeds (Engine.synth_ola_slot_weights) or None for equal shares."""
     fpr = frames_per_run or int(os.environ.get("MAGPHASE_OLA_FRAMES_PER_RUN", 0)) or None
     try:
         if fpr:
@@ -543,10 +558,11 @@ def _plan_ola_runs(plan, pm_rel_list, starts, out_lens, out_off_host, fft_len, n
         sizes = [int(np.size(r)) for r in pm_rel_list]
         rel_cat = np.concatenate([np.asarray(r, dtype=np.int64) for r in pm_rel_list]) if pm_rel_list else np.zeros(0, np.int64)
         runs, slot_off, slot_runs = hostplan.ola_runs(rel_cat, np.concatenate(([0], np.cumsum(sizes))), starts, out_lens,
-                                                      np.asarray(out_off_host)[:len(sizes)], fft_len, n_slots)
+                                                      np.asarray(out_off_host)[:len(sizes)], fft_len, n_slots,
+                                                      weights=weights)
     except hostplan.PlanFallback:
         runs, slot_off, slot_runs = hm.ola_runs(pm_rel_list, starts, out_lens, out_off_host, fft_len, n_slots,
-                                                frames_per_run=fpr)
+                                                frames_per_run=fpr, weights=None if fpr else weights)
     plan.n_runs = int(runs.size)
     plan.runs_host = runs
     plan.strip_floats = plan.n_runs * (int(fft_len) + 64)
@@ -702,7 +718,8 @@ class LosslessSynthesisPlan:
         _up.append(("out_start", np.asarray(starts), np.int32))
         _up.append(("out_off", self.out_off_host, np.int64))
         n_slots = e.synth_ola_slots() if hasattr(e, "synth_ola_slots") else 1024
-        _plan_ola_runs(self, pm_rel, starts, lens, self.out_off_host, fft_len, n_slots, frames_per_run, _up)
+        _plan_ola_runs(self, pm_rel, starts, lens, self.out_off_host, fft_len, n_slots, frames_per_run, _up,
+                       weights=e.synth_ola_slot_weights() if hasattr(e, "synth_ola_slot_weights") else None)
         for _k, _t in e.to_device_packed(_up).items():
             setattr(self, _k, _t)
 
@@ -878,7 +895,8 @@ class CompressedSynthesisPlan:
             np.asarray(hm.synthesis_bin_curves(fs, N)[0], dtype=np.float32)))
         # OLA runs
         n_slots = e.synth_comp_slots() if hasattr(e, "synth_comp_slots") else 1024
-        _plan_ola_runs(self, pm_rel, starts, self.out_len, self.out_off_host, N, n_slots, frames_per_run, _up)
+        _plan_ola_runs(self, pm_rel, starts, self.out_len, self.out_off_host, N, n_slots, frames_per_run, _up,
+                       weights=e.synth_ola_slot_weights(comp=True) if hasattr(e, "synth_ola_slot_weights") else None)
         self._gains_dev = None
         for _k, _t in e.to_device_packed(_up).items():
             setattr(self, _k, _t)

@@ -156,12 +156,24 @@ def _enforce_span(rel, N, cuts):
     return np.asarray(cuts, dtype=np.int64)
 
 
-def ola_runs(pm_rel_list, starts, out_lens, out_offs, fft_len, n_slots, frames_per_run=None):
+def slot_cuts(total, n_slots, weights=None):
+    """Frame indices that deal `total` frames to the slots: equal shares, or shares in proportion to `weights` (the
+    slots' relative speeds, mpx_synth_ola_slot_weights).  int64[min(n_slots, max(total, 1)) + 1], cuts[0] == 0."""
+    ns = min(max(1, int(n_slots)), max(int(total), 1))
+    if weights is None:
+        return np.round(np.linspace(0, total, ns + 1)).astype(np.int64)
+    w = np.asarray(weights, dtype=np.float64)[:ns]
+    if w.size != ns or np.any(w <= 0):
+        raise ValueError("slot weights must be positive, one per slot")
+    return np.round(total * np.concatenate(([0.0], np.cumsum(w))) / w.sum()).astype(np.int64)
+
+
+def ola_runs(pm_rel_list, starts, out_lens, out_offs, fft_len, n_slots, frames_per_run=None, weights=None):
     """
     Plans the fused overlap-add (include/magphase_hip.h: mpx_synthesis_lossless_ola).  The batch's frames, in utterance
-    order, are dealt to the device's pair slots in equal shares: slot s gets the frames
-    [round(s F / n_slots), round((s+1) F / n_slots)) of the concatenated sequence (every slot the same number +- 1: the
-    kernel ends when the slowest slot does).  A share that crosses an utterance boundary is two (or more) RUNS -- the end
+    order, are dealt to the device's pair slots in consecutive shares: equal ones (slot s gets the frames
+    [round(s F / n_slots), round((s+1) F / n_slots)) of the concatenated sequence), or, with ``weights`` (one relative
+    speed per slot, mpx_synth_ola_slot_weights), shares in proportion to them -- the kernel ends when the slowest slot does.  A share that crosses an utterance boundary is two (or more) RUNS -- the end
     of one utterance and the beginning of the next; runs never cross utterances.  ``frames_per_run`` instead cuts every
     utterance on its own into runs of about that many frames and balances the slots longest-run-first (tests, tuning).
     Per run the positions are classified as head strip / final output / dropped (see mpx_ola_run) in the coordinates
@@ -183,7 +195,7 @@ def ola_runs(pm_rel_list, starts, out_lens, out_offs, fft_len, n_slots, frames_p
         target, gcuts = int(frames_per_run), None
     else:
         target = max(1, -(-total // n_slots))
-        gcuts = np.round(np.linspace(0, total, min(n_slots, max(total, 1)) + 1)).astype(np.int64)
+        gcuts = slot_cuts(total, n_slots, weights)
     recs = []
     f_base = 0
     for u, rel in enumerate(pm_rel_list):

@@ -104,7 +104,7 @@ def plan_lossless_synthesis(f0_list, fs_list, fft_len):
     return dict(v_pm=v_pm[:F], pm_rel=pm_rel[:F], frame_off=frame_off, out_start=out_start, out_len=out_len)
 
 
-def ola_runs(pm_rel_cat, frame_off, starts, out_lens, out_offs, fft_len, n_slots):
+def ola_runs(pm_rel_cat, frame_off, starts, out_lens, out_offs, fft_len, n_slots, weights=None):
     """hostmath.ola_runs (default equal-share mode) on the concatenated frame positions -> (runs, slot_off, slot_runs)."""
     if not enabled():
         raise PlanFallback()
@@ -113,7 +113,9 @@ def ola_runs(pm_rel_cat, frame_off, starts, out_lens, out_offs, fft_len, n_slots
     U = int(frame_off.size - 1)
     total = int(frame_off[-1])
     n_slots = max(1, int(n_slots))
-    gcuts = np.round(np.linspace(0, total, min(n_slots, max(total, 1)) + 1)).astype(np.int64)
+    from . import hostmath as hm
+
+    gcuts = np.ascontiguousarray(hm.slot_cuts(total, n_slots, weights))
     pm_rel = np.ascontiguousarray(pm_rel_cat, dtype=np.int64)
     starts, out_lens, out_offs = (np.ascontiguousarray(a, dtype=np.int64) for a in (starts, out_lens, out_offs))
     cap = U + int(gcuts.size) + 1

@@ -284,3 +284,35 @@ def test_native_lossless_synthesis_planner_equals_numpy_form():
             assert (int(r["out_start"][u]), int(r["out_len"][u])) == (start, out_len)
     with pytest.raises(hp.PlanFallback):
         hp.plan_lossless_synthesis([np.array([np.nan, 100.0])], [48000], 4096)
+
+
+def test_weighted_slot_shares_native_equals_numpy():
+    """hostmath.slot_cuts / ola_runs(weights=...): shares in proportion to the slots' relative speeds
+    (mpx_synth_ola_slot_weights: a SIMD serves its waves by age), native planner == numpy planner, every frame once."""
+    from magphase_amd import _lib, hostmath as hm, hostplan
+    lib = _lib.load()
+    n_slots = 24
+    w = np.zeros(n_slots, dtype=np.float32)
+    assert lib.mpx_synth_ola_slot_weights(w.ctypes.data, n_slots) == 0
+    assert np.all(w > 0) and w[0] >= w[-1] and len(set(w.tolist())) >= 2      # older wave groups are faster
+    cuts = hm.slot_cuts(10000, n_slots, w)
+    assert cuts[0] == 0 and cuts[-1] == 10000 and np.all(np.diff(cuts) > 0)
+    shares = np.diff(cuts) / 10000.0
+    assert np.max(np.abs(shares - w / w.sum())) < 1e-3
+    assert np.array_equal(hm.slot_cuts(7, 24, w), np.round(7 * np.concatenate(([0], np.cumsum(w[:7]))) / w[:7].sum()))
+    rng = np.random.RandomState(4)
+    rels, starts, lens = [], [], []
+    for u in range(5):
+        pm = 300 + np.cumsum(rng.randint(150, 500, 400 + 37 * u))
+        rel, start, out_len = hm.ola_plan(pm, 4096)
+        rels.append(rel), starts.append(start), lens.append(out_len)
+    out_off = np.concatenate(([0], np.cumsum(lens))).astype(np.int64)
+    r1, so1, sr1 = hm.ola_runs(rels, starts, lens, out_off, 4096, n_slots, weights=w)
+    sizes = [r.size for r in rels]
+    r2, so2, sr2 = hostplan.ola_runs(np.concatenate(rels), np.concatenate(([0], np.cumsum(sizes))), starts, lens, out_off[:5],
+                                     4096, n_slots, weights=w)
+    assert r1.tobytes() == r2.tobytes() and np.array_equal(so1, so2) and np.array_equal(sr1, sr2)
+    assert r1["frame_begin"][0] == 0 and r1["frame_end"][-1] == sum(sizes)
+    assert np.array_equal(r1["frame_begin"][1:], r1["frame_end"][:-1])
+    per_slot = np.array([sum(int(r1["frame_end"][k] - r1["frame_begin"][k]) for k in sr1[so1[s]:so1[s + 1]]) for s in range(n_slots)])
+    assert per_slot[0] > per_slot[-1] and per_slot.sum() == sum(sizes)

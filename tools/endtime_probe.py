@@ -21,7 +21,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 import ab_bench  # noqa: E402
 import bench  # noqa: E402
 
-name = sys.argv[1] if len(sys.argv) > 1 else "endp"
+name = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else "endp"
 em = ab_bench.load(name)
 eng = em.Engine()
 utts = bench.make_batch(0)
@@ -29,9 +29,12 @@ aplan = em.LosslessAnalysisPlan(eng, utts)
 splan = em.LosslessSynthesisPlan(eng, aplan.v_f0, aplan.fs, aplan.fft_len)
 feats = aplan.run()
 strips, pcm = eng.empty((splan.strip_floats,)), eng.empty((splan.total_out,))
+repeat = "--repeat" in sys.argv     # probe a synthesis launch that follows another synthesis (no freshly written features)
 for rep in range(4):
     aplan.run(out=feats)
     splan.run(feats[0], feats[1], feats[2], strips=strips, out=pcm)
+    if repeat:
+        splan.run(feats[0], feats[1], feats[2], strips=strips, out=pcm)
 torch.cuda.synchronize()
 waves_per_block = 2 * splan.n_slots // 256 if splan.n_slots % 256 == 0 else 12
 n = 256 * waves_per_block
@@ -51,3 +54,14 @@ blk = np.arange(n)[ok] // waves_per_block
 for x in range(8):
     m = (blk % 8) == x
     print("  XCD %d: end median %.1f  max %.1f   us per frame (median) %.2f" % (x, np.median(e[m]), e[m].max(), np.median((e[m] - s[m]) / fr[ok][m])))
+
+# by position in the batch: block b works on the frames [b, b + 1) * F / 256 (slots are dealt in frame order)
+nb = 16
+print("end time (median us) and us per frame by sixteenth of the batch (first frames ... last frames):")
+print("  " + " ".join("%6.1f" % np.median(e[(blk * nb) // 256 == i]) for i in range(nb)))
+print("  " + " ".join("%6.2f" % np.median(((e - s) / fr[ok])[(blk * nb) // 256 == i]) for i in range(nb)))
+widx = np.arange(n)[ok] % waves_per_block
+print("end time (median / max us) and frames by wave index within the workgroup:")
+for w in range(waves_per_block):
+    m = widx == w
+    print("  wave %2d: end %6.1f / %6.1f   us per frame %.2f   frames %.1f" % (w, np.median(e[m]), e[m].max(), np.median(((e - s) / fr[ok])[m]), fr[ok][m].mean()))
