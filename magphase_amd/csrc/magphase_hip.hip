@@ -335,7 +335,7 @@ static_assert(kPairWaves % kGroup == 0, "waves per workgroup must be a multiple 
 #ifdef MPX_PROBE_ENDTIME
 // Probe build (tools/endtime_probe.py): every wave of k_synth_ola_pair stores the constant-rate clock (100 MHz) when it
 // enters and when it leaves its frame loop, and its frame count -- the spread of the end times is the launch tail.
-__device__ unsigned long long g_endprobe[3 * 8192];
+__device__ unsigned long long g_endprobe[4 * 8192];   // per wave: start, end (100 MHz clock), frames, shader cycles
 #endif
 
 template <int P>
@@ -389,7 +389,8 @@ __global__ __launch_bounds__(kPairWaves * 64) void k_synth_ola_pair(const float*
     if constexpr (kCompact) {   // even registers' twiddles only: row l = (P/2 complex + 4 pad floats) out of the full table's row
         for (int i = threadIdx.x; i < tw_half_floats<P>(); i += kPairWaves * 64) {
             const int l = i / tw_half_stride<P>(), c = i % tw_half_stride<P>();
-            tw[i] = (c < P) ? tw_g[l * tw_stride<P>() + 4 * (c >> 1) + (c & 1)] : 0.0f;
+            // natural register order for the DIT first pass: entry e = W_M^{l e}, which the full table keeps at register brev(e)
+            tw[i] = (c < P) ? tw_g[l * tw_stride<P>() + 2 * brev(c >> 1, ilog2(P)) + (c & 1)] : 0.0f;
         }
     } else {
         for (int i = threadIdx.x; i < tw_floats<P>(); i += kPairWaves * 64) tw[i] = tw_g[i];
@@ -441,6 +442,7 @@ __global__ __launch_bounds__(kPairWaves * 64) void k_synth_ola_pair(const float*
 
 #ifdef MPX_PROBE_ENDTIME
     const unsigned long long probe_t0 = wall_clock64();
+    const unsigned long long probe_c0 = clock64();
     int probe_frames = 0;
 #endif
     // Software pipeline over the wave's frames: the features of the wave's NEXT frame are loaded while this frame waits
@@ -477,8 +479,21 @@ __global__ __launch_bounds__(kPairWaves * 64) void k_synth_ola_pair(const float*
         float xr[P], xi[P];
         feat_merge_paired<P>(ff, xr, xi, lane, wl_c, wl_s);
         if constexpr (kCompact) {
-            wave_fft_front_compact<P, +1>(xr, xi, tw, xbuf, lane, lc, ls);
-            fft_inreg<P, +1>(xr, xi);
+            // DIT form (fused multiply-add butterflies): its input wants register brev(j) <- bin lane + 64 j, its output is
+            // register i <-> samples 2 n, 2 n + 1 with n = lane + 64 i: static renamings on both sides
+            constexpr int LB = ilog2(P);
+            float yr[P], yi[P];
+#pragma unroll
+            for (int j = 0; j < P; ++j) {
+                yr[brev(j, LB)] = xr[j];
+                yi[brev(j, LB)] = xi[j];
+            }
+            wave_fft_dit_compact<P, +1>(yr, yi, tw, xbuf, lane, lc, ls);
+#pragma unroll
+            for (int j = 0; j < P; ++j) {
+                xr[j] = yr[j];
+                xi[j] = yi[j];
+            }
         } else {
             wave_fft<P, +1>(xr, xi, tw, xbuf, lane);
         }
@@ -506,13 +521,13 @@ __global__ __launch_bounds__(kPairWaves * 64) void k_synth_ola_pair(const float*
         if (flushed < target) flush_ring<R>(ring, strip, pcm0, rd.head_end, rd.out_lo, rd.out_hi, flushed, target, lane);
         wave_sync();
         const RingAddr ra = ring_addr<P>(ring_byte, x, lane);
-        ring_add_plane<P, 0, kCompact ? MPX_CH : P>(smem, ra, xr, lane, [](float o, float v, int) { return o + v; },
+        ring_add_plane<P, 0, kCompact ? MPX_CH : P, kCompact>(smem, ra, xr, lane, [](float o, float v, int) { return o + v; },
                                                 [](int) { return true; });
         if constexpr (JB > JA) {   // the first plane's registers are free: the second part of the prefetch
             asm volatile("" ::: "memory");
             feat_load_paired_part<P, JA, JB, false>(ff, nm, nr, ni, lane);
         }
-        ring_add_plane<P, 1, kCompact ? MPX_CH : P>(smem, ra, xi, lane, [](float o, float v, int) { return o + v; },
+        ring_add_plane<P, 1, kCompact ? MPX_CH : P, kCompact>(smem, ra, xi, lane, [](float o, float v, int) { return o + v; },
                                                 [](int) { return true; });
         wave_sync();
         if (fi == cur.fe - 1) {   // last frame of the run: stream out the rest, leave the ring cleared
@@ -533,9 +548,10 @@ __global__ __launch_bounds__(kPairWaves * 64) void k_synth_ola_pair(const float*
 #ifdef MPX_PROBE_ENDTIME
     if (lane_id == 0) {
         const int w = (blockIdx.x * kPairWaves + wave) % 8192;
-        g_endprobe[3 * w + 0] = probe_t0;
-        g_endprobe[3 * w + 1] = wall_clock64();
-        g_endprobe[3 * w + 2] = (unsigned long long)probe_frames;
+        g_endprobe[4 * w + 0] = probe_t0;
+        g_endprobe[4 * w + 1] = wall_clock64();
+        g_endprobe[4 * w + 2] = (unsigned long long)probe_frames;
+        g_endprobe[4 * w + 3] = clock64() - probe_c0;
     }
 #endif
 }

@@ -519,6 +519,7 @@ __device__ __forceinline__ void ring_add(float* smem_base, unsigned ring_byte, i
 // PL 1: samples 2n + 1 (the imaginary parts).
 struct RingAddr {
     unsigned a0, a1, b0, b1, m0, m1;
+    int cu0, cu1;   // the wave-uniform parts of the two planes' start indices (without the lane's kappa)
 };
 
 template <int P>
@@ -537,16 +538,73 @@ __device__ __forceinline__ RingAddr ring_addr(unsigned ring_byte, int x, int lan
     const int w1 = (RH - c1 + 63) >> 6;
     r.m0 = (w0 >= 32) ? 0u : (~0u << w0);
     r.m1 = (w1 >= 32) ? 0u : (~0u << w1);
+    r.cu0 = (x >> 1) % RH;
+    r.cu1 = ((x + 1) >> 1) % RH;
     return r;
 }
 
-template <int P, int PL, int CH, typename CFn, typename LFn>
+// LDS pointer from a byte address (address space 3: no generic-pointer arithmetic, the immediate offset folds)
+typedef __attribute__((address_space(3))) float lds_float;
+__device__ __forceinline__ lds_float* lds_ptr(unsigned byte_addr) {
+    return reinterpret_cast<lds_float*>(static_cast<uintptr_t>(byte_addr));
+}
+
+// NAT: register i holds row q = i (the DIT transform's natural output order) instead of q = brev(i).
+template <int P, int PL, int CH, bool NAT = false, typename CFn, typename LFn>
 __device__ __forceinline__ void ring_add_plane(float* smem_base, const RingAddr& ra, const float (&xv)[P], int lane,
                                                CFn combine, LFn live) {
     constexpr int LB = ilog2(P);
     static_assert(P % CH == 0, "chunk size must divide P");
     const int kap = kappa<P>(lane);
     const unsigned a = PL ? ra.a1 : ra.a0, b = PL ? ra.b1 : ra.b0, m = PL ? ra.m1 : ra.m0;
+#ifndef MPX_RING_ADDR_MODE
+#define MPX_RING_ADDR_MODE 2
+#endif
+    if constexpr (P == 32 && MPX_RING_ADDR_MODE != 0) {
+        // kappa(lane) == lane: row q wraps for the lanes >= thr_q = RH - c - 64 q, a WAVE-UNIFORM threshold.  The lane
+        // mask of every row is therefore formed on the scalar unit and the address is ONE v_cndmask per element (unwrapped
+        // / wrapped base + the row's immediate offset).  The per-lane bit-mask form below compiled to v_and + v_cmp +
+        // v_cndmask + v_add per element: 256 of the kernel's 2 350 VALU instructions per frame were ring addresses, and
+        // the kernel is bound by VALU issue (tools/endtime_probe.py: 2.8 cycles per instruction and SIMD at 3 waves).
+        constexpr int RH = ring_len<P>() / 2;
+        const int cu = PL ? ra.cu1 : ra.cu0;
+#ifndef MPX_RING_ADDR_MODE
+#define MPX_RING_ADDR_MODE 2
+#endif
+#if MPX_RING_ADDR_MODE == 1   // lane mask per row on the scalar unit (8 SALU) + one v_cndmask
+        auto addr = [&](int q) -> unsigned {
+            const int thr = RH - cu - 64 * q;
+            const unsigned long long mask = (thr <= 0) ? ~0ull : ((thr >= 64) ? 0ull : (~0ull << thr));
+            unsigned r;
+            asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(mask));
+            return r + 256u * (unsigned)q;
+        };
+#else                         // one v_cmp against a literal + one v_cndmask: lane + 64 q >= RH - c  <=>  d >= -64 q
+        const int d = kap - (RH - cu);
+        auto addr = [&](int q) -> unsigned { return ((d >= -64 * q) ? b : a) + 256u * (unsigned)q; };
+#endif
+#pragma unroll
+        for (int c = 0; c < P; c += CH) {
+            float o[CH];
+            unsigned ad[CH];
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                const int q = NAT ? (c + i) : brev(c + i, LB);
+                o[i] = 0.0f;
+                ad[i] = addr(q);
+                if (live(q)) o[i] = *lds_ptr(ad[i]);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                const int q = NAT ? (c + i) : brev(c + i, LB);
+                if (live(q)) *lds_ptr(ad[i]) = combine(o[i], xv[c + i], 2 * (kap + 64 * q) + PL);
+            }
+        }
+        (void)smem_base;
+        (void)m;
+        return;
+    }
     char* base = reinterpret_cast<char*>(smem_base);
     auto at = [&](int q) -> float* {
         const unsigned sel = (unsigned)__builtin_amdgcn_sbfe((int)m, q, 1);   // 0 or ~0
@@ -557,14 +615,14 @@ __device__ __forceinline__ void ring_add_plane(float* smem_base, const RingAddr&
         float o[CH];
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
-            const int q = brev(c + i, LB);
+            const int q = NAT ? (c + i) : brev(c + i, LB);
             o[i] = 0.0f;
             if (live(q)) o[i] = *at(q);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
-            const int q = brev(c + i, LB);
+            const int q = NAT ? (c + i) : brev(c + i, LB);
             if (live(q)) *at(q) = combine(o[i], xv[c + i], 2 * (kap + 64 * q) + PL);
         }
     }

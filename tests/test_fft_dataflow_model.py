@@ -244,3 +244,54 @@ def test_mel_warp_lds_swizzle_is_conflict_free_and_round2_layout_was_not():
     # the swizzle is a bijection on a row's chunks, and what is written is what is read
     for r in range(16):
         assert sorted((c ^ _warp_swz(r)) for c in range(16)) == list(range(16))
+
+
+def fft_inreg_dit(x, sign):
+    """wave_fft.hpp fft_inreg_dit: x[lane, r] holds element brev(r); radix-2 DIT, out0 = a + w b, out1 = 2 a - out0;
+    output register i holds index i."""
+    P = x.shape[1]
+    x = x.copy()
+    s = 1
+    while s < P:
+        for g in range(0, P, 2 * s):
+            for k in range(s):
+                i0, i1 = g + k, g + k + s
+                w = np.exp(sign * 2j * np.pi * k / (2 * s))
+                o0 = x[:, i0] + w * x[:, i1]
+                x[:, i1] = 2 * x[:, i0] - o0
+                x[:, i0] = o0
+        s *= 2
+    return x
+
+
+@pytest.mark.parametrize("sign", [-1, 1])
+def test_dit_compact_wave_fft_layout(sign):
+    """wave_fft_dit_compact (P = 32): input register brev(j) <- z[l + 64 j], natural-order first-pass twiddles, natural-
+    order transposes, cross-lane stage, DIT second pass on bit-reversed registers -> register i holds Z[lane + 64 i]."""
+    P, LB, M = 32, 5, 2048
+    rng = np.random.RandomState(11 + sign)
+    z = rng.randn(M) + 1j * rng.randn(M)
+    x = z.reshape(P, 64).T.copy()                          # x[l, j] = z[l + 64 j]
+    xin = np.zeros_like(x)
+    for j in range(P):
+        xin[:, brev(j, LB)] = x[:, j]
+    y = fft_inreg_dit(xin, sign)                           # register i: k1 = i
+    lanes = np.arange(64)
+    for i in range(P):
+        y[:, i] *= np.exp(sign * 2j * np.pi * lanes * i / M)
+    v = np.zeros((64, P), dtype=complex)
+    for lam in range(64):                                  # transposes: register l' <- (row k1 = lam % 32, column 32 (lam // 32) + l')
+        for lp in range(P):
+            v[lam, lp] = y[(lam // P) * P + lp, lam % P]
+    out = np.zeros_like(v)
+    for lam in range(64):                                  # cross-lane stage, stride 32
+        own, oth = v[lam], v[lam ^ 32]
+        out[lam] = (oth - own) * np.exp(sign * 2j * np.pi * np.arange(P) / 64) if lam & 32 else own + oth
+    t = np.zeros_like(out)
+    for r in range(P):
+        t[:, brev(r, LB)] = out[:, r]
+    res = fft_inreg_dit(t, sign)
+    Z = np.fft.fft(z) if sign < 0 else np.fft.ifft(z) * M
+    for lam in range(64):
+        for i in range(P):
+            assert abs(res[lam, i] - Z[lam + 64 * i]) < 1e-9

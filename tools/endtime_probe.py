@@ -36,11 +36,11 @@ for rep in range(4):
     if repeat:
         splan.run(feats[0], feats[1], feats[2], strips=strips, out=pcm)
 torch.cuda.synchronize()
-waves_per_block = 2 * splan.n_slots // 256 if splan.n_slots % 256 == 0 else 12
+waves_per_block = int(os.environ.get("WPB", 12))
 n = 256 * waves_per_block
-buf = (ctypes.c_ulonglong * (3 * n))()
-assert eng.lib.mpx_probe_endtimes(buf, 3 * n) == 0
-a = np.frombuffer(buf, dtype=np.uint64).reshape(n, 3).astype(np.float64)
+buf = (ctypes.c_ulonglong * (4 * n))()
+assert eng.lib.mpx_probe_endtimes(buf, 4 * n) == 0
+a = np.frombuffer(buf, dtype=np.uint64).reshape(n, 4).astype(np.float64)
 t0, t1, fr = a[:, 0], a[:, 1], a[:, 2]
 ok = fr > 0
 base = t0[ok].min()
@@ -49,6 +49,8 @@ print("waves %d (with frames: %d), frames per wave %.1f .. %.1f" % (n, ok.sum(),
 print("start  us: min %.1f  median %.1f  max %.1f" % (s.min(), np.median(s), s.max()))
 print("end    us: min %.1f  p10 %.1f  median %.1f  p90 %.1f  p99 %.1f  max %.1f" % (
     e.min(), np.percentile(e, 10), np.median(e), np.percentile(e, 90), np.percentile(e, 99), e.max()))
+cyc = a[:, 3][ok]
+print("shader clock during the launch: median %.0f MHz (s_memtime ticks / wall time per wave); cycles per frame and wave: median %.0f" % (np.median(cyc / (e - s)), np.median(cyc / fr[ok])))
 print("busy   us: mean %.1f  (launch = max end %.1f: %.0f %% of the waves' mean)" % ((e - s).mean(), e.max(), 100 * e.max() / (e - s).mean()))
 blk = np.arange(n)[ok] // waves_per_block
 for x in range(8):
