@@ -509,6 +509,11 @@ int64_t mpx_host_ola_runs(int32_t n_utts, const int64_t* pm_rel, const int64_t* 
  * reference's arrays are float64, magphase.py:457-476; numpy's astype is one thread at ~1.5 GB/s). */
 int32_t mpx_host_widen_f32(const float* src, double* dst, int64_t n, int32_t n_threads);
 
+/* n byte ranges src[i][0 .. nbytes[i]) copied to dst + dst_off[i] on n_threads threads (HOST pointers): the samples of a
+ * batch's utterances into the page-locked staging buffer of the analysis plan.  Returns 0, or MPX_ERR_ARG. */
+int32_t mpx_host_copy_many(int32_t n, const void* const* src, const int64_t* nbytes, const int64_t* dst_off, void* dst,
+                           int32_t n_threads);
+
 /* dst[i] = (float)src[i] (round to nearest even, numpy's astype), i < n, on a few threads: the array API's float64 inputs
  * on their way to the device. */
 int32_t mpx_host_narrow_f64(const double* src, float* dst, int64_t n, int32_t n_threads);

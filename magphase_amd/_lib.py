@@ -46,6 +46,7 @@ SYMBOLS = (
     "mpx_host_ola_runs",
     "mpx_host_widen_f32",
     "mpx_host_narrow_f64",
+    "mpx_host_copy_many",
     "mpx_host_file_sizes",
     "mpx_host_read_est_batch",
     "mpx_host_write_files",
@@ -166,6 +167,8 @@ def _load_locked():
     lib.mpx_host_ola_runs.argtypes = [i32, vp, vp, vp, vp, vp, i32, vp, i64, vp, i64]
     lib.mpx_host_narrow_f64.restype = i32
     lib.mpx_host_narrow_f64.argtypes = [vp, vp, i64, i32]
+    lib.mpx_host_copy_many.restype = i32
+    lib.mpx_host_copy_many.argtypes = [i32, vp, vp, vp, vp, i32]
     lib.mpx_host_widen_f32.restype = i32
     lib.mpx_host_widen_f32.argtypes = [vp, vp, i64, i32]
     lib.mpx_host_file_sizes.restype = i32

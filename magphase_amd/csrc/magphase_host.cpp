@@ -8,6 +8,7 @@
 //   mpx_host_write_files      lu.write_binfile / ndarray.tofile, la.write_audio_file's file write
 //                                                                                      (libutils.py:193-199, libaudio.py:352-365)
 //   mpx_host_read_files       lu.read_binfile's np.fromfile                            (libutils.py:201-211)
+#include <algorithm>
 #include <fcntl.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -154,6 +155,27 @@ int32_t mpx_host_narrow_f64(const double* src, float* dst, int64_t n, int32_t n_
     parallel_for(nb, n_threads, [&](int b) {
         const int64_t a = (int64_t)b * kBlock, e = (a + kBlock < n) ? a + kBlock : n;
         for (int64_t i = a; i < e; ++i) dst[i] = (float)src[i];   // round to nearest even, as numpy's astype
+    });
+    return MPX_OK;
+}
+
+// n byte ranges copied into one destination buffer at the given offsets, on a few threads: the PCM of a batch's utterances
+// into the page-locked staging buffer (one numpy slice assignment per utterance is one thread at ~12 GB/s: 1.2 ms of the 5 ms
+// a 32-utterance extraction batch spends on the host).
+int32_t mpx_host_copy_many(int32_t n, const void* const* src, const int64_t* nbytes, const int64_t* dst_off, void* dst,
+                           int32_t n_threads) {
+    if (n < 0 || (n > 0 && (!src || !nbytes || !dst_off || !dst))) return MPX_ERR_ARG;
+    // tasks of at most 256 KB so that a few long utterances still spread over the threads
+    const int64_t kBlock = 256 << 10;
+    std::vector<int64_t> first(n + 1, 0);
+    for (int i = 0; i < n; ++i) {
+        if (nbytes[i] < 0 || (nbytes[i] > 0 && !src[i])) return MPX_ERR_ARG;
+        first[i + 1] = first[i] + (nbytes[i] + kBlock - 1) / kBlock;
+    }
+    parallel_for((int)first[n], n_threads, [&](int t) {
+        int i = (int)(std::upper_bound(first.begin(), first.end(), (int64_t)t) - first.begin()) - 1;
+        const int64_t a = ((int64_t)t - first[i]) * kBlock, e = (a + kBlock < nbytes[i]) ? a + kBlock : nbytes[i];
+        memcpy((char*)dst + dst_off[i] + a, (const char*)src[i] + a, (size_t)(e - a));
     });
     return MPX_OK;
 }

@@ -613,10 +613,25 @@ class LosslessAnalysisPlan:
         else:
             buf = engine.host_staging(total) if staged else np.empty(total, dtype=np.float32)
         off = 0
+        if all_i16 and len(utts) > 1:   # 16-bit PCM of the whole batch into the staging buffer on a few native threads
+            import ctypes
+            arrs = [np.ascontiguousarray(u[0]) for u in utts]
+            k = len(arrs)
+            src = (ctypes.c_void_p * k)(*[a.ctypes.data for a in arrs])
+            nb = np.asarray([a.nbytes for a in arrs], dtype=np.int64)
+            doff = np.concatenate(([0], np.cumsum(nb)[:-1])).astype(np.int64)
+            n_thr = max(1, int(os.environ.get("MAGPHASE_IO_NATIVE_THREADS", "8")))
+            if engine.lib.mpx_host_copy_many(k, src, nb.ctypes.data, doff.ctypes.data, buf.ctypes.data, n_thr) != 0:
+                raise _lib.MagphaseHipError("mpx_host_copy_many failed")
+            copied = True
+        else:
+            copied = False
         for (v_sig, fs, v_pm_sec, v_voi) in utts:
             v_sig = np.asarray(v_sig)
             n = v_sig.shape[0]
-            if all_i16:
+            if copied:
+                pass
+            elif all_i16:
                 buf[off:off + n] = v_sig
             elif v_sig.dtype == np.int16:
                 np.multiply(v_sig, np.float32(1.0 / 32768.0), out=buf[off:off + n])   # exact: == astype(f32) / 32768

@@ -471,11 +471,13 @@ def analysis_compressed_batch(utts, fft_len=None, mag_dim=60, phase_dim=10, b_co
     # as_float32: the device's float32 values as they are (what the feature files store), no widening to float64
     h_mag, h_real, h_imag = ((engine.to_host_f32 if as_float32 else engine.to_host_f64)(t_) for t_ in plan.run())
     res = []
+    # signal.medfilt of every utterance's f0 in one pass (hostmath.medfilt3_batch: bit-identical; 30 us per scipy call)
+    f0_med = hm.medfilt3_batch(plan.f0_out) if len(utts) > 1 else [signal.medfilt(plan.f0_out[0])]
     for u in range(len(utts)):
         a, b = int(plan.out_off[u]), int(plan.out_off[u + 1])
         v_f0 = plan.f0_out[u]
         v_voi = (v_f0 > 0).astype('float')
-        v_lf0 = la.f0_to_lf0(v_voi * signal.medfilt(v_f0))                 # magphase.py:2499-2501
+        v_lf0 = la.f0_to_lf0(v_voi * f0_med[u])                            # magphase.py:2499-2501
         res.append((h_mag[a:b], h_real[a:b], h_imag[a:b], v_lf0, plan.lossless.v_shift[u].astype(int), plan.fs,
                     plan.fft_len))
     return res

@@ -147,3 +147,32 @@ def test_mkdir_is_race_free_between_ranks(tmp_path):
     f.write_text("x")
     with pytest.raises(FileExistsError):
         lu.mkdir(str(f))
+
+
+def test_medfilt3_batch_equals_scipy_bit_for_bit():
+    import warnings
+    from scipy import signal
+    from magphase_amd import hostmath as hm
+    rng = np.random.RandomState(0)
+    vs = [rng.uniform(0, 300, n) * (rng.rand(n) > 0.3) for n in (1, 2, 3, 7, 500, 5)]
+    vs += [np.array([np.inf, 0.0, 100.0]), np.array([5.0, np.inf, np.inf, 3.0])]      # f0 = inf where the shift is 0 (Q2)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for v, o in zip(vs, hm.medfilt3_batch(vs)):
+            assert np.array_equal(signal.medfilt(v), o)
+    assert hm.medfilt3_batch([]) == []
+
+
+def test_native_copy_many():
+    import ctypes
+    from magphase_amd import _lib
+    lib = _lib.load()
+    rng = np.random.RandomState(1)
+    arrs = [rng.randint(-30000, 30000, n).astype(np.int16) for n in (1, 0, 100000, 480001, 7)]
+    nb = np.asarray([a.nbytes for a in arrs], dtype=np.int64)
+    off = np.concatenate(([0], np.cumsum(nb)[:-1])).astype(np.int64)
+    dst = np.zeros(int(nb.sum()) // 2, dtype=np.int16)
+    src = (ctypes.c_void_p * len(arrs))(*[a.ctypes.data for a in arrs])
+    assert lib.mpx_host_copy_many(len(arrs), src, nb.ctypes.data, off.ctypes.data, dst.ctypes.data, 8) == 0
+    assert np.array_equal(dst, np.concatenate(arrs))
+    assert lib.mpx_host_copy_many(-1, src, nb.ctypes.data, off.ctypes.data, dst.ctypes.data, 8) != 0
