@@ -104,7 +104,7 @@ def _cpu_warm(_):
     return os.getpid()
 
 
-def cpu_baseline(utts, fn, what, unit, budget_s=12.0):
+def cpu_baseline(utts, fn, what, unit, budget_s=12.0, full_pool=True):
     """
     Same parallel model as the reference (libutils.py:32-63: one utterance per multiprocessing.Pool worker).  A pool
     is created and warmed (imports, one BLAS thread per worker) BEFORE its clock starts and every worker gets at least 4
@@ -130,7 +130,9 @@ def cpu_baseline(utts, fn, what, unit, budget_s=12.0):
     out = {"value": round(rate1, 1), "unit": unit, "cores": 1, "kind": "port", "host_cores": ncores,
            "sample": "%s, numpy fp64 oracle, one process: %d utterances (%d %s) in %.1f s" % (what, n1, f1, what_unit, dt1),
            "value_1core": round(rate1, 1), "pools": []}
-    sizes = sorted({max(1, min(ncores, 64)), ncores})
+    # (full_pool=False: only the min(cores, 64) pool -- a Pool(256) of oversubscribed numpy workers needs a minute for one
+    # configs[2] task each)
+    sizes = sorted({max(1, min(ncores, 64)), ncores}) if full_pool else [max(1, min(ncores, 64))]
     for workers in sizes:
         if workers == sizes[0]:
             tasks = int(max(4 * workers, min(8 * workers, workers * (budget_s / 2) / t_task)))
@@ -753,7 +755,7 @@ def main():
                 if not args.no_cpu_baseline:
                     c2["cpu_baseline"] = cpu_baseline(
                         utts, _cpu_lowdim, "configs[2] (analysis_compressed at constant rate -> post_filter -> "
-                        "synthesis_from_compressed) of 5 s utterances", "5ms-frames/s", budget_s=15.0)
+                        "synthesis_from_compressed) of 5 s utterances", "5ms-frames/s", budget_s=15.0, full_pool=False)
                 out["configs2"] = c2
             except Exception as e:
                 out["configs2"] = {"error": "%s: %s" % (type(e).__name__, e)}

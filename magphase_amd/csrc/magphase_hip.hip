@@ -497,7 +497,9 @@ __global__ __launch_bounds__(kPairWaves * 64) void k_synth_ola_pair(const float*
         } else {
             wave_fft<P, +1>(xr, xi, tw, xbuf, lane);
         }
-        const long long fnx = nxt.valid ? nxt.fi : cur.fi;   // (an exhausted cursor re-reads this frame: no branch around loads)
+        // (an exhausted cursor loads row 0 -- no branch around the loads; every finishing wave reads the same 24 KB, which
+        // stay in L2: re-reading its own last frame cost 75 MB of HBM fetches per launch, 5 % of the kernel's traffic)
+        const long long fnx = nxt.valid ? nxt.fi : 0;
         const float* nm = mag + fnx * ld;
         const float* nr = real + fnx * ld;
         const float* ni = imag + fnx * ld;
