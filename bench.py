@@ -229,17 +229,30 @@ class _Marks:
         return [(n1, e0.elapsed_time(e1)) for (_n0, e0), (n1, e1) in zip(self.ev[:-1], self.ev[1:])]
 
 
-def measure_lowdim(eng, utts, steps, warmup, live=None, live_src=None):
+def measure_lowdim(eng, utts, steps, warmup, live=None, live_src=None, n_streams=1):
     import torch
 
     from magphase_amd import engine as em
 
     st = _lowdim_state(em, eng, utts)
     aplan, splan = st["aplan"], st["splan"]
+    # as in the headline: consecutive (independent) steps alternate between n_streams HIP streams, each with its own plans
+    # and buffers; the per-kernel events below are taken one step at a time on the current stream
+    states = [st] + [_lowdim_state(em, eng, utts) for _ in range(max(1, int(n_streams)) - 1)]
+    streams = [torch.cuda.Stream() for _ in states] if len(states) > 1 else [torch.cuda.current_stream()]
+    counter = [0]
 
     def step(mark=None):
-        aplan.run(feats=st["feats"], out=st["out"], mark=mark)
-        splan.run(out=st["pcm"], mark=mark)
+        if mark is not None or len(states) == 1:
+            aplan.run(feats=st["feats"], out=st["out"], mark=mark)
+            splan.run(out=st["pcm"], mark=mark)
+            return
+        k = counter[0] % len(states)
+        counter[0] += 1
+        sk = states[k]
+        with torch.cuda.stream(streams[k]):
+            sk["aplan"].run(feats=sk["feats"], out=sk["out"])
+            sk["splan"].run(out=sk["pcm"])
 
     # Timing, independent of the headline's --steps / --warmup (round 2's driver run timed 10 steps after 2 warm-ups,
     # right behind 15 s of GPU idle under the CPU baseline, and got 3.6 x the kernels' own sum): warm up until two
@@ -266,6 +279,15 @@ def measure_lowdim(eng, utts, steps, warmup, live=None, live_src=None):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     dt_events = e0.elapsed_time(e1) * 1e-3
+    dt_one = None
+    if len(states) > 1:     # for the record: the same number of steps one at a time
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(steps):
+            aplan.run(feats=st["feats"], out=st["out"])
+            splan.run(out=st["pcm"])
+        torch.cuda.synchronize()
+        dt_one = time.perf_counter() - t1
     acc, reps = {}, 20
     for _ in range(reps):
         m = _Marks(torch)
@@ -326,11 +348,15 @@ def measure_lowdim(eng, utts, steps, warmup, live=None, live_src=None):
         "workload": "configs[2]: the same 64 x 5 s @48 kHz; analysis_compressed(mag 60, phase 45, constant 5 ms rate) -> "
                     "post-filter -> synthesis_from_compressed(b_const_rate=True, per_phase_type='magphase')",
         "ms_per_step": round(ms_step, 4), "steps": steps, "warmup_steps_used": warm_used,
-        "ms_per_step_hip_events": round(dt_events / steps * 1e3, 4),
+        "ms_per_step_hip_events": (round(dt_events / steps * 1e3, 4) if len(states) == 1 else None),
+        "streams": len(states),
+        "ms_per_step_single_stream": (round(dt_one / steps * 1e3, 4) if dt_one else None),
         "kernel_sum_ms": round(sum(k["ms"] for k in kern), 4),
         "timing": "fixed %d steps after warming up until two consecutive steps agree to 3 %% (%d used); ms_per_step = host "
-                  "clock around the synchronised loop, ms_per_step_hip_events = one event pair around the same loop, "
-                  "kernel_sum_ms = sum of the per-kernel event durations of a separate 20-step loop" % (steps, warm_used),
+                  "clock around the synchronised loop (consecutive steps alternate between `streams` HIP streams with their "
+                  "own plans and buffers), ms_per_step_single_stream = the same steps one at a time, ms_per_step_hip_events = "
+                  "one event pair around the loop (single stream only), kernel_sum_ms = sum of the per-kernel event durations "
+                  "of a separate 20-step loop, one step at a time" % (steps, warm_used),
         "value": round(Fc / (ms_step * 1e-3), 1), "unit": "5ms-frames/s",
         "x_realtime": round(UTTS_PER_GPU * DUR_S / (ms_step * 1e-3), 1),
         "const_rate_frames": Fc, "variable_rate_frames_analysed": Fv, "variable_rate_frames_resynthesised": Fs,
@@ -474,7 +500,7 @@ def live_traffic(timeout_s=170):
                 return None, "time budget for the PMC passes used up"
             d = os.path.join(tmp, ctr)
             cmd = [rocprof, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "pmc", "--",
-                   sys.executable, os.path.join(ROOT, "bench.py"), "--pmc-child", "--steps", "3", "--warmup", "1"]
+                   sys.executable, os.path.join(ROOT, "bench.py"), "--pmc-child", "--steps", "3", "--warmup", "1", "--streams", "1"]
             r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=left)
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
@@ -547,6 +573,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--streams", type=int, default=2,
+                    help="HIP streams that consecutive (independent) steps alternate between; 1 = one step at a time")
+    ap.add_argument("--no-idle-probe", action="store_true",
+                    help="skip the from-idle repeat of the timed loop (profiling runs: keeps every launch in the steady state)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--quick", action="store_true", help="headline only: no configs2 / e2e / CPU baselines")
     ap.add_argument("--no-e2e", action="store_true", help="skip the array-API / file-interface block (profiling runs)")
@@ -626,27 +656,61 @@ def main():
     N = aplan.fft_len
     H = N // 2 + 1
     F = aplan.total_frames
-    feats = tuple(eng.empty_feats(F, H) for _ in range(3))
-    strips = eng.empty((max(splan.strip_floats, 1),))
-    pcm_out = eng.empty((splan.total_out,))
+    # Consecutive steps are independent (one batch in, one batch out), so they alternate between --streams HIP streams,
+    # each with its own feature matrices / strips / output: the next step's analysis fills the tail of this step's
+    # synthesis launch (a SIMD serves its waves by age: the last waves of a launch run alone).  Every step
+    # does all of its work; nothing is shared between steps but the read-only inputs.  --streams 1 = one step at a time.
+    n_streams = max(1, int(args.streams))
+    streams = [torch.cuda.Stream() for _ in range(n_streams)] if n_streams > 1 else [torch.cuda.current_stream()]
+    bufs = [(tuple(eng.empty_feats(F, H) for _ in range(3)), eng.empty((max(splan.strip_floats, 1),)),
+             eng.empty((splan.total_out,))) for _ in range(n_streams)]
+    feats, strips, pcm_out = bufs[0]
 
-    def step():
-        aplan.run(out=feats)
-        splan.run(feats[0], feats[1], feats[2], strips=strips, out=pcm_out)
+    def step(i=0, one_stream=False):
+        k = 0 if one_stream else i % n_streams
+        f_, s_, p_ = bufs[k]
+        with torch.cuda.stream(streams[0 if one_stream else k]):
+            aplan.run(out=f_)
+            splan.run(f_[0], f_[1], f_[2], strips=s_, out=p_)
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    dt = time.perf_counter() - t0
+    def timed(one_stream=False):
+        for i in range(args.warmup):
+            step(i, one_stream)
+        barrier()
+        t = time.perf_counter()
+        for i in range(args.steps):
+            step(i, one_stream)
+        barrier()
+        return time.perf_counter() - t
+
+    # The plans above were built on the host with the GPU idle, and a GPU coming out of idle goes through a power-management
+    # transient of about 30 ms of busy time (tools/step_curve_probe.py: the analysis launch runs 0.31 -> 0.41 -> 0.30 ms over
+    # the first ~40 steps, after ANY idle period, whatever ran before it).  A corpus job is never in that state, so the
+    # device is taken out of it before the W warm-up steps; `ms_per_step_from_idle` below is the same W + K steps started
+    # 0.5 s after the last launch, for the record.
+    PRECOND_STEPS = 0 if args.pmc_child else 64
+    for i in range(PRECOND_STEPS):
+        step(i)
+    dt = timed()
+    dt_one = dt_idle = None
+    if not args.pmc_child and not args.no_idle_probe:
+        time.sleep(0.5)
+        dt_idle = timed()
+        for i in range(PRECOND_STEPS):
+            step(i)
+        torch.cuda.synchronize()
+    if n_streams > 1 and not args.pmc_child:   # for the record: the same K steps one at a time (untimed for `value`)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            step(i, one_stream=True)
+        torch.cuda.synchronize()
+        dt_one = time.perf_counter() - t1
     if args.pmc_child:      # profiled by live_traffic(): a few configs[2] steps as well, then done (no JSON line)
         from magphase_amd import engine as em
 
@@ -742,6 +806,16 @@ def main():
                        "frames_per_gpu": F, "audio_s_per_gpu": UTTS_PER_GPU * DUR_S,
                        "x_realtime": round(UTTS_PER_GPU * DUR_S * world / (dt / args.steps), 1),
                        "parallelism": "utterance-sharded x%d, no collective" % world,
+                       "streams": n_streams,
+                       "ms_per_step_single_stream": (round(dt_one / args.steps * 1e3, 4) if dt_one else None),
+                       "ms_per_step_from_idle": (round(dt_idle / args.steps * 1e3, 4) if dt_idle else None),
+                       "power_state_note": "%d untimed steps take the device out of its post-idle power transient before the "
+                                           "W warm-up steps (the plans are built on the host with the GPU idle; "
+                                           "tools/step_curve_probe.py); ms_per_step_from_idle = the same W + K steps started "
+                                           "0.5 s after the last launch" % PRECOND_STEPS,
+                       "streams_note": "consecutive steps alternate between %d HIP streams with their own feature / output "
+                                       "buffers (the next step's analysis fills the tail of this step's synthesis launch); "
+                                       "ms_per_step_single_stream = the same K steps one at a time, same process" % n_streams,
                        "ola_runs": splan.n_runs,
                        "host_plan_build_s": round(t_plan, 4), "host_plan_build_cold_s": round(t_plan_cold, 3)},
             "roofline": roof,
@@ -751,7 +825,7 @@ def main():
                                                "frames/s")
         if full:
             try:
-                c2 = measure_lowdim(eng, utts, 50, 3, live=live, live_src=live_src)
+                c2 = measure_lowdim(eng, utts, 50, 3, live=live, live_src=live_src, n_streams=n_streams)
                 if not args.no_cpu_baseline:
                     c2["cpu_baseline"] = cpu_baseline(
                         utts, _cpu_lowdim, "configs[2] (analysis_compressed at constant rate -> post_filter -> "

@@ -1,7 +1,9 @@
 #!/bin/bash
 # One round's rocprofv3 evidence, on the GPU box:   tools/profile_round.sh r02_v1
 #   gpurun_out/prof_<tag>/bench.json          python bench.py (full line)
-#   gpurun_out/prof_<tag>/kernel_stats.csv    rocprofv3 --kernel-trace --stats of bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-e2e --traffic none
+#   gpurun_out/prof_<tag>/kernel_stats.csv    rocprofv3 --kernel-trace --stats of bench.py --steps 40 --warmup 5 --streams 1 --no-cpu-baseline --no-e2e --traffic none
+#                                             (one step at a time: with the default two streams consecutive steps overlap and a
+#                                             launch's duration includes the time it shares the device with its neighbour)
 #   gpurun_out/prof_<tag>/bench_profiled.json the JSON line of THAT profiled process: its roofline (HIP events) and the
 #                                             kernel_stats.csv averages come from the same launches on the same box
 #   gpurun_out/prof_<tag>/pmc_<set>/...       separate --pmc passes (with --kernel-trace only) of bench.py --steps 3 --warmup 1 ...
@@ -15,7 +17,7 @@ cd /tmp && export TMPDIR=/tmp
 if [ -z "$SKIP_BENCH" ]; then
   (cd $R && timeout 1200 python bench.py > $O/bench.json 2> $O/bench.err)
 fi
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o ks -- python $R/bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-e2e --traffic none > $O/stats.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o ks -- python $R/bench.py --steps 40 --warmup 5 --streams 1 --no-idle-probe --no-cpu-baseline --no-e2e --traffic none > $O/stats.log 2>&1
 cp $(find $O/stats -name '*kernel_stats.csv' | head -1) $O/kernel_stats.csv
 grep '^{"metric"' $O/stats.log | tail -1 > $O/bench_profiled.json
 for c in "FETCH_SIZE" "WRITE_SIZE" \
@@ -23,7 +25,7 @@ for c in "FETCH_SIZE" "WRITE_SIZE" \
          "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_ANY SQ_INSTS_SALU SQ_INSTS_VMEM SQ_WAIT_INST_LDS" \
          "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES"; do
   n=$(echo $c | cut -d" " -f1)
-  timeout 400 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$n -o pmc -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-e2e --traffic none > $O/pmc_$n.log 2>&1
+  timeout 400 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$n -o pmc -- python $R/bench.py --steps 3 --warmup 1 --streams 1 --no-cpu-baseline --no-e2e --traffic none > $O/pmc_$n.log 2>&1
 done
 cd $R && python tools/pmc_summary.py $O
 find $O -name '*.db' -delete; rm -rf $O/stats
