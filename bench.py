@@ -229,7 +229,47 @@ class _Marks:
         return [(n1, e0.elapsed_time(e1)) for (_n0, e0), (n1, e1) in zip(self.ev[:-1], self.ev[1:])]
 
 
-def measure_lowdim(eng, utts, steps, warmup, live=None, live_src=None, n_streams=1):
+def pick_streams(n, enqueue, steps=24, tries=10):
+    """
+    n HIP streams that really run side by side.  HIP multiplexes its streams onto a few hardware queues (4 by default) and
+    two streams that land on the same queue serialise (tools/stream_pair_probe.py: of the pairs among 8 streams about one
+    in four does) -- which streams share a queue is not something the API tells.  So: time `steps` steps on one stream,
+    then draw streams until alternating between the chosen ones and the candidate is at least 2.5 % faster than one
+    stream alone with EVERY chosen stream; if none is after `tries` draws, the best candidate is taken.
+    enqueue(stream, k): enqueue one step on `stream` with buffer set k.  Returns (streams, report).
+    """
+    import torch
+
+    def block(ss):
+        dt = None
+        for _rep in range(2):      # the first pass creates the hardware queue of a stream that has not been used yet
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for i in range(steps):
+                enqueue(ss[i % len(ss)], i % len(ss))
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t) / steps * 1e3
+        return dt
+
+    chosen = [torch.cuda.Stream()]
+    block(chosen)
+    single = block(chosen)
+    report = {"single_stream_ms": round(single, 4), "pairs_tried_ms": []}
+    while len(chosen) < n:
+        best = None
+        for _ in range(tries):
+            c = torch.cuda.Stream()
+            t = max(block([s_, c]) for s_ in chosen)
+            report["pairs_tried_ms"].append(round(t, 4))
+            if best is None or t < best[0]:
+                best = (t, c)
+            if t < 0.975 * single:
+                break
+        chosen.append(best[1])
+    return chosen, report
+
+
+def measure_lowdim(eng, utts, steps, warmup, live=None, live_src=None, n_streams=1, streams=None):
     import torch
 
     from magphase_amd import engine as em
@@ -239,7 +279,10 @@ def measure_lowdim(eng, utts, steps, warmup, live=None, live_src=None, n_streams
     # as in the headline: consecutive (independent) steps alternate between n_streams HIP streams, each with its own plans
     # and buffers; the per-kernel events below are taken one step at a time on the current stream
     states = [st] + [_lowdim_state(em, eng, utts) for _ in range(max(1, int(n_streams)) - 1)]
-    streams = [torch.cuda.Stream() for _ in states] if len(states) > 1 else [torch.cuda.current_stream()]
+    if len(states) == 1:
+        streams = [torch.cuda.current_stream()]
+    elif streams is None or len(streams) < len(states):
+        streams = [torch.cuda.Stream() for _ in states]
     counter = [0]
 
     def step(mark=None):
@@ -661,17 +704,25 @@ def main():
     # synthesis launch (a SIMD serves its waves by age: the last waves of a launch run alone).  Every step
     # does all of its work; nothing is shared between steps but the read-only inputs.  --streams 1 = one step at a time.
     n_streams = max(1, int(args.streams))
-    streams = [torch.cuda.Stream() for _ in range(n_streams)] if n_streams > 1 else [torch.cuda.current_stream()]
     bufs = [(tuple(eng.empty_feats(F, H) for _ in range(3)), eng.empty((max(splan.strip_floats, 1),)),
              eng.empty((splan.total_out,))) for _ in range(n_streams)]
     feats, strips, pcm_out = bufs[0]
 
-    def step(i=0, one_stream=False):
-        k = 0 if one_stream else i % n_streams
+    def enqueue(stream, k):
         f_, s_, p_ = bufs[k]
-        with torch.cuda.stream(streams[0 if one_stream else k]):
+        with torch.cuda.stream(stream):
             aplan.run(out=f_)
             splan.run(f_[0], f_[1], f_[2], strips=s_, out=p_)
+
+    stream_pick = None
+    if n_streams > 1:      # streams that map to different hardware queues (pick_streams)
+        streams, stream_pick = pick_streams(n_streams, enqueue)
+    else:
+        streams = [torch.cuda.current_stream()]
+
+    def step(i=0, one_stream=False):
+        k = 0 if one_stream else i % n_streams
+        enqueue(streams[k], k)
 
     def barrier():
         if dist is not None:
@@ -807,6 +858,7 @@ def main():
                        "x_realtime": round(UTTS_PER_GPU * DUR_S * world / (dt / args.steps), 1),
                        "parallelism": "utterance-sharded x%d, no collective" % world,
                        "streams": n_streams,
+                       "stream_pick": stream_pick,
                        "ms_per_step_single_stream": (round(dt_one / args.steps * 1e3, 4) if dt_one else None),
                        "ms_per_step_from_idle": (round(dt_idle / args.steps * 1e3, 4) if dt_idle else None),
                        "power_state_note": "%d untimed steps take the device out of its post-idle power transient before the "
@@ -825,7 +877,7 @@ def main():
                                                "frames/s")
         if full:
             try:
-                c2 = measure_lowdim(eng, utts, 50, 3, live=live, live_src=live_src, n_streams=n_streams)
+                c2 = measure_lowdim(eng, utts, 50, 3, live=live, live_src=live_src, n_streams=n_streams, streams=streams)
                 if not args.no_cpu_baseline:
                     c2["cpu_baseline"] = cpu_baseline(
                         utts, _cpu_lowdim, "configs[2] (analysis_compressed at constant rate -> post_filter -> "
