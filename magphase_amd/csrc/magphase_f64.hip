@@ -17,6 +17,10 @@
 namespace mpx {
 
 constexpr int kAna64Waves = 8;
+#ifndef MPX_F64_DIT
+#define MPX_F64_DIT 1   // the transform in the DIT form (fft_inreg_dit_f64: 136 fewer float64 instructions per frame); 0: DIF
+#endif
+constexpr bool kF64Dit = MPX_F64_DIT != 0;
 template <int P>
 constexpr size_t lds_bytes_ana64() {
     return sizeof(double) * (size_t)tw64_doubles<P>() + sizeof(float) * (size_t)(kAna64Waves * P * kXStride + 4);   // + frame queue
@@ -72,6 +76,12 @@ __device__ __forceinline__ void feat_store(double xr, double xi, double zero2, f
     }
 }
 
+// register that holds z[l + 64 j] on entry / bin kappa + 64 q on exit of the transform
+template <int P>
+__device__ __forceinline__ constexpr int f64_in_reg(int j) { return kF64Dit ? brev(j, ilog2(P)) : j; }
+template <int P>
+__device__ __forceinline__ constexpr int f64_out_reg(int q) { return kF64Dit ? q : brev(q, ilog2(P)); }
+
 template <int P>
 __global__ __launch_bounds__(kAna64Waves * 64) void k_analysis_f64(const float* __restrict__ sig,
                                                                   const long long* __restrict__ fpos,
@@ -89,7 +99,12 @@ __global__ __launch_bounds__(kAna64Waves * 64) void k_analysis_f64(const float* 
     const int wave = rfl((int)(threadIdx.x >> 6));
     float* xbuf = xbase + wave * (P * kXStride);
     const unsigned xbuf_byte = 8u * (unsigned)tw64_doubles<P>() + 4u * (unsigned)(wave * (P * kXStride));
-    for (int i = threadIdx.x; i < tw64_doubles<P>(); i += kAna64Waves * 64) tw[i] = tw_g[i];
+    for (int i = threadIdx.x; i < tw64_doubles<P>(); i += kAna64Waves * 64) {
+        // the global table is in the DIF form's register order (entry i = W_M^{l brev(i)}); the DIT form reads natural rows
+        const int l = i / tw64_stride<P>(), c = i - l * tw64_stride<P>();
+        const int src = (kF64Dit && c < 2 * P) ? l * tw64_stride<P>() + 2 * brev(c >> 1, LB) + (c & 1) : i;
+        tw[i] = tw_g[src];
+    }
     unsigned* queue = reinterpret_cast<unsigned*>(xbase + kAna64Waves * (P * kXStride));
     if (threadIdx.x == 0) *queue = 0u;
     __syncthreads();
@@ -140,10 +155,10 @@ __global__ __launch_bounds__(kAna64Waves * 64) void k_analysis_f64(const float* 
                     int k1 = m + 1 + g.rot;
                     k1 = (k1 >= N) ? k1 - N : k1;
                     if (k0 >= tile0 && k0 < hi)
-                        re[j] = (double)xbuf[k0 - tile0] * hann_half_f64(k0, g.L, g.LR, g.kadd, invL, invR);
+                        re[f64_in_reg<P>(j)] = (double)xbuf[k0 - tile0] * hann_half_f64(k0, g.L, g.LR, g.kadd, invL, invR);
                     if (k1 >= tile0 && k1 < hi)
-                        im[j] = (double)xbuf[k1 - tile0] * hann_half_f64(k1, g.L, g.LR, g.kadd, invL, invR);
-                    s_abs += fabs(re[j]) + fabs(im[j]);
+                        im[f64_in_reg<P>(j)] = (double)xbuf[k1 - tile0] * hann_half_f64(k1, g.L, g.LR, g.kadd, invL, invR);
+                    s_abs += fabs(re[f64_in_reg<P>(j)]) + fabs(im[f64_in_reg<P>(j)]);
                 }
             }
             wave_sync();
@@ -158,7 +173,8 @@ __global__ __launch_bounds__(kAna64Waves * 64) void k_analysis_f64(const float* 
         const double zero2 = fmax(zt * zt, 1.0e-36);
 #endif
 
-        wave_fft_f64<P, -1>(re, im, tw, xbuf, lane);
+        if constexpr (kF64Dit) wave_fft_dit_f64<P, -1>(re, im, tw, xbuf, lane);
+        else wave_fft_f64<P, -1>(re, im, tw, xbuf, lane);
         // scheduling fence: left alone, the last butterfly stage is interleaved with the split below and its inputs AND
         // outputs are live together (16 doubles spilled: 1 GB of scratch traffic per launch)
 #pragma unroll
@@ -183,7 +199,7 @@ __global__ __launch_bounds__(kAna64Waves * 64) void k_analysis_f64(const float* 
                 double zpr[EB], zpi[EB];   // EB partner bins per batch: 4 EB lane exchanges in flight
 #pragma unroll
                 for (int u = 0; u < EB; ++u) {
-                    const int i = brev(qb + u, LB);
+                    const int i = f64_out_reg<P>(qb + u);   // Z[M - k]: register of row P - 1 - q (P - 1 - brev(q) == brev(P - 1 - q))
                     unsigned a, b, c, d;
                     split64(re[P - 1 - i], a, b);
                     split64(im[P - 1 - i], c, d);
@@ -193,8 +209,8 @@ __global__ __launch_bounds__(kAna64Waves * 64) void k_analysis_f64(const float* 
 #pragma unroll
                 for (int u = 0; u < EB; ++u) {
                     const int q = qb + u;
-                    const int i = brev(q, LB);
-                    const int i0 = brev((P - q) % P, LB);
+                    const int i = f64_out_reg<P>(q);
+                    const int i0 = f64_out_reg<P>((P - q) % P);
                     const double pr = lane0 ? re[i0] : zpr[u];
                     const double pi = lane0 ? im[i0] : zpi[u];
                     const double er = 0.5 * (re[i] + pr), ei = 0.5 * (im[i] - pi);
@@ -209,7 +225,8 @@ __global__ __launch_bounds__(kAna64Waves * 64) void k_analysis_f64(const float* 
                     feat_store<PH>(er - tr, ti - ei, zero2, row_m + km, row_r + km, row_i + km);
                 }
             }
-            if (lane0) feat_store<PH>(re[1], -im[1], zero2, row_m + M / 2, row_r + M / 2, row_i + M / 2);
+            constexpr int ih = f64_out_reg<P>(P / 2);   // bin M/2
+            if (lane0) feat_store<PH>(re[ih], -im[ih], zero2, row_m + M / 2, row_r + M / 2, row_i + M / 2);
         };
         // rows whose phase features no consumer reads (the compressed analysis: unvoiced stretches) get the magnitude only:
         // a third of the stores and two conversions per bin less, one wave-uniform branch per frame

@@ -69,8 +69,47 @@ __device__ __forceinline__ void fft_inreg_f64(double (&re)[P], double (&im)[P]) 
     }
 }
 
-// plane transpose through the fp32 buffer: low words, then high words
-template <int P>
+// The DIT form of the in-register transform (wave_fft.hpp fft_inreg_dit): input register r holds element brev(r), output
+// register i holds index i; out0 = a + w b, out1 = 2 a - out0 in fused multiply-adds -- 6 instead of 8 float64
+// instructions per general butterfly (68 fewer per 32-point transform), and float64 instructions are what k_analysis_f64
+// is made of.
+template <int P, int SIGN>
+__device__ __forceinline__ void fft_inreg_dit_f64(double (&re)[P], double (&im)[P]) {
+#pragma unroll
+    for (int s = 1; s < P; s <<= 1) {
+#pragma unroll
+        for (int g = 0; g < P; g += 2 * s) {
+#pragma unroll
+            for (int k = 0; k < s; ++k) {
+                const int i0 = g + k, i1 = g + k + s;
+                const int t = k * (16 / s);  // twiddle W_{2s}^k = W_32^t = W_64^{2t}
+                const double ar = re[i0], ai = im[i0], br = re[i1], bi = im[i1];
+                if (t == 0) {
+                    re[i0] = ar + br;
+                    im[i0] = ai + bi;
+                    re[i1] = ar - br;
+                    im[i1] = ai - bi;
+                } else if (t == 8) {  // w = SIGN * i: w b = SIGN (-bi, br)
+                    re[i0] = (SIGN < 0) ? ar + bi : ar - bi;
+                    im[i0] = (SIGN < 0) ? ai - br : ai + br;
+                    re[i1] = (SIGN < 0) ? ar - bi : ar + bi;
+                    im[i1] = (SIGN < 0) ? ai + br : ai - br;
+                } else {
+                    const double c = dc64(2 * t), sn = (SIGN < 0) ? -ds64(2 * t) : ds64(2 * t);
+                    const double o0r = fma(br, c, fma(-bi, sn, ar));
+                    const double o0i = fma(br, sn, fma(bi, c, ai));
+                    re[i0] = o0r;
+                    im[i0] = o0i;
+                    re[i1] = fma(2.0, ar, -o0r);
+                    im[i1] = fma(2.0, ai, -o0i);
+                }
+            }
+        }
+    }
+}
+
+// plane transpose through the fp32 buffer: low words, then high words (NAT: natural input register order)
+template <int P, bool NAT = false>
 __device__ __forceinline__ void lds_transpose_f64(double (&x)[P], float* xbuf, int lane) {
     float lo[P], hi[P];
 #pragma unroll
@@ -80,8 +119,8 @@ __device__ __forceinline__ void lds_transpose_f64(double (&x)[P], float* xbuf, i
         lo[i] = __builtin_bit_cast(float, a);
         hi[i] = __builtin_bit_cast(float, b);
     }
-    lds_transpose<P>(lo, xbuf, lane);
-    lds_transpose<P>(hi, xbuf, lane);
+    lds_transpose<P, NAT>(lo, xbuf, lane);
+    lds_transpose<P, NAT>(hi, xbuf, lane);
 #pragma unroll
     for (int i = 0; i < P; ++i) x[i] = join64(__builtin_bit_cast(unsigned, lo[i]), __builtin_bit_cast(unsigned, hi[i]));
 }
@@ -214,6 +253,49 @@ __device__ __forceinline__ void wave_fft_f64(double (&re)[P], double (&im)[P], c
         cross_lane_stage_f64<P, SIGN, 8, 16>(re, im, (lane & 8) != 0, false, lane);
     }
     fft_inreg_f64<P, SIGN>(re, im);
+}
+
+// DIT form (layout of wave_fft_dit in wave_fft.hpp): input register brev(j) <- z[l + 64 j], output register i holds
+// Z[kappa(l) + 64 i]; twn: the float64 table with its rows in NATURAL order (entry i of lane l = W_M^{l i}).
+template <int P, int SIGN>
+__device__ __forceinline__ void wave_fft_dit_f64(double (&re)[P], double (&im)[P], const double* twn, float* xbuf, int lane) {
+    constexpr int LB = ilog2(P);
+    fft_inreg_dit_f64<P, SIGN>(re, im);
+    const double2* trow = reinterpret_cast<const double2*>(twn + lane * tw64_stride<P>());
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        if ((i & 7) == 0) asm volatile("" ::: "memory");   // eight table reads in flight at a time (see wave_fft_f64)
+        const double2 w = trow[i];
+        const double ws = (SIGN < 0) ? -w.y : w.y;
+        const double xr = re[i] * w.x - im[i] * ws;
+        const double xi = re[i] * ws + im[i] * w.x;
+        re[i] = xr;
+        im[i] = xi;
+    }
+    lds_transpose_f64<P, true>(re, xbuf, lane);
+    lds_transpose_f64<P, true>(im, xbuf, lane);
+    if (P == 32) {
+        cross_lane_stage_f64<P, SIGN, 32, 64>(re, im, (lane & 32) != 0, false, lane);
+    } else if (P == 16) {
+        cross_lane_stage_f64<P, SIGN, 32, 64>(re, im, (lane & 32) != 0, (lane & 48) == 48, lane);
+        cross_lane_stage_f64<P, SIGN, 16, 32>(re, im, (lane & 16) != 0, false, lane);
+    } else {
+        cross_lane_stage_f64<P, SIGN, 32, 64>(re, im, (lane & 32) != 0, false, lane);
+        cross_lane_stage_f64<P, SIGN, 16, 32>(re, im, (lane & 16) != 0, (lane & 24) == 24, lane);
+        cross_lane_stage_f64<P, SIGN, 8, 16>(re, im, (lane & 8) != 0, false, lane);
+    }
+    double tr[P], ti[P];
+#pragma unroll
+    for (int r = 0; r < P; ++r) {
+        tr[brev(r, LB)] = re[r];
+        ti[brev(r, LB)] = im[r];
+    }
+    fft_inreg_dit_f64<P, SIGN>(tr, ti);
+#pragma unroll
+    for (int r = 0; r < P; ++r) {
+        re[r] = tr[r];
+        im[r] = ti[r];
+    }
 }
 
 }  // namespace mpx

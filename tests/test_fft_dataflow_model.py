@@ -295,3 +295,86 @@ def test_dit_compact_wave_fft_layout(sign):
     for lam in range(64):
         for i in range(P):
             assert abs(res[lam, i] - Z[lam + 64 * i]) < 1e-9
+
+
+def wave_fft_dit(x_brev, sign):
+    """wave_fft.hpp wave_fft_dit (any P): x_brev[lane, brev(j)] = z[lane + 64 j] -> out[lane, i] = Z[kappa(lane) + 64 i]:
+    DIT first pass (natural k1), natural-order twiddles and transposes, the cross-lane stages of wave_fft, DIT second pass on
+    the bit-reversed renaming of the registers."""
+    P = x_brev.shape[1]
+    M, LB = 64 * P, int(np.log2(P))
+    lanes = np.arange(64)
+    y = fft_inreg_dit(x_brev, sign)
+    for i in range(P):
+        y[:, i] *= np.exp(sign * 2j * np.pi * lanes * i / M)
+    v = np.zeros((64, P), dtype=complex)
+    for lam in range(64):
+        for lp in range(P):
+            v[lam, lp] = y[(lam // P) * P + lp, lam % P]
+    S = 32
+    while S >= P:
+        out = np.zeros_like(v)
+        for lam in range(64):
+            own, oth = v[lam], v[lam ^ S]
+            if lam & S:
+                e = (lam // P) % (S // P)
+                out[lam] = (oth - own) * np.exp(sign * 2j * np.pi * np.arange(P) / (2 * S)) \
+                    * np.exp(sign * 2j * np.pi * e * P / (2 * S))
+            else:
+                out[lam] = own + oth
+        v = out
+        S //= 2
+    t = np.zeros_like(v)
+    for r in range(P):
+        t[:, brev(r, LB)] = v[:, r]
+    return fft_inreg_dit(t, sign)
+
+
+@pytest.mark.parametrize("P", [32, 16, 8])
+@pytest.mark.parametrize("sign", [-1, 1])
+def test_dit_wave_fft_layout(P, sign):
+    rng = np.random.RandomState(3 * P + sign)
+    M, LB = 64 * P, int(np.log2(P))
+    z = rng.randn(M) + 1j * rng.randn(M)
+    x = z.reshape(P, 64).T.copy()
+    xin = np.zeros_like(x)
+    for j in range(P):
+        xin[:, brev(j, LB)] = x[:, j]
+    res = wave_fft_dit(xin, sign)
+    Z = np.fft.fft(z) if sign < 0 else np.fft.ifft(z) * M
+    for lam in range(64):
+        for i in range(P):
+            assert abs(res[lam, i] - Z[kappa(lam, P) + 64 * i]) < 1e-9
+
+
+@pytest.mark.parametrize("P", [32, 16, 8])
+def test_real_fft_split_in_natural_register_order(P):
+    """The split of the DIT form (k_analysis_f64, noise_spectrum_paired): lane kappa owns k = kappa + 64 q in register q;
+    Z[M - k] lives in lane (64 - kappa) & 63, register P - 1 - q (kappa == 0: own register (P - q) % P); bin M / 2 is
+    register P / 2 of the kappa == 0 lane."""
+    M, N, LB = 64 * P, 128 * P, int(np.log2(P))
+    rng = np.random.RandomState(P)
+    xr = rng.randn(N)
+    z = xr[0::2] + 1j * xr[1::2]
+    x = z.reshape(P, 64).T.copy()
+    xin = np.zeros_like(x)
+    for j in range(P):
+        xin[:, brev(j, LB)] = x[:, j]
+    Zl = wave_fft_dit(xin, -1)
+    X = np.fft.fft(xr)
+    inv = {kappa(l, P): l for l in range(64)}
+    for lam in range(64):
+        kap = kappa(lam, P)
+        src = inv[(64 - kap) & 63]
+        for q in range(P // 2):
+            own = Zl[lam, q]
+            par = Zl[lam, (P - q) % P] if kap == 0 else Zl[src, P - 1 - q]
+            k = kap + 64 * q
+            E = 0.5 * (own + np.conj(par))
+            O = -0.5j * (own - np.conj(par))
+            T = np.exp(-2j * np.pi * k / N) * O
+            assert abs(E + T - X[k]) < 1e-9
+            if not (kap == 0 and q == 0):
+                assert abs(np.conj(E - T) - X[M - k]) < 1e-9
+    l0 = inv[0]
+    assert abs(np.conj(Zl[l0, P // 2]) - X[M // 2]) < 1e-9
