@@ -9,6 +9,11 @@
 
 #include "mpx_common.hpp"
 
+// waves per workgroup of k_synth_comp_pair (8 = two per SIMD, 12 = three: compact transform front, <= 168 VGPRs)
+#ifndef MPX_COMP_PAIR_WAVES
+#define MPX_COMP_PAIR_WAVES 12
+#endif
+
 namespace mpx {
 
 // ---------------------------------------------------------------------------------------------
@@ -218,10 +223,13 @@ __global__ __launch_bounds__(256) void k_mel_warp(WarpJobs jobs, long long F, in
 // Windowed noise frame (magphase.py:886-897: windowing() with per-frame window list, epoch moved to index 0 by
 // frm_list_to_matrix + fftshift) -> N-point real FFT -> Ns[k] for the bins kappa(lane) + 64 j, j = 0..P-1
 // (natural j), plus the Nyquist bin (real) on the lane with kappa == 0.  Synchronous staging (no prefetch).
-template <int P, bool PRESTAGED = false>   // PRESTAGED: the caller already copied tile 0 into xbuf and waited for it
+// COMPACT (P == 32): half-height exchange buffer (tiles of 32 P samples) and half twiddle table (wave_fft_front_compact;
+// (lc, ls) = W_128^lane) -- k_synth_comp_pair at 12 waves per CU.
+template <int P, bool PRESTAGED = false, bool COMPACT = false>   // PRESTAGED: the caller already copied tile 0 into xbuf and waited for it
 __device__ __forceinline__ void noise_fft(const FrameGeom& g, int wtype, const float* tw, float* xbuf,
-                                          unsigned xbuf_byte, int lane, float (&re)[P], float (&im)[P]) {
-    constexpr int M = 64 * P, N = 2 * M, kTile = 64 * P;
+                                          unsigned xbuf_byte, int lane, float (&re)[P], float (&im)[P], float lc = 1.0f,
+                                          float ls = 0.0f) {
+    constexpr int M = 64 * P, N = 2 * M, kTile = COMPACT ? 32 * P : 64 * P;
 #pragma unroll
     for (int j = 0; j < P; ++j) re[j] = im[j] = 0.0f;
     const int ntiles = (g.len + kTile - 1) / kTile;
@@ -257,7 +265,12 @@ __device__ __forceinline__ void noise_fft(const FrameGeom& g, int wtype, const f
         }
         wave_sync();
     }
-    wave_fft<P, -1>(re, im, tw, xbuf, lane);
+    if constexpr (COMPACT) {
+        wave_fft_front_compact<P, -1>(re, im, tw, xbuf, lane, lc, ls);
+        fft_inreg<P, -1>(re, im);
+    } else {
+        wave_fft<P, -1>(re, im, tw, xbuf, lane);
+    }
 }
 
 // Spectrum of the windowed noise frame in PAIRED layout: lane l (kappa = kappa(l)) gets, for q < P/2, its own bin
@@ -265,51 +278,63 @@ __device__ __forceinline__ void noise_fft(const FrameGeom& g, int wtype, const f
 // (X[k] = E + T, X[M-k] = conj(E - T)): P lane exchanges and P/2 split evaluations per lane instead of 2P and P of the
 // per-bin form.  The kappa == 0 lane's q == 0 pair is (DC, Nyquist); bin M/2 is its own mirror and comes out separately
 // (nh_*, meaningful on the kappa == 0 lane).
-template <int P, bool PRESTAGED = false>
+template <int P, bool PRESTAGED = false, bool COMPACT = false>
 __device__ __forceinline__ void noise_spectrum_paired(const FrameGeom& g, int wtype, const float* tw, float* xbuf,
                                                       unsigned xbuf_byte, int lane, float wl_c, float wl_s,
                                                       float (&no_r)[P / 2], float (&no_i)[P / 2], float (&nm_r)[P / 2],
-                                                      float (&nm_i)[P / 2], float& nh_r, float& nh_i) {
+                                                      float (&nm_i)[P / 2], float& nh_r, float& nh_i, float lc = 1.0f,
+                                                      float ls = 0.0f) {
     constexpr int LB = ilog2(P);
     float re[P], im[P];
-    noise_fft<P, PRESTAGED>(g, wtype, tw, xbuf, xbuf_byte, lane, re, im);
+    noise_fft<P, PRESTAGED, COMPACT>(g, wtype, tw, xbuf, xbuf_byte, lane, re, im, lc, ls);
     const int kap = kappa<P>(lane);
     const int src_lane = kappa<P>((64 - kap) & 63);
     const bool lane0 = (kap == 0);
-    float zpr[P / 2], zpi[P / 2];   // all partner bins first: P lane exchanges in flight together
+    // partner bins SB at a time: 2 SB lane exchanges in flight together.  All P/2 at once (8 waves per CU) keeps 64 inputs +
+    // 32 partners + the growing outputs live; in batches the own (even) and the source (odd) registers of a batch die as
+    // its four outputs per bin pair appear -- what the 12-wave form (<= 168 VGPRs) needs.
+#ifndef MPX_NOISE_SPLIT_BATCH
+#define MPX_NOISE_SPLIT_BATCH (MPX_COMP_PAIR_WAVES > 8 ? 8 : 16)
+#endif
+    constexpr int SB = (P / 2 < MPX_NOISE_SPLIT_BATCH) ? P / 2 : MPX_NOISE_SPLIT_BATCH;
 #pragma unroll
-    for (int q = 0; q < P / 2; ++q) {
-        const int i = brev(q, LB);
-        zpr[q] = __shfl(re[P - 1 - i], src_lane);
-        zpi[q] = __shfl(im[P - 1 - i], src_lane);
-    }
+    for (int qb = 0; qb < P / 2; qb += SB) {
+        float zpr[SB], zpi[SB];
 #pragma unroll
-    for (int q = 0; q < P / 2; ++q) {
-        const int i = brev(q, LB);
-        const int i0 = brev((P - q) % P, LB);
-        const float pr = lane0 ? re[i0] : zpr[q];
-        const float pi = lane0 ? im[i0] : zpi[q];
-        const float er = 0.5f * (re[i] + pr), ei = 0.5f * (im[i] - pi);
-        const float orr = 0.5f * (im[i] + pi), oi = -0.5f * (re[i] - pr);
-        const float cq = cos2p<P>(q), sq = -sin2p<P>(q);   // W_N^k = W_N^kappa * e^{-2 pi i q/(2P)}
-        const float wr = wl_c * cq - wl_s * sq, wi = wl_c * sq + wl_s * cq;
-        const float tr = wr * orr - wi * oi, ti = wr * oi + wi * orr;
-        no_r[q] = er + tr;
-        no_i[q] = ei + ti;
-        nm_r[q] = er - tr;
-        nm_i[q] = ti - ei;
+        for (int u = 0; u < SB; ++u) {
+            const int i = brev(qb + u, LB);
+            zpr[u] = __shfl(re[P - 1 - i], src_lane);
+            zpi[u] = __shfl(im[P - 1 - i], src_lane);
+        }
+#pragma unroll
+        for (int u = 0; u < SB; ++u) {
+            const int q = qb + u;
+            const int i = brev(q, LB);
+            const int i0 = brev((P - q) % P, LB);
+            const float pr = lane0 ? re[i0] : zpr[u];
+            const float pi = lane0 ? im[i0] : zpi[u];
+            const float er = 0.5f * (re[i] + pr), ei = 0.5f * (im[i] - pi);
+            const float orr = 0.5f * (im[i] + pi), oi = -0.5f * (re[i] - pr);
+            const float cq = cos2p<P>(q), sq = -sin2p<P>(q);   // W_N^k = W_N^kappa * e^{-2 pi i q/(2P)}
+            const float wr = wl_c * cq - wl_s * sq, wi = wl_c * sq + wl_s * cq;
+            const float tr = wr * orr - wi * oi, ti = wr * oi + wi * orr;
+            no_r[q] = er + tr;
+            no_i[q] = ei + ti;
+            nm_r[q] = er - tr;
+            nm_i[q] = ti - ei;
+        }
     }
     nh_r = re[1];    // bin M/2 = register brev(P/2) = 1 of the kappa == 0 lane: X = conj Z
     nh_i = -im[1];
 }
 
-template <int P, bool PRESTAGED = false>   // PRESTAGED: the caller already copied tile 0 into xbuf and waited for it
+template <int P, bool PRESTAGED = false, bool COMPACT = false>   // PRESTAGED: the caller already copied tile 0 into xbuf and waited for it
 __device__ __forceinline__ void noise_spectrum(const FrameGeom& g, int wtype, const float* tw, float* xbuf,
                                                unsigned xbuf_byte, int lane, float wl_c, float wl_s,
-                                               float (&nr)[P], float (&ni)[P], float& nM) {
+                                               float (&nr)[P], float (&ni)[P], float& nM, float lc = 1.0f, float ls = 0.0f) {
     constexpr int LB = ilog2(P);
     float re[P], im[P];
-    noise_fft<P, PRESTAGED>(g, wtype, tw, xbuf, xbuf_byte, lane, re, im);
+    noise_fft<P, PRESTAGED, COMPACT>(g, wtype, tw, xbuf, xbuf_byte, lane, re, im, lc, ls);
     // real-FFT split for every own bin (redundant form: each lane evaluates X[k] for all its bins)
     const int kap = kappa<P>(lane);
     const int src_lane = kappa<P>((64 - kap) & 63);
@@ -940,21 +965,35 @@ struct CompFrameTabs {
     const int* pm_rel;
 };
 
-// 4 waves per workgroup = one per SIMD: the kernel keeps the noise spectrum, the features and the FFT working set live
-// at once (> 256 VGPRs); with 512 registers per wave nothing spills to scratch (scratch = VMEM = vmcnt stalls).
 // ---------------------------------------------------------------------------------------------
 // Compressed-feature synthesis + PSOLA, pair form: two waves share one LDS ring and alternate over the frames of the
-// pair's runs (tickets in LDS, exactly as k_synth_ola_pair), 8 waves per CU.  The single-wave form it replaced (git
+// pair's runs (tickets in LDS, exactly as k_synth_ola_pair).  Round 3: 12 waves per CU (three per SIMD, <= 168 VGPRs)
+// instead of 8 -- the kernel is parked in s_waitcnt a third of its wave cycles and moves 1 TB/s, a third wave per SIMD
+// fills those gaps: synthesis side of configs[2] 1.350 -> 1.272 ms (interleaved A/B) with 14 scalar-sized spills left
+// (loop-invariant lane constants; the register allocator's choice of victims is not steerable from the source: removing
+// two of the constants gave 38).  What made it fit: the compact transform front (half-height exchange buffer, noise
+// staged in tiles of 1024 samples: frames longer than that -- f0 below 94 Hz at 48 kHz -- take a second, synchronous
+// tile; half twiddle table), the feature batches of the assembly 2 bin pairs at a time, the overlap-add 16 ring values
+// at a time (ring_add_plane).  The single-wave form it replaced (git
 // history) held both feature rows, the per-bin curves and the noise FFT at once (466 VGPRs, ONE wave per SIMD: at one
 // instruction per ~5.4 cycles and wave its ~7.5 k instructions per frame were the whole 1.35 ms).  Here the noise spectrum is
 // computed first and the features are folded into it in place, half a spectrum (16 register rows) at a time:
 // 64 + 128 live registers instead of 64 + 262, so two waves fit a SIMD.
 // ---------------------------------------------------------------------------------------------
-constexpr int kCompPairWaves = 8;
+constexpr int kCompPairWaves = MPX_COMP_PAIR_WAVES;
 constexpr int kCompPairs = kCompPairWaves / 2;
+// More than 8 waves per CU: P == 32 does not fit the LDS with full-height exchange buffers (6 rings + 12 buffers + the
+// table = 223 KB) -- the compact transform front of wave_fft.hpp (half-height buffers, noise staged in tiles of 1024
+// samples, half twiddle table): 162.9 KB, as k_synth_ola_pair.
+template <int P>
+constexpr bool comp_compact() { return P == 32 && kCompPairWaves > 8; }
+template <int P>
+constexpr int comp_tw_floats() { return comp_compact<P>() ? tw_half_floats<P>() : tw_floats<P>(); }
+template <int P>
+constexpr int comp_xbuf_floats() { return (comp_compact<P>() ? P / 2 : P) * kXStride; }
 template <int P>
 constexpr size_t lds_bytes_comp_pair() {
-    return sizeof(float) * (size_t)(tw_floats<P>() + kCompPairWaves * (P * kXStride) + kCompPairs * ring_len<P>() + 16);
+    return sizeof(float) * (size_t)(comp_tw_floats<P>() + kCompPairWaves * comp_xbuf_floats<P>() + kCompPairs * ring_len<P>() + 16);
 }
 
 // LERP: every frame interpolates between two spectrum rows (row0 / row1 / rowt tables); false: one row per frame, row
@@ -981,13 +1020,21 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_synth_comp_pair(const f
     const int lane_id = threadIdx.x & 63;
     const int wave = rfl((int)(threadIdx.x >> 6));
     const int pair = wave >> 1, half = wave & 1;
-    float* xbuf = smem + tw_floats<P>() + wave * (P * kXStride);
-    const unsigned xbuf_byte = 4u * (unsigned)(tw_floats<P>() + wave * (P * kXStride));
-    constexpr int kRing0 = tw_floats<P>() + kCompPairWaves * (P * kXStride);
+    constexpr bool kCompact = comp_compact<P>();
+    float* xbuf = smem + comp_tw_floats<P>() + wave * comp_xbuf_floats<P>();
+    const unsigned xbuf_byte = 4u * (unsigned)(comp_tw_floats<P>() + wave * comp_xbuf_floats<P>());
+    constexpr int kRing0 = comp_tw_floats<P>() + kCompPairWaves * comp_xbuf_floats<P>();
     float* ring = smem + kRing0 + pair * R;
     const unsigned ring_byte = 4u * (unsigned)(kRing0 + pair * R);
     int* turn = reinterpret_cast<int*>(smem + kRing0 + kCompPairs * R) + pair;
-    for (int i = threadIdx.x; i < tw_floats<P>(); i += kCompPairWaves * 64) tw[i] = tw_g[i];
+    if constexpr (kCompact) {   // the even registers' twiddles only: entry e of a half row = entry 2 e of the full row
+        for (int i = threadIdx.x; i < tw_half_floats<P>(); i += kCompPairWaves * 64) {
+            const int l = i / tw_half_stride<P>(), c = i - l * tw_half_stride<P>();
+            tw[i] = (c < P) ? tw_g[l * tw_stride<P>() + 4 * (c >> 1) + (c & 1)] : 0.0f;
+        }
+    } else {
+        for (int i = threadIdx.x; i < tw_floats<P>(); i += kCompPairWaves * 64) tw[i] = tw_g[i];
+    }
     for (int i = threadIdx.x; i < kCompPairs * R; i += kCompPairWaves * 64) smem[kRing0 + i] = 0.0f;
     if (threadIdx.x < kCompPairs) turn[threadIdx.x - pair] = 0;   // thread t < kCompPairs has pair == 0
     __syncthreads();
@@ -995,6 +1042,8 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_synth_comp_pair(const f
     float wa_s0, wa_c0, ws_s0, ws_c0;   // analysis-side lane twiddle W_N^kappa and synthesis-side conj(W_N^lane)
     sincospif(-2.0f * (float)kappa<P>(lane_id) / (float)N, &wa_s0, &wa_c0);
     sincospif(2.0f * (float)lane_id / (float)N, &ws_s0, &ws_c0);
+    float lc0 = 1.0f, ls0 = 0.0f;
+    if constexpr (kCompact) sincospif((float)lane_id / 64.0f, &ls0, &lc0);   // W_128^lane: the odd registers' twiddle factor
     const int slot = blockIdx.x * kCompPairs + pair;
     if (slot >= nslots) return;
 
@@ -1035,14 +1084,14 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_synth_comp_pair(const f
 
     // the noise samples of a frame are copied HBM -> LDS (into the transpose buffer) while the previous frame's
     // inverse FFT finishes and its overlap-add runs (same scheme as k_analysis)
-    constexpr int kTile = 64 * P;
+    constexpr int kTile = kCompact ? 32 * P : 64 * P;
     FrameGeom g = frame_geom(noise, tb.npos[cur.fi], tb.nleft[cur.fi], tb.nright[cur.fi], N);
     stage_samples_async(g, 0, kTile, xbuf_byte, lane_id);
 
     while (cur.valid) {
         int lane = lane_id;
-        float wa_s = wa_s0, wa_c = wa_c0, ws_s = ws_s0, ws_c = ws_c0;
-        asm volatile("" : "+v"(lane), "+v"(wa_s), "+v"(wa_c), "+v"(ws_s), "+v"(ws_c));
+        float wa_s = wa_s0, wa_c = wa_c0, ws_s = ws_s0, ws_c = ws_c0, lc = lc0, ls = ls0;
+        asm volatile("" : "+v"(lane), "+v"(wa_s), "+v"(wa_c), "+v"(ws_s), "+v"(ws_c), "+v"(lc), "+v"(ls));
         Cursor nxt = cur;
         advance(nxt);
         const int fi = cur.fi;
@@ -1062,8 +1111,8 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_synth_comp_pair(const f
             constexpr int HP = P / 2;
             float no_r[HP], no_i[HP], nm_r[HP], nm_i[HP], nh_r, nh_i;
             staged_wait<0>();
-            noise_spectrum_paired<P, true>(g, tb.wtype[fi], tw, xbuf, xbuf_byte, lane, wa_c, wa_s, no_r, no_i, nm_r, nm_i,
-                                           nh_r, nh_i);
+            noise_spectrum_paired<P, true, kCompact>(g, tb.wtype[fi], tw, xbuf, xbuf_byte, lane, wa_c, wa_s, no_r, no_i, nm_r,
+                                                     nm_i, nh_r, nh_i, lc, ls);
             if (P != 32) {   // FFT output lanes hold bins kappa(lane) + 64 q; everything below wants bins lane + 64 q
                 const int src = kappa<P>(lane);
 #pragma unroll
@@ -1106,7 +1155,7 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_synth_comp_pair(const f
                     o_i = vi * sgn_scale;
                 };
 #ifndef MPX_COMP_QB
-#define MPX_COMP_QB 8
+#define MPX_COMP_QB (MPX_COMP_PAIR_WAVES > 8 ? 2 : 8)
 #endif
                 constexpr int QB = (HP < MPX_COMP_QB) ? HP : MPX_COMP_QB;   // pairs per batch: 10 QB loads in flight
 #pragma unroll
@@ -1170,7 +1219,7 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_synth_comp_pair(const f
             float nM;
             {
                 staged_wait<0>();
-                noise_spectrum<P, true>(g, tb.wtype[fi], tw, xbuf, xbuf_byte, lane, wa_c, wa_s, xr, xi, nM);
+                noise_spectrum<P, true, kCompact>(g, tb.wtype[fi], tw, xbuf, xbuf_byte, lane, wa_c, wa_s, xr, xi, nM, lc, ls);
                 if (P != 32) {   // FFT output lanes hold bins kappa(lane)+64j; everything below wants bins lane+64j
                     const int src = kappa<P>(lane);
     #pragma unroll
@@ -1260,7 +1309,8 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_synth_comp_pair(const f
 
             hermitian_merge<P>(xr, xi, xm, lane, ws_c, ws_s);
         }
-        wave_fft_front<P, +1>(xr, xi, tw, xbuf, lane);
+        if constexpr (kCompact) wave_fft_front_compact<P, +1>(xr, xi, tw, xbuf, lane, lc, ls);
+        else wave_fft_front<P, +1>(xr, xi, tw, xbuf, lane);
         if (nxt.valid) {   // the exchange buffer is idle from here on: start the copy of the next frame's noise
             g = frame_geom(noise, tb.npos[nxt.fi], tb.nleft[nxt.fi], tb.nright[nxt.fi], N);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1290,13 +1340,23 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_synth_comp_pair(const f
         if (flushed < target) flush_ring<R>(ring, strip, pcm0, rd.head_end, rd.out_lo, rd.out_hi, flushed, target, lane);
         wave_sync();
         // register rows whose samples all lie outside the window support add nothing: skipped (wave-uniform)
-        ring_add<P>(smem, ring_byte, x, xr, xi, lane,
-                    [&](float o, float v, int n) {
-                        const int ks = n - n_lo;
-                        const float w = (ks >= 0 && n <= n_hi) ? half_window(ks, wl, wl + wr, kadd, inv_wl, inv_wr, 0) : 0.0f;
-                        return fmaf(v, w, o);
-                    },
-                    [&](int q) { return !(128 * q + 127 < n_lo || 128 * q > n_hi); });
+        auto win_add = [&](float o, float v, int n) {
+            const int ks = n - n_lo;
+            const float w = (ks >= 0 && n <= n_hi) ? half_window(ks, wl, wl + wr, kadd, inv_wl, inv_wr, 0) : 0.0f;
+            return fmaf(v, w, o);
+        };
+        auto row_live = [&](int q) { return !(128 * q + 127 < n_lo || 128 * q > n_hi); };
+        if constexpr (kCompPairWaves > 8) {   // 16 ring values in registers at a time (<= 168 VGPRs)
+#ifndef MPX_COMP_CH
+#define MPX_COMP_CH 16
+#endif
+            constexpr int CH = (P < MPX_COMP_CH) ? P : MPX_COMP_CH;
+            const RingAddr ra = ring_addr<P>(ring_byte, x, lane);
+            ring_add_plane<P, 0, CH>(smem, ra, xr, lane, win_add, row_live);
+            ring_add_plane<P, 1, CH>(smem, ra, xi, lane, win_add, row_live);
+        } else {
+            ring_add<P>(smem, ring_byte, x, xr, xi, lane, win_add, row_live);
+        }
         wave_sync();
         if (fi == cur.fe - 1) {   // last frame of the run: stream out the rest, leave the ring cleared
             flush_ring<R>(ring, strip, pcm0, rd.head_end, rd.out_lo, rd.out_hi, target, rd.flush_end, lane);
@@ -1957,18 +2017,24 @@ int mpx_noise_stats(void* stream, int fft_len, const void* tables, const float* 
 
 int mpx_synth_comp_slots(void) { return device_cus() * kCompPairs; }
 
-// Relative speed of the slots' wave pairs (see mpx_synth_ola_slot_weights): 8 waves per workgroup = two per SIMD, the
-// pairs 0 and 1 hold the older wave of every SIMD.
+// Relative speed of the slots' wave pairs (see mpx_synth_ola_slot_weights): the pairs (0, 1), (2, 3), (4, 5) of a workgroup
+// hold the oldest / middle / youngest wave of every SIMD.  12 waves, interleaved A/B of the configs[2] synthesis side:
+// equal shares 1.332 ms, 100:80:60 1.301, 100:75:55 1.314, 100:90:80 1.287, 100:85:70 .. 100:88:76 1.270-1.277 (flat).
 #ifndef MPX_COMP_W0
 #define MPX_COMP_W0 100
 #endif
 #ifndef MPX_COMP_W1
-#define MPX_COMP_W1 80
+#define MPX_COMP_W1 (MPX_COMP_PAIR_WAVES > 8 ? 86 : 80)
+#endif
+#ifndef MPX_COMP_W2
+#define MPX_COMP_W2 73
 #endif
 int mpx_synth_comp_slot_weights(float* weights_host, int32_t n_slots) {
     if (!weights_host || n_slots < 0) return fail(MPX_ERR_ARG, "mpx_synth_comp_slot_weights: bad arguments%s");
-    for (int s = 0; s < n_slots; ++s)
-        weights_host[s] = (((s % kCompPairs) * 2) / 4 == 0) ? (float)MPX_COMP_W0 : (float)MPX_COMP_W1;
+    for (int s = 0; s < n_slots; ++s) {
+        const int age = ((s % kCompPairs) * 2) / 4;   // age rank of the pair's waves on their SIMDs
+        weights_host[s] = (age == 0) ? (float)MPX_COMP_W0 : ((age == 1) ? (float)MPX_COMP_W1 : (float)MPX_COMP_W2);
+    }
     return MPX_OK;
 }
 

@@ -130,6 +130,25 @@ def test_generation_from_predicted_features_matches_reference_golden(mp, golden_
     within((np.max(np.abs(v - ref))) / (np.max(np.abs(ref))), COMP_PCM_TOL, "COMP_PCM_TOL:128")
 
 
+@pytest.mark.parametrize("f0", [55.0, 93.0, 94.5])
+def test_low_pitch_noise_frames_longer_than_one_staging_tile(mp, orc, golden_dir, f0):
+    """k_synth_comp_pair at 12 waves per CU stages a noise frame in tiles of 1024 samples: below 94 Hz at 48 kHz a
+    voiced frame (two pitch periods + 1 samples) is longer than that and takes a second tile.  The bundled predicted
+    features with their pitch replaced, against the oracle."""
+    g, mm, rr, ii, lf = _hvd704(golden_dir)
+    lf = np.where(lf > 0.0, np.log(f0), lf)[:60]
+    mm, rr, ii = mm[:60], rr[:60], ii[:60]
+    assert 2 * int(round(48000 / f0)) + 1 > 1024 or f0 > 94.0
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        np.random.seed(3)
+        v = mp.synthesis_from_compressed(mm, rr, ii, lf, 48000)
+        np.random.seed(3)
+        ref = orc.synthesis_from_compressed(mm, rr, ii, lf, 48000)
+    assert v.shape == ref.shape
+    within(np.max(np.abs(v - ref)) / max(1.0, np.max(np.abs(ref))), COMP_PCM_TOL, "COMP_PCM_TOL:low_pitch")
+
+
 def test_constant_rate_input_matches_reference_golden(mp, golden_dir):
     g = np.load(os.path.join(golden_dir, "g8_compressed_analysis.npz"))
     np.random.seed(int(g["cr45_seed"]))

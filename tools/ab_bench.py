@@ -52,6 +52,10 @@ def prepare(name, ref, flags):
     srcs = [os.path.join(csrc, f) for f in sorted(os.listdir(csrc)) if f.endswith((".hip", ".cpp"))]
     from magphase_amd import build
 
+    if not ref:   # the working tree: per-unit objects, compiled in parallel and cached per flag set (magphase_amd/_obj)
+        build.build(extra_flags=flags, out=os.path.join(dst, "magphase_amd", "libmagphase_hip.so"), verbose=False)
+        print("built %s %s" % (name, " ".join(flags)), flush=True)
+        return
     cmd = [build.hipcc_path()] + build.FLAGS + flags + srcs + ["-o", os.path.join(dst, "magphase_amd", "libmagphase_hip.so")]
     print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
