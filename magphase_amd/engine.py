@@ -22,6 +22,71 @@ def _torch():
     return torch
 
 
+class HostTicket:
+    """A batch result that is still on its way to the host: views of a page-locked ring slot filled by a non-blocking
+    D2H copy.  wait() blocks until the copy has landed (releases the GIL: meant for the writer thread of iobatch),
+    release() hands the slot back to the ring once the views have been consumed."""
+
+    def __init__(self, ring, slot, event, keep):
+        self._ring, self._slot, self._event, self._keep = ring, slot, event, keep
+
+    def wait(self):
+        if self._event is not None:
+            self._event.synchronize()
+            self._event = self._keep = None
+
+    def release(self):
+        if self._ring is not None:
+            self.wait()
+            self._ring.release(self._slot)
+            self._ring = None
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+
+class _PinnedRing:
+    """A few page-locked host buffers handed out round-robin (grown on demand, never shrunk).  A slot is reusable after
+    its ticket's release(); acquire() waits for that -- the natural back-pressure of a pipeline whose writer is behind."""
+
+    def __init__(self, slots=4):
+        import threading
+
+        self._bufs = [None] * slots
+        self._free = [threading.Event() for _ in range(slots)]
+        for ev in self._free:
+            ev.set()
+        self._next = 0
+        self._lock = threading.Lock()
+
+    def acquire(self, nbytes):
+        torch = _torch()
+        with self._lock:
+            slot = self._next
+            self._next = (slot + 1) % len(self._bufs)
+        if not self._free[slot].wait(timeout=120.0):
+            raise RuntimeError("pinned output ring: slot %d was never released (a consumer dropped its ticket?)" % slot)
+        self._free[slot].clear()
+        buf = self._bufs[slot]
+        if buf is None or buf.numel() < nbytes:
+            # Page-locking is slow (about 60 ms per 24 MB here): every slot is sized by the largest request so far with
+            # headroom, and the FIRST request sizes all of them -- the first batch of a corpus pays, once.
+            size = max([int(nbytes * 1.25), 1 << 20] + [b.numel() for b in self._bufs if b is not None])
+            first = all(b is None for b in self._bufs)
+            self._bufs[slot] = buf = torch.empty(size, dtype=torch.uint8).pin_memory()
+            if first:
+                for k in range(len(self._bufs)):
+                    if self._bufs[k] is None:
+                        self._bufs[k] = torch.empty(size, dtype=torch.uint8).pin_memory()
+        return slot, buf
+
+    def release(self, slot):
+        self._free[slot].set()
+
+
 class Engine:
     def __init__(self, device=None):
         torch = _torch()
@@ -143,11 +208,37 @@ class Engine:
                 dst.copy_(t)
         return dst.numpy()
 
-    def output_pcm16(self, y, out_off_host, norm=0.98):
+    def out_ring(self):
+        r = getattr(self, "_out_ring", None)
+        if r is None:
+            r = self._out_ring = _PinnedRing()
+        return r
+
+    def to_host_f32_async(self, tensors):
+        """Device float32 tensors -> float32 numpy VIEWS of one page-locked ring slot, copied without blocking; returns
+        (views, HostTicket).  The views are valid after ticket.wait() and until ticket.release()."""
+        torch = _torch()
+        sizes = [int(t.numel()) for t in tensors]
+        offs = np.concatenate(([0], np.cumsum([(n + 63) // 64 * 64 for n in sizes]))).astype(np.int64)
+        slot, buf = self.out_ring().acquire(4 * int(offs[-1]) + 256)
+        host = buf[:4 * int(offs[-1])].view(torch.float32)
+        views = []
+        with torch.cuda.device(self.device):
+            for t, n, o in zip(tensors, sizes, offs[:-1]):
+                dst = host[int(o):int(o) + n].view(tuple(int(x) for x in t.shape))
+                if n:
+                    dst.copy_(t, non_blocking=True)
+                views.append(dst.numpy())
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+        return views, HostTicket(self.out_ring(), slot, ev, list(tensors))
+
+    def output_pcm16(self, y, out_off_host, norm=0.98, async_out=False):
         """
         libaudio.py:352-365 on the device (mpx_pcm16): y float64 or float32 [total] (utterances at out_off_host) ->
         int16 numpy [total], each utterance peak-normalised to `norm` (None: no normalisation) and rounded like
         libsndfile's PCM_16 conversion -- bit-identical to la.write_audio_file's samples.
+        async_out: returns (view of a page-locked ring slot, HostTicket) without waiting for the copy.
         """
         torch = _torch()
         out_off_host = np.asarray(out_off_host, dtype=np.int64)
@@ -161,6 +252,13 @@ class Engine:
                                           d_off.data_ptr(), int(lens.size), int(lens.max()) if lens.size else 0,
                                           float(norm) if norm is not None else 0.0, peaks.data_ptr(), out.data_ptr()),
                        "mpx_pcm16")
+            if async_out:   # non-blocking copy into a page-locked ring slot; the consumer waits on the ticket
+                slot, buf = self.out_ring().acquire(2 * max(total, 1))
+                host = buf[:2 * max(total, 1)].view(torch.int16)
+                host.copy_(out, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(self.device))
+                return host[:total].numpy(), HostTicket(self.out_ring(), slot, ev, [out, peaks, d_off])
             # one D2H copy into a fresh pageable array (pinning a new 15-30 MB buffer per batch cost 7 ms, more than the copy)
             host = torch.empty(max(total, 1), dtype=torch.int16)
             host.copy_(out)
@@ -173,7 +271,7 @@ class Engine:
         st = np.random.get_state()
         if st[0] != "MT19937":
             raise RuntimeError("numpy's global generator is not MT19937")
-        key = torch.from_numpy(np.ascontiguousarray(st[1], dtype=np.uint32).view(np.int32)).to(self.device)
+        key = self.to_device(np.ascontiguousarray(st[1], dtype=np.uint32).view(np.int32), np.int32)
         out = self.empty((max(int(n), 1),))
         raw = torch.empty(max(2 * int(n), 1), dtype=torch.int32, device=self.device)
         state = torch.empty(625, dtype=torch.int32, device=self.device)
@@ -191,20 +289,34 @@ class Engine:
         return out[:int(n)]
 
     def host_staging(self, n_floats):
-        """float32 numpy view [n_floats] of a page-locked staging buffer (grown on demand, reused by every plan)."""
+        """float32 numpy view [n_floats] of a page-locked staging buffer (grown on demand, reused by every plan).  TWO
+        buffers alternate: the DMA out of one (upload_staged, not waited for) runs while the host fills the other for the
+        next plan; a buffer is waited for only when its turn comes again.  Always paired with upload_staged, one thread."""
         torch = _torch()
-        cur = getattr(self, "_stage_up", None)
+        st = getattr(self, "_stage", None)
+        if st is None:
+            st = self._stage = {"bufs": [None, None], "events": [None, None], "cur": 1}
+        k = st["cur"] = 1 - st["cur"]
+        if st["events"][k] is not None:
+            st["events"][k].synchronize()
+            st["events"][k] = None
+        cur = st["bufs"][k]
         if cur is None or cur.numel() < n_floats:   # grown with headroom (batches of a corpus differ a little in length:
             # re-pinning 30 MB for every slightly longer batch cost 40 ms each)
-            self._stage_up = cur = torch.empty(max(int(n_floats * 1.5), 1 << 22), dtype=torch.float32).pin_memory()
+            st["bufs"][k] = cur = torch.empty(max(int(n_floats * 1.5), 1 << 22), dtype=torch.float32).pin_memory()
+        self._stage_up = cur
         return cur.numpy()[:int(n_floats)]
 
     def upload_staged(self, n_floats):
-        """The first n_floats of the staging buffer -> a fresh device tensor (one DMA from pinned memory)."""
+        """The first n_floats of the current staging buffer -> a fresh device tensor (one DMA from pinned memory, in
+        stream order; the buffer is protected by an event until host_staging hands it out again)."""
         torch = _torch()
+        st = self._stage
         with torch.cuda.device(self.device):
             t = self._stage_up[:int(n_floats)].to(self.device, non_blocking=True)
-            torch.cuda.current_stream(self.device).synchronize()   # the buffer is free for the next plan
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.device))
+            st["events"][st["cur"]] = ev
         return t
 
     def to_device_pinned(self, arr, dtype):
@@ -255,7 +367,10 @@ class Engine:
         host = np.zeros(max(total, 1), dtype=np.uint8)
         for off, a in zip(offs, prepared):
             host[off:off + a.nbytes] = a.reshape(-1).view(np.uint8)
-        dev = torch.from_numpy(host).to(self.device, non_blocking=False)
+        if host.nbytes <= self._ARENA_MAX_ITEM:
+            dev = self._arena_upload(host)
+        else:
+            dev = torch.from_numpy(host).to(self.device, non_blocking=False)
         out = {}
         for (name, _arr, dt), off, a in zip(items, offs, prepared):
             if a.nbytes == 0:
@@ -264,10 +379,43 @@ class Engine:
                 out[name] = dev[off:off + a.nbytes].view(tmap[np.dtype(dt)]).view(a.shape)
         return out
 
+    _ARENA_BYTES = 8 << 20
+    _ARENA_MAX_ITEM = 1 << 20
+
+    def _arena_upload(self, a):
+        """A small host array -> device tensor through a page-locked bump arena, WITHOUT blocking: a pageable
+        `tensor.to(device)` waits for everything queued on the stream before it -- after a batch's kernels have been
+        launched that is the whole batch, which serialised the host with the device once per small table.  The arena
+        wraps around after 8 MB of uploads; the wrap synchronises the device once (the copies issued so far have
+        certainly left the arena then)."""
+        import threading
+
+        torch = _torch()
+        ar = getattr(self, "_arena", None)
+        if ar is None:
+            buf = torch.empty(self._ARENA_BYTES, dtype=torch.uint8).pin_memory()
+            ar = self._arena = {"t": buf, "np": buf.numpy(), "off": 0, "lock": threading.Lock()}
+        n = int(a.nbytes)
+        with ar["lock"]:
+            off = (ar["off"] + 255) // 256 * 256
+            if off + n > self._ARENA_BYTES:
+                torch.cuda.synchronize(self.device)
+                off = 0
+            ar["off"] = off + n
+            ar["np"][off:off + n] = a.reshape(-1).view(np.uint8)
+            with torch.cuda.device(self.device):
+                dev = ar["t"][off:off + n].to(self.device, non_blocking=True)
+        tmap = {np.dtype(np.float32): torch.float32, np.dtype(np.float64): torch.float64, np.dtype(np.int32): torch.int32,
+                np.dtype(np.int64): torch.int64, np.dtype(np.uint8): torch.uint8, np.dtype(np.int16): torch.int16}
+        return dev.view(tmap[a.dtype]).view(a.shape)
+
     def to_device(self, arr, dtype):
         torch = _torch()
-        t = torch.from_numpy(np.ascontiguousarray(arr, dtype=dtype))
-        return t.to(self.device, non_blocking=False)
+        a = np.ascontiguousarray(arr, dtype=dtype)
+        if 0 < a.nbytes <= self._ARENA_MAX_ITEM and a.dtype in (np.float32, np.float64, np.int32, np.int64, np.uint8,
+                                                                 np.int16) and a.ndim >= 1:
+            return self._arena_upload(a)
+        return torch.from_numpy(a).to(self.device, non_blocking=False)
 
     def tables(self, fft_len):
         if fft_len not in self._tables:

@@ -279,20 +279,39 @@ def extract_features_corpus(wav_files, out_dir, batch_utts=16, fft_len=None, mag
         return utts, failed
 
     def compute(loaded):
+        # The device results are NOT waited for here: they land in a page-locked ring slot (engine.HostTicket) while this
+        # thread plans the next batch; the writer thread waits for the copy and hands the slot back.
         utts, failed = loaded
-        out = []
+        out, tickets = [], []
         for fs in sorted(set(u[1][1] for u in utts)):
             group = [u for u in utts if u[1][1] == fs]
-            # Q7: the reference forwards alpha_phase=b_mag_fbank_mel (False) -- see mp.analysis_for_acoustic_modelling
-            ok, bad = _isolate(group, lambda g: mp.analysis_compressed_batch(
-                [u[1] for u in g], fft_len=fft_len, mag_dim=mag_dim, phase_dim=phase_dim, b_const_rate=b_const_rate,
-                alpha_phase=False, engine=engine, as_float32=True))
+
+            def analyse(g, whole=len(group)):
+                # Q7: the reference forwards alpha_phase=b_mag_fbank_mel (False) -- see mp.analysis_for_acoustic_modelling
+                kw = dict(fft_len=fft_len, mag_dim=mag_dim, phase_dim=phase_dim, b_const_rate=b_const_rate,
+                          alpha_phase=False, engine=engine, as_float32=True)
+                if len(g) != whole:   # _isolate's one-by-one retries after a failed batch: plain synchronous results (a
+                    return mp.analysis_compressed_batch([u[1] for u in g], **kw)   # ring slot each would exhaust the ring)
+                res, ticket = mp.analysis_compressed_batch([u[1] for u in g], async_out=True, **kw)
+                tickets.append(ticket)
+                return res
+
+            ok, bad = _isolate(group, analyse)
             out.extend((group[i][0], r) for i, r in ok)
             failed = failed + [(_tok(group[i][0]), "%s: %s" % (type(e).__name__, e)) for i, e in bad]
-        return out, failed
+        return out, failed, tickets
 
     def store(res):
-        results, failed = res
+        results, failed, tickets = res
+        for t in tickets:
+            t.wait()
+        try:
+            _store(results, failed)
+        finally:
+            for t in tickets:
+                t.release()
+
+    def _store(results, failed):
         # float32 from the device as it is (what write_featfile stores); all files of the batch in one native call
         paths, bodies, owner = [], [], []
         for f, (m_mag, m_real, m_imag, v_lf0, v_shift, _fs, _n) in results:
@@ -368,30 +387,42 @@ def generate_waveforms_corpus(in_feats_dir, tokens, out_syn_dir, mag_dim, phase_
         return utts, failed
 
     def compute(loaded):
+        # (the device results are not waited for here: see extract_features_corpus.compute)
         utts, failed = loaded
-        out = []
+        out, tickets = [], []
         for rate in sorted(set(u[1] for u in utts)):
             group = [u for u in utts if u[1] == rate]
-            def synth(g):
+            def synth(g, whole=len(group)):
                 kw = {}
                 if noise_mode != "reference":   # seed = a hash of the token: the same wav whatever the batching / sharding
                     kw = {"noise_mode": noise_mode, "noise_seeds": [token_seed(u[0]) for u in g]}
                 # pcm16_norm: la.write_audio_file's peak normalisation and 16-bit conversion done on the device
-                return mp.synthesis_from_compressed_batch([u[2] for u in g], rate, fft_len=fft_len,
-                                                          b_const_rate=b_const_rate,
-                                                          b_post_filter=(pf_type if pf_type != "no" else False),
-                                                          engine=engine,
-                                                          pcm16_norm=0.98, **kw)
+                kw.update(fft_len=fft_len, b_const_rate=b_const_rate, b_post_filter=(pf_type if pf_type != "no" else False),
+                          engine=engine, pcm16_norm=0.98)
+                if len(g) != whole:   # _isolate's one-by-one retries: synchronous results (see extract_features_corpus)
+                    return mp.synthesis_from_compressed_batch([u[2] for u in g], rate, **kw)
+                sigs, ticket = mp.synthesis_from_compressed_batch([u[2] for u in g], rate, async_out=True, **kw)
+                tickets.append(ticket)
+                return sigs
 
             ok, bad = _isolate(group, synth, keep_numpy_rng=(noise_mode == "reference"))
             out.extend((group[i][0], rate, sig) for i, sig in ok)
             failed = failed + [(group[i][0], "%s: %s" % (type(e).__name__, e)) for i, e in bad]
         order = {u[0]: k for k, u in enumerate(utts)}
         out.sort(key=lambda r: order[r[0]])
-        return out, failed
+        return out, failed, tickets
 
     def store(res):
-        results, failed = res
+        results, failed, tickets = res
+        for t in tickets:
+            t.wait()
+        try:
+            _store(results, failed)
+        finally:
+            for t in tickets:
+                t.release()
+
+    def _store(results, failed):
         paths = [os.path.join(out_syn_dir, t + ".wav") for t, _r, _p in results]
         pcms = [np.ascontiguousarray(p, dtype="<i2") for _t, _r, p in results]
         heads = [la.wav_header_pcm16(p.size, rate) for (_t, rate, _p), p in zip(results, pcms)]

@@ -391,8 +391,10 @@ def _output_hpf(v_syn_sig, fs):
 def synthesis_from_compressed_batch(utts, fs, fft_len=None, b_voi_ap_win=True, b_const_rate=False, alpha_phase=None,
                                     b_out_hpf=True, noise=None, engine=None, per_phase_type='magphase',
                                     b_post_filter=False, b_fbank_mel=False, noise_mode='reference', noise_seeds=None,
-                                    pcm16_norm=False):
+                                    pcm16_norm=False, async_out=False):
     """Batched synthesis_from_compressed; utts: list of (m_mag_mel_log, m_real_mel, m_imag_mel, v_lf0).
+    async_out (with pcm16_norm): returns (signals, ticket) -- the int16 signals are views of a page-locked buffer the
+    device is still copying into; ticket.wait() before reading them, ticket.release() when done (engine.HostTicket).
     b_post_filter: apply a post-filter to the log-mel magnitudes on the device first: True / 'magphase' = the MagPhase
     post-filter (pf_type='magphase'), 'merlin' = the Merlin-style one (pf_type='merlin', mpx_post_filter_merlin).
     noise_mode: 'reference' (default) draws the aperiodic source from numpy's global RNG like magphase.py:883;
@@ -408,6 +410,11 @@ def synthesis_from_compressed_batch(utts, fs, fft_len=None, b_voi_ap_win=True, b
     pcm_dev = plan.run()
     if b_out_hpf:   # magphase.py:981-995, float64 on the device (engine.output_hpf); _output_hpf is the host form
         pcm_dev = engine.output_hpf(pcm_dev, plan.out_off_host, fs)
+    if pcm16_norm is not False and async_out:
+        pcm, ticket = engine.output_pcm16(pcm_dev, plan.out_off_host, norm=pcm16_norm, async_out=True)
+        return [pcm[plan.out_off_host[u]:plan.out_off_host[u + 1]] for u in range(len(utts))], ticket
+    if async_out:
+        raise ValueError("async_out needs pcm16_norm")
     if pcm16_norm is not False:
         pcm = engine.output_pcm16(pcm_dev, plan.out_off_host, norm=pcm16_norm)
     elif b_out_hpf:
@@ -454,11 +461,13 @@ def synthesis_from_acoustic_modelling(in_feats_dir, filename_token, out_syn_dir,
 # compressed-feature analysis
 # ======================================================================================================
 def analysis_compressed_batch(utts, fft_len=None, mag_dim=60, phase_dim=10, b_const_rate=False, alpha_phase=None,
-                              engine=None, as_float32=False):
+                              engine=None, as_float32=False, async_out=False):
     """
     Batched magphase.py:2947-2988 for utterances with epochs: utts = list of (v_sig, fs, v_pm_sec, v_voi), one
     sample rate per call.  Lossless analysis (k_analysis) stays on the device; the mel warp runs on it directly.
     Returns a list of (m_mag_mel_log, m_real_mel, m_imag_mel, v_lf0_smth, v_shift, fs, fft_len).
+    async_out (with as_float32): returns (list, ticket) -- the three matrices are views of a page-locked buffer the device
+    is still copying into; ticket.wait() before reading them, ticket.release() when done (engine.HostTicket).
     """
     from scipy import signal
 
@@ -469,7 +478,13 @@ def analysis_compressed_batch(utts, fft_len=None, mag_dim=60, phase_dim=10, b_co
         for n in lens:
             warnings.warn(_WARN_LONG % (plan.fft_len, n))
     # as_float32: the device's float32 values as they are (what the feature files store), no widening to float64
-    h_mag, h_real, h_imag = ((engine.to_host_f32 if as_float32 else engine.to_host_f64)(t_) for t_ in plan.run())
+    ticket = None
+    if async_out:
+        if not as_float32:
+            raise ValueError("async_out needs as_float32")
+        (h_mag, h_real, h_imag), ticket = engine.to_host_f32_async(list(plan.run()))
+    else:
+        h_mag, h_real, h_imag = ((engine.to_host_f32 if as_float32 else engine.to_host_f64)(t_) for t_ in plan.run())
     res = []
     # signal.medfilt of every utterance's f0 in one pass (hostmath.medfilt3_batch: bit-identical; 30 us per scipy call)
     f0_med = hm.medfilt3_batch(plan.f0_out) if len(utts) > 1 else [signal.medfilt(plan.f0_out[0])]
@@ -480,7 +495,7 @@ def analysis_compressed_batch(utts, fft_len=None, mag_dim=60, phase_dim=10, b_co
         v_lf0 = la.f0_to_lf0(v_voi * f0_med[u])                            # magphase.py:2499-2501
         res.append((h_mag[a:b], h_real[a:b], h_imag[a:b], v_lf0, plan.lossless.v_shift[u].astype(int), plan.fs,
                     plan.fft_len))
-    return res
+    return (res, ticket) if async_out else res
 
 
 def format_for_modelling(m_mag, m_real, m_imag, v_f0, fs, mag_dim=60, phase_dim=45, b_mag_fbank_mel=False,
