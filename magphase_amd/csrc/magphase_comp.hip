@@ -265,9 +265,12 @@ __device__ __forceinline__ void noise_fft(const FrameGeom& g, int wtype, const f
         }
         wave_sync();
     }
-    if constexpr (COMPACT) {
-        wave_fft_front_compact<P, -1>(re, im, tw, xbuf, lane, lc, ls);
+    if constexpr (COMPACT) {   // (lc, ls) = W_128^lane from the pad of the lane's table row (k_synth_comp_pair keeps them there)
+        const float4 pk = tw_half_pad<P>(tw, lane);
+        wave_fft_front_compact<P, -1>(re, im, tw, xbuf, lane, pk.z, pk.w);
         fft_inreg<P, -1>(re, im);
+        (void)lc;
+        (void)ls;
     } else {
         wave_fft<P, -1>(re, im, tw, xbuf, lane);
     }
@@ -287,6 +290,11 @@ __device__ __forceinline__ void noise_spectrum_paired(const FrameGeom& g, int wt
     constexpr int LB = ilog2(P);
     float re[P], im[P];
     noise_fft<P, PRESTAGED, COMPACT>(g, wtype, tw, xbuf, xbuf_byte, lane, re, im, lc, ls);
+    if constexpr (COMPACT) {   // the split twiddle W_N^kappa from the table row's pad: not live across the transform
+        const float4 pk = tw_half_pad<P>(tw, lane);
+        wl_c = pk.x;
+        wl_s = pk.y;
+    }
     const int kap = kappa<P>(lane);
     const int src_lane = kappa<P>((64 - kap) & 63);
     const bool lane0 = (kap == 0);
@@ -335,6 +343,11 @@ __device__ __forceinline__ void noise_spectrum(const FrameGeom& g, int wtype, co
     constexpr int LB = ilog2(P);
     float re[P], im[P];
     noise_fft<P, PRESTAGED, COMPACT>(g, wtype, tw, xbuf, xbuf_byte, lane, re, im, lc, ls);
+    if constexpr (COMPACT) {
+        const float4 pk = tw_half_pad<P>(tw, lane);
+        wl_c = pk.x;
+        wl_s = pk.y;
+    }
     // real-FFT split for every own bin (redundant form: each lane evaluates X[k] for all its bins)
     const int kap = kappa<P>(lane);
     const int src_lane = kappa<P>((64 - kap) & 63);
@@ -969,12 +982,17 @@ struct CompFrameTabs {
 // Compressed-feature synthesis + PSOLA, pair form: two waves share one LDS ring and alternate over the frames of the
 // pair's runs (tickets in LDS, exactly as k_synth_ola_pair).  Round 3: 12 waves per CU (three per SIMD, <= 168 VGPRs)
 // instead of 8 -- the kernel is parked in s_waitcnt a third of its wave cycles and moves 1 TB/s, a third wave per SIMD
-// fills those gaps: synthesis side of configs[2] 1.350 -> 1.272 ms (interleaved A/B) with 14 scalar-sized spills left
-// (loop-invariant lane constants; the register allocator's choice of victims is not steerable from the source: removing
-// two of the constants gave 38).  What made it fit: the compact transform front (half-height exchange buffer, noise
-// staged in tiles of 1024 samples: frames longer than that -- f0 below 94 Hz at 48 kHz -- take a second, synchronous
-// tile; half twiddle table), the feature batches of the assembly 2 bin pairs at a time, the overlap-add 16 ring values
-// at a time (ring_add_plane).  The single-wave form it replaced (git
+// fills those gaps: synthesis side of configs[2] 1.350 -> 1.25 ms (interleaved A/B), 0.727 -> 0.632 ms for the launch.
+// What made it fit: the compact transform front (half-height exchange buffer, noise staged in tiles of 1024 samples:
+// frames longer than that -- f0 below 94 Hz at 48 kHz -- take a second, synchronous tile; half twiddle table), the lane
+// constants of the split / merge / compact twiddles kept in the PAD of the lane's table row and read where they are used
+// (tw_half_pad: six registers that are not live across the frame loop), the feature loads in the form SGPR row pointer +
+// one zero-extended 32-bit lane offset (the int-indexed form made a 64-bit address per load: 208 v_lshl_add_u64 and as
+// many register pairs in the ISA), the overlap-add 16 ring values at a time (ring_add_plane).  17 registers still spill
+// (the allocator's choice of victims is not steerable from the source: removing two constants once gave 38, feature
+// batches of 1 bin pair none -- and 11 % more time, the loads in flight are what the kernel lives on: batches of 2 / 4 /
+// 8 pairs 1.273 / 1.253 / 1.294 ms); their scratch lines were being evicted from L2 by the feature stream (+340 MB of
+// HBM traffic per launch), so the feature rows -- read once, by one wave -- are loaded non-temporally: +176 MB.  The single-wave form it replaced (git
 // history) held both feature rows, the per-bin curves and the noise FFT at once (466 VGPRs, ONE wave per SIMD: at one
 // instruction per ~5.4 cycles and wave its ~7.5 k instructions per frame were the whole 1.35 ms).  Here the noise spectrum is
 // computed first and the features are folded into it in place, half a spectrum (16 register rows) at a time:
@@ -1030,7 +1048,16 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_synth_comp_pair(const f
     if constexpr (kCompact) {   // the even registers' twiddles only: entry e of a half row = entry 2 e of the full row
         for (int i = threadIdx.x; i < tw_half_floats<P>(); i += kCompPairWaves * 64) {
             const int l = i / tw_half_stride<P>(), c = i - l * tw_half_stride<P>();
-            tw[i] = (c < P) ? tw_g[l * tw_stride<P>() + 4 * (c >> 1) + (c & 1)] : 0.0f;
+            float v = 0.0f;
+            if (c < P) {
+                v = tw_g[l * tw_stride<P>() + 4 * (c >> 1) + (c & 1)];
+            } else {   // the pad: this lane's constants (tw_half_pad): W_N^{-lane} (cos, sin), W_128^lane (cos, sin)
+                float sn, cs;
+                if (c < P + 2) sincospif(-2.0f * (float)l / (float)N, &sn, &cs);
+                else sincospif((float)l / 64.0f, &sn, &cs);
+                v = ((c - P) & 1) ? sn : cs;
+            }
+            tw[i] = v;
         }
     } else {
         for (int i = threadIdx.x; i < tw_floats<P>(); i += kCompPairWaves * 64) tw[i] = tw_g[i];
@@ -1042,8 +1069,8 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_synth_comp_pair(const f
     float wa_s0, wa_c0, ws_s0, ws_c0;   // analysis-side lane twiddle W_N^kappa and synthesis-side conj(W_N^lane)
     sincospif(-2.0f * (float)kappa<P>(lane_id) / (float)N, &wa_s0, &wa_c0);
     sincospif(2.0f * (float)lane_id / (float)N, &ws_s0, &ws_c0);
-    float lc0 = 1.0f, ls0 = 0.0f;
-    if constexpr (kCompact) sincospif((float)lane_id / 64.0f, &ls0, &lc0);   // W_128^lane: the odd registers' twiddle factor
+    // (compact form: these constants live in the pad of the lane's table row and are read where they are used -- six
+    // registers that are not live across the frame loop)
     const int slot = blockIdx.x * kCompPairs + pair;
     if (slot >= nslots) return;
 
@@ -1090,8 +1117,14 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_synth_comp_pair(const f
 
     while (cur.valid) {
         int lane = lane_id;
-        float wa_s = wa_s0, wa_c = wa_c0, ws_s = ws_s0, ws_c = ws_c0, lc = lc0, ls = ls0;
-        asm volatile("" : "+v"(lane), "+v"(wa_s), "+v"(wa_c), "+v"(ws_s), "+v"(ws_c), "+v"(lc), "+v"(ls));
+        float wa_s = 0.0f, wa_c = 1.0f, ws_s = 0.0f, ws_c = 1.0f;
+        constexpr float lc = 1.0f, ls = 0.0f;
+        if constexpr (kCompact) {
+            asm volatile("" : "+v"(lane));
+        } else {
+            wa_s = wa_s0, wa_c = wa_c0, ws_s = ws_s0, ws_c = ws_c0;
+            asm volatile("" : "+v"(lane), "+v"(wa_s), "+v"(wa_c), "+v"(ws_s), "+v"(ws_c));
+        }
         Cursor nxt = cur;
         advance(nxt);
         const int fi = cur.fi;
@@ -1155,9 +1188,26 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_synth_comp_pair(const f
                     o_i = vi * sgn_scale;
                 };
 #ifndef MPX_COMP_QB
-#define MPX_COMP_QB (MPX_COMP_PAIR_WAVES > 8 ? 2 : 8)
+#define MPX_COMP_QB (MPX_COMP_PAIR_WAVES > 8 ? 4 : 8)
 #endif
                 constexpr int QB = (HP < MPX_COMP_QB) ? HP : MPX_COMP_QB;   // pairs per batch: 10 QB loads in flight
+                // bin M/2 (lane 0) first: every lane loads "its" bin M/2 + lane (a lane-0-only load becomes a scalar load with
+                // an immediate wait, see feat_load_paired); only lane 0's value is used by the merge.  First, because the
+                // split's nh_* then die here instead of living through the whole assembly; at 12 waves per CU the result
+                // waits in the (idle) exchange buffer, not in two registers.
+                {
+                    const bool ph = V && M / 2 < n_per;
+                    const unsigned bl = 4u * (unsigned)lane;
+                    auto gh = [&](const float* row) {
+                        return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(row + M / 2) + (size_t)bl);
+                    };
+                    assemble(gh(mrow), ph ? gh(arow) : 0.0f, ph ? gh(brow) : 0.0f, ph ? gh(per_v) : 0.0f, gh(apc), nh_r, nh_i,
+                             false, xh_r, xh_i);
+                    if constexpr (kCompact) {
+                        xbuf[lane] = xh_r;
+                        xbuf[64 + lane] = xh_i;
+                    }
+                }
 #pragma unroll
                 for (int h = 0; h < HP / QB; ++h) {
                     float m0[QB], a0[QB], b0[QB], c0[QB], d0[QB], m1[QB], a1[QB], b1[QB], c1[QB], d1[QB];
@@ -1175,26 +1225,53 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_synth_comp_pair(const f
                                            "v"(nm_r[c + 2]), "v"(nm_r[c + 3]), "v"(nm_i[c]), "v"(nm_i[c + 1]), "v"(nm_i[c + 2]),
                                            "v"(nm_i[c + 3]));
                     }
-                    const int hi_ = M - lo;
+                    // UNSIGNED element offsets: the loads then take the row pointer from SGPRs and a zero-extended 32-bit
+                    // offset (global_load_dword v, v, s[..] offset:imm); with int offsets every load got its own 64-bit
+                    // address (v_lshl_add_u64 + a register pair: 208 of them in the kernel's ISA)
+                    // the row pointer (+ the constant part of the index) stays in SGPRs, the lane part is ONE zero-extended
+                    // 32-bit byte offset
+                    const unsigned blo = 4u * (unsigned)lo, bhi = 4u * (unsigned)(M - lo);
+#ifndef MPX_COMP_SADDR
+#define MPX_COMP_SADDR 1
+#endif
+#ifndef MPX_COMP_NT
+#define MPX_COMP_NT 1   // feature rows are read once, by one wave: non-temporal loads keep them from evicting the waves'
+#endif                  // scratch lines (17 spilled registers at 12 waves per CU) out of L2: 1 132 -> 970 MB per launch
+                    auto gl = [](const float* row, int kel, unsigned boff) {
+#if MPX_COMP_SADDR && MPX_COMP_NT
+                        return __builtin_nontemporal_load(
+                            reinterpret_cast<const float*>(reinterpret_cast<const char*>(row + kel) + (size_t)boff));
+#elif MPX_COMP_SADDR
+                        return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(row + kel) + (size_t)boff);
+#else
+                        return row[kel + (int)(boff >> 2)];
+#endif
+                    };
 #pragma unroll
                     for (int jj = 0; jj < QB; ++jj) {
                         const int k = 64 * (h * QB + jj);
-                        m0[jj] = mrow[lo + k];
-                        d0[jj] = apc[lo + k];
-                        m1[jj] = mrow[hi_ - k];
-                        d1[jj] = apc[hi_ - k];
+                        m0[jj] = gl(mrow, k, blo);
+                        d0[jj] = gl(apc, k, blo);
+                        m1[jj] = gl(mrow, -k, bhi);
+                        d1[jj] = gl(apc, -k, bhi);
                         // the periodic curve is zero from bin n_per on (above the crossfade): the phase rows and the curve
                         // are read only for the register rows that reach below it (wave-uniform conditions)
                         a0[jj] = b0[jj] = c0[jj] = a1[jj] = b1[jj] = c1[jj] = 0.0f;
+                        // (the offset is laundered inside the conditional block: instruction selection works block by block
+                        // and only recognises base + zext(offset) when the zero-extension sits in the same block)
                         if (V && k < n_per) {               // own bins lane + k
-                            a0[jj] = arow[lo + k];
-                            b0[jj] = brow[lo + k];
-                            c0[jj] = per_v[lo + k];
+                            unsigned bq = blo;
+                            asm volatile("" : "+v"(bq));
+                            a0[jj] = gl(arow, k, bq);
+                            b0[jj] = gl(brow, k, bq);
+                            c0[jj] = gl(per_v, k, bq);
                         }
                         if (V && M - k - 63 < n_per) {      // mirrors M - lane - k
-                            a1[jj] = arow[hi_ - k];
-                            b1[jj] = brow[hi_ - k];
-                            c1[jj] = per_v[hi_ - k];
+                            unsigned bq = bhi;
+                            asm volatile("" : "+v"(bq));
+                            a1[jj] = gl(arow, -k, bq);
+                            b1[jj] = gl(brow, -k, bq);
+                            c1[jj] = gl(per_v, -k, bq);
                         }
                     }
 #pragma unroll
@@ -1205,14 +1282,16 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_synth_comp_pair(const f
                         assemble(m1[jj], a1[jj], b1[jj], c1[jj], d1[jj], nm_r[q], nm_i[q], ends, nm_r[q], nm_i[q]);
                     }
                 }
-                // bin M/2 (lane 0): every lane loads "its" bin M/2 + lane (a lane-0-only load becomes a scalar load with an
-                // immediate wait, see feat_load_paired); only lane 0's value is used by the merge
-                const bool ph = V && M / 2 < n_per;
-                assemble(mrow[M / 2 + lane], ph ? arow[M / 2 + lane] : 0.0f, ph ? brow[M / 2 + lane] : 0.0f,
-                         ph ? per_v[M / 2 + lane] : 0.0f, apc[M / 2 + lane], nh_r, nh_i, false, xh_r, xh_i);
             };
             if (voiced) assemble_all(std::true_type{});
             else assemble_all(std::false_type{});
+            if constexpr (kCompact) {   // kappa(lane) == lane: the synthesis-side twiddle is the conjugate of the split's
+                const float4 pk = tw_half_pad<P>(tw, lane);
+                ws_c = pk.x;
+                ws_s = -pk.y;
+                xh_r = xbuf[lane];
+                xh_i = xbuf[64 + lane];
+            }
             merge_paired_complex<P>(no_r, no_i, nm_r, nm_i, xh_r, xh_i, xr, xi, lane, ws_c, ws_s);
         } else {
             // ---- aperiodic source: spectrum of this frame's windowed noise, bins k = lane + 64 j
@@ -1307,10 +1386,19 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_synth_comp_pair(const f
                 xm = __builtin_sqrtf(vr * vr + vi * vi) * (0.5f / (float)M);   // (-1)^M = +1
             }
 
+            if constexpr (kCompact) {
+                const float4 pk = tw_half_pad<P>(tw, lane);
+                ws_c = pk.x;
+                ws_s = -pk.y;
+            }
             hermitian_merge<P>(xr, xi, xm, lane, ws_c, ws_s);
         }
-        if constexpr (kCompact) wave_fft_front_compact<P, +1>(xr, xi, tw, xbuf, lane, lc, ls);
-        else wave_fft_front<P, +1>(xr, xi, tw, xbuf, lane);
+        if constexpr (kCompact) {
+            const float4 pk = tw_half_pad<P>(tw, lane);
+            wave_fft_front_compact<P, +1>(xr, xi, tw, xbuf, lane, pk.z, pk.w);
+        } else {
+            wave_fft_front<P, +1>(xr, xi, tw, xbuf, lane);
+        }
         if (nxt.valid) {   // the exchange buffer is idle from here on: start the copy of the next frame's noise
             g = frame_geom(noise, tb.npos[nxt.fi], tb.nleft[nxt.fi], tb.nright[nxt.fi], N);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

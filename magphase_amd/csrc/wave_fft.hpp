@@ -429,6 +429,14 @@ __host__ __device__ constexpr int tw_half_stride() { return P + 4; }
 template <int P>
 __host__ __device__ constexpr int tw_half_floats() { return 64 * tw_half_stride<P>(); }
 
+// The four padding floats of a lane's half-table row: a kernel may keep per-lane constants there and read them where they
+// are used (one ds_read_b128) instead of holding them in registers across its frame loop (k_synth_comp_pair at <= 168
+// VGPRs: (cos, sin) of the split twiddle and W_128^lane).
+template <int P>
+__device__ __forceinline__ float4 tw_half_pad(const float* twh, int lane) {
+    return *reinterpret_cast<const float4*>(twh + lane * tw_half_stride<P>() + P);
+}
+
 // NAT: the input registers are in natural order (register i holds k1 = i: the DIT first pass) instead of bit-reversed.
 template <int P, bool NAT = false>
 __device__ __forceinline__ void lds_transpose_half(float (&x)[P], float* xbuf, int lane) {
