@@ -22,12 +22,12 @@ def write_est(path, v_pm_sec, v_voi):
             f.write("%.6f %d 0.0\n" % (t, int(v)))
 
 
-def main(n=3, out_dir=None):
+def main(n=3, out_dir=None, dur_s=None):
     out_dir = out_dir or os.path.join(HERE, "data_48k", "wavs_nat")
     os.makedirs(out_dir, exist_ok=True)
     toks = []
     for u in range(n):
-        pcm, pm, voi = syn.make_utterance(500 + u, dur_s=2.0 + 0.5 * u, fs=48000)
+        pcm, pm, voi = syn.make_utterance(500 + u, dur_s=(2.0 + 0.5 * u) if dur_s is None else dur_s + 0.05 * u, fs=48000)
         tok = "syn_%03d" % u
         la.write_audio_file(os.path.join(out_dir, tok + ".wav"), pcm / 32768.0, 48000, norm=None)
         write_est(os.path.join(out_dir, tok + ".est"), pm, voi)

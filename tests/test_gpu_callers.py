@@ -98,6 +98,48 @@ def test_corpus_batching_equals_the_per_file_calls(tmp_path):
     assert _wav_len(str(tmp_path / "gen3" / "hvd_704.wav"))[0] > 40000
 
 
+def test_output_ring_wraps_and_small_uploads_wrap_their_arena(tmp_path):
+    """The compute stage of iobatch does not wait for the device: results land in a 4-slot page-locked ring that the writer
+    thread hands back (engine.HostTicket), small tables go up through an 8 MB page-locked arena that wraps around.  Nine
+    batches of one utterance (the ring wraps twice) with a 64 KB arena (it wraps every batch) must write the files of one
+    batch of nine; the failed-batch path (one bad utterance -> one-by-one retries, synchronous) still isolates the failure."""
+    sys.path.insert(0, os.path.join(ROOT, "demos"))
+    import make_demo_data
+    from magphase_amd import iobatch
+    from magphase_amd.engine import Engine
+    wav_dir = tmp_path / "wavs"
+    toks = make_demo_data.main(n=9, out_dir=str(wav_dir), dur_s=0.6)
+    wavs = [str(wav_dir / (t + ".wav")) for t in toks]
+    eng_small = Engine()
+    eng_small._ARENA_BYTES = 1 << 16
+    eng_small._ARENA_MAX_ITEM = 1 << 13
+    a_dir, b_dir = tmp_path / "a", tmp_path / "b"
+    assert iobatch.extract_features_corpus(wavs, str(a_dir), batch_utts=9, phase_dim=45, verbose=False) == 1
+    assert iobatch.extract_features_corpus(wavs, str(b_dir), batch_utts=1, phase_dim=45, verbose=False,
+                                           engine=eng_small) == 9
+    for t in toks:
+        for ext in (".mag", ".real", ".imag", ".lf0", ".shift"):
+            a = np.fromfile(str(a_dir / (t + ext)), dtype=np.float32)
+            b = np.fromfile(str(b_dir / (t + ext)), dtype=np.float32)
+            assert a.size == b.size and np.array_equal(a, b), (t, ext)
+    g1, g2 = tmp_path / "g1", tmp_path / "g2"
+    kw = dict(pf_type="magphase", verbose=False, noise_mode="device")   # per-token seeds: independent of the batching
+    iobatch.generate_waveforms_corpus(str(a_dir), toks, str(g1), 60, 45, 48000, batch_utts=9, **kw)
+    iobatch.generate_waveforms_corpus(str(b_dir), toks, str(g2), 60, 45, 48000, batch_utts=1, engine=eng_small, **kw)
+    for t in toks:
+        assert (g1 / (t + ".wav")).read_bytes() == (g2 / (t + ".wav")).read_bytes(), t
+    # a truncated feature file in the middle of a batch: the other utterances of the batch are written, the token is listed
+    bad = toks[4]
+    with open(str(a_dir / (bad + ".lf0")), "r+b") as fh:
+        fh.truncate(40)
+    rep = iobatch.CorpusReport()
+    iobatch.generate_waveforms_corpus(str(a_dir), toks, str(tmp_path / "g3"), 60, 45, 48000, batch_utts=3, report=rep, **kw)
+    assert [t for t, _m in rep["failed"]] == [bad] and rep["done"] == 8
+    for t in toks:
+        if t != bad:
+            assert (tmp_path / "g3" / (t + ".wav")).read_bytes() == (g1 / (t + ".wav")).read_bytes(), t
+
+
 def test_pinned_d2h_matches_plain_copy():
     import torch
     from magphase_amd.engine import get_engine
