@@ -112,6 +112,43 @@ def test_unwarp_rows_equals_unwarp_then_interpolation(golden_dir):
             assert np.max(np.abs(got - want)) < 2e-6                 # 45-term fp32 sums in a different association
 
 
+def test_row_table_form_of_the_synthesis_kernel(golden_dir):
+    """mpx_synthesis_compressed_ola with row0 / row1 / row_t (the kernel interpolates between constant-rate spectrum rows
+    itself: the C ABI's other form -- the Python side interpolates in the unwarp instead) against the plan's own run."""
+    import torch
+    from magphase_amd import _lib
+    from magphase_amd.engine import CompressedSynthesisPlan, get_engine
+    g = np.load(os.path.join(golden_dir, "g8_compressed_analysis.npz"))
+    e = get_engine()
+    np.random.seed(3)
+    plan = CompressedSynthesisPlan(e, [(g["cr45_mag"], g["cr45_real"], g["cr45_imag"], g["cr45_lf0"])], int(g["fs"]),
+                                   b_const_rate=True)
+    want = plan.run(keep=True).clone()
+    N = plan.fft_len
+    H = N // 2 + 1
+    ld = int(e.lib.mpx_spec_ld(H))
+    full = [e.empty((plan.n_rows, ld))[:, :H] for _ in range(3)]
+    _lib.check(e.lib.mpx_mel_unwarp(e.stream_ptr(), plan.n_rows, H, plan.a_mag.data_ptr(), plan.mag_dim,
+                                    plan.u_mag.data_ptr(), full[0].data_ptr(), plan.a_real.data_ptr(),
+                                    plan.a_imag.data_ptr(), plan.phase_dim, plan.u_phase.data_ptr(), full[1].data_ptr(),
+                                    full[2].data_ptr(), ld), "mpx_mel_unwarp")
+    buf = plan._buffers()
+    strips = torch.zeros_like(buf["strips"])
+    pcm = torch.zeros_like(want)
+    _lib.check(e.lib.mpx_synthesis_compressed_ola(
+        e.stream_ptr(), N, e.tables(N).data_ptr(), full[0].data_ptr(), full[1].data_ptr(), full[2].data_ptr(),
+        plan.noise.data_ptr(), plan.npos.data_ptr(), plan.nleft.data_ptr(), plan.nright.data_ptr(), plan.wtype.data_ptr(),
+        plan.voiced.data_ptr(), buf["inv_gain"].data_ptr(), plan.row0.data_ptr(), plan.row1.data_ptr(), plan.rowt.data_ptr(),
+        plan.win_l.data_ptr(), plan.win_r.data_ptr(), plan.pm_rel.data_ptr(), plan.per_v.data_ptr(), plan.ap_v.data_ptr(),
+        plan.ap_u.data_ptr(), plan.runs.data_ptr(), plan.n_runs, plan.slot_off.data_ptr(), plan.slot_runs.data_ptr(),
+        plan.n_slots, strips.data_ptr(), pcm.data_ptr(), ld, 0), "mpx_synthesis_compressed_ola")
+    e.ola_fixup(N, plan, strips, pcm)
+    torch.cuda.synchronize()
+    a, b = pcm.cpu().numpy().astype(np.float64), want.cpu().numpy().astype(np.float64)
+    assert np.max(np.abs(b)) > 1e-3
+    within(np.max(np.abs(a - b)) / max(1.0, np.max(np.abs(b))), COMP_PCM_TOL, "COMP_PCM_TOL:row_tables")
+
+
 def test_generation_from_predicted_features_matches_reference_golden(mp, golden_dir):
     g, mm, rr, ii, lf = _hvd704(golden_dir)
     seed = int(g["seed"])
