@@ -988,11 +988,12 @@ struct CompFrameTabs {
 // constants of the split / merge / compact twiddles kept in the PAD of the lane's table row and read where they are used
 // (tw_half_pad: six registers that are not live across the frame loop), the feature loads in the form SGPR row pointer +
 // one zero-extended 32-bit lane offset (the int-indexed form made a 64-bit address per load: 208 v_lshl_add_u64 and as
-// many register pairs in the ISA), the overlap-add 16 ring values at a time (ring_add_plane).  17 registers still spill
-// (the allocator's choice of victims is not steerable from the source: removing two constants once gave 38, feature
-// batches of 1 bin pair none -- and 11 % more time, the loads in flight are what the kernel lives on: batches of 2 / 4 /
-// 8 pairs 1.273 / 1.253 / 1.294 ms); their scratch lines were being evicted from L2 by the feature stream (+340 MB of
-// HBM traffic per launch), so the feature rows -- read once, by one wave -- are loaded non-temporally: +176 MB.  The single-wave form it replaced (git
+// many register pairs in the ISA), the overlap-add 16 ring values at a time (ring_add_plane), and -- what finally removed
+// the spills -- the assembly's load batches sized by what a row can need (template parameter NPQ below): with room for 10
+// values per bin pair on every row, batches of 1 / 2 / 4 pairs spilled 0 / 6-18 / 17 registers at 1.448 / 1.273 / 1.253
+// ms (the loads in flight are what the kernel lives on), and the spilled registers' scratch lines, evicted from L2 by the
+// feature stream, cost 176-340 MB of HBM traffic per launch.  The feature rows -- read once, by one wave -- are loaded
+// non-temporally.  The single-wave form it replaced (git
 // history) held both feature rows, the per-bin curves and the noise FFT at once (466 VGPRs, ONE wave per SIMD: at one
 // instruction per ~5.4 cycles and wave its ~7.5 k instructions per frame were the whole 1.35 ms).  Here the noise spectrum is
 // computed first and the features are folded into it in place, half a spectrum (16 register rows) at a time:
@@ -1016,7 +1017,14 @@ constexpr size_t lds_bytes_comp_pair() {
 
 // LERP: every frame interpolates between two spectrum rows (row0 / row1 / rowt tables); false: one row per frame, row
 // index = frame index (variable-rate input, or rows already interpolated by mpx_mel_unwarp_rows) -- half the feature loads.
-template <int P, bool LERP>
+// NPQ >= 0 (one-row-per-frame form): the caller's promise n_per <= 64 NPQ at compile time -- only the own bins of the
+// register rows q < NPQ can have a periodic component, no mirror bin has (M - k > 64 NPQ).  The assembly then loads 7
+// values per bin pair on those rows and 4 on the others instead of keeping room for 10 everywhere: batches of (4, 4, 8)
+// pairs = 28 / 28 / 32 loads in flight for P == 32, NPQ == 8 (48 / 44.1 kHz: the crossfade ends at bin 512), against
+// four batches of 40 -- the 17 registers the 40-wide batches spilled at 12 waves per CU are gone (166 VGPRs, no scratch),
+// and the freed registers allow batches of (8, 8) = 56 / 32 loads: two exposed load latencies per frame instead of four.
+// NPQ < 0: anything goes (run-time tests only).
+template <int P, bool LERP, int NPQ = -1>
 __global__ __launch_bounds__(kCompPairWaves * 64) void k_synth_comp_pair(const float* __restrict__ mag,
                                                                         const float* __restrict__ real,
                                                                         const float* __restrict__ imag,
@@ -1190,6 +1198,12 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_synth_comp_pair(const f
 #ifndef MPX_COMP_QB
 #define MPX_COMP_QB (MPX_COMP_PAIR_WAVES > 8 ? 4 : 8)
 #endif
+#ifndef MPX_COMP_SADDR
+#define MPX_COMP_SADDR 1
+#endif
+#ifndef MPX_COMP_NT
+#define MPX_COMP_NT 1   // feature rows are read once, by one wave: non-temporal loads keep them from evicting the other
+#endif                  // waves' lines (and any scratch lines) out of L2
                 constexpr int QB = (HP < MPX_COMP_QB) ? HP : MPX_COMP_QB;   // pairs per batch: 10 QB loads in flight
                 // bin M/2 (lane 0) first: every lane loads "its" bin M/2 + lane (a lane-0-only load becomes a scalar load with
                 // an immediate wait, see feat_load_paired); only lane 0's value is used by the merge.  First, because the
@@ -1208,35 +1222,30 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_synth_comp_pair(const f
                         xbuf[64 + lane] = xh_i;
                     }
                 }
-#pragma unroll
-                for (int h = 0; h < HP / QB; ++h) {
-                    float m0[QB], a0[QB], b0[QB], c0[QB], d0[QB], m1[QB], a1[QB], b1[QB], c1[QB], d1[QB];
+                // one batch = the bin pairs q0 .. q0 + QN - 1; OWN / MIR: their own / mirror bins may carry a periodic component
+                auto batch = [&](auto q0_, auto qn_, auto own_, auto mir_) {
+                    constexpr int Q0 = decltype(q0_)::value, QN = decltype(qn_)::value;
+                    constexpr bool OWN = V && decltype(own_)::value, MIR = V && decltype(mir_)::value;
+                    float m0[QN], d0[QN], m1[QN], d1[QN], a0[OWN ? QN : 1], b0[OWN ? QN : 1], c0[OWN ? QN : 1];
+                    float a1[MIR ? QN : 1], b1[MIR ? QN : 1], c1[MIR ? QN : 1];
                     // keep each batch's loads where they are written (the compiler moves loads of read-only memory across
                     // plain barriers; hoisted above the noise spectrum they spill): the lane offset is laundered with a fake
                     // dependency on what has been produced so far
                     int lo = lane;
                     {
-                        const int q0 = (h == 0) ? 0 : (h - 1) * QB, q1 = (h == 0) ? HP : h * QB;
+                        constexpr int c0_ = (Q0 == 0) ? 0 : ((Q0 >= 4) ? Q0 - 4 : 0), c1_ = (Q0 == 0) ? HP : Q0;
 #pragma unroll
-                        for (int c = q0; c < q1; c += 4)
+                        for (int c = c0_; c < c1_; c += 4)
                             asm volatile("" : "+v"(lo)
                                          : "v"(no_r[c]), "v"(no_r[c + 1]), "v"(no_r[c + 2]), "v"(no_r[c + 3]), "v"(no_i[c]),
                                            "v"(no_i[c + 1]), "v"(no_i[c + 2]), "v"(no_i[c + 3]), "v"(nm_r[c]), "v"(nm_r[c + 1]),
                                            "v"(nm_r[c + 2]), "v"(nm_r[c + 3]), "v"(nm_i[c]), "v"(nm_i[c + 1]), "v"(nm_i[c + 2]),
                                            "v"(nm_i[c + 3]));
                     }
-                    // UNSIGNED element offsets: the loads then take the row pointer from SGPRs and a zero-extended 32-bit
-                    // offset (global_load_dword v, v, s[..] offset:imm); with int offsets every load got its own 64-bit
-                    // address (v_lshl_add_u64 + a register pair: 208 of them in the kernel's ISA)
                     // the row pointer (+ the constant part of the index) stays in SGPRs, the lane part is ONE zero-extended
-                    // 32-bit byte offset
+                    // 32-bit byte offset (global_load_dword v, v, s[..] offset:imm); with int element indices every load got
+                    // its own 64-bit address (v_lshl_add_u64 + a register pair: 208 of them in the kernel's ISA)
                     const unsigned blo = 4u * (unsigned)lo, bhi = 4u * (unsigned)(M - lo);
-#ifndef MPX_COMP_SADDR
-#define MPX_COMP_SADDR 1
-#endif
-#ifndef MPX_COMP_NT
-#define MPX_COMP_NT 1   // feature rows are read once, by one wave: non-temporal loads keep them from evicting the waves'
-#endif                  // scratch lines (17 spilled registers at 12 waves per CU) out of L2: 1 132 -> 970 MB per launch
                     auto gl = [](const float* row, int kel, unsigned boff) {
 #if MPX_COMP_SADDR && MPX_COMP_NT
                         return __builtin_nontemporal_load(
@@ -1248,39 +1257,81 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_synth_comp_pair(const f
 #endif
                     };
 #pragma unroll
-                    for (int jj = 0; jj < QB; ++jj) {
-                        const int k = 64 * (h * QB + jj);
+                    for (int jj = 0; jj < QN; ++jj) {
+                        const int k = 64 * (Q0 + jj);
                         m0[jj] = gl(mrow, k, blo);
                         d0[jj] = gl(apc, k, blo);
                         m1[jj] = gl(mrow, -k, bhi);
                         d1[jj] = gl(apc, -k, bhi);
                         // the periodic curve is zero from bin n_per on (above the crossfade): the phase rows and the curve
                         // are read only for the register rows that reach below it (wave-uniform conditions)
-                        a0[jj] = b0[jj] = c0[jj] = a1[jj] = b1[jj] = c1[jj] = 0.0f;
                         // (the offset is laundered inside the conditional block: instruction selection works block by block
                         // and only recognises base + zext(offset) when the zero-extension sits in the same block)
-                        if (V && k < n_per) {               // own bins lane + k
-                            unsigned bq = blo;
-                            asm volatile("" : "+v"(bq));
-                            a0[jj] = gl(arow, k, bq);
-                            b0[jj] = gl(brow, k, bq);
-                            c0[jj] = gl(per_v, k, bq);
+                        if constexpr (OWN) {
+                            a0[jj] = b0[jj] = c0[jj] = 0.0f;
+                            if (k < n_per) {               // own bins lane + k
+                                unsigned bq = blo;
+                                asm volatile("" : "+v"(bq));
+                                a0[jj] = gl(arow, k, bq);
+                                b0[jj] = gl(brow, k, bq);
+                                c0[jj] = gl(per_v, k, bq);
+                            }
                         }
-                        if (V && M - k - 63 < n_per) {      // mirrors M - lane - k
-                            unsigned bq = bhi;
-                            asm volatile("" : "+v"(bq));
-                            a1[jj] = gl(arow, -k, bq);
-                            b1[jj] = gl(brow, -k, bq);
-                            c1[jj] = gl(per_v, -k, bq);
+                        if constexpr (MIR) {
+                            a1[jj] = b1[jj] = c1[jj] = 0.0f;
+                            if (M - k - 63 < n_per) {      // mirrors M - lane - k
+                                unsigned bq = bhi;
+                                asm volatile("" : "+v"(bq));
+                                a1[jj] = gl(arow, -k, bq);
+                                b1[jj] = gl(brow, -k, bq);
+                                c1[jj] = gl(per_v, -k, bq);
+                            }
                         }
                     }
 #pragma unroll
-                    for (int jj = 0; jj < QB; ++jj) {
-                        const int q = h * QB + jj;
+                    for (int jj = 0; jj < QN; ++jj) {
+                        const int q = Q0 + jj;
                         const bool ends = (q == 0) && (lane == 0);   // the (DC, Nyquist) pair
-                        assemble(m0[jj], a0[jj], b0[jj], c0[jj], d0[jj], no_r[q], no_i[q], ends, no_r[q], no_i[q]);
-                        assemble(m1[jj], a1[jj], b1[jj], c1[jj], d1[jj], nm_r[q], nm_i[q], ends, nm_r[q], nm_i[q]);
+                        assemble(m0[jj], OWN ? a0[OWN ? jj : 0] : 0.0f, OWN ? b0[OWN ? jj : 0] : 0.0f,
+                                 OWN ? c0[OWN ? jj : 0] : 0.0f, d0[jj], no_r[q], no_i[q], ends, no_r[q], no_i[q]);
+                        assemble(m1[jj], MIR ? a1[MIR ? jj : 0] : 0.0f, MIR ? b1[MIR ? jj : 0] : 0.0f,
+                                 MIR ? c1[MIR ? jj : 0] : 0.0f, d1[jj], nm_r[q], nm_i[q], ends, nm_r[q], nm_i[q]);
                     }
+                };
+                using std::integral_constant;
+                constexpr auto yes = std::true_type{};
+                constexpr auto no = std::false_type{};
+#ifndef MPX_COMP_QA
+#define MPX_COMP_QA 8   // pairs per batch on the rows with phase (7 loads per pair); (QA, QR) = (8, 8) / (4, 8) / (4, 4) /
+                        // (2, 8): 1.182 / 1.191 / 1.193 / 1.201 ms for the synthesis side of configs[2], none spills
+#endif
+#ifndef MPX_COMP_QR
+#define MPX_COMP_QR 8   // pairs per batch on the rows without (4 loads per pair)
+#endif
+                if constexpr (NPQ >= 0 && P == 32 && NPQ == 8) {   // (4, 4, 8): rows 0-7 with the own bins' phase, rows 8-15 without
+                    constexpr int QA = MPX_COMP_QA, QR = MPX_COMP_QR;
+                    static_assert(8 % QA == 0 && 8 % QR == 0, "MPX_COMP_QA / MPX_COMP_QR divide 8");
+                    batch(integral_constant<int, 0>{}, integral_constant<int, QA>{}, yes, no);
+                    if constexpr (QA < 8) batch(integral_constant<int, QA>{}, integral_constant<int, QA>{}, yes, no);
+                    if constexpr (QA < 4) batch(integral_constant<int, 2 * QA>{}, integral_constant<int, QA>{}, yes, no);
+                    if constexpr (QA < 4) batch(integral_constant<int, 3 * QA>{}, integral_constant<int, QA>{}, yes, no);
+                    batch(integral_constant<int, 8>{}, integral_constant<int, QR>{}, no, no);
+                    if constexpr (QR < 8) batch(integral_constant<int, 8 + QR>{}, integral_constant<int, QR>{}, no, no);
+                    if constexpr (QR < 4) batch(integral_constant<int, 8 + 2 * QR>{}, integral_constant<int, QR>{}, no, no);
+                    if constexpr (QR < 4) batch(integral_constant<int, 8 + 3 * QR>{}, integral_constant<int, QR>{}, no, no);
+                } else {
+                    static_assert(NPQ < 0 || (P == 32 && NPQ == 8), "k_synth_comp_pair: NPQ schedules exist for P == 32, NPQ == 8");
+                    static_assert(QB == 1 || QB == 2 || QB == 4 || QB == 8 || QB == 16, "MPX_COMP_QB");
+                    // uniform batches of QB pairs (unrolled by hand: the batch sizes are template arguments)
+                    if constexpr (HP / QB >= 1) batch(integral_constant<int, 0 * QB>{}, integral_constant<int, QB>{}, yes, yes);
+                    if constexpr (HP / QB >= 2) batch(integral_constant<int, 1 * QB>{}, integral_constant<int, QB>{}, yes, yes);
+                    if constexpr (HP / QB >= 3) batch(integral_constant<int, 2 * QB>{}, integral_constant<int, QB>{}, yes, yes);
+                    if constexpr (HP / QB >= 4) batch(integral_constant<int, 3 * QB>{}, integral_constant<int, QB>{}, yes, yes);
+                    if constexpr (HP / QB >= 5) batch(integral_constant<int, 4 * QB>{}, integral_constant<int, QB>{}, yes, yes);
+                    if constexpr (HP / QB >= 6) batch(integral_constant<int, 5 * QB>{}, integral_constant<int, QB>{}, yes, yes);
+                    if constexpr (HP / QB >= 7) batch(integral_constant<int, 6 * QB>{}, integral_constant<int, QB>{}, yes, yes);
+                    if constexpr (HP / QB >= 8) batch(integral_constant<int, 7 * QB>{}, integral_constant<int, QB>{}, yes, yes);
+                    static_assert(HP / QB <= 8, "more batches than the hand-unrolled schedule covers");
                 }
             };
             if (voiced) assemble_all(std::true_type{});
@@ -2163,7 +2214,12 @@ int mpx_synthesis_compressed_ola(void* stream, int fft_len, const void* tables, 
         else if (P == 16) MPX_LAUNCH_COMP(16, true);
         else MPX_LAUNCH_COMP(8, true);
     } else {
-        if (P == 32) MPX_LAUNCH_COMP(32, false);
+        if (P == 32 && n_per <= 512) {   // the crossfade ends at or below bin 512 (48 / 44.1 kHz): the NPQ == 8 schedule
+            if (int rc = set_lds(k_synth_comp_pair<32, false, 8>, lds_bytes_comp_pair<32>())) return rc;
+            hipLaunchKernelGGL((k_synth_comp_pair<32, false, 8>), pgrid, pblock, lds_bytes_comp_pair<32>(), s, mag, real, imag,
+                               noise, tb, per_v, ap_v, ap_u, (const RunDesc*)runs, slot_off, slot_runs, (int)n_slots,
+                               (const float*)tables, strips, pcm_out, (long long)ld, n_per);
+        } else if (P == 32) MPX_LAUNCH_COMP(32, false);
         else if (P == 16) MPX_LAUNCH_COMP(16, false);
         else MPX_LAUNCH_COMP(8, false);
     }
