@@ -13,6 +13,11 @@
 #ifndef MPX_COMP_PAIR_WAVES
 #define MPX_COMP_PAIR_WAVES 12
 #endif
+#ifndef MPX_COMP_DIT
+#define MPX_COMP_DIT 0   // 1: both transforms of the compact form in the DIT form (fused multiply-add butterflies,
+                         // wave_fft.hpp; parity-green).  Measured: 1.186 vs 1.195-1.205 ms for the synthesis side of configs[2]
+                         // (-1 %), but 10 registers spill again at 12 waves per CU (scratch traffic): off.
+#endif
 
 namespace mpx {
 
@@ -259,16 +264,22 @@ __device__ __forceinline__ void noise_fft(const FrameGeom& g, int wtype, const f
                 k0 = (k0 >= N) ? k0 - N : k0;
                 int k1 = m + 1 + g.rot;
                 k1 = (k1 >= N) ? k1 - N : k1;
-                if (k0 >= tile0 && k0 < hi) re[j] = xbuf[k0 - tile0];
-                if (k1 >= tile0 && k1 < hi) im[j] = xbuf[k1 - tile0];
+                constexpr int LBJ = ilog2(P);
+                const int rj = (COMPACT && MPX_COMP_DIT) ? brev(j, LBJ) : j;   // the DIT form wants register brev(j) <- z[l + 64 j]
+                if (k0 >= tile0 && k0 < hi) re[rj] = xbuf[k0 - tile0];
+                if (k1 >= tile0 && k1 < hi) im[rj] = xbuf[k1 - tile0];
             }
         }
         wave_sync();
     }
     if constexpr (COMPACT) {   // (lc, ls) = W_128^lane from the pad of the lane's table row (k_synth_comp_pair keeps them there)
         const float4 pk = tw_half_pad<P>(tw, lane);
+#if MPX_COMP_DIT
+        wave_fft_dit_compact<P, -1>(re, im, tw, xbuf, lane, pk.z, pk.w);   // output: register i <-> Z[lane + 64 i]
+#else
         wave_fft_front_compact<P, -1>(re, im, tw, xbuf, lane, pk.z, pk.w);
         fft_inreg<P, -1>(re, im);
+#endif
         (void)lc;
         (void)ls;
     } else {
@@ -308,17 +319,19 @@ __device__ __forceinline__ void noise_spectrum_paired(const FrameGeom& g, int wt
 #pragma unroll
     for (int qb = 0; qb < P / 2; qb += SB) {
         float zpr[SB], zpi[SB];
+        // register of row q: brev(q) after the DIF transform, q itself after the DIT one (compact form with MPX_COMP_DIT)
+        constexpr bool NATR = COMPACT && MPX_COMP_DIT;
 #pragma unroll
         for (int u = 0; u < SB; ++u) {
-            const int i = brev(qb + u, LB);
+            const int i = NATR ? qb + u : brev(qb + u, LB);
             zpr[u] = __shfl(re[P - 1 - i], src_lane);
             zpi[u] = __shfl(im[P - 1 - i], src_lane);
         }
 #pragma unroll
         for (int u = 0; u < SB; ++u) {
             const int q = qb + u;
-            const int i = brev(q, LB);
-            const int i0 = brev((P - q) % P, LB);
+            const int i = NATR ? q : brev(q, LB);
+            const int i0 = NATR ? (P - q) % P : brev((P - q) % P, LB);
             const float pr = lane0 ? re[i0] : zpr[u];
             const float pi = lane0 ? im[i0] : zpi[u];
             const float er = 0.5f * (re[i] + pr), ei = 0.5f * (im[i] - pi);
@@ -332,8 +345,9 @@ __device__ __forceinline__ void noise_spectrum_paired(const FrameGeom& g, int wt
             nm_i[q] = ti - ei;
         }
     }
-    nh_r = re[1];    // bin M/2 = register brev(P/2) = 1 of the kappa == 0 lane: X = conj Z
-    nh_i = -im[1];
+    constexpr int ih = (COMPACT && MPX_COMP_DIT) ? P / 2 : 1;   // bin M/2 = register brev(P/2) = 1 (DIF) / P/2 (DIT) of the kappa == 0 lane
+    nh_r = re[ih];   // X = conj Z
+    nh_i = -im[ih];
 }
 
 template <int P, bool PRESTAGED = false, bool COMPACT = false>   // PRESTAGED: the caller already copied tile 0 into xbuf and waited for it
@@ -364,8 +378,9 @@ __device__ __forceinline__ void noise_spectrum(const FrameGeom& g, int wtype, co
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int i = ib + u;
-            const int q = brev(i, LB);
-            const int i0 = brev((P - q) % P, LB);
+            constexpr bool NATR = COMPACT && MPX_COMP_DIT;   // register i holds row q = i (DIT) / brev(i) (DIF)
+            const int q = NATR ? i : brev(i, LB);
+            const int i0 = NATR ? (P - q) % P : brev((P - q) % P, LB);
             const float pr = lane0 ? re[i0] : prb[u];
             const float pi = lane0 ? im[i0] : pib[u];
             const float er = 0.5f * (re[i] + pr), ei = 0.5f * (im[i] - pi);
@@ -1058,7 +1073,11 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_synth_comp_pair(const f
             const int l = i / tw_half_stride<P>(), c = i - l * tw_half_stride<P>();
             float v = 0.0f;
             if (c < P) {
+#if MPX_COMP_DIT   // natural register order for the DIT first pass: entry e = W_M^{l e}, at register brev(e) of the full row
+                v = tw_g[l * tw_stride<P>() + 2 * brev(c >> 1, ilog2(P)) + (c & 1)];
+#else              // the even registers' twiddles: entry e of a half row = entry 2 e of the full row
                 v = tw_g[l * tw_stride<P>() + 4 * (c >> 1) + (c & 1)];
+#endif
             } else {   // the pad: this lane's constants (tw_half_pad): W_N^{-lane} (cos, sin), W_128^lane (cos, sin)
                 float sn, cs;
                 if (c < P + 2) sincospif(-2.0f * (float)l / (float)N, &sn, &cs);
@@ -1444,7 +1463,25 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_synth_comp_pair(const f
             }
             hermitian_merge<P>(xr, xi, xm, lane, ws_c, ws_s);
         }
-        if constexpr (kCompact) {
+        constexpr bool kDit = kCompact && MPX_COMP_DIT;
+        if constexpr (kDit) {
+            // DIT form: its input wants register brev(j) <- bin lane + 64 j, its output is register i <-> samples 2 n, 2 n + 1
+            // with n = lane + 64 i: static renamings on both sides
+            constexpr int LBJ = ilog2(P);
+            float yr[P], yi[P];
+#pragma unroll
+            for (int j = 0; j < P; ++j) {
+                yr[brev(j, LBJ)] = xr[j];
+                yi[brev(j, LBJ)] = xi[j];
+            }
+            const float4 pk = tw_half_pad<P>(tw, lane);
+            wave_fft_dit_compact_front<P, +1>(yr, yi, tw, xbuf, lane, pk.z, pk.w);
+#pragma unroll
+            for (int j = 0; j < P; ++j) {
+                xr[j] = yr[j];
+                xi[j] = yi[j];
+            }
+        } else if constexpr (kCompact) {
             const float4 pk = tw_half_pad<P>(tw, lane);
             wave_fft_front_compact<P, +1>(xr, xi, tw, xbuf, lane, pk.z, pk.w);
         } else {
@@ -1455,7 +1492,8 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_synth_comp_pair(const f
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             stage_samples_async(g, 0, kTile, xbuf_byte, lane);
         }
-        fft_inreg<P, +1>(xr, xi);
+        if constexpr (kDit) wave_fft_dit_back<P, +1>(xr, xi);
+        else fft_inreg<P, +1>(xr, xi);
 
         // ---- anti-ringing window (magphase.py:969-973, Q14): centred asymmetric Hann, zero outside
         const int wl = tb.win_l[fi], wr = tb.win_r[fi];
@@ -1491,8 +1529,8 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_synth_comp_pair(const f
 #endif
             constexpr int CH = (P < MPX_COMP_CH) ? P : MPX_COMP_CH;
             const RingAddr ra = ring_addr<P>(ring_byte, x, lane);
-            ring_add_plane<P, 0, CH>(smem, ra, xr, lane, win_add, row_live);
-            ring_add_plane<P, 1, CH>(smem, ra, xi, lane, win_add, row_live);
+            ring_add_plane<P, 0, CH, kDit>(smem, ra, xr, lane, win_add, row_live);
+            ring_add_plane<P, 1, CH, kDit>(smem, ra, xi, lane, win_add, row_live);
         } else {
             ring_add<P>(smem, ring_byte, x, xr, xi, lane, win_add, row_live);
         }

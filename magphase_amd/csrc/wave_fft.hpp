@@ -504,11 +504,12 @@ __device__ __forceinline__ void wave_fft_front_compact(float (&re)[P], float (&i
 // in NATURAL register order: entry e of a lane's row = W_M^{lane e}, e < P/2; register e + P/2 = that times W_128^lane):
 //   input : lane l, register brev(j)  holds z[l + 64 j]          (bit-reversed register order; a static renaming for the caller)
 //   output: lane l, register i        holds Z[kappa(l) + 64 i]   (natural register order)
+// (two halves, so that a caller can start a copy into xbuf between them: the front leaves the exchange buffer idle)
 template <int P, int SIGN>
-__device__ __forceinline__ void wave_fft_dit_compact(float (&re)[P], float (&im)[P], const float* twh, float* xbuf, int lane,
-                                                     float lc, float ls) {
+__device__ __forceinline__ void wave_fft_dit_compact_front(float (&re)[P], float (&im)[P], const float* twh, float* xbuf,
+                                                           int lane, float lc, float ls) {
     static_assert(P == 32, "compact form: P == 32 only");
-    constexpr int LB = ilog2(P), HP = P / 2;
+    constexpr int HP = P / 2;
     fft_inreg_dit<P, SIGN>(re, im);
     const float4* trow = reinterpret_cast<const float4*>(twh + lane * tw_half_stride<P>());
 #pragma unroll
@@ -532,6 +533,13 @@ __device__ __forceinline__ void wave_fft_dit_compact(float (&re)[P], float (&im)
     lds_transpose_half<P, true>(re, xbuf, lane);
     lds_transpose_half<P, true>(im, xbuf, lane);
     cross_lane_stage<P, SIGN, 32, 64>(re, im, (lane & 32) != 0, false, lane);
+}
+
+template <int P, int SIGN>
+__device__ __forceinline__ void wave_fft_dit_compact(float (&re)[P], float (&im)[P], const float* twh, float* xbuf, int lane,
+                                                     float lc, float ls) {
+    constexpr int LB = ilog2(P);
+    wave_fft_dit_compact_front<P, SIGN>(re, im, twh, xbuf, lane, lc, ls);
     // second pass: the 32-point transforms over l' in DIT form want register brev(l') <- element l'
     float tr[P], ti[P];
 #pragma unroll
