@@ -2197,14 +2197,16 @@ int mpx_synth_comp_slots(void) { return device_cus() * kCompPairs; }
 // Relative speed of the slots' wave pairs (see mpx_synth_ola_slot_weights): the pairs (0, 1), (2, 3), (4, 5) of a workgroup
 // hold the oldest / middle / youngest wave of every SIMD.  12 waves, interleaved A/B of the configs[2] synthesis side:
 // equal shares 1.332 ms, 100:80:60 1.301, 100:75:55 1.314, 100:90:80 1.287, 100:85:70 .. 100:88:76 1.270-1.277 (flat).
+// Re-tuned on the final kernel (no scratch, more of its time in the VALU: the age effect is stronger): 100:86:73 1.190,
+// 100:90:80 1.194, 100:92:86 1.215, 100:82:66 1.167, 100:84:62 1.168, 100:80:62 1.178, 100:78:58 1.177, 100:76:62 1.179.
 #ifndef MPX_COMP_W0
 #define MPX_COMP_W0 100
 #endif
 #ifndef MPX_COMP_W1
-#define MPX_COMP_W1 (MPX_COMP_PAIR_WAVES > 8 ? 86 : 80)
+#define MPX_COMP_W1 (MPX_COMP_PAIR_WAVES > 8 ? 82 : 80)
 #endif
 #ifndef MPX_COMP_W2
-#define MPX_COMP_W2 73
+#define MPX_COMP_W2 66
 #endif
 int mpx_synth_comp_slot_weights(float* weights_host, int32_t n_slots) {
     if (!weights_host || n_slots < 0) return fail(MPX_ERR_ARG, "mpx_synth_comp_slot_weights: bad arguments%s");

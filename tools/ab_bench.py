@@ -47,7 +47,7 @@ def prepare(name, ref, flags):
     else:
         for d in ("magphase_amd", "include"):
             shutil.copytree(os.path.join(ROOT, d), os.path.join(dst, d),
-                            ignore=shutil.ignore_patterns("__pycache__", "*.so", "*.pyc"))
+                            ignore=shutil.ignore_patterns("__pycache__", "*.so", "*.pyc", "_obj"))
     csrc = os.path.join(dst, "magphase_amd", "csrc")
     srcs = [os.path.join(csrc, f) for f in sorted(os.listdir(csrc)) if f.endswith((".hip", ".cpp"))]
     from magphase_amd import build
