@@ -2026,8 +2026,13 @@ __global__ __launch_bounds__(256) void k_mel_unwarp_tiled(UnwarpJob job, long lo
         for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.0f;
 #pragma unroll
         for (int t = 0; t < KH; ++t) {
+#ifdef MPX_PROBE_UNWARP_NOMFMA   // ablation (timing only): one VALU op per step instead of the two matrix instructions
+            acc0[t & 15] = fmaf(a[t], b0[t], acc0[t & 15]);
+            acc1[t & 15] = fmaf(a[t], b1[t], acc1[t & 15]);
+#else
             acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b0[t], acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t], b1[t], acc1, 0, 0, 0);
+#endif
 #ifndef MPX_PROBE_UNWARP_NOBLOAD   // ablation: the first step's U fragments for every step
             const int v = (2 * t + 1 == K) ? vn0e : vn0;
             b0[t] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(urs, v, soff(t), 0));
@@ -2045,7 +2050,13 @@ __global__ __launch_bounds__(256) void k_mel_unwarp_tiled(UnwarpJob job, long lo
         }
         wave_sync();
         const bool col_ok = j0 + lane < jend;
-        for (int fc = fa; fc < fb; fc += 64) {
+#ifdef MPX_PROBE_UNWARP_NOINTERP   // ablation (timing only): no interpolation / store phase
+        if (tile[lane] == 123.456f) job.out[lane] = 1.0f;
+        const int fb_ = fa;
+#else
+        const int fb_ = fb;
+#endif
+        for (int fc = fa; fc < fb_; fc += 64) {
             // lane i writes the tables of frame fc + i (tile offsets of its two rows, weight) into a small per-wave LDS
             // table; the loop below reads one entry per frame as a broadcast -- no v_readlane / SGPR round trips (that
             // form spent its time in scalar hazards: 26 M SALU instructions per launch)
