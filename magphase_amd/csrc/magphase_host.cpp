@@ -21,6 +21,9 @@
 #include <cstring>
 #include <string>
 #include <thread>
+#if defined(__SSE2__)
+#include <emmintrin.h>
+#endif
 #include <vector>
 
 #include "../../include/magphase_hip.h"
@@ -143,7 +146,19 @@ int32_t mpx_host_widen_f32(const float* src, double* dst, int64_t n, int32_t n_t
     const int nb = (int)((n + kBlock - 1) / kBlock);
     parallel_for(nb, n_threads, [&](int b) {
         const int64_t a = (int64_t)b * kBlock, e = (a + kBlock < n) ? a + kBlock : n;
-        for (int64_t i = a; i < e; ++i) dst[i] = (double)src[i];
+        int64_t i = a;
+#if defined(__SSE2__) && !defined(MPX_HOST_NO_STREAM)
+        // streaming (non-temporal) stores: the destination is hundreds of megabytes the caller reads later, if at all --
+        // written through the cache every line is first READ for ownership (0.7 GB of extra traffic per 0.7 GB written)
+        for (; i < e && (reinterpret_cast<uintptr_t>(dst + i) & 15u); ++i) dst[i] = (double)src[i];
+        for (; i + 4 <= e; i += 4) {
+            const __m128 v = _mm_loadu_ps(src + i);
+            _mm_stream_pd(dst + i, _mm_cvtps_pd(v));
+            _mm_stream_pd(dst + i + 2, _mm_cvtps_pd(_mm_movehl_ps(v, v)));
+        }
+        _mm_sfence();
+#endif
+        for (; i < e; ++i) dst[i] = (double)src[i];
     });
     return MPX_OK;
 }
@@ -154,7 +169,17 @@ int32_t mpx_host_narrow_f64(const double* src, float* dst, int64_t n, int32_t n_
     const int nb = (int)((n + kBlock - 1) / kBlock);
     parallel_for(nb, n_threads, [&](int b) {
         const int64_t a = (int64_t)b * kBlock, e = (a + kBlock < n) ? a + kBlock : n;
-        for (int64_t i = a; i < e; ++i) dst[i] = (float)src[i];   // round to nearest even, as numpy's astype
+        int64_t i = a;
+#if defined(__SSE2__) && !defined(MPX_HOST_NO_STREAM)
+        // (streaming stores as in mpx_host_widen_f32: the destination is the page-locked staging buffer the DMA engine reads)
+        for (; i < e && (reinterpret_cast<uintptr_t>(dst + i) & 15u); ++i) dst[i] = (float)src[i];
+        for (; i + 4 <= e; i += 4) {
+            const __m128 lo = _mm_cvtpd_ps(_mm_loadu_pd(src + i)), hi = _mm_cvtpd_ps(_mm_loadu_pd(src + i + 2));
+            _mm_stream_ps(dst + i, _mm_movelh_ps(lo, hi));   // cvtpd2ps rounds to nearest even (MXCSR default), as numpy's astype
+        }
+        _mm_sfence();
+#endif
+        for (; i < e; ++i) dst[i] = (float)src[i];   // round to nearest even, as numpy's astype
     });
     return MPX_OK;
 }
