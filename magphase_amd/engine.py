@@ -150,53 +150,64 @@ class Engine:
         return out
 
     # ------------------------------------------------------------------ pinned staging
-    def _pinned_pair(self, n_floats):
-        """Two page-locked float32 staging buffers of at least n_floats elements (grown on demand, kept)."""
+    def _pinned_ring(self, n_floats, depth):
+        """`depth` page-locked float32 staging buffers of at least n_floats elements (grown on demand, kept)."""
         torch = _torch()
         cur = getattr(self, "_pinned", None)
-        if cur is None or cur[0].numel() < n_floats:   # grown with headroom: page-locking costs milliseconds per 10 MB
+        if cur is None or len(cur) < depth or cur[0].numel() < n_floats:   # grown with headroom: page-locking is slow
             n_alloc = max(int(n_floats * 1.5), 1 << 20)
-            self._pinned = tuple(torch.empty(n_alloc, dtype=torch.float32).pin_memory() for _ in range(2))
+            self._pinned = tuple(torch.empty(n_alloc, dtype=torch.float32).pin_memory() for _ in range(depth))
         return self._pinned
 
-    def to_host_f64(self, t, chunk_bytes=64 << 20):
+    def to_host_f64_many(self, tensors, chunk_bytes=None, depth=3):
         """
-        Device float32 tensor (1-D or 2-D, rows may be pitched) -> fresh float64 numpy array, through two pinned
-        staging buffers: chunk i+1 crosses PCIe (async copy on the current stream) while the host widens chunk i to
-        float64.  Bounded pinned memory (2 x chunk_bytes) whatever the matrix size; the pageable `.cpu()` path is
-        ~3x slower for the 1.4 GB of lossless features of a 64-utterance batch.
+        Device float32 tensors (1-D or 2-D, rows may be pitched) -> fresh float64 numpy arrays through a ring of pinned
+        staging buffers: the chunks of ALL tensors form one pipeline -- chunks i+1, i+2 cross PCIe (async copies on the
+        current stream) while the host widens chunk i to float64 (native threads, streaming stores).  One matrix at a
+        time with two 64 MB chunks each, the three feature matrices of a batch paid the pipeline's fill and drain
+        three times (12 of a call's 16 ms); as one stream of 16 MB chunks the copies hide behind the widening.
+        Bounded pinned memory (depth x chunk_bytes) whatever the sizes.
         """
         torch = _torch()
-        if t.dim() == 1:
-            return self.to_host_f64(t.view(1, -1), chunk_bytes).reshape(-1)
-        rows, cols = int(t.shape[0]), int(t.shape[1])
-        out = np.empty((rows, cols), dtype=np.float64)
-        if rows == 0 or cols == 0:
-            return out
-        rows_per = max(1, int(chunk_bytes) // (4 * cols))
-        bufs = self._pinned_pair(rows_per * cols)
-        events = [torch.cuda.Event(), torch.cuda.Event()]
-        starts = list(range(0, rows, rows_per))
-
         n_thr = max(1, int(os.environ.get("MAGPHASE_IO_NATIVE_THREADS", "8")))
+        if chunk_bytes is None:
+            chunk_bytes = int(os.environ.get("MAGPHASE_D2H_CHUNK_MB", "32")) << 20
+        outs, views, work = [], [], []
+        for k, t in enumerate(tensors):
+            v = t.view(1, -1) if t.dim() == 1 else t
+            rows, cols = int(v.shape[0]), int(v.shape[1])
+            out = np.empty((rows, cols), dtype=np.float64)
+            outs.append(out.reshape(-1) if t.dim() == 1 else out)
+            views.append((v, out, cols))
+            if rows and cols:
+                rows_per = max(1, int(chunk_bytes) // (4 * cols))
+                work.extend((k, r0, min(rows, r0 + rows_per)) for r0 in range(0, rows, rows_per))
+        if not work:
+            return outs
+        biggest = max((r1 - r0) * views[k][2] for k, r0, r1 in work)
+        bufs = self._pinned_ring(biggest, depth)
+        events = [torch.cuda.Event() for _ in range(depth)]
 
         def drain(i):
-            r0 = starts[i]
-            r1 = min(rows, r0 + rows_per)
-            events[i % 2].synchronize()
-            # float32 -> float64 on a few native threads (numpy's cast is one thread at ~1.5 GB/s)
-            self.lib.mpx_host_widen_f32(bufs[i % 2].data_ptr(), out[r0:r1].ctypes.data, (r1 - r0) * cols, n_thr)
+            k, r0, r1 = work[i]
+            _v, out, cols = views[k]
+            events[i % depth].synchronize()
+            self.lib.mpx_host_widen_f32(bufs[i % depth].data_ptr(), out[r0:r1].ctypes.data, (r1 - r0) * cols, n_thr)
 
         with torch.cuda.device(self.device):
-            for i, r0 in enumerate(starts):
-                r1 = min(rows, r0 + rows_per)
-                if i >= 2:
-                    drain(i - 2)                      # the buffer about to be overwritten
-                bufs[i % 2][:(r1 - r0) * cols].view(r1 - r0, cols).copy_(t[r0:r1], non_blocking=True)
-                events[i % 2].record()
-            for i in range(max(0, len(starts) - 2), len(starts)):
+            for i, (k, r0, r1) in enumerate(work):
+                if i >= depth:
+                    drain(i - depth)                  # the buffer about to be overwritten
+                v, _out, cols = views[k]
+                bufs[i % depth][:(r1 - r0) * cols].view(r1 - r0, cols).copy_(v[r0:r1], non_blocking=True)
+                events[i % depth].record()
+            for i in range(max(0, len(work) - depth), len(work)):
                 drain(i)
-        return out
+        return outs
+
+    def to_host_f64(self, t, chunk_bytes=None):
+        """One tensor through to_host_f64_many."""
+        return self.to_host_f64_many([t], chunk_bytes=chunk_bytes)[0]
 
     def to_host_f32(self, t):
         """Device float32 tensor (rows may be pitched) -> fresh float32 numpy array (one D2H copy into a new pageable

@@ -225,7 +225,7 @@ def analysis_lossless_batch(utts, fft_len=None, engine=None, return_device=False
             warnings.warn(_WARN_LONG % (plan.fft_len, n))
     mag, real, imag = plan.run()
     if not return_device:   # one pinned, chunked D2H per stream for the whole batch (engine.to_host_f64)
-        h_feats = tuple(engine.to_host_f64(t) for t in (mag, real, imag))
+        h_feats = tuple(engine.to_host_f64_many([mag, real, imag]))
     out = []
     for u in range(len(utts)):
         a, b = int(plan.frame_off[u]), int(plan.frame_off[u + 1])
