@@ -275,14 +275,29 @@ class Engine:
             host.copy_(out)
         return host[:total].numpy()
 
-    def numpy_global_uniform(self, n):
+    @staticmethod
+    def _mt_next_pos(pos, n_words):
+        """Position of numpy's MT19937 word cursor (0..624) after n_words more 32-bit draws (randomkit: a draw at 624
+        regenerates the state and restarts at 0)."""
+        q = int(pos) + int(n_words)
+        return q if (n_words == 0 or q <= 624) else ((q - 1) % 624) + 1
+
+    def numpy_global_uniform(self, n, defer=False):
         """np.random.uniform(-1, 1, n).astype(float32) drawn from numpy's global generator, on the device
-        (mpx_noise_numpy_mt19937): same values, and the global state is left where the host draw would leave it."""
+        (mpx_noise_numpy_mt19937): same values, and the global state is left where the host draw would leave it.
+        defer=True (the batches of a corpus run, iobatch): the advanced state STAYS on the device and the next deferred
+        call continues from it -- no download, no synchronisation per batch; numpy's own state is stale until mt_sync(),
+        which the caller owes before anything else draws from it."""
         torch = _torch()
-        st = np.random.get_state()
-        if st[0] != "MT19937":
-            raise RuntimeError("numpy's global generator is not MT19937")
-        key = self.to_device(np.ascontiguousarray(st[1], dtype=np.uint32).view(np.int32), np.int32)
+        pend = getattr(self, "_mt_pending", None)
+        if pend is not None:
+            key, pos, meta = pend
+        else:
+            st = np.random.get_state()
+            if st[0] != "MT19937":
+                raise RuntimeError("numpy's global generator is not MT19937")
+            key = self.to_device(np.ascontiguousarray(st[1], dtype=np.uint32).view(np.int32), np.int32)
+            pos, meta = int(st[2]), (st[0], st[3], st[4])
         out = self.empty((max(int(n), 1),))
         raw = torch.empty(max(2 * int(n), 1), dtype=torch.int32, device=self.device)
         state = torch.empty(625, dtype=torch.int32, device=self.device)
@@ -291,13 +306,42 @@ class Engine:
             work = self._mt_work = torch.empty(int(self.lib.mpx_noise_numpy_mt19937_work_words()), dtype=torch.int32,
                                                device=self.device)
         with torch.cuda.device(self.device):
-            _lib.check(self.lib.mpx_noise_numpy_mt19937(self.stream_ptr(), key.data_ptr(), int(st[2]), int(n),
+            _lib.check(self.lib.mpx_noise_numpy_mt19937(self.stream_ptr(), key.data_ptr(), int(pos), int(n),
                                                         raw.data_ptr(), out.data_ptr(), state.data_ptr(),
                                                         state.data_ptr() + 4 * 624, work.data_ptr()),
                        "mpx_noise_numpy_mt19937")
-            h = state.cpu().numpy()          # synchronises: the state goes back before anyone else draws
-        np.random.set_state((st[0], h[:624].view(np.uint32).copy(), int(h[624]), st[3], st[4]))
+        self._mt_pending = (state, self._mt_next_pos(pos, 2 * int(n)), meta)
+        if not defer:
+            self.mt_sync()
         return out[:int(n)]
+
+    def mt_sync(self):
+        """Puts a deferred MT19937 state (numpy_global_uniform(defer=True)) back into numpy's global generator."""
+        pend = getattr(self, "_mt_pending", None)
+        if pend is None:
+            return
+        state, pos, meta = pend
+        self._mt_pending = None
+        with _torch().cuda.device(self.device):
+            h = state.cpu().numpy()          # synchronises
+        if int(h[624]) != int(pos):
+            raise RuntimeError("MT19937 cursor: host %d, device %d" % (pos, int(h[624])))
+        np.random.set_state((meta[0], h[:624].view(np.uint32).copy(), int(pos), meta[1], meta[2]))
+
+    def mt_snapshot(self):
+        """Opaque copy of the generator's current state (deferred device state or numpy's), for mt_restore."""
+        pend = getattr(self, "_mt_pending", None)
+        if pend is not None:
+            return ("dev", (pend[0].clone(), pend[1], pend[2]))
+        return ("host", np.random.get_state())
+
+    def mt_restore(self, snap):
+        kind, val = snap
+        if kind == "dev":
+            self._mt_pending = (val[0].clone(), val[1], val[2])
+        else:
+            self._mt_pending = None
+            np.random.set_state(val)
 
     def host_staging(self, n_floats):
         """float32 numpy view [n_floats] of a page-locked staging buffer (grown on demand, reused by every plan).  TWO
@@ -928,7 +972,9 @@ class CompressedSynthesisPlan:
 
     def __init__(self, engine, utts, fs, fft_len=None, b_voi_ap_win=True, b_const_rate=False, alpha_phase=None,
                  noise=None, frames_per_run=None, per_phase_type="magphase", post_filter=False, b_fbank_mel=False,
-                 noise_mode="reference", noise_seeds=None):
+                 noise_mode="reference", noise_seeds=None, defer_rng=False):
+        # defer_rng: the reference noise stream's advanced state stays on the device (Engine.numpy_global_uniform(defer=True));
+        #            the caller owes Engine.mt_sync() before numpy's global generator is used again
         # post_filter: False / True ('magphase': mp.post_filter on the device) / 'merlin' (mp.post_filter_merlin on the device)
         self.apply_post_filter = post_filter if post_filter in ("merlin", "magphase") else bool(post_filter)
         self.b_const_rate = bool(b_const_rate)
@@ -978,6 +1024,8 @@ class CompressedSynthesisPlan:
                 return v_ns
             if noise_mode == "device" or mt_device:
                 return None                                            # generated on the GPU
+            if hasattr(e, "mt_sync"):
+                e.mt_sync()                                            # a deferred device state goes back first
             return np.random.uniform(-1, 1, ns_len)                    # :883 (global numpy RNG, as the reference)
 
         try:    # index arithmetic of the whole batch in one native call (hostplan / csrc/magphase_plan.cpp) ...
@@ -1082,7 +1130,7 @@ class CompressedSynthesisPlan:
                                                    self.noise_off_dev.data_ptr(), int(max(self.ns_len)),
                                                    self.noise.data_ptr()), "mpx_noise_uniform")
         elif mt_device:
-            self.noise = e.numpy_global_uniform(mt_total)
+            self.noise = e.numpy_global_uniform(mt_total, defer=bool(defer_rng))
 
     @staticmethod
     def _check_rows_for_tiles(r0, r1):

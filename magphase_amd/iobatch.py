@@ -172,21 +172,27 @@ def _record_failures(report, out_dir, failed):
         report["crash_list"] = path
 
 
-def _isolate(items, fn_batch, keep_numpy_rng=False):
+def _isolate(items, fn_batch, keep_numpy_rng=False, rng_engine=None):
     """fn_batch(list) -> list of results.  If the whole batch raises, every item is retried on its own so that one bad
     utterance costs one utterance: returns (results, failed) with failed = [(index, exception)].
     keep_numpy_rng: the batch draws from numpy's GLOBAL generator (reference noise, magphase.py:883); the failed attempt
     may already have advanced it, so its state is put back before the retries -- the good utterances then get the noise
     they would have got without the bad one in the batch (a bad utterance that draws before it fails still shifts the
     stream for the ones after it, as it would in the reference's own loop)."""
-    state = np.random.get_state() if keep_numpy_rng else None
+    # (rng_engine: the generator's state may be a deferred one on the device, Engine.mt_snapshot / mt_restore)
+    state = None
+    if keep_numpy_rng:
+        state = rng_engine.mt_snapshot() if rng_engine is not None else ("host", np.random.get_state())
     try:
         return list(zip(range(len(items)), fn_batch(items))), []
     except (KeyboardInterrupt, SystemExit):
         raise
     except Exception:
         if state is not None:
-            np.random.set_state(state)
+            if rng_engine is not None:
+                rng_engine.mt_restore(state)
+            else:
+                np.random.set_state(state[1])
         ok, failed = [], []
         for i, it in enumerate(items):
             try:
@@ -362,6 +368,8 @@ def generate_waveforms_corpus(in_feats_dir, tokens, out_syn_dir, mag_dim, phase_
     lu.mkdir(out_syn_dir)
     if pf_type not in ("no", "magphase", "merlin"):
         raise ValueError("pf_type must be 'no', 'magphase' or 'merlin'")
+    from .engine import get_engine
+    rng_engine = (engine or get_engine()) if noise_mode == "reference" else None   # resolved in THIS thread (device)
     fs_of = (lambda t: int(fs[t])) if isinstance(fs, dict) else ((lambda t: int(fs(t))) if callable(fs) else (lambda t: int(fs)))
 
     def load(toks):
@@ -398,14 +406,14 @@ def generate_waveforms_corpus(in_feats_dir, tokens, out_syn_dir, mag_dim, phase_
                     kw = {"noise_mode": noise_mode, "noise_seeds": [token_seed(u[0]) for u in g]}
                 # pcm16_norm: la.write_audio_file's peak normalisation and 16-bit conversion done on the device
                 kw.update(fft_len=fft_len, b_const_rate=b_const_rate, b_post_filter=(pf_type if pf_type != "no" else False),
-                          engine=engine, pcm16_norm=0.98)
+                          engine=engine, pcm16_norm=0.98, defer_rng=(rng_engine is not None))
                 if len(g) != whole:   # _isolate's one-by-one retries: synchronous results (see extract_features_corpus)
                     return mp.synthesis_from_compressed_batch([u[2] for u in g], rate, **kw)
                 sigs, ticket = mp.synthesis_from_compressed_batch([u[2] for u in g], rate, async_out=True, **kw)
                 tickets.append(ticket)
                 return sigs
 
-            ok, bad = _isolate(group, synth, keep_numpy_rng=(noise_mode == "reference"))
+            ok, bad = _isolate(group, synth, keep_numpy_rng=(noise_mode == "reference"), rng_engine=rng_engine)
             out.extend((group[i][0], rate, sig) for i, sig in ok)
             failed = failed + [(group[i][0], "%s: %s" % (type(e).__name__, e)) for i, e in bad]
         order = {u[0]: k for k, u in enumerate(utts)}
@@ -441,4 +449,8 @@ def generate_waveforms_corpus(in_feats_dir, tokens, out_syn_dir, mag_dim, phase_
         for tok, msg in failed:
             print("FAILED " + tok + " (" + msg + ")")
 
-    return pipeline(batches(tokens, batch_utts), load, compute, store, timings=report)
+    try:
+        return pipeline(batches(tokens, batch_utts), load, compute, store, timings=report)
+    finally:
+        if rng_engine is not None:   # the noise stream's state was kept on the device between the batches: back to numpy
+            rng_engine.mt_sync()

@@ -391,8 +391,10 @@ def _output_hpf(v_syn_sig, fs):
 def synthesis_from_compressed_batch(utts, fs, fft_len=None, b_voi_ap_win=True, b_const_rate=False, alpha_phase=None,
                                     b_out_hpf=True, noise=None, engine=None, per_phase_type='magphase',
                                     b_post_filter=False, b_fbank_mel=False, noise_mode='reference', noise_seeds=None,
-                                    pcm16_norm=False, async_out=False):
+                                    pcm16_norm=False, async_out=False, defer_rng=False):
     """Batched synthesis_from_compressed; utts: list of (m_mag_mel_log, m_real_mel, m_imag_mel, v_lf0).
+    defer_rng: reference noise only -- numpy's advanced generator state stays on the device between calls; the caller owes
+    engine.mt_sync() before numpy's global generator is used again (iobatch does this for a corpus run).
     async_out (with pcm16_norm): returns (signals, ticket) -- the int16 signals are views of a page-locked buffer the
     device is still copying into; ticket.wait() before reading them, ticket.release() when done (engine.HostTicket).
     b_post_filter: apply a post-filter to the log-mel magnitudes on the device first: True / 'magphase' = the MagPhase
@@ -406,7 +408,7 @@ def synthesis_from_compressed_batch(utts, fs, fft_len=None, b_voi_ap_win=True, b
     plan = CompressedSynthesisPlan(engine, utts, fs, fft_len=fft_len, b_voi_ap_win=b_voi_ap_win,
                                    b_const_rate=b_const_rate, alpha_phase=alpha_phase, noise=noise,
                                    per_phase_type=per_phase_type, post_filter=b_post_filter, b_fbank_mel=b_fbank_mel,
-                                   noise_mode=noise_mode, noise_seeds=noise_seeds)
+                                   noise_mode=noise_mode, noise_seeds=noise_seeds, defer_rng=defer_rng)
     pcm_dev = plan.run()
     if b_out_hpf:   # magphase.py:981-995, float64 on the device (engine.output_hpf); _output_hpf is the host form
         pcm_dev = engine.output_hpf(pcm_dev, plan.out_off_host, fs)

@@ -124,6 +124,44 @@ def test_numpy_global_generator_continued_on_the_device():
         assert np.array_equal(np.random.uniform(-1, 1, 7), nxt)          # and the stream goes on identically
 
 
+@pytest.mark.gpu
+def test_deferred_generator_state_chains_on_the_device():
+    """numpy_global_uniform(defer=True): consecutive draws continue from the state the previous one left ON THE DEVICE (no
+    download per call); mt_sync() puts numpy's global generator where the host draws would have left it; mt_snapshot /
+    mt_restore rewind a deferred state; the host-tracked word cursor equals the device's."""
+    from magphase_amd.engine import get_engine
+    e = get_engine()
+    sizes = (300001, 5, 159744 + 312, 700, 1, 2 * 159744 + 313, 312)
+    np.random.seed(77)
+    np.random.uniform(size=311)
+    st = np.random.get_state()
+    want = [np.random.uniform(-1, 1, n).astype(np.float32) for n in sizes]
+    after = np.random.get_state()
+    np.random.set_state(st)
+    got = []
+    for k, n in enumerate(sizes):
+        if k == 3:                                   # a failed batch: rewind and draw again
+            snap = e.mt_snapshot()
+            e.numpy_global_uniform(12345, defer=True)
+            e.mt_restore(snap)
+        got.append(e.numpy_global_uniform(n, defer=True).cpu().numpy())
+    assert np.array_equal(np.random.get_state()[1], st[1])          # numpy's own state is stale until the sync
+    e.mt_sync()
+    now = np.random.get_state()
+    for a, b, n in zip(got, want, sizes):
+        assert np.array_equal(a, b), n
+    assert np.array_equal(now[1], after[1]) and now[2] == after[2] and now[3:] == after[3:]
+    e.mt_sync()                                      # idempotent
+    assert np.random.get_state()[2] == after[2]
+    for p0, w in ((0, 0), (624, 1), (620, 4), (620, 5), (1, 1247), (1, 1248), (300, 624 * 7 + 324), (300, 624 * 7 + 325)):
+        pos = p0                                     # randomkit's cursor, word by word
+        for _ in range(w):
+            if pos == 624:
+                pos = 0
+            pos += 1
+        assert e._mt_next_pos(p0, w) == pos, (p0, w)
+
+
 def _mt_raw_stream(key, n_words):
     """Raw (untempered) words X[0 .. n_words) of MT19937 continued from a 624-word key (X[0..623] = key)."""
     x = np.zeros(n_words + 624, dtype=np.uint32)
