@@ -75,13 +75,26 @@ def run_extraction(rank, mine, dur, fs):
     items = [_cut(pool[int(u) % POOL], float(dur[u]), 48000) for u in mine]
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
+        kw = dict(mag_dim=60, phase_dim=10, alpha_phase=False, as_float32=True)
         if items:   # warm-up at the timed batch size (page-locked staging, device pools, tables)
-            mp.analysis_compressed_batch(items[:BATCH], mag_dim=60, phase_dim=10, alpha_phase=False, as_float32=True)
+            mp.analysis_compressed_batch(items[:BATCH], **kw)
+            _res, t_ = mp.analysis_compressed_batch(items[:BATCH], async_out=True, **kw)
+            t_.wait()
+            t_.release()
+        # pipelined form (see run_generation): a launch's features are taken one launch later, all of them inside the clock
         t0 = time.perf_counter()
-        frames = 0
+        frames, prev = 0, None
         for b in _batches(items):
-            for r in mp.analysis_compressed_batch(b, mag_dim=60, phase_dim=10, alpha_phase=False, as_float32=True):
-                frames += int(r[0].shape[0])
+            cur = mp.analysis_compressed_batch(b, async_out=True, **kw)
+            if prev is not None:
+                prev[1].wait()
+                frames += sum(int(r[0].shape[0]) for r in prev[0])
+                prev[1].release()
+            prev = cur
+        if prev is not None:
+            prev[1].wait()
+            frames += sum(int(r[0].shape[0]) for r in prev[0])
+            prev[1].release()
         dt = time.perf_counter() - t0
     return {"seconds": dt, "frames": frames, "audio_s": float(np.sum(dur[mine])) if len(mine) else 0.0, "utts": len(mine)}
 
@@ -109,24 +122,47 @@ def run_generation(rank, mine, dur, fs):
             n = max(8, int(round(m.shape[0] * float(dur[u]) / BASE_DUR_S)))
             items.append((rate, (m[:n], re_[:n], im[:n], lf0[:n])))
 
+        # The pipelined form of the batch API, as iobatch uses it: a launch's 16-bit PCM lands in a page-locked ring slot
+        # (async_out: engine.HostTicket) and is taken one launch later, so the host plans launch i + 1 while the device
+        # works on launch i; numpy's noise stream stays on the device between launches (defer_rng) and goes back to numpy
+        # once, at the end.  Every result is waited for and every state put back INSIDE the clock.
+        from collections import deque
+
+        from magphase_amd.engine import get_engine
+
+        eng = get_engine()
+        pending = deque()
+
+        def take(keep):
+            smpls = 0
+            while len(pending) > keep:
+                sigs, ticket = pending.popleft()
+                ticket.wait()
+                smpls += sum(int(x.shape[0]) for x in sigs)
+                ticket.release()
+            return smpls
+
         def synth(batch):
-            frames, smpls = 0, 0
+            frames = 0
             for rate in sorted(set(r for r, _ in batch)):
                 group = [x for r, x in batch if r == rate]
-                for sig in mp.synthesis_from_compressed_batch(group, rate, b_out_hpf=True, b_post_filter=True,
-                                                              pcm16_norm=0.98):
-                    smpls += int(sig.shape[0])
+                pending.append(mp.synthesis_from_compressed_batch(group, rate, b_out_hpf=True, b_post_filter=True,
+                                                                  pcm16_norm=0.98, async_out=True, defer_rng=True))
                 frames += sum(int(g[0].shape[0]) for g in group)
-            return frames, smpls
+            return frames
 
         np.random.seed(1000 + rank)
         if items:
             synth(items[:BATCH])
+            take(0)
+            eng.mt_sync()
         t0 = time.perf_counter()
-        frames, audio = 0, 0.0
+        frames, smpls = 0, 0
         for b in _batches(items):
-            f, _s = synth(b)
-            frames += f
+            frames += synth(b)
+            smpls += take(2)            # the two rate groups of the launch just issued stay in flight
+        smpls += take(0)
+        eng.mt_sync()
         dt = time.perf_counter() - t0
     return {"seconds": dt, "frames": frames, "audio_s": float(np.sum(dur[mine])) if len(mine) else 0.0, "utts": len(mine)}
 
@@ -165,7 +201,9 @@ def run(n_utts, rank=0, world=1, dist=None, barrier=None):
             "time_imbalance_max_over_mean": round(max(secs) / (sum(secs) / len(secs)), 4),
         }
     out["what"] = ("synthetic corpus of %d utterances (2-8 s, mean 5 s), LPT-sharded over %d rank(s) by frames x transform "
-                   "length, %d utterances per launch, array-level batch API (plan build + H2D + kernels + D2H inside the "
+                   "length, %d utterances per launch, array-level batch API in its pipelined form: a launch's results are taken one launch later from a page-locked ring, "
+                   "numpy's noise stream stays on the device between launches (plan build + H2D + kernels + D2H + every wait "
+                   "and the final state hand-back inside the "
                    "clock, files outside): configs[3] = analysis_compressed (48 kHz, 60 / 10, Q7), configs[4] = post-filter "
                    "+ synthesis_from_compressed + output high-pass + 16-bit PCM (60 / 45, 48 kHz and 16 kHz mixed, numpy's "
                    "global noise stream)" % (n_utts, world, BATCH))
