@@ -336,6 +336,21 @@ static_assert(kPairWaves % kGroup == 0, "waves per workgroup must be a multiple 
 // Probe build (tools/endtime_probe.py): every wave of k_synth_ola_pair stores the constant-rate clock (100 MHz) when it
 // enters and when it leaves its frame loop, and its frame count -- the spread of the end times is the launch tail.
 __device__ unsigned long long g_endprobe[4 * 8192];   // per wave: start, end (100 MHz clock), frames, shader cycles
+#ifdef MPX_PROBE_PHASES
+// per wave: s_memtime ticks spent in 8 phases of the frame loop (feature wait, merge, transform, prefetch issue + scalars,
+// ticket wait, flush, overlap-add, tail) -- tools/phase_probe.py
+__device__ unsigned long long g_phaseprobe[8 * 8192];
+#define MPX_PHASE(i)                                                                              \
+    do {                                                                                          \
+        const unsigned t_ = (unsigned)clock64();                                                  \
+        if (lane_id == 0) atomicAdd(probe_ph + (i), t_ - probe_last);   /* LDS: ds_add_u32 */     \
+        probe_last = t_;                                                                          \
+    } while (0)
+#else
+#define MPX_PHASE(i) do { } while (0)
+#endif
+#else
+#define MPX_PHASE(i) do { } while (0)
 #endif
 
 template <int P>
@@ -346,7 +361,11 @@ template <int P>
 constexpr int pair_xbuf_floats() { return (pair_compact<P>() ? P / 2 : P) * kXStride; }
 template <int P>
 constexpr size_t lds_bytes_pair() {
+#ifdef MPX_PROBE_PHASES
+    return sizeof(float) * (size_t)(pair_tw_floats<P>() + kPairWaves * pair_xbuf_floats<P>() + kPairs * ring_len<P>() + 16 + 8 * kPairWaves);
+#else
     return sizeof(float) * (size_t)(pair_tw_floats<P>() + kPairWaves * pair_xbuf_floats<P>() + kPairs * ring_len<P>() + 16);
+#endif
 }
 
 template <int P>
@@ -444,6 +463,11 @@ __global__ __launch_bounds__(kPairWaves * 64) void k_synth_ola_pair(const float*
     const unsigned long long probe_t0 = wall_clock64();
     const unsigned long long probe_c0 = clock64();
     int probe_frames = 0;
+#ifdef MPX_PROBE_PHASES
+    unsigned* probe_ph = reinterpret_cast<unsigned*>(smem + kRing0 + kPairs * R + 16) + 8 * wave;   // LDS accumulators
+    if (lane_id < 8) probe_ph[lane_id] = 0;
+    unsigned probe_last = (unsigned)probe_c0;
+#endif
 #endif
     // Software pipeline over the wave's frames: the features of the wave's NEXT frame are loaded while this frame waits
     // for its ticket and overlap-adds; convert + merge of the next iteration then starts on data that is (mostly) there.
@@ -476,9 +500,31 @@ __global__ __launch_bounds__(kPairWaves * 64) void k_synth_ola_pair(const float*
 #endif
         Cursor nxt = cur;
         advance(nxt);
+#ifdef MPX_PROBE_PHASES
+        probe_last = (unsigned)clock64();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        MPX_PHASE(0);
+#endif
         float xr[P], xi[P];
+#ifdef MPX_ABL_NOMERGE   // energy ablation (tools/energy_probe.py): the loaded values go straight into the transform
+#pragma unroll
+        for (int j = 0; j < P / 2; ++j) {
+            xr[j] = ff.m[j] + ff.a[j];
+            xi[j] = ff.b[j];
+            xr[j + P / 2] = ff.mq[j] + ff.aq[j];
+            xi[j + P / 2] = ff.bq[j] + ff.mH;
+        }
+#else
         feat_merge_paired<P>(ff, xr, xi, lane, wl_c, wl_s);
+#endif
+#ifdef MPX_PROBE_PHASES
+        MPX_PHASE(1);
+#endif
+#ifdef MPX_ABL_NOFFT
+        if constexpr (false) {
+#else
         if constexpr (kCompact) {
+#endif
             // DIT form (fused multiply-add butterflies): its input wants register brev(j) <- bin lane + 64 j, its output is
             // register i <-> samples 2 n, 2 n + 1 with n = lane + 64 i: static renamings on both sides
             constexpr int LB = ilog2(P);
@@ -495,8 +541,26 @@ __global__ __launch_bounds__(kPairWaves * 64) void k_synth_ola_pair(const float*
                 xi[j] = yi[j];
             }
         } else {
+#ifndef MPX_ABL_NOFFT
             wave_fft<P, +1>(xr, xi, tw, xbuf, lane);
+#endif
         }
+#ifdef MPX_FFT_FENCE
+        // scheduling fence: without it the compiler sinks the transform's second pass (~500 VALU) below the ticket wait,
+        // into the ordered section of the ring, where the pair's other wave waits for it
+        {
+#define MPX_F8(a, o) "+v"(a[o]), "+v"(a[o + 1]), "+v"(a[o + 2]), "+v"(a[o + 3]), "+v"(a[o + 4]), "+v"(a[o + 5]), "+v"(a[o + 6]), "+v"(a[o + 7])
+            if constexpr (P == 32) {
+                asm volatile("" : MPX_F8(xr, 0), MPX_F8(xr, 8), MPX_F8(xr, 16));
+                asm volatile("" : MPX_F8(xr, 24), MPX_F8(xi, 0), MPX_F8(xi, 8));
+                asm volatile("" : MPX_F8(xi, 16), MPX_F8(xi, 24));
+            }
+#undef MPX_F8
+        }
+#endif
+#ifdef MPX_PROBE_PHASES
+        MPX_PHASE(2);
+#endif
         // (an exhausted cursor loads row 0 -- no branch around the loads; every finishing wave reads the same 24 KB, which
         // stay in L2: re-reading its own last frame cost 75 MB of HBM fetches per launch, 5 % of the kernel's traffic)
         const long long fnx = nxt.valid ? nxt.fi : 0;
@@ -504,7 +568,16 @@ __global__ __launch_bounds__(kPairWaves * 64) void k_synth_ola_pair(const float*
         const float* nr = real + fnx * ld;
         const float* ni = imag + fnx * ld;
         asm volatile("" ::: "memory");
-        feat_load_paired_part<P, 0, JA, true>(ff, nm, nr, ni, lane);
+#ifdef MPX_ABL_NOLOAD   // energy ablation: no feature loads in the loop; the registers are (re)defined by an empty asm, as a load would
+#define MPX_FEAT_LOAD(J0, J1, WH)                                                                           \
+    do {                                                                                                    \
+        _Pragma("unroll") for (int j_ = J0; j_ < J1; ++j_)                                                  \
+            asm volatile("" : "=v"(ff.m[j_]), "=v"(ff.a[j_]), "=v"(ff.b[j_]), "=v"(ff.mq[j_]), "=v"(ff.aq[j_]), "=v"(ff.bq[j_])); \
+    } while (0)
+#else
+#define MPX_FEAT_LOAD(J0, J1, WH) feat_load_paired_part<P, J0, J1, WH>(ff, nm, nr, ni, lane)
+#endif
+        MPX_FEAT_LOAD(0, JA, true);
 
         // ---- ordered section: wait for this frame's ticket
         const int fi = cur.fi;
@@ -517,32 +590,44 @@ __global__ __launch_bounds__(kPairWaves * 64) void k_synth_ola_pair(const float*
         const int target = x & ~63;
         const int flushed = (fi == cur.fb) ? 0 : ((pm_rel[fi - 1] - cur.x0) & ~63);
         asm volatile("" ::"s"(x), "s"(flushed), "s"(rd.head_end), "s"(rd.out_lo), "s"(rd.out_hi), "s"(rd.flush_end));
+        MPX_PHASE(3);
         while (__hip_atomic_load(turn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != ticket)
             __builtin_amdgcn_s_sleep(1);
         asm volatile("" ::: "memory");
-        if (flushed < target) flush_ring<R>(ring, strip, pcm0, rd.head_end, rd.out_lo, rd.out_hi, flushed, target, lane);
+        MPX_PHASE(4);
+#ifdef MPX_ABL_NOOLA   // energy ablation: no flush, no ring adds (the transform's outputs are kept alive)
+#define MPX_OLA(stmt) do { } while (0)
+#pragma unroll
+        for (int i = 0; i < P; ++i) asm volatile("" ::"v"(xr[i]), "v"(xi[i]));
+#else
+#define MPX_OLA(stmt) stmt
+#endif
+        MPX_OLA(if (flushed < target) flush_ring<R>(ring, strip, pcm0, rd.head_end, rd.out_lo, rd.out_hi, flushed, target, lane));
         wave_sync();
+        MPX_PHASE(5);
         const RingAddr ra = ring_addr<P>(ring_byte, x, lane);
-        ring_add_plane<P, 0, kCompact ? MPX_CH : P, kCompact>(smem, ra, xr, lane, [](float o, float v, int) { return o + v; },
-                                                [](int) { return true; });
+        MPX_OLA((ring_add_plane<P, 0, kCompact ? MPX_CH : P, kCompact>(smem, ra, xr, lane, [](float o, float v, int) { return o + v; },
+                                                [](int) { return true; })));
         if constexpr (JB > JA) {   // the first plane's registers are free: the second part of the prefetch
             asm volatile("" ::: "memory");
-            feat_load_paired_part<P, JA, JB, false>(ff, nm, nr, ni, lane);
+            MPX_FEAT_LOAD(JA, JB, false);
         }
-        ring_add_plane<P, 1, kCompact ? MPX_CH : P, kCompact>(smem, ra, xi, lane, [](float o, float v, int) { return o + v; },
-                                                [](int) { return true; });
+        MPX_OLA((ring_add_plane<P, 1, kCompact ? MPX_CH : P, kCompact>(smem, ra, xi, lane, [](float o, float v, int) { return o + v; },
+                                                [](int) { return true; })));
         wave_sync();
         if (fi == cur.fe - 1) {   // last frame of the run: stream out the rest, leave the ring cleared
-            flush_ring<R>(ring, strip, pcm0, rd.head_end, rd.out_lo, rd.out_hi, target, rd.flush_end, lane);
+            MPX_OLA(flush_ring<R>(ring, strip, pcm0, rd.head_end, rd.out_lo, rd.out_hi, target, rd.flush_end, lane));
             wave_sync();
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        MPX_PHASE(6);
         __hip_atomic_store(turn, ticket + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         if constexpr (JB < P / 2) {
             asm volatile("" ::: "memory");
-            feat_load_paired_part<P, JB, P / 2, false>(ff, nm, nr, ni, lane);
+            MPX_FEAT_LOAD(JB, P / 2, false);
         }
         cur = nxt;
+        MPX_PHASE(7);
 #ifdef MPX_PROBE_ENDTIME
         ++probe_frames;
 #endif
@@ -554,6 +639,10 @@ __global__ __launch_bounds__(kPairWaves * 64) void k_synth_ola_pair(const float*
         g_endprobe[4 * w + 1] = wall_clock64();
         g_endprobe[4 * w + 2] = (unsigned long long)probe_frames;
         g_endprobe[4 * w + 3] = clock64() - probe_c0;
+#ifdef MPX_PROBE_PHASES
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        for (int i = 0; i < 8; ++i) g_phaseprobe[8 * w + i] = probe_ph[i];
+#endif
     }
 #endif
 }
@@ -775,6 +864,13 @@ int mpx_probe_endtimes(unsigned long long* host, int n_words) {   // probe build
     MPX_HIP_CHECK(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_endprobe), sizeof(unsigned long long) * (size_t)n_words));
     return MPX_OK;
 }
+#ifdef MPX_PROBE_PHASES
+int mpx_probe_phases(unsigned long long* host, int n_words) {
+    MPX_HIP_CHECK(hipDeviceSynchronize());
+    MPX_HIP_CHECK(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_phaseprobe), sizeof(unsigned long long) * (size_t)n_words));
+    return MPX_OK;
+}
+#endif
 #endif
 
 int mpx_synth_ola_slots(void) { return device_cus() * kPairs; }

@@ -87,6 +87,13 @@ def main():
     lowdim = os.environ.get("AB_WORKLOAD", "lossless") == "lowdim"
     torch.cuda.set_device(0)
     utts = bench.make_batch(0)
+    if os.environ.get("AB_FS"):   # other sample rates / batch sizes: AB_FS=16000 AB_UTTS=128 (the N = 2048 kernels)
+        from magphase_amd import synthetic as syn
+        fs_ = int(os.environ["AB_FS"])
+        utts = []
+        for i in range(int(os.environ.get("AB_UTTS", "64"))):
+            pcm_, pm_, voi_ = syn.make_utterance(i, dur_s=5.0, fs=fs_)
+            utts.append((pcm_, fs_, pm_, voi_))
     steps = {}
     shared = None   # ONE set of feature matrices / strips / output for all variants: where they land in memory is worth
     # +-3-5 % by itself (tools/alloc_lottery_probe.py) -- per-variant buffers turned that into a fake A/B difference
@@ -97,10 +104,11 @@ def main():
             aplan = em.LosslessAnalysisPlan(eng, utts)
             splan = em.LosslessSynthesisPlan(eng, aplan.v_f0, aplan.fs, aplan.fft_len)
             H, F = aplan.fft_len // 2 + 1, aplan.total_frames
+            print("%s: fft_len %d, frames %d, feature bytes %.3f GB, slots %d" % (name, aplan.fft_len, F, 12e-9 * H * F, splan.n_slots), flush=True)
             if shared is None:
-                shared = (tuple(eng.empty_feats(F, H) for _ in range(3)), eng.empty((max(splan.strip_floats, 1) + 65536,)),
-                          eng.empty((splan.total_out,)))
-            feats, strips, pcm = shared
+                shared = (tuple(eng.empty_feats(F, H) for _ in range(3)), eng.empty((splan.total_out,)))
+            feats, pcm = shared
+            strips = eng.empty((max(splan.strip_floats, 1) + 65536,))   # per variant: its size follows the variant's slot count
             steps[name] = (lambda aplan=aplan, feats=feats: aplan.run(out=feats),
                            lambda splan=splan, feats=feats, strips=strips, pcm=pcm: splan.run(feats[0], feats[1], feats[2], strips=strips, out=pcm))
         else:
@@ -123,6 +131,19 @@ def main():
             if r >= 2:
                 for k in range(3):
                     times[name][k].append(ev[k].elapsed_time(ev[k + 1]))
+    if os.environ.get("AB_ZERO") and not lowdim:   # DVFS check: the same synthesis launches on all-zero / constant features
+        for fill in (0.0, 1.0):
+            for t_ in shared[0]:
+                t_.fill_(fill)
+            for name in names:
+                ts = []
+                for r in range(rounds):
+                    ev[0].record()
+                    steps[name][1]()
+                    ev[1].record()
+                    torch.cuda.synchronize()
+                    ts.append(ev[0].elapsed_time(ev[1]))
+                print("%-14s synthesis on features == %.0f: %.4f / %.4f ms" % (name, fill, statistics.median(ts), min(ts)))
     print("%-14s %22s %22s %22s  (ms: median / min over %d interleaved rounds)"
           % ("variant", "analysis", "synthesis (+fixup)", "synthesis repeated", rounds))
     for name in names:
