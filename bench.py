@@ -468,9 +468,11 @@ def measure_e2e(utts):
 # ------------------------------------------------------------------------------------------------------------------
 def measure_ceilings(eng):
     """
-    What THIS device sustains for a plain streaming read, fill and copy of 1 GiB (mpx_bw_probe: grid-stride float4
-    kernels), timed with HIP events in this process: the "measured device copy-kernel ceiling" of SURVEY.md 8(d), quoted
-    in the roofline object beside the 8 TB/s spec peak.  Median of 7 launches after 2 warm-ups.
+    What THIS device sustains for a plain streaming read, fill and copy of 1 GiB (mpx_bw_probe: float4 kernels in
+    mpx_bw_probe_shapes() launch shapes -- grid x block, accesses in flight per lane, non-temporal bit; tools/bw_sweep.hip),
+    timed with HIP events in this process: the "measured device copy-kernel ceiling" of SURVEY.md 8(d), quoted in the
+    roofline object beside the 8 TB/s spec peak.  Per kind: the BEST shape's median of 5 launches after 2 warm-ups (round 3
+    quoted one shape, 2048 x 256 with one access in flight, which under-drives fills and copies).
     """
     import statistics
 
@@ -483,21 +485,126 @@ def measure_ceilings(eng):
     a.zero_()
     b.zero_()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    out = {"bytes": 4 * n, "how": "mpx_bw_probe (grid-stride float4 kernels, 2048 x 256 threads) over 1 GiB, HIP events, "
-                                  "median of 7 launches after 2 warm-ups, this process, this device"}
+    n_shapes = int(eng.lib.mpx_bw_probe_shapes())
+    out = {"bytes": 4 * n, "how": "mpx_bw_probe over 1 GiB in %d launch shapes (tools/bw_sweep.hip), HIP events, best shape's "
+                                  "median of 5 launches after 2 warm-ups, this process, this device" % n_shapes}
     with torch.cuda.device(eng.device):
-        for mode, name, nbytes in ((0, "read", 4.0 * n), (1, "write", 4.0 * n), (2, "copy", 8.0 * n)):
-            ts = []
-            for r in range(9):
-                e0.record()
-                _lib.check(eng.lib.mpx_bw_probe(eng.stream_ptr(), mode, a.data_ptr(), b.data_ptr(), n), "mpx_bw_probe")
-                e1.record()
-                torch.cuda.synchronize()
-                if r >= 2:
-                    ts.append(e0.elapsed_time(e1))
-            out[name + "_GBps"] = round(nbytes / (statistics.median(ts) * 1e-3) / 1e9, 1)
+        for kind, name, nbytes in ((0, "read", 4.0 * n), (1, "write", 4.0 * n), (2, "copy", 8.0 * n)):
+            best, per_shape = 0.0, []
+            for shape in range(n_shapes):
+                ts = []
+                for r in range(7):
+                    e0.record()
+                    _lib.check(eng.lib.mpx_bw_probe(eng.stream_ptr(), kind + 16 * shape, a.data_ptr(), b.data_ptr(), n), "mpx_bw_probe")
+                    e1.record()
+                    torch.cuda.synchronize()
+                    if r >= 2:
+                        ts.append(e0.elapsed_time(e1))
+                gbps = round(nbytes / (statistics.median(ts) * 1e-3) / 1e9, 1)
+                per_shape.append(gbps)
+                best = max(best, gbps)
+            out[name + "_GBps"] = best
+            out[name + "_GBps_by_shape"] = per_shape
     del a, b
     torch.cuda.empty_cache()
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# board power: the lossless kernels run AT the device's power cap, so the bench samples it
+# ------------------------------------------------------------------------------------------------------------------
+def _hwmon_dir(torch, dev_index=0):
+    """hwmon directory of the card HIP device `dev_index` is (matched by PCI address), or None."""
+    import glob
+
+    try:
+        pr = torch.cuda.get_device_properties(dev_index)
+        bus = "%04x:%02x:%02x" % (getattr(pr, "pci_domain_id", 0), pr.pci_bus_id, pr.pci_device_id)
+    except Exception:
+        return None
+    for d in glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*"):
+        if bus in os.path.realpath(d) and os.path.isfile(os.path.join(d, "power1_input")):
+            return d
+    return None
+
+
+def _read_num(path):
+    try:
+        with open(path) as f:
+            return float(f.read().strip())
+    except Exception:
+        return None
+
+
+class PowerSampler:
+    """Samples power1_input (uW) of one hwmon directory every few ms from a thread; mean_w() over the samples taken
+    after `skip_s` seconds (the sensor is a moving average: the first few hundred ms still show the previous phase)."""
+
+    def __init__(self, hwmon, period_s=0.004):
+        import threading
+
+        self.file = os.path.join(hwmon, "power1_input")
+        self.period, self.rows, self._stop = period_s, [], False
+        self.t0 = time.perf_counter()
+        self.thread = threading.Thread(target=self._run, daemon=True)
+        self.thread.start()
+
+    def _run(self):
+        while not self._stop:
+            v = _read_num(self.file)
+            if v is not None:
+                self.rows.append((time.perf_counter() - self.t0, v * 1e-6))
+            time.sleep(self.period)
+
+    def stop(self):
+        self._stop = True
+        self.thread.join()
+
+    def mean_w(self, skip_s=0.0):
+        v = [w for t, w in self.rows if t >= skip_s]
+        return (sum(v) / len(v)) if v else None
+
+
+def measure_power(torch, dev_index, phases, seconds=1.6):
+    """
+    Board power while each phase (name -> callable enqueueing one launch / step) loops for `seconds`: mean of the sensor
+    over the second half of the loop, with the time per call from HIP events.  Returns None without an hwmon directory.
+    energy_J = power x time per call; energy_above_idle_J subtracts the device's idle power measured first.
+    """
+    d = _hwmon_dir(torch, dev_index)
+    if d is None:
+        return None
+    torch.cuda.synchronize()
+    time.sleep(1.2)
+    idle = _read_num(os.path.join(d, "power1_input"))
+    cap = _read_num(os.path.join(d, "power1_cap"))
+    out = {"cap_W": (round(cap * 1e-6, 1) if cap else None), "idle_W": (round(idle * 1e-6, 1) if idle else None),
+           "source": "amdgpu hwmon power1_input of this device (%s), sampled every 4 ms while the phase loops for %.1f s; mean "
+                     "over the second half" % (d, seconds), "phases": {}}
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for name, fn in phases:
+        smp = PowerSampler(d)
+        t0 = time.perf_counter()
+        ms = []
+        while time.perf_counter() - t0 < seconds:
+            e0.record()
+            for _ in range(20):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            ms.append(e0.elapsed_time(e1) / 20)
+        smp.stop()
+        w = smp.mean_w(skip_s=0.5 * seconds)
+        m = sum(ms[len(ms) // 2:]) / max(1, len(ms[len(ms) // 2:]))
+        ph = {"ms": round(m, 4), "board_W": (round(w, 1) if w else None)}
+        if w:
+            ph["energy_J"] = round(w * m * 1e-3, 4)
+            if idle:
+                ph["energy_above_idle_J"] = round((w - idle * 1e-6) * m * 1e-3, 4)
+            if cap:
+                ph["frac_of_cap"] = round(w / (cap * 1e-6), 3)
+        out["phases"][name] = ph
+        time.sleep(0.3)
     return out
 
 
@@ -612,6 +719,50 @@ def _committed_traffic(kernel):
         return None, "no committed PMC measurement"
 
 
+def _self_launch(n):
+    """
+    `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* in the environment, the same command line), as the reference's "call it, it fans out"
+    (libutils.py:32-63).  Rank 0 prints the JSON line on our stdout.  Returns the exit code.
+    """
+    import socket
+    import subprocess
+
+    if not os.environ.get("BENCH_SHARE_DEVICE"):
+        import torch
+
+        have = torch.cuda.device_count()
+        if have < n:
+            sys.stderr.write("bench.py: --gpus %d but %d device(s) visible (BENCH_SHARE_DEVICE=1 puts every rank on cuda:0)\n" % (n, have))
+            return 2
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=(None if r == 0 else subprocess.DEVNULL)))
+    rc = 0
+    try:
+        while procs:
+            for p_ in list(procs):
+                c = p_.poll()
+                if c is None:
+                    continue
+                procs.remove(p_)
+                if c != 0:      # one rank failed: the others would wait in a barrier forever
+                    rc = rc or c
+                    for q in procs:
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for q in procs:
+            q.kill()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -634,6 +785,8 @@ def main():
     ap.add_argument("--pmc-child", action="store_true",
                     help="internal: the short workload the live PMC passes profile (lossless steps + 3 configs[2] steps)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.pmc_child:
+        sys.exit(_self_launch(args.gpus))   # `python bench.py --gpus N` on its own: fan out like lu.run_multithreaded does
 
     import torch
 
@@ -644,12 +797,32 @@ def main():
     backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
     dev_index = 0 if os.environ.get("BENCH_SHARE_DEVICE") else local_rank
     if world > 1:
+        import datetime
+
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.gpus != world and rank == 0:
+            sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d: the launcher's world size is what runs\n" % (args.gpus, world))
+        if not os.environ.get("BENCH_SHARE_DEVICE") and torch.cuda.device_count() <= dev_index:
+            raise SystemExit("bench.py: rank %d wants cuda:%d but only %d device(s) are visible" % (rank, dev_index, torch.cuda.device_count()))
         torch.cuda.set_device(dev_index)
-        if backend == "nccl":   # "nccl" is RCCL on ROCm; only the barrier and two scalar reductions use it
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
+        if backend == "nccl":   # "nccl" is RCCL on ROCm; only the barrier and two scalar reductions use it -- nothing on the
+            try:                # data path -- so a node whose RCCL cannot initialise still runs, over gloo
+                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index),
+                                        timeout=datetime.timedelta(seconds=180))
+                probe = torch.zeros(1, device="cuda")
+                dist.all_reduce(probe)
+                torch.cuda.synchronize()
+            except Exception as e:
+                sys.stderr.write("bench.py rank %d: RCCL unavailable (%s: %s); falling back to gloo\n" % (rank, type(e).__name__, str(e)[:200]))
+                try:
+                    dist.destroy_process_group()
+                except Exception:
+                    pass
+                os.environ["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1)
+                backend = "gloo"
+                dist.init_process_group(backend="gloo")
         else:
             dist.init_process_group(backend=backend)
     else:
@@ -826,7 +999,7 @@ def main():
             "traffic_over_algorithmic": (round(traffic / alg[dom], 4) if traffic else None),
             "kernels": kern,
             "kernel_time_source": "HIP events on the launch stream, mean of %d launches in this process (the rocprofv3 "
-                                  "--kernel-trace --stats summary of this command: profiles/, latest r03_*kernel_stats.csv)" % reps,
+                                  "--kernel-trace --stats summary of this command: profiles/, latest r04_*kernel_stats.csv)" % reps,
             "path_alg_GBps": round(sum(alg) / (sum(ms) * 1e-3) / 1e9, 1)}
     if full:
         try:    # what this device sustains for plain streams: the read ceiling bounds k_synth_ola_pair, the write one k_analysis
@@ -837,6 +1010,17 @@ def main():
             kern[1]["frac_of_measured_read"] = roof["frac_of_measured_read"]
         except Exception as e:
             roof["measured_ceilings"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        try:    # board power while each kernel loops: both lossless kernels sit at the device's power cap
+            pw = measure_power(torch, dev_index, (
+                ("k_analysis", lambda: aplan.run(out=feats)),
+                ("k_synth_ola_pair+k_ola_fixup", lambda: splan.run(feats[0], feats[1], feats[2], strips=strips, out=pcm_out)),
+                ("step", lambda: (aplan.run(out=feats), splan.run(feats[0], feats[1], feats[2], strips=strips, out=pcm_out)))))
+            if pw is not None:
+                roof["power"] = pw
+                roof["power_note"] = ("a launch at the cap lasts energy / (cap - idle) whatever its memory rate: the 8 TB/s "
+                                      "fraction above is bounded by the board's power limit, not by HBM (tools/energy_probe.py)")
+        except Exception as e:
+            roof["power"] = {"error": "%s: %s" % (type(e).__name__, e)}
 
     if rank == 0:
         ms_step = dt / args.steps * 1e3

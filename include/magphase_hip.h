@@ -441,11 +441,14 @@ int mpx_post_filter_merlin(void* stream, const float* mag_mel_log, int64_t n_fra
                            const float* cf, double magic, float* mcep, float* mcep_w, float* r0, float* p_r0, float* out);
 
 /*
- * Memory-rate probe (csrc/magphase_probe.hip; measurement only, not on the MagPhase path): one grid-stride float4
- * kernel over n_floats (a multiple of 4) elements -- mode 0 reads `a` (b: one float of scratch), mode 1 fills `a`,
- * mode 2 copies a -> b.  bench.py times these with HIP events to quote the device's own streaming read / write / copy
- * ceilings beside the 8 TB/s spec peak in its roofline object.  The reference has no counterpart.
+ * Memory-rate probe (csrc/magphase_probe.hip; measurement only, not on the MagPhase path): one streaming float4 kernel
+ * over n_floats (a multiple of 4) elements.  mode = kind + 16 * shape: kind 0 reads `a` (b: one float of scratch), kind 1
+ * fills `a`, kind 2 copies a -> b; shape < mpx_bw_probe_shapes() selects the launch shape (grid x block, independent
+ * 16-byte accesses in flight per lane, non-temporal bit; shape 0 = 2048 x 256 with one access in flight).  bench.py times
+ * every shape with HIP events and quotes the best per kind as the device's own streaming read / write / copy ceilings
+ * beside the 8 TB/s spec peak in its roofline object.  The reference has no counterpart.
  */
+int mpx_bw_probe_shapes(void);
 int mpx_bw_probe(void* stream, int32_t mode, float* a, float* b, int64_t n_floats);
 
 /* ------------------------------------------------------------------------------------------------------------------

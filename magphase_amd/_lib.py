@@ -64,6 +64,7 @@ SYMBOLS = (
     "mpx_hpf_block",
     "mpx_output_hpf",
     "mpx_bw_probe",
+    "mpx_bw_probe_shapes",
     "mpx_post_filter_merlin",
 )
 
@@ -207,6 +208,8 @@ def _load_locked():
     lib.mpx_post_filter_merlin.restype = ctypes.c_int
     lib.mpx_post_filter_merlin.argtypes = [vp, vp, i64, i32, vp, vp, vp, vp, i32, ctypes.c_double, vp, ctypes.c_double,
                                            vp, vp, vp, vp, vp]
+    lib.mpx_bw_probe_shapes.restype = ctypes.c_int
+    lib.mpx_bw_probe_shapes.argtypes = []
     lib.mpx_bw_probe.restype = ctypes.c_int
     lib.mpx_bw_probe.argtypes = [vp, i32, vp, vp, i64]
     _lib = lib

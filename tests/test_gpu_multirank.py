@@ -54,6 +54,38 @@ def test_bench_two_ranks_on_one_device():
     assert "cpu_baseline" not in j2 and "roofline" in j2
 
 
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it starts two ranks itself (a bare
+    `--gpus 8` used to run one rank and print n_gpus 1).  Both ranks share device 0 here; gloo carries the barrier."""
+    env = dict(os.environ, BENCH_DIST_BACKEND="gloo", BENCH_SHARE_DEVICE="1", OMP_NUM_THREADS="4")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "5", "--warmup", "2", "--quick"], cwd=ROOT,
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and "utterance-sharded x2" in j["config"]["parallelism"]
+    f = j["value"] * j["ms_per_step"] * 1e-3
+    assert 1.9 * j["config"]["frames_per_gpu"] < f < 2.1 * j["config"]["frames_per_gpu"]
+    # the corpus workload through the same self-launch (strong scaling: the corpus is sharded over the ranks)
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--workload", "corpus", "--utts", "48"], cwd=ROOT,
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["n_gpus"] == 2 and j["scaling"] == "strong"
+
+
+def test_bench_refuses_more_ranks_than_devices():
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "BENCH_SHARE_DEVICE"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "64", "--quick"], cwd=ROOT, env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 2 and "device(s) visible" in r.stderr
+
+
 def _make_corpus(tmp_path, n, fs_list):
     sys.path.insert(0, os.path.join(ROOT, "demos"))
     import make_demo_data
