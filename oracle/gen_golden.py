@@ -266,6 +266,22 @@ def gen_labels(mp, la):
     np.savez_compressed(os.path.join(OUT, "g9_labels.npz"), **out)
 
 
+def gen_merlin_legs(la):
+    """G12: the two legs of post_filter_merlin (magphase.py:3398, :3451) that are the reference's own Python --
+    la.rceps(log, compact) and la.mcep_to_sp_cosmat(alpha=0, 'log') -- on seeded log mel magnitudes (60 and 24 bins) and
+    on the bundled predicted magnitudes.  The SPTK legs in between stay unpinned."""
+    rng = np.random.RandomState(1204)
+    out = {"pinned": np.int64(1)}
+    pred = np.fromfile(os.path.join(ref_shim.REF_ROOT, "demos", "data_48k", "params_predicted", "hvd_704.mag"),
+                       dtype=np.float32).reshape(-1, 60).astype(np.float64)
+    for tag, x in (("a60", rng.uniform(-9, 1, (12, 60))), ("b24", rng.uniform(-9, 1, (7, 24))), ("pred", pred[:40])):
+        out[tag + "_in"] = x
+        c = la.rceps(x.copy(), in_type="log", out_type="compact")
+        out[tag + "_rceps"] = c
+        out[tag + "_cos"] = la.mcep_to_sp_cosmat(c.astype(np.float32).astype(np.float64), x.shape[1], alpha=0.0, out_type="log")
+    np.savez_compressed(os.path.join(OUT, "g12_merlin_legs.npz"), **out)
+
+
 def main():
     if not ref_shim.reference_available():
         raise SystemExit("reference not present; golden vectors can only be generated in the build container")
@@ -284,6 +300,7 @@ def main():
             gen_labels(mp, la)
             gen_fbank(mp, la, lu)
             gen_fbank_warp(mp, la)
+            gen_merlin_legs(la)
         finally:
             os.chdir(cwd)
     for f in sorted(os.listdir(OUT)):

@@ -639,6 +639,107 @@ def post_filter(m_mag_mel_log, fs, av_len_at_zero=None, av_len_at_nyq=None, boos
 # =============================================================================================
 # compressed synthesis  (magphase.py:825-997)
 # =============================================================================================
+# =============================================================================================
+# Merlin-style post-filter (magphase.py:3375-3465) -- PARITY UNPINNED for the SPTK legs
+# =============================================================================================
+def rceps_compact(m_log):
+    """la.rceps(m, in_type='log', out_type='compact') (libaudio.py:252-269): even extension, real IFFT, coefficients
+    1 .. n-3 doubled, first n kept.  Pinned: golden g12 (the reference's own function)."""
+    m_log = np.asarray(m_log, dtype=np.float64)
+    n = m_log.shape[1]
+    m_c = np.fft.ifft(add_hermitian_half_real(m_log)).real
+    m_c[:, 1:(n - 2)] *= 2
+    return m_c[:, :n]
+
+
+def _pipe(x):
+    """An SPTK pipe / temp file: float32 on the wire (x2x +af, lu.write_binfile), double inside every tool."""
+    return np.asarray(x, dtype=np.float32).astype(np.float64)
+
+
+def _sptk_freqt_aA(c, order_out, a_in, a_out):
+    """``freqt -m <len-1> -a a_in -M order_out -A a_out``: SPTK derives ONE all-pass constant
+    a = (a_out - a_in) / (1 - a_in a_out) and runs the freqt recursion with it (frame by frame)."""
+    a = (a_out - a_in) / (1.0 - a_in * a_out)
+    return freqt(c, order_out, a)
+
+
+def _sptk_c2acr_r0(c, fft_len):
+    """``c2acr -m <len-1> -M 0 -l fft_len``, frame by frame as the tool does: zero-pad the cepstrum to fft_len, real FFT,
+    x = exp(2 Re C) on every bin, inverse FFT, r[0] = x-sum / fft_len."""
+    c = np.atleast_2d(c)
+    out = np.empty(c.shape[0])
+    for f in range(c.shape[0]):
+        x = np.zeros(fft_len)
+        x[:c.shape[1]] = c[f]
+        re = np.fft.rfft(x).real                       # fftr: bins 0 .. l/2; the upper half mirrors them
+        p = np.exp(2.0 * re)
+        out[f] = (p[0] + p[-1] + 2.0 * np.sum(p[1:-1])) / fft_len
+    return out
+
+
+def _sptk_mc2b(mc, a):
+    """``mc2b -m order -a a``: b[order] = mc[order]; b[m] = mc[m] - a b[m+1] downwards (per frame)."""
+    b = np.array(mc, dtype=np.float64)
+    for f in range(b.shape[0]):
+        for m in range(b.shape[1] - 2, -1, -1):
+            b[f, m] = mc[f, m] - a * b[f, m + 1]
+    return b
+
+
+def _sptk_b2mc(b, a):
+    """``b2mc -m order -a a``: d = b[order]; for m = order-1 .. 0: o = b[m] + a d; d = b[m]; mc[m] = o."""
+    b = np.asarray(b, dtype=np.float64)
+    mc = np.array(b)
+    for f in range(b.shape[0]):
+        d = b[f, -1]
+        for m in range(b.shape[1] - 2, -1, -1):
+            o = b[f, m] + a * d
+            d = b[f, m]
+            mc[f, m] = o
+    return mc
+
+
+def post_filter_merlin(m_mag_mel_log, fs, pf_coef=1.4):
+    """
+    magphase.py:3375-3465, command by command (each ``|`` and each temp file is a float32 stream):
+      temp.mcep   = la.rceps(mag, 'log', 'compact')                                               (:3398-3399)
+      temp.lift   = echo 1 1 pf pf ... | x2x +af          (pf printed with %1.2f)                   (:3404, :3418-3419)
+      temp.r0     = freqt -m n-1 -a alpha -M 2047 -A 0 < mcep | c2acr -m 2047 -M 0 -l 4096          (:3422-3424)
+      temp.p_r0   = vopr -m mcep lift | freqt ... | c2acr ...                                       (:3426-3429)
+      temp.b0     = vopr -m mcep lift | mc2b -a alpha | bcp -s 0 -e 0                               (:3432-3434)
+      temp.p_b0   = vopr -d r0 p_r0 | sopr -LN -d 2 | vopr -a b0                                    (:3437-3439)
+      temp.mcep_pf= vopr -m mcep lift | mc2b | bcp -s 1 -e order | merge -s 0 -N 0 p_b0 | b2mc      (:3442-3445)
+      out         = la.mcep_to_sp_cosmat(mcep_pf, n, alpha=0.0, out_type='log'); NaN -> la.MAGIC    (:3451-3455)
+    PARITY UNPINNED: SPTK-3.9 (x2x, freqt, c2acr, vopr, sopr, mc2b, bcp, merge, b2mc) is an external binary package absent
+    from /root/reference and from this image; its tools are restated from their published algorithms (Tokuda et al.
+    1994 for freqt; the MLSA coefficient recursions for mc2b / b2mc).  The two legs that ARE the reference's own Python
+    (la.rceps, la.mcep_to_sp_cosmat) are pinned by golden g12.  Written independently of magphase_amd.hostmath's
+    table form (matrices) -- frame-by-frame recursions here.
+    """
+    m = np.asarray(m_mag_mel_log, dtype=np.float64)
+    fft_len = 4096
+    minph_ord = fft_len // 2 - 1
+    alpha = define_alpha(fs)
+    n = m.shape[1]
+    mcep = _pipe(rceps_compact(m))
+    lift = _pipe(np.array([1.0, 1.0] + [float("%1.2f" % pf_coef)] * (n - 2)))
+    r0 = _pipe(_sptk_c2acr_r0(_pipe(_sptk_freqt_aA(mcep, minph_ord, alpha, 0.0)), fft_len))
+    mcep_w = _pipe(mcep * lift[None, :])                                        # vopr -m
+    p_r0 = _pipe(_sptk_c2acr_r0(_pipe(_sptk_freqt_aA(mcep_w, minph_ord, alpha, 0.0)), fft_len))
+    b = _pipe(_sptk_mc2b(mcep_w, alpha))
+    b0 = b[:, 0]                                                                # bcp -s 0 -e 0
+    with np.errstate(divide="ignore", invalid="ignore"):
+        ratio = _pipe(r0 / p_r0)                                                # vopr -d
+        half_ln = _pipe(np.log(ratio) / 2.0)                                    # sopr -LN -d 2
+    p_b0 = _pipe(half_ln + b0)                                                  # vopr -a
+    b_pf = np.hstack((p_b0[:, None], b[:, 1:]))                                 # bcp -s 1 -e order | merge -s 0 -N 0
+    mcep_pf = _pipe(_sptk_b2mc(b_pf, alpha))
+    out = mcep_to_sp_cosmat(mcep_pf, n, alpha=0.0, out_type="log")
+    out[np.isnan(out)] = MAGIC
+    return out
+
+
 def frm_list_to_matrix(frames, v_shift, nfft):
     """libaudio.py:122-140: each ragged frame placed so that its epoch lands on index nfft/2."""
     m = np.zeros((len(v_shift), nfft))

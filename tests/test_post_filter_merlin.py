@@ -1,12 +1,18 @@
 """
-Merlin-style post-filter (magphase.py:3375-3465).  PARITY UNPINNED: the reference runs nine SPTK
-binaries that exist neither in the build container nor on the GPU box; these are known-answer properties of the
-restated arithmetic (magphase_amd.magphase.post_filter_merlin).
+Merlin-style post-filter (magphase.py:3375-3465).  PARITY UNPINNED for the SPTK legs: the reference
+runs nine SPTK binaries that exist neither in the build container nor on the GPU box.  The checker is
+oracle.magphase_oracle.post_filter_merlin -- the command chain restated tool by tool, frame by frame, written
+independently of the product's table form (magphase_amd.hostmath.merlin_tables); its two legs that are the reference's
+own Python (la.rceps, la.mcep_to_sp_cosmat) are pinned by golden g12.  The product's host form and its device kernels are
+both compared with THAT (round 3 compared the device form with the product's own host form).
 """
+import os
+
 import numpy as np
 
 from magphase_amd import hostmath as hm
 from magphase_amd import magphase as mp
+from oracle import magphase_oracle as orc   # checker only
 
 
 def _log_mel_mags(n_frames=40, dim=60, seed=5):
@@ -19,6 +25,34 @@ def _log_mel_mags(n_frames=40, dim=60, seed=5):
             + 1.0 * np.exp(-0.5 * ((k - f3) / 3.0) ** 2)
         out.append(env + rng.uniform(-6, -2))
     return np.array(out)
+
+
+def test_oracle_legs_match_the_reference(golden_dir):
+    """g12: la.rceps(log, compact) and la.mcep_to_sp_cosmat(alpha=0, 'log') as run by the reference itself."""
+    g = np.load(os.path.join(golden_dir, "g12_merlin_legs.npz"))
+    assert int(g["pinned"]) == 1
+    for tag in ("a60", "b24", "pred"):
+        c = orc.rceps_compact(g[tag + "_in"])
+        assert np.max(np.abs(c - g[tag + "_rceps"])) <= 1e-13
+        sp = orc.mcep_to_sp_cosmat(orc._pipe(c), c.shape[1], alpha=0.0, out_type="log")
+        assert np.max(np.abs(sp - g[tag + "_cos"])) <= 1e-12
+        assert np.max(np.abs(hm.rceps_compact(g[tag + "_in"]) - g[tag + "_rceps"])) <= 1e-13      # the product's legs too
+        assert np.max(np.abs(hm.cos_matrix_log_spectrum(hm._f32(c), c.shape[1]) - g[tag + "_cos"])) <= 1e-12
+
+
+def test_host_form_matches_the_independent_oracle(golden_dir):
+    """The product's host form (matrix tables) against the oracle's tool-by-tool chain: the same float32 pipe boundaries,
+    so they differ only where a float64 rounding difference flips a float32 pipe value (1 ulp of float32, ~1e-6 at these
+    magnitudes: the bound; measured 8e-15 in the build container -- no flip on these inputs)."""
+    g = np.load(os.path.join(golden_dir, "g5_generation_hvd704.npz"))
+    real = g["in_mag"].reshape(-1, 60).astype(np.float64)
+    for fs in (48000, 16000):
+        for m in (_log_mel_mags(n_frames=25, seed=3), real[:60], _log_mel_mags(n_frames=5, dim=24), np.full((2, 60), -23.0)):
+            for pf in (1.4, 1.0):
+                want = orc.post_filter_merlin(m, fs, pf_coef=pf)
+                got = mp.post_filter_merlin(m, fs, pf_coef=pf)
+                assert got.shape == want.shape and np.array_equal(np.isfinite(got), np.isfinite(want))
+                assert np.max(np.abs(got - want)) < 2e-6, (fs, pf, np.max(np.abs(got - want)))
 
 
 def test_mc2b_b2mc_are_inverse():
@@ -65,10 +99,8 @@ def test_silent_frames_do_not_produce_nans():
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-# device form (mpx_post_filter_merlin, csrc/magphase_merlin.hip): -m gpu, against the host form above
+# device form (mpx_post_filter_merlin, csrc/magphase_merlin.hip): -m gpu, against the oracle
 # ---------------------------------------------------------------------------------------------------------------------
-import os  # noqa: E402
-
 import pytest  # noqa: E402
 
 from _tol import within  # noqa: E402
@@ -89,22 +121,23 @@ def test_merlin_tables_reproduce_the_host_chain():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("fs", [48000, 16000])
-def test_device_form_matches_host_form(fs, golden_dir):
+def test_device_form_matches_the_oracle(fs, golden_dir):
+    """HIP kernels vs oracle.post_filter_merlin (not vs the product's own host form)."""
     x = _log_mel_mags(n_frames=300, seed=11)
     g = np.load(os.path.join(golden_dir, "g5_generation_hvd704.npz"))
     real = g["in_mag"].reshape(-1, 60).astype(np.float64)          # the reference's bundled predicted features
     for m in (x, real, np.full((3, 60), -23.0)):
-        want = mp.post_filter_merlin(m, fs)
+        want = orc.post_filter_merlin(m, fs)
         got = mp.post_filter_merlin_device(m, fs)
         assert got.shape == want.shape and np.all(np.isfinite(got))
         within(np.max(np.abs(got - want)), 3e-5, "MERLIN_PF_ABS")
     x24 = _log_mel_mags(n_frames=10, dim=24)
-    within(np.max(np.abs(mp.post_filter_merlin_device(x24, fs) - mp.post_filter_merlin(x24, fs))), 3e-5, "MERLIN_PF_ABS")
+    within(np.max(np.abs(mp.post_filter_merlin_device(x24, fs) - orc.post_filter_merlin(x24, fs))), 3e-5, "MERLIN_PF_ABS")
 
 
 @pytest.mark.gpu
 def test_batch_synthesis_with_device_merlin_post_filter(golden_dir):
-    """synthesis_from_compressed_batch(b_post_filter='merlin') == synthesis of host-post-filtered magnitudes (same seeded
+    """synthesis_from_compressed_batch(b_post_filter='merlin') == synthesis of ORACLE-post-filtered magnitudes (same seeded
     device noise), and a second run is bit-identical (the post-filter kernels use no atomics)."""
     g = np.load(os.path.join(golden_dir, "g5_generation_hvd704.npz"))
     mm = g["in_mag"].reshape(-1, 60).astype(np.float64)
@@ -116,8 +149,8 @@ def test_batch_synthesis_with_device_merlin_post_filter(golden_dir):
                                            b_post_filter="merlin", **kw)
     a2 = mp.synthesis_from_compressed_batch([(mm, rr, ii, lf), (mm[:120], rr[:120], ii[:120], lf[:120])], 48000,
                                             b_post_filter="merlin", **kw)
-    b = mp.synthesis_from_compressed_batch([(mp.post_filter_merlin(mm, 48000), rr, ii, lf),
-                                            (mp.post_filter_merlin(mm[:120], 48000), rr[:120], ii[:120], lf[:120])], 48000, **kw)
+    b = mp.synthesis_from_compressed_batch([(orc.post_filter_merlin(mm, 48000), rr, ii, lf),
+                                            (orc.post_filter_merlin(mm[:120], 48000), rr[:120], ii[:120], lf[:120])], 48000, **kw)
     for u in range(2):
         assert np.array_equal(a[u], a2[u]) and a[u].shape == b[u].shape
         within(np.max(np.abs(a[u] - b[u])) / np.max(np.abs(b[u])), 6e-6, "MERLIN_PF_PCM")
