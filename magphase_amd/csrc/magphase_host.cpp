@@ -27,6 +27,7 @@
 #if defined(__SSE2__)
 #include <emmintrin.h>
 #endif
+#include <exception>
 #include <vector>
 
 #include "../../include/magphase_hip.h"
@@ -58,10 +59,20 @@ class WorkerPool {
             ++gen_;
         }
         cv_work_.notify_all();
-        body();
-        std::unique_lock<std::mutex> lk(mu_);
-        cv_done_.wait(lk, [&] { return finished_ == want_; });
-        body_ = nullptr;
+        // `body` lives on the caller's stack and the workers dereference it: if it throws on this thread (bad_alloc in a
+        // file reader), the workers are waited for BEFORE the exception leaves this frame
+        std::exception_ptr err;
+        try {
+            body();
+        } catch (...) {
+            err = std::current_exception();
+        }
+        {
+            std::unique_lock<std::mutex> lk(mu_);
+            cv_done_.wait(lk, [&] { return finished_ == want_; });
+            body_ = nullptr;
+        }
+        if (err) std::rethrow_exception(err);
     }
 
    private:
@@ -77,7 +88,10 @@ class WorkerPool {
                 if (idx < want_) body = body_;
             }
             if (body) {
-                (*body)();
+                try {
+                    (*body)();
+                } catch (...) {   // a worker's exception must not terminate the process; the caller's own copy reports
+                }
                 std::unique_lock<std::mutex> lk(mu_);
                 if (++finished_ == want_) cv_done_.notify_one();
             }
@@ -110,6 +124,13 @@ class WorkerPool {
     pid_t pid_ = getpid();
 };
 
+// ONE pool per calling thread, shared by every parallel_for instantiation (a `static thread_local` inside the function
+// template gave each of the six call sites its own pool per calling thread: ~126 parked threads instead of ~21).
+WorkerPool& thread_pool() {
+    static thread_local WorkerPool pool;
+    return pool;
+}
+
 // Runs fn(i) for i in [0, n) on up to n_threads threads (work stealing through one atomic counter).
 template <typename F>
 void parallel_for(int n, int n_threads, F fn) {
@@ -123,8 +144,7 @@ void parallel_for(int n, int n_threads, F fn) {
     const std::function<void()> worker = [&] {
         for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) fn(i);
     };
-    static thread_local WorkerPool pool;
-    pool.run(nt - 1, worker);
+    thread_pool().run(nt - 1, worker);
 }
 
 bool read_whole(const char* path, std::string& out, int* err) {

@@ -92,8 +92,8 @@ __global__ __launch_bounds__(256) void k_merlin_r0(const float* __restrict__ c1,
         for (int e = 0; e < 16; ++e) {
             const int k = k0 + 16 * q + e;
             const float w = (k < nb) ? wk[k] : 0.0f;
-            s1 = fmaf(w, __expf(2.0f * acc1[e]), s1);
-            s2 = fmaf(w, __expf(2.0f * acc2[e]), s2);
+            s1 = fmaf(w, expf(2.0f * acc1[e]), s1);
+            s2 = fmaf(w, expf(2.0f * acc2[e]), s2);
         }
     }
     part[0][q][fl] = s1;
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void k_merlin_b(const float* __restrict__ mcw,
     y[D - 1] = b_next;                  // mcep_pf[D-1] = b[D-1]
     for (int m = D - 2; m >= 0; --m) {
         float b = x[m] - alpha * b_next;                        // mc2b
-        if (m == 0) b += 0.5f * __logf(r0[f] / p_r0[f]);        // vopr -d | sopr -LN -d 2 | vopr -a, merged into b[0]
+        if (m == 0) b += 0.5f * logf(r0[f] / p_r0[f]);        // vopr -d | sopr -LN -d 2 | vopr -a, merged into b[0]
         y[m] = b + alpha * b_next;                              // b2mc (b[m+1] of the unmodified tail: only b[0] changes)
         b_next = b;
     }

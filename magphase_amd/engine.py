@@ -49,42 +49,52 @@ class HostTicket:
 
 
 class _PinnedRing:
-    """A few page-locked host buffers handed out round-robin (grown on demand, never shrunk).  A slot is reusable after
-    its ticket's release(); acquire() waits for that -- the natural back-pressure of a pipeline whose writer is behind."""
+    """A few page-locked host buffers (grown on demand, never shrunk).  A slot is reusable after its ticket's release();
+    acquire() takes ANY free slot (a queue of free slots: two concurrent acquirers can never get the same one) and waits
+    for one when the writer is behind -- the natural back-pressure of the pipeline.  If none comes free within
+    MAGPHASE_RING_WAIT_S (default 20 s: e.g. a batch that needs more tickets at once than there are slots) it returns
+    (None, None) and the caller falls back to a synchronous copy instead of stalling."""
 
     def __init__(self, slots=4):
+        import queue
         import threading
 
         self._bufs = [None] * slots
-        self._free = [threading.Event() for _ in range(slots)]
-        for ev in self._free:
-            ev.set()
-        self._next = 0
+        self._freeq = queue.Queue()
+        for k in range(slots):
+            self._freeq.put(k)
         self._lock = threading.Lock()
 
-    def acquire(self, nbytes):
+    def acquire(self, nbytes, timeout=None):
+        import queue
+
         torch = _torch()
-        with self._lock:
-            slot = self._next
-            self._next = (slot + 1) % len(self._bufs)
-        if not self._free[slot].wait(timeout=120.0):
-            raise RuntimeError("pinned output ring: slot %d was never released (a consumer dropped its ticket?)" % slot)
-        self._free[slot].clear()
-        buf = self._bufs[slot]
-        if buf is None or buf.numel() < nbytes:
-            # Page-locking is slow (about 60 ms per 24 MB here): every slot is sized by the largest request so far with
-            # headroom, and the FIRST request sizes all of them -- the first batch of a corpus pays, once.
-            size = max([int(nbytes * 1.25), 1 << 20] + [b.numel() for b in self._bufs if b is not None])
-            first = all(b is None for b in self._bufs)
-            self._bufs[slot] = buf = torch.empty(size, dtype=torch.uint8).pin_memory()
-            if first:
-                for k in range(len(self._bufs)):
-                    if self._bufs[k] is None:
-                        self._bufs[k] = torch.empty(size, dtype=torch.uint8).pin_memory()
+        if timeout is None:
+            timeout = float(os.environ.get("MAGPHASE_RING_WAIT_S", "20"))
+        try:
+            slot = self._freeq.get(timeout=timeout)
+        except queue.Empty:
+            return None, None
+        try:
+            with self._lock:
+                buf = self._bufs[slot]
+                if buf is None or buf.numel() < nbytes:
+                    # Page-locking is slow (about 60 ms per 24 MB here): every slot is sized by the largest request so far
+                    # with headroom, and the FIRST request sizes all of them -- the first batch of a corpus pays, once.
+                    size = max([int(nbytes * 1.25), 1 << 20] + [b.numel() for b in self._bufs if b is not None])
+                    first = all(b is None for b in self._bufs)
+                    self._bufs[slot] = buf = torch.empty(size, dtype=torch.uint8).pin_memory()
+                    if first:
+                        for k in range(len(self._bufs)):
+                            if self._bufs[k] is None:
+                                self._bufs[k] = torch.empty(size, dtype=torch.uint8).pin_memory()
+        except BaseException:
+            self._freeq.put(slot)
+            raise
         return slot, buf
 
     def release(self, slot):
-        self._free[slot].set()
+        self._freeq.put(slot)
 
 
 class Engine:
@@ -232,16 +242,22 @@ class Engine:
         sizes = [int(t.numel()) for t in tensors]
         offs = np.concatenate(([0], np.cumsum([(n + 63) // 64 * 64 for n in sizes]))).astype(np.int64)
         slot, buf = self.out_ring().acquire(4 * int(offs[-1]) + 256)
-        host = buf[:4 * int(offs[-1])].view(torch.float32)
-        views = []
-        with torch.cuda.device(self.device):
-            for t, n, o in zip(tensors, sizes, offs[:-1]):
-                dst = host[int(o):int(o) + n].view(tuple(int(x) for x in t.shape))
-                if n:
-                    dst.copy_(t, non_blocking=True)
-                views.append(dst.numpy())
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(self.device))
+        if slot is None:   # ring exhausted: plain synchronous copies, a ticket with nothing to wait for
+            return [t.detach().to("cpu").numpy() for t in tensors], HostTicket(None, None, None, None)
+        try:
+            host = buf[:4 * int(offs[-1])].view(torch.float32)
+            views = []
+            with torch.cuda.device(self.device):
+                for t, n, o in zip(tensors, sizes, offs[:-1]):
+                    dst = host[int(o):int(o) + n].view(tuple(int(x) for x in t.shape))
+                    if n:
+                        dst.copy_(t, non_blocking=True)
+                    views.append(dst.numpy())
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(self.device))
+        except BaseException:
+            self.out_ring().release(slot)   # a failed copy must not leak the slot
+            raise
         return views, HostTicket(self.out_ring(), slot, ev, list(tensors))
 
     def output_pcm16(self, y, out_off_host, norm=0.98, async_out=False):
@@ -265,11 +281,19 @@ class Engine:
                        "mpx_pcm16")
             if async_out:   # non-blocking copy into a page-locked ring slot; the consumer waits on the ticket
                 slot, buf = self.out_ring().acquire(2 * max(total, 1))
-                host = buf[:2 * max(total, 1)].view(torch.int16)
-                host.copy_(out, non_blocking=True)
-                ev = torch.cuda.Event()
-                ev.record(torch.cuda.current_stream(self.device))
-                return host[:total].numpy(), HostTicket(self.out_ring(), slot, ev, [out, peaks, d_off])
+                if slot is not None:
+                    try:
+                        host = buf[:2 * max(total, 1)].view(torch.int16)
+                        host.copy_(out, non_blocking=True)
+                        ev = torch.cuda.Event()
+                        ev.record(torch.cuda.current_stream(self.device))
+                    except BaseException:
+                        self.out_ring().release(slot)
+                        raise
+                    return host[:total].numpy(), HostTicket(self.out_ring(), slot, ev, [out, peaks, d_off])
+                host = torch.empty(max(total, 1), dtype=torch.int16)   # ring exhausted: synchronous copy
+                host.copy_(out)
+                return host[:total].numpy(), HostTicket(None, None, None, None)
             # one D2H copy into a fresh pageable array (pinning a new 15-30 MB buffer per batch cost 7 ms, more than the copy)
             host = torch.empty(max(total, 1), dtype=torch.int16)
             host.copy_(out)
@@ -976,7 +1000,16 @@ class CompressedSynthesisPlan:
         # defer_rng: the reference noise stream's advanced state stays on the device (Engine.numpy_global_uniform(defer=True));
         #            the caller owes Engine.mt_sync() before numpy's global generator is used again
         # post_filter: False / True ('magphase': mp.post_filter on the device) / 'merlin' (mp.post_filter_merlin on the device)
-        self.apply_post_filter = post_filter if post_filter in ("merlin", "magphase") else bool(post_filter)
+        # (the reference's pf_type vocabulary: 'no' means no filtering, magphase.py:3229-3262 -- anything else is an error,
+        #  not silently "on")
+        if post_filter is None or post_filter is False or post_filter == "no":
+            self.apply_post_filter = False
+        elif post_filter is True or post_filter == "magphase":
+            self.apply_post_filter = "magphase" if post_filter == "magphase" else True
+        elif post_filter == "merlin":
+            self.apply_post_filter = "merlin"
+        else:
+            raise ValueError("post_filter must be False / None / 'no', True / 'magphase' or 'merlin', not %r" % (post_filter,))
         self.b_const_rate = bool(b_const_rate)
         if noise_mode not in ("reference", "device"):
             raise ValueError("noise_mode must be 'reference' (numpy global RNG, magphase.py:883) or 'device' (Philox on the GPU)")

@@ -128,13 +128,16 @@ def windowing(v_sig, v_pm, win_func=np.hanning):
     return l_frames, v_lens, v_pm_plus, left.astype(int), right.astype(int)
 
 
-def ola(m_frm, v_pm, win_func=None):
+def ola(m_frm, v_pm, win_func=None, device=None):
     """
     magphase.py:34-62 (PSOLA): frame i added at pm[i] - pm[0], head and tail trimmed so that frame centres land on the
     epochs.  Frames of 1024 / 2048 / 4096 samples without a window go through the device gather (mpx_ola_gather: the
     reference's ascending summation order, float32); anything else is summed on the host in float64.  With win_func the
     frames are multiplied by the centred anti-ringing window first -- IN PLACE, like the reference (magphase.py:48).
+    device=False (or MAGPHASE_OLA_HOST=1) keeps every call on the float64 host sum, the reference's own arithmetic.
     """
+    if device is None:
+        device = os.environ.get("MAGPHASE_OLA_HOST", "0") != "1"
     v_pm = np.asarray(v_pm).astype(int)
     nfrms, frmlen = np.shape(m_frm)
     rel, start, out_len = hm.ola_plan(v_pm, frmlen)
@@ -142,7 +145,7 @@ def ola(m_frm, v_pm, win_func=None):
         v_shift = np.append(la.pm_to_shift(v_pm), v_pm[-1] - v_pm[-2] if nfrms > 1 else v_pm[-1])
         for i in range(nfrms):
             m_frm[i, :] *= la.gen_centr_win(v_shift[i], v_shift[i + 1], frmlen, win_func=win_func)
-    if win_func is None and frmlen in (1024, 2048, 4096) and nfrms > 0 and out_len > 0:
+    if device and win_func is None and frmlen in (1024, 2048, 4096) and nfrms > 0 and out_len > 0:
         e = get_engine()
         frames = e.to_device(np.ascontiguousarray(m_frm, dtype=np.float32), np.float32)
         t = e.to_device_packed([("fo", np.array([0, nfrms]), np.int32), ("rel", rel, np.int32),
@@ -449,8 +452,10 @@ def synthesis_from_acoustic_modelling(in_feats_dir, filename_token, out_syn_dir,
         print('Using MagPhase postfilter...')
         m_mag_mel_log = post_filter(m_mag_mel_log, fs)
     elif pf_type == 'merlin':
+        # the device form, as iobatch.generate_waveforms_corpus(pf_type='merlin') runs it: one pf_type, one result whichever
+        # entry point writes the wav (post_filter_merlin, the float64 host chain, stays the array API)
         print('Using Merlin postfilter...')
-        m_mag_mel_log = post_filter_merlin(m_mag_mel_log, fs)
+        m_mag_mel_log = post_filter_merlin_device(m_mag_mel_log, fs)
     elif pf_type == 'no':
         print('No postfilter...')
     v_syn_sig = synthesis_from_compressed(m_mag_mel_log, m_real_mel, m_imag_mel, v_lf0, fs, fft_len=fft_len,
@@ -471,9 +476,11 @@ def analysis_compressed_batch(utts, fft_len=None, mag_dim=60, phase_dim=10, b_co
     async_out (with as_float32): returns (list, ticket) -- the three matrices are views of a page-locked buffer the device
     is still copying into; ticket.wait() before reading them, ticket.release() when done (engine.HostTicket).
     """
-    from scipy import signal
-
     engine = engine or get_engine()
+    if len(utts) == 0:   # nothing to do (the per-utterance loop of the reference would run zero times)
+        from .engine import HostTicket
+
+        return ([], HostTicket(None, None, None, None)) if async_out else []
     plan = CompressedAnalysisPlan(engine, utts, fft_len=fft_len, mag_dim=mag_dim, phase_dim=phase_dim,
                                   b_const_rate=b_const_rate, alpha_phase=alpha_phase)
     for lens in plan.lossless.long_frame_lens:
@@ -488,15 +495,21 @@ def analysis_compressed_batch(utts, fft_len=None, mag_dim=60, phase_dim=10, b_co
     else:
         h_mag, h_real, h_imag = ((engine.to_host_f32 if as_float32 else engine.to_host_f64)(t_) for t_ in plan.run())
     res = []
-    # signal.medfilt of every utterance's f0 in one pass (hostmath.medfilt3_batch: bit-identical; 30 us per scipy call)
-    f0_med = hm.medfilt3_batch(plan.f0_out) if len(utts) > 1 else [signal.medfilt(plan.f0_out[0])]
-    for u in range(len(utts)):
-        a, b = int(plan.out_off[u]), int(plan.out_off[u + 1])
-        v_f0 = plan.f0_out[u]
-        v_voi = (v_f0 > 0).astype('float')
-        v_lf0 = la.f0_to_lf0(v_voi * f0_med[u])                            # magphase.py:2499-2501
-        res.append((h_mag[a:b], h_real[a:b], h_imag[a:b], v_lf0, plan.lossless.v_shift[u].astype(int), plan.fs,
-                    plan.fft_len))
+    try:
+        # signal.medfilt of every utterance's f0 in one pass (hostmath.medfilt3_batch: bit-identical, also for 0 or 1
+        # vectors; 30 us per scipy call)
+        f0_med = hm.medfilt3_batch(plan.f0_out)
+        for u in range(len(utts)):
+            a, b = int(plan.out_off[u]), int(plan.out_off[u + 1])
+            v_f0 = plan.f0_out[u]
+            v_voi = (v_f0 > 0).astype('float')
+            v_lf0 = la.f0_to_lf0(v_voi * f0_med[u])                            # magphase.py:2499-2501
+            res.append((h_mag[a:b], h_real[a:b], h_imag[a:b], v_lf0, plan.lossless.v_shift[u].astype(int), plan.fs,
+                        plan.fft_len))
+    except BaseException:
+        if ticket is not None:   # the page-locked slot goes back to the ring when the host part fails
+            ticket.release()
+        raise
     return (res, ticket) if async_out else res
 
 

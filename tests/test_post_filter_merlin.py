@@ -154,3 +154,30 @@ def test_batch_synthesis_with_device_merlin_post_filter(golden_dir):
     for u in range(2):
         assert np.array_equal(a[u], a2[u]) and a[u].shape == b[u].shape
         within(np.max(np.abs(a[u] - b[u])) / np.max(np.abs(b[u])), 6e-6, "MERLIN_PF_PCM")
+
+
+@pytest.mark.gpu
+def test_post_filter_argument_vocabulary(golden_dir):
+    """b_post_filter takes the reference's pf_type words: 'no' is OFF (it used to count as truthy = the MagPhase filter),
+    a typo raises instead of silently filtering."""
+    g = np.load(os.path.join(golden_dir, "g5_generation_hvd704.npz"))
+    u = (g["in_mag"].reshape(-1, 60).astype(np.float64)[:80], g["in_real"].reshape(-1, 45).astype(np.float64)[:80],
+         g["in_imag"].reshape(-1, 45).astype(np.float64)[:80], g["in_lf0"].astype(np.float64)[:80])
+    kw = dict(noise_mode="device", noise_seeds=[3])
+    off = mp.synthesis_from_compressed_batch([u], 48000, b_post_filter=False, **kw)[0]
+    assert np.array_equal(mp.synthesis_from_compressed_batch([u], 48000, b_post_filter="no", **kw)[0], off)
+    on = mp.synthesis_from_compressed_batch([u], 48000, b_post_filter=True, **kw)[0]
+    assert np.array_equal(mp.synthesis_from_compressed_batch([u], 48000, b_post_filter="magphase", **kw)[0], on)
+    assert not np.array_equal(on, off)
+    for bad in ("Merlin", "yes", 2):
+        with pytest.raises(ValueError):
+            mp.synthesis_from_compressed_batch([u], 48000, b_post_filter=bad, **kw)
+
+
+@pytest.mark.gpu
+def test_empty_batches_return_empty_lists():
+    assert mp.analysis_compressed_batch([]) == []
+    res, ticket = mp.analysis_compressed_batch([], as_float32=True, async_out=True)
+    assert res == []
+    ticket.wait()
+    ticket.release()
