@@ -74,6 +74,20 @@ int mpx_analysis_frames_f64(void* stream, int fft_len, const void* tables_f64, c
                             const float* rows_in_use);
 
 /*
+ * mpx_analysis_frames_f64 with the WINDOW WEIGHTS READ FROM A HOST-BUILT TABLE instead of evaluated on the device:
+ * win_tab (DEVICE, float64) holds, for every half length h <= win_cap, the rising half np.hanning(2 h + 1)[0 .. h] at
+ * offset h (h + 1) / 2 -- (win_cap + 1)(win_cap + 2) / 2 doubles, built by the host's numpy (hostmath.hann_half_table), i.e.
+ * by the very function the reference windows with (libaudio.py:70-84).  The products sample x weight are then the
+ * reference's own float64 values, and a bin that cancels exactly carries the reference's own residue (0.0 or a few 2^-53,
+ * with its sign) instead of being flushed to zero.  Frames with a half longer than win_cap use the analytic window.
+ * win_tab == NULL: exactly mpx_analysis_frames_f64.
+ */
+int mpx_analysis_frames_f64w(void* stream, int fft_len, const void* tables_f64, const float* sig,
+                             const int64_t* frame_pos, const int32_t* frame_left, const int32_t* frame_right,
+                             int64_t n_frames, float* out_mag, float* out_real, float* out_imag, int64_t ld,
+                             const float* rows_in_use, const double* win_tab, int32_t win_cap);
+
+/*
  * Row pitch (in floats) the lossless feature matrices should be allocated with.  Any ld >= H is CORRECT for every
  * entry point that takes `ld` (so the matrices may live inside wider buffers); mpx_feat_ld() returns the pitch
  * measured fastest on MI355X, which is the reference's dense [F x H] layout, ld == H: padding the rows to a

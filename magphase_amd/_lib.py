@@ -21,6 +21,7 @@ SYMBOLS = (
     "mpx_tables_f64_bytes",
     "mpx_tables_f64_init",
     "mpx_analysis_frames_f64",
+    "mpx_analysis_frames_f64w",
     "mpx_synthesis_lossless_frames",
     "mpx_ola_gather",
     "mpx_synth_ola_slots",
@@ -118,6 +119,8 @@ def _load_locked():
     lib.mpx_tables_f64_init.argtypes = [vp, ctypes.c_int, vp]
     lib.mpx_analysis_frames_f64.restype = ctypes.c_int
     lib.mpx_analysis_frames_f64.argtypes = [vp, ctypes.c_int, vp, vp, vp, vp, vp, i64, vp, vp, vp, i64, vp]
+    lib.mpx_analysis_frames_f64w.restype = ctypes.c_int
+    lib.mpx_analysis_frames_f64w.argtypes = [vp, ctypes.c_int, vp, vp, vp, vp, vp, i64, vp, vp, vp, i64, vp, vp, i32]
     lib.mpx_feat_ld.restype = i64
     lib.mpx_feat_ld.argtypes = [ctypes.c_int]
     lib.mpx_synthesis_lossless_frames.restype = ctypes.c_int

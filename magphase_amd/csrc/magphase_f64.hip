@@ -64,12 +64,12 @@ __device__ __forceinline__ double rsqrt_f64(double s) {
 // say) comes out of numpy's FFT as 0.0 and the reference stores (0, 0, 0) for it; a residue of 2^-50 normalised to a
 // "phase" of (1, 0) moved the compressed phase features by 6e-5.
 template <bool PH>
-__device__ __forceinline__ void feat_store(double xr, double xi, double zero2, float* pm, float* pr, float* pi) {
+__device__ __forceinline__ void feat_store(double xr, double xi, double zero2, float mag_scale, float* pm, float* pr, float* pi) {
     const double s = xr * xr + xi * xi;
     // (the fp32 estimate needs a normal float: |X|^2 below 1e-38 is zero for the float32 features anyway)
     const bool nz = s > zero2;
     const double r = nz ? rsqrt_f64(s) : 0.0;
-    *pm = (float)(s * r);
+    *pm = (float)(s * r) * mag_scale;
     if (PH) {
         *pr = (float)(xr * r);
         *pi = (float)(xi * r);
@@ -90,7 +90,8 @@ __global__ __launch_bounds__(kAna64Waves * 64) void k_analysis_f64(const float* 
                                                                   const double* __restrict__ tw_g,
                                                                   float* __restrict__ omag, float* __restrict__ oreal,
                                                                   float* __restrict__ oimag, long long ld,
-                                                                  const float* __restrict__ rows_in_use) {
+                                                                  const float* __restrict__ rows_in_use,
+                                                                  const double* __restrict__ win_tab, int win_cap) {
     constexpr int M = 64 * P, N = 2 * M, LB = ilog2(P), kTile = 64 * P;
     extern __shared__ __attribute__((aligned(16))) double smem64[];
     double* tw = smem64;
@@ -126,6 +127,25 @@ __global__ __launch_bounds__(kAna64Waves * 64) void k_analysis_f64(const float* 
         const FrameGeom g = frame_geom(sig, fpos[f], fleft[f], fright[f], N);
         const double invL = (g.L > 0) ? 1.0 / (double)g.L : 1.0;
         const double invR = (g.LR > g.L) ? 1.0 / (double)(g.LR - g.L) : 0.0;
+        // Window weights from the HOST's np.hanning (win_tab: half window of half length h at h (h + 1) / 2, h <= win_cap;
+        // hostmath.hann_half_table): the products x[n] w[n] are then the reference's own doubles, and a bin that cancels
+        // exactly (DC / Nyquist over exactly periodic pitch periods) leaves the reference's own residue -- 0.0 or a few
+        // 2^-53 with the reference's sign -- instead of this kernel's polynomial's (round 3 flushed such bins to zero and the
+        // configs[2] test had to skip the frames that interpolate from them).  Frames with a half longer than win_cap (F0
+        // below 23 Hz at 48 kHz) keep the analytic window.  Wave-uniform.
+        const int gR = g.LR - g.L;
+        const bool tabw = rfl((int)(win_tab != nullptr && g.L <= win_cap && gR <= win_cap)) != 0;
+        const double* tl = win_tab + ((long long)g.L * (g.L + 1) >> 1);
+        const double* tr = win_tab + ((long long)gR * (gR + 1) >> 1);
+        auto weight = [&](int k) -> double {
+            if (tabw) return (k <= g.L) ? tl[k] : tr[g.LR - k];
+            return hann_half_f64(k, g.L, g.LR, g.kadd, invL, invR);
+        };
+        // The table path scales the frame by 2^30 (exact: a power of two changes no mantissa anywhere in the transform), so
+        // that a residue of 2^-53 x amplitude squares to a normal float for the reciprocal square root's fp32 seed; the
+        // magnitude is scaled back after its conversion to float32 (exact as well).
+        const float in_scale = tabw ? 1073741824.0f : 1.0f;
+        const float mag_scale = tabw ? 9.313225746154785e-10f : 1.0f;
 
         // ---- samples HBM -> LDS (fp32: the PCM is exact in float32), window in float64 while gathering in FFT order
         double re[P], im[P];
@@ -154,10 +174,8 @@ __global__ __launch_bounds__(kAna64Waves * 64) void k_analysis_f64(const float* 
                     k0 = (k0 >= N) ? k0 - N : k0;
                     int k1 = m + 1 + g.rot;
                     k1 = (k1 >= N) ? k1 - N : k1;
-                    if (k0 >= tile0 && k0 < hi)
-                        re[f64_in_reg<P>(j)] = (double)xbuf[k0 - tile0] * hann_half_f64(k0, g.L, g.LR, g.kadd, invL, invR);
-                    if (k1 >= tile0 && k1 < hi)
-                        im[f64_in_reg<P>(j)] = (double)xbuf[k1 - tile0] * hann_half_f64(k1, g.L, g.LR, g.kadd, invL, invR);
+                    if (k0 >= tile0 && k0 < hi) re[f64_in_reg<P>(j)] = (double)(xbuf[k0 - tile0] * in_scale) * weight(k0);
+                    if (k1 >= tile0 && k1 < hi) im[f64_in_reg<P>(j)] = (double)(xbuf[k1 - tile0] * in_scale) * weight(k1);
                     s_abs += fabs(re[f64_in_reg<P>(j)]) + fabs(im[f64_in_reg<P>(j)]);
                 }
             }
@@ -170,7 +188,9 @@ __global__ __launch_bounds__(kAna64Waves * 64) void k_analysis_f64(const float* 
 #ifdef MPX_F64_NOFLUSH   // A/B of the policy (tools/fuzz_vs_oracle.py): the residue normalised like any other value
         const double zero2 = 1.0e-36 + 0.0 * zt;
 #else
-        const double zero2 = fmax(zt * zt, 1.0e-36);
+        // table path: the residue IS the reference's -- nothing is flushed (only |X|^2 too small for the fp32 seed: 1e-27 of
+        // a sample after the 2^30 scaling); analytic path: the round-3 policy
+        const double zero2 = tabw ? 1.0e-36 : fmax(zt * zt, 1.0e-36);
 #endif
 
         if constexpr (kF64Dit) wave_fft_dit_f64<P, -1>(re, im, tw, xbuf, lane);
@@ -220,13 +240,13 @@ __global__ __launch_bounds__(kAna64Waves * 64) void k_analysis_f64(const float* 
                     const double wr = wl_c * cq - wl_s * sq, wi = wl_c * sq + wl_s * cq;
                     const double tr = wr * orr - wi * oi, ti = wr * oi + wi * orr;
                     const int k = kap + 64 * q;
-                    feat_store<PH>(er + tr, ei + ti, zero2, row_m + k, row_r + k, row_i + k);
+                    feat_store<PH>(er + tr, ei + ti, zero2, mag_scale, row_m + k, row_r + k, row_i + k);
                     const int km = M - k;              // kappa == 0, q == 0: bin M
-                    feat_store<PH>(er - tr, ti - ei, zero2, row_m + km, row_r + km, row_i + km);
+                    feat_store<PH>(er - tr, ti - ei, zero2, mag_scale, row_m + km, row_r + km, row_i + km);
                 }
             }
             constexpr int ih = f64_out_reg<P>(P / 2);   // bin M/2
-            if (lane0) feat_store<PH>(re[ih], -im[ih], zero2, row_m + M / 2, row_r + M / 2, row_i + M / 2);
+            if (lane0) feat_store<PH>(re[ih], -im[ih], zero2, mag_scale, row_m + M / 2, row_r + M / 2, row_i + M / 2);
         };
         // rows whose phase features no consumer reads (the compressed analysis: unvoiced stretches) get the magnitude only:
         // a third of the stores and two conversions per bin less, one wave-uniform branch per frame
@@ -278,10 +298,19 @@ int mpx_tables_f64_init(void* stream, int fft_len, void* tables) {
 int mpx_analysis_frames_f64(void* stream, int fft_len, const void* tables_f64, const float* sig, const int64_t* frame_pos,
                             const int32_t* frame_left, const int32_t* frame_right, int64_t n_frames, float* out_mag,
                             float* out_real, float* out_imag, int64_t ld, const float* rows_in_use) {
+    return mpx_analysis_frames_f64w(stream, fft_len, tables_f64, sig, frame_pos, frame_left, frame_right, n_frames, out_mag,
+                                    out_real, out_imag, ld, rows_in_use, nullptr, 0);
+}
+
+int mpx_analysis_frames_f64w(void* stream, int fft_len, const void* tables_f64, const float* sig, const int64_t* frame_pos,
+                             const int32_t* frame_left, const int32_t* frame_right, int64_t n_frames, float* out_mag,
+                             float* out_real, float* out_imag, int64_t ld, const float* rows_in_use, const double* win_tab,
+                             int32_t win_cap) {
     const int P = p_of(fft_len);
     if (!P) return fail(MPX_ERR_ARG, "mpx_analysis_frames_f64: fft_len must be 1024, 2048 or 4096%s");
     if (n_frames < 0) return fail(MPX_ERR_ARG, "mpx_analysis_frames_f64: negative n_frames%s");
     if (ld < fft_len / 2 + 1) return fail(MPX_ERR_ARG, "mpx_analysis_frames_f64: ld < fft_len/2 + 1%s");
+    if (win_tab && win_cap < 0) return fail(MPX_ERR_ARG, "mpx_analysis_frames_f64w: negative win_cap%s");
     if (n_frames == 0) return MPX_OK;
     if (!tables_f64 || !sig || !frame_pos || !frame_left || !frame_right || !out_mag || !out_real || !out_imag)
         return fail(MPX_ERR_ARG, "mpx_analysis_frames_f64: null pointer%s");
@@ -292,7 +321,8 @@ int mpx_analysis_frames_f64(void* stream, int fft_len, const void* tables_f64, c
         if (int rc = set_lds(k_analysis_f64<PP>, lds_bytes_ana64<PP>())) return rc;                               \
         hipLaunchKernelGGL(k_analysis_f64<PP>, grid, block, lds_bytes_ana64<PP>(), s, sig,                        \
                            (const long long*)frame_pos, frame_left, frame_right, (long long)n_frames,             \
-                           (const double*)tables_f64, out_mag, out_real, out_imag, (long long)ld, rows_in_use);   \
+                           (const double*)tables_f64, out_mag, out_real, out_imag, (long long)ld, rows_in_use,    \
+                           win_tab, (int)win_cap);                                                                \
     } while (0)
     if (P == 32) MPX_LAUNCH_A64(32);
     else if (P == 16) MPX_LAUNCH_A64(16);

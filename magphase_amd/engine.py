@@ -522,6 +522,13 @@ class Engine:
         return self._tables[key]
 
     # ------------------------------------------------------------------ kernels
+    def hann_table(self):
+        """hostmath.hann_half_table on the device (float64, built once per engine: ~30 ms of numpy, 16.8 MB)."""
+        t = getattr(self, "_hann_table", None)
+        if t is None:
+            t = self._hann_table = self.to_device(hm.hann_half_table(), np.float64)
+        return t
+
     def analysis_frames(self, fft_len, sig, pos, left, right, out=None, precise=False, rows_in_use=None):
         """sig f32[n], pos i64[F], left/right i32[F] (device) -> (mag, real, imag) f32[F x H] (device).
         precise: window / transform / epilogue in float64 (mpx_analysis_frames_f64): the compressed analysis' choice;
@@ -533,8 +540,13 @@ class Engine:
             out = tuple(self.empty_feats(nfr, H) for _ in range(3))
         ld = self.feat_ld(*out)
         tab = self.tables_f64(fft_len) if precise else self.tables(fft_len)
-        fn = self.lib.mpx_analysis_frames_f64 if precise else self.lib.mpx_analysis_frames
-        extra = ((rows_in_use.data_ptr() if rows_in_use is not None else None),) if precise else ()
+        fn = self.lib.mpx_analysis_frames_f64w if precise else self.lib.mpx_analysis_frames
+        if precise:   # window weights from numpy's own np.hanning (MAGPHASE_F64_WINDOW=analytic: evaluated on the device)
+            wt = self.hann_table() if os.environ.get("MAGPHASE_F64_WINDOW", "table") != "analytic" else None
+            extra = ((rows_in_use.data_ptr() if rows_in_use is not None else None),
+                     (wt.data_ptr() if wt is not None else None), (hm.HANN_TABLE_CAP if wt is not None else 0))
+        else:
+            extra = ()
         with torch.cuda.device(self.device):
             _lib.check(fn(self.stream_ptr(), int(fft_len), tab.data_ptr(), sig.data_ptr(), pos.data_ptr(), left.data_ptr(),
                           right.data_ptr(), nfr, out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), ld, *extra),

@@ -103,6 +103,23 @@ def medfilt3_batch(vectors):
     return [med[a - 1:a - 1 + n] for a, n in zip(starts, sizes)]
 
 
+HANN_TABLE_CAP = 2048   # half lengths covered by hann_half_table (F0 >= 23.4 Hz at 48 kHz); longer halves: analytic window
+
+
+def hann_half_table(cap=HANN_TABLE_CAP):
+    """
+    The rising halves np.hanning(2 h + 1)[0 .. h] for every half length h <= cap, laid end to end (half h at offset
+    h (h + 1) / 2; (cap + 1)(cap + 2) / 2 float64 values, 16.8 MB at cap = 2048).  Built with numpy's own np.hanning -- the
+    function the reference windows with (libaudio.py:70-84: both halves of a frame are rising halves, the right one
+    flipped) -- so that mpx_analysis_frames_f64w multiplies by the reference's very weights.  np.hanning(1) = [1.0].
+    """
+    out = np.empty((cap + 1) * (cap + 2) // 2, dtype=np.float64)
+    for h in range(cap + 1):
+        off = h * (h + 1) // 2
+        out[off:off + h + 1] = np.hanning(2 * h + 1)[:h + 1]
+    return out
+
+
 def ola_plan(v_pm, frmlen):
     """
     Index bookkeeping of magphase.py:34-62 (ola): returns (pm_rel int64[F], out_start, out_len) such that

@@ -15,3 +15,11 @@ def within(value, tol, label):
     rec["n"] += 1
     assert value <= tol, "%s: measured %.4g > tolerance %.4g" % (label, value, tol)
     return True
+
+
+FACTS = {}
+
+
+def note(label, value):
+    """A measured fact that is not a tolerance (e.g. the fraction of frames a comparison leaves out: 0 since round 4)."""
+    FACTS[label] = value

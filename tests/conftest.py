@@ -24,7 +24,7 @@ def pytest_sessionfinish(session, exitstatus):
     try:
         import json
 
-        from _tol import MEASURED
+        from _tol import FACTS, MEASURED
     except Exception:
         return
     if not MEASURED:
@@ -32,5 +32,7 @@ def pytest_sessionfinish(session, exitstatus):
     out_dir = os.path.join(ROOT, "gpurun_out")
     os.makedirs(out_dir, exist_ok=True)
     rows = {k: dict(v, ratio=(round(v["tol"] / v["max"], 2) if v["max"] > 0 else None)) for k, v in sorted(MEASURED.items())}
+    if FACTS:
+        rows["_facts"] = dict(sorted(FACTS.items()))
     with open(os.path.join(out_dir, "tolerance_report.json"), "w") as fh:
         json.dump(rows, fh, indent=1)

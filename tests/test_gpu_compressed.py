@@ -13,7 +13,7 @@ import warnings
 import numpy as np
 import pytest
 
-from _tol import within
+from _tol import note, within
 
 pytestmark = pytest.mark.gpu
 
@@ -282,11 +282,12 @@ def test_f64_analysis_features_are_correctly_rounded(orc):
         assert np.array_equal(plan.v_f0[0], o[3])
 
 
-def test_exactly_cancelling_bins_are_zero_like_the_reference(mp, orc):
+def test_exactly_cancelling_bins_carry_the_references_residue(mp, orc):
     """Found by tools/fuzz_vs_oracle.py: over a stretch of exactly periodic pitch periods (synthetic utterance 447741 at
-    44.1 kHz, frames 132-138) the Nyquist bin cancels exactly; numpy's FFT returns 0.0 and the reference stores
-    (0, 0, 0) (magphase.py:466-472).  The float64 wave FFT leaves a residue of 2^-50: it must not become a phase of
-    (1, 0) -- that moved the warped phase features by 6e-5."""
+    44.1 kHz, frames 132-138) the Nyquist bin cancels exactly; numpy's FFT returns 0.0 -- the reference stores (0, 0, 0)
+    (magphase.py:466-472) -- or a residue of a few 2^-53, which it normalises to (+-1, 0).  With numpy's own window weights
+    (mpx_analysis_frames_f64w) the device's products are the reference's and so is the residue: zero exactly where the
+    reference is zero, the same phasor elsewhere.  (Round 3: everything below 2^-45 of the frame was flushed to zero.)"""
     from magphase_amd import synthetic as syn
     from magphase_amd.engine import LosslessAnalysisPlan, get_engine
     fs = 44100
@@ -296,11 +297,13 @@ def test_exactly_cancelling_bins_are_zero_like_the_reference(mp, orc):
         warnings.simplefilter("ignore")
         o = orc.analysis_lossless_from_epochs(x, fs, pm, voi)
         zero = o[0] == 0.0
+        tiny = o[0] <= 1e-13 * o[0].max(axis=1, keepdims=True)
         assert zero.sum() >= 5 and zero[132, 2048]
         plan = LosslessAnalysisPlan(get_engine(), [(x, fs, pm, voi)])
         m, r, i = (t.cpu().numpy() for t in plan.run(precise=True))
-        assert np.all(m[zero] == 0.0) and np.all(r[zero] == 0.0) and np.all(i[zero] == 0.0)
-        assert np.count_nonzero(m == 0.0) == zero.sum()              # and nothing else was flushed
+        assert np.array_equal(m == 0.0, zero)                        # zero exactly where the reference is, nowhere else
+        assert np.all(r[zero] == 0.0) and np.all(i[zero] == 0.0)
+        within(max(np.max(np.abs(r[tiny] - o[1][tiny])), np.max(np.abs(i[tiny] - o[2][tiny]))), 1e-6, "F64_RESIDUE_PHASOR:447741")
         oc = orc.analysis_compressed_from_epochs(x, fs, pm, voi, mag_dim=60, phase_dim=45)
         g = mp.analysis_compressed_batch([(x, fs, pm, voi)], mag_dim=60, phase_dim=45)[0]
     within(np.max(np.abs(g[1] - oc[1])), WARP_PHASE_TOL, "WARP_PHASE_TOL:247r")
@@ -564,15 +567,16 @@ def test_full_size_config3_constant_rate_post_filter(mp, orc):
             a, b = int(aplan.out_off[u]), int(aplan.out_off[u + 1])
             assert o[0].shape == (b - a, 60)
             within(np.max(np.abs(feats[0][a:b] - o[0])), WARP_TOL, "WARP_TOL:499")
-            # Phase streams, stage by stage -- no allowance.  Re X/|X| has no well-defined reference value where |X| sits
-            # on the reference FFT's own rounding floor (the synthetic generator has stretches of exactly constant pitch:
-            # frames of two identical periods under a symmetric Hann window have exact spectral nulls between the
-            # harmonics; numpy returns ~1e-13 of the frame peak there and the reference normalises that noise to a unit
-            # phasor).  So: (1) the device's LOSSLESS features are the correctly rounded reference values on every bin
-            # the reference itself determines (|X| > 1e-9 of the frame peak); (2) the compression of those features --
-            # constant-rate interpolation + mel warp + mask + clip -- agrees with the oracle's compression of the SAME
-            # features on every value; (3) end to end against the oracle, every constant-rate frame that does not
-            # interpolate from a frame with such a bin agrees to the phase tolerance.
+            # Phase streams, stage by stage AND end to end on every frame -- no allowance, no exclusion (round 4).  The
+            # synthetic generator has stretches of exactly constant pitch; over them the Nyquist / DC bin of a frame
+            # cancels EXACTLY and numpy's FFT returns 0.0 or a residue of a few 2^-53, which the reference normalises to a
+            # unit phasor.  k_analysis_f64 now multiplies by numpy's own np.hanning weights (mpx_analysis_frames_f64w,
+            # hostmath.hann_half_table), so its products -- and with them the residue and its sign -- are the reference's;
+            # round 3 flushed such bins to zero and this test skipped the 0.1 % of constant-rate frames interpolating from
+            # them (errors up to 3.2e-5 there).  (1) the device's LOSSLESS features are the correctly rounded reference
+            # values on every bin above the reference FFT's rounding floor (|X| > 1e-9 of the frame peak); (2) the
+            # compression of those features equals the oracle's compression of the SAME features on every value; (3) end to
+            # end against the oracle, EVERY constant-rate frame agrees to the phase tolerance.
             a0, b0 = int(aplan.lossless.frame_off[u]), int(aplan.lossless.frame_off[u + 1])
             ol = orc.analysis_lossless_from_epochs(x, fs, pm, voi)
             dl = [t[a0:b0].cpu().numpy().astype(np.float64) for t in lossless_dev]
@@ -586,13 +590,15 @@ def test_full_size_config3_constant_rate_post_filter(mp, orc):
             within(np.max(np.abs(feats[0][a:b] - of[0])), WARP_TOL, "WARP_TOL:cfg2_same_inputs")
             for k in (1, 2):
                 within(np.max(np.abs(feats[k][a:b] - of[k])), WARP_PHASE_TOL, "WARP_PHASE_TOL:cfg2_same_inputs")
-            lo, hi, _t = hm.var_to_const_rate_table(np.cumsum(ol[5]), 5.0, fs)
-            bad_var = ~ok.all(axis=1)
-            bad_c = bad_var[lo] | bad_var[hi]
-            assert np.mean(bad_c) < 0.05, (u, np.mean(bad_c))
-            for k in (1, 2):
-                d = np.abs(feats[k][a:b] - o[k]).max(axis=1)
-                within(np.max(d[~bad_c]), WARP_PHASE_TOL, "WARP_PHASE_TOL:cfg2_end_to_end")
+            note("configs2_end_to_end_phase_check:excluded_fraction_of_frames", 0.0)
+            for k in (1, 2):   # every frame: excluded fraction 0
+                within(np.max(np.abs(feats[k][a:b] - o[k])), WARP_PHASE_TOL, "WARP_PHASE_TOL:cfg2_end_to_end_all_frames")
+            # the exactly cancelling bins themselves: zero where the reference's are zero, the same unit phasor elsewhere
+            tiny = ~ok
+            if tiny.any():
+                assert np.array_equal(dl[0][tiny] == 0.0, ol[0][tiny] == 0.0)
+                within(max(np.max(np.abs(dl[1][tiny] - ol[1][tiny])), np.max(np.abs(dl[2][tiny] - ol[2][tiny]))), 1e-6,
+                       "F64_RESIDUE_PHASOR:cfg2")
             assert np.array_equal(lf0s[u], o[3])
             # the oracle on OUR features (so that the waveform check isolates the synthesis side), same noise draw
             np.random.set_state(states[u])

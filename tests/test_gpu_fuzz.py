@@ -23,4 +23,4 @@ def test_fixed_seed_fuzz_slice_against_oracle():
     worst, bad, residue = fz.run(n_batches=20, seed=20260929, verbose=False)
     for k, v in worst.items():
         within(v, fz.LIMITS[k], "FUZZ:" + k)
-    assert not bad and residue <= 2, (worst, bad, residue)
+    assert not bad and residue == 0, (worst, bad, residue)   # round 4: no utterance left at "numpy's rounding residue"
