@@ -88,6 +88,27 @@ int mpx_analysis_frames_f64w(void* stream, int fft_len, const void* tables_f64, 
                              const float* rows_in_use, const double* win_tab, int32_t win_cap);
 
 /*
+ * FUSED compressed analysis at the variable frame rate (magphase.py:2947-2988 with b_const_rate=False: analysis_lossless ->
+ * format_for_modelling; SURVEY.md section 8d, configuration C4 "fused; lossless features never hit HBM"): float64 analysis
+ * of every frame (as mpx_analysis_frames_f64w) -> log power / unit phasor of every bin -> both mel warps on the matrix
+ * cores -> voicing mask and clip, in ONE kernel; the [n_frames x H] lossless features are never written.
+ *   wpack, whalf : the two warp matrices in MFMA fragment order (hostmath.pack_warp_fused of the [mag_dim x H] and
+ *                  [phase_dim x H] matrices mpx_mel_warp takes; DEVICE, float32)
+ *   voiced       : float32[n_frames] (DEVICE): 0 = unvoiced frame, phase outputs +0 (magphase.py:2527-2529)
+ *   mag_fbank    : 0 = cepstral mel warp of ln(mag^2 + 1e-8) (la.sp_mel_warp), 1 = mel filter bank (la.sp_mel_warp_fbank)
+ *   out_mag [n_frames x mag_dim], out_real / out_imag [n_frames x phase_dim], dense float32
+ * mag_dim <= 64, phase_dim <= 48, fft_len 2048 or 4096.  Equals mpx_analysis_frames_f64w followed by mpx_mel_warp up to the
+ * float32 summation order of the warp.
+ */
+int mpx_analysis_compressed_fused(void* stream, int fft_len, const void* tables_f64, const float* sig,
+                                  const int64_t* frame_pos, const int32_t* frame_left, const int32_t* frame_right,
+                                  int64_t n_frames, const double* win_tab, int32_t win_cap, const float* wpack,
+                                  const float* whalf, int32_t mag_dim, int32_t phase_dim, const float* voiced,
+                                  int32_t mag_fbank, float* out_mag, float* out_real, float* out_imag);
+/* column tiles of 16 the fused kernel runs for the magnitude / phase job (what pack_warp_fused must produce) */
+int mpx_analysis_compressed_fused_tiles(int32_t mag_dim, int32_t phase_dim, int32_t* ntm, int32_t* ntp);
+
+/*
  * Row pitch (in floats) the lossless feature matrices should be allocated with.  Any ld >= H is CORRECT for every
  * entry point that takes `ld` (so the matrices may live inside wider buffers); mpx_feat_ld() returns the pitch
  * measured fastest on MI355X, which is the reference's dense [F x H] layout, ld == H: padding the rows to a

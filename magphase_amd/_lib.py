@@ -22,6 +22,8 @@ SYMBOLS = (
     "mpx_tables_f64_init",
     "mpx_analysis_frames_f64",
     "mpx_analysis_frames_f64w",
+    "mpx_analysis_compressed_fused",
+    "mpx_analysis_compressed_fused_tiles",
     "mpx_synthesis_lossless_frames",
     "mpx_ola_gather",
     "mpx_synth_ola_slots",
@@ -119,6 +121,11 @@ def _load_locked():
     lib.mpx_tables_f64_init.argtypes = [vp, ctypes.c_int, vp]
     lib.mpx_analysis_frames_f64.restype = ctypes.c_int
     lib.mpx_analysis_frames_f64.argtypes = [vp, ctypes.c_int, vp, vp, vp, vp, vp, i64, vp, vp, vp, i64, vp]
+    lib.mpx_analysis_compressed_fused.restype = ctypes.c_int
+    lib.mpx_analysis_compressed_fused.argtypes = [vp, ctypes.c_int, vp, vp, vp, vp, vp, i64, vp, i32, vp, vp, i32, i32, vp, i32,
+                                                  vp, vp, vp]
+    lib.mpx_analysis_compressed_fused_tiles.restype = ctypes.c_int
+    lib.mpx_analysis_compressed_fused_tiles.argtypes = [i32, i32, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]
     lib.mpx_analysis_frames_f64w.restype = ctypes.c_int
     lib.mpx_analysis_frames_f64w.argtypes = [vp, ctypes.c_int, vp, vp, vp, vp, vp, i64, vp, vp, vp, i64, vp, vp, i32]
     lib.mpx_feat_ld.restype = i64

@@ -82,6 +82,96 @@ __device__ __forceinline__ constexpr int f64_in_reg(int j) { return kF64Dit ? br
 template <int P>
 __device__ __forceinline__ constexpr int f64_out_reg(int q) { return kF64Dit ? q : brev(q, ilog2(P)); }
 
+// The front of the float64 analysis of ONE frame by one wave: samples HBM -> LDS, window (numpy's own weights from win_tab,
+// or the analytic half Hann), gather in FFT order, transform.  On return lane kappa, register f64_out_reg(q) holds bin row q
+// of the half-size complex transform (see the split in the callers); zero2 / mag_scale as explained inline.
+template <int P>
+__device__ __forceinline__ void f64_frame_transform(const float* __restrict__ sig, long long pos, int Lf, int Rf,
+                                                    const double* __restrict__ win_tab, int win_cap, const double* tw,
+                                                    float* xbuf, unsigned xbuf_byte, int lane, double (&re)[P],
+                                                    double (&im)[P], double& zero2_out, float& mag_scale_out) {
+    constexpr int N = 128 * P, kTile = 64 * P;
+    const FrameGeom g = frame_geom(sig, pos, Lf, Rf, N);
+    const double invL = (g.L > 0) ? 1.0 / (double)g.L : 1.0;
+    const double invR = (g.LR > g.L) ? 1.0 / (double)(g.LR - g.L) : 0.0;
+    // Window weights from the HOST's np.hanning (win_tab: half window of half length h at h (h + 1) / 2, h <= win_cap;
+    // hostmath.hann_half_table): the products x[n] w[n] are then the reference's own doubles, and a bin that cancels
+    // exactly (DC / Nyquist over exactly periodic pitch periods) leaves the reference's own residue -- 0.0 or a few
+    // 2^-53 with the reference's sign -- instead of this kernel's polynomial's (round 3 flushed such bins to zero and the
+    // configs[2] test had to skip the frames that interpolate from them).  Frames with a half longer than win_cap (F0
+    // below 23 Hz at 48 kHz) keep the analytic window.  Wave-uniform.
+    const int gR = g.LR - g.L;
+    const bool tabw = rfl((int)(win_tab != nullptr && g.L <= win_cap && gR <= win_cap)) != 0;
+    const double* tl = win_tab + ((long long)g.L * (g.L + 1) >> 1);
+    const double* tr = win_tab + ((long long)gR * (gR + 1) >> 1);
+    auto weight = [&](int k) -> double {
+        if (tabw) return (k <= g.L) ? tl[k] : tr[g.LR - k];
+        return hann_half_f64(k, g.L, g.LR, g.kadd, invL, invR);
+    };
+    // The table path scales the frame by 2^30 (exact: a power of two changes no mantissa anywhere in the transform), so
+    // that a residue of 2^-53 x amplitude squares to a normal float for the reciprocal square root's fp32 seed; the
+    // magnitude is scaled back after its conversion to float32 (exact as well).
+    const float in_scale = tabw ? 1073741824.0f : 1.0f;
+    const float mag_scale = tabw ? 9.313225746154785e-10f : 1.0f;
+
+    // ---- samples HBM -> LDS (fp32: the PCM is exact in float32), window in float64 while gathering in FFT order
+    double s_abs = 0.0;   // this lane's share of sum |windowed sample|: the scale of the transform's rounding noise
+#pragma unroll
+    for (int j = 0; j < P; ++j) re[j] = im[j] = 0.0;
+    const int ntiles = (g.len + kTile - 1) / kTile;   // 1 except for frames longer than 64 P samples (Q19)
+    for (int t = 0; t < ntiles; ++t) {
+        const int tile0 = t * kTile;
+        const int hi = min(g.len, tile0 + kTile);
+        stage_samples_async(g, tile0, kTile, xbuf_byte, lane);
+        staged_wait<0>();
+        wave_sync();
+        // the window weights depend on this copy of the lane id: the compiler cannot evaluate them (2 x 64 doubles)
+        // ahead of the copy and spill them
+        int lane_g = lane;
+        asm volatile("" : "+v"(lane_g));
+#pragma unroll
+        for (int j = 0; j < P; ++j) {
+            const int m0 = 128 * j;
+            // buffer index m holds windowed sample k = (m + rot) mod N, valid iff k < len
+            const bool any = (m0 < g.len - g.rot) || (m0 + 127 >= N - g.rot);
+            if (any) {
+                const int m = m0 + 2 * lane_g;
+                int k0 = m + g.rot;
+                k0 = (k0 >= N) ? k0 - N : k0;
+                int k1 = m + 1 + g.rot;
+                k1 = (k1 >= N) ? k1 - N : k1;
+                if (k0 >= tile0 && k0 < hi) re[f64_in_reg<P>(j)] = (double)(xbuf[k0 - tile0] * in_scale) * weight(k0);
+                if (k1 >= tile0 && k1 < hi) im[f64_in_reg<P>(j)] = (double)(xbuf[k1 - tile0] * in_scale) * weight(k1);
+                s_abs += fabs(re[f64_in_reg<P>(j)]) + fabs(im[f64_in_reg<P>(j)]);
+            }
+        }
+        wave_sync();
+    }
+    float s_all = (float)s_abs;   // a scale: float is plenty
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s_all += __shfl_xor(s_all, d);
+    const double zt = 2.842170943040401e-14 * (double)s_all;   // 2^-45 * sum: ~20 x the transform's error bound
+#ifdef MPX_F64_NOFLUSH   // A/B of the policy (tools/fuzz_vs_oracle.py): the residue normalised like any other value
+    const double zero2 = 1.0e-36 + 0.0 * zt;
+#else
+    // table path: the residue IS the reference's -- nothing is flushed (only |X|^2 too small for the fp32 seed: 1e-27 of
+    // a sample after the 2^30 scaling); analytic path: the round-3 policy
+    const double zero2 = tabw ? 1.0e-36 : fmax(zt * zt, 1.0e-36);
+#endif
+
+    if constexpr (kF64Dit) wave_fft_dit_f64<P, -1>(re, im, tw, xbuf, lane);
+    else wave_fft_f64<P, -1>(re, im, tw, xbuf, lane);
+    // scheduling fence: left alone, the last butterfly stage is interleaved with the split below and its inputs AND
+    // outputs are live together (16 doubles spilled: 1 GB of scratch traffic per launch)
+#pragma unroll
+    for (int j = 0; j < P; j += 4)
+        asm volatile("" : "+v"(re[j]), "+v"(re[j + 1]), "+v"(re[j + 2]), "+v"(re[j + 3]), "+v"(im[j]), "+v"(im[j + 1]),
+                          "+v"(im[j + 2]), "+v"(im[j + 3]));
+
+    zero2_out = zero2;
+    mag_scale_out = mag_scale;
+}
+
 template <int P>
 __global__ __launch_bounds__(kAna64Waves * 64) void k_analysis_f64(const float* __restrict__ sig,
                                                                   const long long* __restrict__ fpos,
@@ -124,83 +214,10 @@ __global__ __launch_bounds__(kAna64Waves * 64) void k_analysis_f64(const float* 
         const int kap = kappa<P>(lane);
         const int src_lane = kappa<P>((64 - kap) & 63);
         const bool lane0 = (kap == 0);
-        const FrameGeom g = frame_geom(sig, fpos[f], fleft[f], fright[f], N);
-        const double invL = (g.L > 0) ? 1.0 / (double)g.L : 1.0;
-        const double invR = (g.LR > g.L) ? 1.0 / (double)(g.LR - g.L) : 0.0;
-        // Window weights from the HOST's np.hanning (win_tab: half window of half length h at h (h + 1) / 2, h <= win_cap;
-        // hostmath.hann_half_table): the products x[n] w[n] are then the reference's own doubles, and a bin that cancels
-        // exactly (DC / Nyquist over exactly periodic pitch periods) leaves the reference's own residue -- 0.0 or a few
-        // 2^-53 with the reference's sign -- instead of this kernel's polynomial's (round 3 flushed such bins to zero and the
-        // configs[2] test had to skip the frames that interpolate from them).  Frames with a half longer than win_cap (F0
-        // below 23 Hz at 48 kHz) keep the analytic window.  Wave-uniform.
-        const int gR = g.LR - g.L;
-        const bool tabw = rfl((int)(win_tab != nullptr && g.L <= win_cap && gR <= win_cap)) != 0;
-        const double* tl = win_tab + ((long long)g.L * (g.L + 1) >> 1);
-        const double* tr = win_tab + ((long long)gR * (gR + 1) >> 1);
-        auto weight = [&](int k) -> double {
-            if (tabw) return (k <= g.L) ? tl[k] : tr[g.LR - k];
-            return hann_half_f64(k, g.L, g.LR, g.kadd, invL, invR);
-        };
-        // The table path scales the frame by 2^30 (exact: a power of two changes no mantissa anywhere in the transform), so
-        // that a residue of 2^-53 x amplitude squares to a normal float for the reciprocal square root's fp32 seed; the
-        // magnitude is scaled back after its conversion to float32 (exact as well).
-        const float in_scale = tabw ? 1073741824.0f : 1.0f;
-        const float mag_scale = tabw ? 9.313225746154785e-10f : 1.0f;
-
-        // ---- samples HBM -> LDS (fp32: the PCM is exact in float32), window in float64 while gathering in FFT order
         double re[P], im[P];
-        double s_abs = 0.0;   // this lane's share of sum |windowed sample|: the scale of the transform's rounding noise
-#pragma unroll
-        for (int j = 0; j < P; ++j) re[j] = im[j] = 0.0;
-        const int ntiles = (g.len + kTile - 1) / kTile;   // 1 except for frames longer than 64 P samples (Q19)
-        for (int t = 0; t < ntiles; ++t) {
-            const int tile0 = t * kTile;
-            const int hi = min(g.len, tile0 + kTile);
-            stage_samples_async(g, tile0, kTile, xbuf_byte, lane);
-            staged_wait<0>();
-            wave_sync();
-            // the window weights depend on this copy of the lane id: the compiler cannot evaluate them (2 x 64 doubles)
-            // ahead of the copy and spill them
-            int lane_g = lane;
-            asm volatile("" : "+v"(lane_g));
-#pragma unroll
-            for (int j = 0; j < P; ++j) {
-                const int m0 = 128 * j;
-                // buffer index m holds windowed sample k = (m + rot) mod N, valid iff k < len
-                const bool any = (m0 < g.len - g.rot) || (m0 + 127 >= N - g.rot);
-                if (any) {
-                    const int m = m0 + 2 * lane_g;
-                    int k0 = m + g.rot;
-                    k0 = (k0 >= N) ? k0 - N : k0;
-                    int k1 = m + 1 + g.rot;
-                    k1 = (k1 >= N) ? k1 - N : k1;
-                    if (k0 >= tile0 && k0 < hi) re[f64_in_reg<P>(j)] = (double)(xbuf[k0 - tile0] * in_scale) * weight(k0);
-                    if (k1 >= tile0 && k1 < hi) im[f64_in_reg<P>(j)] = (double)(xbuf[k1 - tile0] * in_scale) * weight(k1);
-                    s_abs += fabs(re[f64_in_reg<P>(j)]) + fabs(im[f64_in_reg<P>(j)]);
-                }
-            }
-            wave_sync();
-        }
-        float s_all = (float)s_abs;   // a scale: float is plenty
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) s_all += __shfl_xor(s_all, d);
-        const double zt = 2.842170943040401e-14 * (double)s_all;   // 2^-45 * sum: ~20 x the transform's error bound
-#ifdef MPX_F64_NOFLUSH   // A/B of the policy (tools/fuzz_vs_oracle.py): the residue normalised like any other value
-        const double zero2 = 1.0e-36 + 0.0 * zt;
-#else
-        // table path: the residue IS the reference's -- nothing is flushed (only |X|^2 too small for the fp32 seed: 1e-27 of
-        // a sample after the 2^30 scaling); analytic path: the round-3 policy
-        const double zero2 = tabw ? 1.0e-36 : fmax(zt * zt, 1.0e-36);
-#endif
-
-        if constexpr (kF64Dit) wave_fft_dit_f64<P, -1>(re, im, tw, xbuf, lane);
-        else wave_fft_f64<P, -1>(re, im, tw, xbuf, lane);
-        // scheduling fence: left alone, the last butterfly stage is interleaved with the split below and its inputs AND
-        // outputs are live together (16 doubles spilled: 1 GB of scratch traffic per launch)
-#pragma unroll
-        for (int j = 0; j < P; j += 4)
-            asm volatile("" : "+v"(re[j]), "+v"(re[j + 1]), "+v"(re[j + 2]), "+v"(re[j + 3]), "+v"(im[j]), "+v"(im[j + 1]),
-                              "+v"(im[j + 2]), "+v"(im[j + 3]));
+        double zero2;
+        float mag_scale;
+        f64_frame_transform<P>(sig, fpos[f], fleft[f], fright[f], win_tab, win_cap, tw, xbuf, xbuf_byte, lane, re, im, zero2, mag_scale);
 
         // ---- real-FFT split, one (k, M-k) bin pair per step q (see k_analysis): lane kappa owns k = kappa + 64 q
         // (register brev(q)); Z[M-k] lives in lane (64-kappa)&63, register P-1-i (kappa == 0: own register of bin
@@ -252,6 +269,248 @@ __global__ __launch_bounds__(kAna64Waves * 64) void k_analysis_f64(const float* 
         // a third of the stores and two conversions per bin less, one wave-uniform branch per frame
         if (rows_in_use == nullptr || rfl((int)(rows_in_use[f] != 0.0f))) epilogue(std::true_type{});
         else epilogue(std::false_type{});
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// FUSED compressed analysis at the variable frame rate ("lossless features never hit HBM"):
+// float64 analysis of 8 frames per workgroup round (one per wave) -> log-power / unit phasor of every bin straight from
+// the registers into an LDS tile -> mel warp [8 frames x H] . W^T[H x (mag_dim + 2 phase_dim)] on the matrix cores
+// (v_mfma_f32_16x16x4_f32, f32 in / f32 accumulate) -> mask / clip -> the compressed features.  What reaches HBM is the
+// samples in and the 60 + 2 x 10 (or 45) coefficients per frame out; the staged form wrote 12 H bytes per frame and read
+// them back (1.4 GB + 1.6 GB per 64 utterances).
+//
+// Round structure.  Phase A: every wave transforms its frame (f64_frame_transform: same code as k_analysis_f64).
+// Phase B: P/2 chunk steps; step q splits the bin pair rows (kappa + 64 q, M - kappa - 64 q) exactly like k_analysis_f64's
+// epilogue, applies the warp's prologue (the staged path's float32 values and formulas, so both paths agree to the
+// summation order) and PUBLISHES them to As[buf][stream][wave][column]: column kappa = the low bin, 64 + kappa = its
+// mirror.  After one barrier the eight waves split the chunk's 128 columns (16 each: four MFMA k-steps), read their A
+// fragments (one ds_read_b128 per stream: rows 8..15 of the 16-row tile repeat rows 0..7, their outputs are dropped) and
+// the matching W fragments from `wpack` (host-packed in fragment order: one 16-byte load per tile, L2-resident,
+// hostmath.pack_warp_fused), and accumulate.  The tile is double buffered: one barrier per chunk.  The NEXT chunk's
+// values are computed between issuing the W loads and the MFMAs, so the L2 latency hides under float64 VALU work.
+// Round end: the eight K-slices are added through LDS (deterministic order), bin M/2 (its own mirror, held by lane 0) is
+// added as one product per output, epilogue as k_mel_warp_mfma's, rows stored.
+// Accumulation: 256 terms per wave and accumulator + 8 partial sums -- the same error level as the staged GEMM's fresh
+// accumulator per 64 bins + 33 chunk sums.
+// ---------------------------------------------------------------------------------------------
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+constexpr int kFusedWaves = 8;
+constexpr int kFusedAStride = 132;   // floats per published row (128 columns + 4: rows start 16 bytes apart in the banks)
+
+// the warp's operand prologue / epilogue (same formulas as magphase_comp.hip: warp_prologue / warp_epilogue)
+__device__ __forceinline__ float fused_prologue_mag(int mode, float x) {
+    if (mode == 0) return __builtin_amdgcn_logf(fmaf(x, x, 1.0e-8f)) * 0.69314718055994531f;
+    return (x > 0.0f) ? __logf(x) : -1.0e10f;
+}
+__device__ __forceinline__ float fused_prologue_phase(float x) { return fmaf(1.0e-8f, __expf(-2.0f * x), 2.0f * x); }
+
+template <int P, int NTM, int NTP>
+constexpr size_t lds_bytes_fused() {
+    constexpr size_t tiles = NTM + NTP;
+    constexpr size_t work = sizeof(float) * (size_t)(kFusedWaves * P * kXStride + 2 * 3 * kFusedWaves * kFusedAStride);
+    constexpr size_t red = sizeof(float) * (size_t)(kFusedWaves * tiles * 4 * 64);
+    return sizeof(double) * (size_t)tw64_doubles<P>() + (work > red ? work : red) + sizeof(float) * 32;
+}
+
+template <int P, int NTM, int NTP, int MAGMODE>
+__global__ __launch_bounds__(kFusedWaves * 64) void k_analysis_warp_fused(
+    const float* __restrict__ sig, const long long* __restrict__ fpos, const int* __restrict__ fleft,
+    const int* __restrict__ fright, long long nframes, const double* __restrict__ tw_g,
+    const double* __restrict__ win_tab, int win_cap, const float* __restrict__ wpack, const float* __restrict__ whalf,
+    const float* __restrict__ voiced, int mag_dim, int phase_dim, float* __restrict__ omag, float* __restrict__ oreal,
+    float* __restrict__ oimag) {
+    // T column tiles per chunk: NTM for the magnitudes (rows 0..7 of the 16-row MFMA tile = the round's frames, rows 8..15
+    // repeat them and are dropped) and NTP for BOTH phase streams at once -- they share W_phase, so rows 0..7 take the real
+    // operands of the eight frames and rows 8..15 the imaginary ones: full tiles, half the phase MFMAs.
+    constexpr int M = 64 * P, N = 2 * M, LB = ilog2(P), T = NTM + NTP;
+    extern __shared__ __attribute__((aligned(16))) double smem64[];
+    double* tw = smem64;
+    float* xbase = reinterpret_cast<float*>(smem64 + tw64_doubles<P>());
+    const int lane_id = threadIdx.x & 63;
+    const int wave = rfl((int)(threadIdx.x >> 6));
+    float* xbuf = xbase + wave * (P * kXStride);
+    const unsigned xbuf_byte = 8u * (unsigned)tw64_doubles<P>() + 4u * (unsigned)(wave * (P * kXStride));
+    float* As = xbase + kFusedWaves * (P * kXStride);          // [2][3][8][kFusedAStride]
+    float* red = xbase;                                         // round end: aliases the transpose buffers (and As)
+    constexpr size_t kWork = (size_t)(kFusedWaves * P * kXStride + 2 * 3 * kFusedWaves * kFusedAStride);
+    constexpr size_t kRed = (size_t)(kFusedWaves * T * 4 * 64);
+    float* mid = xbase + (kWork > kRed ? kWork : kRed);         // [3][8]: bin M/2 of every frame of the round
+    for (int i = threadIdx.x; i < tw64_doubles<P>(); i += kFusedWaves * 64) {
+        const int l = i / tw64_stride<P>(), c = i - l * tw64_stride<P>();
+        const int src = (kF64Dit && c < 2 * P) ? l * tw64_stride<P>() + 2 * brev(c >> 1, LB) + (c & 1) : i;
+        tw[i] = tw_g[src];
+    }
+    __syncthreads();
+
+    double wl_s0, wl_c0;
+    sincospi(-2.0 * (double)kappa<P>(lane_id) / (double)N, &wl_s0, &wl_c0);
+    const long long nrounds = (nframes + kFusedWaves - 1) / kFusedWaves;
+    const int li = lane_id & 15, g = lane_id >> 4;
+    const f32x4_t* wp_wave = reinterpret_cast<const f32x4_t*>(wpack) + ((long long)wave * T) * 64;   // wave-uniform
+
+    for (long long rnd = blockIdx.x; rnd < nrounds; rnd += gridDim.x) {
+        int lane = lane_id;   // laundered per round (see k_analysis_f64)
+        double wl_s = wl_s0, wl_c = wl_c0;
+        asm volatile("" : "+v"(lane), "+v"(wl_s), "+v"(wl_c));
+        const int kap = kappa<P>(lane);
+        const int src_lane = kappa<P>((64 - kap) & 63);
+        const bool lane0 = (kap == 0);
+        const long long f = rnd * kFusedWaves + wave;
+        const bool has = f < nframes;                    // wave-uniform
+        double re[P], im[P];
+        double zero2 = 1.0e-36;
+        float mag_scale = 1.0f;
+        bool voi = false;
+        if (has) {
+            f64_frame_transform<P>(sig, fpos[f], fleft[f], fright[f], win_tab, win_cap, tw, xbuf, xbuf_byte, lane, re, im, zero2,
+                                   mag_scale);
+            voi = rfl((int)(voiced[f] != 0.0f)) != 0;
+        } else {
+#pragma unroll
+            for (int j = 0; j < P; ++j) re[j] = im[j] = 0.0;
+        }
+
+        // operand values of one bin: (ln-power, phase operands of Re X/|X| and Im X/|X|) as the staged path forms them
+        auto operand = [&](double xr, double xi, float& a_m, float& a_r, float& a_i) {
+            const double s2 = xr * xr + xi * xi;
+            const bool nz = s2 > zero2;
+            const double rr = nz ? rsqrt_f64(s2) : 0.0;
+            a_m = fused_prologue_mag(MAGMODE, (float)(s2 * rr) * mag_scale);
+            a_r = voi ? fused_prologue_phase((float)(xr * rr)) : 0.0f;
+            a_i = voi ? fused_prologue_phase((float)(xi * rr)) : 0.0f;
+        };
+        // The split of every bin pair row FIRST (k_analysis_f64's epilogue arithmetic), into float32 operand registers:
+        // entry 2 q = the low bin kappa + 64 q of step q, 2 q + 1 = its mirror M - kappa - 64 q.  The float64 spectrum
+        // (128 registers) is dead after this block; what stays live through the chunk loop is 3 x P floats.
+        float vm[P], vr[P], vi[P];
+        {
+#ifndef MPX_FUSED_EB
+#define MPX_FUSED_EB 2
+#endif
+            constexpr int EB = MPX_FUSED_EB;
+#pragma unroll
+            for (int qb = 0; qb < P / 2; qb += EB) {
+                // (fence: the partner exchanges of LATER batches must not be scheduled ahead -- every batch in flight
+                // holds 4 EB more registers while the float64 spectrum is still live)
+                asm volatile("" : "+v"(re[f64_out_reg<P>(qb)]), "+v"(im[f64_out_reg<P>(qb)]));
+                double zpr[EB], zpi[EB];
+#pragma unroll
+                for (int u = 0; u < EB; ++u) {   // Z[M - k]: lane (64 - kappa) & 63, register of row P - 1 - q
+                    const int i = f64_out_reg<P>(qb + u);
+                    unsigned a, b, c, d;
+                    split64(re[P - 1 - i], a, b);
+                    split64(im[P - 1 - i], c, d);
+                    zpr[u] = join64((unsigned)__shfl((int)a, src_lane), (unsigned)__shfl((int)b, src_lane));
+                    zpi[u] = join64((unsigned)__shfl((int)c, src_lane), (unsigned)__shfl((int)d, src_lane));
+                }
+#pragma unroll
+                for (int u = 0; u < EB; ++u) {
+                    const int q = qb + u;
+                    const int i = f64_out_reg<P>(q);
+                    const int i0 = f64_out_reg<P>((P - q) % P);
+                    const double pr_ = lane0 ? re[i0] : zpr[u];
+                    const double pi_ = lane0 ? im[i0] : zpi[u];
+                    const double er = 0.5 * (re[i] + pr_), ei = 0.5 * (im[i] - pi_);
+                    const double orr = 0.5 * (im[i] + pi_), oi = -0.5 * (re[i] - pr_);
+                    constexpr int kq = 64 / (2 * P);
+                    const double cq = dc64(q * kq), sq = -ds64(q * kq);
+                    const double wr = wl_c * cq - wl_s * sq, wi = wl_c * sq + wl_s * cq;
+                    const double tr = wr * orr - wi * oi, ti = wr * oi + wi * orr;
+                    operand(er + tr, ei + ti, vm[2 * q], vr[2 * q], vi[2 * q]);
+                    operand(er - tr, ti - ei, vm[2 * q + 1], vr[2 * q + 1], vi[2 * q + 1]);
+                }
+            }
+            constexpr int ih = f64_out_reg<P>(P / 2);   // bin M/2 (its own mirror; lane kappa == 0 holds it)
+            float m0, m1, m2;
+            operand(re[ih], -im[ih], m0, m1, m2);
+            if (lane0) {
+                mid[0 * kFusedWaves + wave] = m0;
+                mid[1 * kFusedWaves + wave] = m1;
+                mid[2 * kFusedWaves + wave] = m2;
+            }
+        }
+        // a round without a voiced frame has nothing for the phase tiles to do (their outputs are masked to +0)
+        f32x4_t acc[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) acc[t] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int q = 0; q < P / 2; ++q) {
+            float* tile = As + (q & 1) * (3 * kFusedWaves * kFusedAStride);
+            {
+                float* row = tile + wave * kFusedAStride;
+                row[kap] = vm[2 * q];
+                row[64 + kap] = vm[2 * q + 1];
+                row += kFusedWaves * kFusedAStride;
+                row[kap] = vr[2 * q];
+                row[64 + kap] = vr[2 * q + 1];
+                row += kFusedWaves * kFusedAStride;
+                row[kap] = vi[2 * q];
+                row[64 + kap] = vi[2 * q + 1];
+            }
+            // W fragments of this wave's 16 columns (one 16-byte load per tile, from a scalar base + the lane offset; the
+            // base is laundered so that the compiler cannot hoist every chunk's loads to the top of the unrolled loop)
+            const f32x4_t* wq = wp_wave + (long long)q * (kFusedWaves * T * 64);
+            asm volatile("" : "+s"(wq));
+            f32x4_t bw[T];
+#pragma unroll
+            for (int t = 0; t < T; ++t) bw[t] = wq[t * 64 + lane_id];
+            __syncthreads();
+            // A fragments: magnitudes row li & 7; phases: rows 0..7 the real operands, rows 8..15 the imaginary ones
+            const f32x4_t am = *reinterpret_cast<const f32x4_t*>(tile + (li & 7) * kFusedAStride + 16 * wave + 4 * g);
+            const f32x4_t ap = *reinterpret_cast<const f32x4_t*>(tile + ((li < 8 ? 1 : 2) * kFusedWaves + (li & 7)) * kFusedAStride +
+                                                                 16 * wave + 4 * g);
+            // a FRESH accumulator per chunk (16 terms), added to the round's totals afterwards: the partial sums of one
+            // long float32 chain over operands of size ~10 cost 2e-6 on the phase features (the staged GEMM's two-level
+            // accumulation, magphase_comp.hip)
+            f32x4_t ca[T];
+#pragma unroll
+            for (int t = 0; t < T; ++t) ca[t] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                for (int t = 0; t < NTM; ++t) ca[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(am[e], bw[t][e], ca[t], 0, 0, 0);
+#pragma unroll
+                for (int t = NTM; t < T; ++t) ca[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[e], bw[t][e], ca[t], 0, 0, 0);
+            }
+#pragma unroll
+            for (int t = 0; t < T; ++t) acc[t] += ca[t];
+        }
+        __syncthreads();   // every wave is done with the tiles and its transpose buffer: `red` may overwrite them
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[((wave * T + t) * 4 + r) * 64 + lane_id] = acc[t][r];
+        __syncthreads();
+        // outputs of the round.  C of a tile: column c, row 4 g' + r.  Magnitude tiles: row = frame fr.  Phase tiles: row fr =
+        // the real stream, row 8 + fr = the imaginary one.
+        constexpr int kOuts = NTM + 2 * NTP;   // output column tiles per frame: magnitudes, real, imaginary
+        for (int idx = threadIdx.x; idx < kFusedWaves * kOuts * 16; idx += kFusedWaves * 64) {
+            const int c = idx & 15, to = (idx >> 4) % kOuts, fr = idx / (16 * kOuts);
+            const long long fo = rnd * kFusedWaves + fr;
+            if (fo >= nframes) continue;
+            const int sa = (to < NTM) ? 0 : ((to < NTM + NTP) ? 1 : 2);
+            const int t = (sa == 2) ? to - NTP : to;               // the MFMA tile that holds it
+            const int row = (sa == 2) ? 8 + fr : fr;
+            const int gg = row >> 2, r = row & 3;
+            float y = 0.0f;
+#pragma unroll
+            for (int w = 0; w < kFusedWaves; ++w) y += red[((w * T + t) * 4 + r) * 64 + c + 16 * gg];
+            y = fmaf(mid[sa * kFusedWaves + fr], whalf[t * 16 + c], y);
+            if (sa == 0) {
+                const int n = 16 * t + c;
+                if (n >= mag_dim) continue;
+                if (MAGMODE == 2) y = (y < -745.13321f) ? -1.0e10f : y;
+                omag[fo * mag_dim + n] = y;
+            } else {
+                const int n = 16 * (t - NTM) + c;
+                if (n >= phase_dim) continue;
+                const float vo = voiced[fo];
+                y = (vo == 0.0f) ? 0.0f : fminf(fmaxf(y * vo, -1.0f), 1.0f);
+                (sa == 1 ? oreal : oimag)[fo * phase_dim + n] = y;
+            }
+        }
+        __syncthreads();   // `red` / `mid` are reused by the next round
     }
 }
 
@@ -329,6 +588,61 @@ int mpx_analysis_frames_f64w(void* stream, int fft_len, const void* tables_f64, 
     else MPX_LAUNCH_A64(8);
 #undef MPX_LAUNCH_A64
     MPX_HIP_CHECK(hipGetLastError());
+    return MPX_OK;
+}
+
+
+/* (declared in include/magphase_hip.h) */
+int mpx_analysis_compressed_fused(void* stream, int fft_len, const void* tables_f64, const float* sig,
+                                  const int64_t* frame_pos, const int32_t* frame_left, const int32_t* frame_right,
+                                  int64_t n_frames, const double* win_tab, int32_t win_cap, const float* wpack,
+                                  const float* whalf, int32_t mag_dim, int32_t phase_dim, const float* voiced,
+                                  int32_t mag_fbank, float* out_mag, float* out_real, float* out_imag) {
+    const int P = p_of(fft_len);
+    if (P != 32 && P != 16) return fail(MPX_ERR_ARG, "mpx_analysis_compressed_fused: fft_len must be 2048 or 4096%s");
+    if (n_frames < 0) return fail(MPX_ERR_ARG, "mpx_analysis_compressed_fused: negative n_frames%s");
+    if (mag_dim <= 0 || mag_dim > 64 || phase_dim <= 0 || phase_dim > 48)
+        return fail(MPX_ERR_ARG, "mpx_analysis_compressed_fused: mag_dim must be in 1..64 and phase_dim in 1..48%s");
+    if (win_tab && win_cap < 0) return fail(MPX_ERR_ARG, "mpx_analysis_compressed_fused: negative win_cap%s");
+    if (n_frames == 0) return MPX_OK;
+    if (!tables_f64 || !sig || !frame_pos || !frame_left || !frame_right || !wpack || !whalf || !voiced || !out_mag ||
+        !out_real || !out_imag)
+        return fail(MPX_ERR_ARG, "mpx_analysis_compressed_fused: null pointer%s");
+    const long long nrounds = (n_frames + kFusedWaves - 1) / kFusedWaves;
+    const int cus = device_cus();
+    const dim3 grid((unsigned)(nrounds < cus ? nrounds : cus)), block(kFusedWaves * 64);
+    hipStream_t s = (hipStream_t)stream;
+    const int ntp = (phase_dim + 15) / 16;
+#define MPX_FUSED_GO(PP, NTP_, MM)                                                                                        \
+    do {                                                                                                                  \
+        if (int rc = set_lds(k_analysis_warp_fused<PP, 4, NTP_, MM>, (lds_bytes_fused<PP, 4, NTP_>()))) return rc;        \
+        hipLaunchKernelGGL((k_analysis_warp_fused<PP, 4, NTP_, MM>), grid, block, (lds_bytes_fused<PP, 4, NTP_>()), s, sig, \
+                           (const long long*)frame_pos, frame_left, frame_right, (long long)n_frames,                     \
+                           (const double*)tables_f64, win_tab, (int)win_cap, wpack, whalf, voiced, (int)mag_dim,          \
+                           (int)phase_dim, out_mag, out_real, out_imag);                                                  \
+    } while (0)
+#define MPX_FUSED_P(PP)                                                     \
+    do {                                                                    \
+        if (ntp == 1 && !mag_fbank) MPX_FUSED_GO(PP, 1, 0);                 \
+        else if (ntp == 1) MPX_FUSED_GO(PP, 1, 2);                          \
+        else if (ntp == 2 && !mag_fbank) MPX_FUSED_GO(PP, 2, 0);            \
+        else if (ntp == 2) MPX_FUSED_GO(PP, 2, 2);                          \
+        else if (!mag_fbank) MPX_FUSED_GO(PP, 3, 0);                        \
+        else MPX_FUSED_GO(PP, 3, 2);                                        \
+    } while (0)
+    if (P == 32) MPX_FUSED_P(32);
+    else MPX_FUSED_P(16);
+#undef MPX_FUSED_P
+#undef MPX_FUSED_GO
+    MPX_HIP_CHECK(hipGetLastError());
+    return MPX_OK;
+}
+
+int mpx_analysis_compressed_fused_tiles(int32_t mag_dim, int32_t phase_dim, int32_t* ntm, int32_t* ntp) {
+    if (mag_dim <= 0 || mag_dim > 64 || phase_dim <= 0 || phase_dim > 48 || !ntm || !ntp)
+        return fail(MPX_ERR_ARG, "mpx_analysis_compressed_fused_tiles: bad arguments%s");
+    *ntm = 4;                        // the magnitude job always runs four 16-wide column tiles (mag_dim <= 64)
+    *ntp = (phase_dim + 15) / 16;
     return MPX_OK;
 }
 

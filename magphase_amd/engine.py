@@ -1480,6 +1480,20 @@ class CompressedAnalysisPlan:
         self.row0, self.row1, self.rowt = (desc.get(k) for k in ("row0", "row1", "rowt"))
         self.rows_in_use = desc.get("rows_in_use")
         self._phase_tmp = None
+        # Variable frame rate: ONE fused kernel, the lossless features never reach HBM (mpx_analysis_compressed_fused;
+        # MAGPHASE_COMP_FUSED=0 keeps the staged pair k_analysis_f64 -> k_mel_warp_mfma).  The constant-rate path
+        # interpolates staged lossless rows, as the reference does (SURVEY.md 8d allows that staging).
+        self.fused = (not b_const_rate and N in (2048, 4096) and self.mag_dim <= 64 and self.phase_dim <= 48
+                      and os.environ.get("MAGPHASE_COMP_FUSED", "1") != "0"
+                      and os.environ.get("MAGPHASE_COMP_ANALYSIS", "f64") != "f32")
+        if self.fused:
+            key = ("wpack", self._warp_name, int(mag_dim), int(k_full), int(phase_dim), H, float(alpha), float(a_ph))
+            if key not in e._tables:
+                wm = (hm.warp_fbank_matrix(mag_dim, H, alpha) if self._warp_name == "mpx_mel_warp_fbank"
+                      else hm.warp_matrix(mag_dim, H, alpha))
+                wpack, whalf = hm.pack_warp_fused(wm, hm.warp_matrix(k_full, H, a_ph, nrows=phase_dim), N)
+                e._tables[key] = (e.to_device(wpack, np.float32), e.to_device(whalf, np.float32))
+            self.wpack, self.whalf = e._tables[key]
 
     def run(self, feats=None, out=None, mark=None):
         e, torch = self.engine, _torch()
@@ -1488,6 +1502,22 @@ class CompressedAnalysisPlan:
         mark("start")
         # float64 transform: the warp's log / division amplify an fp32 FFT's noise on weak bins (magphase_f64.hip)
         precise = os.environ.get("MAGPHASE_COMP_ANALYSIS", "f64") != "f32"
+        if self.fused and feats is None:
+            if out is None:
+                out = (e.empty((self.total_out_frames, self.mag_dim)), e.empty((self.total_out_frames, self.phase_dim)),
+                       e.empty((self.total_out_frames, self.phase_dim)))
+            pl = self.lossless
+            wt = e.hann_table() if os.environ.get("MAGPHASE_F64_WINDOW", "table") != "analytic" else None
+            with torch.cuda.device(e.device):
+                _lib.check(e.lib.mpx_analysis_compressed_fused(
+                    e.stream_ptr(), int(self.fft_len), e.tables_f64(self.fft_len).data_ptr(), pl.sig.data_ptr(),
+                    pl.pos.data_ptr(), pl.left.data_ptr(), pl.right.data_ptr(), int(pl.total_frames),
+                    (wt.data_ptr() if wt is not None else None), (hm.HANN_TABLE_CAP if wt is not None else 0),
+                    self.wpack.data_ptr(), self.whalf.data_ptr(), self.mag_dim, self.phase_dim, self.voi.data_ptr(),
+                    1 if self._warp_name == "mpx_mel_warp_fbank" else 0, out[0].data_ptr(), out[1].data_ptr(),
+                    out[2].data_ptr()), "mpx_analysis_compressed_fused")
+            mark("k_analysis_warp_fused")
+            return out
         # (the phase rows nobody reads -- rows_in_use == 0 -- are not written either)
         mag, real, imag = self.lossless.run(out=feats, precise=precise,
                                             rows_in_use=self.rows_in_use if self.phase_on_rows else None)

@@ -495,6 +495,63 @@ def warp_matrix(nbins_out, nbins_half, alpha, nrows=None):
     return wm if nrows is None else wm[:nrows]
 
 
+def _kappa(P, lane):
+    """wave_fft.hpp kappa(lane): the output-index residue a lane holds (identity for P = 32)."""
+    lane = np.asarray(lane)
+    if P == 32:
+        return lane
+    if P == 16:
+        return (lane & 15) | (((lane >> 5) & 1) << 4) | (((lane >> 4) & 1) << 5)
+    return (lane & 7) | (((lane >> 5) & 1) << 3) | (lane & 16) | (((lane >> 3) & 1) << 5)
+
+
+def fused_chunk_bins(fft_len):
+    """Bin of column c of chunk q in mpx_analysis_compressed_fused's published tile: int64[P/2, 128] --
+    c < 64: the low bin 64 q + c, c >= 64: its mirror M - 64 q - (c - 64)  (M = fft_len / 2; bin M/2 is not in any chunk)."""
+    P = fft_len // 128
+    M = fft_len // 2
+    q = np.arange(P // 2)[:, None]
+    c = np.arange(64)[None, :]
+    return np.concatenate((64 * q + c, M - 64 * q - c), axis=1).astype(np.int64)
+
+
+def pack_warp_fused(w_mag, w_ph, fft_len, n_waves=8):
+    """
+    The two warp matrices ([mag_dim x H] and [phase_dim x H], float64) in the order mpx_analysis_compressed_fused's MFMA
+    (v_mfma_f32_16x16x4_f32) consumes them: wpack[q][wave][tile][lane][e] = W_tile[16 jt + (lane & 15)][bin(q, 16 wave +
+    4 (lane >> 4) + e)] -- one 16-byte load per lane, tile and chunk; tiles = 4 magnitude column tiles, then
+    ceil(phase_dim / 16) phase tiles (shared by the real and the imaginary stream); rows past the matrix are zero.
+    whalf[tile][16] = the same rows' weight of bin M/2 (added outside the chunks).  Returns (wpack, whalf) float32.
+    """
+    w_mag, w_ph = np.asarray(w_mag, dtype=np.float64), np.asarray(w_ph, dtype=np.float64)
+    H = fft_len // 2 + 1
+    assert w_mag.shape[1] == H and w_ph.shape[1] == H and w_mag.shape[0] <= 64 and w_ph.shape[0] <= 48
+    ntm, ntp = 4, (w_ph.shape[0] + 15) // 16
+    tiles = []
+    for jt in range(ntm):
+        t = np.zeros((16, H))
+        rows = w_mag[16 * jt:16 * jt + 16]
+        t[:rows.shape[0]] = rows
+        tiles.append(t)
+    for jt in range(ntp):
+        t = np.zeros((16, H))
+        rows = w_ph[16 * jt:16 * jt + 16]
+        t[:rows.shape[0]] = rows
+        tiles.append(t)
+    tiles = np.stack(tiles)                                # [TB, 16, H]
+    bins = fused_chunk_bins(fft_len)                       # [P/2, 128]
+    lane = np.arange(64)
+    li, g = lane & 15, lane >> 4
+    e = np.arange(4)
+    col = 16 * np.arange(n_waves)[:, None, None] + 4 * g[None, :, None] + e[None, None, :]      # [wave, lane, e]
+    b = bins[:, col]                                       # [q, wave, lane, e]
+    # wpack[q, wave, tile, lane, e] = tiles[tile, li[lane], b[q, wave, lane, e]]
+    wpack = tiles[:, li[None, None, :, None], b]           # [TB, q, wave, lane, e]
+    wpack = np.ascontiguousarray(np.transpose(wpack, (1, 2, 0, 3, 4)), dtype=np.float32)
+    whalf = np.ascontiguousarray(tiles[:, :, fft_len // 4], dtype=np.float32)   # [TB, 16]
+    return wpack.reshape(-1), whalf.reshape(-1)
+
+
 def var_to_const_rate_table(v_pm_smpls, const_rate_ms, fs):
     """
     Row/weight table of magphase.py:2219-2239 (Q15): grid arange(step, pm[-1], step); the first row is duplicated at

@@ -146,7 +146,8 @@ def test_row_table_form_of_the_synthesis_kernel(golden_dir):
     torch.cuda.synchronize()
     a, b = pcm.cpu().numpy().astype(np.float64), want.cpu().numpy().astype(np.float64)
     assert np.max(np.abs(b)) > 1e-3
-    within(np.max(np.abs(a - b)) / max(1.0, np.max(np.abs(b))), COMP_PCM_TOL, "COMP_PCM_TOL:row_tables")
+    # (same kernel, same arithmetic, only the anti-ringing window's source differs: measured 8.9e-8)
+    within(np.max(np.abs(a - b)) / max(1.0, np.max(np.abs(b))), 2.5e-7, "COMP_PCM_TOL:row_tables")
 
 
 def test_generation_from_predicted_features_matches_reference_golden(mp, golden_dir):
@@ -499,7 +500,7 @@ def test_fbank_warp_analysis_matches_reference(mp, golden_dir):
         got = e.to_host_f64(out[0])
         floor = y == -1.0e10
         assert np.array_equal(got == -1.0e10, floor)
-        within(np.max(np.abs(got[~floor] - y[~floor])), WARP_TOL, "WARP_TOL:434")
+        within(np.max(np.abs(got[~floor] - y[~floor])), 2e-6, "WARP_TOL:434")   # filter-bank magnitudes: measured 6.7e-7
 
 
 def test_full_size_config3_constant_rate_post_filter(mp, orc):
