@@ -107,6 +107,8 @@ int mpx_analysis_compressed_fused(void* stream, int fft_len, const void* tables_
                                   int32_t mag_fbank, float* out_mag, float* out_real, float* out_imag);
 /* column tiles of 16 the fused kernel runs for the magnitude / phase job (what pack_warp_fused must produce) */
 int mpx_analysis_compressed_fused_tiles(int32_t mag_dim, int32_t phase_dim, int32_t* ntm, int32_t* ntp);
+/* waves per workgroup = frames per round = K slices the packed weights are cut into (pack_warp_fused's n_waves) */
+int mpx_analysis_compressed_fused_waves(void);
 
 /*
  * Row pitch (in floats) the lossless feature matrices should be allocated with.  Any ld >= H is CORRECT for every

@@ -24,6 +24,7 @@ SYMBOLS = (
     "mpx_analysis_frames_f64w",
     "mpx_analysis_compressed_fused",
     "mpx_analysis_compressed_fused_tiles",
+    "mpx_analysis_compressed_fused_waves",
     "mpx_synthesis_lossless_frames",
     "mpx_ola_gather",
     "mpx_synth_ola_slots",
@@ -124,6 +125,8 @@ def _load_locked():
     lib.mpx_analysis_compressed_fused.restype = ctypes.c_int
     lib.mpx_analysis_compressed_fused.argtypes = [vp, ctypes.c_int, vp, vp, vp, vp, vp, i64, vp, i32, vp, vp, i32, i32, vp, i32,
                                                   vp, vp, vp]
+    lib.mpx_analysis_compressed_fused_waves.restype = ctypes.c_int
+    lib.mpx_analysis_compressed_fused_waves.argtypes = []
     lib.mpx_analysis_compressed_fused_tiles.restype = ctypes.c_int
     lib.mpx_analysis_compressed_fused_tiles.argtypes = [i32, i32, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]
     lib.mpx_analysis_frames_f64w.restype = ctypes.c_int

@@ -295,7 +295,18 @@ __global__ __launch_bounds__(kAna64Waves * 64) void k_analysis_f64(const float* 
 // accumulator per 64 bins + 33 chunk sums.
 // ---------------------------------------------------------------------------------------------
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
-constexpr int kFusedWaves = 8;
+// Waves (= frames per round) of a workgroup.  8: one workgroup per CU; its transform (float64 VALU) and its GEMM (MFMA)
+// alternate -- 0.96 ms per 57 k frames at 60 / 10 coefficients.  4 (-DMPX_FUSED_WAVES=4): TWO independent workgroups per
+// CU, so that one's MFMA phase could run under the other's float64 VALU phase; the tiles are then a quarter / half full
+// (twice the MFMA instructions per frame) and the kernel got SLOWER, 1.26 ms: like the lossless kernels this one runs at
+// the board's power limit, where time follows the work done, not the overlap ("power").
+#ifndef MPX_FUSED_WAVES
+#define MPX_FUSED_WAVES 8
+#endif
+constexpr int kFusedWaves = MPX_FUSED_WAVES;
+static_assert(kFusedWaves == 4 || kFusedWaves == 8, "4 or 8 waves per fused workgroup");
+constexpr int kFusedCols = 128 / kFusedWaves;      // tile columns per wave and chunk (its K slice): 16 or 32
+constexpr int kFusedKH = kFusedCols / 16;          // 16-column groups per wave: 4 MFMA k-steps each
 constexpr int kFusedAStride = 132;   // floats per published row (128 columns + 4: rows start 16 bytes apart in the banks)
 
 // the warp's operand prologue / epilogue (same formulas as magphase_comp.hip: warp_prologue / warp_epilogue)
@@ -314,6 +325,7 @@ constexpr size_t lds_bytes_fused() {
 }
 
 template <int P, int NTM, int NTP, int MAGMODE>
+__attribute__((amdgpu_waves_per_eu(2, 2)))   // <= 256 registers (VGPR + AGPR): two workgroups of four waves per CU
 __global__ __launch_bounds__(kFusedWaves * 64) void k_analysis_warp_fused(
     const float* __restrict__ sig, const long long* __restrict__ fpos, const int* __restrict__ fleft,
     const int* __restrict__ fright, long long nframes, const double* __restrict__ tw_g,
@@ -347,7 +359,7 @@ __global__ __launch_bounds__(kFusedWaves * 64) void k_analysis_warp_fused(
     sincospi(-2.0 * (double)kappa<P>(lane_id) / (double)N, &wl_s0, &wl_c0);
     const long long nrounds = (nframes + kFusedWaves - 1) / kFusedWaves;
     const int li = lane_id & 15, g = lane_id >> 4;
-    const f32x4_t* wp_wave = reinterpret_cast<const f32x4_t*>(wpack) + ((long long)wave * T) * 64;   // wave-uniform
+    const f32x4_t* wp_wave = reinterpret_cast<const f32x4_t*>(wpack) + ((long long)wave * kFusedKH * T) * 64;   // wave-uniform
 
     for (long long rnd = blockIdx.x; rnd < nrounds; rnd += gridDim.x) {
         int lane = lane_id;   // laundered per round (see k_analysis_f64)
@@ -450,28 +462,38 @@ __global__ __launch_bounds__(kFusedWaves * 64) void k_analysis_warp_fused(
             }
             // W fragments of this wave's 16 columns (one 16-byte load per tile, from a scalar base + the lane offset; the
             // base is laundered so that the compiler cannot hoist every chunk's loads to the top of the unrolled loop)
-            const f32x4_t* wq = wp_wave + (long long)q * (kFusedWaves * T * 64);
+            const f32x4_t* wq = wp_wave + (long long)q * (kFusedWaves * kFusedKH * T * 64);
             asm volatile("" : "+s"(wq));
-            f32x4_t bw[T];
+            f32x4_t bw[T];   // the first 16-column group's fragments fly across the barrier; later groups reuse the registers
 #pragma unroll
             for (int t = 0; t < T; ++t) bw[t] = wq[t * 64 + lane_id];
             __syncthreads();
-            // A fragments: magnitudes row li & 7; phases: rows 0..7 the real operands, rows 8..15 the imaginary ones
-            const f32x4_t am = *reinterpret_cast<const f32x4_t*>(tile + (li & 7) * kFusedAStride + 16 * wave + 4 * g);
-            const f32x4_t ap = *reinterpret_cast<const f32x4_t*>(tile + ((li < 8 ? 1 : 2) * kFusedWaves + (li & 7)) * kFusedAStride +
-                                                                 16 * wave + 4 * g);
-            // a FRESH accumulator per chunk (16 terms), added to the round's totals afterwards: the partial sums of one
-            // long float32 chain over operands of size ~10 cost 2e-6 on the phase features (the staged GEMM's two-level
+            // a FRESH accumulator per chunk (16 or 32 terms), added to the round's totals afterwards: the partial sums of
+            // one long float32 chain over operands of size ~10 cost 2e-6 on the phase features (the staged GEMM's two-level
             // accumulation, magphase_comp.hip)
             f32x4_t ca[T];
 #pragma unroll
             for (int t = 0; t < T; ++t) ca[t] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
+            for (int h = 0; h < kFusedKH; ++h) {
+                // A fragments: magnitudes row li mod frames; phases: rows 0..7 the real operands, rows 8..15 the imaginary ones
+                const int col = kFusedCols * wave + 16 * h + 4 * g;
+                const f32x4_t am = *reinterpret_cast<const f32x4_t*>(tile + (li & (kFusedWaves - 1)) * kFusedAStride + col);
+                const f32x4_t ap = *reinterpret_cast<const f32x4_t*>(
+                    tile + ((li < 8 ? 1 : 2) * kFusedWaves + (li & (kFusedWaves - 1))) * kFusedAStride + col);
+                if (h > 0) {
+                    const f32x4_t* wh = wq + (long long)h * (T * 64);
+                    asm volatile("" : "+s"(wh));
 #pragma unroll
-                for (int t = 0; t < NTM; ++t) ca[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(am[e], bw[t][e], ca[t], 0, 0, 0);
+                    for (int t = 0; t < T; ++t) bw[t] = wh[t * 64 + lane_id];
+                }
 #pragma unroll
-                for (int t = NTM; t < T; ++t) ca[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[e], bw[t][e], ca[t], 0, 0, 0);
+                for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                    for (int t = 0; t < NTM; ++t) ca[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(am[e], bw[t][e], ca[t], 0, 0, 0);
+#pragma unroll
+                    for (int t = NTM; t < T; ++t) ca[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[e], bw[t][e], ca[t], 0, 0, 0);
+                }
             }
 #pragma unroll
             for (int t = 0; t < T; ++t) acc[t] += ca[t];
@@ -609,8 +631,8 @@ int mpx_analysis_compressed_fused(void* stream, int fft_len, const void* tables_
         !out_real || !out_imag)
         return fail(MPX_ERR_ARG, "mpx_analysis_compressed_fused: null pointer%s");
     const long long nrounds = (n_frames + kFusedWaves - 1) / kFusedWaves;
-    const int cus = device_cus();
-    const dim3 grid((unsigned)(nrounds < cus ? nrounds : cus)), block(kFusedWaves * 64);
+    const long long slots = (long long)device_cus() * (8 / kFusedWaves);   // resident workgroups: two per CU with four waves each
+    const dim3 grid((unsigned)(nrounds < slots ? nrounds : slots)), block(kFusedWaves * 64);
     hipStream_t s = (hipStream_t)stream;
     const int ntp = (phase_dim + 15) / 16;
 #define MPX_FUSED_GO(PP, NTP_, MM)                                                                                        \
@@ -645,5 +667,7 @@ int mpx_analysis_compressed_fused_tiles(int32_t mag_dim, int32_t phase_dim, int3
     *ntp = (phase_dim + 15) / 16;
     return MPX_OK;
 }
+
+int mpx_analysis_compressed_fused_waves(void) { return kFusedWaves; }   // frames per round = K slices of the packed weights
 
 }  // extern "C"

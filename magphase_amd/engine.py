@@ -1487,11 +1487,12 @@ class CompressedAnalysisPlan:
                       and os.environ.get("MAGPHASE_COMP_FUSED", "1") != "0"
                       and os.environ.get("MAGPHASE_COMP_ANALYSIS", "f64") != "f32")
         if self.fused:
-            key = ("wpack", self._warp_name, int(mag_dim), int(k_full), int(phase_dim), H, float(alpha), float(a_ph))
+            nw = int(e.lib.mpx_analysis_compressed_fused_waves())
+            key = ("wpack", self._warp_name, int(mag_dim), int(k_full), int(phase_dim), H, float(alpha), float(a_ph), nw)
             if key not in e._tables:
                 wm = (hm.warp_fbank_matrix(mag_dim, H, alpha) if self._warp_name == "mpx_mel_warp_fbank"
                       else hm.warp_matrix(mag_dim, H, alpha))
-                wpack, whalf = hm.pack_warp_fused(wm, hm.warp_matrix(k_full, H, a_ph, nrows=phase_dim), N)
+                wpack, whalf = hm.pack_warp_fused(wm, hm.warp_matrix(k_full, H, a_ph, nrows=phase_dim), N, n_waves=nw)
                 e._tables[key] = (e.to_device(wpack, np.float32), e.to_device(whalf, np.float32))
             self.wpack, self.whalf = e._tables[key]
 
@@ -1502,7 +1503,7 @@ class CompressedAnalysisPlan:
         mark("start")
         # float64 transform: the warp's log / division amplify an fp32 FFT's noise on weak bins (magphase_f64.hip)
         precise = os.environ.get("MAGPHASE_COMP_ANALYSIS", "f64") != "f32"
-        if self.fused and feats is None:
+        if self.fused:   # (feats, the staged path's lossless feature buffers, are not used)
             if out is None:
                 out = (e.empty((self.total_out_frames, self.mag_dim)), e.empty((self.total_out_frames, self.phase_dim)),
                        e.empty((self.total_out_frames, self.phase_dim)))

@@ -518,37 +518,36 @@ def fused_chunk_bins(fft_len):
 def pack_warp_fused(w_mag, w_ph, fft_len, n_waves=8):
     """
     The two warp matrices ([mag_dim x H] and [phase_dim x H], float64) in the order mpx_analysis_compressed_fused's MFMA
-    (v_mfma_f32_16x16x4_f32) consumes them: wpack[q][wave][tile][lane][e] = W_tile[16 jt + (lane & 15)][bin(q, 16 wave +
-    4 (lane >> 4) + e)] -- one 16-byte load per lane, tile and chunk; tiles = 4 magnitude column tiles, then
-    ceil(phase_dim / 16) phase tiles (shared by the real and the imaginary stream); rows past the matrix are zero.
+    (v_mfma_f32_16x16x4_f32) consumes them.  A workgroup of n_waves waves (mpx_analysis_compressed_fused_waves) cuts a
+    chunk's 128 columns into n_waves slices of 128 / n_waves columns = kh groups of 16:
+      wpack[q][wave][h][tile][lane][e] = W_tile[16 jt + (lane & 15)][bin(q, (128 / n_waves) wave + 16 h + 4 (lane >> 4) + e)]
+    -- one 16-byte load per lane, tile and 16-column group; tiles = 4 magnitude column tiles, then ceil(phase_dim / 16)
+    phase tiles (shared by the real and the imaginary stream); rows past the matrix are zero.
     whalf[tile][16] = the same rows' weight of bin M/2 (added outside the chunks).  Returns (wpack, whalf) float32.
     """
     w_mag, w_ph = np.asarray(w_mag, dtype=np.float64), np.asarray(w_ph, dtype=np.float64)
     H = fft_len // 2 + 1
     assert w_mag.shape[1] == H and w_ph.shape[1] == H and w_mag.shape[0] <= 64 and w_ph.shape[0] <= 48
+    assert n_waves in (4, 8)
     ntm, ntp = 4, (w_ph.shape[0] + 15) // 16
     tiles = []
-    for jt in range(ntm):
-        t = np.zeros((16, H))
-        rows = w_mag[16 * jt:16 * jt + 16]
-        t[:rows.shape[0]] = rows
-        tiles.append(t)
-    for jt in range(ntp):
-        t = np.zeros((16, H))
-        rows = w_ph[16 * jt:16 * jt + 16]
-        t[:rows.shape[0]] = rows
-        tiles.append(t)
-    tiles = np.stack(tiles)                                # [TB, 16, H]
+    for src, nt in ((w_mag, ntm), (w_ph, ntp)):
+        for jt in range(nt):
+            t = np.zeros((16, H))
+            rows = src[16 * jt:16 * jt + 16]
+            t[:rows.shape[0]] = rows
+            tiles.append(t)
+    tiles = np.stack(tiles)                                # [T, 16, H]
     bins = fused_chunk_bins(fft_len)                       # [P/2, 128]
     lane = np.arange(64)
     li, g = lane & 15, lane >> 4
-    e = np.arange(4)
-    col = 16 * np.arange(n_waves)[:, None, None] + 4 * g[None, :, None] + e[None, None, :]      # [wave, lane, e]
-    b = bins[:, col]                                       # [q, wave, lane, e]
-    # wpack[q, wave, tile, lane, e] = tiles[tile, li[lane], b[q, wave, lane, e]]
-    wpack = tiles[:, li[None, None, :, None], b]           # [TB, q, wave, lane, e]
-    wpack = np.ascontiguousarray(np.transpose(wpack, (1, 2, 0, 3, 4)), dtype=np.float32)
-    whalf = np.ascontiguousarray(tiles[:, :, fft_len // 4], dtype=np.float32)   # [TB, 16]
+    cols, kh = 128 // n_waves, 128 // n_waves // 16
+    col = (cols * np.arange(n_waves)[:, None, None, None] + 16 * np.arange(kh)[None, :, None, None]
+           + 4 * g[None, None, :, None] + np.arange(4)[None, None, None, :])                    # [wave, h, lane, e]
+    b = bins[:, col]                                       # [q, wave, h, lane, e]
+    wpack = tiles[:, li[None, None, None, :, None], b]     # [T, q, wave, h, lane, e]
+    wpack = np.ascontiguousarray(np.transpose(wpack, (1, 2, 3, 0, 4, 5)), dtype=np.float32)   # [q, wave, h, T, lane, e]
+    whalf = np.ascontiguousarray(tiles[:, :, fft_len // 4], dtype=np.float32)   # [T, 16]
     return wpack.reshape(-1), whalf.reshape(-1)
 
 

@@ -10,43 +10,48 @@ import pytest
 from magphase_amd import hostmath as hm
 
 
+@pytest.mark.parametrize("n_waves", [4, 8])
 @pytest.mark.parametrize("fft_len,mag_dim,phase_dim", [(4096, 60, 10), (4096, 60, 45), (2048, 24, 16), (2048, 64, 33)])
-def test_packed_fragments_reproduce_the_matrix_product(fft_len, mag_dim, phase_dim):
+def test_packed_fragments_reproduce_the_matrix_product(fft_len, mag_dim, phase_dim, n_waves):
     rng = np.random.RandomState(fft_len + mag_dim + phase_dim)
     H, M, P = fft_len // 2 + 1, fft_len // 2, fft_len // 128
     w_mag, w_ph = rng.standard_normal((mag_dim, H)), rng.standard_normal((phase_dim, H))
-    wpack, whalf = hm.pack_warp_fused(w_mag, w_ph, fft_len)
+    wpack, whalf = hm.pack_warp_fused(w_mag, w_ph, fft_len, n_waves=n_waves)
     ntm, ntp = 4, (phase_dim + 15) // 16
-    TB, T = ntm + ntp, ntm + 2 * ntp
-    wpack = wpack.reshape(P // 2, 8, TB, 64, 4).astype(np.float64)
-    whalf = whalf.reshape(TB, 16).astype(np.float64)
+    T = ntm + ntp                                                              # MFMA tiles: real and imaginary share the phase tiles
+    cols, kh = 128 // n_waves, 128 // n_waves // 16
+    wpack = wpack.reshape(P // 2, n_waves, kh, T, 64, 4).astype(np.float64)
+    whalf = whalf.reshape(T, 16).astype(np.float64)
     bins = hm.fused_chunk_bins(fft_len)
     assert sorted(bins.reshape(-1).tolist() + [M // 2]) == list(range(H))      # every bin once, M/2 left out
-    x = rng.standard_normal((3, 8, H))                                          # [stream][frame row][bin] operands
+    nf = n_waves                                                               # frames per round
+    x = rng.standard_normal((3, nf, H))                                        # [stream][frame row][bin] operands
     lane = np.arange(64)
     li, g = lane & 15, lane >> 4
-    acc = np.zeros((8, T, 16, 16))                                             # per wave: D[tile][i][j]
+    acc = np.zeros((n_waves, T, 16, 16))                                       # per wave: D[tile][i][j]
     for q in range(P // 2):
         tile = x[:, :, bins[q]]                                                # the published tile [stream][row][128 columns]
-        for w in range(8):
-            for t in range(T):
-                sa = 0 if t < ntm else (1 if t < ntm + ntp else 2)
-                tb = t if t < ntm + ntp else t - ntp
-                for e in range(4):
-                    a = tile[sa, li & 7, 16 * w + 4 * g + e]                   # A fragment element of every lane
-                    b = wpack[q, w, tb, lane, e]
-                    for gg in range(4):                                        # D[i][j] += A[i][k = gg] B[k = gg][j]
-                        acc[w, t] += np.outer(a[16 * gg:16 * gg + 16], b[16 * gg:16 * gg + 16])
+        for w in range(n_waves):
+            for h in range(kh):
+                for t in range(T):
+                    for e in range(4):
+                        col = cols * w + 16 * h + 4 * g + e
+                        if t < ntm:
+                            a = tile[0, li & (nf - 1), col]                    # magnitudes: row li mod frames
+                        else:                                                  # rows 0..7 real operands, 8..15 imaginary
+                            a = np.where(li < 8, tile[1, li & (nf - 1), col], tile[2, li & (nf - 1), col])
+                        b = wpack[q, w, h, t, lane, e]
+                        for gg in range(4):                                    # D[i][j] += A[i][k = gg] B[k = gg][j]
+                            acc[w, t] += np.outer(a[16 * gg:16 * gg + 16], b[16 * gg:16 * gg + 16])
     d = acc.sum(axis=0)                                                        # the round-end reduction over the waves
     for t in range(T):
-        sa = 0 if t < ntm else (1 if t < ntm + ntp else 2)
-        tb = t if t < ntm + ntp else t - ntp
-        wsrc, jt = (w_mag, t) if sa == 0 else (w_ph, tb - ntm)
+        wsrc, jt = (w_mag, t) if t < ntm else (w_ph, t - ntm)
         rows = wsrc[16 * jt:16 * jt + 16]
         if rows.shape[0] == 0:                                                 # a tile past the matrix: all padding
             assert np.all(d[t] == 0.0)
             continue
-        got = d[t][:8, :rows.shape[0]] + np.outer(x[sa][:, M // 2], whalf[tb][:rows.shape[0]])
-        want = x[sa] @ rows.T
-        assert np.max(np.abs(got - want)) < 2e-5 * max(1.0, np.max(np.abs(want)))   # float32 rounding of the packed weights
-        assert np.all(d[t][:8, rows.shape[0]:] == 0.0)                         # padding columns: zero weights
+        for sa, r0 in ((0, 0),) if t < ntm else ((1, 0), (2, 8)):              # output rows: frames (real), 8 + frames (imaginary)
+            got = d[t][r0:r0 + nf, :rows.shape[0]] + np.outer(x[sa][:, M // 2], whalf[t][:rows.shape[0]])
+            want = x[sa] @ rows.T
+            assert np.max(np.abs(got - want)) < 2e-5 * max(1.0, np.max(np.abs(want)))   # float32 rounding of the packed weights
+        assert np.all(d[t][:, rows.shape[0]:] == 0.0)                          # padding columns: zero weights

@@ -608,3 +608,66 @@ def test_full_size_config3_constant_rate_post_filter(mp, orc):
         y = pcm1[splan.out_off_host[u]:splan.out_off_host[u + 1]]
         assert len(y) == len(ref)
         within((np.max(np.abs(y - ref))) / (np.max(np.abs(ref))), COMP_PCM_TOL, "COMP_PCM_TOL:514")
+
+
+@pytest.mark.parametrize("fs,mag_dim,phase_dim,alpha_phase,fbank", [(48000, 60, 10, False, False), (48000, 60, 45, None, False),
+                                                                   (16000, 60, 45, None, False), (16000, 24, 16, None, False),
+                                                                   (48000, 40, 33, None, True)])
+def test_fused_compressed_analysis_matches_oracle_and_staged_path(orc, fs, mag_dim, phase_dim, alpha_phase, fbank):
+    """mpx_analysis_compressed_fused (variable frame rate: transform + both warps in one kernel, no lossless features in
+    HBM) against the oracle at the staged path's tolerances, against the staged pair k_analysis_f64 -> k_mel_warp_mfma
+    (same arithmetic up to the float32 summation order of the GEMM), bit-reproducible, with a frame count that is not a
+    multiple of the eight frames of a round, an all-unvoiced utterance and the filter-bank magnitudes."""
+    from magphase_amd import synthetic as syn
+    from magphase_amd.engine import CompressedAnalysisPlan, get_engine
+    eng = get_engine()
+    utts = []
+    for u in range(4):
+        pcm, pm, voi = syn.make_utterance(70 + u, dur_s=0.9 + 0.13 * u, fs=fs)
+        if u == 2:
+            voi = np.zeros_like(voi)
+        utts.append((syn.pcm_to_float(pcm), fs, pm, voi))
+    kw = dict(mag_dim=mag_dim, phase_dim=phase_dim, alpha_phase=alpha_phase, b_mag_fbank_mel=fbank)
+    old = os.environ.get("MAGPHASE_COMP_FUSED")
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            os.environ["MAGPHASE_COMP_FUSED"] = "1"
+            pf = CompressedAnalysisPlan(eng, utts, **kw)
+            if pf.lossless.total_frames % 8 == 0:   # the last round must be a partial one: drop one epoch
+                x0, f0_, pm0, voi0 = utts[0]
+                utts[0] = (x0, f0_, pm0[:-1], voi0[:-1])
+                pf = CompressedAnalysisPlan(eng, utts, **kw)
+            assert pf.fused and pf.lossless.total_frames % 8 != 0
+            a = [t.cpu().numpy() for t in pf.run()]
+            a2 = [t.cpu().numpy() for t in pf.run()]
+            os.environ["MAGPHASE_COMP_FUSED"] = "0"
+            ps = CompressedAnalysisPlan(eng, utts, **kw)
+            assert not ps.fused
+            b = [t.cpu().numpy() for t in ps.run()]
+    finally:
+        if old is None:
+            os.environ.pop("MAGPHASE_COMP_FUSED", None)
+        else:
+            os.environ["MAGPHASE_COMP_FUSED"] = old
+    for x, y in zip(a, a2):
+        assert np.array_equal(x, y)
+    floor = b[0] == -1.0e10
+    assert np.array_equal(a[0] == -1.0e10, floor)
+    within(np.max(np.abs(a[0].astype(np.float64) - b[0])[~floor]), 1.5e-5, "FUSED_VS_STAGED:mag")
+    within(max(np.max(np.abs(a[1].astype(np.float64) - b[1])), np.max(np.abs(a[2].astype(np.float64) - b[2]))), 2e-6,
+           "FUSED_VS_STAGED:phase")
+    for u, (x, _fs, pm, voi) in enumerate(utts):
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            ol = orc.analysis_lossless_from_epochs(x, fs, pm, voi)
+            o = orc.format_for_modelling(ol[0], ol[1], ol[2], ol[3], fs, mag_dim=mag_dim, phase_dim=phase_dim,
+                                         alpha_phase=alpha_phase, b_mag_fbank_mel=fbank)
+        s0, s1 = int(pf.out_off[u]), int(pf.out_off[u + 1])
+        assert o[0].shape == (s1 - s0, mag_dim)
+        fl = o[0] == -1.0e10
+        assert np.array_equal(a[0][s0:s1] == -1.0e10, fl)
+        within(np.max(np.abs(a[0][s0:s1] - o[0])[~fl], initial=0.0), WARP_TOL, "WARP_TOL:fused")
+        within(max(np.max(np.abs(a[1][s0:s1] - o[1])), np.max(np.abs(a[2][s0:s1] - o[2]))), WARP_PHASE_TOL, "WARP_PHASE_TOL:fused")
+        if u == 2:
+            assert np.all(a[1][s0:s1] == 0.0) and np.all(a[2][s0:s1] == 0.0)
