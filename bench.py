@@ -216,6 +216,55 @@ def _lowdim_state(em, eng, utts, shared=None):
     return dict(aplan=aplan, splan=splan, feats=feats, out=out, pcm=pcm)
 
 
+def measure_extraction_kernel(eng, utts, live=None, live_src=None, reps=12):
+    """
+    The device part of BASELINE configs[3] on this batch: analysis_compressed at the VARIABLE frame rate, mag_dim 60 /
+    phase_dim 10 (analysis_for_acoustic_modelling's Q7 setting: alpha_phase 0), as ONE fused kernel
+    (mpx_analysis_compressed_fused) and, for comparison, as the staged pair k_analysis_f64 -> k_mel_warp_mfma.
+    Algorithmic bytes: 4 S + 4 (mag_dim + 2 phase_dim + 2) per frame -- samples in, coefficients out.
+    """
+    import torch
+
+    from magphase_amd import engine as em
+
+    out = {"what": "configs[3] extraction kernel(s): 64 x 5 s, variable frame rate, mag 60 / phase 10 (Q7), HIP events, "
+                   "median of %d launches" % (reps - 2)}
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    old = os.environ.get("MAGPHASE_COMP_FUSED")
+    try:
+        for name, flag in (("fused", "1"), ("staged", "0")):
+            os.environ["MAGPHASE_COMP_FUSED"] = flag
+            plan = em.CompressedAnalysisPlan(eng, utts, mag_dim=60, phase_dim=10, alpha_phase=False)
+            res = plan.run()
+            feats = None if plan.fused else tuple(eng.empty_feats(plan.lossless.total_frames, plan.fft_len // 2 + 1) for _ in range(3))
+            ts = []
+            for r in range(reps):
+                e0.record()
+                plan.run(feats=feats, out=res)
+                e1.record()
+                torch.cuda.synchronize()
+                ts.append(e0.elapsed_time(e1))
+            ts = sorted(ts[2:])
+            out[name + "_ms"] = round(ts[len(ts) // 2], 4)
+            if name == "fused":
+                F = plan.lossless.total_frames
+                alg = 4.0 * plan.lossless.total_smpls + 4.0 * (60 + 2 * 10 + 2) * F
+                out.update({"frames": F, "alg_bytes": alg, "alg_bytes_note": "4 S + 4 (60 + 2 x 10 + 2) per frame (SURVEY.md 8d, C4)",
+                            "staged_path_bytes": alg + 2 * 12.0 * (plan.fft_len // 2 + 1) * F})
+            del plan, res, feats
+    finally:
+        if old is None:
+            os.environ.pop("MAGPHASE_COMP_FUSED", None)
+        else:
+            os.environ["MAGPHASE_COMP_FUSED"] = old
+    out["frames_per_s_fused"] = round(out["frames"] / (out["fused_ms"] * 1e-3), 1)
+    if live and "k_analysis_warp_fused" in live:
+        out["hbm_traffic_measured_fused"] = round(live["k_analysis_warp_fused"], 1)
+        out["traffic_over_algorithmic"] = round(live["k_analysis_warp_fused"] / out["alg_bytes"], 3)
+        out["traffic_source"] = live_src
+    return out
+
+
 class _Marks:
     def __init__(self, torch):
         self.torch, self.ev = torch, []
@@ -775,6 +824,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--quick", action="store_true", help="headline only: no configs2 / e2e / CPU baselines")
     ap.add_argument("--no-e2e", action="store_true", help="skip the array-API / file-interface block (profiling runs)")
+    ap.add_argument("--no-power", action="store_true",
+                    help="skip the board-power loops (rocprofv3 --stats runs: their thousands of back-to-back launches of one "
+                         "kernel would dominate its average duration; the steps are what the profile is about)")
     ap.add_argument("--workload", choices=("configs1", "corpus"), default="configs1",
                     help="'corpus' = BASELINE configs[3] + configs[4]: a --utts corpus, LPT-sharded over the ranks "
                          "(tools/corpus_workload.py); the default is the headline configs[1] (+ configs2 / e2e / a corpus shard)")
@@ -944,6 +996,11 @@ def main():
             st["aplan"].run(feats=st["feats"], out=st["out"])
             st["splan"].run(out=st["pcm"])
         torch.cuda.synchronize()
+        del st
+        xp = em.CompressedAnalysisPlan(eng, utts, mag_dim=60, phase_dim=10, alpha_phase=False)   # configs[3]: the fused kernel
+        for _ in range(3):
+            xp.run()
+        torch.cuda.synchronize()
         return
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
@@ -1011,7 +1068,7 @@ def main():
         except Exception as e:
             roof["measured_ceilings"] = {"error": "%s: %s" % (type(e).__name__, e)}
         try:    # board power while each kernel loops: both lossless kernels sit at the device's power cap
-            pw = measure_power(torch, dev_index, (
+            pw = None if args.no_power else measure_power(torch, dev_index, (
                 ("k_analysis", lambda: aplan.run(out=feats)),
                 ("k_synth_ola_pair+k_ola_fixup", lambda: splan.run(feats[0], feats[1], feats[2], strips=strips, out=pcm_out)),
                 ("step", lambda: (aplan.run(out=feats), splan.run(feats[0], feats[1], feats[2], strips=strips, out=pcm_out)))))
@@ -1070,6 +1127,10 @@ def main():
                 out["configs2"] = c2
             except Exception as e:
                 out["configs2"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            try:
+                out["configs3_extraction_kernel"] = measure_extraction_kernel(eng, utts, live=live, live_src=live_src)
+            except Exception as e:
+                out["configs3_extraction_kernel"] = {"error": "%s: %s" % (type(e).__name__, e)}
             if not args.no_e2e:
                 try:
                     out["e2e"] = measure_e2e(utts)

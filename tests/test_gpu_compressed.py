@@ -667,7 +667,7 @@ def test_fused_compressed_analysis_matches_oracle_and_staged_path(orc, fs, mag_d
         assert o[0].shape == (s1 - s0, mag_dim)
         fl = o[0] == -1.0e10
         assert np.array_equal(a[0][s0:s1] == -1.0e10, fl)
-        within(np.max(np.abs(a[0][s0:s1] - o[0])[~fl], initial=0.0), WARP_TOL, "WARP_TOL:fused")
-        within(max(np.max(np.abs(a[1][s0:s1] - o[1])), np.max(np.abs(a[2][s0:s1] - o[2]))), WARP_PHASE_TOL, "WARP_PHASE_TOL:fused")
+        within(np.max(np.abs(a[0][s0:s1] - o[0])[~fl], initial=0.0), 1e-5, "WARP_TOL:fused")          # measured 3.4e-6 (staged: 8e-6)
+        within(max(np.max(np.abs(a[1][s0:s1] - o[1])), np.max(np.abs(a[2][s0:s1] - o[2]))), 2e-6, "WARP_PHASE_TOL:fused")   # measured 6.5e-7
         if u == 2:
             assert np.all(a[1][s0:s1] == 0.0) and np.all(a[2][s0:s1] == 0.0)
