@@ -308,14 +308,21 @@ def extract_features_corpus(wav_files, out_dir, batch_utts=16, fft_len=None, mag
         return out, failed, tickets
 
     def store(res):
+        import time
+
         results, failed, tickets = res
+        t0 = time.perf_counter()
         for t in tickets:
             t.wait()
+        t1 = time.perf_counter()
         try:
             _store(results, failed)
         finally:
             for t in tickets:
                 t.release()
+            if report is not None:   # the writer stage's two parts: waiting for the device's results, writing the files
+                report["store_wait_device_s"] = report.get("store_wait_device_s", 0.0) + t1 - t0
+                report["store_write_files_s"] = report.get("store_write_files_s", 0.0) + time.perf_counter() - t1
 
     def _store(results, failed):
         # float32 from the device as it is (what write_featfile stores); all files of the batch in one native call

@@ -29,6 +29,9 @@ def main():
     ap.add_argument("--wav-dir", default=os.path.join(demo, "wavs_nat"))
     ap.add_argument("--out-dir", default=os.path.join(demo, "params_nat"))
     ap.add_argument("--batch", type=int, default=16, help="utterances per kernel launch (0: one call per file, like the reference)")
+    ap.add_argument("--rank-subdirs", action="store_true",
+                    help="every rank writes into OUT_DIR/rank<r>/ instead of all ranks into OUT_DIR: file creation in ONE "
+                         "directory serialises on its inode lock (tools/file_interface_nproc.py measures it)")
     args = ap.parse_args()
     lu.mkdir(args.out_dir)
     tokens = [str(t) for t in lu.read_text_file2(args.scp, dtype="string", comments="#").tolist()]
@@ -39,6 +42,9 @@ def main():
     sizes = [os.path.getsize(os.path.join(args.wav_dir, t + ".wav")) if os.path.isfile(os.path.join(args.wav_dir, t + ".wav"))
              else 0 for t in tokens]
     mine = sharding.shard_by_cost(sizes, world)[rank]
+    if args.rank_subdirs and world > 1:
+        args.out_dir = os.path.join(args.out_dir, "rank%d" % rank)
+        lu.mkdir(args.out_dir)
     if args.batch > 0:   # reader thread / kernels / writer thread overlapped, args.batch utterances per launch
         rep = iobatch.CorpusReport()
         n = iobatch.extract_features_corpus([os.path.join(args.wav_dir, tokens[i] + ".wav") for i in mine], args.out_dir,

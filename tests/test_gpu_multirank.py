@@ -123,6 +123,19 @@ def test_batch_scripts_two_ranks_write_the_same_files_as_one_process(tmp_path):
     _torchrun(2, [ext, "--scp", scp, "--wav-dir", wav_dir, "--out-dir", p2, "--batch", "2"], {"MAGPHASE_SHARE_DEVICE": "1"})
     feat_names = [t + e for t, _ in toks for e in (".mag", ".real", ".imag", ".lf0", ".shift")]
     _same_files(p1, p2, feat_names)                        # batching and sharding do not change a bit of the features
+    # --rank-subdirs: every rank creates its files in OUT_DIR/rank<r>/ (file creation in one directory serialises on its
+    # lock: tools/file_interface_nproc.py, 8 processes: 20 700 x -> 91 000 x real time); same bytes, every token once
+    p3 = str(tmp_path / "p3")
+    _torchrun(2, [ext, "--scp", scp, "--wav-dir", wav_dir, "--out-dir", p3, "--batch", "2", "--rank-subdirs"],
+              {"MAGPHASE_SHARE_DEVICE": "1"})
+    found = {}
+    for r_ in (0, 1):
+        for n in os.listdir(os.path.join(p3, "rank%d" % r_)):
+            assert n not in found
+            found[n] = os.path.join(p3, "rank%d" % r_, n)
+    assert sorted(found) == sorted(feat_names)
+    for n in feat_names:
+        assert open(found[n], "rb").read() == open(os.path.join(p1, n), "rb").read(), n
     common = ["--scp", scp, "--feats-dir", p1, "--mag-dim", "60", "--phase-dim", "10", "--pf-type", "magphase", "--noise", "device"]
     r = subprocess.run([sys.executable, gen] + common + ["--out-dir", g1, "--batch", "4"], cwd=ROOT, env=env,
                        capture_output=True, text=True, timeout=900)
