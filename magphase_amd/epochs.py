@@ -31,46 +31,6 @@ def _median5(v):
     return np.median(np.lib.stride_tricks.sliding_window_view(vp, 5), axis=1)
 
 
-def _extend_voiced_runs(t_ep, slope, keep, f0_h, fr_of, max_ext=4, max_gap=1.0 / 50.0):
-    """
-    Voicing-boundary hysteresis.  The F0 stage decides voicing on 40 ms correlation frames: the first and last one or two
-    pitch periods of a voiced stretch sit in frames that straddle the boundary and are called unvoiced (8-9 % of all
-    voiced epochs were missed there, profiles/r03_epoch_accuracy.json).  The zero-frequency filter has no such window:
-    its crossings are there.  So every run of kept crossings is grown outwards, crossing by crossing, while the next one
-    continues the run's own rhythm (0.6-1.45 of the period of the run's outermost two epochs; a crossing closer than
-    that is skipped as spurious) with a slope of at least 35 % of the run's edge epochs', at most `max_ext` epochs per side.
-    """
-    keep = keep.copy()
-    n = t_ep.size
-    k_idx = np.flatnonzero(keep)
-    if k_idx.size < 3:
-        return keep
-    # runs of kept crossings (a gap of more than max_gap between kept neighbours starts a new run)
-    brk = np.flatnonzero(np.diff(t_ep[k_idx]) > max_gap)
-    starts = np.r_[0, brk + 1]
-    ends = np.r_[brk, k_idx.size - 1]
-    for a, b in zip(starts, ends):
-        if b - a < 2:
-            continue
-        for side in (-1, 1):
-            e0, e1 = (k_idx[a], k_idx[a + 1]) if side < 0 else (k_idx[b], k_idx[b - 1])
-            period = abs(t_ep[e1] - t_ep[e0])
-            ref_slope = 0.5 * (slope[e0] + slope[e1])
-            cur, added, j = e0, 0, e0 + side
-            while 0 <= j < n and added < max_ext and not keep[j]:
-                d = abs(t_ep[j] - t_ep[cur])
-                if d < 0.6 * period:          # too close: a spurious crossing inside the period
-                    j += side
-                    continue
-                if d > 1.45 * period or slope[j] < 0.35 * ref_slope:
-                    break
-                keep[j] = True
-                period, ref_slope = 0.5 * (period + d), 0.5 * (ref_slope + slope[j])
-                cur, added = j, added + 1
-                j += side
-    return keep
-
-
 def _geometry(fs, hop_s=0.005, win_s=0.040, f_lo=60.0, f_hi=400.0):
     dec = max(1, int(round(fs / 4000.0)))
     fs_d = fs / float(dec)
@@ -186,7 +146,6 @@ def track_epochs_batch(sigs, fs, engine=None, unvoiced_step_s=0.005, nccf_min=0.
         keep = voiced_fr[fr_of] if idx.size else np.zeros(0, dtype=bool)
         if keep.any():
             keep &= slope > 0.15 * np.median(slope[keep])
-            keep = _extend_voiced_runs(t_ep, slope, keep, f0_h, fr_of)
         # the period implied by neighbouring crossings must be plausible for the local F0 (drops spurious crossings)
         t_v = t_ep[keep]
         f_v = f0_h[fr_of[keep]] if idx.size else np.zeros(0)
@@ -194,8 +153,9 @@ def track_epochs_batch(sigs, fs, engine=None, unvoiced_step_s=0.005, nccf_min=0.
             # A crossing much closer to its predecessor than the crossings around it are to theirs is spurious.  The
             # yardstick is the filter's OWN rhythm (median of the seven intervals around it), not the F0 track: where the
             # correlation stage locks onto the double period (an octave error: F0 frames of 73 Hz for a 146 Hz voice),
-            # "closer than half the F0 period" dropped every second epoch of the stretch -- most of round 3's 8 % misses
-            # (tools/_tmp diagnosis: the misses sat in the MIDDLE of voiced runs, with the crossing present and kept).
+            # "closer than half the F0 period" dropped every second epoch of the stretch -- round 3's 8 % misses sat in the
+            # MIDDLE of voiced runs, with the crossing present and kept, not at voicing boundaries.  (Growing the voiced
+            # runs outwards by the filter's crossings was tried as well: no more identified cycles, twice the voicing error.)
             dt = np.diff(t_v)
             pad = np.r_[dt[:3][::-1], dt, dt[-3:][::-1]] if dt.size >= 3 else np.r_[dt, dt, dt, dt, dt, dt, dt][:dt.size + 6]
             local = np.median(np.lib.stride_tricks.sliding_window_view(pad, 7), axis=1)

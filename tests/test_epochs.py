@@ -54,14 +54,14 @@ def test_accuracy_figures_on_synthetic_truth(capsys):
         with capsys.disabled():
             print("\nepoch tracker @ %d Hz, %d utterances, %d true voiced epochs: %s"
                   % (fs, len(rows), int(w.sum()), ", ".join("%s %.4g" % kv for kv in pooled.items())))
-        # measured on MI355X (profiles/r04_epoch_accuracy.json, 64 utterances of 5 s per rate): identification 0.992-0.993,
-        # misses 2-3e-4, false alarms 0.007-0.008, jitter 49-50 us, |bias| 38-120 us, gross F0 errors 1e-4, voicing errors
-        # 0.056-0.061, worst utterance 0.980.  (Round 3: identification 0.905-0.909, misses 8.4-8.8 % -- not at voicing
+        # measured on MI355X (profiles/r04_epoch_accuracy.json, 64 utterances of 5 s per rate): identification 0.991-0.993,
+        # misses 2-8e-4, false alarms 0.007-0.008, jitter 49-50 us, |bias| 38-120 us, gross F0 errors 1e-4, voicing errors
+        # 0.029-0.031, worst utterance 0.980.  (Round 3: identification 0.905-0.909, misses 8.4-8.8 % -- not at voicing
         # boundaries, as believed, but in the middle of voiced stretches whose correlation stage had locked onto the double
         # period: the spacing filter then dropped every second epoch; it now measures against the crossings' own rhythm.)
         assert pooled["identification_rate"] > 0.975 and pooled["miss_rate"] < 0.01 and pooled["false_alarm_rate"] < 0.02
         assert pooled["jitter_us"] < 120.0 and abs(pooled["bias_us"]) < 200.0
-        assert pooled["gross_f0_error_rate"] < 0.005 and pooled["voicing_error_rate"] < 0.10
+        assert pooled["gross_f0_error_rate"] < 0.005 and pooled["voicing_error_rate"] < 0.06
 
 
 def test_corpus_pipeline_with_builtin_tracker_matches_sequential(tmp_path, monkeypatch):
