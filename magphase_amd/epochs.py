@@ -159,7 +159,11 @@ def track_epochs_batch(sigs, fs, engine=None, unvoiced_step_s=0.005, nccf_min=0.
             dt = np.diff(t_v)
             pad = np.r_[dt[:3][::-1], dt, dt[-3:][::-1]] if dt.size >= 3 else np.r_[dt, dt, dt, dt, dt, dt, dt][:dt.size + 6]
             local = np.median(np.lib.stride_tricks.sliding_window_view(pad, 7), axis=1)
-            local = np.minimum(local, 1.0 / np.maximum(f_v[1:], 50.0))      # never longer than the F0 track's period
+            p_f0 = 1.0 / np.maximum(f_v[1:], 50.0)
+            # (never longer than the F0 track's period; never shorter than half of it -- an octave error at worst -- so
+            # that the noise crossings the correlation stage's 40 ms frames let through next to a voiced stretch, which
+            # have no rhythm of their own, are still thinned out)
+            local = np.maximum(np.minimum(local, p_f0), 0.5 * p_f0)
             good = np.ones(t_v.size, dtype=bool)
             good[1:][dt < 0.5 * local] = False
             t_v = t_v[good]
