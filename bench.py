@@ -1080,10 +1080,30 @@ def main():
         except Exception as e:
             roof["measured_ceilings"] = {"error": "%s: %s" % (type(e).__name__, e)}
         try:    # board power while each kernel loops: both lossless kernels sit at the device's power cap
+            from magphase_amd import _lib as _l
+
+            n_pr = 1 << 28   # the streaming probes too: what a GB read / written costs on this board (pJ per byte)
+            pa, pb = eng.empty((n_pr,)), eng.empty((n_pr,))
+            pa.zero_(), pb.zero_()
+            ceil_ = roof.get("measured_ceilings", {})
+
+            def probe(kind):
+                shapes = ceil_.get(("read", "write", "copy")[kind] + "_GBps_by_shape")
+                shape = int(np.argmax(shapes)) if shapes else 0
+                return lambda: _l.check(eng.lib.mpx_bw_probe(eng.stream_ptr(), kind + 16 * shape, pa.data_ptr(), pb.data_ptr(), n_pr),
+                                        "mpx_bw_probe")
+
             pw = None if args.no_power else measure_power(torch, dev_index, (
                 ("k_analysis", lambda: aplan.run(out=feats)),
                 ("k_synth_ola_pair+k_ola_fixup", lambda: splan.run(feats[0], feats[1], feats[2], strips=strips, out=pcm_out)),
-                ("step", lambda: (aplan.run(out=feats), splan.run(feats[0], feats[1], feats[2], strips=strips, out=pcm_out)))))
+                ("step", lambda: (aplan.run(out=feats), splan.run(feats[0], feats[1], feats[2], strips=strips, out=pcm_out))),
+                ("probe_read_1GiB", probe(0)), ("probe_fill_1GiB", probe(1)), ("probe_copy_1GiB", probe(2))))
+            del pa, pb
+            if pw is not None:
+                for nm, nb in (("probe_read_1GiB", 4.0 * n_pr), ("probe_fill_1GiB", 4.0 * n_pr), ("probe_copy_1GiB", 8.0 * n_pr)):
+                    ph = pw["phases"].get(nm, {})
+                    if "energy_above_idle_J" in ph:
+                        ph["pJ_per_byte_above_idle"] = round(ph["energy_above_idle_J"] / nb * 1e12, 1)
             if pw is not None:
                 roof["power"] = pw
                 roof["power_note"] = ("a launch at the cap lasts energy / (cap - idle) whatever its memory rate: the 8 TB/s "
