@@ -512,9 +512,9 @@ def measure_e2e(utts):
     try:    # the extraction batch path under EIGHT processes (all on this device: a 1-GPU box), files inside the clock
         import file_interface_nproc
 
-        r8 = file_interface_nproc.run(procs=8, n_utt=int(os.environ.get("BENCH_NPROC_UTTS", 1024)), share_device=True, reps=3)
-        r1 = file_interface_nproc.run(procs=1, n_utt=int(os.environ.get("BENCH_NPROC_UTTS", 1024)), share_device=True, reps=3,
-                                      layouts=("one_directory",))
+        n8 = int(os.environ.get("BENCH_NPROC_UTTS", 1024))
+        r1 = file_interface_nproc.run(procs=1, n_utt=n8, share_device=True, reps=3, layouts=("one_directory",))
+        r8 = file_interface_nproc.run(procs=8, n_utt=n8, share_device=True, reps=3)
         out["file_interface_8proc"] = dict(r8, one_process_same_corpus=r1["one_directory"],
                                            note="8 ranks creating 5 files per utterance in ONE directory serialise on its lock; "
                                                 "--rank-subdirs of scripts/batch_feature_extraction_for_tts.py (one "
