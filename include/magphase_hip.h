@@ -109,6 +109,8 @@ int mpx_analysis_compressed_fused(void* stream, int fft_len, const void* tables_
 int mpx_analysis_compressed_fused_tiles(int32_t mag_dim, int32_t phase_dim, int32_t* ntm, int32_t* ntp);
 /* waves per workgroup = frames per round = K slices the packed weights are cut into (pack_warp_fused's n_waves) */
 int mpx_analysis_compressed_fused_waves(void);
+/* resident workgroups per CU of the fused kernel (the runtime's occupancy query), < 0 on error: diagnostics */
+int mpx_analysis_compressed_fused_blocks_per_cu(int fft_len, int32_t phase_dim);
 
 /*
  * Row pitch (in floats) the lossless feature matrices should be allocated with.  Any ld >= H is CORRECT for every

@@ -446,6 +446,9 @@ __global__ __launch_bounds__(kFusedWaves * 64) void k_analysis_warp_fused(
         f32x4_t acc[T];
 #pragma unroll
         for (int t = 0; t < T; ++t) acc[t] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
+#ifdef MPX_FUSED_PRIO   // the GEMM phase above the other workgroup's transform phase on the same SIMD (an MFMA needs one issue
+        __builtin_amdgcn_s_setprio(MPX_FUSED_PRIO);   // slot per 32 cycles; losing it to the elder wave's VALU stream stalls the round)
+#endif
 #pragma unroll
         for (int q = 0; q < P / 2; ++q) {
             float* tile = As + (q & 1) * (3 * kFusedWaves * kFusedAStride);
@@ -498,6 +501,9 @@ __global__ __launch_bounds__(kFusedWaves * 64) void k_analysis_warp_fused(
 #pragma unroll
             for (int t = 0; t < T; ++t) acc[t] += ca[t];
         }
+#ifdef MPX_FUSED_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         __syncthreads();   // every wave is done with the tiles and its transpose buffer: `red` may overwrite them
 #pragma unroll
         for (int t = 0; t < T; ++t)
@@ -668,6 +674,28 @@ int mpx_analysis_compressed_fused_tiles(int32_t mag_dim, int32_t phase_dim, int3
     return MPX_OK;
 }
 
-int mpx_analysis_compressed_fused_waves(void) { return kFusedWaves; }   // frames per round = K slices of the packed weights
+int mpx_analysis_compressed_fused_waves(void) { return kFusedWaves; }
+
+// resident workgroups per CU of the fused kernel for (fft_len, phase_dim) as the runtime's occupancy query sees them, or < 0
+int mpx_analysis_compressed_fused_blocks_per_cu(int fft_len, int32_t phase_dim) {
+    const int P = p_of(fft_len);
+    if ((P != 32 && P != 16) || phase_dim <= 0 || phase_dim > 48) return MPX_ERR_ARG;
+    const int ntp = (phase_dim + 15) / 16;
+    int nb = -1;
+#define MPX_FUSED_OCC(PP, NTP_)                                                                                       \
+    do {                                                                                                              \
+        if (set_lds(k_analysis_warp_fused<PP, 4, NTP_, 0>, (lds_bytes_fused<PP, 4, NTP_>()))) return -1;              \
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_analysis_warp_fused<PP, 4, NTP_, 0>, kFusedWaves * 64, \
+                                                         (lds_bytes_fused<PP, 4, NTP_>())) != hipSuccess)             \
+            return -1;                                                                                                \
+    } while (0)
+    if (P == 32) {
+        if (ntp == 1) MPX_FUSED_OCC(32, 1); else if (ntp == 2) MPX_FUSED_OCC(32, 2); else MPX_FUSED_OCC(32, 3);
+    } else {
+        if (ntp == 1) MPX_FUSED_OCC(16, 1); else if (ntp == 2) MPX_FUSED_OCC(16, 2); else MPX_FUSED_OCC(16, 3);
+    }
+#undef MPX_FUSED_OCC
+    return nb;
+}   // frames per round = K slices of the packed weights
 
 }  // extern "C"
