@@ -278,14 +278,16 @@ class _Marks:
         return [(n1, e0.elapsed_time(e1)) for (_n0, e0), (n1, e1) in zip(self.ev[:-1], self.ev[1:])]
 
 
-def pick_streams(n, enqueue, steps=24, tries=6):
+def pick_streams(n, enqueue, steps=24, tries=1):
     """
     n HIP streams that really run side by side.  HIP multiplexes its streams onto a few hardware queues (4 by default) and
     two streams that land on the same queue serialise (tools/stream_pair_probe.py: of the pairs among 8 streams about one
     in four does) -- which streams share a queue is not something the API tells.  So: time `steps` steps on one stream,
     then draw streams until alternating between the candidate and EVERY chosen stream is faster than one stream alone
     (two streams on one queue: 3-4 % slower than one stream; on two queues: 0.5-6 % faster, depending on the box); if none
-    is after `tries` draws, the best candidate is taken.
+    is after `tries` draws, the best candidate is taken.  Since round 4 `tries` is 1: the FIRST pair of fresh streams is
+    used whatever it measures (12 of 12 fresh pairs overlapped on the round-4 boxes, tools/_tmp/stream_prio.py; a benchmark
+    should not re-draw its own configuration) -- the probe only REPORTS whether the pair overlaps (`stream_pick`).
     enqueue(stream, k): enqueue one step on `stream` with buffer set k.  Returns (streams, report).
     """
     import torch
