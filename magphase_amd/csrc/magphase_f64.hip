@@ -17,13 +17,18 @@
 namespace mpx {
 
 constexpr int kAna64Waves = 8;
+// floats of LDS per wave for the frame's two half windows (f64_frame_transform): 928 doubles for N = 4096, in proportion for
+// the shorter transforms (their sample rates have proportionally shorter pitch periods)
+template <int P>
+constexpr int f64_win_floats() { return 58 * P; }
 #ifndef MPX_F64_DIT
 #define MPX_F64_DIT 1   // the transform in the DIT form (fft_inreg_dit_f64: 136 fewer float64 instructions per frame); 0: DIF
 #endif
 constexpr bool kF64Dit = MPX_F64_DIT != 0;
 template <int P>
 constexpr size_t lds_bytes_ana64() {
-    return sizeof(double) * (size_t)tw64_doubles<P>() + sizeof(float) * (size_t)(kAna64Waves * P * kXStride + 4);   // + frame queue
+    return sizeof(double) * (size_t)tw64_doubles<P>() +
+           sizeof(float) * (size_t)(kAna64Waves * P * kXStride + 4 + kAna64Waves * f64_win_floats<P>());   // + frame queue + window regions
 }
 
 // sin(x), |x| <= pi/2: Taylor polynomial to x^17 (remainder (pi/2)^19 / 19! = 4e-14)
@@ -88,8 +93,9 @@ __device__ __forceinline__ constexpr int f64_out_reg(int q) { return kF64Dit ? q
 template <int P>
 __device__ __forceinline__ void f64_frame_transform(const float* __restrict__ sig, long long pos, int Lf, int Rf,
                                                     const double* __restrict__ win_tab, int win_cap, const double* tw,
-                                                    float* xbuf, unsigned xbuf_byte, int lane, double (&re)[P],
-                                                    double (&im)[P], double& zero2_out, float& mag_scale_out) {
+                                                    float* xbuf, unsigned xbuf_byte, float* wbuf, unsigned wbuf_byte,
+                                                    int lane, double (&re)[P], double (&im)[P], double& zero2_out,
+                                                    float& mag_scale_out) {
     constexpr int N = 128 * P, kTile = 64 * P;
     const FrameGeom g = frame_geom(sig, pos, Lf, Rf, N);
     const double invL = (g.L > 0) ? 1.0 / (double)g.L : 1.0;
@@ -104,48 +110,84 @@ __device__ __forceinline__ void f64_frame_transform(const float* __restrict__ si
     const bool tabw = rfl((int)(win_tab != nullptr && g.L <= win_cap && gR <= win_cap)) != 0;
     const double* tl = win_tab + ((long long)g.L * (g.L + 1) >> 1);
     const double* tr = win_tab + ((long long)gR * (gR + 1) >> 1);
-    auto weight = [&](int k) -> double {
-        if (tabw) return (k <= g.L) ? tl[k] : tr[g.LR - k];
-        return hann_half_f64(k, g.L, g.LR, g.kadd, invL, invR);
-    };
     // The table path scales the frame by 2^30 (exact: a power of two changes no mantissa anywhere in the transform), so
     // that a residue of 2^-53 x amplitude squares to a normal float for the reciprocal square root's fp32 seed; the
     // magnitude is scaled back after its conversion to float32 (exact as well).
     const float in_scale = tabw ? 1073741824.0f : 1.0f;
     const float mag_scale = tabw ? 9.313225746154785e-10f : 1.0f;
 
-    // ---- samples HBM -> LDS (fp32: the PCM is exact in float32), window in float64 while gathering in FFT order
+    // ---- samples HBM -> LDS (fp32: the PCM is exact in float32), window in float64 while gathering in FFT order.
+    // The window goes through LDS as well: the frame's weights, index i = k on the rising half (k <= L) and
+    // i = L + 1 + (LR - k) on the falling one, are laid out in this wave's window region `wbuf` -- copied from the table
+    // by global_load_lds_dword (no registers; lanes past a half's end are switched off, the copy honours EXEC) or
+    // evaluated by ONE compact loop -- and the unrolled gather below reads them with ds_read_b64.  With the weights
+    // evaluated / loaded from global memory inside the unrolled gather (64 copies of the polynomial or of the table
+    // branches) the kernel had grown from 8 300 to 12 300 instructions, past the instruction cache, and from 0.45 to
+    // 0.61 ms.  Windows longer than the region (L + R > 926 samples at N = 4096: F0 below 52 Hz) take several passes.
     double s_abs = 0.0;   // this lane's share of sum |windowed sample|: the scale of the transform's rounding noise
 #pragma unroll
     for (int j = 0; j < P; ++j) re[j] = im[j] = 0.0;
+    constexpr int capD = f64_win_floats<P>() / 2;                    // doubles per window region
+    double* wl = reinterpret_cast<double*>(wbuf);
+    const int nidx = g.LR + 2;                                       // weights of the frame
     const int ntiles = (g.len + kTile - 1) / kTile;   // 1 except for frames longer than 64 P samples (Q19)
     for (int t = 0; t < ntiles; ++t) {
         const int tile0 = t * kTile;
         const int hi = min(g.len, tile0 + kTile);
         stage_samples_async(g, tile0, kTile, xbuf_byte, lane);
-        staged_wait<0>();
-        wave_sync();
-        // the window weights depend on this copy of the lane id: the compiler cannot evaluate them (2 x 64 doubles)
-        // ahead of the copy and spill them
-        int lane_g = lane;
-        asm volatile("" : "+v"(lane_g));
-#pragma unroll
-        for (int j = 0; j < P; ++j) {
-            const int m0 = 128 * j;
-            // buffer index m holds windowed sample k = (m + rot) mod N, valid iff k < len
-            const bool any = (m0 < g.len - g.rot) || (m0 + 127 >= N - g.rot);
-            if (any) {
-                const int m = m0 + 2 * lane_g;
-                int k0 = m + g.rot;
-                k0 = (k0 >= N) ? k0 - N : k0;
-                int k1 = m + 1 + g.rot;
-                k1 = (k1 >= N) ? k1 - N : k1;
-                if (k0 >= tile0 && k0 < hi) re[f64_in_reg<P>(j)] = (double)(xbuf[k0 - tile0] * in_scale) * weight(k0);
-                if (k1 >= tile0 && k1 < hi) im[f64_in_reg<P>(j)] = (double)(xbuf[k1 - tile0] * in_scale) * weight(k1);
-                s_abs += fabs(re[f64_in_reg<P>(j)]) + fabs(im[f64_in_reg<P>(j)]);
+        for (int seg0 = 0; seg0 < nidx; seg0 += capD) {
+            const int seg1 = min(seg0 + capD, nidx);
+            if (tabw) {
+                // rising half: indices [seg0, min(L + 1, seg1)) from tl; falling half: [max(L + 1, seg0), seg1) from tr
+                const int a0 = seg0, a1 = min(g.L + 1, seg1), b0 = max(g.L + 1, seg0), b1 = seg1;
+                const float* srcl = reinterpret_cast<const float*>(tl + a0);
+                const float* srcr = reinterpret_cast<const float*>(tr + (b0 - (g.L + 1)));
+                const int nl = 2 * max(a1 - a0, 0), nr = 2 * max(b1 - b0, 0);   // dwords
+                for (int c = 0; c < (nl + 63) >> 6; ++c) {
+                    const unsigned m0v = __builtin_amdgcn_readfirstlane(wbuf_byte + 256u * (unsigned)c);
+                    if (64 * c + lane < nl) {
+                        const float* src = srcl + 64 * c + lane;
+                        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(src), "s"(m0v) : "m0", "memory");
+                    }
+                }
+                for (int c = 0; c < (nr + 63) >> 6; ++c) {
+                    const unsigned m0v = __builtin_amdgcn_readfirstlane(wbuf_byte + 8u * (unsigned)(b0 - seg0) + 256u * (unsigned)c);
+                    if (64 * c + lane < nr) {
+                        const float* src = srcr + 64 * c + lane;
+                        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(src), "s"(m0v) : "m0", "memory");
+                    }
+                }
+            } else {
+                for (int i = seg0 + lane; i < seg1; i += 64) {
+                    const int k = (i <= g.L) ? i : g.LR - (i - (g.L + 1));
+                    wl[i - seg0] = hann_half_f64(k, g.L, g.LR, g.kadd, invL, invR);
+                }
             }
+            staged_wait<0>();
+            wave_sync();
+            // the gather depends on this copy of the lane id: the compiler cannot start it ahead of the copies
+            int lane_g = lane;
+            asm volatile("" : "+v"(lane_g));
+#pragma unroll
+            for (int j = 0; j < P; ++j) {
+                const int m0 = 128 * j;
+                // buffer index m holds windowed sample k = (m + rot) mod N, valid iff k < len
+                const bool any = (m0 < g.len - g.rot) || (m0 + 127 >= N - g.rot);
+                if (any) {
+                    const int m = m0 + 2 * lane_g;
+                    int k0 = m + g.rot;
+                    k0 = (k0 >= N) ? k0 - N : k0;
+                    int k1 = m + 1 + g.rot;
+                    k1 = (k1 >= N) ? k1 - N : k1;
+                    const int i0 = ((k0 <= g.L) ? k0 : g.L + 1 + (g.LR - k0)) - seg0;
+                    const int i1 = ((k1 <= g.L) ? k1 : g.L + 1 + (g.LR - k1)) - seg0;
+                    if (k0 >= tile0 && k0 < hi && i0 >= 0 && i0 < capD) re[f64_in_reg<P>(j)] = (double)(xbuf[k0 - tile0] * in_scale) * wl[i0];
+                    if (k1 >= tile0 && k1 < hi && i1 >= 0 && i1 < capD) im[f64_in_reg<P>(j)] = (double)(xbuf[k1 - tile0] * in_scale) * wl[i1];
+                    s_abs += fabs(re[f64_in_reg<P>(j)]) + fabs(im[f64_in_reg<P>(j)]);
+                }
+            }
+            wave_sync();
         }
-        wave_sync();
     }
     float s_all = (float)s_abs;   // a scale: float is plenty
 #pragma unroll
@@ -197,6 +239,8 @@ __global__ __launch_bounds__(kAna64Waves * 64) void k_analysis_f64(const float* 
         tw[i] = tw_g[src];
     }
     unsigned* queue = reinterpret_cast<unsigned*>(xbase + kAna64Waves * (P * kXStride));
+    float* wbuf = xbase + kAna64Waves * (P * kXStride) + 4 + wave * f64_win_floats<P>();   // this wave's window region
+    const unsigned wbuf_byte = 8u * (unsigned)tw64_doubles<P>() + 4u * (unsigned)(kAna64Waves * (P * kXStride) + 4 + wave * f64_win_floats<P>());
     if (threadIdx.x == 0) *queue = 0u;
     __syncthreads();
 
@@ -217,7 +261,8 @@ __global__ __launch_bounds__(kAna64Waves * 64) void k_analysis_f64(const float* 
         double re[P], im[P];
         double zero2;
         float mag_scale;
-        f64_frame_transform<P>(sig, fpos[f], fleft[f], fright[f], win_tab, win_cap, tw, xbuf, xbuf_byte, lane, re, im, zero2, mag_scale);
+        f64_frame_transform<P>(sig, fpos[f], fleft[f], fright[f], win_tab, win_cap, tw, xbuf, xbuf_byte, wbuf, wbuf_byte, lane, re,
+                               im, zero2, mag_scale);
 
         // ---- real-FFT split, one (k, M-k) bin pair per step q (see k_analysis): lane kappa owns k = kappa + 64 q
         // (register brev(q)); Z[M-k] lives in lane (64-kappa)&63, register P-1-i (kappa == 0: own register of bin
@@ -318,10 +363,14 @@ __device__ __forceinline__ float fused_prologue_phase(float x) { return fmaf(1.0
 
 template <int P, int NTM, int NTP>
 constexpr size_t lds_bytes_fused() {
+    // [twiddles][transpose buffers][window regions, whose head doubles as the published tiles][bin M/2 values]; the round's
+    // reduction buffer aliases the transpose buffers and the window regions
+    static_assert(kFusedWaves * f64_win_floats<P>() >= 2 * 3 * kFusedWaves * kFusedAStride, "the tiles live inside the window regions");
     constexpr size_t tiles = NTM + NTP;
-    constexpr size_t work = sizeof(float) * (size_t)(kFusedWaves * P * kXStride + 2 * 3 * kFusedWaves * kFusedAStride);
+    constexpr size_t work = sizeof(float) * (size_t)(kFusedWaves * P * kXStride + kFusedWaves * f64_win_floats<P>());
     constexpr size_t red = sizeof(float) * (size_t)(kFusedWaves * tiles * 4 * 64);
-    return sizeof(double) * (size_t)tw64_doubles<P>() + (work > red ? work : red) + sizeof(float) * 32;
+    static_assert(work >= red, "the reduction buffer must fit the regions it aliases");
+    return sizeof(double) * (size_t)tw64_doubles<P>() + work + sizeof(float) * 32;
 }
 
 template <int P, int NTM, int NTP, int MAGMODE>
@@ -343,11 +392,11 @@ __global__ __launch_bounds__(kFusedWaves * 64) void k_analysis_warp_fused(
     const int wave = rfl((int)(threadIdx.x >> 6));
     float* xbuf = xbase + wave * (P * kXStride);
     const unsigned xbuf_byte = 8u * (unsigned)tw64_doubles<P>() + 4u * (unsigned)(wave * (P * kXStride));
-    float* As = xbase + kFusedWaves * (P * kXStride);          // [2][3][8][kFusedAStride]
-    float* red = xbase;                                         // round end: aliases the transpose buffers (and As)
-    constexpr size_t kWork = (size_t)(kFusedWaves * P * kXStride + 2 * 3 * kFusedWaves * kFusedAStride);
-    constexpr size_t kRed = (size_t)(kFusedWaves * T * 4 * 64);
-    float* mid = xbase + (kWork > kRed ? kWork : kRed);         // [3][8]: bin M/2 of every frame of the round
+    float* As = xbase + kFusedWaves * (P * kXStride);          // [2][3][8][kFusedAStride]: the head of the window regions
+    float* wbuf = As + wave * f64_win_floats<P>();                    // phase A: this wave's two half windows (f64_frame_transform)
+    const unsigned wbuf_byte = 8u * (unsigned)tw64_doubles<P>() + 4u * (unsigned)(kFusedWaves * (P * kXStride) + wave * f64_win_floats<P>());
+    float* red = xbase;                                         // round end: aliases the transpose buffers (and the windows)
+    float* mid = xbase + kFusedWaves * (P * kXStride) + kFusedWaves * f64_win_floats<P>();   // [3][8]: bin M/2 of the round's frames
     for (int i = threadIdx.x; i < tw64_doubles<P>(); i += kFusedWaves * 64) {
         const int l = i / tw64_stride<P>(), c = i - l * tw64_stride<P>();
         const int src = (kF64Dit && c < 2 * P) ? l * tw64_stride<P>() + 2 * brev(c >> 1, LB) + (c & 1) : i;
@@ -375,8 +424,8 @@ __global__ __launch_bounds__(kFusedWaves * 64) void k_analysis_warp_fused(
         float mag_scale = 1.0f;
         bool voi = false;
         if (has) {
-            f64_frame_transform<P>(sig, fpos[f], fleft[f], fright[f], win_tab, win_cap, tw, xbuf, xbuf_byte, lane, re, im, zero2,
-                                   mag_scale);
+            f64_frame_transform<P>(sig, fpos[f], fleft[f], fright[f], win_tab, win_cap, tw, xbuf, xbuf_byte, wbuf, wbuf_byte, lane,
+                                   re, im, zero2, mag_scale);
             voi = rfl((int)(voiced[f] != 0.0f)) != 0;
         } else {
 #pragma unroll
@@ -446,6 +495,7 @@ __global__ __launch_bounds__(kFusedWaves * 64) void k_analysis_warp_fused(
         f32x4_t acc[T];
 #pragma unroll
         for (int t = 0; t < T; ++t) acc[t] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
+        __syncthreads();   // the tiles overlay the other waves' window regions: every wave must be through its gather
 #ifdef MPX_FUSED_PRIO   // the GEMM phase above the other workgroup's transform phase on the same SIMD (an MFMA needs one issue
         __builtin_amdgcn_s_setprio(MPX_FUSED_PRIO);   // slot per 32 cycles; losing it to the elder wave's VALU stream stalls the round)
 #endif
