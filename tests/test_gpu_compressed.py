@@ -671,3 +671,29 @@ def test_fused_compressed_analysis_matches_oracle_and_staged_path(orc, fs, mag_d
         within(max(np.max(np.abs(a[1][s0:s1] - o[1])), np.max(np.abs(a[2][s0:s1] - o[2]))), 2e-6, "WARP_PHASE_TOL:fused")   # measured 6.5e-7
         if u == 2:
             assert np.all(a[1][s0:s1] == 0.0) and np.all(a[2][s0:s1] == 0.0)
+
+
+def test_float64_front_end_with_windows_longer_than_its_lds_region(orc):
+    """Very low pitch / sparse epochs: half windows of 1 400 - 9 600 samples do not fit a wave's window region (928 doubles) and
+    take several passes; frames longer than fft_len are truncated like the reference's (magphase.py:311-315).  Fused kernel and
+    staged float64 analysis against the oracle."""
+    from magphase_amd.engine import CompressedAnalysisPlan, LosslessAnalysisPlan, get_engine
+    fs = 48000
+    x = np.round(np.random.RandomState(1).uniform(-0.3, 0.3, 60000) * 32768.0) / 32768.0   # 16-bit PCM: exact in float32
+    pm = np.array([0.02, 0.05, 0.09, 0.20, 0.2002, 0.26, 0.40, 0.47, 0.48, 0.60, 0.75, 0.95, 1.0, 1.1, 1.2])
+    voi = np.ones_like(pm)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ol = orc.analysis_lossless_from_epochs(x, fs, pm, voi)
+        o = orc.format_for_modelling(ol[0], ol[1], ol[2], ol[3], fs, mag_dim=60, phase_dim=45)
+        p = CompressedAnalysisPlan(get_engine(), [(x, fs, pm, voi)], mag_dim=60, phase_dim=45)
+        assert p.fused
+        a = [t.cpu().numpy() for t in p.run()]
+        lp = LosslessAnalysisPlan(get_engine(), [(x, fs, pm, voi)])
+        m, r, i = (t.cpu().numpy() for t in lp.run(precise=True))
+    within(np.max(np.abs(a[0] - o[0])), WARP_TOL, "WARP_TOL:long_frames")
+    within(max(np.max(np.abs(a[1] - o[1])), np.max(np.abs(a[2] - o[2]))), WARP_PHASE_TOL, "WARP_PHASE_TOL:long_frames")
+    peak = ol[0].max(axis=1, keepdims=True)
+    ok = ol[0] > 1e-9 * peak
+    within(np.max((np.abs(m - ol[0]) / np.maximum(ol[0], 1e-300))[ok]), 1.2e-7, "F64_MAG_REL:long_frames")
+    within(max(np.max(np.abs(r - ol[1])[ok]), np.max(np.abs(i - ol[2])[ok])), 6e-8, "F64_PHASE_ABS:long_frames")
