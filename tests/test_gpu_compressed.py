@@ -691,8 +691,8 @@ def test_float64_front_end_with_windows_longer_than_its_lds_region(orc):
         a = [t.cpu().numpy() for t in p.run()]
         lp = LosslessAnalysisPlan(get_engine(), [(x, fs, pm, voi)])
         m, r, i = (t.cpu().numpy() for t in lp.run(precise=True))
-    within(np.max(np.abs(a[0] - o[0])), WARP_TOL, "WARP_TOL:long_frames")
-    within(max(np.max(np.abs(a[1] - o[1])), np.max(np.abs(a[2] - o[2]))), WARP_PHASE_TOL, "WARP_PHASE_TOL:long_frames")
+    within(np.max(np.abs(a[0] - o[0])), 2.5e-6, "WARP_TOL:long_frames")            # white noise: no weak bins; measured 8.2e-7
+    within(max(np.max(np.abs(a[1] - o[1])), np.max(np.abs(a[2] - o[2]))), 8e-7, "WARP_PHASE_TOL:long_frames")   # measured 2.7e-7
     peak = ol[0].max(axis=1, keepdims=True)
     ok = ol[0] > 1e-9 * peak
     within(np.max((np.abs(m - ol[0]) / np.maximum(ol[0], 1e-300))[ok]), 1.2e-7, "F64_MAG_REL:long_frames")
