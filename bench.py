@@ -286,7 +286,7 @@ def pick_streams(n, enqueue, steps=24, tries=1):
     then draw streams until alternating between the candidate and EVERY chosen stream is faster than one stream alone
     (two streams on one queue: 3-4 % slower than one stream; on two queues: 0.5-6 % faster, depending on the box); if none
     is after `tries` draws, the best candidate is taken.  Since round 4 `tries` is 1: the FIRST pair of fresh streams is
-    used whatever it measures (12 of 12 fresh pairs overlapped on the round-4 boxes, tools/_tmp/stream_prio.py; a benchmark
+    used whatever it measures (12 of 12 fresh pairs overlapped on the round-4 boxes, tools/stream_priority_probe.py; a benchmark
     should not re-draw its own configuration) -- the probe only REPORTS whether the pair overlaps (`stream_pick`).
     enqueue(stream, k): enqueue one step on `stream` with buffer set k.  Returns (streams, report).
     """
