@@ -21,8 +21,8 @@ import magphase_oracle as orc  # noqa: E402
 from magphase_amd import magphase as mp, synthetic as syn  # noqa: E402
 
 # bounds of the sweep (random coefficient counts, rates, options): the magnitude bound is the looser "fuzz" one of
-# tests/test_gpu_compressed.py (worst seen in 340 batches: 4.1e-5); phases 9.7e-7, PCM 6.4e-7 of peak
-WARP_TOL, WARP_PHASE_TOL, COMP_PCM_TOL, LOSSLESS_TOL = 1e-4, 3e-6, 3e-6, 2e-6
+# tests/test_gpu_compressed.py (round 4, 150 batches: worst 6.5e-6 -- 4.1e-5 in round 3, before the fused kernel and numpy's window weights); phases 8.3e-7, PCM 7.3e-7 of peak
+WARP_TOL, WARP_PHASE_TOL, COMP_PCM_TOL, LOSSLESS_TOL = 2.5e-5, 3e-6, 3e-6, 2e-6
 LIMITS = {"mag": WARP_TOL, "phase": WARP_PHASE_TOL, "pcm": COMP_PCM_TOL, "lossless_feat": LOSSLESS_TOL,
           "lossless_pcm": LOSSLESS_TOL}
 MAX_UTTS = int(os.environ.get("FUZZ_UTTS", "4"))
