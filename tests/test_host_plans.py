@@ -316,3 +316,19 @@ def test_weighted_slot_shares_native_equals_numpy():
     assert np.array_equal(r1["frame_begin"][1:], r1["frame_end"][:-1])
     per_slot = np.array([sum(int(r1["frame_end"][k] - r1["frame_begin"][k]) for k in sr1[so1[s]:so1[s + 1]]) for s in range(n_slots)])
     assert per_slot[0] > per_slot[-1] and per_slot.sum() == sum(sizes)
+
+
+def test_hann_half_table_layout_matches_the_references_window():
+    """hostmath.hann_half_table (what mpx_analysis_frames_f64w / mpx_analysis_compressed_fused read): half length h at offset
+    h (h + 1) / 2, entries np.hanning(2 h + 1)[0 .. h] -- from which a frame's window is assembled exactly as the reference
+    does (libaudio.py:70-84: rising half of the left window, flipped rising half of the right one)."""
+    from oracle import magphase_oracle as orc
+    cap = 300
+    tab = hm.hann_half_table(cap)
+    assert tab.size == (cap + 1) * (cap + 2) // 2 and tab[0] == 1.0          # np.hanning(1) == [1.0]
+    for left, right in ((0, 5), (7, 0), (1, 1), (123, 300), (300, 299), (17, 64)):
+        tl = tab[left * (left + 1) // 2:][:left + 1]
+        tr = tab[right * (right + 1) // 2:][:right + 1]
+        k = np.arange(left + right + 1)
+        w = np.where(k <= left, tl[np.minimum(k, left)], tr[np.clip(left + right - k, 0, right)])   # the kernels' indexing
+        assert np.array_equal(w, orc.half_windows(left, right)), (left, right)
