@@ -523,7 +523,7 @@ def measure_e2e(utts):
                                                 "(one_directory = scripts/batch_feature_extraction_for_tts.py --direct); the "
                                                 "script's multi-rank default writes into OUT/.rank<r>/ and moves the files up "
                                                 "at the end (stage_then_rename: the reference's final layout); --rank-subdirs "
-                                                "keeps one subdirectory per rank; medians of 3 runs with os.sync() before each")
+                                                "keeps one subdirectory per rank; best of 3 runs (all listed) with os.sync() before each")
     except Exception as e:
         out["file_interface_8proc"] = {"error": "%s: %s" % (type(e).__name__, e)}
     return out
