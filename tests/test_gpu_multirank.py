@@ -77,6 +77,20 @@ def test_bench_launches_its_own_ranks():
     assert j["n_gpus"] == 2 and j["scaling"] == "strong"
 
 
+def test_bench_falls_back_to_gloo_when_rccl_cannot_initialise():
+    """Two ranks on ONE device with the default backend: RCCL refuses ("duplicate GPU": ncclInvalidUsage) -- nothing on the
+    data path needs it, so the run carries on over gloo instead of dying (multi-GPU weak points)."""
+    env = dict(os.environ, BENCH_SHARE_DEVICE="1", OMP_NUM_THREADS="4")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "BENCH_DIST_BACKEND"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--steps", "5", "--warmup", "2", "--quick"], cwd=ROOT,
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "falling back to gloo" in r.stderr
+    j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["n_gpus"] == 2
+
+
 def test_bench_refuses_more_ranks_than_devices():
     env = dict(os.environ)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "BENCH_SHARE_DEVICE"):
