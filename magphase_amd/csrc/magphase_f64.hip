@@ -343,8 +343,9 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 // Waves (= frames per round) of a workgroup.  8: one workgroup per CU; its transform (float64 VALU) and its GEMM (MFMA)
 // alternate -- 0.96 ms per 57 k frames at 60 / 10 coefficients.  4 (-DMPX_FUSED_WAVES=4): TWO independent workgroups per
 // CU, so that one's MFMA phase could run under the other's float64 VALU phase; the tiles are then a quarter / half full
-// (twice the MFMA instructions per frame) and the kernel got SLOWER, 1.26 ms: like the lossless kernels this one runs at
-// the board's power limit, where time follows the work done, not the overlap ("power").
+// (twice the MFMA instructions per frame) and the kernel got SLOWER, 1.20-1.26 ms, with or without a raised priority of the
+// GEMM phase (MPX_FUSED_PRIO): the two workgroups' phases do not interleave as hoped.  (Not a power effect: this kernel draws
+// 899 W of the 1400 W cap, tools/power_lowdim.py.)
 #ifndef MPX_FUSED_WAVES
 #define MPX_FUSED_WAVES 8
 #endif
