@@ -584,7 +584,9 @@ class Engine:
     def synth_ola_slots(self):
         torch = _torch()
         with torch.cuda.device(self.device):
-            return int(self.lib.mpx_synth_ola_slots())
+            n = int(self.lib.mpx_synth_ola_slots())
+        cus = os.environ.get("MAGPHASE_SYN_CUS")   # experiment: the synthesis launch on fewer CUs (slots = 6 per workgroup)
+        return n if not cus else max(6, min(n, 6 * int(cus)))
 
     def synth_ola_slot_weights(self, comp=False):
         """Relative speeds of the slots of the lossless (comp=True: the compressed) synthesis kernel
