@@ -191,6 +191,26 @@ int mpx_synthesis_lossless_ola(void* stream, int fft_len, const void* tables, co
 int mpx_ola_fixup(void* stream, int fft_len, const mpx_ola_run* runs, int32_t n_runs, const float* strips,
                   float* pcm_out);
 
+/*
+ * Copy synthesis in one launch: analysis_lossless (magphase.py:2869-2906: windowing :74-119, analysis_with_del_comp_from_pm
+ * :266-334, compute_lossless_feats :457-476) followed by synthesis_from_lossless (:1759-1776, ola :34-62) on the same
+ * frames, as demos/demo_copy_synthesis_lossless.py:44-50 calls them back to back.  Frame f is cut out of `sig` exactly as
+ * by mpx_analysis_frames (frame_pos / frame_left / frame_right), its three feature rows are written to out_mag / out_real /
+ * out_imag (row pitch ld) -- analysis_lossless' return values -- and the frame is rebuilt from those float32 values and
+ * overlap-added exactly as by mpx_synthesis_lossless_ola (runs / slot_off / slot_runs / pm_rel / strips / pcm_out: the
+ * tables of a synthesis plan built from the analysis' v_f0; mpx_ola_fixup afterwards).  pcm_out equals what
+ * mpx_synthesis_lossless_ola gives on the rows written here, and the rows equal mpx_analysis_frames', to the last bits
+ * of float32 (the same arithmetic, contracted differently by the compiler / another order of the same transform).  The
+ * feature rows are not read back from memory.
+ * Every frame of [0, n_frames) must belong to exactly one run (slots: mpx_synth_comp_slots(), weights:
+ * mpx_synth_comp_slot_weights).
+ */
+int mpx_roundtrip_lossless_ola(void* stream, int fft_len, const void* tables, const float* sig, const int64_t* frame_pos,
+                               const int32_t* frame_left, const int32_t* frame_right, int64_t n_frames,
+                               const mpx_ola_run* runs, int32_t n_runs, const int32_t* slot_off, const int32_t* slot_runs,
+                               int32_t n_slots, const int32_t* pm_rel, float* out_mag, float* out_real, float* out_imag,
+                               float* strips, float* pcm_out, int64_t ld);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * Compressed-feature synthesis (magphase.py:825-997 synthesis_from_compressed, b_fbank_mel=False, per_phase_type='magphase')
  * ------------------------------------------------------------------------------------------------------------------ */

@@ -1546,6 +1546,311 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_synth_comp_pair(const f
 }
 
 // ---------------------------------------------------------------------------------------------
+// Lossless analysis -> synthesis of the same frames in ONE launch (copy synthesis: analysis_lossless followed by
+// synthesis_from_lossless, demos/demo_copy_synthesis_lossless.py:44-50; magphase.py:2869-2906, 1759-1776).  The wave that
+// analysed frame f still holds X[k] for the bin pairs (k, M - k) the synthesis wants from it (PairFeat: lane l <-> bins
+// l + 64 q and their mirrors): it writes the three feature rows -- the API's output -- and rebuilds the frame from the
+// very float32 values it stored, so the 3 x 4 H bytes per frame that k_synth_ola_pair reads back from HBM (1.4 GB per
+// 57 k frames: 0.14 J of the step's 0.7 J on a board that runs both kernels at its power limit) are not
+// read at all.  Structure = k_synth_comp_pair without the spectrum assembly: frame geometry from the ANALYSIS tables
+// (position / left / right of the epoch in the recording), samples staged by LDS-DMA into the exchange buffer while the
+// previous frame overlap-adds, Hann halves, real FFT + split in the paired layout (noise_spectrum_paired), features
+// (magphase.py:466-474) stored in k_analysis' line-friendly shape, unit-phase spectrum + Hermitian merge
+// (feat_merge_paired: exactly what k_synth_ola_pair computes from the loaded values), inverse transform, overlap-add
+// into the pair's LDS ring in frame order (runs / slots / tickets / head strips as k_synth_ola_pair; k_ola_fixup
+// afterwards).  The output samples are what k_synth_ola_pair gives on the features this kernel wrote up to float32
+// rounding (the same expressions; the compiler contracts their multiply-adds differently in the two kernels: measured
+// 3.6e-7 of the signal peak); the features differ from k_analysis' in the last bits (DIT instead of DIF forward
+// transform).  Both are held to the two-launch path's tolerances against the oracle.
+// Every frame index of [0, n_frames) must belong to exactly one run: a frame outside the runs is not analysed.
+// ---------------------------------------------------------------------------------------------
+template <int P>
+__global__ __launch_bounds__(kCompPairWaves * 64) void k_roundtrip_pair(const float* __restrict__ sig,
+                                                                       const long long* __restrict__ fpos,
+                                                                       const int* __restrict__ fleft,
+                                                                       const int* __restrict__ fright,
+                                                                       const RunDesc* __restrict__ runs,
+                                                                       const int* __restrict__ slot_off,
+                                                                       const int* __restrict__ slot_runs, int nslots,
+                                                                       const int* __restrict__ pm_rel,
+                                                                       const float* __restrict__ tw_g,
+                                                                       float* __restrict__ omag, float* __restrict__ oreal,
+                                                                       float* __restrict__ oimag, float* __restrict__ strips,
+                                                                       float* __restrict__ pcm, long long ld) {
+    constexpr int M = 64 * P, N = 2 * M, R = ring_len<P>(), HP = P / 2;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* tw = smem;
+    const int lane_id = threadIdx.x & 63;
+    const int wave = rfl((int)(threadIdx.x >> 6));
+    const int pair = wave >> 1, half = wave & 1;
+    constexpr bool kCompact = comp_compact<P>();
+    float* xbuf = smem + comp_tw_floats<P>() + wave * comp_xbuf_floats<P>();
+    const unsigned xbuf_byte = 4u * (unsigned)(comp_tw_floats<P>() + wave * comp_xbuf_floats<P>());
+    constexpr int kRing0 = comp_tw_floats<P>() + kCompPairWaves * comp_xbuf_floats<P>();
+    float* ring = smem + kRing0 + pair * R;
+    const unsigned ring_byte = 4u * (unsigned)(kRing0 + pair * R);
+    int* turn = reinterpret_cast<int*>(smem + kRing0 + kCompPairs * R) + pair;
+    if constexpr (kCompact) {   // half twiddle table + the lane constants in the rows' pads, as k_synth_comp_pair
+        for (int i = threadIdx.x; i < tw_half_floats<P>(); i += kCompPairWaves * 64) {
+            const int l = i / tw_half_stride<P>(), c = i - l * tw_half_stride<P>();
+            float v = 0.0f;
+            if (c < P) {
+#if MPX_COMP_DIT
+                v = tw_g[l * tw_stride<P>() + 2 * brev(c >> 1, ilog2(P)) + (c & 1)];
+#else
+                v = tw_g[l * tw_stride<P>() + 4 * (c >> 1) + (c & 1)];
+#endif
+            } else {
+                float sn, cs;
+                if (c < P + 2) sincospif(-2.0f * (float)l / (float)N, &sn, &cs);
+                else sincospif((float)l / 64.0f, &sn, &cs);
+                v = ((c - P) & 1) ? sn : cs;
+            }
+            tw[i] = v;
+        }
+    } else {
+        for (int i = threadIdx.x; i < tw_floats<P>(); i += kCompPairWaves * 64) tw[i] = tw_g[i];
+    }
+    for (int i = threadIdx.x; i < kCompPairs * R; i += kCompPairWaves * 64) smem[kRing0 + i] = 0.0f;
+    if (threadIdx.x < kCompPairs) turn[threadIdx.x - pair] = 0;   // thread t < kCompPairs has pair == 0
+    __syncthreads();
+
+    float wa_s0, wa_c0, ws_s0, ws_c0;   // analysis-side lane twiddle W_N^kappa and synthesis-side conj(W_N^lane)
+    sincospif(-2.0f * (float)kappa<P>(lane_id) / (float)N, &wa_s0, &wa_c0);
+    sincospif(2.0f * (float)lane_id / (float)N, &ws_s0, &ws_c0);
+    const int slot = blockIdx.x * kCompPairs + pair;
+    if (slot >= nslots) return;
+
+    struct Cursor {
+        int wi, fi, ci, ticket_base, fb, fe, x0, valid;
+    };
+    const int wi_end = slot_off[slot + 1];
+    auto settle = [&](Cursor& c) {
+        while (c.wi < wi_end) {
+            c.ci = slot_runs[c.wi];
+            c.fb = runs[c.ci].frame_begin;
+            c.fe = runs[c.ci].frame_end;
+            c.x0 = runs[c.ci].x0;
+            c.fi = c.fb + half;
+            if (c.fi < c.fe) {
+                c.valid = 1;
+                return;
+            }
+            c.ticket_base += c.fe - c.fb;
+            ++c.wi;
+        }
+        c.valid = 0;
+    };
+    auto advance = [&](Cursor& c) {
+        c.fi += 2;
+        if (c.fi >= c.fe) {
+            c.ticket_base += c.fe - c.fb;
+            ++c.wi;
+            settle(c);
+        }
+    };
+    Cursor cur;
+    cur.wi = slot_off[slot];
+    cur.ticket_base = 0;
+    settle(cur);
+    if (!cur.valid) return;
+
+    constexpr int kTile = kCompact ? 32 * P : 64 * P;
+    FrameGeom g = frame_geom(sig, fpos[cur.fi], fleft[cur.fi], fright[cur.fi], N);
+    stage_samples_async(g, 0, kTile, xbuf_byte, lane_id);
+
+    while (cur.valid) {
+        int lane = lane_id;
+        float wa_s = 0.0f, wa_c = 1.0f, ws_s = 0.0f, ws_c = 1.0f;
+        constexpr float lc = 1.0f, ls = 0.0f;
+        if constexpr (kCompact) {
+            asm volatile("" : "+v"(lane));
+        } else {
+            wa_s = wa_s0, wa_c = wa_c0, ws_s = ws_s0, ws_c = ws_c0;
+            asm volatile("" : "+v"(lane), "+v"(wa_s), "+v"(wa_c), "+v"(ws_s), "+v"(ws_c));
+        }
+        Cursor nxt = cur;
+        advance(nxt);
+        const int fi = cur.fi;
+
+        float xr[P], xi[P];
+        {
+            // ---- analysis: X[k] of the own bins k = lane + 64 q and of their mirrors M - k, bin M/2 on lane 0
+            float no_r[HP], no_i[HP], nm_r[HP], nm_i[HP], nh_r, nh_i;
+            staged_wait<0>();
+            noise_spectrum_paired<P, true, kCompact>(g, 0, tw, xbuf, xbuf_byte, lane, wa_c, wa_s, no_r, no_i, nm_r, nm_i, nh_r,
+                                                     nh_i, lc, ls);
+            if (P != 32) {   // FFT output lanes hold bins kappa(lane) + 64 q; the rows and the merge want bins lane + 64 q
+                const int src = kappa<P>(lane);
+#pragma unroll
+                for (int q = 0; q < HP; ++q) {
+                    no_r[q] = __shfl(no_r[q], src);
+                    no_i[q] = __shfl(no_i[q], src);
+                    nm_r[q] = __shfl(nm_r[q], src);
+                    nm_i[q] = __shfl(nm_i[q], src);
+                }
+                nh_r = __shfl(nh_r, src);
+                nh_i = __shfl(nh_i, src);
+            }
+            // ---- per bin pair q: lossless features (magphase.py:466-474; as k_analysis: X == 0 -> all three 0), their
+            // stores, and the pair's step of the Hermitian merge -- feat_merge_paired's arithmetic on the values just
+            // stored (X = mag (R + jI) / |R + jI|, magphase.py:1761-1766), pair by pair so that a pair's four inputs die
+            // as its four outputs appear (all 99 features at once, as k_synth_ola_pair holds them: 49 spilled registers)
+            auto feat = [](float x_r, float x_i, float& m, float& a, float& b) {
+                const float s2 = x_r * x_r + x_i * x_i;
+                const float r = __builtin_amdgcn_rsqf(fmaxf(s2, 1.0e-37f));
+                m = s2 * r;
+                a = x_r * r;
+                b = x_i * r;
+            };
+            if constexpr (kCompact) {   // kappa(lane) == lane: the synthesis-side twiddle is the conjugate of the split's
+                const float4 pk = tw_half_pad<P>(tw, lane);
+                ws_c = pk.x;
+                ws_s = -pk.y;
+            }
+            const bool lane0 = (lane == 0);
+            const float sgn_scale = ((lane & 1) ? -1.0f : 1.0f) * (0.5f / (float)M);   // (-1)^k fftshift sign, IFFT scale
+            // the three rows in k_analysis' store shape: ascending 256-byte blocks of the own bins in natural q order; the
+            // mirrors of step q regrouped into aligned blocks [M - 64 q - 64, M - 64 q - 1] whose lowest float is lane 0's
+            // mirror of step q + 1 (bin M/2 for the last block); bin M alone from lane 0
+            float* row_m = omag + (long long)fi * ld;
+            float* row_r = oreal + (long long)fi * ld;
+            float* row_i = oimag + (long long)fi * ld;
+            float* mlo = row_m + lane;
+            float* rlo = row_r + lane;
+            float* ilo = row_i + lane;
+            const int hoff = lane0 ? M - 64 : M - lane;
+            float* mhi = row_m + hoff;
+            float* rhi = row_r + hoff;
+            float* ihi = row_i + hoff;
+            float zr[HP], zi[HP];   // Z[M - k]
+            float hm = 0.0f, ha = 0.0f, hb = 0.0f;   // mirror features of the previous step
+#pragma unroll
+            for (int q = 0; q < HP; ++q) {
+                float m, a, b, mq, aq, bq;
+                feat(no_r[q], no_i[q], m, a, b);
+                feat(nm_r[q], nm_i[q], mq, aq, bq);
+                mlo[64 * q] = m;
+                rlo[64 * q] = a;
+                ilo[64 * q] = b;
+                if (q == 0) {
+                    if (lane0) {
+                        row_m[M] = mq;
+                        row_r[M] = aq;
+                        row_i[M] = bq;
+                    }
+                } else {
+                    mhi[-64 * (q - 1)] = lane0 ? mq : hm;
+                    rhi[-64 * (q - 1)] = lane0 ? aq : ha;
+                    ihi[-64 * (q - 1)] = lane0 ? bq : hb;
+                }
+                hm = mq;
+                ha = aq;
+                hb = bq;
+                // feat_merge_paired, step j = q
+                const float s = a * a + b * b;
+                const float gg = m * sgn_scale * __builtin_amdgcn_rsqf(fmaxf(s, 1.0e-37f));
+                const float sq_ = aq * aq + bq * bq;
+                const float gq = mq * sgn_scale * __builtin_amdgcn_rsqf(fmaxf(sq_, 1.0e-37f));
+                const float x_r = a * gg, p_r = aq * gq;
+                float x_i = b * gg, p_i = bq * gq;
+                if (q == 0) {   // DC and Nyquist: imaginary parts dropped (Q5)
+                    x_i = lane0 ? 0.0f : x_i;
+                    p_i = lane0 ? 0.0f : p_i;
+                }
+                const float er = x_r + p_r, ei = x_i - p_i, tr = x_r - p_r, ti = x_i + p_i;
+                const float cq = cos2p<P>(q), sq = sin2p<P>(q);
+                const float wr = ws_c * cq - ws_s * sq, wi = ws_c * sq + ws_s * cq;
+                const float orr = wr * tr - wi * ti, oi = wr * ti + wi * tr;
+                xr[q] = er - oi;
+                xi[q] = ei + orr;
+                zr[q] = er + oi;
+                zi[q] = orr - ei;
+            }
+            float mH, aH, bH;
+            feat(nh_r, nh_i, mH, aH, bH);
+            mhi[-64 * (HP - 1)] = lane0 ? mH : hm;
+            rhi[-64 * (HP - 1)] = lane0 ? aH : ha;
+            ihi[-64 * (HP - 1)] = lane0 ? bH : hb;
+            // bin M/2 (lane 0): Z = 2 conj(X); then the hand-over of Z[M - k] to the lanes that own those registers
+            const float sH = aH * aH + bH * bH;
+            const float gH = 2.0f * mH * sgn_scale * __builtin_amdgcn_rsqf(fmaxf(sH, 1.0e-37f));
+            const float hr = aH * gH, hi = -bH * gH;
+            const int src_lane = (64 - lane) & 63;
+#pragma unroll
+            for (int r = HP; r < P; ++r) {
+                const float pr = lane0 ? ((r == HP) ? hr : zr[P - r]) : zr[P - 1 - r];
+                const float pi = lane0 ? ((r == HP) ? hi : zi[P - r]) : zi[P - 1 - r];
+                xr[r] = __shfl(pr, src_lane);
+                xi[r] = __shfl(pi, src_lane);
+            }
+        }
+        constexpr bool kDit = kCompact && MPX_COMP_DIT;
+        if constexpr (kDit) {
+            constexpr int LBJ = ilog2(P);
+            float yr[P], yi[P];
+#pragma unroll
+            for (int j = 0; j < P; ++j) {
+                yr[brev(j, LBJ)] = xr[j];
+                yi[brev(j, LBJ)] = xi[j];
+            }
+            const float4 pk = tw_half_pad<P>(tw, lane);
+            wave_fft_dit_compact_front<P, +1>(yr, yi, tw, xbuf, lane, pk.z, pk.w);
+#pragma unroll
+            for (int j = 0; j < P; ++j) {
+                xr[j] = yr[j];
+                xi[j] = yi[j];
+            }
+        } else if constexpr (kCompact) {
+            const float4 pk = tw_half_pad<P>(tw, lane);
+            wave_fft_front_compact<P, +1>(xr, xi, tw, xbuf, lane, pk.z, pk.w);
+        } else {
+            wave_fft_front<P, +1>(xr, xi, tw, xbuf, lane);
+        }
+        if (nxt.valid) {   // the exchange buffer is idle from here on: start the copy of the next frame's samples
+            g = frame_geom(sig, fpos[nxt.fi], fleft[nxt.fi], fright[nxt.fi], N);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            stage_samples_async(g, 0, kTile, xbuf_byte, lane);
+        }
+        if constexpr (kDit) wave_fft_dit_back<P, +1>(xr, xi);
+        else fft_inreg<P, +1>(xr, xi);
+
+        // ---- ordered section: wait for this frame's ticket
+        const RunDesc rd = runs[cur.ci];
+        float* strip = strips + rd.strip_off;
+        float* pcm0 = pcm + rd.out_base;
+        const int ticket = cur.ticket_base + (fi - cur.fb);
+        const int x = pm_rel[fi] - cur.x0;   // strip position of the frame's first sample
+        const int target = x & ~63;
+        const int flushed = (fi == cur.fb) ? 0 : ((pm_rel[fi - 1] - cur.x0) & ~63);
+        asm volatile("" ::"s"(x), "s"(flushed), "s"(rd.head_end), "s"(rd.out_lo), "s"(rd.out_hi), "s"(rd.flush_end));
+        while (__hip_atomic_load(turn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != ticket)
+            __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");
+        if (flushed < target) flush_ring<R>(ring, strip, pcm0, rd.head_end, rd.out_lo, rd.out_hi, flushed, target, lane);
+        wave_sync();
+        auto plain_add = [](float o, float v, int) { return o + v; };
+        auto all_rows = [](int) { return true; };
+        if constexpr (kCompPairWaves > 8) {   // 16 ring values in registers at a time (<= 168 VGPRs)
+            constexpr int CH = (P < MPX_COMP_CH) ? P : MPX_COMP_CH;
+            const RingAddr ra = ring_addr<P>(ring_byte, x, lane);
+            ring_add_plane<P, 0, CH, kDit>(smem, ra, xr, lane, plain_add, all_rows);
+            ring_add_plane<P, 1, CH, kDit>(smem, ra, xi, lane, plain_add, all_rows);
+        } else {
+            ring_add<P>(smem, ring_byte, x, xr, xi, lane, plain_add, all_rows);
+        }
+        wave_sync();
+        if (fi == cur.fe - 1) {   // last frame of the run: stream out the rest, leave the ring cleared
+            flush_ring<R>(ring, strip, pcm0, rd.head_end, rd.out_lo, rd.out_hi, target, rd.flush_end, lane);
+            wave_sync();
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __hip_atomic_store(turn, ticket + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        cur = nxt;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Mel warp on the matrix cores: out[F x nout] = ln-prologue(x)[F x H] . W^T[H x nout], v_mfma_f32_16x16x4_f32.
 // One workgroup = 64 output frames x up to 64 outputs; the reduction runs over the H bins in chunks of 64.  Per chunk
 // the 256 threads stage the prologue values and the W slab into LDS as [row][k] (k contiguous, row stride 68 floats:
@@ -2275,6 +2580,37 @@ int mpx_synthesis_compressed_ola(void* stream, int fft_len, const void* tables, 
         else MPX_LAUNCH_COMP(8, false);
     }
 #undef MPX_LAUNCH_COMP
+    MPX_HIP_CHECK(hipGetLastError());
+    return MPX_OK;
+}
+
+int mpx_roundtrip_lossless_ola(void* stream, int fft_len, const void* tables, const float* sig, const int64_t* frame_pos,
+                               const int32_t* frame_left, const int32_t* frame_right, int64_t n_frames,
+                               const mpx_ola_run* runs, int32_t n_runs, const int32_t* slot_off, const int32_t* slot_runs,
+                               int32_t n_slots, const int32_t* pm_rel, float* out_mag, float* out_real, float* out_imag,
+                               float* strips, float* pcm_out, int64_t ld) {
+    const int P = p_of(fft_len);
+    if (!P) return fail(MPX_ERR_ARG, "mpx_roundtrip_lossless_ola: fft_len must be 1024, 2048 or 4096%s");
+    if (n_frames < 0 || n_runs < 0 || n_slots < 0) return fail(MPX_ERR_ARG, "mpx_roundtrip_lossless_ola: negative count%s");
+    if (ld < fft_len / 2 + 1) return fail(MPX_ERR_ARG, "mpx_roundtrip_lossless_ola: ld < fft_len/2 + 1%s");
+    if (n_frames == 0 || n_runs == 0 || n_slots == 0) return MPX_OK;
+    if (!tables || !sig || !frame_pos || !frame_left || !frame_right || !runs || !slot_off || !slot_runs || !pm_rel ||
+        !out_mag || !out_real || !out_imag || !strips || !pcm_out)
+        return fail(MPX_ERR_ARG, "mpx_roundtrip_lossless_ola: null pointer%s");
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 pgrid((n_slots + kCompPairs - 1) / kCompPairs), pblock(kCompPairWaves * 64);
+#define MPX_LAUNCH_RT(PP)                                                                                              \
+    do {                                                                                                             \
+        if (int rc = set_lds(k_roundtrip_pair<PP>, lds_bytes_comp_pair<PP>())) return rc;                            \
+        hipLaunchKernelGGL(k_roundtrip_pair<PP>, pgrid, pblock, lds_bytes_comp_pair<PP>(), s, sig,                   \
+                           (const long long*)frame_pos, frame_left, frame_right, (const RunDesc*)runs, slot_off,     \
+                           slot_runs, (int)n_slots, pm_rel, (const float*)tables, out_mag, out_real, out_imag, strips, \
+                           pcm_out, (long long)ld);                                                                  \
+    } while (0)
+    if (P == 32) MPX_LAUNCH_RT(32);
+    else if (P == 16) MPX_LAUNCH_RT(16);
+    else MPX_LAUNCH_RT(8);
+#undef MPX_LAUNCH_RT
     MPX_HIP_CHECK(hipGetLastError());
     return MPX_OK;
 }

@@ -781,6 +781,25 @@ class Engine:
                 "mpx_synthesis_lossless_ola")
         return pcm_out
 
+    def roundtrip_lossless_ola(self, fft_len, plan_a, plan_s, feats, strips, pcm_out):
+        """Copy synthesis in one launch (mpx_roundtrip_lossless_ola): plan_a's frames are analysed, their feature rows
+        written to feats = (mag, real, imag) and overlap-added by plan_s' runs (a LosslessSynthesisPlan built for this
+        kernel's slots from plan_a's v_f0); ola_fixup(plan_s, strips, pcm_out) completes the run boundaries."""
+        torch = _torch()
+        tab = self.tables(fft_len)
+        mag, real, imag = feats
+        with torch.cuda.device(self.device):
+            _lib.check(
+                self.lib.mpx_roundtrip_lossless_ola(self.stream_ptr(), int(fft_len), tab.data_ptr(), plan_a.sig.data_ptr(),
+                                                    plan_a.pos.data_ptr(), plan_a.left.data_ptr(), plan_a.right.data_ptr(),
+                                                    int(plan_a.total_frames), plan_s.runs.data_ptr(), int(plan_s.n_runs),
+                                                    plan_s.slot_off.data_ptr(), plan_s.slot_runs.data_ptr(),
+                                                    int(plan_s.n_slots), plan_s.pm_rel.data_ptr(), mag.data_ptr(),
+                                                    real.data_ptr(), imag.data_ptr(), strips.data_ptr(),
+                                                    pcm_out.data_ptr(), self.feat_ld(mag, real, imag)),
+                "mpx_roundtrip_lossless_ola")
+        return pcm_out
+
     def ola_fixup(self, fft_len, plan, strips, pcm_out):
         torch = _torch()
         with torch.cuda.device(self.device):
@@ -941,7 +960,8 @@ class LosslessSynthesisPlan:
     All float64/int host math; device gets int tables.
     """
 
-    def __init__(self, engine, f0_list, fs_list, fft_len, frames_per_run=None):
+    def __init__(self, engine, f0_list, fs_list, fft_len, frames_per_run=None, comp_slots=False):
+        # comp_slots: the slot count and weights of the compressed / round-trip pair kernels (mpx_synth_comp_slots)
         self.engine = engine
         self.fft_len = fft_len
         pm_rel, starts, lens, nfr = [], [], [], []
@@ -973,9 +993,13 @@ class LosslessSynthesisPlan:
         _up.append(("pm_rel", np.concatenate(pm_rel) if pm_rel else np.zeros(0), np.int32))
         _up.append(("out_start", np.asarray(starts), np.int32))
         _up.append(("out_off", self.out_off_host, np.int64))
-        n_slots = e.synth_ola_slots() if hasattr(e, "synth_ola_slots") else 1024
-        _plan_ola_runs(self, pm_rel, starts, lens, self.out_off_host, fft_len, n_slots, frames_per_run, _up,
-                       weights=e.synth_ola_slot_weights() if hasattr(e, "synth_ola_slot_weights") else None)
+        if comp_slots:
+            n_slots = e.synth_comp_slots()
+            weights = e.synth_ola_slot_weights(comp=True)
+        else:
+            n_slots = e.synth_ola_slots() if hasattr(e, "synth_ola_slots") else 1024
+            weights = e.synth_ola_slot_weights() if hasattr(e, "synth_ola_slot_weights") else None
+        _plan_ola_runs(self, pm_rel, starts, lens, self.out_off_host, fft_len, n_slots, frames_per_run, _up, weights=weights)
         for _k, _t in e.to_device_packed(_up).items():
             setattr(self, _k, _t)
 
@@ -995,6 +1019,48 @@ class LosslessSynthesisPlan:
         frames = e.synthesis_lossless_frames(self.fft_len, mag, real, imag, out=frames)
         return e.ola_gather(self.fft_len, frames, self.utt_frame_off, self.pm_rel, self.out_start, self.out_off,
                             self.max_out_len, self.total_out, out=out)
+
+
+class LosslessRoundTripPlan:
+    """
+    Copy synthesis of a batch (analysis_lossless followed by synthesis_from_lossless on the same frames,
+    demos/demo_copy_synthesis_lossless.py:44-50) as ONE launch: the analysis plan's frame tables plus a synthesis plan
+    built from the f0 values the analysis derives on the host (magphase.py:2198-2207 -> :1771-1772), cut into runs for
+    the round-trip kernel's slots.  run() returns ((mag, real, imag), pcm): the feature rows analysis_lossless returns
+    and the waveform synthesis_from_lossless builds from them.
+    """
+
+    def __init__(self, engine, utts, fft_len=None, frames_per_run=None):
+        self.engine = engine
+        if not utts:   # an empty batch: nothing to plan, run() returns empty tensors
+            self.analysis = self.synthesis = None
+            self.fft_len = fft_len or 4096
+            self.total_frames = self.total_out = 0
+            self.out_off_host = np.zeros(1, dtype=np.int64)
+            return
+        self.analysis = LosslessAnalysisPlan(engine, utts, fft_len=fft_len)
+        self.fft_len = self.analysis.fft_len
+        self.synthesis = LosslessSynthesisPlan(engine, self.analysis.v_f0, self.analysis.fs, self.fft_len,
+                                               frames_per_run=frames_per_run, comp_slots=True)
+        if self.synthesis.total_frames != self.analysis.total_frames:
+            raise ValueError("round trip: the synthesis plan must cover exactly the analysed frames")
+        self.total_frames = self.analysis.total_frames
+        self.total_out = self.synthesis.total_out
+        self.out_off_host = self.synthesis.out_off_host
+
+    def run(self, feats=None, strips=None, out=None):
+        e, a, s = self.engine, self.analysis, self.synthesis
+        if feats is None:
+            feats = tuple(e.empty_feats(self.total_frames, self.fft_len // 2 + 1) for _ in range(3))
+        if out is None:
+            out = e.empty((self.total_out,))
+        if self.total_frames == 0:
+            return feats, out
+        if strips is None:
+            strips = e.empty((max(s.strip_floats, 1),))
+        e.roundtrip_lossless_ola(self.fft_len, a, s, feats, strips, out)
+        e.ola_fixup(self.fft_len, s, strips, out)
+        return feats, out
 
 
 # ======================================================================================================

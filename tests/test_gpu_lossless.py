@@ -372,3 +372,90 @@ def test_fft_1024_at_8khz(mp, orc):
     splan = LosslessSynthesisPlan(eng, plan.v_f0, plan.fs, plan.fft_len)
     a, b = splan.run(*feats), splan.run_unfused(*feats)          # fused ring form vs frames + gather
     assert float((a - b).abs().max()) <= 1e-6 * max(1.0, float(b.abs().max()))
+
+
+@pytest.mark.parametrize("fs,dur,fpr", [(48000, 1.0, None), (48000, 0.6, 1), (48000, 0.8, 7), (16000, 1.0, None),
+                                         (16000, 0.7, 5), (8000, 0.8, None)])
+def test_round_trip_launch_matches_the_two_launch_path(mp, orc, fs, dur, fpr):
+    """mpx_roundtrip_lossless_ola (analysis -> synthesis of the same frames in one launch, the feature rows written but
+    not read back): (1) its rows against the oracle at the analysis tolerances; (2) its waveform against
+    mpx_synthesis_lossless_ola applied to the rows it wrote (same arithmetic on the same float32 values; the compiler
+    contracts the two instances' multiply-adds differently: last-bit differences); (3) against the oracle's copy
+    synthesis; (4) deterministic.  fft_len 4096 / 2048 / 1024, any run length (one frame per run ... the planner's own cut)."""
+    import torch
+    from magphase_amd import synthetic as syn
+    from magphase_amd.engine import LosslessRoundTripPlan, LosslessSynthesisPlan, get_engine
+    eng = get_engine()
+    utts = []
+    for u in range(5):
+        pcm, pm, voi = syn.make_utterance(300 + u, dur_s=dur + 0.15 * u, fs=fs)
+        utts.append((pcm, fs, pm, voi))
+    plan = LosslessRoundTripPlan(eng, utts, frames_per_run=fpr)   # fft_len from fs: 4096 / 2048 / 1024
+    feats, pcm_out = plan.run()
+    torch.cuda.synchronize()
+    y = pcm_out.cpu().numpy()
+    feats2, pcm2 = plan.run()
+    assert np.array_equal(y, pcm2.cpu().numpy())
+    for k in range(3):
+        assert np.array_equal(feats[k].cpu().numpy(), feats2[k].cpu().numpy())
+    # (2) the two-launch synthesis on the rows just written, same run tables
+    two = plan.synthesis.run(*feats).cpu().numpy()
+    within(np.max(np.abs(y - two)) / np.max(np.abs(two)), PCM_TOL, "PCM_TOL:roundtrip-vs-two-launch")
+    # and with the lossless kernel's own slot count (other run boundaries)
+    s2 = LosslessSynthesisPlan(eng, plan.analysis.v_f0, plan.analysis.fs, plan.fft_len)
+    other = s2.run(*feats).cpu().numpy()
+    assert np.max(np.abs(y - other)) <= 2e-6 * np.max(np.abs(other))
+    a = plan.analysis
+    for u, (pcm, fs_, pm, voi) in enumerate(utts):
+        x = pcm.astype(np.float64) / 32768.0
+        o = orc.analysis_lossless_from_epochs(x, fs_, pm, voi)
+        fa, fb = int(a.frame_off[u]), int(a.frame_off[u + 1])
+        got = [t[fa:fb].cpu().numpy().astype(np.float64) for t in feats]
+        _check_feats(got, o[:3])
+        ref = orc.synthesis_from_lossless(o[0], o[1], o[2], o[3], fs_)
+        yu = y[plan.out_off_host[u]:plan.out_off_host[u + 1]].astype(np.float64)
+        assert len(yu) == len(ref)
+        within(np.max(np.abs(yu - ref)) / np.max(np.abs(ref)), 2 * PCM_TOL, "PCM_TOL:roundtrip")
+
+
+def test_round_trip_launch_edge_frames(mp, orc):
+    """Frames longer than fft_len (truncated, Q19), a first epoch at sample 0 (L = 0), silence, an utterance of two
+    frames and an empty batch through the one-launch round trip."""
+    import torch
+    from magphase_amd import synthetic as syn
+    from magphase_amd.engine import LosslessRoundTripPlan, get_engine
+    eng = get_engine()
+    fs = 48000
+    rng = np.random.RandomState(5)
+    n = 30000
+    x = (rng.uniform(-0.5, 0.5, n) * 32767).astype(np.int16)
+    pm_long = np.array([0.0, 0.01, 0.02, 0.15, 0.16, 0.4]) + 1e-4    # gaps of 6 240 and 11 520 samples: frames longer than N
+    pm0 = np.array([0.0, 0.004, 0.009, 0.015, 0.02])                   # first epoch at sample 0
+    utts = [(x, fs, pm_long, np.ones(pm_long.size)), (x[:2000], fs, pm0, np.array([1.0, 1, 0, 0, 1])),
+            (np.zeros(4000, dtype=np.int16), fs, np.arange(1, 16) * 0.005, np.zeros(15)),
+            (x[:1500], fs, np.array([0.005, 0.012]), np.ones(2))]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        plan = LosslessRoundTripPlan(eng, utts)
+        feats, pcm_out = plan.run()
+        torch.cuda.synchronize()
+        y = pcm_out.cpu().numpy()
+        two = plan.synthesis.run(*feats).cpu().numpy()
+        assert np.max(np.abs(y - two)) <= PCM_TOL * max(np.max(np.abs(two)), 1e-30)
+        a = plan.analysis
+        for u, (pcm, fs_, pm, voi) in enumerate(utts):
+            xs = pcm.astype(np.float64) / 32768.0
+            o = orc.analysis_lossless_from_epochs(xs, fs_, pm, voi)
+            fa, fb = int(a.frame_off[u]), int(a.frame_off[u + 1])
+            got = [t[fa:fb].cpu().numpy().astype(np.float64) for t in feats]
+            if u == 2:
+                assert all(np.all(g == 0.0) for g in got)
+                continue
+            _check_feats(got, o[:3])
+            ref = orc.synthesis_from_lossless(o[0], o[1], o[2], o[3], fs_)
+            yu = y[plan.out_off_host[u]:plan.out_off_host[u + 1]].astype(np.float64)
+            assert len(yu) == len(ref)
+            within(np.max(np.abs(yu - ref)) / max(np.max(np.abs(ref)), 1e-30), 2 * PCM_TOL, "PCM_TOL:roundtrip-edge")
+    empty = LosslessRoundTripPlan(eng, [], fft_len=4096)
+    f, p = empty.run()
+    assert p.numel() == 0 and f[0].shape[0] == 0
