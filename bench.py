@@ -836,6 +836,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--streams", type=int, default=2,
                     help="HIP streams that consecutive (independent) steps alternate between; 1 = one step at a time")
+    ap.add_argument("--form", choices=("one", "two"), default=os.environ.get("BENCH_FORM", "one"),
+                    help="one: a step = ONE launch that analyses every frame, writes its feature rows and overlap-adds the "
+                         "frame rebuilt from them (mpx_roundtrip_lossless_ola + mpx_ola_fixup); two: mpx_analysis_frames, then "
+                         "mpx_synthesis_lossless_ola reading the rows back (+ mpx_ola_fixup).  Same outputs; the other form is "
+                         "measured beside the chosen one (roofline.two_launch / roofline.one_launch)")
     ap.add_argument("--no-idle-probe", action="store_true",
                     help="skip the from-idle repeat of the timed loop (profiling runs: keeps every launch in the steady state)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -899,7 +904,7 @@ def main():
         torch.cuda.set_device(0)
     red_dev = "cuda" if backend == "nccl" else "cpu"
 
-    from magphase_amd.engine import LosslessAnalysisPlan, LosslessSynthesisPlan, get_engine
+    from magphase_amd.engine import LosslessAnalysisPlan, LosslessRoundTripPlan, LosslessSynthesisPlan, get_engine
 
     eng = get_engine()
     if args.workload == "corpus":
@@ -929,16 +934,27 @@ def main():
             dist.destroy_process_group()
         return
     utts = make_batch(rank)
+    one = args.form == "one"
+
+    def build_plans():   # the chosen form's plans (what a caller of that form builds); the other form's come afterwards
+        if one:
+            r = LosslessRoundTripPlan(eng, utts)
+            return r, r.analysis, None
+        a = LosslessAnalysisPlan(eng, utts)
+        return None, a, LosslessSynthesisPlan(eng, a.v_f0, a.fs, a.fft_len)
+
     t_plan0 = time.perf_counter()
-    aplan = LosslessAnalysisPlan(eng, utts)
-    splan = LosslessSynthesisPlan(eng, aplan.v_f0, aplan.fs, aplan.fft_len)
+    rt, aplan, splan = build_plans()
     torch.cuda.synchronize()
     t_plan_cold = time.perf_counter() - t_plan0
     t_plan0 = time.perf_counter()       # again: steady state (pinned staging and tables exist)
-    aplan = LosslessAnalysisPlan(eng, utts)
-    splan = LosslessSynthesisPlan(eng, aplan.v_f0, aplan.fs, aplan.fft_len)
+    rt, aplan, splan = build_plans()
     torch.cuda.synchronize()
     t_plan = time.perf_counter() - t_plan0
+    if splan is None:
+        splan = LosslessSynthesisPlan(eng, aplan.v_f0, aplan.fs, aplan.fft_len)
+    if rt is None:
+        rt = LosslessRoundTripPlan(eng, utts)
     N = aplan.fft_len
     H = N // 2 + 1
     F = aplan.total_frames
@@ -947,15 +963,24 @@ def main():
     # synthesis launch (a SIMD serves its waves by age: the last waves of a launch run alone).  Every step
     # does all of its work; nothing is shared between steps but the read-only inputs.  --streams 1 = one step at a time.
     n_streams = max(1, int(args.streams))
-    bufs = [(tuple(eng.empty_feats(F, H) for _ in range(3)), eng.empty((max(splan.strip_floats, 1),)),
+    assert rt.total_out == splan.total_out and rt.total_frames == F
+    bufs = [(tuple(eng.empty_feats(F, H) for _ in range(3)),
+             eng.empty((max(splan.strip_floats, rt.synthesis.strip_floats, 1),)),
              eng.empty((splan.total_out,))) for _ in range(n_streams)]
     feats, strips, pcm_out = bufs[0]
 
+    def step_two(f_, s_, p_):
+        aplan.run(out=f_)
+        splan.run(f_[0], f_[1], f_[2], strips=s_, out=p_)
+
+    def step_one(f_, s_, p_):
+        rt.run(feats=f_, strips=s_, out=p_)
+
+    step_form = step_one if one else step_two
+
     def enqueue(stream, k):
-        f_, s_, p_ = bufs[k]
         with torch.cuda.stream(stream):
-            aplan.run(out=f_)
-            splan.run(f_[0], f_[1], f_[2], strips=s_, out=p_)
+            step_form(*bufs[k])
 
     stream_pick = None
     if n_streams > 1:      # streams that map to different hardware queues (pick_streams)
@@ -1005,8 +1030,12 @@ def main():
             step(i, one_stream=True)
         torch.cuda.synchronize()
         dt_one = time.perf_counter() - t1
-    if args.pmc_child:      # profiled by live_traffic(): a few configs[2] steps as well, then done (no JSON line)
+    if args.pmc_child:      # profiled by live_traffic(): the other form and a few configs[2] steps as well, then done (no JSON line)
         from magphase_amd import engine as em
+
+        for _ in range(3):
+            (step_two if one else step_one)(*bufs[0])
+        torch.cuda.synchronize()
 
         st = _lowdim_state(em, eng, utts)
         for _ in range(3):
@@ -1030,30 +1059,57 @@ def main():
         total_frames = float(F)
 
     # ---- per-kernel durations with HIP events on the launch stream (separate, untimed-for-value loop)
-    names = ("k_analysis", "k_synth_ola_pair", "k_ola_fixup")
-    acc = [0.0, 0.0, 0.0]
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
     reps = max(5, min(args.steps, 20))
-    for _ in range(reps):
-        ev[0].record()
-        aplan.run(out=feats)
-        ev[1].record()
-        eng.synthesis_lossless_ola(N, feats[0], feats[1], feats[2], splan, strips, pcm_out)
-        ev[2].record()
-        eng.ola_fixup(N, splan, strips, pcm_out)
-        ev[3].record()
-        torch.cuda.synchronize()
-        for k in range(3):
-            acc[k] += ev[k].elapsed_time(ev[k + 1])
-    ms = [a / reps for a in acc]
-    # algorithmic bytes per launch: features are materialised once (the API returns them),
-    # every PCM sample is read once and written once; the run-boundary head strips are NOT algorithmic traffic.
-    alg = [12.0 * H * F + 4.0 * aplan.total_smpls, 12.0 * H * F + 4.0 * splan.total_out, 0.0]
-    kern = [{"name": names[k], "ms": round(ms[k], 4), "alg_bytes": alg[k],
-             "alg_GBps": round(alg[k] / (ms[k] * 1e-3) / 1e9, 1)} for k in range(3)]
-    fix_elems = int(np.sum(np.maximum(splan.runs_host["fix_hi"] - splan.runs_host["fix_lo"], 0)))
-    kern[2]["note"] = "run-boundary fix-up: %d floats read twice and written once; not algorithmic traffic" % fix_elems
-    dom = int(np.argmax(ms[:2]))
+
+    def event_ms(calls):   # mean duration of each call of the sequence, HIP events on the launch stream
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(len(calls) + 1)]
+        acc = [0.0] * len(calls)
+        for _ in range(reps):
+            ev[0].record()
+            for k, c in enumerate(calls):
+                c()
+                ev[k + 1].record()
+            torch.cuda.synchronize()
+            for k in range(len(calls)):
+                acc[k] += ev[k].elapsed_time(ev[k + 1])
+        return [a / reps for a in acc]
+
+    # algorithmic bytes per launch: features are materialised once (the API returns them) and
+    # read once by the synthesis, every PCM sample is read once and written once: 24 H + 8 S per frame for analysis +
+    # synthesis; the run-boundary head strips are NOT algorithmic traffic.  The one-launch form does a frame's analysis AND
+    # synthesis, so its launch carries the whole per-frame figure -- of which it MOVES only the writes (12 H + 8 S per
+    # frame: the rows are not read back), reported beside it as moved_bytes / moved_GBps.
+    def kernel_rows(form_one):
+        if form_one:
+            nm = ("k_roundtrip_pair", "k_ola_fixup")
+            ms_ = event_ms((lambda: eng.roundtrip_lossless_ola(N, aplan, rt.synthesis, feats, strips, pcm_out),
+                            lambda: eng.ola_fixup(N, rt.synthesis, strips, pcm_out)))
+            alg_ = [24.0 * H * F + 4.0 * aplan.total_smpls + 4.0 * splan.total_out, 0.0]
+            sp = rt.synthesis
+        else:
+            nm = ("k_analysis", "k_synth_ola_pair", "k_ola_fixup")
+            ms_ = event_ms((lambda: aplan.run(out=feats),
+                            lambda: eng.synthesis_lossless_ola(N, feats[0], feats[1], feats[2], splan, strips, pcm_out),
+                            lambda: eng.ola_fixup(N, splan, strips, pcm_out)))
+            alg_ = [12.0 * H * F + 4.0 * aplan.total_smpls, 12.0 * H * F + 4.0 * splan.total_out, 0.0]
+            sp = splan
+        rows = [{"name": nm[k], "ms": round(ms_[k], 4), "alg_bytes": alg_[k],
+                 "alg_GBps": round(alg_[k] / (ms_[k] * 1e-3) / 1e9, 1)} for k in range(len(nm))]
+        if form_one:
+            moved = 12.0 * H * F + 4.0 * aplan.total_smpls + 4.0 * splan.total_out
+            rows[0]["moved_bytes"] = moved
+            rows[0]["moved_GBps"] = round(moved / (ms_[0] * 1e-3) / 1e9, 1)
+            rows[0]["note"] = ("analysis + synthesis of every frame in one launch: alg_bytes is SURVEY 8d's per-frame figure "
+                               "(24 H + 8 S: rows written once, read once); the launch writes the rows and does not read them "
+                               "back, moved_bytes (12 H + 8 S per frame) is what it has to move")
+        fix_elems = int(np.sum(np.maximum(sp.runs_host["fix_hi"] - sp.runs_host["fix_lo"], 0)))
+        rows[-1]["note"] = "run-boundary fix-up: %d floats read twice and written once; not algorithmic traffic" % fix_elems
+        return rows, ms_, alg_
+
+    kern, ms, alg = kernel_rows(one)
+    names = [k["name"] for k in kern]
+    kern_other, ms_other, alg_other = kernel_rows(not one)
+    dom = int(np.argmax(ms[:-1]))
     full = rank == 0 and world == 1 and not args.quick
     live, live_src = (live_traffic() if (full and args.traffic == "live") else (None, "not requested"))
     if live is not None and names[dom] in live:
@@ -1075,13 +1131,30 @@ def main():
             "kernel_time_source": "HIP events on the launch stream, mean of %d launches in this process (the rocprofv3 "
                                   "--kernel-trace --stats summary of this command: profiles/, latest r04_*kernel_stats.csv)" % reps,
             "path_alg_GBps": round(sum(alg) / (sum(ms) * 1e-3) / 1e9, 1)}
+    if one:
+        roof["moved_GBps"] = kern[0]["moved_GBps"]
+        roof["frac_moved"] = round(kern[0]["moved_GBps"] / HBM_PEAK_GBS, 4)
+    other_key = "two_launch" if one else "one_launch"
+    roof[other_key] = {"kernels": kern_other, "kernel_sum_ms": round(sum(ms_other), 4),
+                       "path_alg_GBps": round(sum(alg_other) / (sum(ms_other) * 1e-3) / 1e9, 1),
+                       "note": "the same step in the other form (--form %s), same process, one launch at a time" % ("two" if one else "one")}
+    if live is not None:
+        for k in kern_other:
+            if k["name"] in live:
+                k["hbm_traffic"] = round(live[k["name"]], 1)
     if full:
         try:    # what this device sustains for plain streams: the read ceiling bounds k_synth_ola_pair, the write one k_analysis
-            ceil = measure_ceilings(eng)
+            ceil = measure_ceilings(eng)   # and k_roundtrip_pair (it moves writes only)
             roof["measured_ceilings"] = ceil
-            roof["frac_of_measured_read"] = round(kern[1]["alg_GBps"] / ceil["read_GBps"], 4)
-            kern[0]["frac_of_measured_write"] = round(kern[0]["alg_GBps"] / ceil["write_GBps"], 4)
-            kern[1]["frac_of_measured_read"] = roof["frac_of_measured_read"]
+            for k in kern + kern_other:
+                if k["name"] == "k_analysis":
+                    k["frac_of_measured_write"] = round(k["alg_GBps"] / ceil["write_GBps"], 4)
+                elif k["name"] == "k_synth_ola_pair":
+                    k["frac_of_measured_read"] = round(k["alg_GBps"] / ceil["read_GBps"], 4)
+                elif k["name"] == "k_roundtrip_pair":
+                    k["moved_frac_of_measured_write"] = round(k["moved_GBps"] / ceil["write_GBps"], 4)
+            if not one:
+                roof["frac_of_measured_read"] = kern[1]["frac_of_measured_read"]
         except Exception as e:
             roof["measured_ceilings"] = {"error": "%s: %s" % (type(e).__name__, e)}
         try:    # board power while each kernel loops: both lossless kernels sit at the device's power cap
@@ -1102,6 +1175,7 @@ def main():
                 ("k_analysis", lambda: aplan.run(out=feats)),
                 ("k_synth_ola_pair+k_ola_fixup", lambda: splan.run(feats[0], feats[1], feats[2], strips=strips, out=pcm_out)),
                 ("step", lambda: (aplan.run(out=feats), splan.run(feats[0], feats[1], feats[2], strips=strips, out=pcm_out))),
+                ("k_roundtrip_pair+k_ola_fixup", lambda: rt.run(feats=feats, strips=strips, out=pcm_out)),
                 ("probe_read_1GiB", probe(0)), ("probe_fill_1GiB", probe(1)), ("probe_copy_1GiB", probe(2))))
             del pa, pb
             if pw is not None:
@@ -1133,6 +1207,10 @@ def main():
             "data": "synthetic",
             "config": {"workload": "configs[1]: %d synthetic 48 kHz %.0f s utterances per GPU, lossless analysis+synthesis, "
                                    "FFT=4096, variable frame rate" % (UTTS_PER_GPU, DUR_S),
+                       "form": ("one launch per step: every frame analysed, its feature rows written, the frame rebuilt from "
+                                "them and overlap-added (mpx_roundtrip_lossless_ola + mpx_ola_fixup); --form two = "
+                                "mpx_analysis_frames, then mpx_synthesis_lossless_ola reading the rows back: roofline.two_launch"
+                                if one else "two launches per step (mpx_analysis_frames, mpx_synthesis_lossless_ola + mpx_ola_fixup)"),
                        "frames_per_gpu": F, "audio_s_per_gpu": UTTS_PER_GPU * DUR_S,
                        "x_realtime": round(UTTS_PER_GPU * DUR_S * world / (dt / args.steps), 1),
                        "parallelism": "utterance-sharded x%d, no collective" % world,
@@ -1147,7 +1225,7 @@ def main():
                        "streams_note": "consecutive steps alternate between %d HIP streams with their own feature / output "
                                        "buffers (the next step's analysis fills the tail of this step's synthesis launch); "
                                        "ms_per_step_single_stream = the same K steps one at a time, same process" % n_streams,
-                       "ola_runs": splan.n_runs,
+                       "ola_runs": (rt.synthesis.n_runs if one else splan.n_runs),
                        "host_plan_build_s": round(t_plan, 4), "host_plan_build_cold_s": round(t_plan_cold, 3)},
             "roofline": roof,
         }

@@ -29,6 +29,8 @@ def main():
     ap.add_argument("--out-dir", default=os.path.join(HERE, "data_48k", "wavs_syn"))
     ap.add_argument("--epochs", default="builtin", choices=["builtin", "reaper"],
                     help="epoch source when there is no <stem>.est next to the wav")
+    ap.add_argument("--one-launch", action="store_true",
+                    help="analysis + synthesis as one device launch (magphase.copy_synthesis_lossless)")
     args = ap.parse_args()
     if not os.path.isfile(args.wav):
         sys.path.insert(0, HERE)
@@ -39,10 +41,15 @@ def main():
         print("epochs: built-in zero-frequency-filtering tracker (not REAPER)")
         mp.use_builtin_epoch_tracker()
 
-    features = mp.analysis_lossless(args.wav)                    # (m_mag, m_real, m_imag, v_f0, fs, v_shift)
-    m_mag, m_real, m_imag, v_f0, fs = features[:5]
-    print("analysed %d pitch-synchronous frames x %d bins at %d Hz" % (m_mag.shape[0], m_mag.shape[1], fs))
-    v_syn = mp.synthesis_from_lossless(m_mag, m_real, m_imag, v_f0, fs)
+    if args.one_launch:   # the two calls below as one device launch (mpx_roundtrip_lossless_ola): same outputs
+        features, v_syn = mp.copy_synthesis_lossless(args.wav)
+        m_mag, m_real, m_imag, v_f0, fs = features[:5]
+        print("analysed and resynthesised %d pitch-synchronous frames x %d bins at %d Hz" % (m_mag.shape[0], m_mag.shape[1], fs))
+    else:
+        features = mp.analysis_lossless(args.wav)                    # (m_mag, m_real, m_imag, v_f0, fs, v_shift)
+        m_mag, m_real, m_imag, v_f0, fs = features[:5]
+        print("analysed %d pitch-synchronous frames x %d bins at %d Hz" % (m_mag.shape[0], m_mag.shape[1], fs))
+        v_syn = mp.synthesis_from_lossless(m_mag, m_real, m_imag, v_f0, fs)
     target = os.path.join(args.out_dir, lu.get_filename(args.wav) + "_copy_syn_lossless.wav")
     la.write_audio_file(target, v_syn, fs)
     print("wrote", target)

@@ -203,8 +203,9 @@ int mpx_ola_fixup(void* stream, int fft_len, const mpx_ola_run* runs, int32_t n_
  * of float32 (the same arithmetic, contracted differently by the compiler / another order of the same transform).  The
  * feature rows are not read back from memory.
  * Every frame of [0, n_frames) must belong to exactly one run (slots: mpx_synth_comp_slots(), weights:
- * mpx_synth_comp_slot_weights).
+ * mpx_roundtrip_slot_weights).
  */
+int mpx_roundtrip_slot_weights(float* weights_host, int32_t n_slots); /* as mpx_synth_comp_slot_weights, for this kernel */
 int mpx_roundtrip_lossless_ola(void* stream, int fft_len, const void* tables, const float* sig, const int64_t* frame_pos,
                                const int32_t* frame_left, const int32_t* frame_right, int64_t n_frames,
                                const mpx_ola_run* runs, int32_t n_runs, const int32_t* slot_off, const int32_t* slot_runs,

@@ -34,6 +34,7 @@ SYMBOLS = (
     "mpx_synthesis_lossless_ola",
     "mpx_ola_fixup",
     "mpx_roundtrip_lossless_ola",
+    "mpx_roundtrip_slot_weights",
     "mpx_mel_unwarp",
     "mpx_mel_unwarp_rows",
     "mpx_spec_ld",
@@ -151,6 +152,8 @@ def _load_locked():
     lib.mpx_ola_strip_floats.restype = i64
     lib.mpx_ola_strip_floats.argtypes = [ctypes.c_int]
     lib.mpx_synthesis_lossless_ola.argtypes = [vp, ctypes.c_int, vp, vp, vp, vp, vp, i32, vp, vp, i32, vp, vp, vp, i64]
+    lib.mpx_roundtrip_slot_weights.restype = ctypes.c_int
+    lib.mpx_roundtrip_slot_weights.argtypes = [vp, i32]
     lib.mpx_roundtrip_lossless_ola.restype = ctypes.c_int
     lib.mpx_roundtrip_lossless_ola.argtypes = [vp, ctypes.c_int, vp, vp, vp, vp, vp, i64, vp, i32, vp, vp, i32, vp, vp, vp,
                                                vp, vp, vp, i64]

@@ -2584,6 +2584,26 @@ int mpx_synthesis_compressed_ola(void* stream, int fft_len, const void* tables, 
     return MPX_OK;
 }
 
+// Slot weights of k_roundtrip_pair (see mpx_synth_comp_slot_weights: pairs of the oldest / middle / youngest waves of the
+// SIMDs).  Interleaved sweeps of the configs[1] step on two boxes: equal shares 0.592 ms, 100:90:80 0.574, 100:86:73 0.567,
+// 100:82:66 0.555, 100:72:60 0.547, 100:75:55 0.539-0.545; a smallest share below ~25 frames per run (100:70:48, 100:78:50)
+// falls off a cliff (0.80 ms): the planner drops cuts that would let non-adjacent runs overlap (runs shorter than fft_len
+// output samples) and the merged runs unbalance the slots -- hence not the minimum of the sweep but a step short of it.
+#ifndef MPX_RT_W1
+#define MPX_RT_W1 77
+#endif
+#ifndef MPX_RT_W2
+#define MPX_RT_W2 58
+#endif
+int mpx_roundtrip_slot_weights(float* weights_host, int32_t n_slots) {
+    if (!weights_host || n_slots < 0) return fail(MPX_ERR_ARG, "mpx_roundtrip_slot_weights: bad arguments%s");
+    for (int s = 0; s < n_slots; ++s) {
+        const int age = ((s % kCompPairs) * 2) / 4;
+        weights_host[s] = (age == 0) ? 100.0f : ((age == 1) ? (float)MPX_RT_W1 : (float)MPX_RT_W2);
+    }
+    return MPX_OK;
+}
+
 int mpx_roundtrip_lossless_ola(void* stream, int fft_len, const void* tables, const float* sig, const int64_t* frame_pos,
                                const int32_t* frame_left, const int32_t* frame_right, int64_t n_frames,
                                const mpx_ola_run* runs, int32_t n_runs, const int32_t* slot_off, const int32_t* slot_runs,

@@ -589,15 +589,17 @@ class Engine:
         return n if not cus else max(6, min(n, 6 * int(cus)))
 
     def synth_ola_slot_weights(self, comp=False):
-        """Relative speeds of the slots of the lossless (comp=True: the compressed) synthesis kernel
-        (mpx_synth_ola_slot_weights / mpx_synth_comp_slot_weights), cached; MAGPHASE_OLA_WEIGHTS=0 -> None (equal shares)."""
+        """Relative speeds of the slots of the lossless (comp=True: the compressed, comp="roundtrip": the one-launch copy
+        synthesis) kernel (mpx_synth_ola_slot_weights / mpx_synth_comp_slot_weights / mpx_roundtrip_slot_weights), cached;
+        MAGPHASE_OLA_WEIGHTS=0 -> None (equal shares)."""
         if os.environ.get("MAGPHASE_OLA_WEIGHTS", "1") == "0":
             return None
-        key = "comp_w" if comp else "ola_w"
+        key = ("rt_w" if comp == "roundtrip" else "comp_w") if comp else "ola_w"
         if key not in self._tables:
             n = self.synth_comp_slots() if comp else self.synth_ola_slots()
             w = np.zeros(n, dtype=np.float32)
-            fn = self.lib.mpx_synth_comp_slot_weights if comp else self.lib.mpx_synth_ola_slot_weights
+            fn = (self.lib.mpx_roundtrip_slot_weights if comp == "roundtrip" else
+                  self.lib.mpx_synth_comp_slot_weights) if comp else self.lib.mpx_synth_ola_slot_weights
             _lib.check(fn(w.ctypes.data, n), "mpx_synth_*_slot_weights")
             self._tables[key] = w
         return self._tables[key]
@@ -993,9 +995,12 @@ class LosslessSynthesisPlan:
         _up.append(("pm_rel", np.concatenate(pm_rel) if pm_rel else np.zeros(0), np.int32))
         _up.append(("out_start", np.asarray(starts), np.int32))
         _up.append(("out_off", self.out_off_host, np.int64))
-        if comp_slots:
+        if comp_slots:   # True: the compressed synthesis kernel's slots and shares; "roundtrip": k_roundtrip_pair's
             n_slots = e.synth_comp_slots()
-            weights = e.synth_ola_slot_weights(comp=True)
+            weights = e.synth_ola_slot_weights(comp=comp_slots)
+            if os.environ.get("MAGPHASE_RT_WEIGHTS") and weights is not None:   # experiment: "w0,w1,w2" by age rank of the pair
+                w3 = [float(x) for x in os.environ["MAGPHASE_RT_WEIGHTS"].split(",")]
+                weights = np.asarray([w3[((i % 6) * 2) // 4] for i in range(n_slots)], dtype=np.float32)
         else:
             n_slots = e.synth_ola_slots() if hasattr(e, "synth_ola_slots") else 1024
             weights = e.synth_ola_slot_weights() if hasattr(e, "synth_ola_slot_weights") else None
@@ -1041,7 +1046,7 @@ class LosslessRoundTripPlan:
         self.analysis = LosslessAnalysisPlan(engine, utts, fft_len=fft_len)
         self.fft_len = self.analysis.fft_len
         self.synthesis = LosslessSynthesisPlan(engine, self.analysis.v_f0, self.analysis.fs, self.fft_len,
-                                               frames_per_run=frames_per_run, comp_slots=True)
+                                               frames_per_run=frames_per_run, comp_slots="roundtrip")
         if self.synthesis.total_frames != self.analysis.total_frames:
             raise ValueError("round trip: the synthesis plan must cover exactly the analysed frames")
         self.total_frames = self.analysis.total_frames

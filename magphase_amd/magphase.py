@@ -19,7 +19,8 @@ import numpy as np
 from . import hostmath as hm
 from . import libaudio as la
 from . import libutils as lu
-from .engine import (CompressedAnalysisPlan, CompressedSynthesisPlan, LosslessAnalysisPlan, LosslessSynthesisPlan,
+from .engine import (CompressedAnalysisPlan, CompressedSynthesisPlan, LosslessAnalysisPlan, LosslessRoundTripPlan,
+                     LosslessSynthesisPlan,
                      get_engine)
 
 _epoch_provider = None
@@ -299,6 +300,49 @@ def synthesis_from_lossless_batch(feats, engine=None):
 def synthesis_from_lossless(m_mag, m_real, m_imag, v_f0, fs):
     """magphase.py:1759-1776."""
     return synthesis_from_lossless_batch([(m_mag, m_real, m_imag, v_f0, fs)])[0]
+
+
+def copy_synthesis_lossless_batch(utts, fft_len=None, engine=None, return_device=False, with_feats=True):
+    """
+    analysis_lossless followed by synthesis_from_lossless on the same frames (magphase.py:2869-2906, :1759-1776: what
+    demos/demo_copy_synthesis_lossless.py:44-50 does per file) for a batch, as ONE device launch
+    (mpx_roundtrip_lossless_ola): the feature rows are written and the waveform is built from them without reading them
+    back.  utts: list of (v_sig, fs, v_pm_sec, v_voi), one fft_len per batch.  Returns a list of
+    ((m_mag, m_real, m_imag, v_f0, fs, v_shift), v_syn_sig): analysis_lossless' tuple and synthesis_from_lossless' signal,
+    float64 numpy (device tensors with return_device); with_feats=False skips the download of the three matrices
+    (None in their place) when only the waveform is wanted.
+    """
+    engine = engine or get_engine()
+    if not utts:
+        return []
+    plan = LosslessRoundTripPlan(engine, utts, fft_len=fft_len)
+    a = plan.analysis
+    for lens in a.long_frame_lens:
+        for n in lens:  # Q19: truncation warns, it does not raise (magphase.py:311-315)
+            warnings.warn(_WARN_LONG % (plan.fft_len, n))
+    (mag, real, imag), pcm = plan.run()
+    if not return_device:
+        h_feats = tuple(engine.to_host_f64_many([mag, real, imag])) if with_feats else None
+        h_pcm = engine.to_host_f64(pcm)
+    out = []
+    for u in range(len(utts)):
+        fa, fb = int(a.frame_off[u]), int(a.frame_off[u + 1])
+        oa, ob = int(plan.out_off_host[u]), int(plan.out_off_host[u + 1])
+        if return_device:
+            feats, sig = (mag[fa:fb], real[fa:fb], imag[fa:fb]), pcm[oa:ob]
+        else:
+            feats = tuple(h[fa:fb].copy() for h in h_feats) if with_feats else (None, None, None)
+            sig = h_pcm[oa:ob]
+        out.append((feats + (a.v_f0[u], a.fs[u], a.v_shift[u].astype(int)), sig))
+    return out
+
+
+def copy_synthesis_lossless(wav_file, fft_len=None):
+    """analysis_lossless(wav_file) + synthesis_from_lossless of its result in one launch: returns
+    ((m_mag, m_real, m_imag, v_f0, fs, v_shift), v_syn_sig)."""
+    v_sig, fs = la.read_audio_file(wav_file)
+    v_pm_sec, v_voi = _epochs_for(wav_file)
+    return copy_synthesis_lossless_batch([(v_sig, fs, v_pm_sec, v_voi)], fft_len=fft_len)[0]
 
 
 # ======================================================================================================

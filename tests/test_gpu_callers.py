@@ -36,6 +36,16 @@ def test_demos_and_batch_scripts(tmp_path):
     n_in, fs = _wav_len(str(wav_dir / "syn_000.wav"))
     n_out, fs2 = _wav_len(str(syn_dir / "syn_000_copy_syn_lossless.wav"))
     assert fs == fs2 == 48000 and abs(n_out - n_in) < 2000
+    # ... and as one device launch: the same wav up to one 16-bit step (float32 last bits before the rounding)
+    one_dir = tmp_path / "syn_one"
+    _run([os.path.join(ROOT, "demos", "demo_copy_synthesis_lossless.py"), "--wav", str(wav_dir / "syn_000.wav"),
+          "--out-dir", str(one_dir), "--one-launch"], ROOT)
+    import wave
+    pcm = []
+    for d in (syn_dir, one_dir):
+        with wave.open(str(d / "syn_000_copy_syn_lossless.wav")) as w:
+            pcm.append(np.frombuffer(w.readframes(w.getnframes()), dtype=np.int16).astype(np.int32))
+    assert pcm[0].size == pcm[1].size and np.max(np.abs(pcm[0] - pcm[1])) <= 1
     # low-dim copy synthesis
     _run([os.path.join(ROOT, "demos", "demo_copy_synthesis_low_dim.py"), "--wav", str(wav_dir / "syn_000.wav"),
           "--out-dir", str(syn_dir)], ROOT)

@@ -459,3 +459,25 @@ def test_round_trip_launch_edge_frames(mp, orc):
     empty = LosslessRoundTripPlan(eng, [], fft_len=4096)
     f, p = empty.run()
     assert p.numel() == 0 and f[0].shape[0] == 0
+
+
+def test_copy_synthesis_batch_api(mp, orc):
+    """magphase.copy_synthesis_lossless_batch = analysis_lossless_batch + synthesis_from_lossless_batch (one launch):
+    the same tuples, the host-side vectors (v_f0, v_shift) bit for bit, matrices and signal at the two-call tolerances."""
+    from magphase_amd import synthetic as syn
+    utts = []
+    for u in range(4):
+        pcm, pm, voi = syn.make_utterance(500 + u, dur_s=0.5 + 0.2 * u, fs=16000)
+        utts.append((syn.pcm_to_float(pcm), 16000, pm, voi))
+    got = mp.copy_synthesis_lossless_batch(utts)
+    ana = mp.analysis_lossless_batch(utts)
+    sig = mp.synthesis_from_lossless_batch([a[:5] for a in ana])
+    assert len(got) == len(utts)
+    for (f, y), a, s in zip(got, ana, sig):
+        assert np.array_equal(f[3], a[3], equal_nan=True) and f[4] == a[4] and np.array_equal(f[5], a[5])
+        _check_feats(f[:3], tuple(np.asarray(x, dtype=np.float64) for x in a[:3]))
+        assert y.shape == s.shape and y.dtype == np.float64
+        within(np.max(np.abs(y - s)) / np.max(np.abs(s)), PCM_TOL, "PCM_TOL:copy-synthesis-api")
+    only = mp.copy_synthesis_lossless_batch(utts[:1], with_feats=False)
+    assert only[0][0][0] is None and np.array_equal(only[0][1], mp.copy_synthesis_lossless_batch(utts[:1])[0][1])
+    assert mp.copy_synthesis_lossless_batch([]) == []
