@@ -85,6 +85,7 @@ def main():
     names = [parse(a)[0] for a in args] or ["cur"]
     rounds = int(os.environ.get("AB_ROUNDS", "15"))
     lowdim = os.environ.get("AB_WORKLOAD", "lossless") == "lowdim"
+    roundtrip = os.environ.get("AB_WORKLOAD", "lossless") == "roundtrip"   # the one-launch copy synthesis (first column)
     torch.cuda.set_device(0)
     utts = bench.make_batch(0)
     if os.environ.get("AB_FS"):   # other sample rates / batch sizes: AB_FS=16000 AB_UTTS=128 (the N = 2048 kernels)
@@ -111,6 +112,11 @@ def main():
             strips = eng.empty((max(splan.strip_floats, 1) + 65536,))   # per variant: its size follows the variant's slot count
             steps[name] = (lambda aplan=aplan, feats=feats: aplan.run(out=feats),
                            lambda splan=splan, feats=feats, strips=strips, pcm=pcm: splan.run(feats[0], feats[1], feats[2], strips=strips, out=pcm))
+            if roundtrip:
+                rt = em.LosslessRoundTripPlan(eng, utts)
+                rstrips = eng.empty((max(rt.synthesis.strip_floats, 1) + 65536,))
+                steps[name] = (lambda rt=rt, feats=feats, rstrips=rstrips, pcm=pcm: rt.run(feats=feats, strips=rstrips, out=pcm),
+                               steps[name][1])
         else:
             if shared is None:
                 shared = {}
