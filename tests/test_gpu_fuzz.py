@@ -23,7 +23,8 @@ def test_fixed_seed_fuzz_slice_against_oracle():
     worst, bad, residue = fz.run(n_batches=20, seed=20260929, verbose=False)
     # this fixed-seed slice's own bounds (<= 3 x its measured worst: 6.4e-6 / 8.0e-7 / 6.1e-7 / 2.7e-7 / 3.0e-7); the tool's
     # LIMITS are those of the open-ended sweep (worst of 340 batches: 4.1e-5 on the magnitudes)
-    slice_limits = {"mag": 2e-5, "phase": 2.4e-6, "pcm": 1.8e-6, "lossless_feat": 8e-7, "lossless_pcm": 9e-7}
+    slice_limits = {"mag": 2e-5, "phase": 2.4e-6, "pcm": 1.8e-6, "lossless_feat": 8e-7, "lossless_pcm": 9e-7,
+                    "roundtrip_feat": 8e-7, "roundtrip_pcm": 9e-7}   # the one-launch copy synthesis: the two-launch bounds
     for k, v in worst.items():
         within(v, min(fz.LIMITS[k], slice_limits[k]), "FUZZ:" + k)
     assert not bad and residue == 0, (worst, bad, residue)   # round 4: no utterance left at "numpy's rounding residue"

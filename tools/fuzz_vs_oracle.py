@@ -24,7 +24,17 @@ from magphase_amd import magphase as mp, synthetic as syn  # noqa: E402
 # tests/test_gpu_compressed.py (round 4, 150 batches: worst 6.5e-6 -- 4.1e-5 in round 3, before the fused kernel and numpy's window weights); phases 8.3e-7, PCM 7.3e-7 of peak
 WARP_TOL, WARP_PHASE_TOL, COMP_PCM_TOL, LOSSLESS_TOL = 2.5e-5, 3e-6, 3e-6, 2e-6
 LIMITS = {"mag": WARP_TOL, "phase": WARP_PHASE_TOL, "pcm": COMP_PCM_TOL, "lossless_feat": LOSSLESS_TOL,
-          "lossless_pcm": LOSSLESS_TOL}
+          "lossless_pcm": LOSSLESS_TOL, "roundtrip_feat": LOSSLESS_TOL, "roundtrip_pcm": LOSSLESS_TOL}
+
+
+def _roundtrip_leg(mp, orc, utts, lo, fs, worst, tag, fft_len=None):
+    """The one-launch copy synthesis (mpx_roundtrip_lossless_ola) against the oracle's analysis + synthesis."""
+    for (f, y), o in zip(mp.copy_synthesis_lossless_batch(utts, fft_len=fft_len), lo):
+        worst["roundtrip_feat"] = max(worst["roundtrip_feat"], float(np.max(np.abs(f[0] - o[0])) / np.max(o[0])))
+        assert np.array_equal(f[3], o[3]) and np.array_equal(f[5], o[5]), tag
+        r = orc.synthesis_from_lossless(o[0], o[1], o[2], o[3], fs)
+        assert len(y) == len(r), tag
+        worst["roundtrip_pcm"] = max(worst["roundtrip_pcm"], float(np.max(np.abs(y - r)) / np.max(np.abs(r))))
 MAX_UTTS = int(os.environ.get("FUZZ_UTTS", "4"))
 DUR = tuple(float(v) for v in os.environ.get("FUZZ_DUR", "0.25,1.3").split(","))   # utterance length range, seconds
 
@@ -59,7 +69,8 @@ def run(n_batches=12, seed=0, verbose=True):
     """The sweep; returns (worst error per quantity, quantities over their bound, utterances with a bin at numpy's
     rounding residue).  tests/test_gpu_fuzz.py runs a fixed-seed slice of it under -m gpu."""
     rng = np.random.RandomState(int(seed))
-    worst = {"mag": 0.0, "phase": 0.0, "pcm": 0.0, "lossless_feat": 0.0, "lossless_pcm": 0.0}
+    worst = {"mag": 0.0, "phase": 0.0, "pcm": 0.0, "lossless_feat": 0.0, "lossless_pcm": 0.0, "roundtrip_feat": 0.0,
+             "roundtrip_pcm": 0.0}
     bad, residue = [], 0
     for b in range(n_batches):
         fs = int(rng.choice([8000, 16000, 22050, 44100, 48000]))
@@ -92,6 +103,7 @@ def run(n_batches=12, seed=0, verbose=True):
                     r = orc.synthesis_from_lossless(o[0], o[1], o[2], o[3], fs)
                     assert len(a) == len(r), tag
                     worst["lossless_pcm"] = max(worst["lossless_pcm"], float(np.max(np.abs(a - r)) / np.max(np.abs(r))))
+                _roundtrip_leg(mp, orc, utts, lo, fs, worst, tag, fft_len=1024)
                 if verbose:
                     print(tag + " (lossless only): ok", flush=True)
                 continue
@@ -142,6 +154,7 @@ def run(n_batches=12, seed=0, verbose=True):
                 r = orc.synthesis_from_lossless(o[0], o[1], o[2], o[3], fs)
                 assert len(a) == len(r), tag
                 worst["lossless_pcm"] = max(worst["lossless_pcm"], float(np.max(np.abs(a - r)) / np.max(np.abs(r))))
+            _roundtrip_leg(mp, orc, utts, lo, fs, worst, tag)
         if verbose:
             print(tag + ": ok   " + "  ".join("%s %.2e" % kv for kv in worst.items()), flush=True)
     bad = [k for k in worst if worst[k] > LIMITS[k]]
