@@ -39,7 +39,17 @@ for f in sorted(glob.glob(os.path.join(d, "pmc_*", "**", "*counter_collection.cs
     for k, cs in agg.items():
         out.setdefault(k, {}).update({c: sum(v) / len(v) for c, v in cs.items()})
         launches[k] = max(launches.get(k, 0), max(len(v) for v in cs.values()))
-json.dump(out, open(os.path.join(d, "pmc_summary.json"), "w"), indent=1)
+if not out:   # no counter files here (tools/profile_round.sh deletes them after summarising on the GPU box): install-only
+    # mode -- work from the summary written there instead of overwriting it with an empty one
+    prev = os.path.join(d, "pmc_summary.json")
+    if not os.path.exists(prev) or not json.load(open(prev)):
+        sys.exit("pmc_summary: no counter_collection.csv under %s/pmc_* and no earlier summary" % d)
+    out = json.load(open(prev))
+    launches = {k: int(v.get("_launches", 1)) for k, v in out.items()}
+else:
+    for k in out:
+        out[k]["_launches"] = launches[k]
+    json.dump(out, open(os.path.join(d, "pmc_summary.json"), "w"), indent=1)
 
 import bench  # noqa: E402
 

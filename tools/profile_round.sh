@@ -17,9 +17,11 @@ cd /tmp && export TMPDIR=/tmp
 if [ -z "$SKIP_BENCH" ]; then
   (cd $R && timeout 1200 python bench.py > $O/bench.json 2> $O/bench.err)
 fi
+if [ -z "$SKIP_STATS" ]; then
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o ks -- python $R/bench.py --steps 40 --warmup 5 --streams 1 --no-idle-probe --no-power --no-cpu-baseline --no-e2e --traffic none > $O/stats.log 2>&1
 cp $(find $O/stats -name '*kernel_stats.csv' | head -1) $O/kernel_stats.csv
 grep '^{"metric"' $O/stats.log | tail -1 > $O/bench_profiled.json
+fi
 for c in "FETCH_SIZE" "WRITE_SIZE" \
          "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
          "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_ANY SQ_INSTS_SALU SQ_INSTS_VMEM SQ_WAIT_INST_LDS" \
