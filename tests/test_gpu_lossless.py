@@ -157,9 +157,11 @@ def test_batch_equals_single_and_is_deterministic(mp):
         assert np.array_equal(syn1[u], syn2[u])
 
 
-def test_full_size_config2_roundtrip_property(mp, orc):
+@pytest.mark.parametrize("form", ["two_launches", "one_launch"])
+def test_full_size_config2_roundtrip_property(mp, orc, form):
     """
-    BASELINE config 2 size (64 x 5 s @ 48 kHz, N=4096) on the device-resident batch path:
+    BASELINE config 2 size (64 x 5 s @ 48 kHz, N=4096) on the device-resident batch path, as analysis + synthesis
+    launches and as the one-launch copy synthesis (mpx_roundtrip_lossless_ola, bench.py's default form):
       (1) perfect-reconstruction property (Hann halves are complementary) wherever the synthesis epochs equal
           the analysis epochs (Q2: cumsum(fs/f0) truncation moves ~0.01 % of epochs by one sample -- the
           reference has the same behaviour, those neighbourhoods are excluded);
@@ -167,16 +169,21 @@ def test_full_size_config2_roundtrip_property(mp, orc):
     """
     import torch
     from magphase_amd import synthetic as syn
-    from magphase_amd.engine import LosslessAnalysisPlan, LosslessSynthesisPlan, get_engine
+    from magphase_amd.engine import LosslessAnalysisPlan, LosslessRoundTripPlan, LosslessSynthesisPlan, get_engine
     eng = get_engine()
     utts = []
     for u in range(64):
         pcm, pm, voi = syn.make_utterance(u, dur_s=5.0, fs=48000)
         utts.append((pcm, 48000, pm, voi))
-    plan = LosslessAnalysisPlan(eng, utts)
-    mag, real, imag = plan.run()
-    splan = LosslessSynthesisPlan(eng, plan.v_f0, plan.fs, plan.fft_len)
-    pcm_out = splan.run(mag, real, imag)
+    if form == "one_launch":
+        rt = LosslessRoundTripPlan(eng, utts)
+        plan, splan = rt.analysis, rt.synthesis
+        (mag, real, imag), pcm_out = rt.run()
+    else:
+        plan = LosslessAnalysisPlan(eng, utts)
+        mag, real, imag = plan.run()
+        splan = LosslessSynthesisPlan(eng, plan.v_f0, plan.fs, plan.fft_len)
+        pcm_out = splan.run(mag, real, imag)
     torch.cuda.synchronize()
     assert plan.total_frames == splan.total_frames > 50000
     out = pcm_out.cpu().numpy().astype(np.float64)
