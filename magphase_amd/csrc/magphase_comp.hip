@@ -1564,6 +1564,29 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_synth_comp_pair(const f
 // transform).  Both are held to the two-launch path's tolerances against the oracle.
 // Every frame index of [0, n_frames) must belong to exactly one run: a frame outside the runs is not analysed.
 // ---------------------------------------------------------------------------------------------
+#ifdef MPX_PROBE_RT   // probe build (tools/roundtrip_phase_probe.py): per wave, start / end on the 100 MHz clock, frames,
+// shader cycles, and the s_memtime ticks spent in 8 phases of the frame loop (accumulated in LDS, written out at the end)
+__device__ unsigned long long g_rt_end[4 * 8192];
+__device__ unsigned long long g_rt_phase[8 * 8192];
+#define MPX_RT_PHASE(i)                                                        \
+    do {                                                                       \
+        const unsigned t_ = (unsigned)clock64();                               \
+        if (lane_id == 0) atomicAdd(probe_ph + (i), t_ - probe_last);          \
+        probe_last = t_;                                                       \
+    } while (0)
+#define MPX_RT_F8(a, o) "+v"(a[o]), "+v"(a[o + 1]), "+v"(a[o + 2]), "+v"(a[o + 3]), "+v"(a[o + 4]), "+v"(a[o + 5]), "+v"(a[o + 6]), "+v"(a[o + 7])
+#define MPX_RT_PIN()                                                                      \
+    do {   /* pin the 64 values here, or the clock read floats above / below the arithmetic */ \
+        if constexpr (P == 32) {                                                          \
+            asm volatile("" : MPX_RT_F8(xr, 0), MPX_RT_F8(xr, 8), MPX_RT_F8(xr, 16));     \
+            asm volatile("" : MPX_RT_F8(xr, 24), MPX_RT_F8(xi, 0), MPX_RT_F8(xi, 8));     \
+            asm volatile("" : MPX_RT_F8(xi, 16), MPX_RT_F8(xi, 24));                      \
+        }                                                                                 \
+    } while (0)
+#else
+#define MPX_RT_PHASE(i) do { } while (0)
+#define MPX_RT_PIN() do { } while (0)
+#endif
 template <int P>
 __global__ __launch_bounds__(kCompPairWaves * 64) void k_roundtrip_pair(const float* __restrict__ sig,
                                                                        const long long* __restrict__ fpos,
@@ -1658,6 +1681,14 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_roundtrip_pair(const fl
     constexpr int kTile = kCompact ? 32 * P : 64 * P;
     FrameGeom g = frame_geom(sig, fpos[cur.fi], fleft[cur.fi], fright[cur.fi], N);
     stage_samples_async(g, 0, kTile, xbuf_byte, lane_id);
+#ifdef MPX_PROBE_RT
+    const unsigned long long probe_t0 = wall_clock64();
+    const unsigned long long probe_c0 = clock64();
+    int probe_frames = 0;
+    unsigned* probe_ph = reinterpret_cast<unsigned*>(smem + kRing0 + kCompPairs * R + 16) + 8 * wave;
+    if (lane_id < 8) probe_ph[lane_id] = 0;
+    unsigned probe_last = (unsigned)probe_c0;
+#endif
 
     while (cur.valid) {
         int lane = lane_id;
@@ -1672,12 +1703,16 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_roundtrip_pair(const fl
         Cursor nxt = cur;
         advance(nxt);
         const int fi = cur.fi;
+#ifdef MPX_PROBE_RT
+        probe_last = (unsigned)clock64();
+#endif
 
         float xr[P], xi[P];
         {
             // ---- analysis: X[k] of the own bins k = lane + 64 q and of their mirrors M - k, bin M/2 on lane 0
             float no_r[HP], no_i[HP], nm_r[HP], nm_i[HP], nh_r, nh_i;
             staged_wait<0>();
+            MPX_RT_PHASE(0);   // wait for the staged samples (gfx9's one counter: and for the previous frame's stores)
             noise_spectrum_paired<P, true, kCompact>(g, 0, tw, xbuf, xbuf_byte, lane, wa_c, wa_s, no_r, no_i, nm_r, nm_i, nh_r,
                                                      nh_i, lc, ls);
             if (P != 32) {   // FFT output lanes hold bins kappa(lane) + 64 q; the rows and the merge want bins lane + 64 q
@@ -1692,6 +1727,7 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_roundtrip_pair(const fl
                 nh_r = __shfl(nh_r, src);
                 nh_i = __shfl(nh_i, src);
             }
+            MPX_RT_PHASE(1);   // window + gather + forward transform + split
             // ---- per bin pair q: lossless features (magphase.py:466-474; as k_analysis: X == 0 -> all three 0), their
             // stores, and the pair's step of the Hermitian merge -- feat_merge_paired's arithmetic on the values just
             // stored (X = mag (R + jI) / |R + jI|, magphase.py:1761-1766), pair by pair so that a pair's four inputs die
@@ -1785,6 +1821,8 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_roundtrip_pair(const fl
                 xi[r] = __shfl(pi, src_lane);
             }
         }
+        MPX_RT_PIN();
+        MPX_RT_PHASE(2);   // features + stores + Hermitian merge
         constexpr bool kDit = kCompact && MPX_COMP_DIT;
         if constexpr (kDit) {
             constexpr int LBJ = ilog2(P);
@@ -1814,6 +1852,8 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_roundtrip_pair(const fl
         }
         if constexpr (kDit) wave_fft_dit_back<P, +1>(xr, xi);
         else fft_inreg<P, +1>(xr, xi);
+        MPX_RT_PIN();
+        MPX_RT_PHASE(3);   // inverse transform (+ issue of the next frame's staging)
 
         // ---- ordered section: wait for this frame's ticket
         const RunDesc rd = runs[cur.ci];
@@ -1827,8 +1867,10 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_roundtrip_pair(const fl
         while (__hip_atomic_load(turn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != ticket)
             __builtin_amdgcn_s_sleep(1);
         asm volatile("" ::: "memory");
+        MPX_RT_PHASE(4);   // run / position scalars + ticket wait
         if (flushed < target) flush_ring<R>(ring, strip, pcm0, rd.head_end, rd.out_lo, rd.out_hi, flushed, target, lane);
         wave_sync();
+        MPX_RT_PHASE(5);   // flush of the finished samples
         auto plain_add = [](float o, float v, int) { return o + v; };
         auto all_rows = [](int) { return true; };
         if constexpr (kCompPairWaves > 8) {   // 16 ring values in registers at a time (<= 168 VGPRs)
@@ -1845,9 +1887,24 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_roundtrip_pair(const fl
             wave_sync();
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        MPX_RT_PHASE(6);   // overlap-add (+ the run's final flush)
         __hip_atomic_store(turn, ticket + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         cur = nxt;
+#ifdef MPX_PROBE_RT
+        ++probe_frames;
+#endif
     }
+#ifdef MPX_PROBE_RT
+    if (lane_id == 0) {
+        const int w = (blockIdx.x * kCompPairWaves + wave) % 8192;
+        g_rt_end[4 * w + 0] = probe_t0;
+        g_rt_end[4 * w + 1] = wall_clock64();
+        g_rt_end[4 * w + 2] = (unsigned long long)probe_frames;
+        g_rt_end[4 * w + 3] = clock64() - probe_c0;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        for (int i = 0; i < 8; ++i) g_rt_phase[8 * w + i] = probe_ph[i];
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2587,13 +2644,16 @@ int mpx_synthesis_compressed_ola(void* stream, int fft_len, const void* tables, 
 // Slot weights of k_roundtrip_pair (see mpx_synth_comp_slot_weights: pairs of the oldest / middle / youngest waves of the
 // SIMDs).  Interleaved sweeps of the configs[1] step on two boxes: equal shares 0.592 ms, 100:90:80 0.574, 100:86:73 0.567,
 // 100:82:66 0.555, 100:72:60 0.547, 100:75:55 0.539-0.545; a smallest share below ~25 frames per run (100:70:48, 100:78:50)
-// falls off a cliff (0.80 ms): the planner drops cuts that would let non-adjacent runs overlap (runs shorter than fft_len
-// output samples) and the merged runs unbalance the slots -- hence not the minimum of the sweep but a step short of it.
+// fell off a cliff (0.80 ms) while the planner DROPPED cuts that would let non-adjacent runs overlap (runs shorter than
+// fft_len output samples: one slot idle, its neighbour with twice the frames).  It now moves such a cut forward
+// (hostmath._enforce_span); on that planner, another box: 100:77:58 0.522, 100:75:55 0.523, 100:72:52 0.512, 100:71:49 0.511,
+// 100:68:46 0.516, 100:65:42 0.527, 100:60:38 0.548 -- the per-frame times by age (tools/roundtrip_phase_probe.py: 22.5 /
+// 31.6 / 46.3 us) say 100:71:49.
 #ifndef MPX_RT_W1
-#define MPX_RT_W1 77
+#define MPX_RT_W1 71
 #endif
 #ifndef MPX_RT_W2
-#define MPX_RT_W2 58
+#define MPX_RT_W2 50
 #endif
 int mpx_roundtrip_slot_weights(float* weights_host, int32_t n_slots) {
     if (!weights_host || n_slots < 0) return fail(MPX_ERR_ARG, "mpx_roundtrip_slot_weights: bad arguments%s");
@@ -2604,6 +2664,17 @@ int mpx_roundtrip_slot_weights(float* weights_host, int32_t n_slots) {
     return MPX_OK;
 }
 
+#ifdef MPX_PROBE_RT
+constexpr size_t kRtProbeBytes = 4 * 8 * kCompPairWaves;
+int mpx_probe_roundtrip(unsigned long long* host_end, unsigned long long* host_phase, int n_waves) {   // probe builds only
+    MPX_HIP_CHECK(hipDeviceSynchronize());
+    MPX_HIP_CHECK(hipMemcpyFromSymbol(host_end, HIP_SYMBOL(g_rt_end), sizeof(unsigned long long) * 4 * (size_t)n_waves));
+    MPX_HIP_CHECK(hipMemcpyFromSymbol(host_phase, HIP_SYMBOL(g_rt_phase), sizeof(unsigned long long) * 8 * (size_t)n_waves));
+    return MPX_OK;
+}
+#else
+constexpr size_t kRtProbeBytes = 0;
+#endif
 int mpx_roundtrip_lossless_ola(void* stream, int fft_len, const void* tables, const float* sig, const int64_t* frame_pos,
                                const int32_t* frame_left, const int32_t* frame_right, int64_t n_frames,
                                const mpx_ola_run* runs, int32_t n_runs, const int32_t* slot_off, const int32_t* slot_runs,
@@ -2621,8 +2692,8 @@ int mpx_roundtrip_lossless_ola(void* stream, int fft_len, const void* tables, co
     const dim3 pgrid((n_slots + kCompPairs - 1) / kCompPairs), pblock(kCompPairWaves * 64);
 #define MPX_LAUNCH_RT(PP)                                                                                              \
     do {                                                                                                             \
-        if (int rc = set_lds(k_roundtrip_pair<PP>, lds_bytes_comp_pair<PP>())) return rc;                            \
-        hipLaunchKernelGGL(k_roundtrip_pair<PP>, pgrid, pblock, lds_bytes_comp_pair<PP>(), s, sig,                   \
+        if (int rc = set_lds(k_roundtrip_pair<PP>, lds_bytes_comp_pair<PP>() + kRtProbeBytes)) return rc;            \
+        hipLaunchKernelGGL(k_roundtrip_pair<PP>, pgrid, pblock, lds_bytes_comp_pair<PP>() + kRtProbeBytes, s, sig,   \
                            (const long long*)frame_pos, frame_left, frame_right, (const RunDesc*)runs, slot_off,     \
                            slot_runs, (int)n_slots, pm_rel, (const float*)tables, out_mag, out_real, out_imag, strips, \
                            pcm_out, (long long)ld);                                                                  \

@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <algorithm>
 #include <vector>
 
 #include "../../include/magphase_hip.h"
@@ -262,12 +263,24 @@ int64_t mpx_host_ola_runs(int32_t n_utts, const int64_t* pm_rel, const int64_t* 
         for (int64_t g = 0; g < n_gcuts; ++g)
             if (gcuts[g] > f_base && gcuts[g] < f_base + n) cuts.push_back(gcuts[g] - f_base);
         cuts.push_back(n);
-        // _enforce_span: a run with both neighbours must satisfy rel[next run's first] - rel[own first - 1] >= N
+        // _enforce_span (hostmath.py): a run with both neighbours must satisfy rel[next run's first] - rel[own first - 1]
+        // >= N; a cut that comes too early moves forward to the first frame that is far enough if that leaves its
+        // successor a frame, otherwise it is dropped (the run grows into its successor)
         {
             size_t k = 1;
             while (k + 2 < cuts.size()) {
-                if (rel[cuts[k + 1]] - rel[cuts[k] - 1] < N) cuts.erase(cuts.begin() + (long)(k + 1));
-                else ++k;
+                const int64_t need = rel[cuts[k] - 1] + N;
+                if (rel[cuts[k + 1]] < need) {
+                    const int64_t c2 = std::lower_bound(rel, rel + n, need) - rel;   // rel ascends within an utterance
+                    if (c2 < cuts[k + 2]) {
+                        cuts[k + 1] = c2;
+                        ++k;
+                    } else {
+                        cuts.erase(cuts.begin() + (long)(k + 1));
+                    }
+                } else {
+                    ++k;
+                }
             }
         }
         const int64_t k = (int64_t)cuts.size() - 1;

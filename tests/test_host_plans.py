@@ -332,3 +332,35 @@ def test_hann_half_table_layout_matches_the_references_window():
         k = np.arange(left + right + 1)
         w = np.where(k <= left, tl[np.minimum(k, left)], tr[np.clip(left + right - k, 0, right)])   # the kernels' indexing
         assert np.array_equal(w, orc.half_windows(left, right)), (left, right)
+
+
+def test_too_early_cuts_move_forward_instead_of_merging_runs():
+    """hostmath._enforce_span (and its native twin): a run with both neighbours must span >= N output samples between
+    its predecessor's last frame and its successor's first.  A cut that violates it is moved to the first frame that
+    satisfies it -- the slot keeps a run -- and dropped only when its successor has no such frame."""
+    rng = np.random.RandomState(8)
+    N = 4096
+    rel = np.cumsum(rng.randint(150, 260, 3000))                 # high-pitched: ~20 frames per N samples
+    cuts = np.arange(0, 3001, 12)                                 # 12-frame shares: every cut comes too early
+    out = hm._enforce_span(rel, N, cuts)
+    assert out[0] == 0 and out[-1] == 3000 and np.all(np.diff(out) > 0)
+    for k in range(1, len(out) - 2):
+        assert rel[out[k + 1]] - rel[out[k] - 1] >= N
+    dropped_all = []                                              # the round-3 rule, for comparison
+    c = [int(x) for x in cuts]
+    k = 1
+    while k < len(c) - 2:
+        if rel[c[k + 1]] - rel[c[k] - 1] < N:
+            del c[k + 1]
+        else:
+            k += 1
+    dropped_all = c
+    assert len(out) >= len(dropped_all)                           # never fewer runs than dropping gives
+    lens_new, lens_old = np.diff(out), np.diff(dropped_all)
+    assert lens_new[1:-1].max() <= lens_old[1:-1].max()           # and no longer ones
+    # cuts that already satisfy the condition are left alone
+    wide = np.arange(0, 3001, 100)
+    assert np.array_equal(hm._enforce_span(rel, N, wide), wide)
+    # no frame of the successor far enough: the cut is dropped, as before
+    rel2 = np.array([0, 10, 20, 30, 40, 50, 5000, 5010])
+    assert np.array_equal(hm._enforce_span(rel2, N, np.array([0, 2, 4, 6, 8])), np.array([0, 2, 6, 8]))
