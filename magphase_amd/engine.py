@@ -1000,6 +1000,7 @@ class LosslessSynthesisPlan:
             weights = e.synth_ola_slot_weights(comp=comp_slots)
             if os.environ.get("MAGPHASE_RT_WEIGHTS") and weights is not None:   # experiment: "w0,w1,w2" by age rank of the pair
                 w3 = [float(x) for x in os.environ["MAGPHASE_RT_WEIGHTS"].split(",")]
+                # (6 wave pairs per 12-wave workgroup; pairs 0-1 / 2-3 / 4-5 hold the oldest / middle / youngest waves)
                 weights = np.asarray([w3[((i % 6) * 2) // 4] for i in range(n_slots)], dtype=np.float32)
         else:
             n_slots = e.synth_ola_slots() if hasattr(e, "synth_ola_slots") else 1024
