@@ -281,12 +281,12 @@ class _Marks:
 def pick_streams(n, enqueue, steps=24, tries=1):
     """
     n HIP streams that really run side by side.  HIP multiplexes its streams onto a few hardware queues (4 by default) and
-    two streams that land on the same queue serialise (tools/stream_pair_probe.py: of the pairs among 8 streams about one
+    two streams that land on the same queue serialise (tools/archive/stream_pair_probe.py: of the pairs among 8 streams about one
     in four does) -- which streams share a queue is not something the API tells.  So: time `steps` steps on one stream,
     then draw streams until alternating between the candidate and EVERY chosen stream is faster than one stream alone
     (two streams on one queue: 3-4 % slower than one stream; on two queues: 0.5-6 % faster, depending on the box); if none
     is after `tries` draws, the best candidate is taken.  Since round 4 `tries` is 1: the FIRST pair of fresh streams is
-    used whatever it measures (12 of 12 fresh pairs overlapped on the round-4 boxes, tools/stream_priority_probe.py; a benchmark
+    used whatever it measures (12 of 12 fresh pairs overlapped on the round-4 boxes, tools/archive/stream_priority_probe.py; a benchmark
     should not re-draw its own configuration) -- the probe only REPORTS whether the pair overlaps (`stream_pick`).
     enqueue(stream, k): enqueue one step on `stream` with buffer set k.  Returns (streams, report).
     """
@@ -535,7 +535,7 @@ def measure_e2e(utts):
 def measure_ceilings(eng):
     """
     What THIS device sustains for a plain streaming read, fill and copy of 1 GiB (mpx_bw_probe: float4 kernels in
-    mpx_bw_probe_shapes() launch shapes -- grid x block, accesses in flight per lane, non-temporal bit; tools/bw_sweep.hip),
+    mpx_bw_probe_shapes() launch shapes -- grid x block, accesses in flight per lane, non-temporal bit; tools/archive/bw_sweep.hip),
     timed with HIP events in this process: the "measured device copy-kernel ceiling" of SURVEY.md 8(d), quoted in the
     roofline object beside the 8 TB/s spec peak.  Per kind: the BEST shape's median of 5 launches after 2 warm-ups (round 3
     quoted one shape, 2048 x 256 with one access in flight, which under-drives fills and copies).
@@ -552,7 +552,7 @@ def measure_ceilings(eng):
     b.zero_()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     n_shapes = int(eng.lib.mpx_bw_probe_shapes())
-    out = {"bytes": 4 * n, "how": "mpx_bw_probe over 1 GiB in %d launch shapes (tools/bw_sweep.hip), HIP events, best shape's "
+    out = {"bytes": 4 * n, "how": "mpx_bw_probe over 1 GiB in %d launch shapes (tools/archive/bw_sweep.hip), HIP events, best shape's "
                                   "median of 5 launches after 2 warm-ups, this process, this device" % n_shapes}
     with torch.cuda.device(eng.device):
         for kind, name, nbytes in ((0, "read", 4.0 * n), (1, "write", 4.0 * n), (2, "copy", 8.0 * n)):
@@ -876,6 +876,9 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # rank 0 measures its CPU baseline, PMC traffic and the configs[2] / e2e blocks AFTER the timed region while the
+        # other ranks wait in the closing barrier: minutes, not the default collective timeout
+        PG_TIMEOUT = datetime.timedelta(seconds=2400)
         if args.gpus != world and rank == 0:
             sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d: the launcher's world size is what runs\n" % (args.gpus, world))
         if not os.environ.get("BENCH_SHARE_DEVICE") and torch.cuda.device_count() <= dev_index:
@@ -883,8 +886,7 @@ def main():
         torch.cuda.set_device(dev_index)
         if backend == "nccl":   # "nccl" is RCCL on ROCm; only the barrier and two scalar reductions use it -- nothing on the
             try:                # data path -- so a node whose RCCL cannot initialise still runs, over gloo
-                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index),
-                                        timeout=datetime.timedelta(seconds=180))
+                dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index), timeout=PG_TIMEOUT)
                 probe = torch.zeros(1, device="cuda")
                 dist.all_reduce(probe)
                 torch.cuda.synchronize()
@@ -896,9 +898,9 @@ def main():
                     pass
                 os.environ["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1)
                 backend = "gloo"
-                dist.init_process_group(backend="gloo")
+                dist.init_process_group(backend="gloo", timeout=PG_TIMEOUT)
         else:
-            dist.init_process_group(backend=backend)
+            dist.init_process_group(backend=backend, timeout=PG_TIMEOUT)
     else:
         dist = None
         torch.cuda.set_device(0)
@@ -1008,7 +1010,7 @@ def main():
         return time.perf_counter() - t
 
     # The plans above were built on the host with the GPU idle, and a GPU coming out of idle goes through a power-management
-    # transient of about 30 ms of busy time (tools/step_curve_probe.py: the analysis launch runs 0.31 -> 0.41 -> 0.30 ms over
+    # transient of about 30 ms of busy time (tools/archive/step_curve_probe.py: the analysis launch runs 0.31 -> 0.41 -> 0.30 ms over
     # the first ~40 steps, after ANY idle period, whatever ran before it).  A corpus job is never in that state, so the
     # device is taken out of it before the W warm-up steps; `ms_per_step_from_idle` below is the same W + K steps started
     # 0.5 s after the last launch, for the record.
@@ -1048,6 +1050,7 @@ def main():
             xp.run()
         torch.cuda.synchronize()
         return
+    dt_own = dt
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -1110,7 +1113,38 @@ def main():
     names = [k["name"] for k in kern]
     kern_other, ms_other, alg_other = kernel_rows(not one)
     dom = int(np.argmax(ms[:-1]))
-    full = rank == 0 and world == 1 and not args.quick
+    full = rank == 0 and not args.quick
+    # ---- per rank (every rank of an N > 1 run measures these on ITS device; rank 0 gathers them into `per_rank`): the
+    # rank's own time for the K steps, its dominant kernel's duration (HIP events above), the board power of its device
+    # while the headline step loops.  The reference's model is one worker per utterance with nothing shared
+    # (libutils.py:32-63); the N > 1 line says how even the ranks are.
+    moved_dom = kern[dom].get("moved_bytes", alg[dom])     # bytes the dominant launch has to move (== alg for two launches)
+    rank_power = None
+    if not args.quick and not args.no_power:
+        try:
+            rank_power = measure_power(torch, dev_index, (("headline_step", lambda: step_form(*bufs[0])),), seconds=1.2)
+        except Exception:
+            rank_power = None
+    rp = (rank_power or {}).get("phases", {}).get("headline_step", {})
+    mine = [float(rank), float(dev_index), dt_own / args.steps * 1e3, ms[dom], moved_dom / (ms[dom] * 1e-3) / 1e9,
+            alg[dom] / (ms[dom] * 1e-3) / 1e9, float(F), rp.get("board_W") or float("nan"),
+            rp.get("energy_above_idle_J") or float("nan"), rp.get("frac_of_cap") or float("nan")]
+    if dist is not None:
+        mt = torch.tensor(mine, dtype=torch.float64, device=red_dev)
+        allr = [torch.zeros_like(mt) for _ in range(world)]
+        dist.all_gather(allr, mt)
+        allr = [[float(v) for v in t_.cpu().tolist()] for t_ in allr]
+    else:
+        allr = [mine]
+
+    def _num(v, nd):
+        return None if v != v else round(v, nd)
+
+    per_rank = [{"rank": int(r_[0]), "device": int(r_[1]), "ms_per_step": _num(r_[2], 4), "kernel": names[dom],
+                 "kernel_ms": _num(r_[3], 4), "moved_GBps": _num(r_[4], 1), "frac": _num(r_[4] / HBM_PEAK_GBS, 4),
+                 "alg_8d_GBps": _num(r_[5], 1), "frac_8d": _num(r_[5] / HBM_PEAK_GBS, 4), "frames": int(r_[6]),
+                 "board_W": _num(r_[7], 1), "energy_above_idle_J": _num(r_[8], 4), "frac_of_cap": _num(r_[9], 3)}
+                for r_ in allr]
     live, live_src = (live_traffic() if (full and args.traffic == "live") else (None, "not requested"))
     if live is not None and names[dom] in live:
         traffic, traffic_src = live[names[dom]], live_src
@@ -1123,17 +1157,27 @@ def main():
         traffic, traffic_src = _committed_traffic(names[dom])
         if live is None and args.traffic == "live" and full:
             traffic_src += " (live passes: %s)" % live_src
-    roof = {"bound": "hbm", "kernel": names[dom], "achieved": kern[dom]["alg_GBps"], "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": round(kern[dom]["alg_GBps"] / HBM_PEAK_GBS, 4), "traffic": traffic,
-            "traffic_source": traffic_src,
+    # The headline fraction is what the launch MOVES over its duration against 8 TB/s.  A fused launch (the one-launch
+    # step) does not read its feature rows back, so it moves 12 H + 8 S per frame; SURVEY 8d's per-frame figure
+    # (24 H + 8 S: rows written once AND read once) is kept beside it as achieved_8d / frac_8d -- for the two-launch
+    # form the two are the same number.
+    moved_GBps = round(moved_dom / (ms[dom] * 1e-3) / 1e9, 1)
+    fr_ = [r_["frac"] for r_ in per_rank if r_["frac"] is not None]
+    roof = {"bound": "hbm", "kernel": names[dom], "achieved": moved_GBps, "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(moved_GBps / HBM_PEAK_GBS, 4),
+            "frac_definition": "moved_bytes / kernel time / peak (bytes the launch has to move: rows written once, samples in "
+                               "and out); frac_8d prices the launch at SURVEY 8d's analysis + synthesis bytes (rows written "
+                               "once and read once), which a fused launch does not move",
+            "moved_bytes": moved_dom, "alg_bytes_8d": alg[dom],
+            "achieved_8d": kern[dom]["alg_GBps"], "frac_8d": round(kern[dom]["alg_GBps"] / HBM_PEAK_GBS, 4),
+            "frac_ranks": {"min": min(fr_), "mean": round(sum(fr_) / len(fr_), 4), "max": max(fr_)},
+            "traffic": traffic, "traffic_source": traffic_src,
+            "traffic_over_moved": (round(traffic / moved_dom, 4) if traffic else None),
             "traffic_over_algorithmic": (round(traffic / alg[dom], 4) if traffic else None),
             "kernels": kern,
             "kernel_time_source": "HIP events on the launch stream, mean of %d launches in this process (the rocprofv3 "
-                                  "--kernel-trace --stats summary of this command: profiles/, latest r04_*kernel_stats.csv)" % reps,
+                                  "--kernel-trace --stats summary of this command: profiles/, latest r05_*kernel_stats.csv)" % reps,
             "path_alg_GBps": round(sum(alg) / (sum(ms) * 1e-3) / 1e9, 1)}
-    if one:
-        roof["moved_GBps"] = kern[0]["moved_GBps"]
-        roof["frac_moved"] = round(kern[0]["moved_GBps"] / HBM_PEAK_GBS, 4)
     other_key = "two_launch" if one else "one_launch"
     roof[other_key] = {"kernels": kern_other, "kernel_sum_ms": round(sum(ms_other), 4),
                        "path_alg_GBps": round(sum(alg_other) / (sum(ms_other) * 1e-3) / 1e9, 1),
@@ -1220,7 +1264,7 @@ def main():
                        "ms_per_step_from_idle": (round(dt_idle / args.steps * 1e3, 4) if dt_idle else None),
                        "power_state_note": "%d untimed steps take the device out of its post-idle power transient before the "
                                            "W warm-up steps (the plans are built on the host with the GPU idle; "
-                                           "tools/step_curve_probe.py); ms_per_step_from_idle = the same W + K steps started "
+                                           "tools/archive/step_curve_probe.py); ms_per_step_from_idle = the same W + K steps started "
                                            "0.5 s after the last launch" % PRECOND_STEPS,
                        "streams_note": "consecutive steps alternate between %d HIP streams with their own feature / output "
                                        "buffers (the next step's analysis fills the tail of this step's synthesis launch); "
@@ -1228,6 +1272,7 @@ def main():
                        "ola_runs": (rt.synthesis.n_runs if one else splan.n_runs),
                        "host_plan_build_s": round(t_plan, 4), "host_plan_build_cold_s": round(t_plan_cold, 3)},
             "roofline": roof,
+            "per_rank": per_rank,
         }
         if full and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(utts, _cpu_lossless, "lossless analysis+synthesis of 5 s utterances",

@@ -28,6 +28,7 @@ extern "C" {
 #define MPX_OK 0
 #define MPX_ERR_ARG (-1)     /* bad argument (unsupported fft_len, null pointer, negative count) */
 #define MPX_ERR_HIP (-2)     /* a HIP runtime call failed */
+#define MPX_ERR_HOST (-3)    /* a host-side helper ran out of memory (or threw) in one of its worker threads */
 
 int mpx_version(void);
 const char* mpx_last_error(void);

@@ -181,9 +181,18 @@ __device__ __forceinline__ void f64_frame_transform(const float* __restrict__ si
                     k1 = (k1 >= N) ? k1 - N : k1;
                     const int i0 = ((k0 <= g.L) ? k0 : g.L + 1 + (g.LR - k0)) - seg0;
                     const int i1 = ((k1 <= g.L) ? k1 : g.L + 1 + (g.LR - k1)) - seg0;
-                    if (k0 >= tile0 && k0 < hi && i0 >= 0 && i0 < capD) re[f64_in_reg<P>(j)] = (double)(xbuf[k0 - tile0] * in_scale) * wl[i0];
-                    if (k1 >= tile0 && k1 < hi && i1 >= 0 && i1 < capD) im[f64_in_reg<P>(j)] = (double)(xbuf[k1 - tile0] * in_scale) * wl[i1];
-                    s_abs += fabs(re[f64_in_reg<P>(j)]) + fabs(im[f64_in_reg<P>(j)]);
+                    // (s_abs counts a register when it is WRITTEN: a window that takes several passes / tiles must not
+                    // count it once per pass -- the flush threshold of the analytic path would grow with the pass count)
+                    if (k0 >= tile0 && k0 < hi && i0 >= 0 && i0 < capD) {
+                        const double v = (double)(xbuf[k0 - tile0] * in_scale) * wl[i0];
+                        re[f64_in_reg<P>(j)] = v;
+                        s_abs += fabs(v);
+                    }
+                    if (k1 >= tile0 && k1 < hi && i1 >= 0 && i1 < capD) {
+                        const double v = (double)(xbuf[k1 - tile0] * in_scale) * wl[i1];
+                        im[f64_in_reg<P>(j)] = v;
+                        s_abs += fabs(v);
+                    }
                 }
             }
             wave_sync();

@@ -333,12 +333,12 @@ static_assert(kPairWaves % kGroup == 0, "waves per workgroup must be a multiple 
 #define MPX_PRIO_SHIFT 10
 #endif
 #ifdef MPX_PROBE_ENDTIME
-// Probe build (tools/endtime_probe.py): every wave of k_synth_ola_pair stores the constant-rate clock (100 MHz) when it
+// Probe build (tools/archive/endtime_probe.py): every wave of k_synth_ola_pair stores the constant-rate clock (100 MHz) when it
 // enters and when it leaves its frame loop, and its frame count -- the spread of the end times is the launch tail.
 __device__ unsigned long long g_endprobe[4 * 8192];   // per wave: start, end (100 MHz clock), frames, shader cycles
 #ifdef MPX_PROBE_PHASES
 // per wave: s_memtime ticks spent in 8 phases of the frame loop (feature wait, merge, transform, prefetch issue + scalars,
-// ticket wait, flush, overlap-add, tail) -- tools/phase_probe.py
+// ticket wait, flush, overlap-add, tail) -- tools/archive/phase_probe.py
 __device__ unsigned long long g_phaseprobe[8 * 8192];
 #define MPX_PHASE(i)                                                                              \
     do {                                                                                          \
@@ -484,7 +484,7 @@ __global__ __launch_bounds__(kPairWaves * 64) void k_synth_ola_pair(const float*
         // Fair shares of a SIMD.  The waves of a SIMD are arbitrated by priority, then AGE: at equal priority the oldest
         // wave issues whenever it can and the youngest gets what is left (MI355X_MICROARCH.md, "Two waves per SIMD").
         // Every wave here has the same static amount of work, so the old waves finished at 220 us, the young ones at
-        // 370-400 us (tools/endtime_probe.py: launch = 126-134 % of the waves' mean busy time) and the SIMDs idled through
+        // 370-400 us (tools/archive/endtime_probe.py: launch = 126-134 % of the waves' mean busy time) and the SIMDs idled through
         // the tail.  The priority therefore rotates with the constant-rate clock: the waves w, w + 4, w + 8 of a workgroup
         // share a SIMD (dispatch order 0 -> 2 -> 1 -> 3) and take the priorities (t + w / 4) mod kPerSimd in turn, t
         // advancing every 2^MPX_PRIO_SHIFT ticks of 10 ns.
@@ -876,7 +876,7 @@ int mpx_probe_phases(unsigned long long* host, int n_words) {
 int mpx_synth_ola_slots(void) { return device_cus() * kPairs; }
 
 // Relative speed of the slots' wave groups.  The waves i, i + 4, i + 8 of a workgroup share a SIMD, and a SIMD serves its
-// waves by age: measured on MI355X (tools/endtime_probe.py) the first four waves of a 12-wave workgroup take 14.4 us per
+// waves by age: measured on MI355X (tools/archive/endtime_probe.py) the first four waves of a 12-wave workgroup take 14.4 us per
 // frame, the next four 17.2, the last four 20.5 while all are resident (18.0 / 23.9 corrected for the time they run
 // without their elders) -- with equal shares the launch lasted 126-134 % of the waves' mean busy time.  The planner
 // therefore deals the frames in proportion to these weights; a rotating s_setprio (MPX_PRIO_ROTATE) narrows the spread

@@ -56,6 +56,7 @@ class WorkerPool {
             body_ = &body;
             want_ = n_workers;
             finished_ = 0;
+            worker_err_ = nullptr;
             ++gen_;
         }
         cv_work_.notify_all();
@@ -71,6 +72,10 @@ class WorkerPool {
             std::unique_lock<std::mutex> lk(mu_);
             cv_done_.wait(lk, [&] { return finished_ == want_; });
             body_ = nullptr;
+            // a worker's copy of the body ran OTHER indices than this thread's: its exception (bad_alloc in a file
+            // reader) is not reproduced here, so the first one is carried over and rethrown
+            if (!err) err = worker_err_;
+            worker_err_ = nullptr;
         }
         if (err) std::rethrow_exception(err);
     }
@@ -88,11 +93,14 @@ class WorkerPool {
                 if (idx < want_) body = body_;
             }
             if (body) {
+                std::exception_ptr err;
                 try {
                     (*body)();
-                } catch (...) {   // a worker's exception must not terminate the process; the caller's own copy reports
+                } catch (...) {   // must not terminate the process from a pool thread: handed to run(), which rethrows it
+                    err = std::current_exception();
                 }
                 std::unique_lock<std::mutex> lk(mu_);
+                if (err && !worker_err_) worker_err_ = err;
                 if (++finished_ == want_) cv_done_.notify_one();
             }
         }
@@ -118,6 +126,7 @@ class WorkerPool {
     std::condition_variable cv_work_, cv_done_;
     std::vector<std::thread> th_;
     const std::function<void()>* body_ = nullptr;
+    std::exception_ptr worker_err_;
     int want_ = 0, finished_ = 0;
     unsigned gen_ = 0;
     bool stop_ = false;
@@ -145,6 +154,17 @@ void parallel_for(int n, int n_threads, F fn) {
         for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) fn(i);
     };
     thread_pool().run(nt - 1, worker);
+}
+
+// No exception may leave an extern "C" entry point (ctypes would terminate the process): MPX_ERR_HOST instead.
+template <typename F>
+int32_t guarded(F body) {
+    try {
+        body();
+    } catch (...) {
+        return MPX_ERR_HOST;
+    }
+    return MPX_OK;
 }
 
 bool read_whole(const char* path, std::string& out, int* err) {
@@ -241,7 +261,7 @@ int32_t mpx_host_widen_f32(const float* src, double* dst, int64_t n, int32_t n_t
     if (n < 0 || (n > 0 && (!src || !dst))) return MPX_ERR_ARG;
     const int64_t kBlock = 1 << 18;   // 1 MB of input per task
     const int nb = (int)((n + kBlock - 1) / kBlock);
-    parallel_for(nb, n_threads, [&](int b) {
+    return guarded([&] { parallel_for(nb, n_threads, [&](int b) {
         const int64_t a = (int64_t)b * kBlock, e = (a + kBlock < n) ? a + kBlock : n;
         int64_t i = a;
 #if defined(__SSE2__) && !defined(MPX_HOST_NO_STREAM)
@@ -256,15 +276,14 @@ int32_t mpx_host_widen_f32(const float* src, double* dst, int64_t n, int32_t n_t
         _mm_sfence();
 #endif
         for (; i < e; ++i) dst[i] = (double)src[i];
-    });
-    return MPX_OK;
+    }); });
 }
 
 int32_t mpx_host_narrow_f64(const double* src, float* dst, int64_t n, int32_t n_threads) {
     if (n < 0 || (n > 0 && (!src || !dst))) return MPX_ERR_ARG;
     const int64_t kBlock = 1 << 17;   // 1 MB of input per task
     const int nb = (int)((n + kBlock - 1) / kBlock);
-    parallel_for(nb, n_threads, [&](int b) {
+    return guarded([&] { parallel_for(nb, n_threads, [&](int b) {
         const int64_t a = (int64_t)b * kBlock, e = (a + kBlock < n) ? a + kBlock : n;
         int64_t i = a;
 #if defined(__SSE2__) && !defined(MPX_HOST_NO_STREAM)
@@ -277,8 +296,7 @@ int32_t mpx_host_narrow_f64(const double* src, float* dst, int64_t n, int32_t n_
         _mm_sfence();
 #endif
         for (; i < e; ++i) dst[i] = (float)src[i];   // round to nearest even, as numpy's astype
-    });
-    return MPX_OK;
+    }); });
 }
 
 // n byte ranges copied into one destination buffer at the given offsets, on a few threads: the PCM of a batch's utterances
@@ -294,12 +312,11 @@ int32_t mpx_host_copy_many(int32_t n, const void* const* src, const int64_t* nby
         if (nbytes[i] < 0 || (nbytes[i] > 0 && !src[i])) return MPX_ERR_ARG;
         first[i + 1] = first[i] + (nbytes[i] + kBlock - 1) / kBlock;
     }
-    parallel_for((int)first[n], n_threads, [&](int t) {
+    return guarded([&] { parallel_for((int)first[n], n_threads, [&](int t) {
         int i = (int)(std::upper_bound(first.begin(), first.end(), (int64_t)t) - first.begin()) - 1;
         const int64_t a = ((int64_t)t - first[i]) * kBlock, e = (a + kBlock < nbytes[i]) ? a + kBlock : nbytes[i];
         memcpy((char*)dst + dst_off[i] + a, (const char*)src[i] + a, (size_t)(e - a));
-    });
-    return MPX_OK;
+    }); });
 }
 
 int32_t mpx_host_file_sizes(int32_t n, const char* const* paths, int64_t* sizes) {
@@ -314,7 +331,7 @@ int32_t mpx_host_file_sizes(int32_t n, const char* const* paths, int64_t* sizes)
 int32_t mpx_host_read_est_batch(int32_t n, const char* const* paths, int32_t skiprows, const int64_t* row_off,
                                 double* col0, double* col1, int64_t* counts, int32_t n_threads) {
     if (n < 0 || skiprows < 0 || (n > 0 && (!paths || !row_off || !col0 || !col1 || !counts))) return MPX_ERR_ARG;
-    parallel_for(n, n_threads, [&](int i) {
+    return guarded([&] { parallel_for(n, n_threads, [&](int i) {
         std::string txt;
         int err = 0;
         if (!read_whole(paths[i], txt, &err)) {
@@ -353,14 +370,13 @@ int32_t mpx_host_read_est_batch(int32_t n, const char* const* paths, int32_t ski
             p = nl ? nl + 1 : end;
         }
         counts[i] = rows;
-    });
-    return MPX_OK;
+    }); });
 }
 
 int32_t mpx_host_write_files(int32_t n, const char* const* paths, const void* const* headers, const int64_t* header_bytes,
                              const void* const* bodies, const int64_t* body_bytes, int32_t* status, int32_t n_threads) {
     if (n < 0 || (n > 0 && (!paths || !bodies || !body_bytes || !status))) return MPX_ERR_ARG;
-    parallel_for(n, n_threads, [&](int i) {
+    return guarded([&] { parallel_for(n, n_threads, [&](int i) {
         status[i] = 0;
         const int fd = open(paths[i], O_WRONLY | O_CREAT | O_TRUNC, 0666);
         if (fd < 0) {
@@ -385,14 +401,13 @@ int32_t mpx_host_write_files(int32_t n, const char* const* paths, const void* co
         if (headers && header_bytes && headers[i] && header_bytes[i] > 0) ok = put(headers[i], header_bytes[i]);
         if (ok && body_bytes[i] > 0) put(bodies[i], body_bytes[i]);
         if (close(fd) != 0 && status[i] == 0) status[i] = errno;
-    });
-    return MPX_OK;
+    }); });
 }
 
 int32_t mpx_host_read_files(int32_t n, const char* const* paths, void* const* bufs, const int64_t* cap, int64_t* got,
                             int32_t n_threads) {
     if (n < 0 || (n > 0 && (!paths || !bufs || !cap || !got))) return MPX_ERR_ARG;
-    parallel_for(n, n_threads, [&](int i) {
+    return guarded([&] { parallel_for(n, n_threads, [&](int i) {
         const int fd = open(paths[i], O_RDONLY);
         if (fd < 0) {
             got[i] = -(int64_t)errno;
@@ -412,8 +427,7 @@ int32_t mpx_host_read_files(int32_t n, const char* const* paths, void* const* bu
         }
         close(fd);
         got[i] = total;
-    });
-    return MPX_OK;
+    }); });
 }
 
 }  // extern "C"

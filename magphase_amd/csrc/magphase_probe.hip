@@ -2,7 +2,7 @@
 // launches them in the same process as the timed kernels so that the roofline object can quote, next to the 8 TB/s
 // spec peak, what THIS device sustains for a plain streaming read, a plain streaming write and a copy (SURVEY.md 8d:
 // "also report against a measured device copy-kernel ceiling").
-// Round 4: one launch shape is not a ceiling (tools/bw_sweep.hip: the same 1 GiB reads at 6.1-6.6 TB/s, fills at 3.8-5.4
+// Round 4: one launch shape is not a ceiling (tools/archive/bw_sweep.hip: the same 1 GiB reads at 6.1-6.6 TB/s, fills at 3.8-5.4
 // and copies at 4.6-5.5 TB/s depending on grid / block size, accesses in flight per lane and the non-temporal bit; the
 // round-3 shape, 2048 x 256 with one access in flight, was among the slowest for fill and copy).  mode = kind + 16 * shape
 // selects one of kShapes; the caller times them all and quotes the best per kind.
@@ -63,7 +63,7 @@ __global__ __launch_bounds__(512) void k_probe_copy(const v4f* __restrict__ a, v
 struct ProbeShape {
     int blocks, threads, unroll, nt;
 };
-// (the winners of tools/bw_sweep.hip per kind, plus the round-3 shape as index 0)
+// (the winners of tools/archive/bw_sweep.hip per kind, plus the round-3 shape as index 0)
 constexpr ProbeShape kShapes[] = {{2048, 256, 1, 0}, {1024, 256, 1, 0}, {1024, 512, 1, 0}, {8192, 512, 1, 0},
                                   {8192, 512, 4, 0}, {8192, 512, 4, 1}, {4096, 512, 8, 0}};
 constexpr int kNumShapes = (int)(sizeof(kShapes) / sizeof(kShapes[0]));

@@ -42,7 +42,7 @@ constexpr size_t lds_bytes() {
 #define MPX_ANA_WAVES 12
 #endif
 // k_analysis: 12 waves = 3 per SIMD (<= 168 VGPRs).  A wave issues at most one instruction per ~5 cycles on this
-// chip (tools/clock_probe.hip), so 2 waves per SIMD leave the VALU idle half the time; the third wave only pays once
+// chip (tools/archive/clock_probe.hip), so 2 waves per SIMD leave the VALU idle half the time; the third wave only pays once
 // every store is a full aligned 256-byte block (tools/ab_bench.py: 8 -> 12 waves = +10 % time with the old store
 // shape, -20 % with the aligned one).
 constexpr int kAnaWaves = MPX_ANA_WAVES;
@@ -57,7 +57,7 @@ __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlan
 // ---------------------------------------------------------------------------------------------
 // Frame queue of a workgroup.  A SIMD serves its resident waves by AGE (MI355X_MICROARCH.md, "Two waves per SIMD"): with
 // a static frame list per wave (grid-stride) the first-dispatched wave of every SIMD ran 14 us per frame, the last one 21
-// (tools/endtime_probe.py), the old waves finished a third earlier and the SIMDs idled through the tail.  The frame-per-
+// (tools/archive/endtime_probe.py), the old waves finished a third earlier and the SIMDs idled through the tail.  The frame-per-
 // wave kernels therefore give every workgroup a contiguous range of the batch's frames and let its waves PULL the next
 // frame from a counter in LDS (one ds_add_rtn_u32 by lane 0 per frame): fast waves simply take more frames, all waves
 // of a workgroup finish together.  Frames are independent, so the order changes nothing in the output.
@@ -565,7 +565,7 @@ __device__ __forceinline__ void ring_add_plane(float* smem_base, const RingAddr&
         // mask of every row is therefore formed on the scalar unit and the address is ONE v_cndmask per element (unwrapped
         // / wrapped base + the row's immediate offset).  The per-lane bit-mask form below compiled to v_and + v_cmp +
         // v_cndmask + v_add per element: 256 of the kernel's 2 350 VALU instructions per frame were ring addresses, and
-        // the kernel is bound by VALU issue (tools/endtime_probe.py: 2.8 cycles per instruction and SIMD at 3 waves).
+        // the kernel is bound by VALU issue (tools/archive/endtime_probe.py: 2.8 cycles per instruction and SIMD at 3 waves).
         constexpr int RH = ring_len<P>() / 2;
         const int cu = PL ? ra.cu1 : ra.cu0;
 #ifndef MPX_RING_ADDR_MODE

@@ -60,7 +60,10 @@ class _PinnedRing:
         import threading
 
         self._bufs = [None] * slots
-        self._freeq = queue.Queue()
+        # SimpleQueue: release() runs from HostTicket.__del__, i.e. possibly from the cyclic GC while this very thread
+        # is inside get() / put() -- queue.Queue's mutex is not reentrant (deadlock), SimpleQueue.put() is documented
+        # safe from destructors and weakref callbacks
+        self._freeq = queue.SimpleQueue()
         for k in range(slots):
             self._freeq.put(k)
         self._lock = threading.Lock()
@@ -145,7 +148,8 @@ class Engine:
             if a.ndim != 2 or a.shape[1] != H:
                 raise ValueError("feature matrices must be [frames x %d]" % H)
             if a.dtype == np.float64 and a.flags.c_contiguous:
-                self.lib.mpx_host_narrow_f64(a.ctypes.data, stage[off:off + r * H].ctypes.data, r * H, n_thr)
+                if self.lib.mpx_host_narrow_f64(a.ctypes.data, stage[off:off + r * H].ctypes.data, r * H, n_thr) != 0:
+                    raise _lib.MagphaseHipError("mpx_host_narrow_f64 failed")
             else:
                 stage[off:off + r * H] = a.reshape(-1)
             off += r * H
@@ -202,7 +206,8 @@ class Engine:
             k, r0, r1 = work[i]
             _v, out, cols = views[k]
             events[i % depth].synchronize()
-            self.lib.mpx_host_widen_f32(bufs[i % depth].data_ptr(), out[r0:r1].ctypes.data, (r1 - r0) * cols, n_thr)
+            if self.lib.mpx_host_widen_f32(bufs[i % depth].data_ptr(), out[r0:r1].ctypes.data, (r1 - r0) * cols, n_thr) != 0:
+                raise _lib.MagphaseHipError("mpx_host_widen_f32 failed")
 
         with torch.cuda.device(self.device):
             for i, (k, r0, r1) in enumerate(work):
@@ -1088,12 +1093,15 @@ class CompressedSynthesisPlan:
         # post_filter: False / True ('magphase': mp.post_filter on the device) / 'merlin' (mp.post_filter_merlin on the device)
         # (the reference's pf_type vocabulary: 'no' means no filtering, magphase.py:3229-3262 -- anything else is an error,
         #  not silently "on")
-        if post_filter is None or post_filter is False or post_filter == "no":
-            self.apply_post_filter = False
-        elif post_filter is True or post_filter == "magphase":
-            self.apply_post_filter = "magphase" if post_filter == "magphase" else True
-        elif post_filter == "merlin":
-            self.apply_post_filter = "merlin"
+        if isinstance(post_filter, str):
+            if post_filter not in ("no", "magphase", "merlin"):
+                raise ValueError("post_filter must be False / None / 'no', True / 'magphase' or 'merlin', not %r" % (post_filter,))
+            self.apply_post_filter = {"no": False, "magphase": "magphase", "merlin": "merlin"}[post_filter]
+        elif post_filter is None or isinstance(post_filter, (bool, np.bool_, int, np.integer)):
+            # truthy non-bool callers (b_post_filter=1, a numpy comparison's np.bool_) mean what bool() says
+            if post_filter is not None and not isinstance(post_filter, (bool, np.bool_)) and int(post_filter) not in (0, 1):
+                raise ValueError("post_filter must be False / None / 'no', True / 'magphase' or 'merlin', not %r" % (post_filter,))
+            self.apply_post_filter = bool(post_filter)
         else:
             raise ValueError("post_filter must be False / None / 'no', True / 'magphase' or 'merlin', not %r" % (post_filter,))
         self.b_const_rate = bool(b_const_rate)
@@ -1219,7 +1227,7 @@ class CompressedSynthesisPlan:
         _up.append(("out_off", self.out_off_host, np.int64))
         # constants: unwarp matrices and per-bin curves (float64 -> float32)
         # (resident on the device per configuration: rebuilding them costs 7 ms on the host, as much as the rest of a
-        # single-utterance call -- tools/latency_probe.py)
+        # single-utterance call -- tools/archive/latency_probe.py)
         if b_fbank_mel:   # magphase.py:851-852: filter-bank unwarp = a different [mag_dim x H] matrix, same kernel
             self.u_mag = e.constant(("u_mag_fbank", self.mag_dim, H, float(alpha)),
                                     lambda: hm.unwarp_fbank_matrix(self.mag_dim, H, alpha))

@@ -225,7 +225,8 @@ def ola_runs(pm_rel_list, starts, out_lens, out_offs, fft_len, n_slots, frames_p
     Per run the positions are classified as head strip / final output / dropped (see mpx_ola_run) in the coordinates
     of the reference's OLA buffer (magphase.py:38-61): frame i covers [pm_rel[i], pm_rel[i] + N), the kept part is
     [start, start + out_len).  Only ADJACENT runs of an utterance may overlap: rel[next run's first frame] -
-    rel[own first frame - 1] >= N for every run with both neighbours (cuts violating it are dropped).
+    rel[own first frame - 1] >= N for every run with both neighbours (a cut violating it is MOVED FORWARD to the first
+    frame that satisfies it, _enforce_span; only a cut with no such frame left in the utterance is dropped).
 
     pm_rel_list: per utterance int64[F_u]; starts / out_lens: ola_plan's (out_start, out_len) per utterance;
     out_offs: int64[U+1] offsets of the utterances in pcm_out.

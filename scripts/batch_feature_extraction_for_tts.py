@@ -52,22 +52,36 @@ def main():
         lu.mkdir(args.out_dir)
     elif world > 1 and not args.direct:
         final_dir, args.out_dir = args.out_dir, os.path.join(args.out_dir, ".rank%d" % rank)
+        if os.path.isdir(args.out_dir):   # left by a run that was killed: its files are NOT this run's results
+            stale = os.listdir(args.out_dir)
+            for n in stale:
+                os.remove(os.path.join(args.out_dir, n))
+            if stale:
+                print("[rank %d] removed %d stale files of an earlier, interrupted run from %s" % (rank, len(stale), args.out_dir))
         lu.mkdir(args.out_dir)
-    if args.batch > 0:   # reader thread / kernels / writer thread overlapped, args.batch utterances per launch
-        rep = iobatch.CorpusReport()
-        n = iobatch.extract_features_corpus([os.path.join(args.wav_dir, tokens[i] + ".wav") for i in mine], args.out_dir,
-                                            batch_utts=args.batch, report=rep)
-        print("[rank %d] %d of %d files analysed in %d batches" % (rank, rep.get("done", 0), len(mine), n))
-        if rep.get("failed"):
-            print("[rank %d] %d files failed, listed in %s" % (rank, len(rep["failed"]), rep["crash_list"]))
-    else:
-        for i in mine:
-            print("[rank %d] analysing %s.wav" % (rank, tokens[i]))
-            mp.analysis_for_acoustic_modelling(os.path.join(args.wav_dir, tokens[i] + ".wav"), args.out_dir)
-    if final_dir is not None:   # this rank's files move up into the common directory
+
+    def move_up():   # this rank's finished files (and its crash list) move up into the common directory
+        if final_dir is None or not os.path.isdir(args.out_dir):
+            return
         for n in os.listdir(args.out_dir):
             os.rename(os.path.join(args.out_dir, n), os.path.join(final_dir, n))
         os.rmdir(args.out_dir)
+
+    try:   # whatever stops this rank mid-corpus, what it finished is where consumers of OUT_DIR look for it
+        if args.batch > 0:   # reader thread / kernels / writer thread overlapped, args.batch utterances per launch
+            rep = iobatch.CorpusReport()
+            n = iobatch.extract_features_corpus([os.path.join(args.wav_dir, tokens[i] + ".wav") for i in mine], args.out_dir,
+                                                batch_utts=args.batch, report=rep)
+            print("[rank %d] %d of %d files analysed in %d batches" % (rank, rep.get("done", 0), len(mine), n))
+            if rep.get("failed"):
+                print("[rank %d] %d files failed, listed in %s" % (rank, len(rep["failed"]), os.path.join(
+                    final_dir or args.out_dir, os.path.basename(rep["crash_list"]))))
+        else:
+            for i in mine:
+                print("[rank %d] analysing %s.wav" % (rank, tokens[i]))
+                mp.analysis_for_acoustic_modelling(os.path.join(args.wav_dir, tokens[i] + ".wav"), args.out_dir)
+    finally:
+        move_up()
     print("rank %d done" % rank)
 
 

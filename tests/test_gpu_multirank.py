@@ -39,8 +39,12 @@ def test_bench_two_ranks_on_one_device():
                          capture_output=True, text=True, timeout=900)
     assert one.returncode == 0, one.stderr[-2000:]
     j1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
-    out = _torchrun(2, ["bench.py", "--gpus", "2", "--steps", "5", "--warmup", "2"],
-                    {"BENCH_DIST_BACKEND": "gloo", "BENCH_SHARE_DEVICE": "1"})
+    assert len(j1["per_rank"]) == 1
+    # the N > 1 line carries the WHOLE contract: cpu_baseline, roofline with the fraction's spread
+    # over the ranks, per_rank -- `BENCH_SHARE_DEVICE=1 python bench.py --gpus 2 --steps 20 --warmup 5` (no e2e block: the
+    # file-interface runs are covered by test_gpu_callers.py and take a minute)
+    out = _torchrun(2, ["bench.py", "--gpus", "2", "--steps", "20", "--warmup", "5", "--no-e2e"],
+                    {"BENCH_DIST_BACKEND": "gloo", "BENCH_SHARE_DEVICE": "1"}, timeout=1500)
     lines = [l for l in out.splitlines() if l.startswith("{")]
     assert len(lines) == 1                                             # rank 0 only
     j2 = json.loads(lines[0])
@@ -51,7 +55,18 @@ def test_bench_two_ranks_on_one_device():
     f2 = j2["value"] * j2["ms_per_step"] * 1e-3
     assert abs(f1 - j1["config"]["frames_per_gpu"]) < 1e-3 * f1
     assert 1.9 * j1["config"]["frames_per_gpu"] < f2 < 2.1 * j1["config"]["frames_per_gpu"]
-    assert "cpu_baseline" not in j2 and "roofline" in j2
+    cb, roof, pr = j2["cpu_baseline"], j2["roofline"], j2["per_rank"]
+    assert cb["value"] > 0 and cb["cores"] >= 1 and cb["kind"] == "port"
+    assert [r["rank"] for r in pr] == [0, 1]
+    for r in pr:
+        assert r["ms_per_step"] > 0 and r["kernel_ms"] > 0 and 0 < r["frac"] <= r["frac_8d"] < 1 and r["frames"] > 0
+        assert r["ms_per_step"] <= j2["ms_per_step"] * 1.0001        # the line's time is the max over the ranks
+    fr = roof["frac_ranks"]
+    assert fr["min"] <= fr["mean"] <= fr["max"] and fr["min"] == min(r["frac"] for r in pr)
+    # the headline fraction is the MOVED one (item 3); SURVEY 8d's figure is kept beside it
+    assert abs(roof["frac"] - roof["moved_bytes"] / (roof["kernels"][0]["ms"] * 1e-3) / 1e9 / roof["peak"]) < 2e-3
+    assert roof["frac_8d"] >= roof["frac"] and roof["alg_bytes_8d"] >= roof["moved_bytes"]
+    assert "configs2" in j2 and "ms_per_step" in j2["configs2"]
 
 
 def test_bench_launches_its_own_ranks():
@@ -215,3 +230,100 @@ def test_corpus_workload_two_ranks_on_one_device():
         # base utterances are seeded per rank, so the frame counts of the two jobs agree to a few percent, not exactly
         assert abs(b["frames"] - a["frames"]) < 0.05 * a["frames"] and b["frames_per_s"] > 0
     assert j2["value"] > 0 and j2["config"]["x_realtime"] > 50
+
+
+def test_whole_10k_corpus_on_one_gpu():
+    """
+    BASELINE configs[3] + configs[4] at their FULL size on one device (the only BASELINE size no
+    driver-run test had touched): the 10 000-utterance corpus of tools/corpus_workload.py (2-8 s utterances; extraction at
+    48 kHz, 60 / 10, Q7; generation from perturbed features, 60 / 45, post-filter + output high-pass + 16-bit PCM, 48 kHz
+    and 16 kHz MIXED), in 64-utterance launches through the batch API, as scripts/batch_feature_extraction_for_tts.py:40-57
+    and scripts/batch_waveform_generation.py:28-58 run it.  Size-independent properties on EVERY utterance -- each one
+    produced exactly once, frame counts / output lengths equal to the host plan (numpy planners, not the native batch
+    planner the product used), finite values in range -- and three utterances per sample rate against the oracle (features;
+    waveform with the noise draw the batch made for that utterance).
+    """
+    import warnings
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import corpus_workload as cw
+    from _tol import within
+    from magphase_amd import engine as em, hostmath as hm, magphase as mp
+    from oracle import magphase_oracle as orc
+
+    n = 10000
+    batches = [np.arange(i, min(i + cw.BATCH, n)) for i in range(0, n, cw.BATCH)]
+    picked = (0, len(batches) // 2, len(batches) - 1)         # launches whose first utterance per rate meets the oracle
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        # ---------------- configs[3]: feature extraction, 48 kHz
+        dur, fs_all = cw.corpus_spec(n, False)
+        pool = cw._pool(0, 48000)
+        seen, frames = np.zeros(n, dtype=int), np.zeros(n, dtype=int)
+        n_oracle = 0
+        for bi, idx in enumerate(batches):
+            items = [cw._cut(pool[int(u) % cw.POOL], float(dur[u]), 48000) for u in idx]
+            res = mp.analysis_compressed_batch(items, mag_dim=60, phase_dim=10, alpha_phase=False, as_float32=True)
+            assert len(res) == len(idx)
+            for u, it, r in zip(idx, items, res):
+                seen[u] += 1
+                frames[u] = r[0].shape[0]
+                pm_s, voi_c = hm.clean_epochs(it[2], it[3], check_len_smpls=len(it[0]), fs=48000)   # the host plan, in numpy
+                assert r[0].shape == (len(pm_s), 60) and r[1].shape == r[2].shape == (len(pm_s), 10)
+                assert len(r[3]) == len(r[4]) == len(pm_s) and r[5] == 48000 and r[6] == 4096
+                assert np.all(np.isfinite(r[0])) and max(np.max(np.abs(r[1])), np.max(np.abs(r[2]))) <= 1.0
+            if bi in picked:
+                pcm, fs, pm, voi = items[0]
+                o = orc.analysis_compressed_from_epochs(pcm.astype(np.float64) / 32768.0, fs, pm, voi, mag_dim=60, phase_dim=10,
+                                                        alpha_phase=False)
+                assert np.array_equal(res[0][4], o[4]) and np.array_equal(res[0][3], o[3])
+                within(np.max(np.abs(res[0][0] - o[0])), 1e-5, "CORPUS10K_FUSED_MAG")
+                within(max(np.max(np.abs(res[0][1] - o[1])), np.max(np.abs(res[0][2] - o[2]))), 2e-6, "CORPUS10K_FUSED_PHASE")
+                n_oracle += 1
+        assert np.all(seen == 1) and n_oracle == 3
+        assert 150 * dur.sum() < frames.sum() < 260 * dur.sum()           # ~175-200 pitch-synchronous frames per second
+
+        # ---------------- configs[4]: waveform generation, 48 kHz (even utterances) and 16 kHz (odd) mixed
+        dur, fs_all = cw.corpus_spec(n, True)
+        rng = np.random.RandomState(777)
+        feats = {}
+        for rate in (16000, 48000):
+            pool = cw._pool(0, rate)
+            res = []
+            for b in cw._batches([(p[0], rate, p[1], p[2]) for p in pool]):
+                res += mp.analysis_compressed_batch(b, mag_dim=60, phase_dim=45, as_float32=True)
+            feats[rate] = [(r[0] + rng.normal(0, 0.05, r[0].shape).astype(np.float32),
+                            np.clip(r[1] + rng.normal(0, 0.05, r[1].shape).astype(np.float32), -1, 1),
+                            np.clip(r[2] + rng.normal(0, 0.05, r[2].shape).astype(np.float32), -1, 1), r[3]) for r in res]
+        seen, n_oracle = np.zeros(n, dtype=int), {16000: 0, 48000: 0}
+        np.random.seed(4242)
+        for bi, idx in enumerate(batches):
+            for rate in (16000, 48000):
+                grp = [int(u) for u in idx if int(fs_all[u]) == rate]
+                if not grp:
+                    continue
+                group = []
+                for u in grp:
+                    m, re_, im, lf0 = feats[rate][u % cw.POOL]
+                    k = max(8, int(round(m.shape[0] * float(dur[u]) / cw.BASE_DUR_S)))
+                    group.append((m[:k], re_[:k], im[:k], lf0[:k]))
+                state = np.random.get_state()                 # the launch draws its first utterance's noise from here
+                sigs = mp.synthesis_from_compressed_batch(group, rate, b_out_hpf=True, b_post_filter=True, pcm16_norm=0.98)
+                assert len(sigs) == len(grp)
+                N = 4096 if rate == 48000 else 2048
+                plan = em.plan_synthesis_numpy([g[3] for g in group], rate, N, False, True)      # numpy planner, per utterance
+                for u, s, ln in zip(grp, sigs, plan["out_len"]):
+                    seen[u] += 1
+                    assert s.dtype == np.int16 and s.shape == (int(ln),)
+                    assert 32100 <= int(np.max(np.abs(s.astype(np.int32)))) <= 32120       # 0.98 of full scale at the peak
+                if bi in picked:
+                    m, re_, im, lf0 = (np.asarray(a, dtype=np.float64) for a in group[0])
+                    now = np.random.get_state()
+                    np.random.set_state(state)
+                    ref = orc.synthesis_from_compressed(orc.post_filter(m, rate), re_, im, lf0, rate, b_out_hpf=True)
+                    np.random.set_state(now)
+                    assert len(ref) == len(sigs[0])
+                    within(np.max(np.abs(sigs[0].astype(np.float64) / 32768.0 - orc.normalise_for_wav(ref, 0.98))) * 32768.0,
+                           1.0, "CORPUS10K_PCM16_LSB")
+                    n_oracle[rate] += 1
+        assert np.all(seen == 1) and n_oracle == {16000: 3, 48000: 3}

@@ -97,7 +97,7 @@ def main():
             utts.append((pcm_, fs_, pm_, voi_))
     steps = {}
     shared = None   # ONE set of feature matrices / strips / output for all variants: where they land in memory is worth
-    # +-3-5 % by itself (tools/alloc_lottery_probe.py) -- per-variant buffers turned that into a fake A/B difference
+    # +-3-5 % by itself (tools/archive/alloc_lottery_probe.py) -- per-variant buffers turned that into a fake A/B difference
     for name in names:
         em = load(name)
         eng = em.Engine()
