@@ -164,9 +164,15 @@ def _permlane16_swap(a, b):
     return a, b
 
 
+def _half_swz(row):
+    """lds_transpose_half (round 5): the rows 4-11 store their two 16-column halves swapped."""
+    return ((row + 4) >> 3) & 1
+
+
 def test_half_height_transpose_equals_full_transpose():
     """wave_fft.hpp lds_transpose_half (P = 32): two phases of 16 rows, every lane reads 16 columns of row lane % 16, one
-    permlane16 swap per register pair -> the full transpose's layout: register l' holds (k1 = lane % 32, l = 32 (lane / 32) + l')."""
+    permlane16 swap per register pair -> the full transpose's layout: register l' holds (k1 = lane % 32, l = 32 (lane / 32) + l').
+    Rows 4-11 are stored with column c at c ^ 16 (bank layout, see the next test): writes and reads use the same map."""
     P, LB, HP = 32, 5, 16
     rng = np.random.RandomState(3)
     y = rng.randn(64, P)                       # y[lane, i]: register i holds k1 = brev(i), column l = lane
@@ -182,13 +188,33 @@ def test_half_height_transpose_equals_full_transpose():
         for i in range(P):
             k1 = brev(i, LB)
             if (k1 >> (LB - 1)) == h:
-                buf[k1 & (HP - 1)] = y[:, i]
+                r = k1 & (HP - 1)
+                for lane in range(64):
+                    buf[r, lane ^ (HP if _half_swz(r) else 0)] = y[lane, i]
         for lam in range(64):
-            col = (lam // P) * P + ((lam >> (LB - 1)) & 1) * HP
-            t[lam, h * HP:(h + 1) * HP] = buf[lam & (HP - 1), col:col + HP]
+            r = lam & (HP - 1)
+            col = (lam // P) * P + (((lam >> (LB - 1)) & 1) ^ _half_swz(r)) * HP
+            t[lam, h * HP:(h + 1) * HP] = buf[r, col:col + HP]
     for j in range(HP):
         t[:, j], t[:, HP + j] = _permlane16_swap(t[:, j], t[:, HP + j])
     assert np.array_equal(t, full)
+
+
+def test_half_height_transpose_bank_layout():
+    """The half-height transpose's ds_read_b128 on MI355X's lane groups: conflict-free with the rows 4-11 swapped; the
+    round-4 layout (every row in column order) cost 4 extra LDS cycles per read = 64 per transform -- exactly the
+    SQ_LDS_BANK_CONFLICT / frame measured on k_synth_ola_pair (profiles/r05_conflict_ablation.txt).  The dword writes
+    (two 32-lane groups, 32 banks) stay conflict-free: the swap permutes lanes inside a group."""
+    S = 68
+    for q in range(4):
+        new = [(l & 15) * S + (l // 32) * 32 + ((((l >> 4) & 1) ^ _half_swz(l & 15)) * 16) + 4 * q for l in range(64)]
+        old = [(l & 15) * S + (l // 32) * 32 + ((l >> 4) & 1) * 16 + 4 * q for l in range(64)]
+        assert _conflicts(new, B128_READ_GROUPS) == 0
+        assert _conflicts(old, B128_READ_GROUPS) == 4
+    for r in range(16):
+        for half in (range(0, 32), range(32, 64)):
+            banks = [(r * S + (l ^ (16 if _half_swz(r) else 0))) % 32 for l in half]
+            assert len(set(banks)) == 32
 
 
 def test_half_twiddle_table_identity():

@@ -323,7 +323,9 @@ def test_whole_10k_corpus_on_one_gpu():
                     ref = orc.synthesis_from_compressed(orc.post_filter(m, rate), re_, im, lf0, rate, b_out_hpf=True)
                     np.random.set_state(now)
                     assert len(ref) == len(sigs[0])
-                    within(np.max(np.abs(sigs[0].astype(np.float64) / 32768.0 - orc.normalise_for_wav(ref, 0.98))) * 32768.0,
-                           1.0, "CORPUS10K_PCM16_LSB")
+                    # libsndfile's float -> 16-bit conversion (what la.write_audio_file / mpx_pcm16 do): x * 32767, rounded --
+                    # half an LSB of rounding + the float path's 3e-7 of the peak (measured 0.52)
+                    within(np.max(np.abs(sigs[0].astype(np.float64) - 32767.0 * orc.normalise_for_wav(ref, 0.98))),
+                           0.75, "CORPUS10K_PCM16_LSB")
                     n_oracle[rate] += 1
         assert np.all(seen == 1) and n_oracle == {16000: 3, 48000: 3}
