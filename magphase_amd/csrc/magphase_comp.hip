@@ -1030,6 +1030,127 @@ constexpr size_t lds_bytes_comp_pair() {
     return sizeof(float) * (size_t)(comp_tw_floats<P>() + kCompPairWaves * comp_xbuf_floats<P>() + kCompPairs * ring_len<P>() + 16);
 }
 
+// ---------------------------------------------------------------------------------------------
+// FUSED form (round 5): mel unwarp -> spectrum assembly -> inverse FFT -> overlap-add in ONE launch (magphase.py:852-870
+// then :900-973).  The pair's run is cut into SEGMENTS on the host (hostmath.plan_segments): at most kFuseFmax
+// consecutive frames whose constant-rate rows lie within kFuseRows consecutive rows.  Before it synthesises a segment the
+// pair unwarps it: the two waves share the 64-bin column steps of a [16 rows x K] . [K x H] product on
+// v_mfma_f32_16x16x4_f32 (f32 in, f32 accumulate), exponentiate (magnitudes), park the 16 x 64 tile in the wave's
+// exchange buffer (idle between frames), interpolate the segment's frames out of it (magphase.py:2242-2252, on the
+// exponentials as the reference does) and store them in the PAIR's scratch rows -- 16 frames x (2112 + 2 x 512) floats
+// that the same two waves read back a few microseconds later, frame by frame, exactly where the staged form reads the
+// [F x H] spectra.  The spectra never exist as matrices: no mpx_mel_unwarp_rows launch, no 3 x F x H round trip.
+// U is host-packed in fragment order (hostmath.pack_unwarp_frag: one 16-byte load per lane = 4 k-steps of a column
+// tile).  Two waves, two barriers per segment (pair_barrier: an LDS counter): scratch free -> produce -> scratch full.
+// ---------------------------------------------------------------------------------------------
+constexpr int kFuseRows = 16;                       // constant-rate rows per product tile (the MFMA's M)
+constexpr int kFuseFmax = 16;                       // frames per segment (entries of the frame table in the buffer's pad)
+constexpr int kFuseLdm = 2112;                      // magnitude floats per scratch frame (33 steps of 64 bins)
+constexpr int kFuseLdp = 512;                       // real / imag floats per scratch frame (bins below the crossfade's end)
+constexpr int kFuseFrame = kFuseLdm + 2 * kFuseLdp; // floats per scratch frame
+constexpr int kFuseMagSteps = kFuseLdm / 64;        // 33
+constexpr int kFusePhSteps = kFuseLdp / 64;         // 8 per stream
+
+struct FuseArgs {
+    const float* a_mag;      // [n_rows x k_mag] log-mel magnitudes (after the post-filter, if any)
+    const float* a_real;     // [n_rows x k_phase]
+    const float* a_imag;
+    const float4* up_mag;    // hostmath.pack_unwarp_frag(u_mag): [132 column tiles][KQ][64 lanes] float4
+    const float4* up_phase;  // the same of u_phase: [32 column tiles][KQ][64 lanes]
+    const int* seg_fb;       // first frame of every segment
+    const int* seg_rb;       // first constant-rate row of every segment
+    const int* run_seg_off;  // [n_runs + 1] segments of run r: run_seg_off[r] .. run_seg_off[r + 1]
+    float* scratch;          // [n_slots x kFuseFmax x kFuseFrame]
+    long long n_rows;
+    int k_mag, k_phase;
+};
+
+typedef float fuse_f32x4 __attribute__((ext_vector_type(4)));
+
+// Column steps [s0, s1) of one stream of a segment: out[i][64 s + lane] = lerp(op(U A[r0_i]), op(U A[r1_i]), t_i) for the
+// segment's frames i < 16 (table entries past the last frame repeat it: branch-free, the repeats store the same values).
+// KT: k-steps of four coefficients (K <= 4 KT; U is packed in groups of four k-steps, KQ = ceil(KT / 4)).  xbuf: the wave's exchange buffer = the 16 x 64 tile (row stride kXStride) with
+// the frame table in the rows' four pad floats (entry i: tile offsets of its two rows, weight).
+template <int KT, bool EXP>
+__device__ __forceinline__ void fuse_unwarp_steps(const float* __restrict__ A, int K, long long n_rows, int rb,
+                                                  const float4* __restrict__ up, int s0, int s1, int nf,
+                                                  float* xbuf, float* __restrict__ out, int lane) {
+    constexpr int KQ = (KT + 3) / 4;
+    // (laundered: everything derived from the lane id here is invariant over the whole kernel, and hoisted out of the
+    // frame loop it costs the frame body its registers)
+    asm volatile("" : "+v"(lane));
+    const int li = lane & 15, gq = lane >> 4;
+    float a[4 * KQ];
+    {
+        const float* arow = A + min((long long)rb + li, n_rows - 1) * K;
+#pragma unroll
+        for (int t = 0; t < 4 * KQ; ++t) {
+            const int k = 4 * t + gq;
+            const float v = arow[min(k, K - 1)];
+            a[t] = (k < K) ? v : 0.0f;
+        }
+    }
+    // one column tile (16 bins) at a time: its U fragments (KQ 16-byte loads, the NEXT tile's in flight behind this tile's
+    // matrix instructions), KT dependent MFMAs into one accumulator -- the matrix pipe takes one instruction per 32
+    // cycles whatever their dependence --, op, four values per lane into the tile buffer.  Every fourth tile completes a
+    // 64-bin step: the segment's frames are interpolated out of the buffer and stored.
+    float4 b[2][KQ];
+    const float4* upl = up + lane;
+#pragma unroll
+    for (int q = 0; q < KQ; ++q) b[0][q] = upl[((size_t)(4 * s0) * KQ + q) * 64];
+    for (int s = s0; s < s1; ++s) {
+        wave_sync();   // the previous step's readers are done with the tile
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int ct = 4 * s + c;
+            const int ctn = min(ct + 1, 4 * s1 - 1);   // (the last tile reloads itself: branch-free)
+#pragma unroll
+            for (int q = 0; q < KQ; ++q) b[(c + 1) & 1][q] = upl[((size_t)ctn * KQ + q) * 64];
+            fuse_f32x4 acc = fuse_f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+            for (int q = 0; q < KQ; ++q) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (4 * q + e < KT) {
+                        const float4 bq = b[c & 1][q];
+                        const float bv = (e == 0) ? bq.x : ((e == 1) ? bq.y : ((e == 2) ? bq.z : bq.w));
+#ifdef MPX_PROBE_FUSE_NOMFMA   // ablation (timing only)
+                        acc[e] = fmaf(a[4 * q + e], bv, acc[e]);
+#else
+                        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * q + e], bv, acc, 0, 0, 0);
+#endif
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xbuf[(4 * gq + r) * kXStride + 16 * c + li] = EXP ? __expf(acc[r]) : acc[r];
+        }
+        wave_sync();
+        float* o = out + 64 * s + lane;
+#ifdef MPX_PROBE_FUSE_NOINTERP   // ablation (timing only): no interpolation / store phase
+        if (xbuf[lane] == 123.456f) o[0] = 1.0f;
+        const int nf_ = 0;
+#else
+        const int nf_ = nf;
+#endif
+        for (int i0 = 0; i0 < nf_; i0 += 4) {   // four frames per batch: their LDS reads are in flight together
+            float m0[4], m1[4], w[4];
+            int oo[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float4 e = *reinterpret_cast<const float4*>(xbuf + (i0 + u) * kXStride + 64);
+                m0[u] = xbuf[__builtin_bit_cast(int, e.x) + lane];
+                m1[u] = xbuf[__builtin_bit_cast(int, e.y) + lane];
+                w[u] = e.z;
+                oo[u] = __builtin_bit_cast(int, e.w);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) o[(size_t)oo[u]] = fmaf(m1[u] - m0[u], w[u], m0[u]);
+        }
+    }
+    wave_sync();
+}
+
 // LERP: every frame interpolates between two spectrum rows (row0 / row1 / rowt tables); false: one row per frame, row
 // index = frame index (variable-rate input, or rows already interpolated by mpx_mel_unwarp_rows) -- half the feature loads.
 // NPQ >= 0 (one-row-per-frame form): the caller's promise n_per <= 64 NPQ at compile time -- only the own bins of the
@@ -1039,7 +1160,7 @@ constexpr size_t lds_bytes_comp_pair() {
 // four batches of 40 -- the 17 registers the 40-wide batches spilled at 12 waves per CU are gone (166 VGPRs, no scratch),
 // and the freed registers allow batches of (8, 8) = 56 / 32 loads: two exposed load latencies per frame instead of four.
 // NPQ < 0: anything goes (run-time tests only).
-template <int P, bool LERP, int NPQ = -1>
+template <int P, bool LERP, int NPQ = -1, bool FUSED = false, int KTM = 15, int KTP = 12>
 __global__ __launch_bounds__(kCompPairWaves * 64) void k_synth_comp_pair(const float* __restrict__ mag,
                                                                         const float* __restrict__ real,
                                                                         const float* __restrict__ imag,
@@ -1054,7 +1175,10 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_synth_comp_pair(const f
                                                                         int nslots,
                                                                         const float* __restrict__ tw_g,
                                                                         float* __restrict__ strips,
-                                                                        float* __restrict__ pcm, long long ld, int n_per) {
+                                                                        float* __restrict__ pcm, long long ld, int n_per,
+                                                                        FuseArgs fz) {
+    static_assert(!FUSED || (P == 32 && !LERP && NPQ == 8 && comp_compact<P>()),
+                  "the fused form is built on the 12-wave one-row-per-frame kernel of N = 4096");
     constexpr int M = 64 * P, N = 2 * M, R = ring_len<P>();
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* tw = smem;
@@ -1068,6 +1192,8 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_synth_comp_pair(const f
     float* ring = smem + kRing0 + pair * R;
     const unsigned ring_byte = 4u * (unsigned)(kRing0 + pair * R);
     int* turn = reinterpret_cast<int*>(smem + kRing0 + kCompPairs * R) + pair;
+    int* pbar = turn + kCompPairs;   // FUSED: the pair's barrier counter (2 kCompPairs <= 16 ints of slack)
+    static_assert(2 * kCompPairs <= 16, "turn + barrier counters fit the 16 floats behind the rings");
     if constexpr (kCompact) {   // the even registers' twiddles only: entry e of a half row = entry 2 e of the full row
         for (int i = threadIdx.x; i < tw_half_floats<P>(); i += kCompPairWaves * 64) {
             const int l = i / tw_half_stride<P>(), c = i - l * tw_half_stride<P>();
@@ -1090,7 +1216,7 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_synth_comp_pair(const f
         for (int i = threadIdx.x; i < tw_floats<P>(); i += kCompPairWaves * 64) tw[i] = tw_g[i];
     }
     for (int i = threadIdx.x; i < kCompPairs * R; i += kCompPairWaves * 64) smem[kRing0 + i] = 0.0f;
-    if (threadIdx.x < kCompPairs) turn[threadIdx.x - pair] = 0;   // thread t < kCompPairs has pair == 0
+    if (threadIdx.x < 2 * kCompPairs) turn[threadIdx.x - pair] = 0;   // thread t < 2 kCompPairs has pair == 0 (turn + pbar)
     __syncthreads();
 
     float wa_s0, wa_c0, ws_s0, ws_c0;   // analysis-side lane twiddle W_N^kappa and synthesis-side conj(W_N^lane)
@@ -1134,15 +1260,105 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_synth_comp_pair(const f
     cur.wi = slot_off[slot];
     cur.ticket_base = 0;
     settle(cur);
-    if (!cur.valid) return;
+
+    // ---- FUSED: the pair's production cursor over the segments of its work list.  Both waves call produce_next() once per
+    // segment, in the same order (a wave without a frame in a segment still takes its share of the product), so the two
+    // barriers of a segment pair up: [scratch free] produce [scratch full].
+    int pz_wi = slot_off[slot], pz_s = -1;      // work item / segment to produce next (-1: run not opened yet)
+    int cs_wi = -1, cs_fb = 0, cs_fe = 0;       // the segment the scratch holds: work item, frames [cs_fb, cs_fe)
+    int nbar = 0;
+    float* const scr = FUSED ? fz.scratch + (size_t)slot * (size_t)(kFuseFmax * kFuseFrame) : nullptr;
+    auto pair_barrier = [&]() {
+#ifdef MPX_PROBE_FUSE_NOBAR   // ablation (timing only: the scratch rows are then read while they are written)
+        return;
+#endif
+        ++nbar;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        if (lane_id == 0) __hip_atomic_fetch_add(pbar, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        int spins = 0;   // bounded: a lost partner must not hang the device (the output is then wrong, and the tests say so)
+        while (__hip_atomic_load(pbar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 2 * nbar && ++spins < (1 << 24))
+            __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");
+    };
+    auto produce = [&](int sfb, int sfe, int rb) {
+        const int nf = sfe - sfb;
+        int any_v;
+        int lane_p = lane_id;
+        asm volatile("" : "+v"(lane_p));
+        {   // frame table in the pad of the tile's rows: entry i = (tile offsets of the frame's two rows, weight, scratch offset)
+            const int i = min(lane_p & 15, nf - 1);
+            const int f = sfb + i;
+            const int r0 = tb.row0[f] - rb, r1 = tb.row1[f] - rb;
+            if (lane_p < kFuseFmax)
+                *reinterpret_cast<float4*>(xbuf + lane_p * kXStride + 64) =
+                    make_float4(__builtin_bit_cast(float, r0 * kXStride), __builtin_bit_cast(float, r1 * kXStride), tb.rowt[f],
+                                __builtin_bit_cast(float, i * kFuseFrame));
+            any_v = __any(tb.voiced[f] != 0);
+        }
+        wave_sync();
+#ifdef MPX_PROBE_FUSE_NOPROD   // ablation (timing only): barriers and the frame table, no product
+        return;
+#endif
+        // shares: the magnitude steps (60 MFMAs each) and, with a voiced frame in the segment, the 2 x 8 phase steps
+        const int split = any_v ? (kFuseMagSteps * 7) / 10 : (kFuseMagSteps + 1) / 2;
+        if (half == 0) {
+            fuse_unwarp_steps<KTM, true>(fz.a_mag, fz.k_mag, fz.n_rows, rb, fz.up_mag, 0, split, nf, xbuf, scr, lane_id);
+        } else {
+            fuse_unwarp_steps<KTM, true>(fz.a_mag, fz.k_mag, fz.n_rows, rb, fz.up_mag, split, kFuseMagSteps, nf, xbuf, scr, lane_id);
+            if (any_v) {
+                fuse_unwarp_steps<KTP, false>(fz.a_real, fz.k_phase, fz.n_rows, rb, fz.up_phase, 0, kFusePhSteps, nf, xbuf,
+                                              scr + kFuseLdm, lane_id);
+                fuse_unwarp_steps<KTP, false>(fz.a_imag, fz.k_phase, fz.n_rows, rb, fz.up_phase, 0, kFusePhSteps, nf, xbuf,
+                                              scr + kFuseLdm + kFuseLdp, lane_id);
+            }
+        }
+    };
+    auto produce_next = [&]() -> bool {
+        for (;;) {
+            if (pz_wi >= wi_end) return false;
+            const int ci = slot_runs[pz_wi];
+            if (pz_s < 0) pz_s = fz.run_seg_off[ci];
+            const int se = fz.run_seg_off[ci + 1];
+            if (pz_s < se) {
+                cs_wi = pz_wi;
+                cs_fb = fz.seg_fb[pz_s];
+                cs_fe = (pz_s + 1 < se) ? fz.seg_fb[pz_s + 1] : runs[ci].frame_end;
+                const int rb = fz.seg_rb[pz_s];
+                ++pz_s;
+                pair_barrier();   // both waves are done with the previous segment's scratch rows
+                produce(cs_fb, cs_fe, rb);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                pair_barrier();   // both shares are stored
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                return true;
+            }
+            ++pz_wi;
+            pz_s = -1;
+        }
+    };
+    if (!cur.valid) {
+        if constexpr (FUSED) {
+            while (produce_next()) {
+            }
+        }
+        return;
+    }
 
     // the noise samples of a frame are copied HBM -> LDS (into the transpose buffer) while the previous frame's
     // inverse FFT finishes and its overlap-add runs (same scheme as k_analysis)
     constexpr int kTile = kCompact ? 32 * P : 64 * P;
     FrameGeom g = frame_geom(noise, tb.npos[cur.fi], tb.nleft[cur.fi], tb.nright[cur.fi], N);
-    stage_samples_async(g, 0, kTile, xbuf_byte, lane_id);
+    bool staged = false;   // FUSED: the exchange buffer is the product tile between segments, the copy starts after it
+    if constexpr (!FUSED) stage_samples_async(g, 0, kTile, xbuf_byte, lane_id);
 
     while (cur.valid) {
+        if constexpr (FUSED) {
+            while (!(cs_wi == cur.wi && cur.fi < cs_fe)) produce_next();
+            if (!staged) {
+                g = frame_geom(noise, tb.npos[cur.fi], tb.nleft[cur.fi], tb.nright[cur.fi], N);
+                stage_samples_async(g, 0, kTile, xbuf_byte, lane_id);
+            }
+        }
         int lane = lane_id;
         float wa_s = 0.0f, wa_c = 1.0f, ws_s = 0.0f, ws_c = 1.0f;
         constexpr float lc = 1.0f, ls = 0.0f;
@@ -1155,6 +1371,43 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_synth_comp_pair(const f
         Cursor nxt = cur;
         advance(nxt);
         const int fi = cur.fi;
+#ifdef MPX_PROBE_SYNTH_MFMA   // probe (timing only): N independent matrix instructions per frame in front of the frame's
+        {                     // VALU work -- what does a wave's own MFMA burst cost the pair kernel?
+            typedef float pf32x4 __attribute__((ext_vector_type(4)));
+            pf32x4 pa0 = {0, 0, 0, 0}, pa1 = pa0, pa2 = pa0, pa3 = pa0;
+            float pav = (float)lane, pbv = 1.0f;
+            asm volatile("" : "+v"(pav), "+v"(pbv));
+#ifndef MPX_PROBE_PACE
+#define MPX_PROBE_PACE 0
+#endif
+#if MPX_PROBE_PACE == 1      // the burst at the lowest priority, the frame's VALU work above it
+            __builtin_amdgcn_s_setprio(0);
+#endif
+#if MPX_PROBE_PACE == 2
+#define MPX_PROBE_GAP() asm volatile("s_nop 15\n\ts_nop 11" ::: "memory")
+#elif MPX_PROBE_PACE == 3
+#define MPX_PROBE_GAP() asm volatile("s_nop 15" ::: "memory")
+#elif MPX_PROBE_PACE == 4
+#define MPX_PROBE_GAP() __builtin_amdgcn_s_sleep(1)
+#else
+#define MPX_PROBE_GAP() do { } while (0)
+#endif
+            for (int i_ = 0; i_ < MPX_PROBE_SYNTH_MFMA / 4; ++i_) {
+                pa0 = __builtin_amdgcn_mfma_f32_16x16x4f32(pav, pbv, pa0, 0, 0, 0);
+                MPX_PROBE_GAP();
+                pa1 = __builtin_amdgcn_mfma_f32_16x16x4f32(pav, pbv, pa1, 0, 0, 0);
+                MPX_PROBE_GAP();
+                pa2 = __builtin_amdgcn_mfma_f32_16x16x4f32(pav, pbv, pa2, 0, 0, 0);
+                MPX_PROBE_GAP();
+                pa3 = __builtin_amdgcn_mfma_f32_16x16x4f32(pav, pbv, pa3, 0, 0, 0);
+                MPX_PROBE_GAP();
+            }
+            asm volatile("" ::"v"(pa0), "v"(pa1), "v"(pa2), "v"(pa3));
+#if MPX_PROBE_PACE == 1
+            __builtin_amdgcn_s_setprio(2);
+#endif
+        }
+#endif
 
         float xr[P], xi[P];
         const int voiced = tb.voiced[fi];
@@ -1185,9 +1438,9 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_synth_comp_pair(const f
                 nh_r = __shfl(nh_r, src);
                 nh_i = __shfl(nh_i, src);
             }
-            const float* mrow = mag + (long long)fi * ld;
-            const float* arow = real + (long long)fi * ld;
-            const float* brow = imag + (long long)fi * ld;
+            const float* mrow = FUSED ? scr + (size_t)(fi - cs_fb) * kFuseFrame : mag + (long long)fi * ld;
+            const float* arow = FUSED ? mrow + kFuseLdm : real + (long long)fi * ld;
+            const float* brow = FUSED ? arow + kFuseLdp : imag + (long long)fi * ld;
             // Unvoiced frames have no periodic component (its mask is zero, magphase.py:873-876): the phase features and
             // the periodic curve are neither loaded nor used -- one wave-uniform branch per frame, 4 instead of 10 loads and
             // a third of the arithmetic per bin pair for about a third of the frames.
@@ -1487,7 +1740,9 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_synth_comp_pair(const f
         } else {
             wave_fft_front<P, +1>(xr, xi, tw, xbuf, lane);
         }
-        if (nxt.valid) {   // the exchange buffer is idle from here on: start the copy of the next frame's noise
+        // FUSED: only inside the segment -- the next segment's product needs the buffer first
+        staged = nxt.valid && (!FUSED || (nxt.wi == cur.wi && nxt.fi < cs_fe));
+        if (staged) {   // the exchange buffer is idle from here on: start the copy of the next frame's noise
             g = frame_geom(noise, tb.npos[nxt.fi], tb.nleft[nxt.fi], tb.nright[nxt.fi], N);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             stage_samples_async(g, 0, kTile, xbuf_byte, lane);
@@ -1542,6 +1797,10 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_synth_comp_pair(const f
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __hip_atomic_store(turn, ticket + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         cur = nxt;
+    }
+    if constexpr (FUSED) {   // segments after this wave's last frame: the partner still needs this wave's share
+        while (produce_next()) {
+        }
     }
 }
 
@@ -2620,7 +2879,7 @@ int mpx_synthesis_compressed_ola(void* stream, int fft_len, const void* tables, 
         if (int rc = set_lds(k_synth_comp_pair<PP, LL>, lds_bytes_comp_pair<PP>())) return rc;                       \
         hipLaunchKernelGGL((k_synth_comp_pair<PP, LL>), pgrid, pblock, lds_bytes_comp_pair<PP>(), s, mag, real, imag, \
                            noise, tb, per_v, ap_v, ap_u, (const RunDesc*)runs, slot_off, slot_runs, (int)n_slots,    \
-                           (const float*)tables, strips, pcm_out, (long long)ld, n_per);                             \
+                           (const float*)tables, strips, pcm_out, (long long)ld, n_per, FuseArgs{});                 \
     } while (0)
     if (lerp) {
         if (P == 32) MPX_LAUNCH_COMP(32, true);
@@ -2631,12 +2890,79 @@ int mpx_synthesis_compressed_ola(void* stream, int fft_len, const void* tables, 
             if (int rc = set_lds(k_synth_comp_pair<32, false, 8>, lds_bytes_comp_pair<32>())) return rc;
             hipLaunchKernelGGL((k_synth_comp_pair<32, false, 8>), pgrid, pblock, lds_bytes_comp_pair<32>(), s, mag, real, imag,
                                noise, tb, per_v, ap_v, ap_u, (const RunDesc*)runs, slot_off, slot_runs, (int)n_slots,
-                               (const float*)tables, strips, pcm_out, (long long)ld, n_per);
+                               (const float*)tables, strips, pcm_out, (long long)ld, n_per, FuseArgs{});
         } else if (P == 32) MPX_LAUNCH_COMP(32, false);
         else if (P == 16) MPX_LAUNCH_COMP(16, false);
         else MPX_LAUNCH_COMP(8, false);
     }
 #undef MPX_LAUNCH_COMP
+    MPX_HIP_CHECK(hipGetLastError());
+    return MPX_OK;
+}
+
+// ---- fused form: unwarp + synthesis in one launch (k_synth_comp_pair<32, false, 8, true, KTM, KTP>) ----
+// k-steps of the instantiation that serves (k_mag, k_phase); 0 / 0: none (the caller stages the spectra instead)
+static void fused_ksteps(int fft_len, int k_mag, int k_phase, int n_per, int* ktm, int* ktp) {
+    *ktm = *ktp = 0;
+    if (fft_len != 4096 || kCompPairWaves <= 8 || k_mag < 1 || k_phase < 1 || k_mag > 64 || k_phase > 64) return;
+    if (n_per < 1 || n_per > kFuseLdp) return;
+    if (k_mag <= 60 && k_phase <= 48) *ktm = 15, *ktp = 12;
+    else *ktm = 16, *ktp = 16;
+}
+
+int mpx_synth_fused_ksteps(int fft_len, int32_t k_mag, int32_t k_phase, int32_t n_per_bins, int32_t* ksteps_mag,
+                           int32_t* ksteps_phase) {
+    if (!ksteps_mag || !ksteps_phase) return fail(MPX_ERR_ARG, "mpx_synth_fused_ksteps: null pointer%s");
+    int a, b;
+    fused_ksteps(fft_len, k_mag, k_phase, n_per_bins, &a, &b);
+    *ksteps_mag = a;
+    *ksteps_phase = b;
+    return MPX_OK;
+}
+
+int64_t mpx_synth_fused_scratch_floats(int32_t n_slots) {
+    return n_slots <= 0 ? 0 : (int64_t)n_slots * kFuseFmax * kFuseFrame;
+}
+
+int mpx_synthesis_compressed_fused(void* stream, int fft_len, const void* tables, const float* a_mag, int32_t k_mag,
+                                   const float* upack_mag, const float* a_real, const float* a_imag, int32_t k_phase,
+                                   const float* upack_phase, int64_t n_rows, const int32_t* row0, const int32_t* row1,
+                                   const float* row_t, const int32_t* seg_frame_begin, const int32_t* seg_row_begin,
+                                   const int32_t* run_seg_off, const float* noise, const int64_t* noise_pos,
+                                   const int32_t* noise_left, const int32_t* noise_right, const int32_t* noise_wtype,
+                                   const int32_t* voiced, const float* inv_gain, const int32_t* win_left,
+                                   const int32_t* win_right, const int32_t* pm_rel, const float* per_v, const float* ap_v,
+                                   const float* ap_u, const mpx_ola_run* runs, int32_t n_runs, const int32_t* slot_off,
+                                   const int32_t* slot_runs, int32_t n_slots, float* scratch, float* strips,
+                                   float* pcm_out, int32_t n_per_bins) {
+    int ktm, ktp;
+    fused_ksteps(fft_len, k_mag, k_phase, n_per_bins, &ktm, &ktp);
+    if (!ktm) return fail(MPX_ERR_ARG, "mpx_synthesis_compressed_fused: no fused kernel for this configuration (see mpx_synth_fused_ksteps)%s");
+    if (n_runs < 0 || n_slots < 0 || n_rows < 0) return fail(MPX_ERR_ARG, "mpx_synthesis_compressed_fused: negative count%s");
+    if (n_runs == 0 || n_slots == 0) return MPX_OK;
+    if (n_rows == 0) return fail(MPX_ERR_ARG, "mpx_synthesis_compressed_fused: frames without coefficient rows%s");
+    if (!tables || !a_mag || !upack_mag || !a_real || !a_imag || !upack_phase || !row0 || !row1 || !row_t ||
+        !seg_frame_begin || !seg_row_begin || !run_seg_off || !noise || !noise_pos || !noise_left || !noise_right ||
+        !noise_wtype || !voiced || !inv_gain || !win_left || !win_right || !pm_rel || !per_v || !ap_v || !ap_u || !runs ||
+        !slot_off || !slot_runs || !scratch || !strips || !pcm_out)
+        return fail(MPX_ERR_ARG, "mpx_synthesis_compressed_fused: null pointer%s");
+    CompFrameTabs tb{(const long long*)noise_pos, noise_left, noise_right, noise_wtype, voiced, inv_gain,
+                     row0, row1, row_t, win_left, win_right, pm_rel};
+    FuseArgs fz{a_mag, a_real, a_imag, (const float4*)upack_mag, (const float4*)upack_phase, seg_frame_begin,
+                seg_row_begin, run_seg_off, scratch, (long long)n_rows, (int)k_mag, (int)k_phase};
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 pgrid((n_slots + kCompPairs - 1) / kCompPairs), pblock(kCompPairWaves * 64);
+#define MPX_LAUNCH_FUSED(KM, KP)                                                                                       \
+    do {                                                                                                             \
+        if (int rc = set_lds(k_synth_comp_pair<32, false, 8, true, KM, KP>, lds_bytes_comp_pair<32>())) return rc;    \
+        hipLaunchKernelGGL((k_synth_comp_pair<32, false, 8, true, KM, KP>), pgrid, pblock, lds_bytes_comp_pair<32>(), \
+                           s, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, noise, tb, per_v,  \
+                           ap_v, ap_u, (const RunDesc*)runs, slot_off, slot_runs, (int)n_slots, (const float*)tables, \
+                           strips, pcm_out, (long long)kFuseFrame, (int)n_per_bins, fz);                             \
+    } while (0)
+    if (ktm == 15) MPX_LAUNCH_FUSED(15, 12);
+    else MPX_LAUNCH_FUSED(16, 16);
+#undef MPX_LAUNCH_FUSED
     MPX_HIP_CHECK(hipGetLastError());
     return MPX_OK;
 }

@@ -9,6 +9,7 @@ Data layout in HBM (all float32, row-major):
   frames   [F_tot x N]          epoch-centred time-domain frames (scratch between IFFT and PSOLA)
   pcm_out  [sum_u len_u]        resynthesised PCM, concatenated
 """
+import ctypes
 import os
 
 import numpy as np
@@ -1087,7 +1088,7 @@ class CompressedSynthesisPlan:
 
     def __init__(self, engine, utts, fs, fft_len=None, b_voi_ap_win=True, b_const_rate=False, alpha_phase=None,
                  noise=None, frames_per_run=None, per_phase_type="magphase", post_filter=False, b_fbank_mel=False,
-                 noise_mode="reference", noise_seeds=None, defer_rng=False):
+                 noise_mode="reference", noise_seeds=None, defer_rng=False, fused=None):
         # defer_rng: the reference noise stream's advanced state stays on the device (Engine.numpy_global_uniform(defer=True));
         #            the caller owes Engine.mt_sync() before numpy's global generator is used again
         # post_filter: False / True ('magphase': mp.post_filter on the device) / 'merlin' (mp.post_filter_merlin on the device)
@@ -1247,6 +1248,35 @@ class CompressedSynthesisPlan:
         _plan_ola_runs(self, pm_rel, starts, self.out_len, self.out_off_host, N, n_slots, frames_per_run, _up,
                        weights=e.synth_ola_slot_weights(comp=True) if hasattr(e, "synth_ola_slot_weights") else None)
         self._gains_dev = None
+        # Fused unwarp -> synthesis (mpx_synthesis_compressed_fused; opt-in: MAGPHASE_SYNTH_FUSED=1 or fused=True): N = 4096,
+        # the transmitted phase, a crossfade that ends at or below bin 512.  The runs are cut into segments of <= 16 frames
+        # within 16 coefficient rows; U goes up in MFMA fragment order.  Built, parity-green and MEASURED SLOWER than the
+        # staged pair mpx_mel_unwarp[_rows] -> mpx_synthesis_compressed_ola (1.20 vs 0.90 ms per 57 k frames, the same HBM
+        # traffic: docs/LAB_NOTES.md, "Round 5: the fused synthesis side"), so the staged pair stays the default.
+        self.fused = False
+        want_fused = (os.environ.get("MAGPHASE_SYNTH_FUSED", "0") == "1") if fused is None else bool(fused)
+        if (want_fused and per_phase_type == "magphase" and self.n_runs > 0
+                and hasattr(e.lib, "mpx_synth_fused_ksteps") and 0 < self.n_per <= 512):
+            ktm, ktp = ctypes.c_int32(0), ctypes.c_int32(0)
+            _lib.check(e.lib.mpx_synth_fused_ksteps(N, self.mag_dim, self.phase_dim, int(self.n_per), ctypes.byref(ktm),
+                                                    ctypes.byref(ktp)), "mpx_synth_fused_ksteps")
+            if ktm.value > 0:
+                self.fused = True
+                key_m = "u_mag_fbank" if b_fbank_mel else "u_mag"
+                self.up_mag = e.constant(
+                    ("upack", key_m, self.mag_dim, H, float(alpha), ktm.value),
+                    lambda: hm.pack_unwarp_frag((hm.unwarp_fbank_matrix if b_fbank_mel else hm.unwarp_matrix)(
+                        self.mag_dim, H, alpha), ktm.value, 132))
+                self.up_phase = e.constant(
+                    ("upack", "u_phase", self.phase_dim, N, int(fs), float(self.alpha_phase), ktp.value),
+                    lambda: hm.pack_unwarp_frag(hm.phase_unwarp_matrix(self.phase_dim, N, fs, self.alpha_phase),
+                                                ktp.value, 32))
+                seg_fb, seg_rb, run_seg_off = hm.plan_segments(self.runs_host["frame_begin"], self.runs_host["frame_end"],
+                                                               cat(row0), cat(row1))
+                self.n_segments = int(seg_fb.size)
+                _up.append(("seg_fb", seg_fb, np.int32))
+                _up.append(("seg_rb", seg_rb, np.int32))
+                _up.append(("run_seg_off", run_seg_off, np.int32))
         for _k, _t in e.to_device_packed(_up).items():
             setattr(self, _k, _t)
         if noise_mode == "device":
@@ -1291,18 +1321,27 @@ class CompressedSynthesisPlan:
             gains.append(tuple(g))
         return inv
 
-    def _buffers(self):
+    def _buffers(self, staged=None):
         """Work buffers of run(), allocated once per plan (the caching allocator makes a re-allocation per call cheap
-        but not free: ~1.6 GB of spectra + strips + per-frame scalars)."""
+        but not free: ~1.6 GB of spectra + strips + per-frame scalars).  staged: the [F x H] spectra are needed (the
+        staged form; default: whatever the plan runs)."""
+        staged = (not self.fused) if staged is None else staged
         b = getattr(self, "_buf", None)
+        if b is not None and staged and b.get("spec") is None:
+            H = self.fft_len // 2 + 1
+            b["spec"] = tuple(self.engine.empty((self.total_frames, b["ld"]))[:, :H] for _ in range(3))
+        if b is not None and self.fused and b.get("scratch") is None:
+            b["scratch"] = self.engine.empty((max(int(self.engine.lib.mpx_synth_fused_scratch_floats(self.n_slots)), 1),))
         if b is None:
             e, torch = self.engine, _torch()
             H = self.fft_len // 2 + 1
             ld = int(e.lib.mpx_spec_ld(H))
             b = self._buf = dict(
                 ld=ld,
-                # unwarped spectra at the VARIABLE rate: one row per synthesis frame (mpx_mel_unwarp_rows interpolates)
-                spec=tuple(e.empty((self.total_frames, ld))[:, :H] for _ in range(3)),
+                # unwarped spectra at the VARIABLE rate: one row per synthesis frame (mpx_mel_unwarp_rows interpolates);
+                # the fused form keeps a segment's rows in the wave pair's scratch instead
+                spec=tuple(e.empty((self.total_frames, ld))[:, :H] for _ in range(3)) if staged else None,
+                scratch=e.empty((max(int(e.lib.mpx_synth_fused_scratch_floats(self.n_slots)), 1),)) if self.fused else None,
                 sums=e.empty((self.total_frames,)),
                 inv_gain=e.empty((self.total_frames,)),
                 gains=torch.empty((self.n_utts, 2), dtype=torch.float64, device=e.device),
@@ -1322,10 +1361,11 @@ class CompressedSynthesisPlan:
         H = N // 2 + 1
         tab = e.tables(N)
         mark = mark or (lambda name: None)
-        buf = self._buffers()
+        fused = self.fused and not keep   # keep: the caller wants the unwarped spectra themselves
+        buf = self._buffers(staged=not fused)
         # unwarped spectra: internal matrices, rows 128-byte aligned (mpx_spec_ld: full-line stores of the MFMA unwarp)
         ld = buf["ld"]
-        mag, real, imag = buf["spec"]
+        mag, real, imag = buf["spec"] if not fused else (None, None, None)
         sums, strips, inv_gain = buf["sums"], buf["strips"], buf["inv_gain"]
         pcm = out if out is not None else e.empty((self.total_out,))
         with torch.cuda.device(e.device):
@@ -1338,7 +1378,9 @@ class CompressedSynthesisPlan:
             elif self.apply_post_filter:   # magphase.py:3259-3261
                 a_mag = e.post_filter(self.a_mag, self.fs)
                 mark("k_post_filter")
-            if self.b_const_rate:   # constant -> variable rate inside the unwarp: one spectrum row per synthesis frame
+            if fused:
+                pass                # the synthesis launch unwarps its own segments
+            elif self.b_const_rate:   # constant -> variable rate inside the unwarp: one spectrum row per synthesis frame
                 _lib.check(lib.mpx_mel_unwarp_rows(
                     st, self.total_frames, H, a_mag.data_ptr(), self.mag_dim, self.u_mag.data_ptr(), mag.data_ptr(),
                     self.a_real.data_ptr(), self.a_imag.data_ptr(), self.phase_dim, self.u_phase.data_ptr(),
@@ -1351,7 +1393,8 @@ class CompressedSynthesisPlan:
                                               mag.data_ptr(), self.a_real.data_ptr(), self.a_imag.data_ptr(),
                                               self.phase_dim, self.u_phase.data_ptr(), real.data_ptr(), imag.data_ptr(),
                                               ld), "mpx_mel_unwarp")
-            mark("k_mel_unwarp_mfma")
+            if not fused:
+                mark("k_mel_unwarp_mfma")
             # (the noise chain is independent of the unwarp, but a second HIP stream does not help: measured 3.13 vs
             # 3.18 ms per step with 12-wave and 3.15 vs 3.16 with 8-wave noise workgroups -- the two grids do not co-run)
             _lib.check(lib.mpx_noise_stats(st, N, tab.data_ptr(), self.noise.data_ptr(), self.npos.data_ptr(),
@@ -1380,6 +1423,21 @@ class CompressedSynthesisPlan:
                 else:
                     real.fill_(1.0)
                     imag.fill_(0.0)
+            if fused:
+                _lib.check(lib.mpx_synthesis_compressed_fused(
+                    st, N, tab.data_ptr(), a_mag.data_ptr(), self.mag_dim, self.up_mag.data_ptr(), self.a_real.data_ptr(),
+                    self.a_imag.data_ptr(), self.phase_dim, self.up_phase.data_ptr(), self.n_rows, self.row0.data_ptr(),
+                    self.row1.data_ptr(), self.rowt.data_ptr(), self.seg_fb.data_ptr(), self.seg_rb.data_ptr(),
+                    self.run_seg_off.data_ptr(), self.noise.data_ptr(), self.npos.data_ptr(), self.nleft.data_ptr(),
+                    self.nright.data_ptr(), self.wtype.data_ptr(), self.voiced.data_ptr(), inv_gain.data_ptr(),
+                    self.win_l.data_ptr(), self.win_r.data_ptr(), self.pm_rel.data_ptr(), self.per_v.data_ptr(),
+                    self.ap_v.data_ptr(), self.ap_u.data_ptr(), self.runs.data_ptr(), self.n_runs, self.slot_off.data_ptr(),
+                    self.slot_runs.data_ptr(), self.n_slots, buf["scratch"].data_ptr(), strips.data_ptr(), pcm.data_ptr(),
+                    int(self.n_per)), "mpx_synthesis_compressed_fused")
+                mark("k_synth_comp_fused")
+                e.ola_fixup(N, self, strips, pcm)
+                mark("k_ola_fixup")
+                return pcm
             _lib.check(lib.mpx_synthesis_compressed_ola(
                 st, N, tab.data_ptr(), mag.data_ptr(), real.data_ptr(), imag.data_ptr(), self.noise.data_ptr(),
                 self.npos.data_ptr(), self.nleft.data_ptr(), self.nright.data_ptr(), self.wtype.data_ptr(),

@@ -120,7 +120,15 @@ def main():
         else:
             if shared is None:
                 shared = {}
+            # a variant named *_staged builds its synthesis plan with the staged unwarp (MAGPHASE_SYNTH_FUSED=0)
+            prev = os.environ.get("MAGPHASE_SYNTH_FUSED")
+            if name.endswith("_staged"):
+                os.environ["MAGPHASE_SYNTH_FUSED"] = "0"
             sa, ss = bench.lowdim_plans(em, eng, utts, shared)
+            if name.endswith("_staged"):
+                os.environ.pop("MAGPHASE_SYNTH_FUSED")
+                if prev is not None:
+                    os.environ["MAGPHASE_SYNTH_FUSED"] = prev
             steps[name] = (sa, ss)
     times = {n: ([], [], []) for n in names}
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
