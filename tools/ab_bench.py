@@ -85,6 +85,7 @@ def main():
     names = [parse(a)[0] for a in args] or ["cur"]
     rounds = int(os.environ.get("AB_ROUNDS", "15"))
     lowdim = os.environ.get("AB_WORKLOAD", "lossless") == "lowdim"
+    extract = os.environ.get("AB_WORKLOAD", "lossless") == "extract"   # configs[3] kernel: fused compressed analysis, 60 / 10 and 60 / 45
     roundtrip = os.environ.get("AB_WORKLOAD", "lossless") == "roundtrip"   # the one-launch copy synthesis (first column)
     torch.cuda.set_device(0)
     utts = bench.make_batch(0)
@@ -101,7 +102,13 @@ def main():
     for name in names:
         em = load(name)
         eng = em.Engine()
-        if not lowdim:
+        if extract:
+            plans = [em.CompressedAnalysisPlan(eng, utts, mag_dim=60, phase_dim=pd, alpha_phase=False) for pd in (10, 45)]
+            outs = [pl.run() for pl in plans]
+            assert all(pl.fused for pl in plans)
+            steps[name] = (lambda plans=plans, outs=outs: plans[0].run(out=outs[0]),
+                           lambda plans=plans, outs=outs: plans[1].run(out=outs[1]))
+        elif not lowdim:
             aplan = em.LosslessAnalysisPlan(eng, utts)
             splan = em.LosslessSynthesisPlan(eng, aplan.v_f0, aplan.fs, aplan.fft_len)
             H, F = aplan.fft_len // 2 + 1, aplan.total_frames
