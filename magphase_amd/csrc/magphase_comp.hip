@@ -742,7 +742,14 @@ __global__ __launch_bounds__(256) void k_post_filter(const float* __restrict__ x
 // entries of 3e8 and the block hand-over loses everything -- measured), while the biquads' tables stay below 120.
 // The cascade differs from scipy's direct-form lfilter by ~1e-7 of peak, which is lfilter's own round-off noise.
 // ---------------------------------------------------------------------------------------------
-constexpr int kHpfBlock = 1024;
+// Round 5: on the corpus generation path (32 utterances per launch) the two section passes took 0.57 ms of the launch's
+// 2.8 ms of device time -- one THREAD per 1024-sample block, every lane of a wave reading its own cache line.  Now a
+// block is 256 samples and a WAVE takes 64 consecutive blocks of an utterance: 64 x 64 tiles go through LDS (row stride
+// 65 doubles: the wave-wide loads / stores are 64 consecutive samples, a lane's serial pass reads its own row without bank
+// conflicts), and the carry kernel is one wave per utterance with the block states staged through LDS the same way.
+constexpr int kHpfBlock = 256;
+constexpr int kHpfTile = 64;                    // samples of a block per LDS pass (and blocks per wave)
+constexpr int kHpfTileStride = kHpfTile + 1;    // doubles per LDS row
 
 struct BiquadCoef {
     double b0, b1, b2, a1, a2;
@@ -752,39 +759,83 @@ template <typename TIn>
 __global__ __launch_bounds__(64) void k_hpf_zero_state(const TIn* __restrict__ x, const long long* __restrict__ off,
                                                        const int* __restrict__ blk_off, BiquadCoef c,
                                                        double* __restrict__ y, double* __restrict__ zend) {
-    // one thread per (utterance, block); blk_off[u] = first global block index of utterance u
+    // one wave per 64 consecutive blocks of an utterance, lane t = block 64 blockIdx.x + t; blk_off[u] = first global
+    // block index of utterance u
+    __shared__ double tile[kHpfTile * kHpfTileStride];
     const int u = blockIdx.y;
     const int nb = blk_off[u + 1] - blk_off[u];
-    const int j = blockIdx.x * 64 + threadIdx.x;
-    if (j >= nb) return;
-    const long long n0 = off[u] + (long long)j * kHpfBlock;
-    const long long n1 = min(n0 + kHpfBlock, off[u + 1]);
+    const int j0 = blockIdx.x * 64;
+    if (j0 >= nb) return;
+    const int t = threadIdx.x;
+    const long long base = off[u] + (long long)j0 * kHpfBlock;   // first sample of the wave's blocks
+    const long long end = off[u + 1];
     double z0 = 0, z1 = 0;
-    for (long long n = n0; n < n1; ++n) {
-        const double xv = (double)x[n];
-        const double yv = c.b0 * xv + z0;
-        z0 = c.b1 * xv + z1 - c.a1 * yv;
-        z1 = c.b2 * xv - c.a2 * yv;
-        y[n] = yv;
+    for (int ch = 0; ch < kHpfBlock / kHpfTile; ++ch) {
+        // row r = block j0 + r, its samples [ch * 64, ch * 64 + 64): lane t loads column t of every row (coalesced)
+#pragma unroll 8
+        for (int r = 0; r < kHpfTile; ++r) {
+            const long long n = base + (long long)r * kHpfBlock + ch * kHpfTile + t;
+            tile[r * kHpfTileStride + t] = (n < end) ? (double)x[n] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int i = 0; i < kHpfTile; ++i) {
+            const double xv = tile[t * kHpfTileStride + i];
+            const double yv = c.b0 * xv + z0;
+            z0 = c.b1 * xv + z1 - c.a1 * yv;
+            z1 = c.b2 * xv - c.a2 * yv;
+            tile[t * kHpfTileStride + i] = yv;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int r = 0; r < kHpfTile; ++r) {
+            const long long n = base + (long long)r * kHpfBlock + ch * kHpfTile + t;
+            if (n < end) y[n] = tile[r * kHpfTileStride + t];
+        }
+        __syncthreads();
     }
-    double* ze = zend + 2 * (long long)(blk_off[u] + j);
-    ze[0] = z0;
-    ze[1] = z1;
+    // (a block that ends before its 256th sample ran on zero padding: its end state is never used -- it is the
+    // utterance's last block)
+    if (j0 + t < nb) {
+        double* ze = zend + 2 * (long long)(blk_off[u] + j0 + t);
+        ze[0] = z0;
+        ze[1] = z1;
+    }
 }
 
 __global__ __launch_bounds__(64) void k_hpf_carry(const int* __restrict__ blk_off, int n_utts,
                                                   const double* __restrict__ pmat /* A^B, row-major 2x2 */,
                                                   const double* __restrict__ zend, double* __restrict__ zstart) {
-    const int u = blockIdx.x * 64 + threadIdx.x;
+    // one wave per utterance: 64 block states at a time through LDS (coalesced), the chain itself on every lane
+    __shared__ double ze[2 * 64], zs[2 * 64];
+    const int u = blockIdx.x;
     if (u >= n_utts) return;
+    const int g0 = blk_off[u], g1 = blk_off[u + 1], t = threadIdx.x;
+    const double p0 = pmat[0], p1 = pmat[1], p2 = pmat[2], p3 = pmat[3];
     double z0 = 0, z1 = 0;
-    for (int g = blk_off[u]; g < blk_off[u + 1]; ++g) {
-        zstart[2 * (long long)g + 0] = z0;
-        zstart[2 * (long long)g + 1] = z1;
-        const double n0 = pmat[0] * z0 + pmat[1] * z1 + zend[2 * (long long)g + 0];
-        const double n1 = pmat[2] * z0 + pmat[3] * z1 + zend[2 * (long long)g + 1];
-        z0 = n0;
-        z1 = n1;
+    for (int g = g0; g < g1; g += 64) {
+        const int cnt = min(64, g1 - g);
+        if (t < cnt) {
+            ze[2 * t] = zend[2 * (long long)(g + t)];
+            ze[2 * t + 1] = zend[2 * (long long)(g + t) + 1];
+        }
+        __syncthreads();
+        for (int i = 0; i < cnt; ++i) {
+            if (t == 0) {
+                zs[2 * i] = z0;
+                zs[2 * i + 1] = z1;
+            }
+            const double n0 = p0 * z0 + p1 * z1 + ze[2 * i];
+            const double n1 = p2 * z0 + p3 * z1 + ze[2 * i + 1];
+            z0 = n0;
+            z1 = n1;
+        }
+        __syncthreads();
+        if (t < cnt) {
+            zstart[2 * (long long)(g + t)] = zs[2 * t];
+            zstart[2 * (long long)(g + t) + 1] = zs[2 * t + 1];
+        }
+        __syncthreads();
     }
 }
 
@@ -807,20 +858,33 @@ __global__ __launch_bounds__(256) void k_hpf_apply(const long long* __restrict__
 // from fusing them -- so the samples are bit-identical; the device hands the writer thread ready int16 samples and the
 // D2H copy is a quarter of the float64 one.  k_peak_abs: one block per utterance; k_pcm16: one thread per sample.
 // ---------------------------------------------------------------------------------------------
+constexpr int kPeakPerThread = 16;   // elements per thread of k_peak_abs
 template <typename T>
 __global__ __launch_bounds__(256) void k_peak_abs(const T* __restrict__ y, const long long* __restrict__ off,
                                                   double* __restrict__ peak) {
+    // peak[u] = max |y| over utterance u; peak[] zeroed by the caller.  blockIdx.y = utterance, 4096 elements per block
+    // (one block per utterance ran 240 us per 32 x 5 s: a single wave front of loads in flight per CU).  The maximum is
+    // order-independent, so the result is the serial one bit for bit; non-negative doubles order like their bit patterns.
     __shared__ double s_max[256];
-    const int u = blockIdx.x;
+    const int u = blockIdx.y;
+    const long long b0 = off[u] + (long long)blockIdx.x * (256 * kPeakPerThread), b1 = off[u + 1];
+    if (b0 >= b1) return;
     double m = 0.0;
-    for (long long i = off[u] + threadIdx.x; i < off[u + 1]; i += 256) m = fmax(m, fabs((double)y[i]));
+#pragma unroll
+    for (int k = 0; k < kPeakPerThread; ++k) {
+        const long long i = b0 + k * 256 + threadIdx.x;
+        if (i < b1) m = fmax(m, fabs((double)y[i]));
+    }
     s_max[threadIdx.x] = m;
     __syncthreads();
     for (int k = 128; k >= 1; k >>= 1) {
         if (threadIdx.x < k) s_max[threadIdx.x] = fmax(s_max[threadIdx.x], s_max[threadIdx.x + k]);
         __syncthreads();
     }
-    if (threadIdx.x == 0) peak[u] = s_max[0];
+    if (threadIdx.x == 0) {
+        // (fmax drops NaNs, as the serial chain did: s_max[0] is a non-negative number)
+        atomicMax(reinterpret_cast<unsigned long long*>(peak + u), (unsigned long long)__double_as_longlong(s_max[0]));
+    }
 }
 
 template <typename T>
@@ -3265,11 +3329,13 @@ int mpx_pcm16(void* stream, const void* y, int32_t y_is_f64, const int64_t* out_
     if (n_utts > 65535) return fail(MPX_ERR_ARG, "mpx_pcm16: at most 65535 utterances per call%s");
     hipStream_t s = (hipStream_t)stream;
     const dim3 g2((unsigned)((max_len + 255) / 256), (unsigned)n_utts);
+    const dim3 gp((unsigned)((max_len + 256 * kPeakPerThread - 1) / (256 * kPeakPerThread)), (unsigned)n_utts);
+    MPX_HIP_CHECK(hipMemsetAsync(peaks, 0, sizeof(double) * (size_t)n_utts, s));
     if (y_is_f64) {
-        hipLaunchKernelGGL(k_peak_abs<double>, dim3((unsigned)n_utts), dim3(256), 0, s, (const double*)y, (const long long*)out_off, peaks);
+        hipLaunchKernelGGL(k_peak_abs<double>, gp, dim3(256), 0, s, (const double*)y, (const long long*)out_off, peaks);
         hipLaunchKernelGGL(k_pcm16<double>, g2, dim3(256), 0, s, (const double*)y, (const long long*)out_off, peaks, norm, (short*)out);
     } else {
-        hipLaunchKernelGGL(k_peak_abs<float>, dim3((unsigned)n_utts), dim3(256), 0, s, (const float*)y, (const long long*)out_off, peaks);
+        hipLaunchKernelGGL(k_peak_abs<float>, gp, dim3(256), 0, s, (const float*)y, (const long long*)out_off, peaks);
         hipLaunchKernelGGL(k_pcm16<float>, g2, dim3(256), 0, s, (const float*)y, (const long long*)out_off, peaks, norm, (short*)out);
     }
     MPX_HIP_CHECK(hipGetLastError());
@@ -3300,7 +3366,7 @@ int mpx_output_hpf(void* stream, const float* pcm, const int64_t* out_off, const
     if (n_utts > 65535) return fail(MPX_ERR_ARG, "mpx_output_hpf: at most 65535 utterances per call%s");
     hipStream_t s = (hipStream_t)stream;
     const unsigned max_blocks = (unsigned)((max_len + kHpfBlock - 1) / kHpfBlock);
-    const dim3 gz((max_blocks + 63) / 64, (unsigned)n_utts), gc((unsigned)((n_utts + 63) / 64)),
+    const dim3 gz((max_blocks + 63) / 64, (unsigned)n_utts), gc((unsigned)n_utts),
         ga((unsigned)((max_len + 255) / 256), (unsigned)n_utts);
     for (int sec = 0; sec < 2; ++sec) {
         const double* q = sos_host + 6 * sec;   // scipy sos row: b0 b1 b2 a0 a1 a2

@@ -117,6 +117,43 @@ class Engine:
     def stream_ptr(self):
         return _torch().cuda.current_stream(self.device).cuda_stream
 
+    def copy_stream(self, kind):
+        """The engine's H2D ('up') / D2H ('down') stream, or None (MAGPHASE_COPY_STREAMS=0: copies in the compute stream).
+        A corpus job's launches are device-bound, and a third of a launch's device time was its own PCIe traffic queued
+        in front of / behind its kernels (30 MB of PCM or 17 MB of coefficients up, 15 MB of PCM down): on their own
+        streams the next launch's upload and the previous launch's download run beside this launch's kernels -- the
+        host builds plans ahead of the device, so the uploads are there to be overlapped."""
+        if os.environ.get("MAGPHASE_COPY_STREAMS", "1") == "0":
+            return None
+        cs = getattr(self, "_copy_streams", None)
+        if cs is None:
+            torch = _torch()
+            cs = self._copy_streams = {"up": torch.cuda.Stream(self.device), "down": torch.cuda.Stream(self.device)}
+        return cs[kind]
+
+    def _download(self, pairs):
+        """pairs: [(pinned host tensor view, device tensor)]: non-blocking D2H copies on the download stream, behind
+        what the compute stream has queued so far.  Returns the event that marks their completion."""
+        torch = _torch()
+        cur = torch.cuda.current_stream(self.device)
+        down = self.copy_stream("down")
+        if down is None:
+            for dst, src in pairs:
+                dst.copy_(src, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(cur)
+            return ev
+        ready = torch.cuda.Event()
+        ready.record(cur)
+        with torch.cuda.stream(down):
+            down.wait_event(ready)
+            for dst, src in pairs:
+                dst.copy_(src, non_blocking=True)
+                src.record_stream(down)
+            ev = torch.cuda.Event()
+            ev.record(down)
+        return ev
+
     def empty(self, shape, dtype=None):
         torch = _torch()
         return torch.empty(shape, dtype=dtype or torch.float32, device=self.device)
@@ -252,15 +289,14 @@ class Engine:
             return [t.detach().to("cpu").numpy() for t in tensors], HostTicket(None, None, None, None)
         try:
             host = buf[:4 * int(offs[-1])].view(torch.float32)
-            views = []
+            views, pairs = [], []
             with torch.cuda.device(self.device):
                 for t, n, o in zip(tensors, sizes, offs[:-1]):
                     dst = host[int(o):int(o) + n].view(tuple(int(x) for x in t.shape))
                     if n:
-                        dst.copy_(t, non_blocking=True)
+                        pairs.append((dst, t))
                     views.append(dst.numpy())
-                ev = torch.cuda.Event()
-                ev.record(torch.cuda.current_stream(self.device))
+                ev = self._download(pairs)
         except BaseException:
             self.out_ring().release(slot)   # a failed copy must not leak the slot
             raise
@@ -290,9 +326,7 @@ class Engine:
                 if slot is not None:
                     try:
                         host = buf[:2 * max(total, 1)].view(torch.int16)
-                        host.copy_(out, non_blocking=True)
-                        ev = torch.cuda.Event()
-                        ev.record(torch.cuda.current_stream(self.device))
+                        ev = self._download([(host, out)])
                     except BaseException:
                         self.out_ring().release(slot)
                         raise
@@ -392,15 +426,53 @@ class Engine:
         self._stage_up = cur
         return cur.numpy()[:int(n_floats)]
 
+    def stage_rows(self, arrays, out):
+        """np.concatenate(arrays, axis=0, out=out, casting='same_kind') for a float32 ``out`` (a slice of the staging
+        buffer): float32 C-contiguous blocks are copied, float64 ones narrowed (round to nearest even, as astype), both on
+        a few native threads (mpx_host_copy_many / mpx_host_narrow_f64) -- numpy's concatenate is one thread at ~10 GB/s and
+        was a quarter of a synthesis plan's build time.  Anything else goes through numpy."""
+        n_thr = max(1, int(os.environ.get("MAGPHASE_IO_NATIVE_THREADS", "8")))
+        k = len(arrays)
+        if k > 1 and all(a.dtype == np.float32 and a.flags.c_contiguous for a in arrays):
+            src = (ctypes.c_void_p * k)(*[a.ctypes.data for a in arrays])
+            nb = np.fromiter((a.nbytes for a in arrays), dtype=np.int64, count=k)
+            doff = np.zeros(k, dtype=np.int64)
+            np.cumsum(nb[:-1], out=doff[1:])
+            if int(nb.sum()) != out.nbytes:
+                raise ValueError("stage_rows: blocks do not fill the destination")
+            if self.lib.mpx_host_copy_many(k, src, nb.ctypes.data, doff.ctypes.data, out.ctypes.data, n_thr) != 0:
+                raise _lib.MagphaseHipError("mpx_host_copy_many failed")
+            return
+        if k > 0 and all(a.dtype == np.float64 and a.flags.c_contiguous for a in arrays):
+            flat, o = out.reshape(-1), 0
+            if int(sum(a.size for a in arrays)) != flat.size:
+                raise ValueError("stage_rows: blocks do not fill the destination")
+            for a in arrays:
+                if a.size and self.lib.mpx_host_narrow_f64(a.ctypes.data, flat[o:].ctypes.data, a.size, n_thr) != 0:
+                    raise _lib.MagphaseHipError("mpx_host_narrow_f64 failed")
+                o += a.size
+            return
+        np.concatenate(arrays, axis=0, out=out, casting="same_kind")
+
     def upload_staged(self, n_floats):
         """The first n_floats of the current staging buffer -> a fresh device tensor (one DMA from pinned memory, in
         stream order; the buffer is protected by an event until host_staging hands it out again)."""
         torch = _torch()
         st = self._stage
+        up = self.copy_stream("up")
         with torch.cuda.device(self.device):
-            t = self._stage_up[:int(n_floats)].to(self.device, non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(self.device))
+            if up is None:
+                t = self._stage_up[:int(n_floats)].to(self.device, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(self.device))
+            else:   # on the upload stream; the compute stream waits for it, the tensor is the compute stream's from then on
+                cur = torch.cuda.current_stream(self.device)
+                with torch.cuda.stream(up):
+                    t = self._stage_up[:int(n_floats)].to(self.device, non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record(up)
+                cur.wait_event(ev)
+                t.record_stream(cur)
             st["events"][st["cur"]] = ev
         return t
 
@@ -816,6 +888,22 @@ class Engine:
         return pcm_out
 
 
+class _FlatRows:
+    """A list of per-utterance rows kept as ONE array + offsets; iterating / indexing cuts the views."""
+
+    def __init__(self, flat, off):
+        self.flat, self.off = flat, np.asarray(off, dtype=np.int64)
+
+    def __len__(self):
+        return int(self.off.size - 1)
+
+    def __getitem__(self, u):
+        return self.flat[int(self.off[u]):int(self.off[u + 1])]
+
+    def __iter__(self):
+        return (self[u] for u in range(len(self)))
+
+
 def _plan_ola_runs(plan, pm_rel_list, starts, out_lens, out_off_host, fft_len, n_slots, frames_per_run, up, weights=None):
     """Shared by the two synthesis plans: runs + slot work lists (hostmath.ola_runs / balance_chunks) -> upload list.
     weights: the slots' relative speeds (Engine.synth_ola_slot_weights) or None for equal shares."""
@@ -823,9 +911,14 @@ def _plan_ola_runs(plan, pm_rel_list, starts, out_lens, out_off_host, fft_len, n
     try:
         if fpr:
             raise hostplan.PlanFallback()      # per-utterance run lengths (tests, tuning): the numpy planner only
-        sizes = [int(np.size(r)) for r in pm_rel_list]
-        rel_cat = np.concatenate([np.asarray(r, dtype=np.int64) for r in pm_rel_list]) if pm_rel_list else np.zeros(0, np.int64)
-        runs, slot_off, slot_runs = hostplan.ola_runs(rel_cat, np.concatenate(([0], np.cumsum(sizes))), starts, out_lens,
+        if isinstance(pm_rel_list, _FlatRows):   # already one array + offsets (CompressedSynthesisPlan)
+            rel_cat, f_off = np.asarray(pm_rel_list.flat, dtype=np.int64), pm_rel_list.off
+            sizes = np.diff(f_off)
+        else:
+            sizes = [int(np.size(r)) for r in pm_rel_list]
+            rel_cat = np.concatenate([np.asarray(r, dtype=np.int64) for r in pm_rel_list]) if pm_rel_list else np.zeros(0, np.int64)
+            f_off = np.concatenate(([0], np.cumsum(sizes)))
+        runs, slot_off, slot_runs = hostplan.ola_runs(rel_cat, f_off, starts, out_lens,
                                                       np.asarray(out_off_host)[:len(sizes)], fft_len, n_slots,
                                                       weights=weights)
     except hostplan.PlanFallback:
@@ -936,10 +1029,17 @@ class LosslessAnalysisPlan:
         self.total_frames = int(sum(self.n_frames))
         self.frame_off = np.concatenate(([0], np.cumsum(self.n_frames))).astype(np.int64)
         right_cat = np.concatenate(right) if right else np.zeros(0, dtype=np.int64)
-        self.long_frame_lens = []
-        for u, lft in enumerate(self.v_shift):
-            tot = lft + right_cat[int(self.frame_off[u]):int(self.frame_off[u + 1])] + 1
-            self.long_frame_lens.append(tot[tot > self.fft_len].tolist())
+        # frames longer than fft_len (the reference warns once per such frame): rare -- one pass over the batch, the
+        # per-utterance lists only where there is something to list
+        self.long_frame_lens = [[] for _ in self.v_shift]
+        if right_cat.size:
+            left_cat = np.concatenate(left) if len(left) > 1 else np.asarray(left[0])
+            tot = left_cat + right_cat + 1
+            hit = np.flatnonzero(tot > self.fft_len)
+            if hit.size:
+                utt_of = np.searchsorted(self.frame_off, hit, side="right") - 1
+                for i, u in zip(hit.tolist(), utt_of.tolist()):
+                    self.long_frame_lens[u].append(int(tot[i]))
         e = engine
         if all_i16:
             raw = e.upload_staged((total + 1) // 2 + 2)
@@ -1128,12 +1228,14 @@ class CompressedSynthesisPlan:
 
         a_mag, a_real, a_imag = [], [], []
         npos, nleft, nright, wtype, voiced, row0, row1, rowt, win_l, win_r = ([] for _ in range(10))
-        pm_rel, starts, lens, nfr, noises, lf0s = [], [], [], [], [], []
-        self.v_shift, self.v_pm, self.v_voi, self.ns_len = [], [], [], []
+        noises, lf0s = [], []
         row_base = 0
+        nd = np.ndarray
         for ui, (mml, rm, im, lf0) in enumerate(utts):
             # the coefficient matrices go to the device as float32 whatever they arrive as: no float64 round trip here
-            mml, rm, im = np.atleast_2d(np.asarray(mml)), np.atleast_2d(np.asarray(rm)), np.atleast_2d(np.asarray(im))
+            # (a plan is built per launch of a corpus job: the usual case -- 2-D ndarrays -- skips the generic conversions)
+            if not (type(mml) is nd and type(rm) is nd and type(im) is nd and mml.ndim == 2 and rm.ndim == 2 and im.ndim == 2):
+                mml, rm, im = np.atleast_2d(np.asarray(mml)), np.atleast_2d(np.asarray(rm)), np.atleast_2d(np.asarray(im))
             lf0 = np.atleast_1d(np.asarray(lf0, dtype=np.float64))
             n_rows = mml.shape[0]
             if rm.shape[0] != n_rows or im.shape[0] != n_rows or lf0.shape[0] != n_rows:
@@ -1167,13 +1269,15 @@ class CompressedSynthesisPlan:
         mt_total = int(np.sum(r["ns_len"]))
         mt_device = (noise_mode == "reference" and noise is None and mt_total >= (1 << 18)
                      and os.environ.get("MAGPHASE_MT_DEVICE", "1") != "0" and np.random.get_state()[0] == "MT19937")
-        for ui in range(len(utts)):
-            a_, b_ = int(fo[ui]), int(fo[ui + 1])
-            self.v_shift.append(r["v_shift"][a_:b_]), self.v_pm.append(r["v_pm"][a_:b_])
-            self.v_voi.append(r["voiced"][a_:b_].astype(bool)), self.ns_len.append(int(r["ns_len"][ui]))
-            starts.append(int(r["out_start"][ui])), lens.append(int(r["out_len"][ui])), nfr.append(b_ - a_)
-            pm_rel.append(r["pm_rel"][a_:b_])
-            noises.append(noise_for(ui, self.ns_len[-1]))
+        # per-utterance views (v_shift / v_pm / v_voi: properties below) are cut from the batch tables on demand
+        self._tabs, self._fo = r, fo
+        self.ns_len = [int(x) for x in np.asarray(r["ns_len"]).tolist()]
+        starts = [int(x) for x in np.asarray(r["out_start"]).tolist()]
+        lens = [int(x) for x in np.asarray(r["out_len"]).tolist()]
+        nfr = np.diff(np.asarray(fo, dtype=np.int64)).tolist()
+        pm_rel = _FlatRows(np.asarray(r["pm_rel"]), fo)
+        if noise is not None or not (noise_mode == "device" or mt_device):
+            noises = [noise_for(ui, self.ns_len[ui]) for ui in range(len(utts))]
         npos, nleft, nright, wtype, voiced = [r["npos"]], [r["nleft"]], [r["nright"]], [r["wtype"]], [r["voiced"]]
         row0, row1, rowt, win_l, win_r = [r["row0"]], [r["row1"]], [r["rowt"]], [r["win_l"]], [r["win_r"]]
 
@@ -1191,9 +1295,9 @@ class CompressedSynthesisPlan:
         # coefficient matrices: concatenated straight into the page-locked staging buffer, one DMA
         n_m, n_p = self.n_rows * self.mag_dim, self.n_rows * self.phase_dim
         stage = e.host_staging(n_m + 2 * n_p)
-        np.concatenate(a_mag, axis=0, out=stage[:n_m].reshape(self.n_rows, self.mag_dim), casting="same_kind")
-        np.concatenate(a_real, axis=0, out=stage[n_m:n_m + n_p].reshape(self.n_rows, self.phase_dim), casting="same_kind")
-        np.concatenate(a_imag, axis=0, out=stage[n_m + n_p:].reshape(self.n_rows, self.phase_dim), casting="same_kind")
+        e.stage_rows(a_mag, stage[:n_m].reshape(self.n_rows, self.mag_dim))
+        e.stage_rows(a_real, stage[n_m:n_m + n_p].reshape(self.n_rows, self.phase_dim))
+        e.stage_rows(a_imag, stage[n_m + n_p:].reshape(self.n_rows, self.phase_dim))
         coef = e.upload_staged(n_m + 2 * n_p)
         self.a_mag = coef[:n_m].view(self.n_rows, self.mag_dim)
         self.a_real = coef[n_m:n_m + n_p].view(self.n_rows, self.phase_dim)
@@ -1223,7 +1327,7 @@ class CompressedSynthesisPlan:
         _up.append(("rowt", cat(rowt), np.float32))
         _up.append(("win_l", cat(win_l), np.int32))
         _up.append(("win_r", cat(win_r), np.int32))
-        _up.append(("pm_rel", cat(pm_rel), np.int32))
+        _up.append(("pm_rel", pm_rel.flat, np.int32))
         _up.append(("out_start", np.asarray(starts), np.int32))
         _up.append(("out_off", self.out_off_host, np.int64))
         # constants: unwarp matrices and per-bin curves (float64 -> float32)
@@ -1288,6 +1392,26 @@ class CompressedSynthesisPlan:
                                                    self.noise.data_ptr()), "mpx_noise_uniform")
         elif mt_device:
             self.noise = e.numpy_global_uniform(mt_total, defer=bool(defer_rng))
+
+    def _per_utt(self, key, cast=None):
+        r, fo = self._tabs, self._fo
+        out = [r[key][int(fo[u]):int(fo[u + 1])] for u in range(len(self.ns_len))]
+        return [cast(x) for x in out] if cast else out
+
+    @property
+    def v_shift(self):
+        """Per utterance: the frames' shifts in samples (magphase.py:862-868 / :2210-2215)."""
+        return self._per_utt("v_shift")
+
+    @property
+    def v_pm(self):
+        """Per utterance: the frames' epochs in samples (la.shift_to_pm, magphase.py:880)."""
+        return self._per_utt("v_pm")
+
+    @property
+    def v_voi(self):
+        """Per utterance: the frames' voicing decisions (magphase.py:847, :866)."""
+        return self._per_utt("voiced", lambda x: x.astype(bool))
 
     @staticmethod
     def _check_rows_for_tiles(r0, r1):
@@ -1588,20 +1712,21 @@ class CompressedAnalysisPlan:
         self.w_ph = e.constant(("w_ph", int(k_full), H, float(a_ph), int(phase_dim)),
                                lambda: hm.warp_matrix(k_full, H, a_ph, nrows=phase_dim))
         row0, row1, rowt, self.f0_out = [], [], [], []
-        for u in range(len(utts)):
-            v_f0 = plan.v_f0[u]
-            base = int(plan.frame_off[u])
-            if b_const_rate:
+        if b_const_rate:
+            for u in range(len(utts)):
+                v_f0 = plan.v_f0[u]
+                base = int(plan.frame_off[u])
                 v_pm = np.cumsum(plan.v_shift[u])
                 lo, hi, t = hm.var_to_const_rate_table(v_pm, 5.0, fs)
                 v_f0 = _const_rate_f0_voi(v_f0, v_pm, fs)
-            else:
-                lo = hi = np.arange(plan.n_frames[u])
-                t = np.zeros(plan.n_frames[u])
-            row0.append(lo + base), row1.append(hi + base), rowt.append(t), self.f0_out.append(v_f0)
-        self.out_off = np.concatenate(([0], np.cumsum([len(f) for f in self.f0_out]))).astype(np.int64)
+                row0.append(lo + base), row1.append(hi + base), rowt.append(t), self.f0_out.append(v_f0)
+            self.out_off = np.concatenate(([0], np.cumsum([len(f) for f in self.f0_out]))).astype(np.int64)
+        else:   # variable rate: output rows == frames (no row tables go to the device)
+            self.f0_out = list(plan.v_f0)
+            self.out_off = np.asarray(plan.frame_off, dtype=np.int64)
         self.total_out_frames = int(self.out_off[-1])
-        items = [("voi", np.concatenate([(f > 0).astype(np.float64) for f in self.f0_out]), np.float32)]
+        f0_cat = np.concatenate(self.f0_out) if self.f0_out else np.zeros(0)
+        items = [("voi", (f0_cat > 0).astype(np.float32), np.float32)]
         if b_const_rate:
             items += [("row0", np.concatenate(row0), np.int32), ("row1", np.concatenate(row1), np.int32),
                       ("rowt", np.concatenate(rowt), np.float32)]

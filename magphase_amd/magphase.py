@@ -543,13 +543,16 @@ def analysis_compressed_batch(utts, fft_len=None, mag_dim=60, phase_dim=10, b_co
         # signal.medfilt of every utterance's f0 in one pass (hostmath.medfilt3_batch: bit-identical, also for 0 or 1
         # vectors; 30 us per scipy call)
         f0_med = hm.medfilt3_batch(plan.f0_out)
+        # lf0 of the whole batch in one pass (la.f0_to_lf0 per utterance: the same element-wise operations)
+        sizes = [int(np.size(f)) for f in plan.f0_out]
+        lf0_cat = la.f0_to_lf0((np.concatenate(plan.f0_out) > 0).astype('float') * np.concatenate(f0_med)) if sizes else np.zeros(0)  # magphase.py:2499-2501
+        off = np.concatenate(([0], np.cumsum(sizes))).tolist()
+        o_off = np.asarray(plan.out_off).tolist()
+        shifts = plan.lossless.v_shift
         for u in range(len(utts)):
-            a, b = int(plan.out_off[u]), int(plan.out_off[u + 1])
-            v_f0 = plan.f0_out[u]
-            v_voi = (v_f0 > 0).astype('float')
-            v_lf0 = la.f0_to_lf0(v_voi * f0_med[u])                            # magphase.py:2499-2501
-            res.append((h_mag[a:b], h_real[a:b], h_imag[a:b], v_lf0, plan.lossless.v_shift[u].astype(int), plan.fs,
-                        plan.fft_len))
+            a, b = o_off[u], o_off[u + 1]
+            v_lf0 = lf0_cat[off[u]:off[u + 1]].copy()
+            res.append((h_mag[a:b], h_real[a:b], h_imag[a:b], v_lf0, shifts[u].astype(int), plan.fs, plan.fft_len))
     except BaseException:
         if ticket is not None:   # the page-locked slot goes back to the ring when the host part fails
             ticket.release()
