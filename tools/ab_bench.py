@@ -127,12 +127,13 @@ def main():
         else:
             if shared is None:
                 shared = {}
-            # a variant named *_staged builds its synthesis plan with the staged unwarp (MAGPHASE_SYNTH_FUSED=0)
+            # a variant named *_fused builds its synthesis plan with the fused unwarp -> synthesis launch
+            # (MAGPHASE_SYNTH_FUSED=1, opt-in), *_staged forces the staged pair
             prev = os.environ.get("MAGPHASE_SYNTH_FUSED")
-            if name.endswith("_staged"):
-                os.environ["MAGPHASE_SYNTH_FUSED"] = "0"
+            if name.endswith("_staged") or name.endswith("_fused"):
+                os.environ["MAGPHASE_SYNTH_FUSED"] = "1" if name.endswith("_fused") else "0"
             sa, ss = bench.lowdim_plans(em, eng, utts, shared)
-            if name.endswith("_staged"):
+            if name.endswith("_staged") or name.endswith("_fused"):
                 os.environ.pop("MAGPHASE_SYNTH_FUSED")
                 if prev is not None:
                     os.environ["MAGPHASE_SYNTH_FUSED"] = prev
