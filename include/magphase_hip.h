@@ -360,6 +360,11 @@ int mpx_synthesis_compressed_ola(void* stream, int fft_len, const void* tables, 
  *   n_per_bins : as mpx_synthesis_compressed_ola, required <= 512
  * Everything else as mpx_synthesis_compressed_ola; followed by mpx_ola_fixup.
  */
+/* Operand format of upack_mag / upack_phase: 1 (default) = hostmath.pack_unwarp_frag_bf16 -- bfloat16 bit patterns
+ * [column tiles][2 blocks of 32 coefficients][3 splits][64 lanes][8], the three-way split u = u0 + u1 + u2 of float32(U)
+ * for v_mfma_f32_16x16x32_bf16 (six exact partial products per term, float32 accumulation: float32 accuracy at 0.4 of the
+ * float32 instruction's matrix-pipe time); 0 (MAGPHASE_FUSED_F32=1) = the float32 fragments described above. */
+int mpx_synth_fused_format(void);
 int mpx_synth_fused_ksteps(int fft_len, int32_t k_mag, int32_t k_phase, int32_t n_per_bins, int32_t* ksteps_mag,
                            int32_t* ksteps_phase);
 int64_t mpx_synth_fused_scratch_floats(int32_t n_slots);

@@ -46,6 +46,7 @@ SYMBOLS = (
     "mpx_synth_comp_slots",
     "mpx_synth_comp_slot_weights",
     "mpx_synthesis_compressed_ola",
+    "mpx_synth_fused_format",
     "mpx_synth_fused_ksteps",
     "mpx_synth_fused_scratch_floats",
     "mpx_synthesis_compressed_fused",
@@ -182,6 +183,8 @@ def _load_locked():
     lib.mpx_synth_comp_slots.argtypes = []
     lib.mpx_synthesis_compressed_ola.restype = ctypes.c_int
     lib.mpx_synthesis_compressed_ola.argtypes = [vp, ctypes.c_int, vp] + [vp] * 19 + [vp, i32, vp, vp, i32, vp, vp, i64, i32]
+    lib.mpx_synth_fused_format.restype = ctypes.c_int
+    lib.mpx_synth_fused_format.argtypes = []
     lib.mpx_synth_fused_ksteps.restype = ctypes.c_int
     lib.mpx_synth_fused_ksteps.argtypes = [ctypes.c_int, i32, i32, i32, vp, vp]
     lib.mpx_synth_fused_scratch_floats.restype = i64

@@ -1163,6 +1163,35 @@ typedef float fuse_f32x4 __attribute__((ext_vector_type(4)));
 // segment's frames i < 16 (table entries past the last frame repeat it: branch-free, the repeats store the same values).
 // KT: k-steps of four coefficients (K <= 4 KT; U is packed in groups of four k-steps, KQ = ceil(KT / 4)).  xbuf: the wave's exchange buffer = the 16 x 64 tile (row stride kXStride) with
 // the frame table in the rows' four pad floats (entry i: tile offsets of its two rows, weight).
+// Interpolation of the segment's frames out of the 16 x 64 tile and their stores, FOUR frames per wave instruction: lane
+// = (frame 4 it + (lane >> 4), bin quad lane & 15) reads its two rows' 16 bytes (a 16-lane group reads one row's 256
+// contiguous bytes: conflict-free at any row offset), interpolates four bins and stores them as one 16-byte store -- a
+// quarter of the LDS reads and global stores of the lane-per-bin form (which cost 0.16 ms of the fused launch).
+__device__ __forceinline__ void fuse_interp_store(const float* xbuf, int nf, float* __restrict__ o /* + 64 s */, int lane) {
+    const int fq = lane >> 4, q4 = 4 * (lane & 15);
+    for (int i0 = 0; i0 < nf; i0 += 8) {   // two batches of four frames in flight
+        float4 e[2], m0[2], m1[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            e[u] = *reinterpret_cast<const float4*>(xbuf + (i0 + 4 * u + fq) * kXStride + 64);   // (entries >= nf repeat the last frame)
+            m0[u] = *reinterpret_cast<const float4*>(xbuf + __builtin_bit_cast(int, e[u].x) + q4);
+            m1[u] = *reinterpret_cast<const float4*>(xbuf + __builtin_bit_cast(int, e[u].y) + q4);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (i0 + 4 * u < nf) {
+                const float w = e[u].z;
+                float4 v;
+                v.x = fmaf(m1[u].x - m0[u].x, w, m0[u].x);
+                v.y = fmaf(m1[u].y - m0[u].y, w, m0[u].y);
+                v.z = fmaf(m1[u].z - m0[u].z, w, m0[u].z);
+                v.w = fmaf(m1[u].w - m0[u].w, w, m0[u].w);
+                *reinterpret_cast<float4*>(o + (size_t)__builtin_bit_cast(int, e[u].w) + q4) = v;
+            }
+        }
+    }
+}
+
 template <int KT, bool EXP>
 __device__ __forceinline__ void fuse_unwarp_steps(const float* __restrict__ A, int K, long long n_rows, int rb,
                                                   const float4* __restrict__ up, int s0, int s1, int nf,
@@ -1233,27 +1262,119 @@ __device__ __forceinline__ void fuse_unwarp_steps(const float* __restrict__ A, i
             }
         }
         wave_sync();
-        float* o = out + 64 * s + lane;
+        float* o = out + 64 * s;
 #ifdef MPX_PROBE_FUSE_NOINTERP   // ablation (timing only): no interpolation / store phase
         if (xbuf[lane] == 123.456f) o[0] = 1.0f;
         const int nf_ = 0;
 #else
         const int nf_ = nf;
 #endif
-        for (int i0 = 0; i0 < nf_; i0 += 4) {   // four frames per batch: their LDS reads are in flight together
-            float m0[4], m1[4], w[4];
-            int oo[4];
+        fuse_interp_store(xbuf, nf_, o, lane);
+    }
+    wave_sync();
+}
+
+// The same product on v_mfma_f32_16x16x32_bf16 (the matrix pipe proper: 16 cycles per instruction) with float32 accuracy:
+// every operand is split into three bfloat16 values (x = x0 + x1 + x2 up to 2^-24 |x|; U on the host,
+// hostmath.pack_unwarp_frag_bf16, the 16 coefficient rows here), the six partial products x_i u_j with i + j <= 2 are
+// exact in float32 and summed by the instruction's float32 accumulator, smallest first.  A [16 x 64] . [64 x 16] tile is
+// 2 k-blocks x 6 terms = 12 instructions = 192 cycles against 15 x 32-40 for the float32 form -- and short bursts of
+// these hide under the other waves' VALU work where the float32 ones did not (probe: 176 per frame +0.011 ms on the
+// launch, 208 float32 ones +0.154; profiles/r05_fused_synthesis_ablation.txt).  Accuracy: as the float32 chain
+// (tests/test_fused_synthesis_host.py: 5e-6 against 6e-6 on a log-spectrum warp; the dropped terms are below 2^-24).
+typedef __bf16 fuse_bf16x8 __attribute__((ext_vector_type(8)));
+
+template <bool EXP>
+__device__ __forceinline__ void fuse_unwarp_steps_bf16(const float* __restrict__ A, int K, long long n_rows, int rb,
+                                                       const uint4* __restrict__ up, int s0, int s1, int nf, float* xbuf,
+                                                       float* __restrict__ out, int lane) {
+    asm volatile("" : "+v"(lane));   // (see fuse_unwarp_steps)
+    const int li = lane & 15, gq = lane >> 4;
+    // A fragments: row rb + li, k-slots 32 kb + 8 gq + j, split three ways
+    fuse_bf16x8 a[2][3];
+    {
+        const float* arow = A + min((long long)rb + li, n_rows - 1) * K;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const float4 e = *reinterpret_cast<const float4*>(xbuf + (i0 + u) * kXStride + 64);
-                m0[u] = xbuf[__builtin_bit_cast(int, e.x) + lane];
-                m1[u] = xbuf[__builtin_bit_cast(int, e.y) + lane];
-                w[u] = e.z;
-                oo[u] = __builtin_bit_cast(int, e.w);
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = 32 * kb + 8 * gq + j;
+                const float t = arow[min(k, K - 1)];
+                const float v = (k < K) ? t : 0.0f;
+                const __bf16 h0 = (__bf16)v;
+                const float r1 = v - (float)h0;
+                const __bf16 h1 = (__bf16)r1;
+                const __bf16 h2 = (__bf16)(r1 - (float)h1);
+                a[kb][0][j] = h0;
+                a[kb][1][j] = h1;
+                a[kb][2][j] = h2;
             }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) o[(size_t)oo[u]] = fmaf(m1[u] - m0[u], w[u], m0[u]);
         }
+    }
+    // U fragments of a column tile: [kb][split] 16-byte loads; two tiles (two accumulator chains) per pass, the next pair's
+    // loads in flight behind this pair's matrix instructions
+    uint4 b[2][2][2][3];   // [buffer][tile of the pair][kb][split]
+    const uint4* upl = up + lane;
+    auto load_pair = [&](int buf, int ct_first, int ct_last) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int ct = min(ct_first + h, ct_last);
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int sp = 0; sp < 3; ++sp) b[buf][h][kb][sp] = upl[((size_t)(ct * 2 + kb) * 3 + sp) * 64];
+        }
+    };
+    load_pair(0, 4 * s0, 4 * s1 - 1);
+    for (int s = s0; s < s1; ++s) {
+        wave_sync();   // the previous step's readers are done with the tile
+#pragma unroll
+        for (int cp = 0; cp < 2; ++cp) {
+#ifndef MPX_PROBE_FUSE_NOULOAD   // ablation (timing only): the first pair's U fragments for every tile
+            load_pair((cp + 1) & 1, 4 * s + 2 * cp + 2, 4 * s1 - 1);   // (past the end: the last tile again, branch-free)
+#else
+            if (cp == 1) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                        for (int sp = 0; sp < 3; ++sp) asm volatile("" : "+v"(b[0][h][kb][sp].x), "+v"(b[1][h][kb][sp].x));
+            }
+#endif
+            fuse_f32x4 acc0 = fuse_f32x4{0.0f, 0.0f, 0.0f, 0.0f}, acc1 = acc0;
+            // terms (i, j) = (split of A, split of U), smallest products first
+#define MPX_FUSE_TERM(I, J)                                                                                                 \
+    do {                                                                                                                    \
+        _Pragma("unroll") for (int kb = 0; kb < 2; ++kb) {                                                                  \
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kb][I], __builtin_bit_cast(fuse_bf16x8, b[cp & 1][0][kb][J]),  \
+                                                           acc0, 0, 0, 0);                                                  \
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kb][I], __builtin_bit_cast(fuse_bf16x8, b[cp & 1][1][kb][J]),  \
+                                                           acc1, 0, 0, 0);                                                  \
+        }                                                                                                                   \
+    } while (0)
+            MPX_FUSE_TERM(2, 0);
+            MPX_FUSE_TERM(1, 1);
+            MPX_FUSE_TERM(0, 2);
+            MPX_FUSE_TERM(1, 0);
+            MPX_FUSE_TERM(0, 1);
+            MPX_FUSE_TERM(0, 0);
+#undef MPX_FUSE_TERM
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                xbuf[(4 * gq + r) * kXStride + 32 * cp + li] = EXP ? __expf(acc0[r]) : acc0[r];
+                xbuf[(4 * gq + r) * kXStride + 32 * cp + 16 + li] = EXP ? __expf(acc1[r]) : acc1[r];
+            }
+        }
+        wave_sync();
+        float* o = out + 64 * s;
+#ifdef MPX_PROBE_FUSE_NOINTERP   // ablation (timing only): no interpolation / store phase
+        if (xbuf[lane] == 123.456f) o[0] = 1.0f;
+        const int nf_ = 0;
+#else
+        const int nf_ = nf;
+#endif
+        fuse_interp_store(xbuf, nf_, o, lane);
     }
     wave_sync();
 }
@@ -1408,14 +1529,28 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_synth_comp_pair(const f
 #endif
         // shares: the magnitude steps (60 MFMAs each) and, with a voiced frame in the segment, the 2 x 8 phase steps
         const int split = any_v ? (kFuseMagSteps * 7) / 10 : (kFuseMagSteps + 1) / 2;
-        if (half == 0) {
-            fuse_unwarp_steps<KTM, true>(fz.a_mag, fz.k_mag, fz.n_rows, rb, fz.up_mag, 0, split, nf, xbuf, scr, lane_id);
+        if constexpr (KTM == 0) {   // the three-way bfloat16 split on v_mfma_f32_16x16x32_bf16
+            const uint4* um = reinterpret_cast<const uint4*>(fz.up_mag);
+            const uint4* uph = reinterpret_cast<const uint4*>(fz.up_phase);
+            if (half == 0) {
+                fuse_unwarp_steps_bf16<true>(fz.a_mag, fz.k_mag, fz.n_rows, rb, um, 0, split, nf, xbuf, scr, lane_id);
+            } else {
+                fuse_unwarp_steps_bf16<true>(fz.a_mag, fz.k_mag, fz.n_rows, rb, um, split, kFuseMagSteps, nf, xbuf, scr, lane_id);
+                if (any_v) {
+                    fuse_unwarp_steps_bf16<false>(fz.a_real, fz.k_phase, fz.n_rows, rb, uph, 0, kFusePhSteps, nf, xbuf,
+                                                  scr + kFuseLdm, lane_id);
+                    fuse_unwarp_steps_bf16<false>(fz.a_imag, fz.k_phase, fz.n_rows, rb, uph, 0, kFusePhSteps, nf, xbuf,
+                                                  scr + kFuseLdm + kFuseLdp, lane_id);
+                }
+            }
+        } else if (half == 0) {
+            fuse_unwarp_steps<(KTM > 0 ? KTM : 1), true>(fz.a_mag, fz.k_mag, fz.n_rows, rb, fz.up_mag, 0, split, nf, xbuf, scr, lane_id);
         } else {
-            fuse_unwarp_steps<KTM, true>(fz.a_mag, fz.k_mag, fz.n_rows, rb, fz.up_mag, split, kFuseMagSteps, nf, xbuf, scr, lane_id);
+            fuse_unwarp_steps<(KTM > 0 ? KTM : 1), true>(fz.a_mag, fz.k_mag, fz.n_rows, rb, fz.up_mag, split, kFuseMagSteps, nf, xbuf, scr, lane_id);
             if (any_v) {
-                fuse_unwarp_steps<KTP, false>(fz.a_real, fz.k_phase, fz.n_rows, rb, fz.up_phase, 0, kFusePhSteps, nf, xbuf,
+                fuse_unwarp_steps<(KTP > 0 ? KTP : 1), false>(fz.a_real, fz.k_phase, fz.n_rows, rb, fz.up_phase, 0, kFusePhSteps, nf, xbuf,
                                               scr + kFuseLdm, lane_id);
-                fuse_unwarp_steps<KTP, false>(fz.a_imag, fz.k_phase, fz.n_rows, rb, fz.up_phase, 0, kFusePhSteps, nf, xbuf,
+                fuse_unwarp_steps<(KTP > 0 ? KTP : 1), false>(fz.a_imag, fz.k_phase, fz.n_rows, rb, fz.up_phase, 0, kFusePhSteps, nf, xbuf,
                                               scr + kFuseLdm + kFuseLdp, lane_id);
             }
         }
@@ -1499,6 +1634,20 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_synth_comp_pair(const f
 #else
 #define MPX_PROBE_GAP() do { } while (0)
 #endif
+#ifdef MPX_PROBE_SYNTH_BF16   // the same burst as bf16 matrix instructions (16 cycles each on the matrix pipe proper)
+            typedef __bf16 pbf16x8 __attribute__((ext_vector_type(8)));
+            pbf16x8 pa8, pb8;
+            for (int e_ = 0; e_ < 8; ++e_) {
+                pa8[e_] = (__bf16)pav;
+                pb8[e_] = (__bf16)pbv;
+            }
+            for (int i_ = 0; i_ < MPX_PROBE_SYNTH_MFMA / 4; ++i_) {
+                pa0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa8, pb8, pa0, 0, 0, 0);
+                pa1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa8, pb8, pa1, 0, 0, 0);
+                pa2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa8, pb8, pa2, 0, 0, 0);
+                pa3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa8, pb8, pa3, 0, 0, 0);
+            }
+#else
             for (int i_ = 0; i_ < MPX_PROBE_SYNTH_MFMA / 4; ++i_) {
                 pa0 = __builtin_amdgcn_mfma_f32_16x16x4f32(pav, pbv, pa0, 0, 0, 0);
                 MPX_PROBE_GAP();
@@ -1509,6 +1658,7 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_synth_comp_pair(const f
                 pa3 = __builtin_amdgcn_mfma_f32_16x16x4f32(pav, pbv, pa3, 0, 0, 0);
                 MPX_PROBE_GAP();
             }
+#endif
             asm volatile("" ::"v"(pa0), "v"(pa1), "v"(pa2), "v"(pa3));
 #if MPX_PROBE_PACE == 1
             __builtin_amdgcn_s_setprio(2);
@@ -3017,6 +3167,13 @@ static void fused_ksteps(int fft_len, int k_mag, int k_phase, int n_per, int* kt
     else *ktm = 16, *ktp = 16;
 }
 
+// 1: upack_* are hostmath.pack_unwarp_frag_bf16's three-way bfloat16 splits (v_mfma_f32_16x16x32_bf16, the default);
+// 0: hostmath.pack_unwarp_frag's float32 fragments (v_mfma_f32_16x16x4_f32; MAGPHASE_FUSED_F32=1, kept for A/B runs)
+int mpx_synth_fused_format(void) {
+    const char* e = getenv("MAGPHASE_FUSED_F32");
+    return (e && e[0] == '1') ? 0 : 1;
+}
+
 int mpx_synth_fused_ksteps(int fft_len, int32_t k_mag, int32_t k_phase, int32_t n_per_bins, int32_t* ksteps_mag,
                            int32_t* ksteps_phase) {
     if (!ksteps_mag || !ksteps_phase) return fail(MPX_ERR_ARG, "mpx_synth_fused_ksteps: null pointer%s");
@@ -3067,7 +3224,8 @@ int mpx_synthesis_compressed_fused(void* stream, int fft_len, const void* tables
                            ap_v, ap_u, (const RunDesc*)runs, slot_off, slot_runs, (int)n_slots, (const float*)tables, \
                            strips, pcm_out, (long long)kFuseFrame, (int)n_per_bins, fz);                             \
     } while (0)
-    if (ktm == 15) MPX_LAUNCH_FUSED(15, 12);
+    if (mpx_synth_fused_format() == 1) MPX_LAUNCH_FUSED(0, 0);
+    else if (ktm == 15) MPX_LAUNCH_FUSED(15, 12);
     else MPX_LAUNCH_FUSED(16, 16);
 #undef MPX_LAUNCH_FUSED
     MPX_HIP_CHECK(hipGetLastError());

@@ -565,10 +565,17 @@ __global__ __launch_bounds__(kFusedWaves * 64) void k_analysis_warp_fused(
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
+#ifdef MPX_PROBE_FUSEDA_NOMFMA   // ablation (timing only): one VALU operation per matrix instruction
+#pragma unroll
+                    for (int t = 0; t < NTM; ++t) ca[t][e] = fmaf(am[e], bw[t][e], ca[t][e]);
+#pragma unroll
+                    for (int t = NTM; t < T; ++t) ca[t][e] = fmaf(ap[e], bw[t][e], ca[t][e]);
+#else
 #pragma unroll
                     for (int t = 0; t < NTM; ++t) ca[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(am[e], bw[t][e], ca[t], 0, 0, 0);
 #pragma unroll
                     for (int t = NTM; t < T; ++t) ca[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[e], bw[t][e], ca[t], 0, 0, 0);
+#endif
                 }
             }
 #pragma unroll

@@ -1367,14 +1367,19 @@ class CompressedSynthesisPlan:
             if ktm.value > 0:
                 self.fused = True
                 key_m = "u_mag_fbank" if b_fbank_mel else "u_mag"
-                self.up_mag = e.constant(
-                    ("upack", key_m, self.mag_dim, H, float(alpha), ktm.value),
-                    lambda: hm.pack_unwarp_frag((hm.unwarp_fbank_matrix if b_fbank_mel else hm.unwarp_matrix)(
-                        self.mag_dim, H, alpha), ktm.value, 132))
-                self.up_phase = e.constant(
-                    ("upack", "u_phase", self.phase_dim, N, int(fs), float(self.alpha_phase), ktp.value),
-                    lambda: hm.pack_unwarp_frag(hm.phase_unwarp_matrix(self.phase_dim, N, fs, self.alpha_phase),
-                                                ktp.value, 32))
+                fmt = int(e.lib.mpx_synth_fused_format())   # 1: three-way bfloat16 splits, 0: float32 fragments
+                u_mag_fn = lambda: (hm.unwarp_fbank_matrix if b_fbank_mel else hm.unwarp_matrix)(self.mag_dim, H, alpha)  # noqa: E731
+                u_ph_fn = lambda: hm.phase_unwarp_matrix(self.phase_dim, N, fs, self.alpha_phase)                        # noqa: E731
+                if fmt == 1:
+                    self.up_mag = e.constant(("upack_bf16", key_m, self.mag_dim, H, float(alpha)),
+                                             lambda: hm.pack_unwarp_frag_bf16(u_mag_fn(), 132).view(np.int16), dtype=np.int16)
+                    self.up_phase = e.constant(("upack_bf16", "u_phase", self.phase_dim, N, int(fs), float(self.alpha_phase)),
+                                               lambda: hm.pack_unwarp_frag_bf16(u_ph_fn(), 32).view(np.int16), dtype=np.int16)
+                else:
+                    self.up_mag = e.constant(("upack", key_m, self.mag_dim, H, float(alpha), ktm.value),
+                                             lambda: hm.pack_unwarp_frag(u_mag_fn(), ktm.value, 132))
+                    self.up_phase = e.constant(("upack", "u_phase", self.phase_dim, N, int(fs), float(self.alpha_phase), ktp.value),
+                                               lambda: hm.pack_unwarp_frag(u_ph_fn(), ktp.value, 32))
                 seg_fb, seg_rb, run_seg_off = hm.plan_segments(self.runs_host["frame_begin"], self.runs_host["frame_end"],
                                                                cat(row0), cat(row1))
                 self.n_segments = int(seg_fb.size)

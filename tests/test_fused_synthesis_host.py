@@ -45,3 +45,47 @@ def test_pack_unwarp_frag_layout():
                     if k < 45:
                         acc[:, 16 * ct:16 * ct + 16] += a[:, k][:, None] * pk[ct, q, 16 * g:16 * g + 16, e][None, :]
     assert np.allclose(acc[:, :512], (a @ u)[:, :512], atol=1e-5)
+
+
+def test_bf16_split_is_exact_to_2_pow_minus_24_and_packs_in_fragment_order():
+    """hostmath.bf16_split3 / pack_unwarp_frag_bf16: the three bfloat16 parts sum back to the float32 value to 2^-24 of it,
+    and out[ct][kb][s][lane][j] = split_s(U)[32 kb + 8 (lane >> 4) + j][16 ct + (lane & 15)]."""
+    from magphase_amd import hostmath as hm
+
+    rng = np.random.RandomState(2)
+    v = (rng.randn(4000) * np.exp(rng.uniform(-20, 5, 4000))).astype(np.float32)
+    a, b, c = hm.bf16_split3(v)
+    for part in (a, b, c):   # each part IS a bfloat16 value: its low 16 bits are zero
+        assert np.all((part.view(np.uint32) & 0xFFFF) == 0)
+    rec = a.astype(np.float64) + b.astype(np.float64) + c.astype(np.float64)
+    assert np.max(np.abs(rec - v.astype(np.float64)) / np.abs(v.astype(np.float64))) <= 2.0 ** -23
+    u = rng.randn(45, 700) * 0.4
+    pk = hm.pack_unwarp_frag_bf16(u, 32)
+    assert pk.shape == (32, 2, 3, 64, 8) and pk.dtype == np.uint16
+    parts = hm.bf16_split3(u.astype(np.float32))
+    for ct, kb, s_, lane, j in ((0, 0, 0, 0, 0), (31, 1, 2, 63, 7), (9, 1, 1, 21, 3), (17, 0, 2, 40, 6)):
+        k, col = 32 * kb + 8 * (lane >> 4) + j, 16 * ct + (lane & 15)
+        want = parts[s_][k, col] if (k < 45 and col < 700) else np.float32(0)
+        got = (np.uint32(pk[ct, kb, s_, lane, j]) << 16).view(np.float32) if hasattr(np.uint32(0), "view") else None
+        assert np.uint16(np.float32(want).view(np.uint32) >> 16) == pk[ct, kb, s_, lane, j]
+
+
+def test_six_term_bf16_product_sum_matches_the_float32_chain():
+    """sum_k a_k u_k from the six partial products a_i u_j (i + j <= 2) of the three-way splits, float32 accumulation:
+    as accurate as a float32 fmaf chain on operands of the unwarp's size (what v_mfma_f32_16x16x32_bf16 computes)."""
+    from magphase_amd import hostmath as hm
+
+    rng = np.random.RandomState(3)
+    a = (rng.randn(16, 60) * 3.0).astype(np.float32)
+    u = (rng.randn(60, 256) * 0.3).astype(np.float32)
+    ref = a.astype(np.float64) @ u.astype(np.float64)
+    chain = np.zeros((16, 256), dtype=np.float32)
+    for k in range(60):
+        chain = (chain + a[:, k:k + 1] * u[k][None, :]).astype(np.float32)
+    sa, su = hm.bf16_split3(a), hm.bf16_split3(u)
+    acc = np.zeros((16, 256), dtype=np.float32)
+    for i, j in ((2, 0), (1, 1), (0, 2), (1, 0), (0, 1), (0, 0)):
+        for k in range(60):
+            acc = (acc + sa[i][:, k:k + 1] * su[j][k][None, :]).astype(np.float32)
+    e_chain, e_split = np.max(np.abs(chain - ref)), np.max(np.abs(acc - ref))
+    assert e_split <= 2.0 * e_chain + 1e-7, (e_split, e_chain)
