@@ -129,14 +129,18 @@ def main():
                 shared = {}
             # a variant named *_fused builds its synthesis plan with the fused unwarp -> synthesis launch
             # (MAGPHASE_SYNTH_FUSED=1, opt-in), *_staged forces the staged pair
-            prev = os.environ.get("MAGPHASE_SYNTH_FUSED")
+            # AB_ENV_<name>="K=V,K2=V2": environment of this variant's plan construction (e.g. MAGPHASE_UNWARP_BF16=0)
+            extra = dict(kv.split("=", 1) for kv in os.environ.get("AB_ENV_" + name, "").split(",") if "=" in kv)
             if name.endswith("_staged") or name.endswith("_fused"):
-                os.environ["MAGPHASE_SYNTH_FUSED"] = "1" if name.endswith("_fused") else "0"
+                extra["MAGPHASE_SYNTH_FUSED"] = "1" if name.endswith("_fused") else "0"
+            saved = {k: os.environ.get(k) for k in extra}
+            os.environ.update(extra)
             sa, ss = bench.lowdim_plans(em, eng, utts, shared)
-            if name.endswith("_staged") or name.endswith("_fused"):
-                os.environ.pop("MAGPHASE_SYNTH_FUSED")
-                if prev is not None:
-                    os.environ["MAGPHASE_SYNTH_FUSED"] = prev
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
             steps[name] = (sa, ss)
     times = {n: ([], [], []) for n in names}
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
