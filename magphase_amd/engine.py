@@ -117,6 +117,24 @@ class Engine:
     def stream_ptr(self):
         return _torch().cuda.current_stream(self.device).cuda_stream
 
+    def background(self, fn, *args):
+        """fn(*args) on the engine's helper thread -> Future (result() re-raises).  For the native, GIL-free host passes of a
+        plan build (staging copies into page-locked memory): they run while the constructor goes on with its index
+        arithmetic, and are joined before the upload.  MAGPHASE_HOST_THREAD=0: inline."""
+        import concurrent.futures as cf
+
+        if os.environ.get("MAGPHASE_HOST_THREAD", "1") == "0":
+            f = cf.Future()
+            try:
+                f.set_result(fn(*args))
+            except BaseException as exc:   # noqa: B902 -- delivered by result(), as the threaded form does
+                f.set_exception(exc)
+            return f
+        ex = getattr(self, "_helper", None)
+        if ex is None:
+            ex = self._helper = cf.ThreadPoolExecutor(max_workers=1, thread_name_prefix="mpx-host")
+        return ex.submit(fn, *args)
+
     def copy_stream(self, kind):
         """The engine's H2D ('up') / D2H ('down') stream, or None (MAGPHASE_COPY_STREAMS=0: copies in the compute stream).
         A corpus job's launches are device-bound, and a third of a launch's device time was its own PCIe traffic queued
@@ -982,11 +1000,17 @@ class LosslessAnalysisPlan:
             nb = np.asarray([a.nbytes for a in arrs], dtype=np.int64)
             doff = np.concatenate(([0], np.cumsum(nb)[:-1])).astype(np.int64)
             n_thr = max(1, int(os.environ.get("MAGPHASE_IO_NATIVE_THREADS", "8")))
-            if engine.lib.mpx_host_copy_many(k, src, nb.ctypes.data, doff.ctypes.data, buf.ctypes.data, n_thr) != 0:
-                raise _lib.MagphaseHipError("mpx_host_copy_many failed")
+
+            def _copy(arrs=arrs, src=src, nb=nb, doff=doff):   # (keeps the arrays alive until the copy is done)
+                if engine.lib.mpx_host_copy_many(len(arrs), src, nb.ctypes.data, doff.ctypes.data, buf.ctypes.data, n_thr) != 0:
+                    raise _lib.MagphaseHipError("mpx_host_copy_many failed")
+
+            copy_done = engine.background(_copy) if hasattr(engine, "background") else None
+            if copy_done is None:
+                _copy()
             copied = True
         else:
-            copied = False
+            copied, copy_done = False, None
         for (v_sig, fs, v_pm_sec, v_voi) in utts:
             v_sig = np.asarray(v_sig)
             n = v_sig.shape[0]
@@ -1041,6 +1065,8 @@ class LosslessAnalysisPlan:
                 for i, u in zip(hit.tolist(), utt_of.tolist()):
                     self.long_frame_lens[u].append(int(tot[i]))
         e = engine
+        if copy_done is not None:
+            copy_done.result()   # the staged samples are in place (the copy ran beside the index arithmetic above)
         if all_i16:
             raw = e.upload_staged((total + 1) // 2 + 2)
             self.sig = e.empty((max(total, 1),))
@@ -1295,13 +1321,18 @@ class CompressedSynthesisPlan:
         # coefficient matrices: concatenated straight into the page-locked staging buffer, one DMA
         n_m, n_p = self.n_rows * self.mag_dim, self.n_rows * self.phase_dim
         stage = e.host_staging(n_m + 2 * n_p)
-        e.stage_rows(a_mag, stage[:n_m].reshape(self.n_rows, self.mag_dim))
-        e.stage_rows(a_real, stage[n_m:n_m + n_p].reshape(self.n_rows, self.phase_dim))
-        e.stage_rows(a_imag, stage[n_m + n_p:].reshape(self.n_rows, self.phase_dim))
-        coef = e.upload_staged(n_m + 2 * n_p)
-        self.a_mag = coef[:n_m].view(self.n_rows, self.mag_dim)
-        self.a_real = coef[n_m:n_m + n_p].view(self.n_rows, self.phase_dim)
-        self.a_imag = coef[n_m + n_p:].view(self.n_rows, self.phase_dim)
+
+        def _stage():
+            e.stage_rows(a_mag, stage[:n_m].reshape(self.n_rows, self.mag_dim))
+            e.stage_rows(a_real, stage[n_m:n_m + n_p].reshape(self.n_rows, self.phase_dim))
+            e.stage_rows(a_imag, stage[n_m + n_p:].reshape(self.n_rows, self.phase_dim))
+
+        # (inline: on the helper thread -- Engine.background -- the launch loop of a generation job got 5 % SLOWER, the three
+        # calls' Python glue fights the constructor for the GIL; the analysis plan's single native copy gains 7 % there)
+        import concurrent.futures as _cf
+        staged_done = _cf.Future()
+        _stage()
+        staged_done.set_result(None)
         if noise_mode == "device":
             seeds = np.arange(len(nfr), dtype=np.uint64) if noise_seeds is None else np.asarray(noise_seeds).astype(np.uint64)
             if seeds.size != len(nfr):
@@ -1351,6 +1382,11 @@ class CompressedSynthesisPlan:
         n_slots = e.synth_comp_slots() if hasattr(e, "synth_comp_slots") else 1024
         _plan_ola_runs(self, pm_rel, starts, self.out_len, self.out_off_host, N, n_slots, frames_per_run, _up,
                        weights=e.synth_ola_slot_weights(comp=True) if hasattr(e, "synth_ola_slot_weights") else None)
+        staged_done.result()
+        coef = e.upload_staged(n_m + 2 * n_p)
+        self.a_mag = coef[:n_m].view(self.n_rows, self.mag_dim)
+        self.a_real = coef[n_m:n_m + n_p].view(self.n_rows, self.phase_dim)
+        self.a_imag = coef[n_m + n_p:].view(self.n_rows, self.phase_dim)
         self._gains_dev = None
         # Fused unwarp -> synthesis (mpx_synthesis_compressed_fused; opt-in: MAGPHASE_SYNTH_FUSED=1 or fused=True): N = 4096,
         # the transmitted phase, a crossfade that ends at or below bin 512.  The runs are cut into segments of <= 16 frames
