@@ -34,7 +34,12 @@ if ROOT not in sys.path:
 
 POOL = 64
 BASE_DUR_S = 8.0
-BATCH = 64
+# utterances per launch.  Extraction: 64 (30 MB of PCM per launch; 128 / 256 measured 14 / 10 % slower: the staging copy grows
+# with the launch and the plan build is the bound).  Generation: 256 = 128 per sample rate (per-launch fixed costs -- plan
+# build, noise stream, PCIe copies -- amortise: 64 / 128 / 256 / 512 per launch = 70.9 / 84.9 / 96.1 / 44.2 k x real time on one
+# box; at 512 the page-locked buffers re-grow).  CORPUS_BATCH overrides both.
+BATCH = int(os.environ.get("CORPUS_BATCH", "64"))
+BATCH_GEN = int(os.environ.get("CORPUS_BATCH", "256"))
 
 
 def corpus_spec(n_utts, mixed_rates):
@@ -63,7 +68,8 @@ def _cut(base, dur, fs):
     return pcm[:n], int(fs), pm[keep], voi[keep]
 
 
-def _batches(items, n=BATCH):
+def _batches(items, n=None):
+    n = n or BATCH
     return [items[i:i + n] for i in range(0, len(items), n)]
 
 
@@ -153,12 +159,12 @@ def run_generation(rank, mine, dur, fs):
 
         np.random.seed(1000 + rank)
         if items:
-            synth(items[:BATCH])
+            synth(items[:BATCH_GEN])
             take(0)
             eng.mt_sync()
         t0 = time.perf_counter()
         frames, smpls = 0, 0
-        for b in _batches(items):
+        for b in _batches(items, BATCH_GEN):
             frames += synth(b)
             smpls += take(2)            # the two rate groups of the launch just issued stay in flight
         smpls += take(0)
@@ -193,7 +199,7 @@ def run(n_utts, rank=0, world=1, dist=None, barrier=None):
         frames, audio = sum(x["frames"] for x in allr), sum(x["audio_s"] for x in allr)
         costs, secs = [x["cost"] for x in allr], [x["seconds"] for x in allr]
         out[name] = {
-            "utterances": int(n_utts), "ranks": world, "launch_utts": BATCH,
+            "utterances": int(n_utts), "ranks": world, "launch_utts": BATCH_GEN if fn is run_generation else BATCH,
             "frames": frames, "audio_s": round(audio, 1), "seconds_max_over_ranks": round(t_max, 4),
             "frames_per_s": round(frames / t_max, 1), "x_realtime": round(audio / t_max, 1),
             "per_rank_utts": [x["utts"] for x in allr], "per_rank_seconds": [round(s, 4) for s in secs],
@@ -201,10 +207,10 @@ def run(n_utts, rank=0, world=1, dist=None, barrier=None):
             "time_imbalance_max_over_mean": round(max(secs) / (sum(secs) / len(secs)), 4),
         }
     out["what"] = ("synthetic corpus of %d utterances (2-8 s, mean 5 s), LPT-sharded over %d rank(s) by frames x transform "
-                   "length, %d utterances per launch, array-level batch API in its pipelined form: a launch's results are taken one launch later from a page-locked ring, "
+                   "length, %d utterances per launch (generation: %d), array-level batch API in its pipelined form: a launch's results are taken one launch later from a page-locked ring, "
                    "numpy's noise stream stays on the device between launches (plan build + H2D + kernels + D2H + every wait "
                    "and the final state hand-back inside the "
                    "clock, files outside): configs[3] = analysis_compressed (48 kHz, 60 / 10, Q7), configs[4] = post-filter "
                    "+ synthesis_from_compressed + output high-pass + 16-bit PCM (60 / 45, 48 kHz and 16 kHz mixed, numpy's "
-                   "global noise stream)" % (n_utts, world, BATCH))
+                   "global noise stream)" % (n_utts, world, BATCH, BATCH_GEN))
     return out
