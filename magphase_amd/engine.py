@@ -84,14 +84,25 @@ class _PinnedRing:
                 buf = self._bufs[slot]
                 if buf is None or buf.numel() < nbytes:
                     # Page-locking is slow (about 60 ms per 24 MB here): every slot is sized by the largest request so far
-                    # with headroom, and the FIRST request sizes all of them -- the first batch of a corpus pays, once.
+                    # with headroom, and a request that outgrows the slots re-sizes ALL the free ones at once -- the first
+                    # (warm-up) launch of a job with larger launches pays, once, instead of each of the next launches paying
+                    # for its own slot inside the job (round 5: bench.py's corpus shard ran at 2/3 of its warm rate because
+                    # the slots sized by the earlier blocks re-grew one per launch).
                     size = max([int(nbytes * 1.25), 1 << 20] + [b.numel() for b in self._bufs if b is not None])
-                    first = all(b is None for b in self._bufs)
                     self._bufs[slot] = buf = torch.empty(size, dtype=torch.uint8).pin_memory()
-                    if first:
-                        for k in range(len(self._bufs)):
-                            if self._bufs[k] is None:
+                    idle = []
+                    while True:   # the slots nobody holds right now
+                        try:
+                            idle.append(self._freeq.get_nowait())
+                        except queue.Empty:
+                            break
+                    try:
+                        for k in idle:
+                            if self._bufs[k] is None or self._bufs[k].numel() < size:
                                 self._bufs[k] = torch.empty(size, dtype=torch.uint8).pin_memory()
+                    finally:
+                        for k in idle:
+                            self._freeq.put(k)
         except BaseException:
             self._freeq.put(slot)
             raise
@@ -439,8 +450,14 @@ class Engine:
             st["events"][k] = None
         cur = st["bufs"][k]
         if cur is None or cur.numel() < n_floats:   # grown with headroom (batches of a corpus differ a little in length:
-            # re-pinning 30 MB for every slightly longer batch cost 40 ms each)
-            st["bufs"][k] = cur = torch.empty(max(int(n_floats * 1.5), 1 << 22), dtype=torch.float32).pin_memory()
+            # re-pinning 30 MB for every slightly longer batch cost 40 ms each); the OTHER buffer grows with it when it is
+            # idle, so that the second launch of a job does not pay for it inside the job
+            size = max(int(n_floats * 1.5), 1 << 22)
+            st["bufs"][k] = cur = torch.empty(size, dtype=torch.float32).pin_memory()
+            o = 1 - k
+            if (st["bufs"][o] is None or st["bufs"][o].numel() < size) and (st["events"][o] is None or st["events"][o].query()):
+                st["events"][o] = None
+                st["bufs"][o] = torch.empty(size, dtype=torch.float32).pin_memory()
         self._stage_up = cur
         return cur.numpy()[:int(n_floats)]
 
