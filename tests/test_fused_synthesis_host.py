@@ -89,3 +89,59 @@ def test_six_term_bf16_product_sum_matches_the_float32_chain():
             acc = (acc + sa[i][:, k:k + 1] * su[j][k][None, :]).astype(np.float32)
     e_chain, e_split = np.max(np.abs(chain - ref)), np.max(np.abs(acc - ref))
     assert e_split <= 2.0 * e_chain + 1e-7, (e_split, e_chain)
+
+
+def test_data_flow_model_of_the_fused_product():
+    """CPU model of csrc/magphase_comp.hip: fuse_unwarp_steps_bf16 + fuse_interp_store for one segment -- the lane <-> element
+    maps of v_mfma_f32_16x16x32_bf16 as the kernel uses them (A: row lane & 15, k-slots 32 kb + 8 (lane >> 4) + j; B: the
+    packed fragments; C: column lane & 15, rows 4 (lane >> 4) + r), the 16 x 64 tile, the frame table and the four-frames-
+    per-instruction interpolation -- against exp(A U) interpolated directly."""
+    from magphase_amd import hostmath as hm
+
+    rng = np.random.RandomState(7)
+    K, H, n_rows = 60, 2049, 40
+    u = rng.randn(K, H) * 0.2
+    a_rows = (rng.randn(n_rows, K) * 1.5).astype(np.float32)
+    pk = hm.pack_unwarp_frag_bf16(u, 132)                       # [ct][kb][split][lane][8] bf16 bits
+    pkf = (pk.astype(np.uint32) << 16).view(np.float32)
+    rb, nf = 17, 11                                             # segment: rows 17 .. 32, 11 frames
+    row0 = rb + np.sort(rng.randint(0, 15, nf))
+    row1 = np.minimum(row0 + rng.randint(0, 2, nf), rb + 15)
+    wt = rng.rand(nf).astype(np.float32)
+    lane = np.arange(64)
+    li, gq = lane & 15, lane >> 4
+    # A fragments: three-way split of the 16 rows' coefficients, k-slots of every lane
+    asp = hm.bf16_split3(np.pad(a_rows[rb:rb + 16], ((0, 0), (0, 64 - K))))
+    afrag = np.stack([[sp[li][:, 32 * kb + 8 * gq[:, None] + np.arange(8)[None, :]][np.arange(64), np.arange(64)]
+                       for sp in asp] for kb in range(2)])     # [kb][split][lane][8]
+    out = np.zeros((nf, 64 * 33), dtype=np.float32)
+    for s in (0, 5, 32):                                        # three of the 33 column steps (the last: bin 2048 alone)
+        tile = np.zeros((16, 64), dtype=np.float32)
+        for c in range(4):                                      # four 16-bin column tiles of the step
+            ct = 4 * s + c
+            acc = np.zeros((16, 16), dtype=np.float64)          # C[row][col]
+            for i, j in ((2, 0), (1, 1), (0, 2), (1, 0), (0, 1), (0, 0)):
+                for kb in range(2):
+                    # D[m][n] += sum over lanes with (lane & 15 == m resp. n) and the same k-slot of A[m][slot] B[slot][n]
+                    A = np.zeros((16, 32))
+                    B = np.zeros((32, 16))
+                    for l in range(64):
+                        A[li[l], 8 * gq[l]:8 * gq[l] + 8] = afrag[kb][i][l]
+                        B[8 * gq[l]:8 * gq[l] + 8, li[l]] = pkf[ct, kb, j, l]
+                    acc += A @ B
+            tile[:, 16 * c:16 * c + 16] = np.exp(acc.astype(np.float32))
+        for i0 in range(0, nf, 8):                              # fuse_interp_store: lane = (frame 4 u + (lane >> 4), bin quad lane & 15)
+            for uu in range(2):
+                if i0 + 4 * uu >= nf:
+                    continue
+                for l in range(64):
+                    f = min(i0 + 4 * uu + (l >> 4), nf - 1)     # table entries past the last frame repeat it
+                    q4 = 4 * (l & 15)
+                    m0, m1 = tile[row0[f] - rb, q4:q4 + 4], tile[row1[f] - rb, q4:q4 + 4]
+                    out[f, 64 * s + q4:64 * s + q4 + 4] = (m1 - m0) * wt[f] + m0
+    ref = np.exp(a_rows.astype(np.float64) @ u)
+    for s in (0, 5, 32):
+        cols = np.arange(64 * s, min(64 * s + 64, H))
+        want = ref[row0][:, cols] + (ref[row1][:, cols] - ref[row0][:, cols]) * wt[:, None]
+        got = out[:, cols]
+        assert np.max(np.abs(got - want) / want) < 5e-6, (s, np.max(np.abs(got - want) / want))
