@@ -2843,6 +2843,9 @@ static int dispatch_unwarp_mfma(hipStream_t s, const UnwarpJobs& jobs, int job0,
 // variable-rate frame of the tile -- [tile_first[T], tile_first[T + 1]), planned on the host -- reads its two rows
 // back (lane = bin: 256 contiguous bytes), interpolates with fmaf(m1 - m0, t, m0) and stores its 256-byte row segment.
 // Same values as MODE 2 (each row's product is the same fmaf chain).
+#ifndef MPX_UNWARP_QUADS
+#define MPX_UNWARP_QUADS 1
+#endif
 constexpr int kTileRows = 31;          // new constant-rate rows per tile
 constexpr int kTileStride = 72;        // floats per LDS row
 
@@ -2854,7 +2857,7 @@ __global__ __launch_bounds__(256) void k_mel_unwarp_tiled(UnwarpJob job, long lo
                                                           const int* __restrict__ row0, const int* __restrict__ row1,
                                                           const float* __restrict__ rowt,
                                                           const int* __restrict__ tile_first) {
-    __shared__ float tiles[4][32 * kTileStride];
+    __shared__ __attribute__((aligned(16))) float tiles[4][32 * kTileStride];
     __shared__ __attribute__((aligned(16))) float4 tabs[4][64];
     const int lane = threadIdx.x & 63;
     const int wave = rfl((int)(threadIdx.x >> 6));
@@ -2946,6 +2949,37 @@ __global__ __launch_bounds__(256) void k_mel_unwarp_tiled(UnwarpJob job, long lo
                                     rowt[fl], 0.0f);
             wave_sync();
             const int cnt = min(64, fb - fc);
+#if MPX_UNWARP_QUADS
+            // FOUR frames per wave instruction (round 5): lane = (frame i + (lane >> 4), bin quad lane & 15) reads 16 bytes of
+            // each of its two rows (a 16-lane group reads one row's 256 contiguous bytes: conflict-free), interpolates four
+            // bins and stores them as one 16-byte store -- a quarter of the LDS reads and store instructions of the
+            // lane-per-bin form, the same values.  Rows are ld floats apart (ld a multiple of 32: 16-byte aligned); the quad
+            // that holds bin H - 1 writes up to three floats of the row's padding.
+            const int fq = lane >> 4, q4 = 4 * (lane & 15);
+            const bool q_ok = j0 + q4 < jend;
+            (void)col_ok;
+            float* obase = job.out + (long long)fc * ld + j0 + q4;
+            for (int i = 0; i < cnt; i += 8) {   // two batches of four frames in flight
+                float4 e[2], m0[2], m1[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    e[u] = tab[min(i + 4 * u + fq, cnt - 1)];
+                    m0[u] = *reinterpret_cast<const float4*>(tile + __builtin_bit_cast(int, e[u].x) + q4);
+                    m1[u] = *reinterpret_cast<const float4*>(tile + __builtin_bit_cast(int, e[u].y) + q4);
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int f = i + 4 * u + fq;
+                    const float w = e[u].z;
+                    float4 v;
+                    v.x = fmaf(m1[u].x - m0[u].x, w, m0[u].x);
+                    v.y = fmaf(m1[u].y - m0[u].y, w, m0[u].y);
+                    v.z = fmaf(m1[u].z - m0[u].z, w, m0[u].z);
+                    v.w = fmaf(m1[u].w - m0[u].w, w, m0[u].w);
+                    if (q_ok && f < cnt) *reinterpret_cast<float4*>(obase + (long long)f * ld) = v;
+                }
+            }
+#else
             float* orow = job.out + (long long)fc * ld + j0 + lane;
             for (int i = 0; i < cnt; i += 4) {   // four frames per iteration: their LDS reads are in flight together
                 float m0[4], m1[4], w[4];
@@ -2965,6 +2999,7 @@ __global__ __launch_bounds__(256) void k_mel_unwarp_tiled(UnwarpJob job, long lo
 #endif
                 }
             }
+#endif
         }
     }
 }
@@ -2983,6 +3018,8 @@ static int launch_unwarp_tiled(hipStream_t s, const UnwarpJob& job, long long F,
 static int dispatch_unwarp_tiled(hipStream_t s, const UnwarpJob& job, int K, long long F, long long n_rows, int H, int ld,
                                  const UnwarpRows& rw, const int* tile_first) {
     if (job.op != 1) return fail(MPX_ERR_ARG, "mpx_mel_unwarp_rows: the tiled form is the exp job's%s");
+    if (MPX_UNWARP_QUADS && ((ld & 3) || (reinterpret_cast<uintptr_t>(job.out) & 15)))
+        return fail(MPX_ERR_ARG, "mpx_mel_unwarp_rows: with tile_first the output rows must be 16-byte aligned (ld a multiple of 4: mpx_spec_ld)%s");
     switch ((K + 3) / 4) {
 #define MPX_UNWARP_CASE(q) case q: return launch_unwarp_tiled<2 * q>(s, job, F, n_rows, H, ld, rw, tile_first);
         MPX_UNWARP_CASE(1) MPX_UNWARP_CASE(2) MPX_UNWARP_CASE(3) MPX_UNWARP_CASE(4) MPX_UNWARP_CASE(5) MPX_UNWARP_CASE(6)
