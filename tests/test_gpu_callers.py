@@ -240,3 +240,28 @@ def test_device_pcm16_equals_the_host_wav_conversion(tmp_path):
             else:        # the host widens the device's float32 PCM first: same values, same result
                 assert np.array_equal(pcm[u], ref)
             assert 32000 < int(np.max(np.abs(ref.astype(np.int32)))) <= 32112      # 0.98 * 32767
+
+
+def test_device_pcm16_on_ragged_lengths_around_the_peak_kernels_blocks():
+    """mpx_pcm16's peak is an atomic maximum over blocks of 4 096 samples (round 5): utterances of 1 .. 100 001 samples, a
+    silent one among them, float64 and float32 input, against the host's operations (libaudio.py:352-365) sample for sample."""
+    import torch
+    from magphase_amd.engine import get_engine
+    eng = get_engine()
+    rng = np.random.RandomState(9)
+    lens = [1, 7, 4095, 4096, 4097, 8193, 100001, 300]
+    for dt in (np.float64, np.float32):
+        sigs = [(rng.uniform(-1, 1, n) * rng.uniform(0.01, 3.0)).astype(dt) for n in lens]
+        sigs[5][:] = 0.0                                     # a silent utterance: 0 / 0 -> the bound, as on the host
+        sigs[6][77777] = -3.5                                # the peak deep inside a long utterance, negative
+        off = np.concatenate(([0], np.cumsum(lens))).astype(np.int64)
+        y = torch.from_numpy(np.concatenate(sigs)).to(eng.device)
+        got = eng.output_pcm16(y, off, norm=0.98)
+        for u, x in enumerate(sigs):
+            x64 = x.astype(np.float64)
+            with np.errstate(invalid="ignore", divide="ignore"):
+                v = 0.98 * x64 / np.max(np.abs(x64))
+            ref = np.clip(np.rint(v * 32767.0), -32768, 32767)
+            g = got[off[u]:off[u + 1]].astype(np.float64)
+            ok = ~np.isnan(ref)
+            assert np.array_equal(g[ok], ref[ok]), (dt, u)

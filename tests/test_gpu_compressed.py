@@ -428,7 +428,9 @@ def test_device_output_hpf_matches_lfilter(mp):
     eng = get_engine()
     rng = np.random.RandomState(2)
     for fs in (48000, 16000):
-        lens = [1, 5, 1023, 1024, 1025, 50000, 3000]
+        # around the scan's units: blocks of 256 samples, 64 x 64 tiles, 64 blocks (16 384 samples) per wave and per carry
+        # step, an utterance of several carry steps; (1 023-1 025: the block size of rounds 2-4)
+        lens = [1, 5, 63, 64, 65, 255, 256, 257, 1023, 1024, 1025, 16383, 16384, 16385, 50000, 3000, 240001]
         sigs = [rng.uniform(-1, 1, n).astype(np.float32) for n in lens]
         off = np.concatenate(([0], np.cumsum(lens)))
         y = eng.output_hpf(eng.to_device(np.concatenate(sigs), np.float32), off, fs).cpu().numpy()
