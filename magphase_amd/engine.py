@@ -544,59 +544,85 @@ class Engine:
         """
         items: list of (name, array, numpy dtype).  ONE host-to-device copy for all of them (each ~25 us on its own: a
         plan has 15-25 small index tables); returns {name: tensor}, the tensors being 256-byte aligned views of one
-        device buffer.
+        device buffer.  The arrays are cast straight into the page-locked arena (one pass: no intermediate host image) and
+        the copy never blocks: round 5 found the tables of a launch of more than ~20 k frames (> 1 MB) going up as a PAGEABLE
+        synchronous copy, which waits for everything queued on the stream -- the host and the device took turns.
         """
         torch = _torch()
         tmap = {np.dtype(np.float32): torch.float32, np.dtype(np.float64): torch.float64,
                 np.dtype(np.int32): torch.int32, np.dtype(np.int64): torch.int64, np.dtype(np.uint8): torch.uint8}
-        prepared, offs, total = [], [], 0
+        shapes, offs, sizes, total = [], [], [], 0
         for _name, arr, dt in items:
-            a = np.ascontiguousarray(arr, dtype=dt)
+            shp = np.shape(arr)
+            nb = int(np.prod(shp, dtype=np.int64)) * np.dtype(dt).itemsize
             total = (total + 255) // 256 * 256
             offs.append(total)
-            prepared.append(a)
-            total += a.nbytes
-        host = np.zeros(max(total, 1), dtype=np.uint8)
-        for off, a in zip(offs, prepared):
-            host[off:off + a.nbytes] = a.reshape(-1).view(np.uint8)
-        if host.nbytes <= self._ARENA_MAX_ITEM:
-            dev = self._arena_upload(host)
+            shapes.append(shp)
+            sizes.append(nb)
+            total += nb
+        total = max(total, 1)
+
+        def fill(host):   # host: uint8 view of `total` bytes (page-locked arena, or a fresh array for oversized sets)
+            for (_name, arr, dt), off, shp, nb in zip(items, offs, shapes, sizes):
+                if nb:
+                    np.copyto(host[off:off + nb].view(dt).reshape(shp), arr, casting="unsafe")
+
+        if total <= self._ARENA_MAX_ITEM:
+            dev = self._arena_upload(None, nbytes=total, fill=fill)
         else:
+            host = np.zeros(total, dtype=np.uint8)
+            fill(host)
             dev = torch.from_numpy(host).to(self.device, non_blocking=False)
         out = {}
-        for (name, _arr, dt), off, a in zip(items, offs, prepared):
-            if a.nbytes == 0:
-                out[name] = torch.empty(a.shape, dtype=tmap[np.dtype(dt)], device=self.device)
+        for (name, _arr, dt), off, shp, nb in zip(items, offs, shapes, sizes):
+            if nb == 0:
+                out[name] = torch.empty(shp, dtype=tmap[np.dtype(dt)], device=self.device)
             else:
-                out[name] = dev[off:off + a.nbytes].view(tmap[np.dtype(dt)]).view(a.shape)
+                out[name] = dev[off:off + nb].view(tmap[np.dtype(dt)]).view(shp)
         return out
 
-    _ARENA_BYTES = 8 << 20
-    _ARENA_MAX_ITEM = 1 << 20
+    _ARENA_BYTES = 64 << 20
+    _ARENA_PARTS = 4
+    _ARENA_MAX_ITEM = (64 << 20) // 4
 
-    def _arena_upload(self, a):
-        """A small host array -> device tensor through a page-locked bump arena, WITHOUT blocking: a pageable
-        `tensor.to(device)` waits for everything queued on the stream before it -- after a batch's kernels have been
-        launched that is the whole batch, which serialised the host with the device once per small table.  The arena
-        wraps around after 8 MB of uploads; the wrap synchronises the device once (the copies issued so far have
-        certainly left the arena then)."""
+    def _arena_upload(self, a, nbytes=None, fill=None):
+        """A host array (or `nbytes` written by fill(view)) -> device tensor through a page-locked bump arena, WITHOUT
+        blocking: a pageable `tensor.to(device)` waits for everything queued on the stream before it -- after a batch's
+        kernels have been launched that is the whole batch, which serialised the host with the device once per table.
+        The arena is four parts used in turn; a part is waited for (the event of its last copy) only when the bump pointer
+        comes round to it again, three parts of uploads later -- in practice never a wait."""
         import threading
 
         torch = _torch()
         ar = getattr(self, "_arena", None)
         if ar is None:
             buf = torch.empty(self._ARENA_BYTES, dtype=torch.uint8).pin_memory()
-            ar = self._arena = {"t": buf, "np": buf.numpy(), "off": 0, "lock": threading.Lock()}
-        n = int(a.nbytes)
+            ar = self._arena = {"t": buf, "np": buf.numpy(), "off": 0, "lock": threading.Lock(),
+                                "ev": [None] * self._ARENA_PARTS}
+        n = int(a.nbytes) if a is not None else int(nbytes)
+        part = self._ARENA_BYTES // self._ARENA_PARTS
         with ar["lock"]:
             off = (ar["off"] + 255) // 256 * 256
-            if off + n > self._ARENA_BYTES:
-                torch.cuda.synchronize(self.device)
-                off = 0
+            q = off // part
+            if off + n > (q + 1) * part or q >= self._ARENA_PARTS:   # does not fit the current part: on to the next one
+                q = (q + 1) % self._ARENA_PARTS
+                off = q * part
+                if ar["ev"][q] is not None:
+                    ar["ev"][q].synchronize()
+                    ar["ev"][q] = None
             ar["off"] = off + n
-            ar["np"][off:off + n] = a.reshape(-1).view(np.uint8)
+            view = ar["np"][off:off + n]
+            if a is not None:
+                view[:] = a.reshape(-1).view(np.uint8)
+            else:
+                fill(view)
             with torch.cuda.device(self.device):
                 dev = ar["t"][off:off + n].to(self.device, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(self.device))
+                ar["ev"][q] = ev
+        if a is None:
+            return dev
         tmap = {np.dtype(np.float32): torch.float32, np.dtype(np.float64): torch.float64, np.dtype(np.int32): torch.int32,
                 np.dtype(np.int64): torch.int64, np.dtype(np.uint8): torch.uint8, np.dtype(np.int16): torch.int16}
         return dev.view(tmap[a.dtype]).view(a.shape)
