@@ -1391,7 +1391,13 @@ class CompressedSynthesisPlan:
         _up.append(("nright", cat(nright), np.int32))
         _up.append(("wtype", cat(wtype), np.int32))
         _up.append(("voiced", cat(voiced), np.int32))
-        if self.b_const_rate:   # frames of every 31-row tile of the constant-rate matrix (mpx_mel_unwarp_rows)
+        # Variable-rate features (rows == frames: identity tables, weight 0) take the same unwarp launch as constant-rate ones
+        # (mpx_mel_unwarp_rows): the interpolation is then exact (fmaf(0, 0, m) = m: the same values as mpx_mel_unwarp), and the
+        # phase rows are produced only where the synthesis reads them -- voiced frames, bins below the crossfade's end: a
+        # quarter of the work of the plain form, which unwarped all 2 049 bins of both phase streams for every frame (round 5:
+        # 0.81 -> ... ms per 128-utterance generation launch).  MAGPHASE_UNWARP_ROWS_VAR=0: the plain form.
+        self.unwarp_rows = self.b_const_rate or os.environ.get("MAGPHASE_UNWARP_ROWS_VAR", "1") != "0"
+        if self.unwarp_rows:   # frames of every 31-row tile of the coefficient matrix (mpx_mel_unwarp_rows)
             r0c = cat(row0)
             self._check_rows_for_tiles(r0c, cat(row1))
             _up.append(("tile_first", np.searchsorted(r0c, 31 * np.arange((self.n_rows + 30) // 31 + 1), side="left"),
@@ -1588,7 +1594,7 @@ class CompressedSynthesisPlan:
                 mark("k_post_filter")
             if fused:
                 pass                # the synthesis launch unwarps its own segments
-            elif self.b_const_rate:   # constant -> variable rate inside the unwarp: one spectrum row per synthesis frame
+            elif self.unwarp_rows:   # constant -> variable rate inside the unwarp: one spectrum row per synthesis frame
                 _lib.check(lib.mpx_mel_unwarp_rows(
                     st, self.total_frames, H, a_mag.data_ptr(), self.mag_dim, self.u_mag.data_ptr(), mag.data_ptr(),
                     self.a_real.data_ptr(), self.a_imag.data_ptr(), self.phase_dim, self.u_phase.data_ptr(),
