@@ -755,10 +755,13 @@ struct BiquadCoef {
     double b0, b1, b2, a1, a2;
 };
 
+// cg / cz (second section only): the PREVIOUS section's free response is added while loading -- x[n] + G[n mod 256] . z_start
+// of the block -- instead of by a k_hpf_apply pass over the whole signal in between (0.49 GB of traffic per 128 utterances).
 template <typename TIn>
 __global__ __launch_bounds__(64) void k_hpf_zero_state(const TIn* __restrict__ x, const long long* __restrict__ off,
                                                        const int* __restrict__ blk_off, BiquadCoef c,
-                                                       double* __restrict__ y, double* __restrict__ zend) {
+                                                       double* __restrict__ y, double* __restrict__ zend,
+                                                       const double* __restrict__ cg, const double* __restrict__ cz) {
     // one wave per 64 consecutive blocks of an utterance, lane t = block 64 blockIdx.x + t; blk_off[u] = first global
     // block index of utterance u
     __shared__ double tile[kHpfTile * kHpfTileStride];
@@ -769,13 +772,36 @@ __global__ __launch_bounds__(64) void k_hpf_zero_state(const TIn* __restrict__ x
     const int t = threadIdx.x;
     const long long base = off[u] + (long long)j0 * kHpfBlock;   // first sample of the wave's blocks
     const long long end = off[u + 1];
+    __shared__ double czs[2 * kHpfTile];
+    if (cg) {   // start states of the wave's 64 blocks in the previous section
+        const int jb = min(j0 + t, nb - 1);
+        czs[2 * t] = cz[2 * (long long)(blk_off[u] + jb)];
+        czs[2 * t + 1] = cz[2 * (long long)(blk_off[u] + jb) + 1];
+        __syncthreads();
+    }
     double z0 = 0, z1 = 0;
     for (int ch = 0; ch < kHpfBlock / kHpfTile; ++ch) {
         // row r = block j0 + r, its samples [ch * 64, ch * 64 + 64): lane t loads column t of every row (coalesced)
-#pragma unroll 8
-        for (int r = 0; r < kHpfTile; ++r) {
-            const long long n = base + (long long)r * kHpfBlock + ch * kHpfTile + t;
-            tile[r * kHpfTileStride + t] = (n < end) ? (double)x[n] : 0.0;
+        {   // all 64 row loads in flight before the first LDS write (eight at a time left the pass waiting on memory
+            // latency: 266 us per 128 utterances; see the round-5 notes)
+            TIn xv[kHpfTile];
+#pragma unroll
+            for (int r = 0; r < kHpfTile; ++r) {
+                const long long n = base + (long long)r * kHpfBlock + ch * kHpfTile + t;
+                xv[r] = x[min(n, end - 1)];
+            }
+            double g0 = 0.0, g1 = 0.0;
+            if (cg) {
+                g0 = cg[2 * (ch * kHpfTile + t)];
+                g1 = cg[2 * (ch * kHpfTile + t) + 1];
+            }
+#pragma unroll
+            for (int r = 0; r < kHpfTile; ++r) {
+                const long long n = base + (long long)r * kHpfBlock + ch * kHpfTile + t;
+                double xd = (double)xv[r];
+                if (cg) xd += g0 * czs[2 * r] + g1 * czs[2 * r + 1];   // the same operations as k_hpf_apply's
+                tile[r * kHpfTileStride + t] = (n < end) ? xd : 0.0;
+            }
         }
         __syncthreads();
         {   // the lane's row into registers first: 64 independent LDS reads in flight, then the recurrence alone is the chain
@@ -794,7 +820,7 @@ __global__ __launch_bounds__(64) void k_hpf_zero_state(const TIn* __restrict__ x
             for (int i = 0; i < kHpfTile; ++i) tile[t * kHpfTileStride + i] = v[i];
         }
         __syncthreads();
-#pragma unroll 8
+#pragma unroll
         for (int r = 0; r < kHpfTile; ++r) {
             const long long n = base + (long long)r * kHpfBlock + ch * kHpfTile + t;
             if (n < end) y[n] = tile[r * kHpfTileStride + t];
@@ -3610,15 +3636,18 @@ int mpx_output_hpf(void* stream, const float* pcm, const int64_t* out_off, const
         const double* q = sos_host + 6 * sec;   // scipy sos row: b0 b1 b2 a0 a1 a2
         const BiquadCoef c{q[0] / q[3], q[1] / q[3], q[2] / q[3], q[4] / q[3], q[5] / q[3]};
         double* out = (sec == 0) ? y_tmp : y;
+        // section 0's free response is folded into section 1's loads: no k_hpf_apply pass over y_tmp in between
         if (sec == 0)
             hipLaunchKernelGGL(k_hpf_zero_state<float>, gz, dim3(64), 0, s, pcm, (const long long*)out_off, blk_off, c,
-                               out, zend);
+                               out, zend, (const double*)nullptr, (const double*)nullptr);
         else
             hipLaunchKernelGGL(k_hpf_zero_state<double>, gz, dim3(64), 0, s, (const double*)y_tmp,
-                               (const long long*)out_off, blk_off, c, out, zend);
+                               (const long long*)out_off, blk_off, c, out, zend, gtab, (const double*)zstart);
+        // (section 1's zero-state pass has consumed zstart: the carry may overwrite it -- same stream, in order)
         hipLaunchKernelGGL(k_hpf_carry, gc, dim3(64), 0, s, blk_off, (int)n_utts, pmat + 4 * sec, zend, zstart);
-        hipLaunchKernelGGL(k_hpf_apply, ga, dim3(256), 0, s, (const long long*)out_off, blk_off,
-                           gtab + 2 * (size_t)kHpfBlock * sec, zstart, out);
+        if (sec == 1)
+            hipLaunchKernelGGL(k_hpf_apply, ga, dim3(256), 0, s, (const long long*)out_off, blk_off,
+                               gtab + 2 * (size_t)kHpfBlock * sec, zstart, out);
     }
     MPX_HIP_CHECK(hipGetLastError());
     return MPX_OK;
