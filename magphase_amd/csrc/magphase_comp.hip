@@ -3531,15 +3531,32 @@ int mpx_noise_numpy_mt19937(void* stream, const uint32_t* key, int32_t pos, int6
     } else {
         int levels = 0;
         while ((1 << levels) < K) ++levels;
-        static thread_local std::vector<uint32_t> polys;
-        polys.resize((size_t)(shift + levels) * 624);
-        if (mpx_host_mt19937_jump_poly(kMtSegWords, shift + levels, polys.data()) != MPX_OK)
-            return fail(MPX_ERR_ARG, "mpx_noise_numpy_mt19937: jump polynomials unavailable%s");
+        // The ladder of jump polynomials (x^(J 2^l) mod the characteristic polynomial, l < levels) lives on the device, one
+        // copy per (device, shift, levels), uploaded once: round 5 found this call copying it from pageable memory and then
+        // SYNCHRONISING the stream on every launch of a generation job -- the host could never run ahead of the device.
         unsigned* windows = (unsigned*)work;
-        unsigned* dpoly = windows + 624ll * kMtMaxSegs;
-        MPX_HIP_CHECK(hipMemcpyAsync(dpoly, polys.data() + (size_t)shift * 624, (size_t)levels * 624 * sizeof(uint32_t),
-                                     hipMemcpyHostToDevice, s));
-        MPX_HIP_CHECK(hipStreamSynchronize(s));   // pageable source: the copy has left the host buffer
+        const unsigned* dpoly = nullptr;
+        {
+            struct Entry { int dev, shift, levels; unsigned* ptr; };
+            static std::mutex mu;
+            static std::vector<Entry> cache;
+            int dev = 0;
+            (void)hipGetDevice(&dev);
+            std::lock_guard<std::mutex> lock(mu);
+            for (const Entry& e : cache)
+                if (e.dev == dev && e.shift == shift && e.levels >= levels) dpoly = e.ptr;
+            if (!dpoly) {
+                std::vector<uint32_t> polys((size_t)(shift + levels) * 624);
+                if (mpx_host_mt19937_jump_poly(kMtSegWords, shift + levels, polys.data()) != MPX_OK)
+                    return fail(MPX_ERR_ARG, "mpx_noise_numpy_mt19937: jump polynomials unavailable%s");
+                unsigned* p = nullptr;
+                MPX_HIP_CHECK(hipMalloc((void**)&p, (size_t)levels * 624 * sizeof(uint32_t)));
+                MPX_HIP_CHECK(hipMemcpy(p, polys.data() + (size_t)shift * 624, (size_t)levels * 624 * sizeof(uint32_t),
+                                        hipMemcpyHostToDevice));   // synchronous, once
+                cache.push_back(Entry{dev, shift, levels, p});
+                dpoly = p;
+            }
+        }
         MPX_HIP_CHECK(hipMemsetAsync(windows, 0, (size_t)K * 624 * sizeof(unsigned), s));   // jump results are xor-ed in
         hipLaunchKernelGGL(k_mt_first, dim3(1), dim3(256), 0, s, (const unsigned*)key, windows);
         const size_t lds = (size_t)kMtJumpWords * sizeof(unsigned);
