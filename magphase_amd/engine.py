@@ -467,6 +467,8 @@ class Engine:
         a few native threads (mpx_host_copy_many / mpx_host_narrow_f64) -- numpy's concatenate is one thread at ~10 GB/s and
         was a quarter of a synthesis plan's build time.  Anything else goes through numpy."""
         n_thr = max(1, int(os.environ.get("MAGPHASE_IO_NATIVE_THREADS", "8")))
+        if out.nbytes >= (16 << 20) and "MAGPHASE_IO_NATIVE_THREADS" not in os.environ:
+            n_thr = 32   # launches of 100+ utterances stage tens of MB per matrix: 8 / 16 / 32 threads = 116 / 131 / 144 k x real time
         k = len(arrays)
         if k > 1 and all(a.dtype == np.float32 and a.flags.c_contiguous for a in arrays):
             src = (ctypes.c_void_p * k)(*[a.ctypes.data for a in arrays])
