@@ -606,12 +606,14 @@ class Engine:
         with ar["lock"]:
             off = (ar["off"] + 255) // 256 * 256
             q = off // part
-            if off + n > (q + 1) * part or q >= self._ARENA_PARTS:   # does not fit the current part: on to the next one
-                q = (q + 1) % self._ARENA_PARTS
+            if q >= self._ARENA_PARTS or off + n > (q + 1) * part:   # does not fit the part the pointer is in: on to the next
+                q = (q + 1) % self._ARENA_PARTS if q < self._ARENA_PARTS else 0
                 off = q * part
+            if q != ar.get("cur"):   # entering a part (by overflow or because the pointer walked into it): its old copies first
                 if ar["ev"][q] is not None:
                     ar["ev"][q].synchronize()
                     ar["ev"][q] = None
+                ar["cur"] = q
             ar["off"] = off + n
             view = ar["np"][off:off + n]
             if a is not None:
