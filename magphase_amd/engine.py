@@ -158,6 +158,8 @@ class Engine:
         if cs is None:
             torch = _torch()
             cs = self._copy_streams = {"up": torch.cuda.Stream(self.device), "down": torch.cuda.Stream(self.device)}
+        if kind not in cs:   # "rng": the noise stream's generator kernels (a few workgroups each: numpy_global_uniform)
+            cs[kind] = _torch().cuda.Stream(self.device)
         return cs[kind]
 
     def _download(self, pairs):
@@ -391,18 +393,43 @@ class Engine:
                 raise RuntimeError("numpy's global generator is not MT19937")
             key = self.to_device(np.ascontiguousarray(st[1], dtype=np.uint32).view(np.int32), np.int32)
             pos, meta = int(st[2]), (st[0], st[3], st[4])
-        out = self.empty((max(int(n), 1),))
-        raw = torch.empty(max(2 * int(n), 1), dtype=torch.int32, device=self.device)
-        state = torch.empty(625, dtype=torch.int32, device=self.device)
-        work = getattr(self, "_mt_work", None)
-        if work is None:   # segment windows + jump polynomials of the many-workgroup form
-            work = self._mt_work = torch.empty(int(self.lib.mpx_noise_numpy_mt19937_work_words()), dtype=torch.int32,
-                                               device=self.device)
+        # The generator's kernels are a ladder of launches of 1 .. 128 workgroups (0.7 ms per 128 utterances with the GPU
+        # nearly idle): they run on their own stream, beside whatever the compute stream has queued (the previous launch's
+        # synthesis), one generation after the other; the compute stream waits for the samples' event.
+        rng = self.copy_stream("rng")
         with torch.cuda.device(self.device):
-            _lib.check(self.lib.mpx_noise_numpy_mt19937(self.stream_ptr(), key.data_ptr(), int(pos), int(n),
-                                                        raw.data_ptr(), out.data_ptr(), state.data_ptr(),
-                                                        state.data_ptr() + 4 * 624, work.data_ptr()),
-                       "mpx_noise_numpy_mt19937")
+            cur = torch.cuda.current_stream(self.device)
+            if rng is not None:
+                ready = None
+                if pend is None:               # the key was just uploaded in the compute stream; a deferred state comes
+                    ready = torch.cuda.Event()  # from the generator's own stream and needs no wait -- and must not get one:
+                    ready.record(cur)           # waiting for the compute stream here is waiting for the previous launch
+                ctx = torch.cuda.stream(rng)
+            else:
+                import contextlib
+                ctx = contextlib.nullcontext()
+            with ctx:
+                if rng is not None and ready is not None:
+                    rng.wait_event(ready)
+                out = self.empty((max(int(n), 1),))
+                raw = torch.empty(max(2 * int(n), 1), dtype=torch.int32, device=self.device)
+                state = torch.empty(625, dtype=torch.int32, device=self.device)
+                work = getattr(self, "_mt_work", None)
+                if work is None:   # segment windows + jump polynomials of the many-workgroup form
+                    work = self._mt_work = torch.empty(int(self.lib.mpx_noise_numpy_mt19937_work_words()),
+                                                       dtype=torch.int32, device=self.device)
+                _lib.check(self.lib.mpx_noise_numpy_mt19937(self.stream_ptr(), key.data_ptr(), int(pos), int(n),
+                                                            raw.data_ptr(), out.data_ptr(), state.data_ptr(),
+                                                            state.data_ptr() + 4 * 624, work.data_ptr()),
+                           "mpx_noise_numpy_mt19937")
+                if rng is not None:
+                    done = torch.cuda.Event()
+                    done.record(rng)
+            if rng is not None:
+                cur.wait_event(done)           # everything the caller enqueues from here on sees the samples and the state
+                for t_ in (out, state, key):
+                    t_.record_stream(cur)
+                    t_.record_stream(rng)
         self._mt_pending = (state, self._mt_next_pos(pos, 2 * int(n)), meta)
         if not defer:
             self.mt_sync()
@@ -432,6 +459,14 @@ class Engine:
         kind, val = snap
         if kind == "dev":
             self._mt_pending = (val[0].clone(), val[1], val[2])
+            rng = self.copy_stream("rng")
+            if rng is not None:   # the clone was made in the compute stream: the generator's stream reads it next
+                torch = _torch()
+                with torch.cuda.device(self.device):
+                    ev = torch.cuda.Event()
+                    ev.record(torch.cuda.current_stream(self.device))
+                    rng.wait_event(ev)
+                    self._mt_pending[0].record_stream(rng)
         else:
             self._mt_pending = None
             np.random.set_state(val)
