@@ -106,10 +106,26 @@ int mpx_analysis_compressed_fused(void* stream, int fft_len, const void* tables_
                                   int64_t n_frames, const double* win_tab, int32_t win_cap, const float* wpack,
                                   const float* whalf, int32_t mag_dim, int32_t phase_dim, const float* voiced,
                                   int32_t mag_fbank, float* out_mag, float* out_real, float* out_imag);
+/*
+ * The same kernel with its two matrix products on v_mfma_f32_16x16x32_bf16: operand values and weights in three bfloat16
+ * parts each (x = x0 + x1 + x2 to 2^-24 |x|), the six partial products with part indices i + j <= 2 exact in float32 and
+ * summed in the instruction's float32 accumulator -- the float32 product's accuracy at 0.4 of its matrix-pipe time.
+ *   wpack_bf16 : hostmath.pack_warp_fused_bf16 (DEVICE, uint16 bfloat16 bit patterns, 16-byte aligned); whalf as above.
+ * Every other argument, the outputs' meaning and the error behaviour as mpx_analysis_compressed_fused.
+ */
+int mpx_analysis_compressed_fused_bf16x3(void* stream, int fft_len, const void* tables_f64, const float* sig,
+                                         const int64_t* frame_pos, const int32_t* frame_left, const int32_t* frame_right,
+                                         int64_t n_frames, const double* win_tab, int32_t win_cap, const void* wpack_bf16,
+                                         const float* whalf, int32_t mag_dim, int32_t phase_dim, const float* voiced,
+                                         int32_t mag_fbank, float* out_mag, float* out_real, float* out_imag);
 /* column tiles of 16 the fused kernel runs for the magnitude / phase job (what pack_warp_fused must produce) */
 int mpx_analysis_compressed_fused_tiles(int32_t mag_dim, int32_t phase_dim, int32_t* ntm, int32_t* ntp);
 /* waves per workgroup = frames per round = K slices the packed weights are cut into (pack_warp_fused's n_waves) */
 int mpx_analysis_compressed_fused_waves(void);
+/* fragment layout of `wpack` this build's mpx_analysis_compressed_fused expects (pack_warp_fused's `layout`): 0 = one
+ * v_mfma_f32_16x16x4_f32 fragment per column tile; 1 = the magnitude product on v_mfma_f32_4x4x1_16b_f32 (eight
+ * fragments [bin group][half of the 64 coefficients] per wave and chunk), then the phase tiles' fragments */
+int mpx_analysis_compressed_fused_layout(void);
 /* resident workgroups per CU of the fused kernel (the runtime's occupancy query), < 0 on error: diagnostics */
 int mpx_analysis_compressed_fused_blocks_per_cu(int fft_len, int32_t phase_dim);
 

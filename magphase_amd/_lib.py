@@ -23,8 +23,10 @@ SYMBOLS = (
     "mpx_analysis_frames_f64",
     "mpx_analysis_frames_f64w",
     "mpx_analysis_compressed_fused",
+    "mpx_analysis_compressed_fused_bf16x3",
     "mpx_analysis_compressed_fused_tiles",
     "mpx_analysis_compressed_fused_waves",
+    "mpx_analysis_compressed_fused_layout",
     "mpx_analysis_compressed_fused_blocks_per_cu",
     "mpx_synthesis_lossless_frames",
     "mpx_ola_gather",
@@ -132,10 +134,15 @@ def _load_locked():
     lib.mpx_analysis_compressed_fused.restype = ctypes.c_int
     lib.mpx_analysis_compressed_fused.argtypes = [vp, ctypes.c_int, vp, vp, vp, vp, vp, i64, vp, i32, vp, vp, i32, i32, vp, i32,
                                                   vp, vp, vp]
+    lib.mpx_analysis_compressed_fused_bf16x3.restype = ctypes.c_int
+    lib.mpx_analysis_compressed_fused_bf16x3.argtypes = [vp, ctypes.c_int, vp, vp, vp, vp, vp, i64, vp, i32, vp, vp, i32, i32, vp, i32,
+                                                  vp, vp, vp]
     lib.mpx_analysis_compressed_fused_blocks_per_cu.restype = ctypes.c_int
     lib.mpx_analysis_compressed_fused_blocks_per_cu.argtypes = [ctypes.c_int, i32]
     lib.mpx_analysis_compressed_fused_waves.restype = ctypes.c_int
     lib.mpx_analysis_compressed_fused_waves.argtypes = []
+    lib.mpx_analysis_compressed_fused_layout.restype = ctypes.c_int
+    lib.mpx_analysis_compressed_fused_layout.argtypes = []
     lib.mpx_analysis_compressed_fused_tiles.restype = ctypes.c_int
     lib.mpx_analysis_compressed_fused_tiles.argtypes = [i32, i32, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]
     lib.mpx_analysis_frames_f64w.restype = ctypes.c_int

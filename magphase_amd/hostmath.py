@@ -527,7 +527,7 @@ def fused_chunk_bins(fft_len):
     return np.concatenate((64 * q + c, M - 64 * q - c), axis=1).astype(np.int64)
 
 
-def pack_warp_fused(w_mag, w_ph, fft_len, n_waves=8):
+def pack_warp_fused(w_mag, w_ph, fft_len, n_waves=8, layout=0):
     """
     The two warp matrices ([mag_dim x H] and [phase_dim x H], float64) in the order mpx_analysis_compressed_fused's MFMA
     (v_mfma_f32_16x16x4_f32) consumes them.  A workgroup of n_waves waves (mpx_analysis_compressed_fused_waves) cuts a
@@ -536,6 +536,12 @@ def pack_warp_fused(w_mag, w_ph, fft_len, n_waves=8):
     -- one 16-byte load per lane, tile and 16-column group; tiles = 4 magnitude column tiles, then ceil(phase_dim / 16)
     phase tiles (shared by the real and the imaginary stream); rows past the matrix are zero.
     whalf[tile][16] = the same rows' weight of bin M/2 (added outside the chunks).  Returns (wpack, whalf) float32.
+
+    layout = 1 (mpx_analysis_compressed_fused_layout, n_waves = 8): the magnitude product runs on v_mfma_f32_4x4x1_16b_f32 --
+    per (chunk q, wave) eight magnitude fragments, then the phase tiles' fragments as above:
+      wpack[q][wave][2 kg + half][lane][e] = W_mag[32 half + (lane & 31)][bin(q, 16 wave + 4 kg + e)]      (kg < 4, half < 2)
+      wpack[q][wave][8 + jt][lane][e]      = W_ph[16 jt + (lane & 15)][bin(q, 16 wave + 4 (lane >> 4) + e)]
+    whalf is the same in both layouts.
     """
     w_mag, w_ph = np.asarray(w_mag, dtype=np.float64), np.asarray(w_ph, dtype=np.float64)
     H = fft_len // 2 + 1
@@ -560,7 +566,57 @@ def pack_warp_fused(w_mag, w_ph, fft_len, n_waves=8):
     wpack = tiles[:, li[None, None, None, :, None], b]     # [T, q, wave, h, lane, e]
     wpack = np.ascontiguousarray(np.transpose(wpack, (1, 2, 3, 0, 4, 5)), dtype=np.float32)   # [q, wave, h, T, lane, e]
     whalf = np.ascontiguousarray(tiles[:, :, fft_len // 4], dtype=np.float32)   # [T, 16]
+    if layout == 1:
+        assert n_waves == 8
+        wm64 = np.zeros((64, H))
+        wm64[:w_mag.shape[0]] = w_mag
+        colm = (16 * np.arange(8)[:, None, None] + 4 * np.arange(4)[None, :, None] + np.arange(4)[None, None, :])   # [wave, kg, e]
+        bm = bins[:, colm]                                                                     # [q, wave, kg, e]
+        rows = 32 * np.arange(2)[:, None] + (lane & 31)[None, :]                               # [half, lane]
+        magf = wm64[rows[None, None, None, :, :, None], bm[:, :, :, None, None, :]]            # [q, wave, kg, half, lane, e]
+        magf = magf.reshape(bm.shape[0], 8, 8, 64, 4)
+        phf = wpack[:, :, 0, ntm:]                                                             # [q, wave, ntp, lane, e]
+        out = np.concatenate((magf, phf), axis=2)
+        return np.ascontiguousarray(out, dtype=np.float32).reshape(-1), whalf.reshape(-1)
     return wpack.reshape(-1), whalf.reshape(-1)
+
+
+def pack_warp_fused_bf16(w_mag, w_ph, fft_len):
+    """
+    The two warp matrices for mpx_analysis_compressed_fused_bf16x3 (csrc/magphase_f64.hip, template parameter BF): the B
+    operand of v_mfma_f32_16x16x32_bf16 in the three-way bfloat16 split of float32(W) (bf16_split3).  A chunk's 128 columns
+    are four K slices of 32 slots; slot k of slice s is column pair kappa = 16 s + (k >> 1) of the published tile, k & 1 = 0
+    the low bin 64 q + kappa, 1 its mirror M - 64 q - kappa (the publisher writes the two as one 32-bit word).  uint16
+    (bfloat16 bit patterns)
+      wpack[q][s][tile][part][lane][j] = part(W_tile[16 jt + (lane & 15)][bin(q, s, k = 8 (lane >> 4) + j)])
+    -- one 16-byte load per lane, tile and part; tiles as pack_warp_fused (4 magnitude tiles, then the phase tiles).
+    whalf as pack_warp_fused (float32: bin M/2 is added outside the chunks).  Returns (wpack uint16, whalf float32), flat.
+    """
+    w_mag, w_ph = np.asarray(w_mag, dtype=np.float64), np.asarray(w_ph, dtype=np.float64)
+    H, M, P = fft_len // 2 + 1, fft_len // 2, fft_len // 128
+    assert w_mag.shape[1] == H and w_ph.shape[1] == H and w_mag.shape[0] <= 64 and w_ph.shape[0] <= 48
+    ntm, ntp = 4, (w_ph.shape[0] + 15) // 16
+    tiles = []
+    for src, nt in ((w_mag, ntm), (w_ph, ntp)):
+        for jt in range(nt):
+            t = np.zeros((16, H))
+            rows = src[16 * jt:16 * jt + 16]
+            t[:rows.shape[0]] = rows
+            tiles.append(t)
+    tiles = np.stack(tiles).astype(np.float32)             # [T, 16, H]
+    lane = np.arange(64)
+    li, g = lane & 15, lane >> 4
+    k = 8 * g[:, None] + np.arange(8)[None, :]             # [lane, j]: slot within the slice
+    kap = 16 * np.arange(4)[:, None, None] + (k >> 1)[None]                    # [s, lane, j]
+    q = np.arange(P // 2)[:, None, None, None]
+    b = np.where((k & 1)[None, None] == 0, 64 * q + kap[None], M - 64 * q - kap[None])   # [q, s, lane, j]
+    parts = bf16_split3(tiles)                             # 3 x [T, 16, H] float32 holding bfloat16 values
+    out = np.empty((P // 2, 4, tiles.shape[0], 3, 64, 8), dtype=np.uint16)
+    for p_, sp in enumerate(parts):
+        v = sp[:, li[None, None, :, None], b]              # [T, q, s, lane, j]
+        out[:, :, :, p_] = np.transpose((np.ascontiguousarray(v).view(np.uint32) >> 16).astype(np.uint16), (1, 2, 0, 3, 4))
+    whalf = np.ascontiguousarray(tiles[:, :, fft_len // 4], dtype=np.float32)
+    return out.reshape(-1), whalf.reshape(-1)
 
 
 def var_to_const_rate_table(v_pm_smpls, const_rate_ms, fs):

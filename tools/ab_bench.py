@@ -103,7 +103,16 @@ def main():
         em = load(name)
         eng = em.Engine()
         if extract:
+            # AB_ENV_<name>="K=V,...": environment of this variant's plan construction (e.g. MAGPHASE_FUSED_ANALYSIS=f32)
+            extra = dict(kv.split("=", 1) for kv in os.environ.get("AB_ENV_" + name, "").split(",") if "=" in kv)
+            saved = {k: os.environ.get(k) for k in extra}
+            os.environ.update(extra)
             plans = [em.CompressedAnalysisPlan(eng, utts, mag_dim=60, phase_dim=pd, alpha_phase=False) for pd in (10, 45)]
+            for k, v in saved.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
             outs = [pl.run() for pl in plans]
             assert all(pl.fused for pl in plans)
             steps[name] = (lambda plans=plans, outs=outs: plans[0].run(out=outs[0]),
