@@ -94,7 +94,8 @@ int mpx_analysis_frames_f64w(void* stream, int fft_len, const void* tables_f64, 
  * of every frame (as mpx_analysis_frames_f64w) -> log power / unit phasor of every bin -> both mel warps on the matrix
  * cores -> voicing mask and clip, in ONE kernel; the [n_frames x H] lossless features are never written.
  *   wpack, whalf : the two warp matrices in MFMA fragment order (hostmath.pack_warp_fused of the [mag_dim x H] and
- *                  [phase_dim x H] matrices mpx_mel_warp takes; DEVICE, float32)
+ *                  [phase_dim x H] matrices mpx_mel_warp takes, in the layout mpx_analysis_compressed_fused_layout()
+ *                  names; DEVICE, float32)
  *   voiced       : float32[n_frames] (DEVICE): 0 = unvoiced frame, phase outputs +0 (magphase.py:2527-2529)
  *   mag_fbank    : 0 = cepstral mel warp of ln(mag^2 + 1e-8) (la.sp_mel_warp), 1 = mel filter bank (la.sp_mel_warp_fbank)
  *   out_mag [n_frames x mag_dim], out_real / out_imag [n_frames x phase_dim], dense float32
@@ -106,18 +107,6 @@ int mpx_analysis_compressed_fused(void* stream, int fft_len, const void* tables_
                                   int64_t n_frames, const double* win_tab, int32_t win_cap, const float* wpack,
                                   const float* whalf, int32_t mag_dim, int32_t phase_dim, const float* voiced,
                                   int32_t mag_fbank, float* out_mag, float* out_real, float* out_imag);
-/*
- * The same kernel with its two matrix products on v_mfma_f32_16x16x32_bf16: operand values and weights in three bfloat16
- * parts each (x = x0 + x1 + x2 to 2^-24 |x|), the six partial products with part indices i + j <= 2 exact in float32 and
- * summed in the instruction's float32 accumulator -- the float32 product's accuracy at 0.4 of its matrix-pipe time.
- *   wpack_bf16 : hostmath.pack_warp_fused_bf16 (DEVICE, uint16 bfloat16 bit patterns, 16-byte aligned); whalf as above.
- * Every other argument, the outputs' meaning and the error behaviour as mpx_analysis_compressed_fused.
- */
-int mpx_analysis_compressed_fused_bf16x3(void* stream, int fft_len, const void* tables_f64, const float* sig,
-                                         const int64_t* frame_pos, const int32_t* frame_left, const int32_t* frame_right,
-                                         int64_t n_frames, const double* win_tab, int32_t win_cap, const void* wpack_bf16,
-                                         const float* whalf, int32_t mag_dim, int32_t phase_dim, const float* voiced,
-                                         int32_t mag_fbank, float* out_mag, float* out_real, float* out_imag);
 /* column tiles of 16 the fused kernel runs for the magnitude / phase job (what pack_warp_fused must produce) */
 int mpx_analysis_compressed_fused_tiles(int32_t mag_dim, int32_t phase_dim, int32_t* ntm, int32_t* ntp);
 /* waves per workgroup = frames per round = K slices the packed weights are cut into (pack_warp_fused's n_waves) */

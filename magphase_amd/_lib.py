@@ -23,7 +23,6 @@ SYMBOLS = (
     "mpx_analysis_frames_f64",
     "mpx_analysis_frames_f64w",
     "mpx_analysis_compressed_fused",
-    "mpx_analysis_compressed_fused_bf16x3",
     "mpx_analysis_compressed_fused_tiles",
     "mpx_analysis_compressed_fused_waves",
     "mpx_analysis_compressed_fused_layout",
@@ -133,9 +132,6 @@ def _load_locked():
     lib.mpx_analysis_frames_f64.argtypes = [vp, ctypes.c_int, vp, vp, vp, vp, vp, i64, vp, vp, vp, i64, vp]
     lib.mpx_analysis_compressed_fused.restype = ctypes.c_int
     lib.mpx_analysis_compressed_fused.argtypes = [vp, ctypes.c_int, vp, vp, vp, vp, vp, i64, vp, i32, vp, vp, i32, i32, vp, i32,
-                                                  vp, vp, vp]
-    lib.mpx_analysis_compressed_fused_bf16x3.restype = ctypes.c_int
-    lib.mpx_analysis_compressed_fused_bf16x3.argtypes = [vp, ctypes.c_int, vp, vp, vp, vp, vp, i64, vp, i32, vp, vp, i32, i32, vp, i32,
                                                   vp, vp, vp]
     lib.mpx_analysis_compressed_fused_blocks_per_cu.restype = ctypes.c_int
     lib.mpx_analysis_compressed_fused_blocks_per_cu.argtypes = [ctypes.c_int, i32]

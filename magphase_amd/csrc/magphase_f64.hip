@@ -338,11 +338,14 @@ __global__ __launch_bounds__(kAna64Waves * 64) void k_analysis_f64(const float* 
 // Phase B: P/2 chunk steps; step q splits the bin pair rows (kappa + 64 q, M - kappa - 64 q) exactly like k_analysis_f64's
 // epilogue, applies the warp's prologue (the staged path's float32 values and formulas, so both paths agree to the
 // summation order) and PUBLISHES them to As[buf][stream][wave][column]: column kappa = the low bin, 64 + kappa = its
-// mirror.  After one barrier the eight waves split the chunk's 128 columns (16 each: four MFMA k-steps), read their A
-// fragments (one ds_read_b128 per stream: rows 8..15 of the 16-row tile repeat rows 0..7, their outputs are dropped) and
-// the matching W fragments from `wpack` (host-packed in fragment order: one 16-byte load per tile, L2-resident,
-// hostmath.pack_warp_fused), and accumulate.  The tile is double buffered: one barrier per chunk.  The NEXT chunk's
-// values are computed between issuing the W loads and the MFMAs, so the L2 latency hides under float64 VALU work.
+// mirror.  After one barrier the eight waves split the chunk's 128 columns (16 each), read their A fragments and the
+// matching W fragments from `wpack` (host-packed in fragment order: 16-byte loads, L2-resident,
+// hostmath.pack_warp_fused), and accumulate: the magnitudes as 4 x 4 blocks on v_mfma_f32_4x4x1_16b_f32 (8 frames x 32
+// coefficients per instruction, every product used), the two phase streams as rows 0..7 / 8..15 of 16 x 16 x 4 tiles
+// (round 5; before, the magnitudes ran on 16 x 16 x 4 tiles whose rows 8..15 repeated rows 0..7).  The tile is double
+// buffered: one barrier per chunk.  A fragment of the NEXT chunk is requested right behind the last use of this chunk's,
+// and the compiler sinks the next chunk's operand arithmetic (float64 -> log / phase operands) into the loop: L2 latency
+// and matrix instructions run under VALU work.
 // Round end: the eight K-slices are added through LDS (deterministic order), bin M/2 (its own mirror, held by lane 0) is
 // added as one product per output, epilogue as k_mel_warp_mfma's, rows stored.
 // Accumulation: 256 terms per wave and accumulator + 8 partial sums -- the same error level as the staged GEMM's fresh
@@ -379,44 +382,6 @@ constexpr int kFusedRedStride = 68;
 #ifndef MPX_FUSED_M4      // magnitude product on v_mfma_f32_4x4x1_16b_f32 (full blocks) -- the default; 0: 16 x 16 x 4 tiles
 #define MPX_FUSED_M4 1
 #endif
-#ifndef MPX_FUSED_WPIPE   // (MPX_FUSED_M4=0:) weights of the next chunk requested tile by tile
-#define MPX_FUSED_WPIPE 1
-#endif
-
-// ---- the split-bfloat16 form of the product (round 5; template parameter BF) --------------------------------------------
-// v_mfma_f32_16x16x32_bf16 runs 8 x the k-slots of v_mfma_f32_16x16x4_f32 in half its cycles.  Both operands are cut into
-// three bfloat16 parts (x = x0 + x1 + x2 to 2^-24 |x|; the subtractions are exact in float32): W on the host
-// (hostmath.pack_warp_fused_bf16), the operand values by their publisher, which writes the (low bin, mirror) pair of a lane
-// as ONE 32-bit word per part.  The six products with part indices i + j <= 2 are exact in float32 and are summed by the
-// instruction's float32 accumulator, smallest first: the float32 chain's accuracy (tests/test_fused_pack_model.py) at
-// 6 x 16 cycles per tile and 32 columns against 8 x 32.
-// A chunk's 128 columns are then FOUR K slices of 32 (slot k of slice s = column pair kappa = 16 s + (k >> 1), k & 1 = the
-// mirror), and the eight waves are 4 slices x 2 tile groups: group 0 runs the first ceil(T / 2) column tiles, group 1 the
-// rest (waves s and s + 4 share a SIMD: T tiles per SIMD and chunk whatever the split).
-// Published row: [slice][part][32 bfloat16] = 768 bytes + 32: row pitch / 16 = 2 mod 16, the same bank argument as above.
-constexpr int kFusedBRow = 800;
-typedef __bf16 fz_bf16x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 fz_bf16x8 __attribute__((ext_vector_type(8)));
-template <int V>
-struct fz_int {
-    static constexpr int value = V;
-};
-
-__device__ __forceinline__ unsigned fz_pk_bf16(float x, float y) {
-    fz_bf16x2 v;
-    v[0] = (__bf16)x;
-    v[1] = (__bf16)y;
-    return __builtin_bit_cast(unsigned, v);
-}
-// (x, y) -> three words of (bfloat16 part of x, bfloat16 part of y)
-__device__ __forceinline__ void fz_split3(float x, float y, unsigned& h0, unsigned& h1, unsigned& h2) {
-    h0 = fz_pk_bf16(x, y);
-    float rx = x - __uint_as_float(h0 << 16), ry = y - __uint_as_float(h0 & 0xffff0000u);
-    h1 = fz_pk_bf16(rx, ry);
-    rx -= __uint_as_float(h1 << 16);
-    ry -= __uint_as_float(h1 & 0xffff0000u);
-    h2 = fz_pk_bf16(rx, ry);
-}
 
 // the warp's operand prologue / epilogue (same formulas as magphase_comp.hip: warp_prologue / warp_epilogue)
 __device__ __forceinline__ float fused_prologue_mag(int mode, float x) {
@@ -434,11 +399,10 @@ constexpr size_t lds_bytes_fused() {
     constexpr size_t work = sizeof(float) * (size_t)(kFusedWaves * P * kXStride + kFusedWaves * f64_win_floats<P>());
     constexpr size_t red = sizeof(float) * (size_t)(kFusedWaves * tiles * 4 * kFusedRedStride);
     static_assert(work >= red, "the reduction buffer must fit the regions it aliases");
-    static_assert(work >= (size_t)2 * 3 * kFusedWaves * kFusedBRow, "the bfloat16 tiles alias the same regions from their start");
     return sizeof(double) * (size_t)tw64_doubles<P>() + work + sizeof(float) * 32;
 }
 
-template <int P, int NTM, int NTP, int MAGMODE, bool BF = false>
+template <int P, int NTM, int NTP, int MAGMODE>
 __attribute__((amdgpu_waves_per_eu(2, 2)))   // <= 256 registers (VGPR + AGPR): two workgroups of four waves per CU
 __global__ __launch_bounds__(kFusedWaves * 64) void k_analysis_warp_fused(
     const float* __restrict__ sig, const long long* __restrict__ fpos, const int* __restrict__ fleft,
@@ -559,114 +523,12 @@ __global__ __launch_bounds__(kFusedWaves * 64) void k_analysis_warp_fused(
         // a round without a voiced frame has nothing for the phase tiles to do (their outputs are masked to +0)
         // the float32 form's magnitude product on v_mfma_f32_4x4x1_16b_f32 (M4, see the chunk loop): two accumulators of
         // [8 frames x 32 coefficients] instead of four half-empty 16 x 16 tiles
-        constexpr bool M4 = !BF && kFusedKH == 1 && MPX_FUSED_M4 != 0;
-        constexpr int TR = M4 ? 2 + NTP : T;              // accumulator tiles per K slice in `red`
-        constexpr int TL = BF ? (T + 1) / 2 : TR;         // accumulators per wave
-        f32x4_t acc[TL];
+        constexpr bool M4 = kFusedKH == 1 && MPX_FUSED_M4 != 0;
+        constexpr int TR = M4 ? 2 + NTP : T;              // accumulator tiles per wave (= per K slice in `red`)
+        f32x4_t acc[TR];
 #pragma unroll
-        for (int t = 0; t < TL; ++t) acc[t] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
+        for (int t = 0; t < TR; ++t) acc[t] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
         __syncthreads();   // the tiles overlay the other waves' window regions: every wave must be through its gather
-        if constexpr (BF) {
-            static_assert(!BF || kFusedWaves == 8, "4 K slices x 2 tile groups");
-            const int sl = wave & 3;                  // K slice: columns pairs 16 sl .. 16 sl + 15
-            const int gr = rfl(wave >> 2);            // tile group
-            unsigned char* tb0 = reinterpret_cast<unsigned char*>(xbase);
-            const uint4* wpk = reinterpret_cast<const uint4*>(wpack);
-            const unsigned pub_off = (unsigned)(wave * kFusedBRow + (kap >> 4) * 192 + (kap & 15) * 4);
-            const unsigned rd_m = (unsigned)((li & 7) * kFusedBRow + sl * 192 + g * 16);
-            const unsigned rd_p = (unsigned)(((li < 8 ? 1 : 2) * 8 + (li & 7)) * kFusedBRow + sl * 192 + g * 16);
-            // the (low bin, mirror) pairs of chunk q in three bfloat16 parts: nine 32-bit words per lane
-            auto publish = [&](int q) {
-                unsigned char* row = tb0 + (q & 1) * (3 * 8 * kFusedBRow) + pub_off;
-                unsigned h0, h1, h2;
-                fz_split3(vm[2 * q], vm[2 * q + 1], h0, h1, h2);
-                *reinterpret_cast<unsigned*>(row) = h0;
-                *reinterpret_cast<unsigned*>(row + 64) = h1;
-                *reinterpret_cast<unsigned*>(row + 128) = h2;
-                row += 8 * kFusedBRow;
-                fz_split3(vr[2 * q], vr[2 * q + 1], h0, h1, h2);
-                *reinterpret_cast<unsigned*>(row) = h0;
-                *reinterpret_cast<unsigned*>(row + 64) = h1;
-                *reinterpret_cast<unsigned*>(row + 128) = h2;
-                row += 8 * kFusedBRow;
-                fz_split3(vi[2 * q], vi[2 * q + 1], h0, h1, h2);
-                *reinterpret_cast<unsigned*>(row) = h0;
-                *reinterpret_cast<unsigned*>(row + 64) = h1;
-                *reinterpret_cast<unsigned*>(row + 128) = h2;
-            };
-            publish(0);
-#pragma unroll
-            for (int q = 0; q < P / 2; ++q) {
-                const unsigned char* tile = tb0 + (q & 1) * (3 * 8 * kFusedBRow);
-                // W fragments of this wave's slice and tiles: [q][slice][tile][part][lane] x 16 bytes, in flight across the barrier
-                // (the OFFSET is laundered, not the pointer: a pointer out of an asm statement is a generic one, its loads are
-                // flat_load, those count on lgkmcnt too, and the barrier's LDS wait then waits for the weights as well)
-                int wo = ((q * 4 + sl) * T) * (3 * 64);
-                asm volatile("" : "+s"(wo));
-                const uint4* wq = wpk + wo;
-                uint4 bw[TL][3];
-#pragma unroll
-                for (int j = 0; j < TL; ++j) {
-                    const int t = gr * TL + j;
-                    if (t < T) {   // (group 1 of an odd T has one tile less)
-#pragma unroll
-                        for (int p_ = 0; p_ < 3; ++p_) {
-#ifdef MPX_PROBE_FUSEDB_NOWLOAD   // ablation (timing only): one weight fragment per wave and chunk instead of 3 TL
-                            if (j == 0 && p_ == 0) bw[0][0] = wq[(t * 3) * 64 + lane_id];
-                            else bw[j][p_] = bw[0][0];
-#else
-                            bw[j][p_] = wq[(t * 3 + p_) * 64 + lane_id];
-#endif
-                        }
-                    } else {
-#pragma unroll
-                        for (int p_ = 0; p_ < 3; ++p_) bw[j][p_] = uint4{0u, 0u, 0u, 0u};
-                    }
-                }
-                __syncthreads();
-                uint4 am[3], ap[3];
-#pragma unroll
-                for (int p_ = 0; p_ < 3; ++p_) {
-                    am[p_] = *reinterpret_cast<const uint4*>(tile + rd_m + 64 * p_);
-                    ap[p_] = *reinterpret_cast<const uint4*>(tile + rd_p + 64 * p_);
-                }
-                // the NEXT chunk's values go to the other buffer (its readers passed the barrier above) under these
-                // matrix instructions
-#ifndef MPX_PROBE_FUSEDB_NOPUB   // ablation (timing only): chunk 0's tile for every chunk
-                if (q + 1 < P / 2) publish(q + 1);
-#endif
-                // a FRESH accumulator per chunk, six terms (operand part, weight part), smallest products first
-                auto consume = [&](auto gc) {
-                    constexpr int G = decltype(gc)::value;
-                    f32x4_t ca[TL];
-#pragma unroll
-                    for (int j = 0; j < TL; ++j) ca[j] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
-                    constexpr int kTermA[6] = {2, 1, 0, 1, 0, 0};
-                    constexpr int kTermW[6] = {0, 1, 2, 0, 1, 0};
-#pragma unroll
-                    for (int term = 0; term < 6; ++term) {
-#pragma unroll
-                        for (int j = 0; j < TL; ++j) {
-                            const int t = G * TL + j;
-                            if (t < T) {
-                                const uint4 a_ = (t < NTM) ? am[kTermA[term]] : ap[kTermA[term]];
-#ifdef MPX_PROBE_FUSEDB_NOMFMA   // ablation (timing only): one VALU operation per matrix instruction
-                                ca[j][term & 3] = fmaf(__uint_as_float(a_.x), __uint_as_float(bw[j][kTermW[term]].x), ca[j][term & 3]);
-                                continue;
-#endif
-                                ca[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(fz_bf16x8, a_),
-                                                                                __builtin_bit_cast(fz_bf16x8, bw[j][kTermW[term]]),
-                                                                                ca[j], 0, 0, 0);
-                            }
-                        }
-                    }
-#pragma unroll
-                    for (int j = 0; j < TL; ++j) acc[j] += ca[j];
-                };
-                if (gr == 0) consume(fz_int<0>{});
-                else consume(fz_int<1>{});
-            }
-        } else {
 #ifdef MPX_FUSED_PRIO   // the GEMM phase above the other workgroup's transform phase on the same SIMD (an MFMA needs one issue
         __builtin_amdgcn_s_setprio(MPX_FUSED_PRIO);   // slot per 32 cycles; losing it to the elder wave's VALU stream stalls the round)
 #endif
@@ -754,54 +616,6 @@ __global__ __launch_bounds__(kFusedWaves * 64) void k_analysis_warp_fused(
                 acc[0] += cm[0][0] + cm[0][1];
                 acc[1] += cm[1][0] + cm[1][1];
             }
-        } else if constexpr (kFusedKH == 1 && MPX_FUSED_WPIPE != 0) {
-            // Tile by tile: a tile's four k-steps back to back on its accumulator, and the NEXT chunk's fragment of that tile
-            // requested as soon as they are issued -- the L2 round trip of the weights (loads issued at the end of a chunk
-            // were waited for right behind the barrier: ~0.1 ms per launch) runs under the remaining tiles' matrix
-            // instructions and the barrier.  Same sums in the same order as the chunk-wide form below.
-            f32x4_t bw[T];
-            {
-                int wo = 0;
-                asm volatile("" : "+s"(wo));
-#pragma unroll
-                for (int t = 0; t < T; ++t) bw[t] = wp_wave[wo + t * 64 + lane_id];
-            }
-#pragma unroll
-            for (int q = 0; q < P / 2; ++q) {
-                float* tile = As + (q & 1) * (3 * kFusedWaves * kFusedAStride);
-                {
-                    float* row = tile + wave * kFusedAStride;
-                    row[kap] = vm[2 * q];
-                    row[64 + kap] = vm[2 * q + 1];
-                    row += kFusedWaves * kFusedAStride;
-                    row[kap] = vr[2 * q];
-                    row[64 + kap] = vr[2 * q + 1];
-                    row += kFusedWaves * kFusedAStride;
-                    row[kap] = vi[2 * q];
-                    row[64 + kap] = vi[2 * q + 1];
-                }
-                __syncthreads();
-                const int col = kFusedCols * wave + 4 * g;
-                const f32x4_t am = *reinterpret_cast<const f32x4_t*>(tile + (li & (kFusedWaves - 1)) * kFusedAStride + col);
-                const f32x4_t ap = *reinterpret_cast<const f32x4_t*>(
-                    tile + ((li < 8 ? 1 : 2) * kFusedWaves + (li & (kFusedWaves - 1))) * kFusedAStride + col);
-                int wo = (q + 1 < P / 2 ? q + 1 : q) * (kFusedWaves * kFusedKH * T * 64);
-                asm volatile("" : "+s"(wo));
-#pragma unroll
-                for (int t = 0; t < T; ++t) {
-                    f32x4_t ca = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};   // a FRESH accumulator per chunk (see below)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-#ifdef MPX_PROBE_FUSEDA_NOMFMA
-                        ca[e] = fmaf((t < NTM ? am : ap)[e], bw[t][e], ca[e]);
-#else
-                        ca = __builtin_amdgcn_mfma_f32_16x16x4f32((t < NTM ? am : ap)[e], bw[t][e], ca, 0, 0, 0);
-#endif
-                    }
-                    if (q + 1 < P / 2) bw[t] = wp_wave[wo + t * 64 + lane_id];
-                    acc[t] += ca;
-                }
-            }
         } else
 #pragma unroll
         for (int q = 0; q < P / 2; ++q) {
@@ -866,28 +680,14 @@ __global__ __launch_bounds__(kFusedWaves * 64) void k_analysis_warp_fused(
 #pragma unroll
             for (int t = 0; t < T; ++t) acc[t] += ca[t];
         }
-        }   // (the float32 form)
 #ifdef MPX_FUSED_PRIO
         __builtin_amdgcn_s_setprio(0);
 #endif
         __syncthreads();   // every wave is done with the tiles and its transpose buffer: `red` may overwrite them
-        constexpr int kSlices = BF ? 4 : kFusedWaves;   // K slices whose partial sums meet in `red`
-        if constexpr (BF) {
-            const int gr = rfl(wave >> 2);
 #pragma unroll
-            for (int j = 0; j < TL; ++j) {
-                const int t = gr * TL + j;
-                if (t < T) {
+        for (int t = 0; t < TR; ++t)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) red[(((wave & 3) * T + t) * 4 + r) * kFusedRedStride + lane_id] = acc[j][r];
-                }
-            }
-        } else {
-#pragma unroll
-            for (int t = 0; t < TR; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) red[((wave * TR + t) * 4 + r) * kFusedRedStride + lane_id] = acc[t][r];
-        }
+            for (int r = 0; r < 4; ++r) red[((wave * TR + t) * 4 + r) * kFusedRedStride + lane_id] = acc[t][r];
         __syncthreads();
         // outputs of the round.  C of a tile: column c, row 4 g' + r.  Magnitude tiles: row = frame fr.  Phase tiles: row fr =
         // the real stream, row 8 + fr = the imaginary one.
@@ -904,12 +704,12 @@ __global__ __launch_bounds__(kFusedWaves * 64) void k_analysis_warp_fused(
             if (M4 && sa == 0) {   // 4 x 4 blocks: coefficient n of frame fr is register fr & 3 of lane (n & 31) + 32 (fr >> 2), half n >> 5
                 const int n = 16 * to + c;
 #pragma unroll
-                for (int w = 0; w < kSlices; ++w)
+                for (int w = 0; w < kFusedWaves; ++w)
                     y += red[((w * TR + (n >> 5)) * 4 + (fr & 3)) * kFusedRedStride + (n & 31) + 32 * (fr >> 2)];
             } else {
                 const int tr = M4 ? t - NTM + 2 : t;
 #pragma unroll
-                for (int w = 0; w < kSlices; ++w) y += red[((w * TR + tr) * 4 + r) * kFusedRedStride + c + 16 * gg];
+                for (int w = 0; w < kFusedWaves; ++w) y += red[((w * TR + tr) * 4 + r) * kFusedRedStride + c + 16 * gg];
             }
             y = fmaf(mid[sa * kFusedWaves + fr], whalf[t * 16 + c], y);
             if (sa == 0) {
@@ -1007,14 +807,12 @@ int mpx_analysis_frames_f64w(void* stream, int fft_len, const void* tables_f64, 
 }
 
 
-}   // extern "C"
-
-template <bool BF>
-static int analysis_compressed_fused_impl(void* stream, int fft_len, const void* tables_f64, const float* sig,
-                                          const int64_t* frame_pos, const int32_t* frame_left, const int32_t* frame_right,
-                                          int64_t n_frames, const double* win_tab, int32_t win_cap, const float* wpack,
-                                          const float* whalf, int32_t mag_dim, int32_t phase_dim, const float* voiced,
-                                          int32_t mag_fbank, float* out_mag, float* out_real, float* out_imag) {
+/* (declared in include/magphase_hip.h) */
+int mpx_analysis_compressed_fused(void* stream, int fft_len, const void* tables_f64, const float* sig,
+                                  const int64_t* frame_pos, const int32_t* frame_left, const int32_t* frame_right,
+                                  int64_t n_frames, const double* win_tab, int32_t win_cap, const float* wpack,
+                                  const float* whalf, int32_t mag_dim, int32_t phase_dim, const float* voiced,
+                                  int32_t mag_fbank, float* out_mag, float* out_real, float* out_imag) {
     const int P = p_of(fft_len);
     if (P != 32 && P != 16) return fail(MPX_ERR_ARG, "mpx_analysis_compressed_fused: fft_len must be 2048 or 4096%s");
     if (n_frames < 0) return fail(MPX_ERR_ARG, "mpx_analysis_compressed_fused: negative n_frames%s");
@@ -1032,8 +830,8 @@ static int analysis_compressed_fused_impl(void* stream, int fft_len, const void*
     const int ntp = (phase_dim + 15) / 16;
 #define MPX_FUSED_GO(PP, NTP_, MM)                                                                                        \
     do {                                                                                                                  \
-        if (int rc = set_lds(k_analysis_warp_fused<PP, 4, NTP_, MM, BF>, (lds_bytes_fused<PP, 4, NTP_>()))) return rc;        \
-        hipLaunchKernelGGL((k_analysis_warp_fused<PP, 4, NTP_, MM, BF>), grid, block, (lds_bytes_fused<PP, 4, NTP_>()), s, sig, \
+        if (int rc = set_lds(k_analysis_warp_fused<PP, 4, NTP_, MM>, (lds_bytes_fused<PP, 4, NTP_>()))) return rc;        \
+        hipLaunchKernelGGL((k_analysis_warp_fused<PP, 4, NTP_, MM>), grid, block, (lds_bytes_fused<PP, 4, NTP_>()), s, sig, \
                            (const long long*)frame_pos, frame_left, frame_right, (long long)n_frames,                     \
                            (const double*)tables_f64, win_tab, (int)win_cap, wpack, whalf, voiced, (int)mag_dim,          \
                            (int)phase_dim, out_mag, out_real, out_imag);                                                  \
@@ -1053,30 +851,6 @@ static int analysis_compressed_fused_impl(void* stream, int fft_len, const void*
 #undef MPX_FUSED_GO
     MPX_HIP_CHECK(hipGetLastError());
     return MPX_OK;
-}
-
-extern "C" {
-
-/* (declared in include/magphase_hip.h) */
-int mpx_analysis_compressed_fused(void* stream, int fft_len, const void* tables_f64, const float* sig,
-                                  const int64_t* frame_pos, const int32_t* frame_left, const int32_t* frame_right,
-                                  int64_t n_frames, const double* win_tab, int32_t win_cap, const float* wpack,
-                                  const float* whalf, int32_t mag_dim, int32_t phase_dim, const float* voiced,
-                                  int32_t mag_fbank, float* out_mag, float* out_real, float* out_imag) {
-    return analysis_compressed_fused_impl<false>(stream, fft_len, tables_f64, sig, frame_pos, frame_left, frame_right, n_frames,
-                                                 win_tab, win_cap, wpack, whalf, mag_dim, phase_dim, voiced, mag_fbank, out_mag,
-                                                 out_real, out_imag);
-}
-
-int mpx_analysis_compressed_fused_bf16x3(void* stream, int fft_len, const void* tables_f64, const float* sig,
-                                         const int64_t* frame_pos, const int32_t* frame_left, const int32_t* frame_right,
-                                         int64_t n_frames, const double* win_tab, int32_t win_cap, const void* wpack_bf16,
-                                         const float* whalf, int32_t mag_dim, int32_t phase_dim, const float* voiced,
-                                         int32_t mag_fbank, float* out_mag, float* out_real, float* out_imag) {
-    if (kFusedWaves != 8) return fail(MPX_ERR_ARG, "mpx_analysis_compressed_fused_bf16x3: built for workgroups of eight waves%s");
-    return analysis_compressed_fused_impl<true>(stream, fft_len, tables_f64, sig, frame_pos, frame_left, frame_right, n_frames,
-                                                win_tab, win_cap, (const float*)wpack_bf16, whalf, mag_dim, phase_dim, voiced,
-                                                mag_fbank, out_mag, out_real, out_imag);
 }
 
 int mpx_analysis_compressed_fused_tiles(int32_t mag_dim, int32_t phase_dim, int32_t* ntm, int32_t* ntp) {

@@ -1884,22 +1884,15 @@ class CompressedAnalysisPlan:
                       and os.environ.get("MAGPHASE_COMP_ANALYSIS", "f64") != "f32")
         if self.fused:
             nw = int(e.lib.mpx_analysis_compressed_fused_waves())
-            # the products on the bfloat16 matrix pipe in three-way operand splits (float32 accuracy, 0.4 of the pipe time:
-            # mpx_analysis_compressed_fused_bf16x3); MAGPHASE_FUSED_ANALYSIS=f32 keeps v_mfma_f32_16x16x4_f32
-            self.fused_bf16 = nw == 8 and os.environ.get("MAGPHASE_FUSED_ANALYSIS", "bf16") != "f32"
-            layout = int(e.lib.mpx_analysis_compressed_fused_layout())
+            layout = int(e.lib.mpx_analysis_compressed_fused_layout())   # fragment order this build of the kernel reads
             key = ("wpack", self._warp_name, int(mag_dim), int(k_full), int(phase_dim), H, float(alpha), float(a_ph), nw,
-                   self.fused_bf16, layout)
+                   layout)
             if key not in e._tables:
                 wm = (hm.warp_fbank_matrix(mag_dim, H, alpha) if self._warp_name == "mpx_mel_warp_fbank"
                       else hm.warp_matrix(mag_dim, H, alpha))
                 wph = hm.warp_matrix(k_full, H, a_ph, nrows=phase_dim)
-                if self.fused_bf16:
-                    wpack, whalf = hm.pack_warp_fused_bf16(wm, wph, N)
-                    e._tables[key] = (e.to_device(wpack.view(np.int16), np.int16), e.to_device(whalf, np.float32))
-                else:
-                    wpack, whalf = hm.pack_warp_fused(wm, wph, N, n_waves=nw, layout=layout)
-                    e._tables[key] = (e.to_device(wpack, np.float32), e.to_device(whalf, np.float32))
+                wpack, whalf = hm.pack_warp_fused(wm, wph, N, n_waves=nw, layout=layout)
+                e._tables[key] = (e.to_device(wpack, np.float32), e.to_device(whalf, np.float32))
             self.wpack, self.whalf = e._tables[key]
 
     def run(self, feats=None, out=None, mark=None):
@@ -1916,8 +1909,7 @@ class CompressedAnalysisPlan:
             pl = self.lossless
             wt = e.hann_table() if os.environ.get("MAGPHASE_F64_WINDOW", "table") != "analytic" else None
             with torch.cuda.device(e.device):
-                _lib.check((e.lib.mpx_analysis_compressed_fused_bf16x3 if self.fused_bf16
-                            else e.lib.mpx_analysis_compressed_fused)(
+                _lib.check(e.lib.mpx_analysis_compressed_fused(
                     e.stream_ptr(), int(self.fft_len), e.tables_f64(self.fft_len).data_ptr(), pl.sig.data_ptr(),
                     pl.pos.data_ptr(), pl.left.data_ptr(), pl.right.data_ptr(), int(pl.total_frames),
                     (wt.data_ptr() if wt is not None else None), (hm.HANN_TABLE_CAP if wt is not None else 0),

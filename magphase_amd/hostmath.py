@@ -581,44 +581,6 @@ def pack_warp_fused(w_mag, w_ph, fft_len, n_waves=8, layout=0):
     return wpack.reshape(-1), whalf.reshape(-1)
 
 
-def pack_warp_fused_bf16(w_mag, w_ph, fft_len):
-    """
-    The two warp matrices for mpx_analysis_compressed_fused_bf16x3 (csrc/magphase_f64.hip, template parameter BF): the B
-    operand of v_mfma_f32_16x16x32_bf16 in the three-way bfloat16 split of float32(W) (bf16_split3).  A chunk's 128 columns
-    are four K slices of 32 slots; slot k of slice s is column pair kappa = 16 s + (k >> 1) of the published tile, k & 1 = 0
-    the low bin 64 q + kappa, 1 its mirror M - 64 q - kappa (the publisher writes the two as one 32-bit word).  uint16
-    (bfloat16 bit patterns)
-      wpack[q][s][tile][part][lane][j] = part(W_tile[16 jt + (lane & 15)][bin(q, s, k = 8 (lane >> 4) + j)])
-    -- one 16-byte load per lane, tile and part; tiles as pack_warp_fused (4 magnitude tiles, then the phase tiles).
-    whalf as pack_warp_fused (float32: bin M/2 is added outside the chunks).  Returns (wpack uint16, whalf float32), flat.
-    """
-    w_mag, w_ph = np.asarray(w_mag, dtype=np.float64), np.asarray(w_ph, dtype=np.float64)
-    H, M, P = fft_len // 2 + 1, fft_len // 2, fft_len // 128
-    assert w_mag.shape[1] == H and w_ph.shape[1] == H and w_mag.shape[0] <= 64 and w_ph.shape[0] <= 48
-    ntm, ntp = 4, (w_ph.shape[0] + 15) // 16
-    tiles = []
-    for src, nt in ((w_mag, ntm), (w_ph, ntp)):
-        for jt in range(nt):
-            t = np.zeros((16, H))
-            rows = src[16 * jt:16 * jt + 16]
-            t[:rows.shape[0]] = rows
-            tiles.append(t)
-    tiles = np.stack(tiles).astype(np.float32)             # [T, 16, H]
-    lane = np.arange(64)
-    li, g = lane & 15, lane >> 4
-    k = 8 * g[:, None] + np.arange(8)[None, :]             # [lane, j]: slot within the slice
-    kap = 16 * np.arange(4)[:, None, None] + (k >> 1)[None]                    # [s, lane, j]
-    q = np.arange(P // 2)[:, None, None, None]
-    b = np.where((k & 1)[None, None] == 0, 64 * q + kap[None], M - 64 * q - kap[None])   # [q, s, lane, j]
-    parts = bf16_split3(tiles)                             # 3 x [T, 16, H] float32 holding bfloat16 values
-    out = np.empty((P // 2, 4, tiles.shape[0], 3, 64, 8), dtype=np.uint16)
-    for p_, sp in enumerate(parts):
-        v = sp[:, li[None, None, :, None], b]              # [T, q, s, lane, j]
-        out[:, :, :, p_] = np.transpose((np.ascontiguousarray(v).view(np.uint32) >> 16).astype(np.uint16), (1, 2, 0, 3, 4))
-    whalf = np.ascontiguousarray(tiles[:, :, fft_len // 4], dtype=np.float32)
-    return out.reshape(-1), whalf.reshape(-1)
-
-
 def var_to_const_rate_table(v_pm_smpls, const_rate_ms, fs):
     """
     Row/weight table of magphase.py:2219-2239 (Q15): grid arange(step, pm[-1], step); the first row is duplicated at

@@ -55,3 +55,44 @@ def test_packed_fragments_reproduce_the_matrix_product(fft_len, mag_dim, phase_d
             want = x[sa] @ rows.T
             assert np.max(np.abs(got - want)) < 2e-5 * max(1.0, np.max(np.abs(want)))   # float32 rounding of the packed weights
         assert np.all(d[t][:, rows.shape[0]:] == 0.0)                          # padding columns: zero weights
+
+
+@pytest.mark.parametrize("fft_len,mag_dim,phase_dim", [(4096, 60, 10), (2048, 24, 33), (2048, 64, 48)])
+def test_layout_1_magnitudes_on_4x4_blocks(fft_len, mag_dim, phase_dim):
+    """pack_warp_fused(layout=1) with v_mfma_f32_4x4x1_16b_f32's register layout (measured: tools/archive/mfma4x4_layout_probe.hip
+    -- block b = lane >> 2; D[lane 4 b + j][register r] += A(lane 4 b + r) * B(lane 4 b + j)): lane 4 b + x supplies frame
+    4 (lane >> 5) + x and coefficient lane & 31 (+ 32 for the second half); the phase fragments are layout 0's."""
+    rng = np.random.RandomState(7 + fft_len + mag_dim)
+    H, M, P = fft_len // 2 + 1, fft_len // 2, fft_len // 128
+    w_mag, w_ph = rng.standard_normal((mag_dim, H)), rng.standard_normal((phase_dim, H))
+    wp1, wh1 = hm.pack_warp_fused(w_mag, w_ph, fft_len, n_waves=8, layout=1)
+    wp0, wh0 = hm.pack_warp_fused(w_mag, w_ph, fft_len, n_waves=8, layout=0)
+    ntp = (phase_dim + 15) // 16
+    wp1 = wp1.reshape(P // 2, 8, 8 + ntp, 64, 4)
+    assert np.array_equal(wh0, wh1)
+    assert np.array_equal(wp1[:, :, 8:], wp0.reshape(P // 2, 8, 1, 4 + ntp, 64, 4)[:, :, 0, 4:])      # phase fragments unchanged
+    wp1 = wp1.astype(np.float64)
+    bins = hm.fused_chunk_bins(fft_len)
+    x = rng.standard_normal((8, H))
+    lane = np.arange(64)
+    blk = lane >> 2
+    acc = np.zeros((8, 2, 64, 4))                                              # [wave][half][lane][register]
+    for q in range(P // 2):
+        tile = x[:, bins[q]]                                                   # published magnitudes [frame row][128 columns]
+        for w in range(8):
+            for kg in range(4):
+                for e in range(4):
+                    a = tile[4 * (lane >> 5) + (lane & 3), 16 * w + 4 * kg + e]
+                    for hf in range(2):
+                        b = wp1[q, w, 2 * kg + hf, :, e]
+                        for r in range(4):
+                            acc[w, hf, :, r] += a[4 * blk + r] * b
+    d = acc.sum(axis=0)                                                        # the round-end reduction over the waves
+    got = np.empty((8, 64))
+    for fr in range(8):
+        for n in range(64):                                                    # the output loop's addressing
+            got[fr, n] = d[n >> 5, (n & 31) + 32 * (fr >> 2), fr & 3]
+    got += np.outer(x[:, M // 2], wh1.reshape(-1, 16)[:4].reshape(-1).astype(np.float64))
+    want = x @ w_mag.T
+    assert np.max(np.abs(got[:, :mag_dim] - want)) < 2e-5 * max(1.0, np.max(np.abs(want)))
+    assert np.all(got[:, mag_dim:] == 0.0)
