@@ -379,6 +379,9 @@ static_assert(kFusedAStride % 4 == 0 && kFusedAStride >= 128, "published rows: 1
 // floats per (wave, tile, register) row of the round's reduction buffer: 64 lanes + 4.  The output loop's 64 consecutive
 // threads read column c of four consecutive tiles: 4 rows = 4 x 68 floats apart = 16 banks apart (64: the same bank, 4-way).
 constexpr int kFusedRedStride = 68;
+#ifndef MPX_FUSED_PAIR    // two chunks per barrier where four tile buffers fit the window regions (N = 4096) and it pays (fused_pair)
+#define MPX_FUSED_PAIR 1
+#endif
 #ifndef MPX_FUSED_M4      // magnitude product on v_mfma_f32_4x4x1_16b_f32 (full blocks) -- the default; 0: 16 x 16 x 4 tiles
 #define MPX_FUSED_M4 1
 #endif
@@ -389,6 +392,13 @@ __device__ __forceinline__ float fused_prologue_mag(int mode, float x) {
     return (x > 0.0f) ? __logf(x) : -1.0e10f;
 }
 __device__ __forceinline__ float fused_prologue_phase(float x) { return fmaf(1.0e-8f, __expf(-2.0f * x), 2.0f * x); }
+
+// (measured, 57 k frames: 60 / 45 coefficients 1.043 -> 1.018 ms; 60 / 10: 0.893 -> 0.909 ms -- so only with three phase tiles)
+template <int P, int NTP>
+constexpr bool fused_pair() {
+    return MPX_FUSED_PAIR != 0 && NTP >= 3 && kFusedWaves == 8 &&
+           kFusedWaves * f64_win_floats<P>() >= 4 * 3 * kFusedWaves * kFusedAStride;
+}
 
 template <int P, int NTM, int NTP>
 constexpr size_t lds_bytes_fused() {
@@ -555,21 +565,31 @@ __global__ __launch_bounds__(kFusedWaves * 64) void k_analysis_warp_fused(
                 for (int t = 0; t < NTP; ++t) bp[t] = wp4[wo + (8 + t) * 64 + lane_id];
             }
             const int arow4 = (4 * (lane_id >> 5) + (lane_id & 3)) * kFusedAStride + kFusedCols * wave;
+            // N = 4096: FOUR tile buffers, two chunks published per barrier (half the barriers of a round: MPX_FUSED_PAIR)
+            constexpr bool PAIR = fused_pair<P, NTP>();
+            constexpr int NB = PAIR ? 4 : 2;
+            auto publish = [&](int q) {
+                float* row = As + (q & (NB - 1)) * (3 * kFusedWaves * kFusedAStride) + wave * kFusedAStride;
+                row[kap] = vm[2 * q];
+                row[64 + kap] = vm[2 * q + 1];
+                row += kFusedWaves * kFusedAStride;
+                row[kap] = vr[2 * q];
+                row[64 + kap] = vr[2 * q + 1];
+                row += kFusedWaves * kFusedAStride;
+                row[kap] = vi[2 * q];
+                row[64 + kap] = vi[2 * q + 1];
+            };
 #pragma unroll
             for (int q = 0; q < P / 2; ++q) {
-                float* tile = As + (q & 1) * (3 * kFusedWaves * kFusedAStride);
-                {
-                    float* row = tile + wave * kFusedAStride;
-                    row[kap] = vm[2 * q];
-                    row[64 + kap] = vm[2 * q + 1];
-                    row += kFusedWaves * kFusedAStride;
-                    row[kap] = vr[2 * q];
-                    row[64 + kap] = vr[2 * q + 1];
-                    row += kFusedWaves * kFusedAStride;
-                    row[kap] = vi[2 * q];
-                    row[64 + kap] = vi[2 * q + 1];
+                const float* tile = As + (q & (NB - 1)) * (3 * kFusedWaves * kFusedAStride);
+                if (!PAIR) {
+                    publish(q);
+                    __syncthreads();
+                } else if ((q & 1) == 0) {
+                    publish(q);
+                    publish(q + 1);
+                    __syncthreads();
                 }
-                __syncthreads();
                 f32x4_t a4[4];
 #pragma unroll
                 for (int kg = 0; kg < 4; ++kg) a4[kg] = *reinterpret_cast<const f32x4_t*>(tile + arow4 + 4 * kg);
