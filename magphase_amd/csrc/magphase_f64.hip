@@ -382,6 +382,9 @@ constexpr int kFusedRedStride = 68;
 #ifndef MPX_FUSED_PAIR    // two chunks per barrier where four tile buffers fit the window regions (N = 4096) and it pays (fused_pair)
 #define MPX_FUSED_PAIR 1
 #endif
+#ifndef MPX_FUSED_VOIBRANCH
+#define MPX_FUSED_VOIBRANCH 1
+#endif
 #ifndef MPX_FUSED_M4      // magnitude product on v_mfma_f32_4x4x1_16b_f32 (full blocks) -- the default; 0: 16 x 16 x 4 tiles
 #define MPX_FUSED_M4 1
 #endif
@@ -477,8 +480,17 @@ __global__ __launch_bounds__(kFusedWaves * 64) void k_analysis_warp_fused(
             const bool nz = s2 > zero2;
             const double rr = nz ? rsqrt_f64(s2) : 0.0;
             a_m = fused_prologue_mag(MAGMODE, (float)(s2 * rr) * mag_scale);
+#if MPX_FUSED_VOIBRANCH   // a real (wave-uniform) branch: an unvoiced frame skips the phase operands' arithmetic instead of discarding it
+            if (voi) {
+                a_r = fused_prologue_phase((float)(xr * rr));
+                a_i = fused_prologue_phase((float)(xi * rr));
+            } else {
+                a_r = a_i = 0.0f;
+            }
+#else
             a_r = voi ? fused_prologue_phase((float)(xr * rr)) : 0.0f;
             a_i = voi ? fused_prologue_phase((float)(xi * rr)) : 0.0f;
+#endif
         };
         // The split of every bin pair row FIRST (k_analysis_f64's epilogue arithmetic), into float32 operand registers:
         // entry 2 q = the low bin kappa + 64 q of step q, 2 q + 1 = its mirror M - kappa - 64 q.  The float64 spectrum

@@ -631,7 +631,8 @@ def test_full_size_config3_constant_rate_post_filter(mp, orc):
 
 @pytest.mark.parametrize("fs,mag_dim,phase_dim,alpha_phase,fbank", [(48000, 60, 10, False, False), (48000, 60, 45, None, False),
                                                                    (16000, 60, 45, None, False), (16000, 24, 16, None, False),
-                                                                   (48000, 40, 33, None, True)])
+                                                                   (48000, 40, 33, None, True), (48000, 64, 48, None, False),
+                                                                   (16000, 3, 1, None, False)])
 def test_fused_compressed_analysis_matches_oracle_and_staged_path(orc, fs, mag_dim, phase_dim, alpha_phase, fbank):
     """mpx_analysis_compressed_fused (variable frame rate: transform + both warps in one kernel, no lossless features in
     HBM) against the oracle at the staged path's tolerances, against the staged pair k_analysis_f64 -> k_mel_warp_mfma
