@@ -23,6 +23,7 @@ frames/s and x real time of the whole job (max over ranks), the per-rank cost an
 """
 import os
 import sys
+import gc
 import time
 import warnings
 
@@ -91,6 +92,10 @@ def run_extraction(rank, mine, dur, fs):
                 t_.wait()
                 t_.release()
         # pipelined form (see run_generation): a launch's features are taken one launch later, all of them inside the clock
+        # (the cyclic collector is paused over the timed pass, as timeit does: one generation-2 sweep over the job's
+        # tens of thousands of arrays is 50 ms, as long as the whole pass)
+        gc.collect()
+        gc.disable()
         t0 = time.perf_counter()
         frames, prev = 0, None
         for b in _batches(items):
@@ -105,6 +110,7 @@ def run_extraction(rank, mine, dur, fs):
             frames += sum(int(r[0].shape[0]) for r in prev[0])
             prev[1].release()
         dt = time.perf_counter() - t0
+        gc.enable()
     return {"seconds": dt, "frames": frames, "audio_s": float(np.sum(dur[mine])) if len(mine) else 0.0, "utts": len(mine)}
 
 
@@ -167,6 +173,8 @@ def run_generation(rank, mine, dur, fs):
                 synth(big)
                 take(0)
             eng.mt_sync()
+        gc.collect()
+        gc.disable()   # (see run_extraction)
         t0 = time.perf_counter()
         frames, smpls = 0, 0
         for b in _batches(items, BATCH_GEN):
@@ -175,6 +183,7 @@ def run_generation(rank, mine, dur, fs):
         smpls += take(0)
         eng.mt_sync()
         dt = time.perf_counter() - t0
+        gc.enable()
     return {"seconds": dt, "frames": frames, "audio_s": float(np.sum(dur[mine])) if len(mine) else 0.0, "utts": len(mine)}
 
 
