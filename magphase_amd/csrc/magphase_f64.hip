@@ -385,6 +385,9 @@ constexpr int kFusedRedStride = 68;
 #ifndef MPX_FUSED_VOIBRANCH
 #define MPX_FUSED_VOIBRANCH 1
 #endif
+#ifndef MPX_FUSED_F32NORM   // |X| and X / |X| of the float64 spectrum formed in float32 (see `operand`): measured error-neutral against
+#define MPX_FUSED_F32NORM 1 // the oracle (worst case and sum of squares within 3 %), -1 % (60 / 10) / -3.4 % (60 / 45)
+#endif
 #ifndef MPX_FUSED_M4      // magnitude product on v_mfma_f32_4x4x1_16b_f32 (full blocks) -- the default; 0: 16 x 16 x 4 tiles
 #define MPX_FUSED_M4 1
 #endif
@@ -478,6 +481,20 @@ __global__ __launch_bounds__(kFusedWaves * 64) void k_analysis_warp_fused(
         auto operand = [&](double xr, double xi, float& a_m, float& a_r, float& a_i) {
             const double s2 = xr * xr + xi * xi;
             const bool nz = s2 > zero2;
+#if MPX_FUSED_F32NORM   // |X| and the unit phasor in float32 from the float64 spectrum: v_rsq_f32 (1 ulp) and float32 products, no
+            // Newton step -- <= 2 ulp on operands that the float32 matrix product then sums over 2 049 bins (the staged path
+            // rounds the float64 quotient once instead: k_analysis_f64's rows are API outputs, these operands are not)
+            const float s2f = (float)s2;
+            const float rf = nz ? __builtin_amdgcn_rsqf(s2f) : 0.0f;
+            a_m = fused_prologue_mag(MAGMODE, (s2f * rf) * mag_scale);
+            if (voi) {
+                a_r = fused_prologue_phase((float)xr * rf);
+                a_i = fused_prologue_phase((float)xi * rf);
+            } else {
+                a_r = a_i = 0.0f;
+            }
+            return;
+#endif
             const double rr = nz ? rsqrt_f64(s2) : 0.0;
             a_m = fused_prologue_mag(MAGMODE, (float)(s2 * rr) * mag_scale);
 #if MPX_FUSED_VOIBRANCH   // a real (wave-uniform) branch: an unvoiced frame skips the phase operands' arithmetic instead of discarding it
