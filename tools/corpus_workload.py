@@ -40,6 +40,10 @@ BASE_DUR_S = 8.0
 # build, noise stream, PCIe copies -- amortise: 64 / 128 / 256 / 512 per launch = 70.9 / 84.9 / 96.1 / 44.2 k x real time on one
 # box; at 512 the page-locked buffers re-grow).  CORPUS_BATCH overrides both.
 BATCH = int(os.environ.get("CORPUS_BATCH", "64"))
+# Warm-up of a timed pass: the largest launch repeated for this long (the passes are 30-50 ms of device work, and a device that
+# comes out of idle -- the corpus is generated on the host for seconds before -- runs its first tens of ms at idle clocks:
+# tools/archive/step_curve_probe.py; a production job of minutes does not see that)
+WARM_S = float(os.environ.get("CORPUS_WARM_S", "0.25"))
 BATCH_GEN = int(os.environ.get("CORPUS_BATCH", "256"))
 
 
@@ -83,19 +87,22 @@ def run_extraction(rank, mine, dur, fs):
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         kw = dict(mag_dim=60, phase_dim=10, alpha_phase=False, as_float32=True)
+        # (the cyclic collector is paused from here to the end of the timed pass, as timeit does: one generation-2 sweep over the
+        # job's tens of thousands of arrays is 50 ms, as long as the whole pass.  Collected BEFORE the warm-up launches so that
+        # the device does not sit idle -- and drop its clocks -- between them and the clock's start)
+        gc.collect()
+        gc.disable()
         if items:   # warm-up on the LARGEST launch of the job (page-locked staging and ring slots, device pools, tables: a
             # launch that outgrows them re-pins / re-allocates inside the clock -- a production job pays that once in minutes)
             big = max(_batches(items), key=lambda b: sum(int(x[0].shape[0]) for x in b))
             mp.analysis_compressed_batch(big, **kw)
-            for _ in range(2):
+            tw, nw = time.perf_counter(), 0
+            while nw < 2 or time.perf_counter() - tw < WARM_S:   # at least twice, and until the device is out of its idle clocks
                 _res, t_ = mp.analysis_compressed_batch(big, async_out=True, **kw)
                 t_.wait()
                 t_.release()
+                nw += 1
         # pipelined form (see run_generation): a launch's features are taken one launch later, all of them inside the clock
-        # (the cyclic collector is paused over the timed pass, as timeit does: one generation-2 sweep over the job's
-        # tens of thousands of arrays is 50 ms, as long as the whole pass)
-        gc.collect()
-        gc.disable()
         t0 = time.perf_counter()
         frames, prev = 0, None
         for b in _batches(items):
@@ -167,14 +174,16 @@ def run_generation(rank, mine, dur, fs):
             return frames
 
         np.random.seed(1000 + rank)
-        if items:   # warm-up on the largest launch (see run_extraction), twice: both staging buffers, every ring slot
-            big = max(_batches(items, BATCH_GEN), key=lambda b: sum(int(x[1][0].shape[0]) for x in b))
-            for _ in range(2):
-                synth(big)
-                take(0)
-            eng.mt_sync()
         gc.collect()
         gc.disable()   # (see run_extraction)
+        if items:   # warm-up on the largest launch (see run_extraction), twice: both staging buffers, every ring slot
+            big = max(_batches(items, BATCH_GEN), key=lambda b: sum(int(x[1][0].shape[0]) for x in b))
+            tw, nw = time.perf_counter(), 0
+            while nw < 2 or time.perf_counter() - tw < WARM_S:   # (see run_extraction)
+                synth(big)
+                take(0)
+                nw += 1
+            eng.mt_sync()
         t0 = time.perf_counter()
         frames, smpls = 0, 0
         for b in _batches(items, BATCH_GEN):
