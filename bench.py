@@ -19,7 +19,8 @@ ONE JSON line.  Next to the headline (metric / value / roofline / cpu_baseline) 
   "e2e":      what a caller gets -- the numpy-in / numpy-out array API and the file interface (wav + .est files ->
               feature files -> wavs through iobatch), as multiples of real time.
   "corpus_shard": one 1 250-utterance shard of the 8-GPU corpus job (configs[3] extraction + configs[4] mixed-rate
-              generation through the batch API, tools/corpus_workload.py).
+              generation through the batch API, tools/corpus_workload.py; x_realtime = the first pass of the process,
+              x_realtime_second_pass = the same pass again).
 roofline carries, besides the spec-peak fraction: the HBM traffic of the dominant kernel measured IN THIS RUN (two
 rocprofv3 --pmc child passes; --traffic committed|none skips them) and this device's measured streaming read / write /
 copy ceilings (mpx_bw_probe).
