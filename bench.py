@@ -440,7 +440,42 @@ def measure_lowdim(eng, utts, steps, warmup, live=None, live_src=None, n_streams
                 k["hbm_traffic"] = round(live[k["name"]], 1)
     else:
         traffic, src = _committed_traffic("lowdim_step")
+    # "noise spectra once" (opt-in, MAGPHASE_NOISE_SPECTRA=store): the synthesis side of the same step in both forms,
+    # interleaved in this process (HIP events, one launch chain at a time); skipped when the run itself is in that form
+    nso = None
+    if not getattr(splan, "noise_spectra", False) and hasattr(eng.lib, "mpx_noise_stats_spectra"):
+        try:
+            saved = os.environ.get("MAGPHASE_NOISE_SPECTRA")
+            os.environ["MAGPHASE_NOISE_SPECTRA"] = "store"
+            try:
+                st2 = _lowdim_state(em, eng, utts)
+            finally:
+                if saved is None:
+                    os.environ.pop("MAGPHASE_NOISE_SPECTRA", None)
+                else:
+                    os.environ["MAGPHASE_NOISE_SPECTRA"] = saved
+            forms = (("recompute", st), ("store", st2))
+            ts = {n: [] for n, _ in forms}
+            for r in range(17):
+                for n, s_ in forms:
+                    e0.record()
+                    s_["splan"].run(out=s_["pcm"])
+                    e1.record()
+                    torch.cuda.synchronize()
+                    if r >= 2:
+                        ts[n].append(e0.elapsed_time(e1))
+            spec_bytes = 4.0 * int(eng.lib.mpx_noise_spectra_floats(N, Fs))
+            nso = {"what": "synthesis side (unwarp -> noise statistics -> gains -> synthesis -> fix-up) with every noise frame "
+                           "transformed twice (default) or once, its spectrum stored by the statistics launch and loaded by "
+                           "the synthesis launch; median of 15 interleaved rounds, HIP events",
+                   "synthesis_ms_recompute": round(float(np.median(ts["recompute"])), 4),
+                   "synthesis_ms_store": round(float(np.median(ts["store"])), 4),
+                   "extra_hbm_bytes_store": 2.0 * spec_bytes, "default": "recompute"}
+            del st2
+        except Exception as e:   # the comparison is a side measurement: never the reason a bench line is lost
+            nso = {"error": "%s: %s" % (type(e).__name__, e)}
     return {
+        "noise_spectra_once": nso,
         "workload": "configs[2]: the same 64 x 5 s @48 kHz; analysis_compressed(mag 60, phase 45, constant 5 ms rate) -> "
                     "post-filter -> synthesis_from_compressed(b_const_rate=True, per_phase_type='magphase')",
         "ms_per_step": round(ms_step, 4), "steps": steps, "warmup_steps_used": warm_used,

@@ -313,6 +313,18 @@ int32_t mpx_host_mt19937_jump_poly(int64_t jump_words, int32_t n_levels, uint32_
 int mpx_noise_stats(void* stream, int fft_len, const void* tables, const float* noise, const int64_t* frame_pos,
                     const int32_t* frame_left, const int32_t* frame_right, const int32_t* frame_wtype,
                     int64_t n_frames, float* out_sum);
+/*
+ * "Noise spectra once" form of the pair mpx_noise_stats -> mpx_synthesis_compressed_ola (fft_len 4096 only; the same
+ * reference lines, magphase.py:886-903 and :908-976): mpx_noise_stats_spectra also stores every frame's noise spectrum
+ * (mpx_noise_spectra_floats(fft_len, n_frames) floats, in the kernels' own register layout), and
+ * mpx_synthesis_compressed_ola_spectra (one row per frame: row0 / row1 / row_t NULL) loads it instead of transforming
+ * the noise frame a second time.  Trades the second FFT for 17.4 KB of HBM traffic per frame each way; opt-in
+ * (MAGPHASE_NOISE_SPECTRA=store), measured in docs/LAB_NOTES.md (round 5).
+ */
+int64_t mpx_noise_spectra_floats(int fft_len, int64_t n_frames);
+int mpx_noise_stats_spectra(void* stream, int fft_len, const void* tables, const float* noise, const int64_t* frame_pos,
+                            const int32_t* frame_left, const int32_t* frame_right, const int32_t* frame_wtype,
+                            int64_t n_frames, float* out_sum, float* spectra);
 
 /*
  * Spectrum assembly + inverse FFT + anti-ringing window + PSOLA for compressed-feature synthesis
@@ -343,6 +355,16 @@ int mpx_synthesis_compressed_ola(void* stream, int fft_len, const void* tables, 
                                  float* strips, float* pcm_out,
                                  int64_t ld /* row pitch of mag/real/imag in floats, >= fft_len/2 + 1 */,
                                  int32_t n_per_bins);
+int mpx_synthesis_compressed_ola_spectra(void* stream, int fft_len, const void* tables, const float* mag, const float* real,
+                                 const float* imag, const float* noise, const int64_t* noise_pos,
+                                 const int32_t* noise_left, const int32_t* noise_right, const int32_t* noise_wtype,
+                                 const int32_t* voiced, const float* inv_gain, const int32_t* row0,
+                                 const int32_t* row1, const float* row_t, const int32_t* win_left,
+                                 const int32_t* win_right, const int32_t* pm_rel, const float* per_v,
+                                 const float* ap_v, const float* ap_u, const mpx_ola_run* runs, int32_t n_runs,
+                                 const int32_t* slot_off, const int32_t* slot_runs, int32_t n_slots,
+                                 float* strips, float* pcm_out, int64_t ld, int32_t n_per_bins,
+                                 const float* spectra /* as stored by mpx_noise_stats_spectra */);
 
 /*
  * mpx_mel_unwarp_rows + mpx_synthesis_compressed_ola as ONE launch (magphase.py:852-870 followed by :900-973; N = 4096,

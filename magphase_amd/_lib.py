@@ -44,9 +44,12 @@ SYMBOLS = (
     "mpx_noise_numpy_mt19937_work_words",
     "mpx_host_mt19937_jump_poly",
     "mpx_noise_stats",
+    "mpx_noise_spectra_floats",
+    "mpx_noise_stats_spectra",
     "mpx_synth_comp_slots",
     "mpx_synth_comp_slot_weights",
     "mpx_synthesis_compressed_ola",
+    "mpx_synthesis_compressed_ola_spectra",
     "mpx_synth_fused_format",
     "mpx_synth_fused_ksteps",
     "mpx_synth_fused_scratch_floats",
@@ -182,10 +185,17 @@ def _load_locked():
     lib.mpx_host_mt19937_jump_poly.argtypes = [i64, i32, vp]
     lib.mpx_noise_stats.restype = ctypes.c_int
     lib.mpx_noise_stats.argtypes = [vp, ctypes.c_int, vp, vp, vp, vp, vp, vp, i64, vp]
+    lib.mpx_noise_spectra_floats.restype = i64
+    lib.mpx_noise_spectra_floats.argtypes = [ctypes.c_int, i64]
+    lib.mpx_noise_stats_spectra.restype = ctypes.c_int
+    lib.mpx_noise_stats_spectra.argtypes = [vp, ctypes.c_int, vp, vp, vp, vp, vp, vp, i64, vp, vp]
     lib.mpx_synth_comp_slots.restype = ctypes.c_int
     lib.mpx_synth_comp_slots.argtypes = []
     lib.mpx_synthesis_compressed_ola.restype = ctypes.c_int
     lib.mpx_synthesis_compressed_ola.argtypes = [vp, ctypes.c_int, vp] + [vp] * 19 + [vp, i32, vp, vp, i32, vp, vp, i64, i32]
+    lib.mpx_synthesis_compressed_ola_spectra.restype = ctypes.c_int
+    lib.mpx_synthesis_compressed_ola_spectra.argtypes = ([vp, ctypes.c_int, vp] + [vp] * 19 +
+                                                         [vp, i32, vp, vp, i32, vp, vp, i64, i32, vp])
     lib.mpx_synth_fused_format.restype = ctypes.c_int
     lib.mpx_synth_fused_format.argtypes = []
     lib.mpx_synth_fused_ksteps.restype = ctypes.c_int

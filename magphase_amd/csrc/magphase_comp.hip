@@ -394,6 +394,10 @@ __device__ __forceinline__ void noise_spectrum(const FrameGeom& g, int wtype, co
     nM = re[0] - im[0];   // Nyquist bin X[M] = Re Z[0] - Im Z[0] (meaningful on the kappa == 0 lane)
 }
 
+// floats per frame of the stored noise spectra (N = 4096): 17 slots x 64 lanes x float4
+constexpr int kSpecFrameFloats = 17 * 64 * 4;
+typedef float spec_f32x4 __attribute__((ext_vector_type(4)));
+
 template <int P>
 __global__ __launch_bounds__(kAnaThreads) void k_noise_stats(const float* __restrict__ noise,
                                                           const long long* __restrict__ npos,
@@ -401,7 +405,8 @@ __global__ __launch_bounds__(kAnaThreads) void k_noise_stats(const float* __rest
                                                           const int* __restrict__ nright,
                                                           const int* __restrict__ wtype, long long nframes,
                                                           const float* __restrict__ tw_g,
-                                                          float* __restrict__ out_sum) {
+                                                          float* __restrict__ out_sum,
+                                                          float* __restrict__ spec_out) {
     constexpr int M = 64 * P, N = 2 * M;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* tw = smem;
@@ -426,6 +431,22 @@ __global__ __launch_bounds__(kAnaThreads) void k_noise_stats(const float* __rest
         const FrameGeom g = frame_geom(noise, npos[f], nleft[f], nright[f], N);
         float no_r[P / 2], no_i[P / 2], nm_r[P / 2], nm_i[P / 2], nh_r, nh_i;
         noise_spectrum_paired<P>(g, wtype[f], tw, xbuf, xbuf_byte, lane, wl_c, wl_s, no_r, no_i, nm_r, nm_i, nh_r, nh_i);
+        if constexpr (P == 32) {
+            // "noise spectra once" form (mpx_noise_stats_spectra): the frame's paired spectrum goes to HBM as the registers
+            // hold it -- 17 slots of 64 lanes x float4 (no_r, no_i, nm_r, nm_i four rows at a time, then the bin-M/2 pair),
+            // 1 KB per wave store -- and k_synth_comp_pair<.., SPEC> loads it back instead of transforming the frame again
+            if (spec_out) {
+                spec_f32x4* d = reinterpret_cast<spec_f32x4*>(spec_out + f * (long long)kSpecFrameFloats) + lane_id;
+#pragma unroll
+                for (int s_ = 0; s_ < 4; ++s_) {
+                    __builtin_nontemporal_store(spec_f32x4{no_r[4 * s_], no_r[4 * s_ + 1], no_r[4 * s_ + 2], no_r[4 * s_ + 3]}, d + 64 * s_);
+                    __builtin_nontemporal_store(spec_f32x4{no_i[4 * s_], no_i[4 * s_ + 1], no_i[4 * s_ + 2], no_i[4 * s_ + 3]}, d + 64 * (4 + s_));
+                    __builtin_nontemporal_store(spec_f32x4{nm_r[4 * s_], nm_r[4 * s_ + 1], nm_r[4 * s_ + 2], nm_r[4 * s_ + 3]}, d + 64 * (8 + s_));
+                    __builtin_nontemporal_store(spec_f32x4{nm_i[4 * s_], nm_i[4 * s_ + 1], nm_i[4 * s_ + 2], nm_i[4 * s_ + 3]}, d + 64 * (12 + s_));
+                }
+                __builtin_nontemporal_store(spec_f32x4{nh_r, nh_i, 0.0f, 0.0f}, d + 64 * 16);
+            }
+        }
         // sum over bins 1..M-1 of (ln|Ns|)^2 = (0.5 ln |Ns|^2)^2 ; |Ns| == 0 -> protected log MAGIC = -1e10 (libaudio.py:241-248)
         // paired layout: own bin + mirror per step; the kappa == 0 lane's first pair is (DC, Nyquist), both excluded, and
         // that lane adds bin M/2
@@ -1109,6 +1130,7 @@ struct CompFrameTabs {
     const int* win_l;        // anti-ringing window half lengths (Q14)
     const int* win_r;
     const int* pm_rel;
+    const float* nspec;      // SPEC form: the frames' noise spectra as k_noise_stats stored them (else unused)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -1414,7 +1436,8 @@ __device__ __forceinline__ void fuse_unwarp_steps_bf16(const float* __restrict__
 // four batches of 40 -- the 17 registers the 40-wide batches spilled at 12 waves per CU are gone (166 VGPRs, no scratch),
 // and the freed registers allow batches of (8, 8) = 56 / 32 loads: two exposed load latencies per frame instead of four.
 // NPQ < 0: anything goes (run-time tests only).
-template <int P, bool LERP, int NPQ = -1, bool FUSED = false, int KTM = 15, int KTP = 12>
+// SPEC: the noise spectra come from HBM (tb.nspec, stored by k_noise_stats) instead of a second transform of the frame.
+template <int P, bool LERP, int NPQ = -1, bool FUSED = false, int KTM = 15, int KTP = 12, bool SPEC = false>
 __global__ __launch_bounds__(kCompPairWaves * 64) void k_synth_comp_pair(const float* __restrict__ mag,
                                                                         const float* __restrict__ real,
                                                                         const float* __restrict__ imag,
@@ -1433,6 +1456,7 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_synth_comp_pair(const f
                                                                         FuseArgs fz) {
     static_assert(!FUSED || (P == 32 && !LERP && NPQ == 8 && comp_compact<P>()),
                   "the fused form is built on the 12-wave one-row-per-frame kernel of N = 4096");
+    static_assert(!SPEC || (P == 32 && !LERP && !FUSED), "stored noise spectra: N = 4096, one row per frame, staged unwarp");
     constexpr int M = 64 * P, N = 2 * M, R = ring_len<P>();
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* tw = smem;
@@ -1617,7 +1641,7 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_synth_comp_pair(const f
     constexpr int kTile = kCompact ? 32 * P : 64 * P;
     FrameGeom g = frame_geom(noise, tb.npos[cur.fi], tb.nleft[cur.fi], tb.nright[cur.fi], N);
     bool staged = false;   // FUSED: the exchange buffer is the product tile between segments, the copy starts after it
-    if constexpr (!FUSED) stage_samples_async(g, 0, kTile, xbuf_byte, lane_id);
+    if constexpr (!FUSED && !SPEC) stage_samples_async(g, 0, kTile, xbuf_byte, lane_id);
 
     while (cur.valid) {
         if constexpr (FUSED) {
@@ -1706,9 +1730,25 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_synth_comp_pair(const f
             // merge arithmetic per frame.
             constexpr int HP = P / 2;
             float no_r[HP], no_i[HP], nm_r[HP], nm_i[HP], nh_r, nh_i;
-            staged_wait<0>();
-            noise_spectrum_paired<P, true, kCompact>(g, tb.wtype[fi], tw, xbuf, xbuf_byte, lane, wa_c, wa_s, no_r, no_i, nm_r,
-                                                     nm_i, nh_r, nh_i, lc, ls);
+            if constexpr (SPEC) {
+                const spec_f32x4* sp = reinterpret_cast<const spec_f32x4*>(tb.nspec + (long long)fi * kSpecFrameFloats) + lane;
+                spec_f32x4 v[16];
+#pragma unroll
+                for (int s_ = 0; s_ < 16; ++s_) v[s_] = __builtin_nontemporal_load(sp + 64 * s_);
+                const spec_f32x4 vh = __builtin_nontemporal_load(sp + 64 * 16);
+#pragma unroll
+                for (int s_ = 0; s_ < 4; ++s_) {
+                    no_r[4 * s_] = v[s_].x, no_r[4 * s_ + 1] = v[s_].y, no_r[4 * s_ + 2] = v[s_].z, no_r[4 * s_ + 3] = v[s_].w;
+                    no_i[4 * s_] = v[4 + s_].x, no_i[4 * s_ + 1] = v[4 + s_].y, no_i[4 * s_ + 2] = v[4 + s_].z, no_i[4 * s_ + 3] = v[4 + s_].w;
+                    nm_r[4 * s_] = v[8 + s_].x, nm_r[4 * s_ + 1] = v[8 + s_].y, nm_r[4 * s_ + 2] = v[8 + s_].z, nm_r[4 * s_ + 3] = v[8 + s_].w;
+                    nm_i[4 * s_] = v[12 + s_].x, nm_i[4 * s_ + 1] = v[12 + s_].y, nm_i[4 * s_ + 2] = v[12 + s_].z, nm_i[4 * s_ + 3] = v[12 + s_].w;
+                }
+                nh_r = vh.x, nh_i = vh.y;
+            } else {
+                staged_wait<0>();
+                noise_spectrum_paired<P, true, kCompact>(g, tb.wtype[fi], tw, xbuf, xbuf_byte, lane, wa_c, wa_s, no_r, no_i,
+                                                         nm_r, nm_i, nh_r, nh_i, lc, ls);
+            }
             if (P != 32) {   // FFT output lanes hold bins kappa(lane) + 64 q; everything below wants bins lane + 64 q
                 const int src = kappa<P>(lane);
 #pragma unroll
@@ -2024,7 +2064,7 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_synth_comp_pair(const f
             wave_fft_front<P, +1>(xr, xi, tw, xbuf, lane);
         }
         // FUSED: only inside the segment -- the next segment's product needs the buffer first
-        staged = nxt.valid && (!FUSED || (nxt.wi == cur.wi && nxt.fi < cs_fe));
+        staged = !SPEC && nxt.valid && (!FUSED || (nxt.wi == cur.wi && nxt.fi < cs_fe));
         if (staged) {   // the exchange buffer is idle from here on: start the copy of the next frame's noise
             g = frame_geom(noise, tb.npos[nxt.fi], tb.nleft[nxt.fi], tb.nright[nxt.fi], N);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -3116,9 +3156,9 @@ int mpx_mel_unwarp_rows(void* stream, int64_t n_frames, int32_t n_bins, const fl
                            out_real, out_imag, ld, UnwarpRows{row0, row1, row_t, voiced, (int)n_phase_bins}, n_rows, tile_first);
 }
 
-int mpx_noise_stats(void* stream, int fft_len, const void* tables, const float* noise, const int64_t* frame_pos,
-                    const int32_t* frame_left, const int32_t* frame_right, const int32_t* frame_wtype,
-                    int64_t n_frames, float* out_sum) {
+static int noise_stats_impl(void* stream, int fft_len, const void* tables, const float* noise, const int64_t* frame_pos,
+                            const int32_t* frame_left, const int32_t* frame_right, const int32_t* frame_wtype,
+                            int64_t n_frames, float* out_sum, float* spectra) {
     const int P = p_of(fft_len);
     if (!P) return fail(MPX_ERR_ARG, "mpx_noise_stats: fft_len must be 1024, 2048 or 4096%s");
     if (n_frames < 0) return fail(MPX_ERR_ARG, "mpx_noise_stats: negative n_frames%s");
@@ -3130,18 +3170,38 @@ int mpx_noise_stats(void* stream, int fft_len, const void* tables, const float* 
     if (P == 32) {
         if (int rc = set_lds(k_noise_stats<32>, lds_bytes_ana<32>())) return rc;
         hipLaunchKernelGGL(k_noise_stats<32>, grid, block, lds_bytes_ana<32>(), s, noise, (const long long*)frame_pos,
-                           frame_left, frame_right, frame_wtype, (long long)n_frames, (const float*)tables, out_sum);
+                           frame_left, frame_right, frame_wtype, (long long)n_frames, (const float*)tables, out_sum, spectra);
     } else if (P == 16) {
         if (int rc = set_lds(k_noise_stats<16>, lds_bytes_ana<16>())) return rc;
         hipLaunchKernelGGL(k_noise_stats<16>, grid, block, lds_bytes_ana<16>(), s, noise, (const long long*)frame_pos,
-                           frame_left, frame_right, frame_wtype, (long long)n_frames, (const float*)tables, out_sum);
+                           frame_left, frame_right, frame_wtype, (long long)n_frames, (const float*)tables, out_sum, spectra);
     } else {
         if (int rc = set_lds(k_noise_stats<8>, lds_bytes_ana<8>())) return rc;
         hipLaunchKernelGGL(k_noise_stats<8>, grid, block, lds_bytes_ana<8>(), s, noise, (const long long*)frame_pos,
-                           frame_left, frame_right, frame_wtype, (long long)n_frames, (const float*)tables, out_sum);
+                           frame_left, frame_right, frame_wtype, (long long)n_frames, (const float*)tables, out_sum, spectra);
     }
     MPX_HIP_CHECK(hipGetLastError());
     return MPX_OK;
+}
+
+int mpx_noise_stats(void* stream, int fft_len, const void* tables, const float* noise, const int64_t* frame_pos,
+                    const int32_t* frame_left, const int32_t* frame_right, const int32_t* frame_wtype,
+                    int64_t n_frames, float* out_sum) {
+    return noise_stats_impl(stream, fft_len, tables, noise, frame_pos, frame_left, frame_right, frame_wtype, n_frames,
+                            out_sum, nullptr);
+}
+
+int64_t mpx_noise_spectra_floats(int fft_len, int64_t n_frames) {
+    return (fft_len == 4096 && n_frames > 0) ? n_frames * (int64_t)kSpecFrameFloats : 0;
+}
+
+int mpx_noise_stats_spectra(void* stream, int fft_len, const void* tables, const float* noise, const int64_t* frame_pos,
+                            const int32_t* frame_left, const int32_t* frame_right, const int32_t* frame_wtype,
+                            int64_t n_frames, float* out_sum, float* spectra) {
+    if (fft_len != 4096) return fail(MPX_ERR_ARG, "mpx_noise_stats_spectra: fft_len must be 4096%s");
+    if (!spectra && n_frames > 0) return fail(MPX_ERR_ARG, "mpx_noise_stats_spectra: null pointer%s");
+    return noise_stats_impl(stream, fft_len, tables, noise, frame_pos, frame_left, frame_right, frame_wtype, n_frames,
+                            out_sum, spectra);
 }
 
 int mpx_synth_comp_slots(void) { return device_cus() * kCompPairs; }
@@ -3169,7 +3229,7 @@ int mpx_synth_comp_slot_weights(float* weights_host, int32_t n_slots) {
     return MPX_OK;
 }
 
-int mpx_synthesis_compressed_ola(void* stream, int fft_len, const void* tables, const float* mag, const float* real,
+static int synthesis_compressed_ola_impl(void* stream, int fft_len, const void* tables, const float* mag, const float* real,
                                  const float* imag, const float* noise, const int64_t* noise_pos,
                                  const int32_t* noise_left, const int32_t* noise_right, const int32_t* noise_wtype,
                                  const int32_t* voiced, const float* inv_gain, const int32_t* row0,
@@ -3177,7 +3237,8 @@ int mpx_synthesis_compressed_ola(void* stream, int fft_len, const void* tables, 
                                  const int32_t* win_right, const int32_t* pm_rel, const float* per_v,
                                  const float* ap_v, const float* ap_u, const mpx_ola_run* runs, int32_t n_runs,
                                  const int32_t* slot_off, const int32_t* slot_runs, int32_t n_slots,
-                                 float* strips, float* pcm_out, int64_t ld, int32_t n_per_bins) {
+                                 float* strips, float* pcm_out, int64_t ld, int32_t n_per_bins,
+                                 const float* spectra) {
     const int P = p_of(fft_len);
     if (!P) return fail(MPX_ERR_ARG, "mpx_synthesis_compressed_ola: fft_len must be 1024, 2048 or 4096%s");
     const int n_per = (n_per_bins <= 0 || n_per_bins > fft_len / 2 + 1) ? fft_len / 2 + 1 : (int)n_per_bins;
@@ -3191,9 +3252,26 @@ int mpx_synthesis_compressed_ola(void* stream, int fft_len, const void* tables, 
     if (lerp && (!row0 || !row1 || !row_t))
         return fail(MPX_ERR_ARG, "mpx_synthesis_compressed_ola: row0 / row1 / row_t must be given together%s");
     CompFrameTabs tb{(const long long*)noise_pos, noise_left, noise_right, noise_wtype, voiced, inv_gain,
-                     row0, row1, row_t, win_left, win_right, pm_rel};
+                     row0, row1, row_t, win_left, win_right, pm_rel, spectra};
     hipStream_t s = (hipStream_t)stream;
     const dim3 pgrid((n_slots + kCompPairs - 1) / kCompPairs), pblock(kCompPairWaves * 64);
+    if (spectra) {   // stored noise spectra (mpx_noise_stats_spectra): N = 4096, one row per frame
+        if (P != 32 || lerp)
+            return fail(MPX_ERR_ARG, "mpx_synthesis_compressed_ola_spectra: fft_len 4096 and one row per frame only%s");
+        if (n_per <= 512) {
+            if (int rc = set_lds(k_synth_comp_pair<32, false, 8, false, 15, 12, true>, lds_bytes_comp_pair<32>())) return rc;
+            hipLaunchKernelGGL((k_synth_comp_pair<32, false, 8, false, 15, 12, true>), pgrid, pblock, lds_bytes_comp_pair<32>(),
+                               s, mag, real, imag, noise, tb, per_v, ap_v, ap_u, (const RunDesc*)runs, slot_off, slot_runs,
+                               (int)n_slots, (const float*)tables, strips, pcm_out, (long long)ld, n_per, FuseArgs{});
+        } else {
+            if (int rc = set_lds(k_synth_comp_pair<32, false, -1, false, 15, 12, true>, lds_bytes_comp_pair<32>())) return rc;
+            hipLaunchKernelGGL((k_synth_comp_pair<32, false, -1, false, 15, 12, true>), pgrid, pblock, lds_bytes_comp_pair<32>(),
+                               s, mag, real, imag, noise, tb, per_v, ap_v, ap_u, (const RunDesc*)runs, slot_off, slot_runs,
+                               (int)n_slots, (const float*)tables, strips, pcm_out, (long long)ld, n_per, FuseArgs{});
+        }
+        MPX_HIP_CHECK(hipGetLastError());
+        return MPX_OK;
+    }
 #define MPX_LAUNCH_COMP(PP, LL)                                                                                        \
     do {                                                                                                             \
         if (int rc = set_lds(k_synth_comp_pair<PP, LL>, lds_bytes_comp_pair<PP>())) return rc;                       \
@@ -3218,6 +3296,36 @@ int mpx_synthesis_compressed_ola(void* stream, int fft_len, const void* tables, 
 #undef MPX_LAUNCH_COMP
     MPX_HIP_CHECK(hipGetLastError());
     return MPX_OK;
+}
+
+int mpx_synthesis_compressed_ola(void* stream, int fft_len, const void* tables, const float* mag, const float* real,
+                                 const float* imag, const float* noise, const int64_t* noise_pos,
+                                 const int32_t* noise_left, const int32_t* noise_right, const int32_t* noise_wtype,
+                                 const int32_t* voiced, const float* inv_gain, const int32_t* row0,
+                                 const int32_t* row1, const float* row_t, const int32_t* win_left,
+                                 const int32_t* win_right, const int32_t* pm_rel, const float* per_v,
+                                 const float* ap_v, const float* ap_u, const mpx_ola_run* runs, int32_t n_runs,
+                                 const int32_t* slot_off, const int32_t* slot_runs, int32_t n_slots,
+                                 float* strips, float* pcm_out, int64_t ld, int32_t n_per_bins) {
+    return synthesis_compressed_ola_impl(stream, fft_len, tables, mag, real, imag, noise, noise_pos, noise_left, noise_right,
+                                         noise_wtype, voiced, inv_gain, row0, row1, row_t, win_left, win_right, pm_rel, per_v,
+                                         ap_v, ap_u, runs, n_runs, slot_off, slot_runs, n_slots, strips, pcm_out, ld, n_per_bins, nullptr);
+}
+
+int mpx_synthesis_compressed_ola_spectra(void* stream, int fft_len, const void* tables, const float* mag, const float* real,
+                                 const float* imag, const float* noise, const int64_t* noise_pos,
+                                 const int32_t* noise_left, const int32_t* noise_right, const int32_t* noise_wtype,
+                                 const int32_t* voiced, const float* inv_gain, const int32_t* row0,
+                                 const int32_t* row1, const float* row_t, const int32_t* win_left,
+                                 const int32_t* win_right, const int32_t* pm_rel, const float* per_v,
+                                 const float* ap_v, const float* ap_u, const mpx_ola_run* runs, int32_t n_runs,
+                                 const int32_t* slot_off, const int32_t* slot_runs, int32_t n_slots,
+                                 float* strips, float* pcm_out, int64_t ld, int32_t n_per_bins, const float* spectra) {
+    if (!spectra && n_runs > 0 && n_slots > 0)
+        return fail(MPX_ERR_ARG, "mpx_synthesis_compressed_ola_spectra: null pointer%s");
+    return synthesis_compressed_ola_impl(stream, fft_len, tables, mag, real, imag, noise, noise_pos, noise_left, noise_right,
+                                         noise_wtype, voiced, inv_gain, row0, row1, row_t, win_left, win_right, pm_rel, per_v,
+                                         ap_v, ap_u, runs, n_runs, slot_off, slot_runs, n_slots, strips, pcm_out, ld, n_per_bins, spectra);
 }
 
 // ---- fused form: unwarp + synthesis in one launch (k_synth_comp_pair<32, false, 8, true, KTM, KTP>) ----

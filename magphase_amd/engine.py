@@ -1484,6 +1484,8 @@ class CompressedSynthesisPlan:
         # staged pair mpx_mel_unwarp[_rows] -> mpx_synthesis_compressed_ola (1.20 vs 0.90 ms per 57 k frames, the same HBM
         # traffic: docs/LAB_NOTES.md, "Round 5: the fused synthesis side"), so the staged pair stays the default.
         self.fused = False
+        # "noise spectra once" (opt-in): see run()
+        self.noise_spectra = os.environ.get("MAGPHASE_NOISE_SPECTRA", "recompute") == "store"
         want_fused = (os.environ.get("MAGPHASE_SYNTH_FUSED", "0") == "1") if fused is None else bool(fused)
         if (want_fused and per_phase_type == "magphase" and self.n_runs > 0
                 and hasattr(e.lib, "mpx_synth_fused_ksteps") and 0 < self.n_per <= 512):
@@ -1652,9 +1654,23 @@ class CompressedSynthesisPlan:
                 mark("k_mel_unwarp_mfma")
             # (the noise chain is independent of the unwarp, but a second HIP stream does not help: measured 3.13 vs
             # 3.18 ms per step with 12-wave and 3.15 vs 3.16 with 8-wave noise workgroups -- the two grids do not co-run)
-            _lib.check(lib.mpx_noise_stats(st, N, tab.data_ptr(), self.noise.data_ptr(), self.npos.data_ptr(),
-                                           self.nleft.data_ptr(), self.nright.data_ptr(), self.wtype.data_ptr(),
-                                           self.total_frames, sums.data_ptr()), "mpx_noise_stats")
+            # "noise spectra once" (opt-in, MAGPHASE_NOISE_SPECTRA=store; N = 4096, staged unwarp): the statistics launch
+            # stores every frame's noise spectrum and the synthesis launch loads it instead of a second transform --
+            # 17.4 KB per frame each way for the arithmetic of one forward FFT (measured: docs/LAB_NOTES.md, round 5)
+            nspec = None
+            if not fused and N == 4096 and self.total_frames > 0 and self.noise_spectra:
+                nspec = buf.get("nspec")
+                if nspec is None:
+                    nspec = buf["nspec"] = e.empty((int(lib.mpx_noise_spectra_floats(N, self.total_frames)),))
+            if nspec is not None:
+                _lib.check(lib.mpx_noise_stats_spectra(st, N, tab.data_ptr(), self.noise.data_ptr(), self.npos.data_ptr(),
+                                                       self.nleft.data_ptr(), self.nright.data_ptr(),
+                                                       self.wtype.data_ptr(), self.total_frames, sums.data_ptr(),
+                                                       nspec.data_ptr()), "mpx_noise_stats_spectra")
+            else:
+                _lib.check(lib.mpx_noise_stats(st, N, tab.data_ptr(), self.noise.data_ptr(), self.npos.data_ptr(),
+                                               self.nleft.data_ptr(), self.nright.data_ptr(), self.wtype.data_ptr(),
+                                               self.total_frames, sums.data_ptr()), "mpx_noise_stats")
             mark("k_noise_stats")
             # two gains per utterance (Q10): float64 reduction on the device, no host round trip
             self._gains_dev = buf["gains"]
@@ -1693,15 +1709,19 @@ class CompressedSynthesisPlan:
                 e.ola_fixup(N, self, strips, pcm)
                 mark("k_ola_fixup")
                 return pcm
-            _lib.check(lib.mpx_synthesis_compressed_ola(
+            ola_args = (
                 st, N, tab.data_ptr(), mag.data_ptr(), real.data_ptr(), imag.data_ptr(), self.noise.data_ptr(),
                 self.npos.data_ptr(), self.nleft.data_ptr(), self.nright.data_ptr(), self.wtype.data_ptr(),
                 self.voiced.data_ptr(), inv_gain.data_ptr(), None, None, None,
                 self.win_l.data_ptr(), self.win_r.data_ptr(), self.pm_rel.data_ptr(),
                 self.per_v.data_ptr(), self.ap_v.data_ptr(), self.ap_u.data_ptr(), self.runs.data_ptr(),
                 self.n_runs, self.slot_off.data_ptr(), self.slot_runs.data_ptr(), self.n_slots,
-                strips.data_ptr(), pcm.data_ptr(), ld, self.n_per if self.per_phase_type == "magphase" else 0),
-                "mpx_synthesis_compressed_ola")
+                strips.data_ptr(), pcm.data_ptr(), ld, self.n_per if self.per_phase_type == "magphase" else 0)
+            if nspec is not None:
+                _lib.check(lib.mpx_synthesis_compressed_ola_spectra(*ola_args, nspec.data_ptr()),
+                           "mpx_synthesis_compressed_ola_spectra")
+            else:
+                _lib.check(lib.mpx_synthesis_compressed_ola(*ola_args), "mpx_synthesis_compressed_ola")
             mark("k_synth_comp_pair")
         e.ola_fixup(N, self, strips, pcm)
         mark("k_ola_fixup")

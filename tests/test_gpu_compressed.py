@@ -770,3 +770,56 @@ def test_fused_unwarp_synthesis_matches_reference_golden_and_staged(mp, orc, gol
         outs[fused] = plan.run().cpu().numpy().astype(np.float64)
     peak = np.max(np.abs(outs[False]))
     within(np.max(np.abs(outs[True] - outs[False])) / peak, COMP_PCM_TOL, "COMP_PCM_TOL:fused_vs_staged")
+
+
+def test_stored_noise_spectra_matches_reference_golden_and_recomputed(mp, orc, golden_dir, monkeypatch):
+    """mpx_noise_stats_spectra + mpx_synthesis_compressed_ola_spectra (opt-in, MAGPHASE_NOISE_SPECTRA=store): every noise
+    frame is transformed once, its spectrum stored by the statistics launch and loaded by the synthesis launch
+    (magphase.py:886-903, :908-976).  Against the reference's golden outputs (variable rate G5, constant rate G8), the
+    oracle at low pitch (noise frames longer than one staging tile) and the default (recomputing) pair on a batch."""
+    from magphase_amd import engine as em
+
+    g, mm, rr, ii, lf = _hvd704(golden_dir)
+    eng = em.get_engine()
+    rng = np.random.RandomState(5)
+    utts = []
+    for u in range(6):
+        n = min(mm.shape[0] - 1, 150 + 37 * u)
+        a = rng.randint(0, mm.shape[0] - n)
+        utts.append((mm[a:a + n], rr[a:a + n], ii[a:a + n], lf[a:a + n]))
+    np.random.seed(11)
+    plan = em.CompressedSynthesisPlan(eng, utts, 48000, b_const_rate=True, fused=False, frames_per_run=23)
+    base = plan.run().cpu().numpy().astype(np.float64)
+    assert plan._buf.get("nspec") is None
+
+    monkeypatch.setenv("MAGPHASE_NOISE_SPECTRA", "store")
+    np.random.seed(11)
+    plan = em.CompressedSynthesisPlan(eng, utts, 48000, b_const_rate=True, fused=False, frames_per_run=23)
+    got = plan.run().cpu().numpy().astype(np.float64)
+    assert plan._buf.get("nspec") is not None     # the stored form really ran
+    within(np.max(np.abs(got - base)) / np.max(np.abs(base)), COMP_PCM_TOL, "COMP_PCM_TOL:nspec_vs_recomputed")
+
+    seed = int(g["seed"])
+    pf = mp.post_filter(mm, 48000)
+    np.random.seed(seed)
+    v = mp.synthesis_from_compressed(pf, rr, ii, lf, 48000, b_out_hpf=False)
+    ref = g["syn_pf_hpf0"]
+    assert len(v) == len(ref)
+    within(np.max(np.abs(v - ref)) / np.max(np.abs(ref)), COMP_PCM_TOL, "COMP_PCM_TOL:nspec_var")
+    g8 = np.load(os.path.join(golden_dir, "g8_compressed_analysis.npz"))
+    np.random.seed(int(g8["cr45_seed"]))
+    v = mp.synthesis_from_compressed(g8["cr45_mag"], g8["cr45_real"], g8["cr45_imag"], g8["cr45_lf0"], int(g8["fs"]),
+                                     b_const_rate=True, b_out_hpf=False)
+    ref = g8["cr45_syn"]
+    assert len(v) == len(ref)
+    within(np.max(np.abs(v - ref)) / np.max(np.abs(ref)), COMP_PCM_TOL, "COMP_PCM_TOL:nspec_const")
+    for f0 in (55.0, 400.0):
+        lf2 = np.where(lf > 0.0, np.log(f0), lf)[:80]
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            np.random.seed(3)
+            v = mp.synthesis_from_compressed(mm[:80], rr[:80], ii[:80], lf2, 48000, b_const_rate=True)
+            np.random.seed(3)
+            ref = orc.synthesis_from_compressed(mm[:80], rr[:80], ii[:80], lf2, 48000, b_const_rate=True)
+        assert v.shape == ref.shape
+        within(np.max(np.abs(v - ref)) / max(1.0, np.max(np.abs(ref))), COMP_PCM_TOL, "COMP_PCM_TOL:nspec_f0")
