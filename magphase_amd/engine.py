@@ -1298,7 +1298,9 @@ class CompressedSynthesisPlan:
 
     def __init__(self, engine, utts, fs, fft_len=None, b_voi_ap_win=True, b_const_rate=False, alpha_phase=None,
                  noise=None, frames_per_run=None, per_phase_type="magphase", post_filter=False, b_fbank_mel=False,
-                 noise_mode="reference", noise_seeds=None, defer_rng=False, fused=None):
+                 noise_mode="reference", noise_seeds=None, defer_rng=False, fused=None, noise_spectra=None):
+        # noise_spectra: None = MAGPHASE_NOISE_SPECTRA ("recompute", the default / "store"); True: every noise frame is
+        #            transformed once, its spectrum kept in HBM between the statistics and the synthesis launch (N = 4096)
         # defer_rng: the reference noise stream's advanced state stays on the device (Engine.numpy_global_uniform(defer=True));
         #            the caller owes Engine.mt_sync() before numpy's global generator is used again
         # post_filter: False / True ('magphase': mp.post_filter on the device) / 'merlin' (mp.post_filter_merlin on the device)
@@ -1485,7 +1487,8 @@ class CompressedSynthesisPlan:
         # traffic: docs/LAB_NOTES.md, "Round 5: the fused synthesis side"), so the staged pair stays the default.
         self.fused = False
         # "noise spectra once" (opt-in): see run()
-        self.noise_spectra = os.environ.get("MAGPHASE_NOISE_SPECTRA", "recompute") == "store"
+        self.noise_spectra = ((os.environ.get("MAGPHASE_NOISE_SPECTRA", "recompute") == "store")
+                              if noise_spectra is None else bool(noise_spectra))
         want_fused = (os.environ.get("MAGPHASE_SYNTH_FUSED", "0") == "1") if fused is None else bool(fused)
         if (want_fused and per_phase_type == "magphase" and self.n_runs > 0
                 and hasattr(e.lib, "mpx_synth_fused_ksteps") and 0 < self.n_per <= 512):
