@@ -322,7 +322,7 @@ def pick_streams(n, enqueue, steps=24, tries=1):
     return chosen, report
 
 
-def measure_lowdim(eng, utts, steps, warmup, live=None, live_src=None, n_streams=1, streams=None):
+def measure_lowdim(eng, utts, steps, warmup, live=None, live_src=None, n_streams=1, streams=None, side_forms=True):
     import torch
 
     from magphase_amd import engine as em
@@ -443,7 +443,8 @@ def measure_lowdim(eng, utts, steps, warmup, live=None, live_src=None, n_streams
     # "noise spectra once" (opt-in, MAGPHASE_NOISE_SPECTRA=store): the synthesis side of the same step in both forms,
     # interleaved in this process (HIP events, one launch chain at a time); skipped when the run itself is in that form
     nso = None
-    if not getattr(splan, "noise_spectra", False) and hasattr(eng.lib, "mpx_noise_stats_spectra"):
+    # (not in profiling runs, --traffic none: rocprofv3's per-kernel averages are to be those of the default form)
+    if side_forms and not getattr(splan, "noise_spectra", False) and hasattr(eng.lib, "mpx_noise_stats_spectra"):
         try:
             saved = os.environ.get("MAGPHASE_NOISE_SPECTRA")
             os.environ["MAGPHASE_NOISE_SPECTRA"] = "store"
@@ -1315,7 +1316,8 @@ def main():
                                                "frames/s")
         if full:
             try:
-                c2 = measure_lowdim(eng, utts, 50, 3, live=live, live_src=live_src, n_streams=n_streams, streams=streams)
+                c2 = measure_lowdim(eng, utts, 50, 3, live=live, live_src=live_src, n_streams=n_streams, streams=streams,
+                                    side_forms=(args.traffic != "none"))
                 if not args.no_cpu_baseline:
                     c2["cpu_baseline"] = cpu_baseline(
                         utts, _cpu_lowdim, "configs[2] (analysis_compressed at constant rate -> post_filter -> "
