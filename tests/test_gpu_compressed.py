@@ -823,3 +823,27 @@ def test_stored_noise_spectra_matches_reference_golden_and_recomputed(mp, orc, g
             ref = orc.synthesis_from_compressed(mm[:80], rr[:80], ii[:80], lf2, 48000, b_const_rate=True)
         assert v.shape == ref.shape
         within(np.max(np.abs(v - ref)) / max(1.0, np.max(np.abs(ref))), COMP_PCM_TOL, "COMP_PCM_TOL:nspec_f0")
+    # the other periodic-phase branches run the kernel's any-crossfade instantiation (all bins may carry a periodic part)
+    np.random.seed(seed)
+    v = mp.synthesis_from_compressed(mm, rr, ii, lf, 48000, per_phase_type="min_phase")
+    ref = g["syn_nopf_minphase"]
+    assert len(v) == len(ref)
+    within(np.max(np.abs(v - ref)) / np.max(np.abs(ref)), COMP_PCM_TOL, "COMP_PCM_TOL:nspec_minphase")
+    np.random.seed(4)
+    v = mp.synthesis_from_compressed(mm, rr, ii, lf, 48000, per_phase_type="linear", b_out_hpf=False)
+    np.random.seed(4)
+    ref = orc.synthesis_from_compressed(mm, rr, ii, lf, 48000, per_phase_type="linear", b_out_hpf=False)
+    assert len(v) == len(ref)
+    within(np.max(np.abs(v - ref)) / np.max(np.abs(ref)), COMP_PCM_TOL, "COMP_PCM_TOL:nspec_linear")
+    # FFT lengths other than 4096 keep the recomputing pair (no stored form there): same call, same result as the oracle
+    from magphase_amd import synthetic as syn
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        pcm, pm, voi = syn.make_utterance(90, dur_s=0.6, fs=16000)
+        f = orc.analysis_compressed_from_epochs(syn.pcm_to_float(pcm), 16000, pm, voi, mag_dim=60, phase_dim=45)[:4]
+        np.random.seed(21)
+        ref = orc.synthesis_from_compressed(f[0], f[1], f[2], f[3], 16000)
+        np.random.seed(21)
+        v = mp.synthesis_from_compressed(f[0], f[1], f[2], f[3], 16000)
+    assert len(v) == len(ref)
+    within(np.max(np.abs(v - ref)) / np.max(np.abs(ref)), COMP_PCM_TOL, "COMP_PCM_TOL:nspec_16k")
