@@ -603,6 +603,30 @@ int64_t mpx_host_plan_analysis(int32_t n_utts, const double* pm_sec, const doubl
                                int64_t* pm_out, int64_t* left, int64_t* right, double* f0, int64_t* frame_off);
 
 /*
+ * mpx_host_plan_analysis_batch: the WHOLE host side of a lossless / compressed analysis launch in one call, the utterances
+ * given by pointer (nothing is concatenated by the caller), on n_threads threads -- what the reference does once per
+ * utterance in its Pool worker (libutils.py:32-63; scripts/batch_feature_extraction_for_tts.py:40-57):
+ *   - the samples of all utterances copied into `stage`, the page-locked buffer the H2D DMA reads (stage_kind 0: every
+ *     utterance is int16, staged as int16 and widened on the device by mpx_pcm16_to_f32; 1: float32, int16 * 2^-15 /
+ *     float64 rounded to nearest even; pcm_kind[u] 0 int16, 1 float32, 2 float64; stage may be null: no copy);
+ *   - mpx_host_plan_analysis' arithmetic per utterance (libaudio.py:435-447, magphase.py:77-98, :2198-2207) with the device
+ *     tables written in their final types: pos int64, left32 / right32 int32, voi32 float32 (f0 > 0; may be null);
+ *   - host results: pm, left64 (the reference's v_shift), f0, f0_med = scipy.signal.medfilt(f0) per utterance (kernel 3,
+ *     zero-padded; magphase.py:2499-2500; may be null), frame_off [n_utts + 1];
+ *   - frames longer than fft_len (the reference warns once per such frame, magphase.py:311-315): their global frame index
+ *     and length in long_frame / long_len (capacity long_cap), their number in *n_long_out (fft_len <= 0: not looked for).
+ * Every per-frame output has capacity sum(n_epochs).  Returns the number of frames, -(u + 2) for the first utterance the
+ * numpy form raises on (no epochs), -1 for bad arguments.
+ */
+int64_t mpx_host_plan_analysis_batch(int32_t n_utts, const void* const* pcm, const int32_t* pcm_kind,
+                                     const int64_t* n_smpls, const double* fs, const double* const* pm_sec,
+                                     const double* const* voi, const int64_t* n_epochs, void* stage, int32_t stage_kind,
+                                     int64_t* pos, int32_t* left32, int32_t* right32, float* voi32, int64_t* pm_out,
+                                     int64_t* left64, double* f0, double* f0_med, int64_t* frame_off, int32_t fft_len,
+                                     int64_t* long_frame, int64_t* long_len, int64_t long_cap, int64_t* n_long_out,
+                                     int32_t n_threads);
+
+/*
  * mpx_host_plan_synthesis: the per-utterance part of synthesis_from_compressed before any spectrum (magphase.py:846-848
  * f0 -> voicing / shifts, :861-868 constant -> variable rate via mpx_host_const_to_var_scan, :879-882 epochs and noise
  * length, :77-98 noise frame bounds, :969-973 anti-ringing window lengths, :34-62 OLA offsets).  f0 = exp(lf0) of the
@@ -636,6 +660,37 @@ int64_t mpx_host_plan_lossless_synthesis(int32_t n_utts, const double* f0, const
 int64_t mpx_host_ola_runs(int32_t n_utts, const int64_t* pm_rel, const int64_t* frame_off, const int64_t* starts,
                           const int64_t* out_lens, const int64_t* out_offs, int32_t fft_len, const int64_t* gcuts,
                           int64_t n_gcuts, mpx_ola_run* runs, int64_t cap_runs);
+
+/*
+ * mpx_host_plan_synthesis_batch: the whole host side of a compressed-feature synthesis launch (what the reference does per
+ * utterance in scripts/batch_waveform_generation.py:28-58 -> magphase.py:3229-3275 -> :836-897, :969-976), utterances by
+ * pointer, on n_threads threads:
+ *   - the coefficient matrices (kind[u] 1 float32 / 2 float64, C-contiguous [n_rows[u] x mag_dim | phase_dim]) copied /
+ *     narrowed into `stage` (page-locked, float32) as [R x mag_dim | R x phase_dim | R x phase_dim], R = sum n_rows; null:
+ *     no copy;
+ *   - mpx_host_plan_synthesis' arithmetic per utterance on f0 = exp(lf0) (concatenated, evaluated by the caller with
+ *     numpy's exp), mpx_host_ola_runs over n_slots slots (wcum / wsum: np.concatenate(([0.], np.cumsum(w))) and w.sum() of
+ *     the slots' float64 weights, null = equal shares), the slots' work lists and, with want_tiles, the frames of every
+ *     31-row tile of the coefficient matrix (mpx_mel_unwarp_rows);
+ *   - every device table written in its final type into `desc` (page-locked; one H2D copy), table k at byte offset
+ *     desc_off[k], 256-byte aligned, in this order: utt_frame_off i32[U+1], npos i64[F], nleft, nright, wtype, voiced i32[F],
+ *     tile_first i32[tiles+1], row0, row1 i32[F], rowt f32[F], win_l, win_r, pm_rel i32[F], out_start i32[U], out_off
+ *     i64[U+1], runs (mpx_ola_run[n_runs]), slot_off i32[slots+1], slot_runs i32[n_runs]      (desc_off: int64[18]);
+ *   - host results: v_shift, v_pm (int64), voiced_host (int32) with capacity 2 R + 2 U; frame_off [U+1]; ns_len, out_start,
+ *     out_len [U]; runs_host (capacity runs_cap >= U + n_slots + 1);
+ *     counts[8] = {frames, runs, slots in use, bytes of desc in use, noise samples, output samples, tiles + 1, R}.
+ * Returns the number of frames; -(u + 2): the numpy form raises on utterance u; <= -1000000: a capacity / table-order /
+ * slot-count case left to the numpy form; -1: bad arguments.
+ */
+int64_t mpx_host_plan_synthesis_batch(int32_t n_utts, const void* const* mag, const void* const* real,
+                                      const void* const* imag, const int32_t* kind, const int64_t* n_rows,
+                                      int32_t mag_dim, int32_t phase_dim, float* stage, const double* f0, double fs,
+                                      int32_t fft_len, int32_t b_const_rate, int32_t b_voi_ap_win, int32_t n_slots,
+                                      const double* wcum, double wsum, int32_t want_tiles, uint8_t* desc,
+                                      int64_t desc_cap, int64_t* desc_off, int64_t* v_shift, int64_t* v_pm,
+                                      int32_t* voiced_host, int64_t* frame_off, int64_t* ns_len, int64_t* out_start,
+                                      int64_t* out_len, mpx_ola_run* runs_host, int64_t runs_cap, int64_t* counts,
+                                      int32_t n_threads);
 
 /* dst[i] = (double)src[i], i < n, on a few threads: the float32 -> float64 widening of the array API's outputs (the
  * reference's arrays are float64, magphase.py:457-476; numpy's astype is one thread at ~1.5 GB/s). */

@@ -56,7 +56,9 @@ SYMBOLS = (
     "mpx_synthesis_compressed_fused",
     "mpx_host_const_to_var_scan",
     "mpx_host_plan_analysis",
+    "mpx_host_plan_analysis_batch",
     "mpx_host_plan_synthesis",
+    "mpx_host_plan_synthesis_batch",
     "mpx_host_plan_lossless_synthesis",
     "mpx_host_ola_runs",
     "mpx_host_widen_f32",
@@ -213,6 +215,11 @@ def _load_locked():
     lib.mpx_host_plan_synthesis.argtypes = [i32, vp, vp, ctypes.c_double, i32, i32, i32, i64] + [vp] * 17
     lib.mpx_host_plan_lossless_synthesis.restype = i64
     lib.mpx_host_plan_lossless_synthesis.argtypes = [i32, vp, vp, vp, i32, vp, vp, vp, vp]
+    lib.mpx_host_plan_analysis_batch.restype = i64
+    lib.mpx_host_plan_analysis_batch.argtypes = [i32] + [vp] * 7 + [vp, i32] + [vp] * 9 + [i32, vp, vp, i64, vp, i32]
+    lib.mpx_host_plan_synthesis_batch.restype = i64
+    lib.mpx_host_plan_synthesis_batch.argtypes = ([i32] + [vp] * 5 + [i32, i32, vp, vp, ctypes.c_double, i32, i32, i32, i32,
+                                                   vp, ctypes.c_double, i32, vp, i64] + [vp] * 9 + [i64, vp, i32])
     lib.mpx_host_ola_runs.restype = i64
     lib.mpx_host_ola_runs.argtypes = [i32, vp, vp, vp, vp, vp, i32, vp, i64, vp, i64]
     lib.mpx_host_narrow_f64.restype = i32

@@ -27,8 +27,13 @@ UNITS = ["magphase_hip.hip", "magphase_comp.hip", "magphase_f64.hip", "magphase_
 SRCS = [os.path.join(CSRC, u) for u in UNITS]
 SRC = SRCS[0]
 HEADERS = [os.path.join(CSRC, "wave_fft.hpp"), os.path.join(CSRC, "wave_fft_f64.hpp"),
-           os.path.join(CSRC, "mpx_common.hpp"), os.path.join(os.path.dirname(HERE), "include", "magphase_hip.h")]
-DEPS = SRCS + HEADERS
+           os.path.join(CSRC, "mpx_common.hpp"), os.path.join(CSRC, "host_pool.hpp"),
+           os.path.join(os.path.dirname(HERE), "include", "magphase_hip.h")]
+# The marshalling layer of the batch API (csrc/magphase_pyhost.cpp): a CPython extension beside the C-ABI library, linked
+# against it.  It needs Python.h; where that is missing the batch API marshals in Python (slower, same results).
+PYHOST_SRC = os.path.join(CSRC, "magphase_pyhost.cpp")
+PYHOST = os.path.join(HERE, "_mpx_pyhost.so")
+DEPS = SRCS + HEADERS + [PYHOST_SRC]
 LIB = os.path.join(HERE, "libmagphase_hip.so")
 OBJ_DIR = os.path.join(HERE, "_obj")
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fno-slp-vectorize", "-Wno-inline-asm", "-fPIC", "-pthread"]
@@ -44,7 +49,32 @@ def is_stale():
     if not os.path.isfile(LIB):
         return True
     t = os.path.getmtime(LIB)
-    return any(os.path.getmtime(d) > t for d in DEPS)
+    if any(os.path.getmtime(d) > t for d in DEPS):
+        return True
+    return _python_include() is not None and (not os.path.isfile(PYHOST) or os.path.getmtime(PYHOST) < t)
+
+
+def _python_include():
+    import sysconfig
+
+    inc = sysconfig.get_paths().get("include")
+    return inc if inc and os.path.isfile(os.path.join(inc, "Python.h")) else None
+
+
+def build_pyhost(lib, verbose=True):
+    """_mpx_pyhost.so next to `lib` (linked against it, found through $ORIGIN); None when Python.h is not installed."""
+    inc = _python_include()
+    if inc is None:
+        if verbose:
+            print("magphase_amd.build: no Python.h: _mpx_pyhost not built (the batch API marshals in Python)", flush=True)
+        return None
+    out = os.path.join(os.path.dirname(lib), "_mpx_pyhost.so")
+    cmd = [shutil.which("g++") or "g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I" + inc, PYHOST_SRC, "-o", out,
+           "-L" + os.path.dirname(lib), "-l:" + os.path.basename(lib), "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return out
 
 
 def _obj_for(src, extra_flags):
@@ -91,6 +121,8 @@ def build(force=False, verbose=True, extra_flags=(), out=None):
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
+    if out is None:
+        build_pyhost(lib, verbose=verbose)
     last_action = "compiled %d of %d units, linked" % (len(todo), len(SRCS))
     if verbose:
         print("magphase_amd.build: %s: %s" % (last_action, lib), flush=True)

@@ -548,6 +548,233 @@ class Engine:
             st["events"][st["cur"]] = ev
         return t
 
+    # ------------------------------------------------------------------ prepared launches (native planners, planner thread)
+    def host_threads(self, nbytes=0):
+        """Native threads one staging pass of `nbytes` may use: MAGPHASE_IO_NATIVE_THREADS, or 8 (32 from 16 MB up: launches of
+        100+ utterances), never more than the cores this process may run on (sharding.bind_rank_to_cores gives every rank of
+        a node its own share -- the reference's model is one worker per core with nothing shared, libutils.py:61-62)."""
+        env = os.environ.get("MAGPHASE_IO_NATIVE_THREADS")
+        want = int(env) if env else (32 if nbytes >= (16 << 20) else 8)
+        try:
+            cores = len(os.sched_getaffinity(0))
+        except (AttributeError, OSError):
+            cores = os.cpu_count() or 1
+        return max(1, min(want, cores))
+
+    _N_SLOTS = 3
+
+    def _slot_acquire(self, stage_bytes, desc_bytes, wait=True):
+        """One of the engine's sets of page-locked buffers (sample / coefficient staging + table image) for a prepared launch;
+        blocks while all are in use (wait=False: returns None instead -- a plan constructor that prepares its own launch must
+        not wait for slots that launches prepared AHEAD of it hold: they are committed after it).  A slot is handed out again
+        only after the H2D copies out of it have completed."""
+        import queue
+
+        torch = _torch()
+        pool = getattr(self, "_slots", None)
+        if pool is None:
+            import threading
+
+            with self.__dict__.setdefault("_slots_lock", threading.Lock()):
+                pool = getattr(self, "_slots", None)
+                if pool is None:
+                    pool = queue.SimpleQueue()
+                    for _ in range(self._N_SLOTS):
+                        pool.put({"stage": None, "desc": None, "event": None})
+                    self._slots = pool
+        try:
+            slot = pool.get(block=bool(wait))
+        except queue.Empty:
+            return None
+        try:
+            if slot["event"] is not None:
+                slot["event"].synchronize()
+                slot["event"] = None
+            with torch.cuda.device(self.device):
+                for key, need in (("stage", int(stage_bytes)), ("desc", int(desc_bytes))):
+                    cur = slot[key]
+                    if cur is None or cur.numel() < need:   # grown with headroom: page-locking is slow (40 ms per 30 MB)
+                        slot[key] = None
+                        slot[key] = torch.empty(max(int(need * 1.5), 1 << 20), dtype=torch.uint8).pin_memory()
+                        slot[key + "_np"] = slot[key].numpy()
+        except BaseException:
+            pool.put(slot)
+            raise
+        return slot
+
+    def _slot_release(self, slot, event=None):
+        slot["event"] = event
+        self._slots.put(slot)
+
+    def _slot_upload(self, slot, stage_bytes, desc_bytes):
+        """The first stage_bytes / desc_bytes of the slot's two buffers -> device uint8 tensors (two DMAs on the upload stream);
+        the slot goes back to the pool guarded by the copies' event.  Returns (stage_dev, desc_dev, ready event)."""
+        torch = _torch()
+        up = self.copy_stream("up")
+        with torch.cuda.device(self.device):
+            cur = torch.cuda.current_stream(self.device)
+            ctx = torch.cuda.stream(up) if up is not None else None
+            if ctx is not None:
+                ctx.__enter__()
+            try:
+                sd = slot["stage"][:max(int(stage_bytes), 1)].to(self.device, non_blocking=True)
+                dd = slot["desc"][:max(int(desc_bytes), 1)].to(self.device, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(up if up is not None else cur)
+            finally:
+                if ctx is not None:
+                    ctx.__exit__(None, None, None)
+            if up is not None:
+                cur.wait_event(ev)
+                sd.record_stream(cur), dd.record_stream(cur)
+        self._slot_release(slot, ev)
+        return sd, dd, ev
+
+    def planner(self):
+        """The engine's planner thread (one): prepare_* calls for launch i + 1 run here while the calling thread enqueues
+        launch i -- the native planners release the interpreter lock.  MAGPHASE_PLANNER_THREAD=0: inline."""
+        import concurrent.futures as cf
+
+        ex = getattr(self, "_planner", None)
+        if ex is None:
+            ex = self._planner = cf.ThreadPoolExecutor(max_workers=1, thread_name_prefix="mpx-plan")
+        return ex
+
+    def prepare_async(self, kind, *args, **kw):
+        """Future of prepare_analysis / prepare_synthesis (kind 'analysis' / 'synthesis') on the planner thread."""
+        import concurrent.futures as cf
+
+        fn = self.prepare_analysis if kind == "analysis" else self.prepare_synthesis
+        if os.environ.get("MAGPHASE_PLANNER_THREAD", "1") == "0":
+            f = cf.Future()
+            try:
+                f.set_result(fn(*args, **kw))
+            except BaseException as exc:   # noqa: B902 -- delivered by result()
+                f.set_exception(exc)
+            return f
+        return self.planner().submit(fn, *args, **kw)
+
+    def prepare_analysis(self, utts, fft_len=None, wait=True):
+        """The host side of an analysis launch (LosslessAnalysisPlan / CompressedAnalysisPlan) without touching a stream:
+        utterance list walked in native code, samples staged into a page-locked slot, frame tables written in their device
+        types (mpx_host_plan_analysis_batch), f0 and its median-3 on the host.  Returns a PreparedAnalysis, or None when
+        the batch is not in the plain shape the native path handles (the plan constructor then takes the generic path,
+        which converts -- or raises what the reference's arithmetic raises)."""
+        ph = hostplan.pyhost()
+        if ph is None or not utts:
+            return None
+        m = ph.analysis_marshal(utts)
+        if m is None:
+            return None
+        U, total, E, all_i16 = ph.analysis_info(m)
+        fs_list = [u[1] for u in utts]
+        N = None
+        for fs in set(fs_list):
+            n_ = fft_len if fft_len is not None else hm.define_fft_len(fs)
+            if N is not None and n_ != N:
+                return None    # the generic path raises "all utterances of a plan must share fft_len"
+            N = n_
+        if E <= 0 or total <= 0:
+            return None
+        stage_bytes = (2 * total + 8) if all_i16 else 4 * total
+        a256 = lambda n: (int(n) + 255) // 256 * 256   # noqa: E731
+        o_pos, o_left, o_right, o_voi = 0, a256(8 * E), a256(8 * E) + a256(4 * E), a256(8 * E) + 2 * a256(4 * E)
+        desc_bytes = o_voi + a256(4 * E)
+        slot = self._slot_acquire(stage_bytes, desc_bytes, wait=wait)
+        if slot is None:
+            return None
+        try:
+            d = slot["desc_np"]
+            pm, left64, f0, f0_med = (np.empty(E, dtype=np.int64), np.empty(E, dtype=np.int64), np.empty(E), np.empty(E))
+            frame_off = np.empty(U + 1, dtype=np.int64)
+            long_f, long_l = np.empty(512, dtype=np.int64), np.empty(512, dtype=np.int64)
+            F, n_long = ph.analysis_run(m, slot["stage"].data_ptr(), 0 if all_i16 else 1, d[o_pos:o_pos + 8 * E],
+                                        d[o_left:o_left + 4 * E], d[o_right:o_right + 4 * E], d[o_voi:o_voi + 4 * E], pm,
+                                        left64, f0, f0_med, frame_off, int(N), long_f, long_l,
+                                        self.host_threads(stage_bytes))
+            if F < 0 or n_long > 512:
+                self._slot_release(slot)
+                return None
+        except BaseException:
+            self._slot_release(slot)
+            raise
+        p = PreparedAnalysis()
+        p.engine, p.slot, p.n_utts, p.fs, p.fft_len = self, slot, U, fs_list, int(N)
+        p.total_smpls, p.total_frames, p.all_i16 = int(total), int(F), bool(all_i16)
+        p.stage_bytes, p.desc_bytes, p.cap = stage_bytes, desc_bytes, int(E)
+        p.offs = (o_pos, o_left, o_right, o_voi)
+        p.frame_off, p.pm, p.left64, p.f0, p.f0_med = frame_off, pm[:F], left64[:F], f0[:F], f0_med[:F]
+        p.long = [(int(long_f[k]), int(long_l[k])) for k in range(int(n_long))]
+        return p
+
+    def _comp_slot_shares(self):
+        """(slots of the compressed synthesis kernel, np.concatenate(([0], cumsum(w))), w.sum()) of their float64 weights --
+        what mpx_host_plan_synthesis_batch deals the frames by (hostmath.slot_cuts' operands, evaluated by numpy once)."""
+        w = self.synth_ola_slot_weights(comp=True)
+        n = self.host_constant("comp_slots_n", self.synth_comp_slots)
+        if w is None:
+            return n, None, 0.0
+        key = ("comp_shares", id(w))
+        if key not in self._tables:
+            w64 = np.asarray(w, dtype=np.float64)[:n]
+            self._tables[key] = (np.ascontiguousarray(np.concatenate(([0.0], np.cumsum(w64)))), float(w64.sum()))
+        return (n,) + self._tables[key]
+
+    def prepare_synthesis(self, utts, fs, fft_len=None, b_voi_ap_win=True, b_const_rate=False, wait=True):
+        """The host side of a compressed-feature synthesis launch (CompressedSynthesisPlan) without touching a stream:
+        coefficient rows staged into a page-locked slot, every device table written in its final type
+        (mpx_host_plan_synthesis_batch).  Returns a PreparedSynthesis, or None when the batch is not in the plain shape the
+        native path handles or the numpy form would raise (the plan constructor then takes the generic path)."""
+        ph = hostplan.pyhost()
+        if ph is None or not utts:
+            return None
+        m = ph.synthesis_marshal(utts)
+        if m is None:
+            return None
+        U, R, mag_dim, phase_dim = ph.synthesis_info(m)
+        if R <= 0 or R >= (1 << 30):
+            return None
+        N = int(fft_len) if fft_len else hm.define_fft_len(fs)
+        f0 = np.empty(R)
+        ph.synthesis_lf0(m, f0)
+        np.exp(f0, out=f0)                                               # magphase.py:846 (numpy's exp, as the array API)
+        n_slots, wcum, wsum = self._comp_slot_shares()
+        unwarp_rows = bool(b_const_rate) or os.environ.get("MAGPHASE_UNWARP_ROWS_VAR", "1") != "0"
+        stage_bytes = 4 * R * (mag_dim + 2 * phase_dim)
+        desc_cap = hostplan.synth_desc_bytes(R, U, n_slots, True)
+        cap = 2 * R + 2 * U
+        slot = self._slot_acquire(stage_bytes, desc_cap, wait=wait)
+        if slot is None:
+            return None
+        try:
+            v_shift, v_pm = np.empty(cap, dtype=np.int64), np.empty(cap, dtype=np.int64)
+            voiced_host = np.empty(cap, dtype=np.int32)
+            frame_off = np.empty(U + 1, dtype=np.int64)
+            ns_len, out_start, out_len = (np.empty(U, dtype=np.int64) for _ in range(3))
+            runs_host = np.zeros(U + n_slots + 1, dtype=hm.OLA_RUN_DTYPE)
+            counts, desc_off = np.zeros(8, dtype=np.int64), np.zeros(18, dtype=np.int64)
+            F = ph.synthesis_run(m, slot["stage"].data_ptr(), f0, float(fs), N, int(bool(b_const_rate)),
+                                 int(bool(b_voi_ap_win)), int(n_slots), wcum, float(wsum), int(unwarp_rows),
+                                 slot["desc_np"][:desc_cap], desc_off, v_shift, v_pm, voiced_host, frame_off, ns_len,
+                                 out_start, out_len, runs_host, counts, self.host_threads(stage_bytes))
+            if F < 0:
+                self._slot_release(slot)
+                return None
+        except BaseException:
+            self._slot_release(slot)
+            raise
+        p = PreparedSynthesis()
+        p.engine, p.slot = self, slot
+        p.key = (int(fs), N, bool(b_const_rate), bool(b_voi_ap_win), unwarp_rows)
+        p.n_utts, p.n_rows, p.mag_dim, p.phase_dim = int(U), int(R), int(mag_dim), int(phase_dim)
+        p.total_frames, p.n_runs, p.n_slots = int(F), int(counts[1]), int(counts[2])
+        p.stage_bytes, p.desc_bytes, p.n_tiles1 = stage_bytes, int(counts[3]), int(counts[6])
+        p.desc_off = desc_off
+        p.v_shift, p.v_pm, p.voiced_host = v_shift[:F], v_pm[:F], voiced_host[:F]
+        p.frame_off, p.ns_len, p.out_start, p.out_len = frame_off, ns_len, out_start, out_len
+        p.runs_host = runs_host[:p.n_runs]
+        return p
+
     def to_device_pinned(self, arr, dtype):
         """Host array -> device tensor through a page-locked copy (async H2D on the current stream)."""
         torch = _torch()
@@ -988,17 +1215,46 @@ class Engine:
         return pcm_out
 
 
+class _Prepared:
+    """Host side of one launch, built by Engine.prepare_* (possibly on the planner thread): page-locked slot filled, tables
+    ready; the plan constructor uploads it.  release(): hands the slot back when the launch is not going to happen."""
+    slot = None
+    engine = None
+
+    def release(self):
+        if self.slot is not None:
+            slot, self.slot = self.slot, None
+            self.engine._slot_release(slot)
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:
+            pass
+
+
+class PreparedAnalysis(_Prepared):
+    pass
+
+
+class PreparedSynthesis(_Prepared):
+    pass
+
+
 class _FlatRows:
     """A list of per-utterance rows kept as ONE array + offsets; iterating / indexing cuts the views."""
 
     def __init__(self, flat, off):
         self.flat, self.off = flat, np.asarray(off, dtype=np.int64)
+        self._o = self.off.tolist()
 
     def __len__(self):
-        return int(self.off.size - 1)
+        return len(self._o) - 1
 
     def __getitem__(self, u):
-        return self.flat[int(self.off[u]):int(self.off[u + 1])]
+        if u < 0:
+            u += len(self._o) - 1
+        return self.flat[self._o[u]:self._o[u + 1]]
 
     def __iter__(self):
         return (self[u] for u in range(len(self)))
@@ -1058,8 +1314,15 @@ class LosslessAnalysisPlan:
     Host math follows magphase.py:2877-2879 (pm_sec*fs), libaudio.py:435-447, magphase.py:77-98, :2198-2199.
     """
 
-    def __init__(self, engine, utts, fft_len=None):
+    def __init__(self, engine, utts, fft_len=None, prepared=None):
+        # prepared: a PreparedAnalysis of these utterances (Engine.prepare_analysis, e.g. from the planner thread); None:
+        # prepared here when the batch is in the plain shape the native path takes, else the generic path below
         self.engine = engine
+        if prepared is None and hasattr(engine, "prepare_analysis") and os.environ.get("MAGPHASE_NATIVE_PREPARE", "1") != "0":
+            prepared = engine.prepare_analysis(utts, fft_len, wait=False)
+        if prepared is not None:
+            self._from_prepared(prepared, utts)
+            return
         pos, left, right = [], [], []
         self.v_shift, self.v_f0, self.fs, self.n_frames, self.n_smpls, self.v_pm = [], [], [], [], [], []
         # the samples of all utterances go straight into ONE float32 buffer (page-locked when the engine has one):
@@ -1095,6 +1358,24 @@ class LosslessAnalysisPlan:
             copied = True
         else:
             copied, copy_done = False, None
+        try:
+            self._build_generic(engine, utts, fft_len, buf, off, copied, all_i16, staged, total, pos, left, right)
+        except BaseException:
+            # Whatever goes wrong between the submit and the upload (a malformed utterance, an fft_len mismatch): the native
+            # copy must have stopped writing into the page-locked staging buffer before this constructor is left --
+            # iobatch retries a failed batch one utterance at a time straight away, and host_staging would hand the same
+            # buffer out again while the copy still runs (silent corruption of the retry's samples)
+            if copy_done is not None:
+                try:
+                    copy_done.result()
+                except BaseException:
+                    pass
+            raise
+        if copy_done is not None:
+            copy_done.result()   # the staged samples are in place (the copy ran beside the index arithmetic)
+        self._upload_generic(engine, buf, all_i16, staged, total, pos, left, right)
+
+    def _build_generic(self, engine, utts, fft_len, buf, off, copied, all_i16, staged, total, pos, left, right):
         for (v_sig, fs, v_pm_sec, v_voi) in utts:
             v_sig = np.asarray(v_sig)
             n = v_sig.shape[0]
@@ -1122,7 +1403,7 @@ class LosslessAnalysisPlan:
                 a, b = int(fo[u]), int(fo[u + 1])
                 self.v_shift.append(r["left"][a:b]), self.v_pm.append(r["pm"][a:b]), self.v_f0.append(r["f0"][a:b])
                 self.n_frames.append(b - a)
-            pos, left, right = [r["pos"]], [r["left"]], [r["right"]]
+            pos[:], left[:], right[:] = [r["pos"]], [r["left"]], [r["right"]]
         except hostplan.PlanFallback:   # ... or utterance by utterance in numpy (same arithmetic; raises what it raises)
             for (v_sig, fs, v_pm_sec, v_voi), n, o in zip(utts, self.n_smpls, sig_off):
                 pm_sec, voi = hm.clean_epochs(v_pm_sec, v_voi, check_len_smpls=n, fs=fs)
@@ -1148,9 +1429,10 @@ class LosslessAnalysisPlan:
                 utt_of = np.searchsorted(self.frame_off, hit, side="right") - 1
                 for i, u in zip(hit.tolist(), utt_of.tolist()):
                     self.long_frame_lens[u].append(int(tot[i]))
+        self.total_smpls = int(off)
+
+    def _upload_generic(self, engine, buf, all_i16, staged, total, pos, left, right):
         e = engine
-        if copy_done is not None:
-            copy_done.result()   # the staged samples are in place (the copy ran beside the index arithmetic above)
         if all_i16:
             raw = e.upload_staged((total + 1) // 2 + 2)
             self.sig = e.empty((max(total, 1),))
@@ -1164,9 +1446,53 @@ class LosslessAnalysisPlan:
                                    ("left", np.concatenate(left) if left else np.zeros(0), np.int32),
                                    ("right", np.concatenate(right) if right else np.zeros(0), np.int32)])
         self.pos, self.left, self.right = desc["pos"], desc["left"], desc["right"]
-        self.total_smpls = int(off)
+
+    def _from_prepared(self, p, utts):
+        """Takes over a PreparedAnalysis: two DMAs (samples, tables) and, for 16-bit input, the widening kernel."""
+        e, torch = self.engine, _torch()
+        if p.n_utts != len(utts) or p.engine is not e:
+            p.release()
+            raise ValueError("prepared: not the host side of this batch on this engine")
+        self.fft_len, self.fs = p.fft_len, p.fs
+        self.n_smpls = [int(u[0].shape[0]) for u in utts]
+        fo = self.frame_off = p.frame_off
+        self.total_frames, self.total_smpls = p.total_frames, p.total_smpls
+        self.n_frames = np.diff(fo).tolist()
+        self.v_shift, self.v_pm, self.v_f0 = _FlatRows(p.left64, fo), _FlatRows(p.pm, fo), _FlatRows(p.f0, fo)
+        self.f0_med_flat = p.f0_med
+        self.long_frame_lens = [[] for _ in range(p.n_utts)]
+        if p.long:
+            utt_of = np.searchsorted(fo, [i for i, _n in p.long], side="right") - 1
+            for (i, n), u in zip(p.long, utt_of.tolist()):
+                self.long_frame_lens[u].append(n)
+        F, total = p.total_frames, p.total_smpls
+        o_pos, o_left, o_right, o_voi = p.offs
+        slot, p.slot = p.slot, None          # from here on the upload's event guards the slot
+        sd, dd, ev = e._slot_upload(slot, p.stage_bytes, p.desc_bytes)
+        self._ready = ev
+        if p.all_i16:
+            self.sig = e.empty((max(total, 1),))
+            with torch.cuda.device(e.device):
+                _lib.check(e.lib.mpx_pcm16_to_f32(e.stream_ptr(), sd.data_ptr(), total, self.sig.data_ptr()),
+                           "mpx_pcm16_to_f32")
+            self.sig = self.sig[:total]
+        else:
+            self.sig = sd[:4 * total].view(torch.float32)
+        self.pos = dd[o_pos:o_pos + 8 * F].view(torch.int64)
+        self.left = dd[o_left:o_left + 4 * F].view(torch.int32)
+        self.right = dd[o_right:o_right + 4 * F].view(torch.int32)
+        self.voi_dev = dd[o_voi:o_voi + 4 * F].view(torch.float32)    # (f0 > 0): CompressedAnalysisPlan's voicing row
+
+    def _wait_ready(self):
+        """A plan may be run on another stream than the one it was built on (bench.py alternates streams): that stream
+        waits for the plan's uploads too (the build stream already does)."""
+        ev = getattr(self, "_ready", None)
+        if ev is not None:
+            e = self.engine
+            _torch().cuda.current_stream(e.device).wait_event(ev)
 
     def run(self, out=None, precise=False, rows_in_use=None):
+        self._wait_ready()
         return self.engine.analysis_frames(self.fft_len, self.sig, self.pos, self.left, self.right, out=out,
                                            precise=precise, rows_in_use=rows_in_use if precise else None)
 
@@ -1298,7 +1624,8 @@ class CompressedSynthesisPlan:
 
     def __init__(self, engine, utts, fs, fft_len=None, b_voi_ap_win=True, b_const_rate=False, alpha_phase=None,
                  noise=None, frames_per_run=None, per_phase_type="magphase", post_filter=False, b_fbank_mel=False,
-                 noise_mode="reference", noise_seeds=None, defer_rng=False, fused=None, noise_spectra=None):
+                 noise_mode="reference", noise_seeds=None, defer_rng=False, fused=None, noise_spectra=None, prepared=None):
+        # prepared: a PreparedSynthesis of these utterances (Engine.prepare_synthesis, e.g. from the planner thread)
         # noise_spectra: None = MAGPHASE_NOISE_SPECTRA ("recompute", the default / "store"); True: every noise frame is
         #            transformed once, its spectrum kept in HBM between the statistics and the synthesis launch (N = 4096)
         # defer_rng: the reference noise stream's advanced state stays on the device (Engine.numpy_global_uniform(defer=True));
@@ -1329,12 +1656,143 @@ class CompressedSynthesisPlan:
         self.per_phase_type = per_phase_type
 
         self.engine = e = engine
-        _up = []   # (attribute, host array, dtype): uploaded together at the end (Engine.to_device_packed)
         self.fs = fs
         N = self.fft_len = int(fft_len) if fft_len else hm.define_fft_len(fs)
-        H = N // 2 + 1
         alpha = hm.define_alpha(fs)
         self.alpha_phase = alpha if alpha_phase is None else alpha_phase
+        # Variable-rate features (rows == frames: identity tables, weight 0) take the same unwarp launch as constant-rate ones
+        # (mpx_mel_unwarp_rows): the interpolation is then exact (fmaf(0, 0, m) = m: the same values as mpx_mel_unwarp), and the
+        # phase rows are produced only where the synthesis reads them -- voiced frames, bins below the crossfade's end: a
+        # quarter of the work of the plain form, which unwarped all 2 049 bins of both phase streams for every frame (round 5:
+        # 0.81 -> ... ms per 128-utterance generation launch).  MAGPHASE_UNWARP_ROWS_VAR=0: the plain form.
+        self.unwarp_rows = self.b_const_rate or os.environ.get("MAGPHASE_UNWARP_ROWS_VAR", "1") != "0"
+        want_fused = (os.environ.get("MAGPHASE_SYNTH_FUSED", "0") == "1") if fused is None else bool(fused)
+        # the native whole-launch planner (Engine.prepare_synthesis; `prepared`: built ahead, e.g. on the planner thread) takes
+        # the plain case: ndarray coefficient matrices, the default run planner, no opt-in fused launch
+        if (prepared is None and not want_fused and frames_per_run is None and hasattr(e, "prepare_synthesis")
+                and not os.environ.get("MAGPHASE_OLA_FRAMES_PER_RUN") and os.environ.get("MAGPHASE_NATIVE_PREPARE", "1") != "0"):
+            prepared = e.prepare_synthesis(utts, fs, fft_len=fft_len, b_voi_ap_win=b_voi_ap_win, b_const_rate=b_const_rate,
+                                           wait=False)
+        if prepared is not None and (prepared.n_utts != len(utts) or prepared.engine is not e):
+            prepared.release()
+            raise ValueError("prepared: not the host side of this batch on this engine")
+        if prepared is not None and (want_fused or frames_per_run is not None or prepared.key != (
+                int(fs), N, bool(b_const_rate), bool(b_voi_ap_win), bool(self.unwarp_rows))):
+            prepared.release()
+            prepared = None
+        if prepared is not None:
+            mt_device = self._tables_prepared(prepared, noise, noise_mode, noise_seeds)
+            self.fused = False
+        else:
+            mt_device = self._tables_generic(utts, b_voi_ap_win, noise, noise_mode, noise_seeds, frames_per_run, b_fbank_mel,
+                                             want_fused)
+        H = N // 2 + 1
+        # constants: unwarp matrices and per-bin curves (float64 -> float32)
+        # (resident on the device per configuration: rebuilding them costs 7 ms on the host, as much as the rest of a
+        # single-utterance call -- tools/archive/latency_probe.py)
+        if b_fbank_mel:   # magphase.py:851-852: filter-bank unwarp = a different [mag_dim x H] matrix, same kernel
+            self.u_mag = e.constant(("u_mag_fbank", self.mag_dim, H, float(alpha)),
+                                    lambda: hm.unwarp_fbank_matrix(self.mag_dim, H, alpha))
+        else:
+            self.u_mag = e.constant(("u_mag", self.mag_dim, H, float(alpha)),
+                                    lambda: hm.unwarp_matrix(self.mag_dim, H, alpha))
+        self.u_phase = e.constant(("u_phase", self.phase_dim, N, int(fs), float(self.alpha_phase)),
+                                  lambda: hm.phase_unwarp_matrix(self.phase_dim, N, fs, self.alpha_phase))
+        self.per_v, self.ap_v, self.ap_u = (
+            e.constant(("bin_curve", k, int(fs), N), lambda k=k: hm.synthesis_bin_curves(fs, N)[k]) for k in range(3))
+        self._gains_dev = None
+        # "noise spectra once" (opt-in): see run()
+        self.noise_spectra = ((os.environ.get("MAGPHASE_NOISE_SPECTRA", "recompute") == "store")
+                              if noise_spectra is None else bool(noise_spectra))
+        if noise_mode == "device":
+            torch = _torch()
+            self.noise = e.empty((max(int(self.noise_off_host[-1]), 1),))
+            with torch.cuda.device(e.device):
+                _lib.check(e.lib.mpx_noise_uniform(e.stream_ptr(), self.n_utts, self.noise_seeds_dev.data_ptr(),
+                                                   self.noise_off_dev.data_ptr(), int(max(self.ns_len)),
+                                                   self.noise.data_ptr()), "mpx_noise_uniform")
+        elif mt_device:
+            self.noise = e.numpy_global_uniform(int(sum(self.ns_len)), defer=bool(defer_rng))
+
+    def _mt_device(self, noise, noise_mode, mt_total):
+        """Reference noise (np.random.uniform from numpy's GLOBAL generator, magphase.py:883) for more than a few utterances
+        is continued on the device from numpy's own MT19937 state (mpx_noise_numpy_mt19937: the same samples, the state put
+        back advanced) -- the host draw is 4 ns per sample, 0.13 s per 128 utterances."""
+        return (noise_mode == "reference" and noise is None and mt_total >= (1 << 18)
+                and os.environ.get("MAGPHASE_MT_DEVICE", "1") != "0" and np.random.get_state()[0] == "MT19937")
+
+    def _host_noise(self, noise, ui, ns_len):
+        e = self.engine
+        if noise is not None:
+            v_ns = np.asarray(noise[ui], dtype=np.float64)
+            if v_ns.size != ns_len:
+                raise ValueError("noise length %d != ns_len %d" % (v_ns.size, ns_len))
+            return v_ns
+        if hasattr(e, "mt_sync"):
+            e.mt_sync()                                            # a deferred device state goes back first
+        return np.random.uniform(-1, 1, ns_len)                    # :883 (global numpy RNG, as the reference)
+
+    def _tables_prepared(self, p, noise, noise_mode, noise_seeds):
+        """Takes over a PreparedSynthesis (Engine.prepare_synthesis): two DMAs (coefficient rows, every table)."""
+        e, torch = self.engine, _torch()
+        self.mag_dim, self.phase_dim = p.mag_dim, p.phase_dim
+        F, U = p.total_frames, p.n_utts
+        fo = p.frame_off
+        self._tabs = {"v_shift": p.v_shift, "v_pm": p.v_pm, "voiced": p.voiced_host}
+        self._fo = fo
+        self.ns_len = p.ns_len.tolist()
+        self.n_rows, self.total_frames, self.frame_off, self.n_utts = p.n_rows, F, fo, U
+        self.out_len = p.out_len.tolist()
+        self.out_off_host = np.concatenate(([0], np.cumsum(p.out_len))).astype(np.int64)
+        self.total_out = int(self.out_off_host[-1])
+        self.max_out_len = int(p.out_len.max())
+        self.voiced_host = p.voiced_host.astype(bool)
+        self.n_runs, self.n_slots = p.n_runs, p.n_slots
+        self.runs_host = p.runs_host
+        self.strip_floats = self.n_runs * (self.fft_len + 64)
+        self.n_per = e.host_constant(("n_per", int(self.fs), self.fft_len), lambda: _first_all_zero_from(
+            np.asarray(hm.synthesis_bin_curves(self.fs, self.fft_len)[0], dtype=np.float32)))
+        mt_device = self._mt_device(noise, noise_mode, int(p.ns_len.sum()))
+        slot, p.slot = p.slot, None
+        sd, dd, ev = e._slot_upload(slot, p.stage_bytes, p.desc_bytes)
+        self._ready = ev
+        n_m, n_p = self.n_rows * self.mag_dim, self.n_rows * self.phase_dim
+        coef = sd.view(torch.float32)
+        self.a_mag = coef[:n_m].view(self.n_rows, self.mag_dim)
+        self.a_real = coef[n_m:n_m + n_p].view(self.n_rows, self.phase_dim)
+        self.a_imag = coef[n_m + n_p:n_m + 2 * n_p].view(self.n_rows, self.phase_dim)
+        sizes = {"utt_frame_off": U + 1, "tile_first": p.n_tiles1, "out_start": U, "out_off": U + 1,
+                 "runs": 56 * p.n_runs, "slot_off": p.n_slots + 1, "slot_runs": p.n_runs}
+        tmap = {np.int32: torch.int32, np.int64: torch.int64, np.float32: torch.float32, np.uint8: torch.uint8}
+        for (name, dt), off in zip(hostplan.SYNTH_TABLES, p.desc_off.tolist()):
+            n = sizes.get(name, F)
+            if name == "tile_first" and not self.unwarp_rows:
+                continue
+            setattr(self, name, dd[off:off + n * np.dtype(dt).itemsize].view(tmap[dt]))
+        if noise_mode == "device":
+            self._noise_seed_tables(noise_seeds)
+        elif not mt_device:
+            self.noise = e.to_device(np.concatenate([self._host_noise(noise, ui, n) for ui, n in enumerate(self.ns_len)]),
+                                     np.float32)
+        return mt_device
+
+    def _noise_seed_tables(self, noise_seeds):
+        e = self.engine
+        seeds = np.arange(self.n_utts, dtype=np.uint64) if noise_seeds is None else np.asarray(noise_seeds).astype(np.uint64)
+        if seeds.size != self.n_utts:
+            raise ValueError("noise_seeds: one per utterance")
+        self.noise_seeds = seeds
+        self.noise_off_host = np.concatenate(([0], np.cumsum(self.ns_len))).astype(np.int64)
+        d = e.to_device_packed([("s", seeds.view(np.int64), np.int64), ("o", self.noise_off_host, np.int64)])
+        self.noise_seeds_dev, self.noise_off_dev = d["s"], d["o"]
+
+    def _tables_generic(self, utts, b_voi_ap_win, noise, noise_mode, noise_seeds, frames_per_run, b_fbank_mel, want_fused):
+        """The generic path: any array-like input, utterance by utterance in Python where the native planner declines."""
+        e = self.engine
+        fs, N, b_const_rate, per_phase_type = self.fs, self.fft_len, self.b_const_rate, self.per_phase_type
+        H = N // 2 + 1
+        alpha = hm.define_alpha(fs)
+        _up = []   # (attribute, host array, dtype): uploaded together at the end (Engine.to_device_packed)
         self.mag_dim = int(np.shape(utts[0][0])[1])
         self.phase_dim = int(np.shape(utts[0][1])[1])
 
@@ -1355,32 +1813,21 @@ class CompressedSynthesisPlan:
                                  % (ui, n_rows, rm.shape[0], im.shape[0], lf0.shape[0]))
             if rm.shape[1] != im.shape[1]:
                 raise ValueError("utterance %d: real and imag have different dimensions" % ui)
+            if mml.shape[1] != self.mag_dim or rm.shape[1] != self.phase_dim:
+                # (stage_rows checks totals only: rows of another width whose totals happen to match would be copied flat,
+                # silently scrambled -- np.concatenate(axis=0, out=[rows x dim]) used to raise here)
+                raise ValueError("utterance %d: mag / phase dimensions %d / %d differ from the batch's %d / %d"
+                                 % (ui, mml.shape[1], rm.shape[1], self.mag_dim, self.phase_dim))
             a_mag.append(mml), a_real.append(rm), a_imag.append(im), lf0s.append(lf0)
             row_base += n_rows
-
-        def noise_for(ui, ns_len):
-            if noise is not None:
-                v_ns = np.asarray(noise[ui], dtype=np.float64)
-                if v_ns.size != ns_len:
-                    raise ValueError("noise length %d != ns_len %d" % (v_ns.size, ns_len))
-                return v_ns
-            if noise_mode == "device" or mt_device:
-                return None                                            # generated on the GPU
-            if hasattr(e, "mt_sync"):
-                e.mt_sync()                                            # a deferred device state goes back first
-            return np.random.uniform(-1, 1, ns_len)                    # :883 (global numpy RNG, as the reference)
 
         try:    # index arithmetic of the whole batch in one native call (hostplan / csrc/magphase_plan.cpp) ...
             r = hostplan.plan_synthesis([np.exp(l) for l in lf0s], fs, N, b_const_rate, b_voi_ap_win)   # :846
         except hostplan.PlanFallback:   # ... or utterance by utterance in numpy: the same arithmetic, spelled out
             r = plan_synthesis_numpy(lf0s, fs, N, b_const_rate, b_voi_ap_win)
         fo = r["frame_off"]
-        # Reference noise (np.random.uniform from numpy's GLOBAL generator, magphase.py:883) for more than a few
-        # utterances is continued on the device from numpy's own MT19937 state (mpx_noise_numpy_mt19937: the same
-        # samples, the state put back advanced) -- the host draw is 4 ns per sample, 0.13 s per 128 utterances.
         mt_total = int(np.sum(r["ns_len"]))
-        mt_device = (noise_mode == "reference" and noise is None and mt_total >= (1 << 18)
-                     and os.environ.get("MAGPHASE_MT_DEVICE", "1") != "0" and np.random.get_state()[0] == "MT19937")
+        mt_device = self._mt_device(noise, noise_mode, mt_total)
         # per-utterance views (v_shift / v_pm / v_voi: properties below) are cut from the batch tables on demand
         self._tabs, self._fo = r, fo
         self.ns_len = [int(x) for x in np.asarray(r["ns_len"]).tolist()]
@@ -1389,7 +1836,7 @@ class CompressedSynthesisPlan:
         nfr = np.diff(np.asarray(fo, dtype=np.int64)).tolist()
         pm_rel = _FlatRows(np.asarray(r["pm_rel"]), fo)
         if noise is not None or not (noise_mode == "device" or mt_device):
-            noises = [noise_for(ui, self.ns_len[ui]) for ui in range(len(utts))]
+            noises = [self._host_noise(noise, ui, self.ns_len[ui]) for ui in range(len(utts))]
         npos, nleft, nright, wtype, voiced = [r["npos"]], [r["nleft"]], [r["nright"]], [r["wtype"]], [r["voiced"]]
         row0, row1, rowt, win_l, win_r = [r["row0"]], [r["row1"]], [r["rowt"]], [r["win_l"]], [r["win_r"]]
 
@@ -1407,18 +1854,11 @@ class CompressedSynthesisPlan:
         # coefficient matrices: concatenated straight into the page-locked staging buffer, one DMA
         n_m, n_p = self.n_rows * self.mag_dim, self.n_rows * self.phase_dim
         stage = e.host_staging(n_m + 2 * n_p)
-
-        def _stage():
-            e.stage_rows(a_mag, stage[:n_m].reshape(self.n_rows, self.mag_dim))
-            e.stage_rows(a_real, stage[n_m:n_m + n_p].reshape(self.n_rows, self.phase_dim))
-            e.stage_rows(a_imag, stage[n_m + n_p:].reshape(self.n_rows, self.phase_dim))
-
         # (inline: on the helper thread -- Engine.background -- the launch loop of a generation job got 5 % SLOWER, the three
         # calls' Python glue fights the constructor for the GIL; the analysis plan's single native copy gains 7 % there)
-        import concurrent.futures as _cf
-        staged_done = _cf.Future()
-        _stage()
-        staged_done.set_result(None)
+        e.stage_rows(a_mag, stage[:n_m].reshape(self.n_rows, self.mag_dim))
+        e.stage_rows(a_real, stage[n_m:n_m + n_p].reshape(self.n_rows, self.phase_dim))
+        e.stage_rows(a_imag, stage[n_m + n_p:].reshape(self.n_rows, self.phase_dim))
         if noise_mode == "device":
             seeds = np.arange(len(nfr), dtype=np.uint64) if noise_seeds is None else np.asarray(noise_seeds).astype(np.uint64)
             if seeds.size != len(nfr):
@@ -1434,12 +1874,6 @@ class CompressedSynthesisPlan:
         _up.append(("nright", cat(nright), np.int32))
         _up.append(("wtype", cat(wtype), np.int32))
         _up.append(("voiced", cat(voiced), np.int32))
-        # Variable-rate features (rows == frames: identity tables, weight 0) take the same unwarp launch as constant-rate ones
-        # (mpx_mel_unwarp_rows): the interpolation is then exact (fmaf(0, 0, m) = m: the same values as mpx_mel_unwarp), and the
-        # phase rows are produced only where the synthesis reads them -- voiced frames, bins below the crossfade's end: a
-        # quarter of the work of the plain form, which unwarped all 2 049 bins of both phase streams for every frame (round 5:
-        # 0.81 -> ... ms per 128-utterance generation launch).  MAGPHASE_UNWARP_ROWS_VAR=0: the plain form.
-        self.unwarp_rows = self.b_const_rate or os.environ.get("MAGPHASE_UNWARP_ROWS_VAR", "1") != "0"
         if self.unwarp_rows:   # frames of every 31-row tile of the coefficient matrix (mpx_mel_unwarp_rows)
             r0c = cat(row0)
             self._check_rows_for_tiles(r0c, cat(row1))
@@ -1453,19 +1887,6 @@ class CompressedSynthesisPlan:
         _up.append(("pm_rel", pm_rel.flat, np.int32))
         _up.append(("out_start", np.asarray(starts), np.int32))
         _up.append(("out_off", self.out_off_host, np.int64))
-        # constants: unwarp matrices and per-bin curves (float64 -> float32)
-        # (resident on the device per configuration: rebuilding them costs 7 ms on the host, as much as the rest of a
-        # single-utterance call -- tools/archive/latency_probe.py)
-        if b_fbank_mel:   # magphase.py:851-852: filter-bank unwarp = a different [mag_dim x H] matrix, same kernel
-            self.u_mag = e.constant(("u_mag_fbank", self.mag_dim, H, float(alpha)),
-                                    lambda: hm.unwarp_fbank_matrix(self.mag_dim, H, alpha))
-        else:
-            self.u_mag = e.constant(("u_mag", self.mag_dim, H, float(alpha)),
-                                    lambda: hm.unwarp_matrix(self.mag_dim, H, alpha))
-        self.u_phase = e.constant(("u_phase", self.phase_dim, N, int(fs), float(self.alpha_phase)),
-                                  lambda: hm.phase_unwarp_matrix(self.phase_dim, N, fs, self.alpha_phase))
-        self.per_v, self.ap_v, self.ap_u = (
-            e.constant(("bin_curve", k, int(fs), N), lambda k=k: hm.synthesis_bin_curves(fs, N)[k]) for k in range(3))
         # bins from n_per on have no periodic component (the crossfade mask is exactly zero there): their phase rows are
         # neither unwarped nor read
         self.n_per = e.host_constant(("n_per", int(fs), N), lambda: _first_all_zero_from(
@@ -1474,22 +1895,16 @@ class CompressedSynthesisPlan:
         n_slots = e.synth_comp_slots() if hasattr(e, "synth_comp_slots") else 1024
         _plan_ola_runs(self, pm_rel, starts, self.out_len, self.out_off_host, N, n_slots, frames_per_run, _up,
                        weights=e.synth_ola_slot_weights(comp=True) if hasattr(e, "synth_ola_slot_weights") else None)
-        staged_done.result()
         coef = e.upload_staged(n_m + 2 * n_p)
         self.a_mag = coef[:n_m].view(self.n_rows, self.mag_dim)
         self.a_real = coef[n_m:n_m + n_p].view(self.n_rows, self.phase_dim)
         self.a_imag = coef[n_m + n_p:].view(self.n_rows, self.phase_dim)
-        self._gains_dev = None
         # Fused unwarp -> synthesis (mpx_synthesis_compressed_fused; opt-in: MAGPHASE_SYNTH_FUSED=1 or fused=True): N = 4096,
         # the transmitted phase, a crossfade that ends at or below bin 512.  The runs are cut into segments of <= 16 frames
         # within 16 coefficient rows; U goes up in MFMA fragment order.  Built, parity-green and MEASURED SLOWER than the
         # staged pair mpx_mel_unwarp[_rows] -> mpx_synthesis_compressed_ola (1.20 vs 0.90 ms per 57 k frames, the same HBM
         # traffic: docs/LAB_NOTES.md, "Round 5: the fused synthesis side"), so the staged pair stays the default.
         self.fused = False
-        # "noise spectra once" (opt-in): see run()
-        self.noise_spectra = ((os.environ.get("MAGPHASE_NOISE_SPECTRA", "recompute") == "store")
-                              if noise_spectra is None else bool(noise_spectra))
-        want_fused = (os.environ.get("MAGPHASE_SYNTH_FUSED", "0") == "1") if fused is None else bool(fused)
         if (want_fused and per_phase_type == "magphase" and self.n_runs > 0
                 and hasattr(e.lib, "mpx_synth_fused_ksteps") and 0 < self.n_per <= 512):
             ktm, ktp = ctypes.c_int32(0), ctypes.c_int32(0)
@@ -1519,15 +1934,7 @@ class CompressedSynthesisPlan:
                 _up.append(("run_seg_off", run_seg_off, np.int32))
         for _k, _t in e.to_device_packed(_up).items():
             setattr(self, _k, _t)
-        if noise_mode == "device":
-            torch = _torch()
-            self.noise = e.empty((max(int(self.noise_off_host[-1]), 1),))
-            with torch.cuda.device(e.device):
-                _lib.check(e.lib.mpx_noise_uniform(e.stream_ptr(), len(nfr), self.noise_seeds_dev.data_ptr(),
-                                                   self.noise_off_dev.data_ptr(), int(max(self.ns_len)),
-                                                   self.noise.data_ptr()), "mpx_noise_uniform")
-        elif mt_device:
-            self.noise = e.numpy_global_uniform(mt_total, defer=bool(defer_rng))
+        return mt_device
 
     def _per_utt(self, key, cast=None):
         r, fo = self._tabs, self._fo
@@ -1622,6 +2029,9 @@ class CompressedSynthesisPlan:
         tab = e.tables(N)
         mark = mark or (lambda name: None)
         fused = self.fused and not keep   # keep: the caller wants the unwarped spectra themselves
+        ev = getattr(self, "_ready", None)
+        if ev is not None:   # (a plan run on another stream than the one it was built on: that stream waits for the uploads too)
+            torch.cuda.current_stream(e.device).wait_event(ev)
         buf = self._buffers(staged=not fused)
         # unwarped spectra: internal matrices, rows 128-byte aligned (mpx_spec_ld: full-line stores of the MFMA unwarp)
         ld = buf["ld"]
@@ -1849,11 +2259,12 @@ class CompressedAnalysisPlan:
     """
 
     def __init__(self, engine, utts, fft_len=None, mag_dim=60, phase_dim=10, b_const_rate=False, alpha_phase=None,
-                 b_mag_fbank_mel=False):
+                 b_mag_fbank_mel=False, prepared=None):
+        # prepared: see LosslessAnalysisPlan (Engine.prepare_analysis, e.g. from the planner thread)
         self.engine = e = engine
-        self.lossless = plan = LosslessAnalysisPlan(engine, utts, fft_len=fft_len)
+        self.lossless = plan = LosslessAnalysisPlan(engine, utts, fft_len=fft_len, prepared=prepared)
         fs = self.fs = plan.fs[0]
-        if any(f != fs for f in plan.fs):
+        if plan.fs.count(fs) != len(plan.fs):
             raise ValueError("one sample rate per batch")
         N = self.fft_len = plan.fft_len
         H = N // 2 + 1
@@ -1876,11 +2287,15 @@ class CompressedAnalysisPlan:
                 row0.append(lo + base), row1.append(hi + base), rowt.append(t), self.f0_out.append(v_f0)
             self.out_off = np.concatenate(([0], np.cumsum([len(f) for f in self.f0_out]))).astype(np.int64)
         else:   # variable rate: output rows == frames (no row tables go to the device)
-            self.f0_out = list(plan.v_f0)
+            self.f0_out = plan.v_f0 if isinstance(plan.v_f0, _FlatRows) else list(plan.v_f0)
             self.out_off = np.asarray(plan.frame_off, dtype=np.int64)
         self.total_out_frames = int(self.out_off[-1])
-        f0_cat = np.concatenate(self.f0_out) if self.f0_out else np.zeros(0)
-        items = [("voi", (f0_cat > 0).astype(np.float32), np.float32)]
+        if isinstance(self.f0_out, _FlatRows):
+            f0_cat = self.f0_out.flat
+        else:
+            f0_cat = np.concatenate(self.f0_out) if self.f0_out else np.zeros(0)
+        voi_dev = None if b_const_rate else getattr(plan, "voi_dev", None)   # already in the prepared tables' upload
+        items = [] if voi_dev is not None else [("voi", (f0_cat > 0).astype(np.float32), np.float32)]
         if b_const_rate:
             items += [("row0", np.concatenate(row0), np.int32), ("row1", np.concatenate(row1), np.int32),
                       ("rowt", np.concatenate(rowt), np.float32)]
@@ -1888,14 +2303,14 @@ class CompressedAnalysisPlan:
         # the rows a voiced constant-rate frame interpolates from
         self.phase_on_rows = bool(b_const_rate) and os.environ.get("MAGPHASE_WARP_PHASE_ROWS", "1") != "0"
         if self.phase_on_rows:
-            voiced = items[0][1] > 0
+            voiced = f0_cat > 0
             r0, r1 = np.concatenate(row0), np.concatenate(row1)
             need = np.zeros(plan.total_frames, dtype=np.float32)
             need[r0[voiced]] = 1.0
             need[r1[voiced]] = 1.0
             items.append(("rows_in_use", need, np.float32))
-        desc = e.to_device_packed(items)   # one H2D copy
-        self.voi = desc["voi"]
+        desc = e.to_device_packed(items) if items else {}   # one H2D copy
+        self.voi = desc["voi"] if voi_dev is None else voi_dev
         self.row0, self.row1, self.rowt = (desc.get(k) for k in ("row0", "row1", "rowt"))
         self.rows_in_use = desc.get("rows_in_use")
         self._phase_tmp = None
@@ -1925,6 +2340,7 @@ class CompressedAnalysisPlan:
         mark("start")
         # float64 transform: the warp's log / division amplify an fp32 FFT's noise on weak bins (magphase_f64.hip)
         precise = os.environ.get("MAGPHASE_COMP_ANALYSIS", "f64") != "f32"
+        self.lossless._wait_ready()
         if self.fused:   # (feats, the staged path's lossless feature buffers, are not used)
             if out is None:
                 out = (e.empty((self.total_out_frames, self.mag_dim)), e.empty((self.total_out_frames, self.phase_dim)),

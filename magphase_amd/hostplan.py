@@ -130,3 +130,42 @@ def ola_runs(pm_rel_cat, frame_off, starts, out_lens, out_offs, fft_len, n_slots
     slot_of = np.clip(np.searchsorted(gcuts, runs["frame_begin"], side="right") - 1, 0, ns - 1)
     slot_off = np.searchsorted(slot_of, np.arange(ns + 1), side="left").astype(np.int64)
     return runs, slot_off, np.arange(runs.size, dtype=np.int64)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Whole-launch planners (mpx_host_plan_analysis_batch / mpx_host_plan_synthesis_batch) through the marshalling layer
+# _mpx_pyhost (csrc/magphase_pyhost.cpp): the utterance list is walked once in native code, the interpreter lock is
+# released for the call.  Used by Engine.prepare_analysis / prepare_synthesis; the list-based functions above stay as the
+# generic path (any array-like input) and as what the tests compare against.
+# ----------------------------------------------------------------------------------------------------------------------
+_PYHOST = False
+
+
+def pyhost():
+    """The _mpx_pyhost extension module, or None (not built: no Python.h at build time; MAGPHASE_PYHOST=0)."""
+    global _PYHOST
+    if _PYHOST is False:
+        _PYHOST = None
+        if enabled() and os.environ.get("MAGPHASE_PYHOST", "1") != "0":
+            try:
+                _lib.load()                      # the extension links against the C-ABI library
+                from . import _mpx_pyhost
+                _PYHOST = _mpx_pyhost
+            except Exception:
+                _PYHOST = None
+    return _PYHOST
+
+
+# order of the device tables mpx_host_plan_synthesis_batch lays out in its `desc` buffer: (name, numpy dtype)
+SYNTH_TABLES = (("utt_frame_off", np.int32), ("npos", np.int64), ("nleft", np.int32), ("nright", np.int32),
+                ("wtype", np.int32), ("voiced", np.int32), ("tile_first", np.int32), ("row0", np.int32),
+                ("row1", np.int32), ("rowt", np.float32), ("win_l", np.int32), ("win_r", np.int32), ("pm_rel", np.int32),
+                ("out_start", np.int32), ("out_off", np.int64), ("runs", np.uint8), ("slot_off", np.int32),
+                ("slot_runs", np.int32))
+
+
+def synth_desc_bytes(n_rows, n_utts, n_slots, b_const_rate):
+    """Upper bound of the bytes mpx_host_plan_synthesis_batch writes into `desc`."""
+    cap = (2 * int(n_rows) + 2 * int(n_utts)) if b_const_rate else int(n_rows)
+    runs = int(n_utts) + int(n_slots) + 1
+    return 52 * cap + 4 * (int(n_rows) // 31 + 3) + 16 * (int(n_utts) + 1) + 60 * runs + 4 * (int(n_slots) + 1) + 256 * 20

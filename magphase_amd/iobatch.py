@@ -270,6 +270,11 @@ def extract_features_corpus(wav_files, out_dir, batch_utts=16, fft_len=None, mag
     elif os.environ.get("MAGPHASE_EPOCHS", "") == "builtin":
         from .engine import get_engine
         tracker_device = get_engine().device
+    # the engine whose planner prepares a batch's launches in the READER thread, one batch ahead of the compute stage
+    # (Engine.prepare_analysis: native planners, samples into page-locked memory, no stream touched) -- resolved here for the
+    # same reason
+    from .engine import get_engine as _ge
+    prep_engine = engine or _ge()
 
     def load(files):
         # the bytes of the wavs and the parsed epoch tracks (text) each come from one native call (a few threads, no GIL)
@@ -282,23 +287,32 @@ def extract_features_corpus(wav_files, out_dir, batch_utts=16, fft_len=None, mag
                 failed.append((_tok(f), "%s: %s" % (type(bad).__name__, bad)))
             else:
                 utts.append((f, (w[0], w[1], ep[0], ep[1])))
-        return utts, failed
+        prepared = {}
+        for fs in sorted(set(u[1][1] for u in utts)):   # one launch per sample rate: its host side, here in the reader thread
+            try:
+                prepared[fs] = prep_engine.prepare_analysis([u[1] for u in utts if u[1][1] == fs], fft_len)
+            except (KeyboardInterrupt, SystemExit):
+                raise
+            except Exception:
+                prepared[fs] = None      # the compute stage's own attempt raises (and isolates) what there is to raise
+        return utts, failed, prepared
 
     def compute(loaded):
         # The device results are NOT waited for here: they land in a page-locked ring slot (engine.HostTicket) while this
         # thread plans the next batch; the writer thread waits for the copy and hands the slot back.
-        utts, failed = loaded
+        utts, failed, prepared = loaded
         out, tickets = [], []
         for fs in sorted(set(u[1][1] for u in utts)):
             group = [u for u in utts if u[1][1] == fs]
 
-            def analyse(g, whole=len(group)):
+            def analyse(g, whole=len(group), fs=fs):
                 # Q7: the reference forwards alpha_phase=b_mag_fbank_mel (False) -- see mp.analysis_for_acoustic_modelling
                 kw = dict(fft_len=fft_len, mag_dim=mag_dim, phase_dim=phase_dim, b_const_rate=b_const_rate,
                           alpha_phase=False, engine=engine, as_float32=True)
                 if len(g) != whole:   # _isolate's one-by-one retries after a failed batch: plain synchronous results (a
                     return mp.analysis_compressed_batch([u[1] for u in g], **kw)   # ring slot each would exhaust the ring)
-                res, ticket = mp.analysis_compressed_batch([u[1] for u in g], async_out=True, **kw)
+                res, ticket = mp.analysis_compressed_batch([u[1] for u in g], async_out=True,
+                                                           prepared=prepared.pop(fs, None), **kw)
                 tickets.append(ticket)
                 return res
 
@@ -377,6 +391,7 @@ def generate_waveforms_corpus(in_feats_dir, tokens, out_syn_dir, mag_dim, phase_
         raise ValueError("pf_type must be 'no', 'magphase' or 'merlin'")
     from .engine import get_engine
     rng_engine = (engine or get_engine()) if noise_mode == "reference" else None   # resolved in THIS thread (device)
+    prep_engine = engine or get_engine()   # its planner prepares a batch's launches in the reader thread (see extraction)
     fs_of = (lambda t: int(fs[t])) if isinstance(fs, dict) else ((lambda t: int(fs(t))) if callable(fs) else (lambda t: int(fs)))
 
     def load(toks):
@@ -399,15 +414,24 @@ def generate_waveforms_corpus(in_feats_dir, tokens, out_syn_dir, mag_dim, phase_
                 raise
             except Exception as e:
                 failed.append((t, "%s: %s" % (type(e).__name__, e)))
-        return utts, failed
+        prepared = {}
+        for rate in sorted(set(u[1] for u in utts)):   # the launches' host side, here in the reader thread (see extraction)
+            try:
+                prepared[rate] = prep_engine.prepare_synthesis([u[2] for u in utts if u[1] == rate], rate, fft_len=fft_len,
+                                                               b_const_rate=b_const_rate)
+            except (KeyboardInterrupt, SystemExit):
+                raise
+            except Exception:
+                prepared[rate] = None
+        return utts, failed, prepared
 
     def compute(loaded):
         # (the device results are not waited for here: see extract_features_corpus.compute)
-        utts, failed = loaded
+        utts, failed, prepared = loaded
         out, tickets = [], []
         for rate in sorted(set(u[1] for u in utts)):
             group = [u for u in utts if u[1] == rate]
-            def synth(g, whole=len(group)):
+            def synth(g, whole=len(group), rate=rate):
                 kw = {}
                 if noise_mode != "reference":   # seed = a hash of the token: the same wav whatever the batching / sharding
                     kw = {"noise_mode": noise_mode, "noise_seeds": [token_seed(u[0]) for u in g]}
@@ -416,7 +440,8 @@ def generate_waveforms_corpus(in_feats_dir, tokens, out_syn_dir, mag_dim, phase_
                           engine=engine, pcm16_norm=0.98, defer_rng=(rng_engine is not None))
                 if len(g) != whole:   # _isolate's one-by-one retries: synchronous results (see extract_features_corpus)
                     return mp.synthesis_from_compressed_batch([u[2] for u in g], rate, **kw)
-                sigs, ticket = mp.synthesis_from_compressed_batch([u[2] for u in g], rate, async_out=True, **kw)
+                sigs, ticket = mp.synthesis_from_compressed_batch([u[2] for u in g], rate, async_out=True,
+                                                                  prepared=prepared.pop(rate, None), **kw)
                 tickets.append(ticket)
                 return sigs
 

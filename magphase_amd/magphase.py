@@ -438,7 +438,7 @@ def _output_hpf(v_syn_sig, fs):
 def synthesis_from_compressed_batch(utts, fs, fft_len=None, b_voi_ap_win=True, b_const_rate=False, alpha_phase=None,
                                     b_out_hpf=True, noise=None, engine=None, per_phase_type='magphase',
                                     b_post_filter=False, b_fbank_mel=False, noise_mode='reference', noise_seeds=None,
-                                    pcm16_norm=False, async_out=False, defer_rng=False):
+                                    pcm16_norm=False, async_out=False, defer_rng=False, prepared=None):
     """Batched synthesis_from_compressed; utts: list of (m_mag_mel_log, m_real_mel, m_imag_mel, v_lf0).
     defer_rng: reference noise only -- numpy's advanced generator state stays on the device between calls; the caller owes
     engine.mt_sync() before numpy's global generator is used again (iobatch does this for a corpus run).
@@ -450,12 +450,15 @@ def synthesis_from_compressed_batch(utts, fs, fft_len=None, b_voi_ap_win=True, b
     'device' generates it on the GPU (Philox, one uint64 seed per utterance in noise_seeds, default 0, 1, ...): same
     distribution, not the reference's sample values, independent of batching and sharding.
     pcm16_norm: False (default) returns float64 signals; a number (la.write_audio_file's norm, 0.98) or None returns
-    the int16 samples la.write_audio_file(..., norm=pcm16_norm) would store, converted on the device (mpx_pcm16)."""
+    the int16 samples la.write_audio_file(..., norm=pcm16_norm) would store, converted on the device (mpx_pcm16).
+    prepared: the host side of THIS batch built ahead of time (engine.prepare_async("synthesis", utts, fs, fft_len=...,
+    b_voi_ap_win=..., b_const_rate=...).result(): the planner thread prepares launch i + 1 while this thread enqueues
+    launch i; None: prepared here)."""
     engine = engine or get_engine()
     plan = CompressedSynthesisPlan(engine, utts, fs, fft_len=fft_len, b_voi_ap_win=b_voi_ap_win,
                                    b_const_rate=b_const_rate, alpha_phase=alpha_phase, noise=noise,
                                    per_phase_type=per_phase_type, post_filter=b_post_filter, b_fbank_mel=b_fbank_mel,
-                                   noise_mode=noise_mode, noise_seeds=noise_seeds, defer_rng=defer_rng)
+                                   noise_mode=noise_mode, noise_seeds=noise_seeds, defer_rng=defer_rng, prepared=prepared)
     pcm_dev = plan.run()
     if b_out_hpf:   # magphase.py:981-995, float64 on the device (engine.output_hpf); _output_hpf is the host form
         pcm_dev = engine.output_hpf(pcm_dev, plan.out_off_host, fs)
@@ -512,13 +515,15 @@ def synthesis_from_acoustic_modelling(in_feats_dir, filename_token, out_syn_dir,
 # compressed-feature analysis
 # ======================================================================================================
 def analysis_compressed_batch(utts, fft_len=None, mag_dim=60, phase_dim=10, b_const_rate=False, alpha_phase=None,
-                              engine=None, as_float32=False, async_out=False):
+                              engine=None, as_float32=False, async_out=False, prepared=None):
     """
     Batched magphase.py:2947-2988 for utterances with epochs: utts = list of (v_sig, fs, v_pm_sec, v_voi), one
     sample rate per call.  Lossless analysis (k_analysis) stays on the device; the mel warp runs on it directly.
     Returns a list of (m_mag_mel_log, m_real_mel, m_imag_mel, v_lf0_smth, v_shift, fs, fft_len).
     async_out (with as_float32): returns (list, ticket) -- the three matrices are views of a page-locked buffer the device
     is still copying into; ticket.wait() before reading them, ticket.release() when done (engine.HostTicket).
+    prepared: the host side of THIS batch built ahead of time (engine.prepare_async("analysis", utts, fft_len).result():
+    the planner thread prepares launch i + 1 while this thread enqueues launch i; None: prepared here).
     """
     engine = engine or get_engine()
     if len(utts) == 0:   # nothing to do (the per-utterance loop of the reference would run zero times)
@@ -526,7 +531,7 @@ def analysis_compressed_batch(utts, fft_len=None, mag_dim=60, phase_dim=10, b_co
 
         return ([], HostTicket(None, None, None, None)) if async_out else []
     plan = CompressedAnalysisPlan(engine, utts, fft_len=fft_len, mag_dim=mag_dim, phase_dim=phase_dim,
-                                  b_const_rate=b_const_rate, alpha_phase=alpha_phase)
+                                  b_const_rate=b_const_rate, alpha_phase=alpha_phase, prepared=prepared)
     for lens in plan.lossless.long_frame_lens:
         for n in lens:
             warnings.warn(_WARN_LONG % (plan.fft_len, n))
@@ -542,11 +547,17 @@ def analysis_compressed_batch(utts, fft_len=None, mag_dim=60, phase_dim=10, b_co
     try:
         # signal.medfilt of every utterance's f0 in one pass (hostmath.medfilt3_batch: bit-identical, also for 0 or 1
         # vectors; 30 us per scipy call)
-        f0_med = hm.medfilt3_batch(plan.f0_out)
-        # lf0 of the whole batch in one pass (la.f0_to_lf0 per utterance: the same element-wise operations)
-        sizes = [int(np.size(f)) for f in plan.f0_out]
-        lf0_cat = la.f0_to_lf0((np.concatenate(plan.f0_out) > 0).astype('float') * np.concatenate(f0_med)) if sizes else np.zeros(0)  # magphase.py:2499-2501
-        off = np.concatenate(([0], np.cumsum(sizes))).tolist()
+        med_flat = None if b_const_rate else getattr(plan.lossless, "f0_med_flat", None)
+        if med_flat is not None:   # the native planner already holds f0 and its median-3 for the whole batch
+            f0_flat = plan.f0_out.flat
+            lf0_cat = la.f0_to_lf0((f0_flat > 0).astype('float') * med_flat)   # magphase.py:2499-2501
+            off = np.asarray(plan.out_off).tolist()
+        else:
+            f0_med = hm.medfilt3_batch(plan.f0_out)
+            # lf0 of the whole batch in one pass (la.f0_to_lf0 per utterance: the same element-wise operations)
+            sizes = [int(np.size(f)) for f in plan.f0_out]
+            lf0_cat = la.f0_to_lf0((np.concatenate(plan.f0_out) > 0).astype('float') * np.concatenate(f0_med)) if sizes else np.zeros(0)  # magphase.py:2499-2501
+            off = np.concatenate(([0], np.cumsum(sizes))).tolist()
         o_off = np.asarray(plan.out_off).tolist()
         shifts = plan.lossless.v_shift
         for u in range(len(utts)):

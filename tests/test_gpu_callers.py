@@ -265,3 +265,85 @@ def test_device_pcm16_on_ragged_lengths_around_the_peak_kernels_blocks():
             g = got[off[u]:off[u + 1]].astype(np.float64)
             ok = ~np.isnan(ref)
             assert np.array_equal(g[ok], ref[ok]), (dt, u)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# prepared launches (Engine.prepare_analysis / prepare_synthesis: native whole-launch planners, planner thread) give the
+# generic path's results bit for bit
+# ----------------------------------------------------------------------------------------------------------------------
+def _prep_utts(n=5, fs=48000):
+    from magphase_amd import synthetic as syn
+    return [(lambda r: (r[0], fs, r[1], r[2]))(syn.make_utterance(300 + u, dur_s=0.5 + 0.2 * u, fs=fs)) for u in range(n)]
+
+
+def test_prepared_analysis_equals_generic_path(monkeypatch):
+    from magphase_amd import hostplan, magphase as mp
+    from magphase_amd.engine import get_engine
+    if hostplan.pyhost() is None:
+        pytest.skip("_mpx_pyhost not built")
+    eng = get_engine()
+    utts = _prep_utts()
+    kw = dict(mag_dim=60, phase_dim=10, alpha_phase=False, as_float32=True)
+    monkeypatch.setenv("MAGPHASE_NATIVE_PREPARE", "0")
+    ref = mp.analysis_compressed_batch(utts, **kw)
+    ref_ll = mp.analysis_lossless_batch(utts, return_device=True)
+    monkeypatch.delenv("MAGPHASE_NATIVE_PREPARE")
+    prep = eng.prepare_async("analysis", utts).result()
+    assert prep is not None
+    for got in (mp.analysis_compressed_batch(utts, prepared=prep, **kw), mp.analysis_compressed_batch(utts, **kw)):
+        for a, b in zip(ref, got):
+            for x, y in zip(a[:5], b[:5]):
+                assert np.array_equal(np.asarray(x), np.asarray(y), equal_nan=True)
+            assert a[5:] == b[5:]
+    got_ll = mp.analysis_lossless_batch(utts, return_device=True)
+    for a, b in zip(ref_ll, got_ll):
+        for x, y in zip(a[:3], b[:3]):
+            assert bool((x == y).all())
+        assert np.array_equal(a[3], b[3], equal_nan=True) and np.array_equal(a[5], b[5])
+    # float64 / float32 samples take the float32 staging of the native path
+    utts64 = [(u[0].astype(np.float64) / 32768.0, u[1], u[2], u[3]) for u in utts]
+    monkeypatch.setenv("MAGPHASE_NATIVE_PREPARE", "0")
+    ref64 = mp.analysis_compressed_batch(utts64, **kw)
+    monkeypatch.delenv("MAGPHASE_NATIVE_PREPARE")
+    for a, b in zip(ref64, mp.analysis_compressed_batch(utts64, **kw)):
+        for x, y in zip(a[:5], b[:5]):
+            assert np.array_equal(np.asarray(x), np.asarray(y), equal_nan=True)
+    # a prepared object of another batch is refused
+    with pytest.raises(ValueError):
+        mp.analysis_compressed_batch(utts[:3], prepared=eng.prepare_analysis(utts), **kw)
+
+
+@pytest.mark.parametrize("b_const_rate", [False, True])
+def test_prepared_synthesis_equals_generic_path(monkeypatch, b_const_rate):
+    from magphase_amd import hostplan, magphase as mp
+    from magphase_amd.engine import get_engine
+    if hostplan.pyhost() is None:
+        pytest.skip("_mpx_pyhost not built")
+    eng = get_engine()
+    feats = [r[:4] for r in mp.analysis_compressed_batch(_prep_utts(4), mag_dim=60, phase_dim=45, b_const_rate=b_const_rate,
+                                                         as_float32=True)]
+    feats[1] = tuple(np.asarray(x, dtype=np.float64) for x in feats[1])   # one utterance in float64
+    kw = dict(b_const_rate=b_const_rate, b_out_hpf=True, b_post_filter=True, pcm16_norm=0.98)
+    monkeypatch.setenv("MAGPHASE_NATIVE_PREPARE", "0")
+    np.random.seed(5)
+    ref = mp.synthesis_from_compressed_batch(feats, 48000, **kw)
+    np.random.seed(5)
+    ref_f = mp.synthesis_from_compressed_batch(feats, 48000, b_const_rate=b_const_rate)
+    monkeypatch.delenv("MAGPHASE_NATIVE_PREPARE")
+    prep = eng.prepare_async("synthesis", feats, 48000, b_const_rate=b_const_rate).result()
+    assert prep is not None
+    np.random.seed(5)
+    got = mp.synthesis_from_compressed_batch(feats, 48000, prepared=prep, **kw)
+    np.random.seed(5)
+    got_f = mp.synthesis_from_compressed_batch(feats, 48000, b_const_rate=b_const_rate)
+    for a, b in zip(ref, got):
+        assert a.dtype == np.int16 and np.array_equal(a, b)
+    for a, b in zip(ref_f, got_f):
+        assert np.array_equal(a, b)
+    # a prepared object built for other flags is dropped (the constructor prepares again), not misused
+    prep2 = eng.prepare_synthesis(feats, 48000, b_const_rate=not b_const_rate)
+    if prep2 is not None:
+        np.random.seed(5)
+        again = mp.synthesis_from_compressed_batch(feats, 48000, prepared=prep2, **kw)
+        for a, b in zip(ref, again):
+            assert np.array_equal(a, b)

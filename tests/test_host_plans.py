@@ -364,3 +364,181 @@ def test_too_early_cuts_move_forward_instead_of_merging_runs():
     # no frame of the successor far enough: the cut is dropped, as before
     rel2 = np.array([0, 10, 20, 30, 40, 50, 5000, 5010])
     assert np.array_equal(hm._enforce_span(rel2, N, np.array([0, 2, 4, 6, 8])), np.array([0, 2, 6, 8]))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# whole-launch planners (mpx_host_plan_analysis_batch / _synthesis_batch through _mpx_pyhost) == the list-based forms
+# ----------------------------------------------------------------------------------------------------------------------
+def _pyhost():
+    from magphase_amd import hostplan as hp
+    ph = hp.pyhost()
+    if ph is None:
+        pytest.skip("_mpx_pyhost not built (no Python.h)")
+    return ph
+
+
+def _analysis_batch_utts():
+    from magphase_amd import synthetic as syn
+    rng = np.random.default_rng(1)
+    utts = []
+    for u in range(9):
+        fs = (48000, 16000)[u % 2] if u < 6 else 48000
+        pcm, pm, voi = syn.make_utterance(30 + u, dur_s=0.3 + 0.1 * u, fs=fs)
+        utts.append([pcm, fs, pm, voi])
+    pcm0, fs0, pm0, voi0 = utts[0]
+    n0 = len(pcm0)
+    utts.append([pcm0, fs0, np.r_[pm0, pm0[-1], pm0[-1] - 1e-4, n0 / fs0 + 0.01], np.r_[voi0, 1, 0, 1]])   # repeats, past the end
+    utts.append([pcm0, fs0, np.r_[0.0, pm0], np.r_[1.0, voi0]])                                            # first epoch at sample 0
+    utts.append([pcm0, fs0, (np.arange(1, 200) + 0.5) / fs0 * 37, rng.integers(0, 2, 199).astype(float)])   # half-even ties
+    utts.append([pcm0, fs0, np.r_[pm0[:5], pm0[5] + 0.2, pm0[6:] + 0.2], voi0])                              # a frame longer than fft_len
+    return utts
+
+
+@pytest.mark.parametrize("sig_kind", ["i16", "mixed"])
+def test_native_analysis_batch_equals_list_planner(sig_kind):
+    from magphase_amd import hostplan as hp, synthetic as syn
+    ph = _pyhost()
+    utts = _analysis_batch_utts()
+    if sig_kind == "mixed":
+        for k, u in enumerate(utts):
+            if k % 3 == 1:
+                u[0] = syn.pcm_to_float(u[0]).astype(np.float32)
+            elif k % 3 == 2:
+                u[0] = syn.pcm_to_float(u[0]).astype(np.float64) * 0.999
+    utts = [tuple(u) for u in utts]
+    m = ph.analysis_marshal(utts)
+    assert m is not None
+    U, total, E, all_i16 = ph.analysis_info(m)
+    assert U == len(utts) and total == sum(len(u[0]) for u in utts) and E == sum(len(u[2]) for u in utts)
+    assert all_i16 == (sig_kind == "i16")
+    stage = np.zeros(total + 8, dtype=np.int16 if all_i16 else np.float32)
+    pos, pm, left64 = (np.empty(E, dtype=np.int64) for _ in range(3))
+    left32, right32 = np.empty(E, dtype=np.int32), np.empty(E, dtype=np.int32)
+    voi32, f0, f0_med = np.empty(E, dtype=np.float32), np.empty(E), np.empty(E)
+    frame_off = np.empty(U + 1, dtype=np.int64)
+    lf, ll = np.empty(64, dtype=np.int64), np.empty(64, dtype=np.int64)
+    for n_thr in (1, 5):
+        F, n_long = ph.analysis_run(m, stage.ctypes.data, 0 if all_i16 else 1, pos, left32, right32, voi32, pm, left64, f0,
+                                    f0_med, frame_off, 4096, lf, ll, n_thr)
+        sig_off = np.concatenate(([0], np.cumsum([len(u[0]) for u in utts])))[:-1]
+        r = hp.plan_analysis([u[2] for u in utts], [u[3] for u in utts], [len(u[0]) for u in utts], [u[1] for u in utts], sig_off)
+        assert F == r["pos"].size and np.array_equal(frame_off, r["frame_off"])
+        assert np.array_equal(pos[:F], r["pos"]) and np.array_equal(pm[:F], r["pm"])
+        assert np.array_equal(left64[:F], r["left"]) and np.array_equal(left32[:F], r["left"])
+        assert np.array_equal(right32[:F], r["right"]) and np.array_equal(f0[:F], r["f0"], equal_nan=True)
+        with np.errstate(invalid="ignore"):
+            assert np.array_equal(voi32[:F], (r["f0"] > 0).astype(np.float32))
+        med = hm.medfilt3_batch([r["f0"][int(a):int(b)] for a, b in zip(frame_off[:-1], frame_off[1:])])
+        assert np.array_equal(f0_med[:F], np.concatenate(med), equal_nan=True)
+        tot = r["left"] + r["right"] + 1
+        hit = np.flatnonzero(tot > 4096)
+        assert n_long == hit.size and n_long >= 1
+        assert np.array_equal(lf[:n_long], hit) and np.array_equal(ll[:n_long], tot[hit])
+        o = 0
+        for u in utts:   # the staged samples: int16 as they are / float32 as the generic path converts them
+            x = np.asarray(u[0])
+            want = x if all_i16 else (x.astype(np.float32) * np.float32(1.0 / 32768.0) if x.dtype == np.int16 else x.astype(np.float32))
+            assert np.array_equal(stage[o:o + len(x)], want)
+            o += len(x)
+    # not the plain shape: a Python list of samples, float32 epochs, unequal lengths -> None (the generic path takes over)
+    assert ph.analysis_marshal([(list(range(10)), 48000, utts[0][2], utts[0][3])]) is None
+    assert ph.analysis_marshal([(utts[0][0], 48000, utts[0][2].astype(np.float32), utts[0][3])]) is None
+    assert ph.analysis_marshal([(utts[0][0], 48000, utts[0][2], utts[0][3][:-1])]) is None
+    # an utterance without epochs: negative code naming it
+    m2 = ph.analysis_marshal([utts[0], (utts[0][0], 48000, np.zeros(0), np.zeros(0))])
+    F, _ = ph.analysis_run(m2, 0, 1, pos, left32, right32, voi32, pm, left64, f0, f0_med, frame_off, 4096, lf, ll, 2)
+    assert F == -3
+
+
+@pytest.mark.parametrize("b_const_rate", [False, True])
+@pytest.mark.parametrize("fs,N,weighted", [(48000, 4096, True), (16000, 2048, False)])
+def test_native_synthesis_batch_equals_list_planner(b_const_rate, fs, N, weighted):
+    from magphase_amd import hostplan as hp
+    ph = _pyhost()
+    rng = np.random.RandomState(11 + int(b_const_rate))
+    utts, mag_dim, phase_dim = [], 60, 45
+    for u in range(7):
+        rows = int(rng.randint(40, 260))
+        f0 = np.where(rng.rand(rows) < 0.3, 0.0, rng.uniform(70, 300, rows))
+        f0[:3] = 0.0 if u % 2 else 150.0
+        with np.errstate(divide="ignore"):
+            lf0 = np.where(f0 > 0, np.log(np.maximum(f0, 1e-300)), -1e10)
+        dt = np.float32 if u % 2 == 0 else np.float64
+        utts.append((rng.randn(rows, mag_dim).astype(dt), rng.randn(rows, phase_dim).astype(dt),
+                     rng.randn(rows, phase_dim).astype(dt), lf0.astype(np.float32 if u % 3 == 0 else np.float64)))
+    m = ph.synthesis_marshal(utts)
+    assert m is not None
+    U, R, md, pd = ph.synthesis_info(m)
+    assert (U, md, pd) == (len(utts), mag_dim, phase_dim) and R == sum(u[0].shape[0] for u in utts)
+    lf0_cat = np.empty(R)
+    ph.synthesis_lf0(m, lf0_cat)
+    assert np.array_equal(lf0_cat, np.concatenate([u[3].astype(np.float64) for u in utts]))
+    f0 = np.exp(lf0_cat)
+    n_slots = 37
+    w = (1.0 + 0.5 * rng.rand(n_slots)).astype(np.float32) if weighted else None
+    wcum = np.concatenate(([0.0], np.cumsum(np.asarray(w, dtype=np.float64)))) if weighted else None
+    wsum = float(np.asarray(w, dtype=np.float64).sum()) if weighted else 0.0
+    stage = np.zeros(R * (mag_dim + 2 * phase_dim), dtype=np.float32)
+    cap = 2 * R + 2 * U
+    desc = np.zeros(hp.synth_desc_bytes(R, U, n_slots, True), dtype=np.uint8)
+    desc_off, counts = np.zeros(18, dtype=np.int64), np.zeros(8, dtype=np.int64)
+    v_shift, v_pm, voiced = np.empty(cap, dtype=np.int64), np.empty(cap, dtype=np.int64), np.empty(cap, dtype=np.int32)
+    frame_off = np.empty(U + 1, dtype=np.int64)
+    ns_len, out_start, out_len = (np.empty(U, dtype=np.int64) for _ in range(3))
+    runs_host = np.zeros(U + n_slots + 1, dtype=hm.OLA_RUN_DTYPE)
+    for n_thr in (1, 4):
+        F = ph.synthesis_run(m, stage.ctypes.data, f0, float(fs), N, int(b_const_rate), 1, n_slots, wcum, wsum, 1, desc, desc_off,
+                             v_shift, v_pm, voiced, frame_off, ns_len, out_start, out_len, runs_host, counts, n_thr)
+        r = hp.plan_synthesis([np.exp(u[3].astype(np.float64)) for u in utts], fs, N, b_const_rate, True)
+        assert F == r["v_pm"].size == counts[0] and np.array_equal(frame_off, r["frame_off"])
+        assert np.array_equal(v_shift[:F], r["v_shift"]) and np.array_equal(v_pm[:F], r["v_pm"])
+        assert np.array_equal(voiced[:F], r["voiced"]) and np.array_equal(ns_len, r["ns_len"])
+        assert np.array_equal(out_start, r["out_start"]) and np.array_equal(out_len, r["out_len"])
+        out_off = np.concatenate(([0], np.cumsum(r["out_len"]))).astype(np.int64)
+        runs, slot_off, slot_runs = hp.ola_runs(r["pm_rel"], r["frame_off"], r["out_start"], r["out_len"], out_off[:U], N,
+                                                n_slots, weights=w)
+        nr = int(counts[1])
+        assert nr == runs.size and counts[2] == slot_off.size - 1
+        assert np.array_equal(runs_host[:nr], runs)
+        tab = {}
+        sizes = {"utt_frame_off": U + 1, "tile_first": int(counts[6]), "out_start": U, "out_off": U + 1, "runs": 56 * nr,
+                 "slot_off": int(counts[2]) + 1, "slot_runs": nr}
+        for (name, dt), off in zip(hp.SYNTH_TABLES, desc_off.tolist()):
+            assert off % 256 == 0
+            n = sizes.get(name, F)
+            tab[name] = desc[off:off + n * np.dtype(dt).itemsize].view(dt)
+        assert np.array_equal(tab["utt_frame_off"], r["frame_off"]) and np.array_equal(tab["npos"], r["npos"])
+        for k in ("nleft", "nright", "wtype", "voiced", "row0", "row1", "win_l", "win_r", "pm_rel"):
+            assert np.array_equal(tab[k], r[k]), k
+        assert np.array_equal(tab["rowt"], r["rowt"].astype(np.float32))
+        assert np.array_equal(tab["out_start"], r["out_start"]) and np.array_equal(tab["out_off"], out_off)
+        assert np.array_equal(tab["runs"].view(hm.OLA_RUN_DTYPE), runs)
+        assert np.array_equal(tab["slot_off"], slot_off) and np.array_equal(tab["slot_runs"], slot_runs)
+        assert np.array_equal(tab["tile_first"], np.searchsorted(r["row0"], 31 * np.arange((R + 30) // 31 + 1), side="left"))
+        assert counts[4] == int(r["ns_len"].sum()) and counts[5] == int(out_off[-1]) and counts[7] == R
+        n_m, n_p = R * mag_dim, R * phase_dim
+        assert np.array_equal(stage[:n_m].reshape(R, mag_dim), np.concatenate([u[0] for u in utts]).astype(np.float32))
+        assert np.array_equal(stage[n_m:n_m + n_p].reshape(R, phase_dim), np.concatenate([u[1] for u in utts]).astype(np.float32))
+        assert np.array_equal(stage[n_m + n_p:].reshape(R, phase_dim), np.concatenate([u[2] for u in utts]).astype(np.float32))
+    # shapes the native path leaves to the generic one
+    bad = list(utts)
+    bad[2] = (bad[2][0], bad[2][1][:, :44], bad[2][2][:, :44], bad[2][3])            # another phase dimension
+    assert ph.synthesis_marshal(bad) is None
+    bad[2] = (utts[2][0][:-1], utts[2][1], utts[2][2], utts[2][3])                   # frame counts disagree
+    assert ph.synthesis_marshal(bad) is None
+    bad[2] = (utts[2][0].T.copy().T, utts[2][1], utts[2][2], utts[2][3])             # not C-contiguous
+    assert ph.synthesis_marshal(bad) is None
+    # an utterance the numpy form raises on (one row): negative code naming it
+    one = list(utts) + [(utts[0][0][:1], utts[0][1][:1], utts[0][2][:1], utts[0][3][:1])]
+    m1 = ph.synthesis_marshal(one)
+    _, R1, _, _ = ph.synthesis_info(m1)
+    f1 = np.empty(R1)
+    ph.synthesis_lf0(m1, f1)
+    np.exp(f1, out=f1)
+    st1 = np.zeros(R1 * (mag_dim + 2 * phase_dim), dtype=np.float32)
+    big = lambda n, dt=np.int64: np.empty(n, dtype=dt)   # noqa: E731
+    rc = ph.synthesis_run(m1, st1.ctypes.data, f1, float(fs), N, int(b_const_rate), 1, n_slots, None, 0.0, 1,
+                          np.zeros(hp.synth_desc_bytes(R1, U + 1, n_slots, True), dtype=np.uint8), desc_off, big(2 * R1 + 2 * U + 2),
+                          big(2 * R1 + 2 * U + 2), big(2 * R1 + 2 * U + 2, np.int32), big(U + 2), big(U + 1), big(U + 1), big(U + 1),
+                          np.zeros(U + n_slots + 2, dtype=hm.OLA_RUN_DTYPE), counts, 2)
+    assert rc == -(U + 2)

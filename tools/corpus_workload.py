@@ -102,11 +102,20 @@ def run_extraction(rank, mine, dur, fs):
                 t_.wait()
                 t_.release()
                 nw += 1
-        # pipelined form (see run_generation): a launch's features are taken one launch later, all of them inside the clock
+        # pipelined form (see run_generation): a launch's features are taken one launch later, all of them inside the clock;
+        # the host side of launch i + 1 (native planners, samples into page-locked memory) is prepared on the engine's planner
+        # thread while this thread enqueues launch i (engine.prepare_async; the plan constructors take the result)
+        from magphase_amd.engine import get_engine
+
+        eng = get_engine()
         t0 = time.perf_counter()
         frames, prev = 0, None
-        for b in _batches(items):
-            cur = mp.analysis_compressed_batch(b, async_out=True, **kw)
+        todo = _batches(items)
+        fut = eng.prepare_async("analysis", todo[0]) if todo else None
+        for i, b in enumerate(todo):
+            prep = fut.result()
+            fut = eng.prepare_async("analysis", todo[i + 1]) if i + 1 < len(todo) else None
+            cur = mp.analysis_compressed_batch(b, async_out=True, prepared=prep, **kw)
             if prev is not None:
                 prev[1].wait()
                 frames += sum(int(r[0].shape[0]) for r in prev[0])
@@ -164,14 +173,20 @@ def run_generation(rank, mine, dur, fs):
                 ticket.release()
             return smpls
 
-        def synth(batch):
+        def groups_of(batch):   # one launch per sample rate
+            return [(rate, [x for r, x in batch if r == rate]) for rate in sorted(set(r for r, _ in batch))]
+
+        def synth(groups, prepared=None):
             frames = 0
-            for rate in sorted(set(r for r, _ in batch)):
-                group = [x for r, x in batch if r == rate]
+            for k, (rate, group) in enumerate(groups):
                 pending.append(mp.synthesis_from_compressed_batch(group, rate, b_out_hpf=True, b_post_filter=True,
-                                                                  pcm16_norm=0.98, async_out=True, defer_rng=True))
+                                                                  pcm16_norm=0.98, async_out=True, defer_rng=True,
+                                                                  prepared=prepared[k].result() if prepared else None))
                 frames += sum(int(g[0].shape[0]) for g in group)
             return frames
+
+        def prepare(groups):   # the launches' host side on the planner thread, one batch ahead (see run_extraction)
+            return [eng.prepare_async("synthesis", group, rate) for rate, group in groups]
 
         np.random.seed(1000 + rank)
         gc.collect()
@@ -180,14 +195,17 @@ def run_generation(rank, mine, dur, fs):
             big = max(_batches(items, BATCH_GEN), key=lambda b: sum(int(x[1][0].shape[0]) for x in b))
             tw, nw = time.perf_counter(), 0
             while nw < 2 or time.perf_counter() - tw < WARM_S:   # (see run_extraction)
-                synth(big)
+                synth(groups_of(big))
                 take(0)
                 nw += 1
             eng.mt_sync()
         t0 = time.perf_counter()
         frames, smpls = 0, 0
-        for b in _batches(items, BATCH_GEN):
-            frames += synth(b)
+        todo = [groups_of(b) for b in _batches(items, BATCH_GEN)]
+        fut = prepare(todo[0]) if todo else None
+        for i, g in enumerate(todo):
+            cur, fut = fut, (prepare(todo[i + 1]) if i + 1 < len(todo) else None)
+            frames += synth(g, cur)
             smpls += take(2)            # the two rate groups of the launch just issued stay in flight
         smpls += take(0)
         eng.mt_sync()
