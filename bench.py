@@ -748,25 +748,30 @@ def live_traffic(timeout_s=170):
     vals, launches = {}, {}
     t_start = time.perf_counter()
     try:
-        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES"):
             left = timeout_s - (time.perf_counter() - t_start)
             if left < 20:
+                if ctr.startswith("SQ_"):
+                    break                  # the instruction counts are an extra: the traffic passes are what must be there
                 return None, "time budget for the PMC passes used up"
-            d = os.path.join(tmp, ctr)
-            cmd = [rocprof, "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "pmc", "--",
+            d = os.path.join(tmp, ctr.split()[0])
+            cmd = [rocprof, "--pmc"] + ctr.split() + ["--kernel-trace", "--output-format", "csv", "-d", d, "-o", "pmc", "--",
                    sys.executable, os.path.join(ROOT, "bench.py"), "--pmc-child", "--steps", "3", "--warmup", "1", "--streams", "1"]
             r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=left)
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
+                if ctr.startswith("SQ_"):
+                    break
                 return None, "rocprofv3 --pmc %s pass failed (rc %d)" % (ctr, r.returncode)
             for f in files:
                 with open(f) as fh:
                     for row in csv.DictReader(fh):
-                        if row.get("Counter_Name") != ctr:
+                        if row.get("Counter_Name") not in ctr.split():
                             continue
+                        ctr_ = row["Counter_Name"]
                         k = _short_kernel_name(row["Kernel_Name"])
                         if k.startswith("k_"):
-                            vals.setdefault(k, {}).setdefault(ctr, []).append(float(row["Counter_Value"]))
+                            vals.setdefault(k, {}).setdefault(ctr_, []).append(float(row["Counter_Value"]))
     except Exception as e:   # timeout, no permission for the counters, ...
         return None, "live PMC passes unavailable: %s" % type(e).__name__
     finally:
@@ -777,6 +782,9 @@ def live_traffic(timeout_s=170):
             f_, w_ = c["FETCH_SIZE"], c["WRITE_SIZE"]
             out[k] = (2.0 * sum(f_) / len(f_) + sum(w_) / len(w_)) * 1024.0
             launches[k] = len(f_)
+    # wave-level instruction counts per launch (SQ_INSTS_*: the third pass), for roofline.valu
+    out["_insts"] = {k: {c_: sum(v_) / len(v_) for c_, v_ in c.items() if c_.startswith("SQ_")} for k, c in vals.items()
+                     if any(c_.startswith("SQ_") for c_ in c)}
     if "k_noise_stats" in out:
         ks = [k for k in LOWDIM_KERNELS if k in out]
         out["lowdim_step"] = sum(max(1, round(launches[k] / launches["k_noise_stats"])) * out[k] for k in ks)
@@ -872,7 +880,9 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--streams", type=int, default=2,
-                    help="HIP streams that consecutive (independent) steps alternate between; 1 = one step at a time")
+                    help="HIP streams of the SECONDARY figure (value_overlapped / ms_per_step_overlapped): consecutive "
+                         "(independent) steps alternating between that many streams.  `value` / `ms_per_step` are always "
+                         "one step at a time on one stream; 1 = no secondary figure")
     ap.add_argument("--form", choices=("one", "two"), default=os.environ.get("BENCH_FORM", "one"),
                     help="one: a step = ONE launch that analyses every frame, writes its feature rows and overlap-adds the "
                          "frame rebuilt from them (mpx_roundtrip_lossless_ola + mpx_ola_fixup); two: mpx_analysis_frames, then "
@@ -904,6 +914,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    from magphase_amd import sharding as _sharding
+    # every rank on its own share of the cores next to its GPU (its native staging threads inherit it): the reference's
+    # model is one worker per core with nothing shared (libutils.py:61-62)
+    core_binding = _sharding.bind_rank_to_cores(local_rank, world) if world > 1 else None
     # BENCH_DIST_BACKEND=gloo + BENCH_SHARE_DEVICE=1: test hook to exercise the N > 1 code path on a 1-GPU box
     backend = os.environ.get("BENCH_DIST_BACKEND", "nccl")
     dev_index = 0 if os.environ.get("BENCH_SHARE_DEVICE") else local_rank
@@ -1053,22 +1067,30 @@ def main():
     # 0.5 s after the last launch, for the record.
     PRECOND_STEPS = 0 if args.pmc_child else 64
     for i in range(PRECOND_STEPS):
-        step(i)
-    dt = timed()
-    dt_one = dt_idle = None
+        step(i, one_stream=True)
+    # THE timed region: W warm-up steps, then exactly K steps between barriers, one step at a time on ONE stream -- the
+    # figure a reader can reconcile with rocprofv3's kernel durations (ms_per_step = the dominant kernel + the fix-up)
+    dt = timed(one_stream=True)
+    dt_ov = dt_idle = dt_two = None
     if not args.pmc_child and not args.no_idle_probe:
         time.sleep(0.5)
-        dt_idle = timed()
+        dt_idle = timed(one_stream=True)
         for i in range(PRECOND_STEPS):
-            step(i)
-        torch.cuda.synchronize()
-    if n_streams > 1 and not args.pmc_child:   # for the record: the same K steps one at a time (untimed for `value`)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for i in range(args.steps):
             step(i, one_stream=True)
         torch.cuda.synchronize()
-        dt_one = time.perf_counter() - t1
+    if n_streams > 1 and not args.pmc_child:   # secondary figure: consecutive (independent) steps alternating between streams
+        dt_ov = timed()                        # (the next step's analysis fills the tail of this step's launch)
+    if not args.pmc_child and not args.quick:  # the same K steps in the OTHER form (what a caller of the reference's two
+        step_other = step_two if one else step_one   # functions, analysis_lossless then synthesis_from_lossless, gets)
+        with torch.cuda.stream(streams[0]):
+            for _ in range(args.warmup):
+                step_other(*bufs[0])
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                step_other(*bufs[0])
+            barrier()
+            dt_two = time.perf_counter() - t1
     if args.pmc_child:      # profiled by live_traffic(): the other form and a few configs[2] steps as well, then done (no JSON line)
         from magphase_amd import engine as em
 
@@ -1089,9 +1111,11 @@ def main():
         return
     dt_own = dt
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
+        t = torch.tensor([dt, dt_ov or 0.0, dt_two or 0.0], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt = float(t[0].item())
+        dt_ov = float(t[1].item()) if dt_ov else None
+        dt_two = float(t[2].item()) if dt_two else None
         fr = torch.tensor([float(F)], dtype=torch.float64, device=red_dev)
         dist.all_reduce(fr, op=dist.ReduceOp.SUM)
         total_frames = float(fr.item())
@@ -1163,9 +1187,39 @@ def main():
         except Exception:
             rank_power = None
     rp = (rank_power or {}).get("phases", {}).get("headline_step", {})
+    # Host side of ONE launch (Engine.prepare_analysis of this rank's 64-utterance batch: native planner + the samples
+    # into page-locked memory, no stream touched), every rank at the same time between barriers -- and, for N > 1, rank 0
+    # once more ALONE while the others wait: what the ranks cost each other on the host (memory system, cores).
+    def host_prepare_ms(reps=12):
+        ts = []
+        for _ in range(reps):
+            t0_ = time.perf_counter()
+            p_ = eng.prepare_analysis(utts)
+            ts.append(time.perf_counter() - t0_)
+            if p_ is not None:
+                p_.release()
+        ts.sort()
+        return 1e3 * ts[len(ts) // 2]
+
+    host_ms = host_ms_alone = float("nan")
+    if not args.quick:
+        try:
+            host_prepare_ms(3)
+            barrier()
+            host_ms = host_prepare_ms()
+            barrier()
+            if world > 1:
+                if rank == 0:
+                    host_ms_alone = host_prepare_ms()
+                barrier()
+        except Exception:
+            pass
+    n_cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     mine = [float(rank), float(dev_index), dt_own / args.steps * 1e3, ms[dom], moved_dom / (ms[dom] * 1e-3) / 1e9,
             alg[dom] / (ms[dom] * 1e-3) / 1e9, float(F), rp.get("board_W") or float("nan"),
-            rp.get("energy_above_idle_J") or float("nan"), rp.get("frac_of_cap") or float("nan")]
+            rp.get("energy_above_idle_J") or float("nan"), rp.get("frac_of_cap") or float("nan"),
+            host_ms, float(n_cores), float(eng.host_threads(32 << 20)),
+            float(core_binding["numa_node"]) if (core_binding and core_binding.get("numa_node") is not None) else float("nan")]
     if dist is not None:
         mt = torch.tensor(mine, dtype=torch.float64, device=red_dev)
         allr = [torch.zeros_like(mt) for _ in range(world)]
@@ -1180,8 +1234,22 @@ def main():
     per_rank = [{"rank": int(r_[0]), "device": int(r_[1]), "ms_per_step": _num(r_[2], 4), "kernel": names[dom],
                  "kernel_ms": _num(r_[3], 4), "moved_GBps": _num(r_[4], 1), "frac": _num(r_[4] / HBM_PEAK_GBS, 4),
                  "alg_8d_GBps": _num(r_[5], 1), "frac_8d": _num(r_[5] / HBM_PEAK_GBS, 4), "frames": int(r_[6]),
-                 "board_W": _num(r_[7], 1), "energy_above_idle_J": _num(r_[8], 4), "frac_of_cap": _num(r_[9], 3)}
+                 "board_W": _num(r_[7], 1), "energy_above_idle_J": _num(r_[8], 4), "frac_of_cap": _num(r_[9], 3),
+                 "host_prepare_ms": _num(r_[10], 4), "host_cores": int(r_[11]), "native_threads_cap": int(r_[12]),
+                 "numa_node": (None if r_[13] != r_[13] else int(r_[13]))}
                 for r_ in allr]
+    hp_ = [r_["host_prepare_ms"] for r_ in per_rank if r_["host_prepare_ms"] is not None]
+    host_contention = None
+    if hp_:
+        host_contention = {
+            "what": "host side of one 64-utterance launch (Engine.prepare_analysis: native planner + 30 MB of samples into "
+                    "page-locked memory), median of 12, every rank at the same time",
+            "ms_max_over_ranks": max(hp_), "ms_mean_over_ranks": round(sum(hp_) / len(hp_), 4),
+            "ms_rank0_alone": (_num(host_ms_alone, 4) if world > 1 else None),
+            "ratio_together_over_alone": (round(max(hp_) / host_ms_alone, 3) if (world > 1 and host_ms_alone == host_ms_alone
+                                                                                 and host_ms_alone > 0) else None),
+            "cores_bound": bool(core_binding), "cores_per_rank": per_rank[0]["host_cores"],
+            "native_threads_cap": per_rank[0]["native_threads_cap"]}
     live, live_src = (live_traffic() if (full and args.traffic == "live") else (None, "not requested"))
     if live is not None and names[dom] in live:
         traffic, traffic_src = live[names[dom]], live_src
@@ -1215,6 +1283,32 @@ def main():
             "kernel_time_source": "HIP events on the launch stream, mean of %d launches in this process (the rocprofv3 "
                                   "--kernel-trace --stats summary of this command: profiles/, latest r05_*kernel_stats.csv)" % reps,
             "path_alg_GBps": round(sum(alg) / (sum(ms) * 1e-3) / 1e9, 1)}
+    # The VALU side (SQ_INSTS_VALU of the live third PMC pass): wave-level vector instructions per frame, and their issue rate
+    # against what this chip sustains -- a pure v_fma_f32 stream saturates at 0.80 G wave-instructions / s per SIMD whatever
+    # the occupancy (tools/archive/pk_probe.hip, clock_probe.hip: the board's power limit sets the clock), 1024 SIMDs.
+    insts = (live or {}).get("_insts", {}).get(names[dom]) if live is not None else None
+    VALU_SAT_G = 0.80
+    n_simd = 4 * int(torch.cuda.get_device_properties(dev_index).multi_processor_count)
+    if insts and insts.get("SQ_INSTS_VALU"):
+        v_ = insts["SQ_INSTS_VALU"]
+        rate = v_ / (ms[dom] * 1e-3) / n_simd / 1e9
+        roof["valu"] = {"insts_per_launch": round(v_, 0), "insts_per_frame": round(v_ / F, 1),
+                        "salu_per_frame": (round(insts.get("SQ_INSTS_SALU", 0.0) / F, 1) if insts.get("SQ_INSTS_SALU") else None),
+                        "lds_per_frame": (round(insts.get("SQ_INSTS_LDS", 0.0) / F, 1) if insts.get("SQ_INSTS_LDS") else None),
+                        "butterfly_floor_per_frame": 2112,
+                        "rate_G_per_s_per_simd": round(rate, 4), "sat_rate_G_per_s_per_simd": VALU_SAT_G, "simds": n_simd,
+                        "frac": round(rate / VALU_SAT_G, 4),
+                        "source": "SQ_INSTS_VALU of this run's third rocprofv3 --pmc child pass / HIP-event kernel time; "
+                                  "saturation rate: tools/archive/pk_probe.hip (v_fma_f32 stream at the board's power limit)"}
+        cand = {"hbm": roof["frac"], "valu": roof["valu"]["frac"]}
+        pw_ = (rank_power or {}).get("phases", {}).get("headline_step", {}).get("frac_of_cap")
+        if pw_:
+            cand["power"] = pw_
+        roof["bound"] = max(cand, key=cand.get)
+        roof["bound_candidates"] = {k_: round(v__, 4) for k_, v__ in cand.items()}
+        roof["bound_note"] = ("fractions of the three ceilings this launch runs against: hbm = bytes moved / time / 8 TB/s, valu = "
+                              "wave-level VALU instructions / time / saturation rate, power = board watts / cap while the step "
+                              "loops; `bound` names the largest (frac / achieved / peak above stay the HBM ones, per the bench contract)")
     other_key = "two_launch" if one else "one_launch"
     roof[other_key] = {"kernels": kern_other, "kernel_sum_ms": round(sum(ms_other), 4),
                        "path_alg_GBps": round(sum(alg_other) / (sum(ms_other) * 1e-3) / 1e9, 1),
@@ -1281,6 +1375,8 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(ms_step, 4),
+            "value_two_launch": (round(total_frames * args.steps / dt_two, 1) if (dt_two and one) else None),
+            "value_overlapped": (round(total_frames * args.steps / dt_ov, 1) if dt_ov else None),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -1295,21 +1391,31 @@ def main():
                        "frames_per_gpu": F, "audio_s_per_gpu": UTTS_PER_GPU * DUR_S,
                        "x_realtime": round(UTTS_PER_GPU * DUR_S * world / (dt / args.steps), 1),
                        "parallelism": "utterance-sharded x%d, no collective" % world,
-                       "streams": n_streams,
-                       "stream_pick": stream_pick,
-                       "ms_per_step_single_stream": (round(dt_one / args.steps * 1e3, 4) if dt_one else None),
+                       "streams": 1,
+                       "ms_per_step_single_stream": round(ms_step, 4),   # (== ms_per_step since round 6; kept for readers of old lines)
+                       "overlapped": ({"streams": n_streams, "stream_pick": stream_pick,
+                                       "ms_per_step_overlapped": round(dt_ov / args.steps * 1e3, 4),
+                                       "value_overlapped": round(total_frames * args.steps / dt_ov, 1),
+                                       "note": "the same K steps alternating between %d HIP streams with their own feature / "
+                                               "output buffers (the next step's analysis fills the tail of this step's launch): "
+                                               "rounds 3-5 printed THIS as `value`" % n_streams} if dt_ov else None),
+                       "other_form": ({"form": "two launches per step (mpx_analysis_frames, then mpx_synthesis_lossless_ola "
+                                               "reading the rows back, + mpx_ola_fixup): what analysis_lossless followed by "
+                                               "synthesis_from_lossless costs" if one else "one launch per step",
+                                       "ms_per_step": round(dt_two / args.steps * 1e3, 4),
+                                       "value": round(total_frames * args.steps / dt_two, 1)} if dt_two else None),
                        "ms_per_step_from_idle": (round(dt_idle / args.steps * 1e3, 4) if dt_idle else None),
                        "power_state_note": "%d untimed steps take the device out of its post-idle power transient before the "
                                            "W warm-up steps (the plans are built on the host with the GPU idle; "
                                            "tools/archive/step_curve_probe.py); ms_per_step_from_idle = the same W + K steps started "
                                            "0.5 s after the last launch" % PRECOND_STEPS,
-                       "streams_note": "consecutive steps alternate between %d HIP streams with their own feature / output "
-                                       "buffers (the next step's analysis fills the tail of this step's synthesis launch); "
-                                       "ms_per_step_single_stream = the same K steps one at a time, same process" % n_streams,
+                       "streams_note": "value / ms_per_step: one step at a time on one stream (the figure rocprofv3's kernel "
+                                       "durations add up to); config.overlapped: the same steps alternating between HIP streams",
                        "ola_runs": (rt.synthesis.n_runs if one else splan.n_runs),
                        "host_plan_build_s": round(t_plan, 4), "host_plan_build_cold_s": round(t_plan_cold, 3)},
             "roofline": roof,
             "per_rank": per_rank,
+            "host_contention": host_contention,
         }
         if full and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(utts, _cpu_lossless, "lossless analysis+synthesis of 5 s utterances",

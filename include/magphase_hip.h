@@ -679,8 +679,9 @@ int64_t mpx_host_ola_runs(int32_t n_utts, const int64_t* pm_rel, const int64_t* 
  *   - host results: v_shift, v_pm (int64), voiced_host (int32) with capacity 2 R + 2 U; frame_off [U+1]; ns_len, out_start,
  *     out_len [U]; runs_host (capacity runs_cap >= U + n_slots + 1);
  *     counts[8] = {frames, runs, slots in use, bytes of desc in use, noise samples, output samples, tiles + 1, R}.
- * Returns the number of frames; -(u + 2): the numpy form raises on utterance u; <= -1000000: a capacity / table-order /
- * slot-count case left to the numpy form; -1: bad arguments.
+ * Returns the number of frames; -(u + 2): the numpy form raises on utterance u; -4000000: weighted shares and fewer frames
+ * than slots (counts[0] = frames: call again with n_slots = frames and the first `frames` weights' cumsum / sum); other
+ * values <= -1000000: a capacity / table-order case left to the numpy form; -1: bad arguments.
  */
 int64_t mpx_host_plan_synthesis_batch(int32_t n_utts, const void* const* mag, const void* const* real,
                                       const void* const* imag, const int32_t* kind, const int64_t* n_rows,

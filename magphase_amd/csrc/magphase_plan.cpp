@@ -683,7 +683,10 @@ int64_t mpx_host_plan_synthesis_batch(int32_t n_utts, const void* const* mag, co
     }
     // ---- OLA runs and the slots' work lists (hostmath.ola_runs / hostplan.ola_runs)
     const int32_t ns = (int32_t)std::min<int64_t>(n_slots, std::max<int64_t>(F, 1));
-    if (wcum && ns != n_slots) return -4000000;   // fewer frames than slots: the weights are cut (numpy's sum): numpy form
+    if (wcum && ns != n_slots) {   // fewer frames than slots: the weights are cut to the first F (their sum is numpy's):
+        counts[0] = F;             // the caller calls again with n_slots = F and the cut weights' cumsum / sum
+        return -4000000;
+    }
     std::vector<int64_t> gcuts;
     slot_cuts(F, ns, wcum, wsum, gcuts);
     const int64_t nr = mpx_host_ola_runs(U, rel64.data(), frame_off, out_start, out_len, out_off.data(), fft_len,

@@ -753,10 +753,17 @@ class Engine:
             ns_len, out_start, out_len = (np.empty(U, dtype=np.int64) for _ in range(3))
             runs_host = np.zeros(U + n_slots + 1, dtype=hm.OLA_RUN_DTYPE)
             counts, desc_off = np.zeros(8, dtype=np.int64), np.zeros(18, dtype=np.int64)
-            F = ph.synthesis_run(m, slot["stage"].data_ptr(), f0, float(fs), N, int(bool(b_const_rate)),
-                                 int(bool(b_voi_ap_win)), int(n_slots), wcum, float(wsum), int(unwarp_rows),
-                                 slot["desc_np"][:desc_cap], desc_off, v_shift, v_pm, voiced_host, frame_off, ns_len,
-                                 out_start, out_len, runs_host, counts, self.host_threads(stage_bytes))
+            def run(n_sl, wc, ws, stage_ptr):
+                return ph.synthesis_run(m, stage_ptr, f0, float(fs), N, int(bool(b_const_rate)), int(bool(b_voi_ap_win)),
+                                        int(n_sl), wc, float(ws), int(unwarp_rows), slot["desc_np"][:desc_cap], desc_off,
+                                        v_shift, v_pm, voiced_host, frame_off, ns_len, out_start, out_len, runs_host, counts,
+                                        self.host_threads(stage_bytes))
+
+            F = run(n_slots, wcum, wsum, slot["stage"].data_ptr())
+            if F == -4000000 and 0 < counts[0] < n_slots:   # fewer frames than slots: shares by the first F weights
+                nf = int(counts[0])                        # (hostmath.slot_cuts: w[:ns], their sum numpy's)
+                w64 = np.asarray(self.synth_ola_slot_weights(comp=True), dtype=np.float64)[:nf]
+                F = run(nf, np.ascontiguousarray(np.concatenate(([0.0], np.cumsum(w64)))), float(w64.sum()), 0)
             if F < 0:
                 self._slot_release(slot)
                 return None

@@ -43,6 +43,7 @@ def main():
     if world > 1:
         import torch
         torch.cuda.set_device(sharding.local_device_index())
+        sharding.bind_rank_to_cores(local_rank, world)   # this rank's share of the cores next to its GPU (libutils.py:61-62)
     sizes = [os.path.getsize(os.path.join(args.wav_dir, t + ".wav")) if os.path.isfile(os.path.join(args.wav_dir, t + ".wav"))
              else 0 for t in tokens]
     mine = sharding.shard_by_cost(sizes, world)[rank]
@@ -53,19 +54,36 @@ def main():
     elif world > 1 and not args.direct:
         final_dir, args.out_dir = args.out_dir, os.path.join(args.out_dir, ".rank%d" % rank)
         if os.path.isdir(args.out_dir):   # left by a run that was killed: its files are NOT this run's results
+            import shutil
             stale = os.listdir(args.out_dir)
             for n in stale:
-                os.remove(os.path.join(args.out_dir, n))
+                q = os.path.join(args.out_dir, n)
+                shutil.rmtree(q, ignore_errors=True) if os.path.isdir(q) and not os.path.islink(q) else os.remove(q)
             if stale:
                 print("[rank %d] removed %d stale files of an earlier, interrupted run from %s" % (rank, len(stale), args.out_dir))
         lu.mkdir(args.out_dir)
 
     def move_up():   # this rank's finished files (and its crash list) move up into the common directory
+        # Runs after ANY exit of the block below (an interrupt included): files are written under "<name>.part~" and renamed
+        # when complete (mpx_host_write_files), so whatever carries its final name is whole -- unfinished ones stay behind --
+        # and an error here must not replace the exception that is already on its way out.
         if final_dir is None or not os.path.isdir(args.out_dir):
             return
+        left = 0
         for n in os.listdir(args.out_dir):
-            os.rename(os.path.join(args.out_dir, n), os.path.join(final_dir, n))
-        os.rmdir(args.out_dir)
+            if n.endswith(".part~"):
+                left += 1
+                continue
+            try:
+                os.rename(os.path.join(args.out_dir, n), os.path.join(final_dir, n))
+            except OSError as e:
+                left += 1
+                print("[rank %d] could not move %s up: %s" % (rank, n, e))
+        if not left:
+            try:
+                os.rmdir(args.out_dir)
+            except OSError:
+                pass
 
     try:   # whatever stops this rank mid-corpus, what it finished is where consumers of OUT_DIR look for it
         if args.batch > 0:   # reader thread / kernels / writer thread overlapped, args.batch utterances per launch

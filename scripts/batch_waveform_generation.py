@@ -45,6 +45,7 @@ def main():
     if world > 1:
         import torch
         torch.cuda.set_device(sharding.local_device_index())
+        sharding.bind_rank_to_cores(local_rank, world)   # this rank's share of the cores next to its GPU (libutils.py:61-62)
     fs_map = {}
     if args.fs_map:
         for line in open(args.fs_map):

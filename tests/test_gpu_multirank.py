@@ -67,6 +67,17 @@ def test_bench_two_ranks_on_one_device():
     assert abs(roof["frac"] - roof["moved_bytes"] / (roof["kernels"][0]["ms"] * 1e-3) / 1e9 / roof["peak"]) < 2e-3
     assert roof["frac_8d"] >= roof["frac"] and roof["alg_bytes_8d"] >= roof["moved_bytes"]
     assert "configs2" in j2 and "ms_per_step" in j2["configs2"]
+    # host hygiene: every rank on its own cores, its native threads capped by them, and the host side
+    # of a launch measured with all ranks at once against rank 0 alone
+    hc = j2["host_contention"]
+    assert hc["cores_bound"] and hc["ms_rank0_alone"] > 0 and hc["ms_max_over_ranks"] > 0
+    assert hc["ratio_together_over_alone"] is not None and hc["ratio_together_over_alone"] < 2.0
+    ncpu = len(os.sched_getaffinity(0))
+    for r in pr:
+        assert 1 <= r["native_threads_cap"] <= r["host_cores"] <= max(1, ncpu // 2) + 1 and r["host_prepare_ms"] > 0
+    # the headline is one step at a time on one stream; the overlapped figure and the two-launch form stand beside it
+    assert j2["config"]["streams"] == 1 and j2["value_overlapped"] >= 0.9 * j2["value"]
+    assert j2["value_two_launch"] > 0 and j2["config"]["other_form"]["ms_per_step"] > j2["ms_per_step"] * 0.9
 
 
 def test_bench_launches_its_own_ranks():

@@ -542,3 +542,44 @@ def test_native_synthesis_batch_equals_list_planner(b_const_rate, fs, N, weighte
                           big(2 * R1 + 2 * U + 2), big(2 * R1 + 2 * U + 2, np.int32), big(U + 2), big(U + 1), big(U + 1), big(U + 1),
                           np.zeros(U + n_slots + 2, dtype=hm.OLA_RUN_DTYPE), counts, 2)
     assert rc == -(U + 2)
+
+
+def test_native_synthesis_batch_with_fewer_frames_than_slots():
+    """Weighted shares and fewer frames than slots: the native planner asks for the first F weights' cumsum / sum (their sum
+    is numpy's pairwise one) and then equals hostmath.slot_cuts' cut-down shares."""
+    from magphase_amd import hostplan as hp
+    ph = _pyhost()
+    rng = np.random.RandomState(3)
+    utts = []
+    for u in range(3):
+        rows = 30 + 5 * u
+        lf0 = np.log(rng.uniform(80, 250, rows))
+        utts.append((rng.randn(rows, 60).astype(np.float32), rng.randn(rows, 45).astype(np.float32),
+                     rng.randn(rows, 45).astype(np.float32), lf0))
+    m = ph.synthesis_marshal(utts)
+    U, R, _, _ = ph.synthesis_info(m)
+    f0 = np.empty(R)
+    ph.synthesis_lf0(m, f0)
+    np.exp(f0, out=f0)
+    n_slots = 1536
+    w = (1.0 + 0.5 * rng.rand(n_slots)).astype(np.float32)
+    w64 = np.asarray(w, dtype=np.float64)
+    cap = 2 * R + 2 * U
+    desc = np.zeros(hp.synth_desc_bytes(R, U, n_slots, True), dtype=np.uint8)
+    desc_off, counts = np.zeros(18, dtype=np.int64), np.zeros(8, dtype=np.int64)
+    outs = (np.empty(cap, dtype=np.int64), np.empty(cap, dtype=np.int64), np.empty(cap, dtype=np.int32),
+            np.empty(U + 1, dtype=np.int64), np.empty(U, dtype=np.int64), np.empty(U, dtype=np.int64), np.empty(U, dtype=np.int64))
+    runs_host = np.zeros(U + n_slots + 1, dtype=hm.OLA_RUN_DTYPE)
+
+    def run(ns, wc, ws):
+        return ph.synthesis_run(m, 0, f0, 48000.0, 4096, 0, 1, ns, wc, ws, 1, desc, desc_off, *outs, runs_host, counts, 2)
+
+    assert run(n_slots, np.concatenate(([0.0], np.cumsum(w64))), float(w64.sum())) == -4000000
+    F = int(counts[0])
+    assert F == R < n_slots
+    assert run(F, np.concatenate(([0.0], np.cumsum(w64[:F]))), float(w64[:F].sum())) == F
+    r = hp.plan_synthesis([np.exp(u[3]) for u in utts], 48000, 4096, False, True)
+    out_off = np.concatenate(([0], np.cumsum(r["out_len"]))).astype(np.int64)
+    runs, slot_off, _ = hp.ola_runs(r["pm_rel"], r["frame_off"], r["out_start"], r["out_len"], out_off[:U], 4096, n_slots, weights=w)
+    nr = int(counts[1])
+    assert nr == runs.size and np.array_equal(runs_host[:nr], runs) and counts[2] == slot_off.size - 1 == F

@@ -100,3 +100,23 @@ def test_corpus_spec_shards_cover_the_10k_corpus_evenly():
         assert sorted(np.concatenate(shards).tolist()) == list(range(10000))
         loads = np.array([cost[s].sum() for s in shards])
         assert loads.max() / loads.mean() < 1.001
+
+
+def test_rank_core_sets_partition_numa_nodes():
+    """sharding.rank_core_sets: the cores of a GPU's NUMA node split evenly among the ranks on that node, disjoint sets;
+    without NUMA information an even split of everything allowed (libutils.py:61-62: one worker per core, nothing shared)."""
+    from magphase_amd import sharding as sh
+    node_of = {0: 0, 1: 0, 2: 0, 3: 0, 4: 1, 5: 1, 6: 1, 7: 1}
+    cpus = {0: list(range(0, 64)) + list(range(128, 192)), 1: list(range(64, 128)) + list(range(192, 256))}
+    sets = sh.rank_core_sets(list(range(8)), range(256), node_of_device=node_of.get, cpus_of_node=cpus.get)
+    assert all(len(x) == 32 for x in sets) and len(set().union(*map(set, sets))) == 256
+    for r, x in enumerate(sets):
+        assert set(x) <= set(cpus[node_of[r]])
+    # no NUMA information (or ranks sharing one device in a test): an even split of the allowed cores
+    sets = sh.rank_core_sets([0] * 8, range(64), node_of_device=lambda d: None, cpus_of_node=lambda n: [])
+    assert [len(x) for x in sets] == [8] * 8 and len(set().union(*map(set, sets))) == 64
+    # a restricted affinity mask is respected; more ranks than cores on a node: they share them
+    sets = sh.rank_core_sets([0, 1], [3, 4, 5, 70], node_of_device=node_of.get, cpus_of_node=cpus.get)
+    assert sorted(sets[0] + sets[1]) == [3, 4] or set(sets[0]) | set(sets[1]) <= {3, 4, 5}
+    sets = sh.rank_core_sets([0, 1, 2], [3, 4], node_of_device=node_of.get, cpus_of_node=cpus.get)
+    assert all(set(x) <= {3, 4} and x for x in sets)
