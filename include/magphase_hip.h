@@ -530,11 +530,13 @@ int mpx_epoch_f0_track(void* stream, const float* sig, const int64_t* off, int32
  * 1: positive-going) holds counts[2u + p] entries at [(2u + p) * cap ...): sample index, |slope|, and the excitation
  * energy of the w_score samples after the crossing minus the w_score before it (which direction carries the epochs
  * depends on the recording's polarity: the host keeps the one with the larger mean score).  Entries are unordered.
+ * cross_frac (may be null): the zero of the line through the two samples of the sign change, as the fraction of a sample
+ * BEFORE sample index cross_idx (0 .. 1): sub-sample crossing position = cross_idx - cross_frac.
  * buf_a/b/c: float64 scratch of the total sample count each.
  */
 int mpx_epoch_zff(void* stream, const float* sig, const int64_t* off, int32_t n_utts, int64_t max_len,
                   const int32_t* half_win, int32_t w_score, double* buf_a, double* buf_b, double* buf_c, int32_t cap,
-                  int32_t* counts, int32_t* cross_idx, float* cross_slope, float* cross_score);
+                  int32_t* counts, int32_t* cross_idx, float* cross_slope, float* cross_score, float* cross_frac);
 
 /*
  * 16-bit PCM of the synthesised utterances for the wav writer (libaudio.py:352-365 write_audio_file, Q17): per

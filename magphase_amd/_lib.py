@@ -252,7 +252,7 @@ def _load_locked():
     lib.mpx_epoch_f0_track.argtypes = [vp, vp, vp, i32, i32, vp, i64, vp, vp, vp, i64, i32, i32, i32, i32, ctypes.c_double,
                                        vp, vp, vp]
     lib.mpx_epoch_zff.restype = ctypes.c_int
-    lib.mpx_epoch_zff.argtypes = [vp, vp, vp, i32, i64, vp, i32, vp, vp, vp, i32, vp, vp, vp, vp]
+    lib.mpx_epoch_zff.argtypes = [vp, vp, vp, i32, i64, vp, i32, vp, vp, vp, i32, vp, vp, vp, vp, vp]
     lib.mpx_pcm16.restype = ctypes.c_int
     lib.mpx_pcm16.argtypes = [vp, vp, i32, vp, i32, i64, ctypes.c_double, vp, vp]
     lib.mpx_pcm16_to_f32.restype = ctypes.c_int

@@ -254,20 +254,29 @@ __device__ __forceinline__ void noise_fft(const FrameGeom& g, int wtype, const f
                 xbuf[k - tile0] *= half_window(k, g.L, g.LR, g.kadd, g.invL, g.invR, 1);
         }
         wave_sync();
+        // Gather y[n] = x[(n + rot) mod N]: lane l, row j <-> n = 128 j + 2 l (real part), + 1 (imaginary part).  Rows that
+        // hold no sample of the frame are skipped (wave-uniform: n < len - rot is the frame's right half, n >= N - rot its
+        // left half); inside an active row every lane reads -- clamped address, no exec-masked branch, so all reads of the
+        // row batch are in flight together instead of one LDS round trip per element -- and keeps the value only where its
+        // sample index falls into the tile.  (Round 6: the branchy form was ~5 SALU + a serialised s_waitcnt per element, and
+        // its 32 hoisted row masks were 64 SGPRs of the pair kernels' spills.)
+        {
+            int n_lo = g.len - g.rot, n_hi = N - g.rot;
+            asm volatile("" : "+s"(n_lo), "+s"(n_hi));   // evaluated here, per tile: not hoisted as 32 lane masks
+            const unsigned span = (unsigned)(hi - tile0);
+            const unsigned b0 = (unsigned)(2 * lane + g.rot) - (unsigned)tile0;
 #pragma unroll
-        for (int j = 0; j < P; ++j) {
-            const int m0 = 128 * j;
-            const bool any = (m0 < g.len - g.rot) || (m0 + 127 >= N - g.rot);
-            if (any) {
-                const int m = m0 + 2 * lane;
-                int k0 = m + g.rot;
-                k0 = (k0 >= N) ? k0 - N : k0;
-                int k1 = m + 1 + g.rot;
-                k1 = (k1 >= N) ? k1 - N : k1;
+            for (int j = 0; j < P; ++j) {
                 constexpr int LBJ = ilog2(P);
-                const int rj = (COMPACT && MPX_COMP_DIT) ? brev(j, LBJ) : j;   // the DIT form wants register brev(j) <- z[l + 64 j]
-                if (k0 >= tile0 && k0 < hi) re[rj] = xbuf[k0 - tile0];
-                if (k1 >= tile0 && k1 < hi) im[rj] = xbuf[k1 - tile0];
+                const int m0 = 128 * j;
+                if ((m0 < n_lo) || (m0 + 127 >= n_hi)) {
+                    const int rj = (COMPACT && MPX_COMP_DIT) ? brev(j, LBJ) : j;   // the DIT form wants register brev(j) <- z[l + 64 j]
+                    // sample index relative to the tile, modulo N (tile0 is a multiple of the tile length, which divides N)
+                    const unsigned d0 = (b0 + (unsigned)m0) & (unsigned)(N - 1), d1 = (d0 + 1u) & (unsigned)(N - 1);
+                    const float v0 = xbuf[min(d0, (unsigned)(kTile - 1))], v1 = xbuf[min(d1, (unsigned)(kTile - 1))];
+                    re[rj] = (d0 < span) ? v0 : re[rj];
+                    im[rj] = (d1 < span) ? v1 : im[rj];
+                }
             }
         }
         wave_sync();
@@ -2327,7 +2336,6 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_roundtrip_pair(const fl
                 ws_s = -pk.y;
             }
             const bool lane0 = (lane == 0);
-            const float sgn_scale = ((lane & 1) ? -1.0f : 1.0f) * (0.5f / (float)M);   // (-1)^k fftshift sign, IFFT scale
             // the three rows in k_analysis' store shape: ascending 256-byte blocks of the own bins in natural q order; the
             // mirrors of step q regrouped into aligned blocks [M - 64 q - 64, M - 64 q - 1] whose lowest float is lane 0's
             // mirror of step q + 1 (bin M/2 for the last block); bin M alone from lane 0
@@ -2365,13 +2373,14 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_roundtrip_pair(const fl
                 hm = mq;
                 ha = aq;
                 hb = bq;
-                // feat_merge_paired, step j = q
-                const float s = a * a + b * b;
-                const float gg = m * sgn_scale * __builtin_amdgcn_rsqf(fmaxf(s, 1.0e-37f));
-                const float sq_ = aq * aq + bq * bq;
-                const float gq = mq * sgn_scale * __builtin_amdgcn_rsqf(fmaxf(sq_, 1.0e-37f));
-                const float x_r = a * gg, p_r = aq * gq;
-                float x_i = b * gg, p_i = bq * gq;
+                // feat_merge_paired, step j = q, on X itself: mag (R + jI) / |R + jI| of the three values just formed IS X up
+                // to their float32 rounding (m = |X|^2 r, (a, b) = X r with r = rsq(|X|^2): the product differs from X by the
+                // relative error of r, < 2.5e-7), so the magnitude, the second inverse square root and four products per bin
+                // that feat_merge_paired spends on rebuilding it are not spent here.  The (-1)^k of the fftshift is a rotation
+                // of the inverse transform's output by half its length -- a renaming of registers in the overlap-add below --
+                // and the 0.5 / M of the inverse transform rides on the overlap-add's multiply-add: both exact.
+                const float x_r = no_r[q], p_r = nm_r[q];
+                float x_i = no_i[q], p_i = nm_i[q];
                 if (q == 0) {   // DC and Nyquist: imaginary parts dropped (Q5)
                     x_i = lane0 ? 0.0f : x_i;
                     p_i = lane0 ? 0.0f : p_i;
@@ -2391,9 +2400,7 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_roundtrip_pair(const fl
             rhi[-64 * (HP - 1)] = lane0 ? aH : ha;
             ihi[-64 * (HP - 1)] = lane0 ? bH : hb;
             // bin M/2 (lane 0): Z = 2 conj(X); then the hand-over of Z[M - k] to the lanes that own those registers
-            const float sH = aH * aH + bH * bH;
-            const float gH = 2.0f * mH * sgn_scale * __builtin_amdgcn_rsqf(fmaxf(sH, 1.0e-37f));
-            const float hr = aH * gH, hi = -bH * gH;
+            const float hr = 2.0f * nh_r, hi = -2.0f * nh_i;
             const int src_lane = (64 - lane) & 63;
 #pragma unroll
             for (int r = HP; r < P; ++r) {
@@ -2453,15 +2460,14 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_roundtrip_pair(const fl
         if (flushed < target) flush_ring<R>(ring, strip, pcm0, rd.head_end, rd.out_lo, rd.out_hi, flushed, target, lane);
         wave_sync();
         MPX_RT_PHASE(5);   // flush of the finished samples
-        auto plain_add = [](float o, float v, int) { return o + v; };
+        constexpr float kScale = 0.5f / (float)M;   // the inverse transform's scale, on the overlap-add's multiply-add
+        auto plain_add = [](float o, float v, int) { return fmaf(v, kScale, o); };
         auto all_rows = [](int) { return true; };
-        if constexpr (kCompPairWaves > 8) {   // 16 ring values in registers at a time (<= 168 VGPRs)
+        {   // 16 ring values in registers at a time (<= 168 VGPRs); rows taken half a transform apart: the fftshift
             constexpr int CH = (P < MPX_COMP_CH) ? P : MPX_COMP_CH;
             const RingAddr ra = ring_addr<P>(ring_byte, x, lane);
-            ring_add_plane<P, 0, CH, kDit>(smem, ra, xr, lane, plain_add, all_rows);
-            ring_add_plane<P, 1, CH, kDit>(smem, ra, xi, lane, plain_add, all_rows);
-        } else {
-            ring_add<P>(smem, ring_byte, x, xr, xi, lane, plain_add, all_rows);
+            ring_add_plane<P, 0, CH, kDit, true>(smem, ra, xr, lane, plain_add, all_rows);
+            ring_add_plane<P, 1, CH, kDit, true>(smem, ra, xi, lane, plain_add, all_rows);
         }
         wave_sync();
         if (fi == cur.fe - 1) {   // last frame of the run: stream out the rest, leave the ring cleared

@@ -198,7 +198,8 @@ __global__ __launch_bounds__(256) void k_epoch_mean(const T* __restrict__ x, con
 __global__ __launch_bounds__(256) void k_epoch_crossings(const double* __restrict__ y, const double* __restrict__ c2,
                                                          const long long* __restrict__ off, int w_score, int cap,
                                                          int* __restrict__ cnt, int* __restrict__ idx,
-                                                         float* __restrict__ slope, float* __restrict__ score) {
+                                                         float* __restrict__ slope, float* __restrict__ score,
+                                                         float* __restrict__ frac) {
     const int u = blockIdx.y;
     const long long n = off[u + 1] - off[u];
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x + 1;
@@ -218,6 +219,9 @@ __global__ __launch_bounds__(256) void k_epoch_crossings(const double* __restric
     const double cq = c[q - 1], cp = c[q + w_score - 1], cm = (q - w_score - 1 >= 0) ? c[q - w_score - 1] : 0.0;
     const long long slot = (long long)(2 * u + p) * cap + k;
     idx[slot] = (int)i;
+    // where between samples i - 1 and i the line through the two values crosses zero, as a fraction of the step back from i
+    // (0: at sample i, towards 1: at sample i - 1): sub-sample epochs -- at 16 kHz a sample is 62 us, the tracker's jitter 40
+    if (frac) frac[slot] = (float)(b / (b - a));
     slope[slot] = (float)fabs(b - a);
     score[slot] = (float)((cp - cq) - (cq - cm));
 }
@@ -255,7 +259,7 @@ int mpx_epoch_f0_track(void* stream, const float* sig, const int64_t* off, int32
 
 int mpx_epoch_zff(void* stream, const float* sig, const int64_t* off, int32_t n_utts, int64_t max_len,
                   const int32_t* half_win, int32_t w_score, double* buf_a, double* buf_b, double* buf_c, int32_t cap,
-                  int32_t* counts, int32_t* cross_idx, float* cross_slope, float* cross_score) {
+                  int32_t* counts, int32_t* cross_idx, float* cross_slope, float* cross_score, float* cross_frac) {
     if (n_utts < 0 || max_len < 0 || cap < 1) return fail(MPX_ERR_ARG, "mpx_epoch_zff: bad size%s");
     if (n_utts == 0 || max_len == 0) return MPX_OK;
     if (n_utts > 65535) return fail(MPX_ERR_ARG, "mpx_epoch_zff: at most 65535 utterances per call%s");
@@ -284,7 +288,7 @@ int mpx_epoch_zff(void* stream, const float* sig, const int64_t* off, int32_t n_
     hipLaunchKernelGGL(k_epoch_scan<2>, gs, bs, 0, s, (const void*)sig, o, B);
     MPX_HIP_CHECK(hipMemsetAsync(counts, 0, sizeof(int32_t) * 2 * (size_t)n_utts, s));
     hipLaunchKernelGGL(k_epoch_crossings, ge, be, 0, s, A, B, o, (int)w_score, (int)cap, counts, cross_idx, cross_slope,
-                       cross_score);
+                       cross_score, cross_frac);
     MPX_HIP_CHECK(hipGetLastError());
     return MPX_OK;
 }

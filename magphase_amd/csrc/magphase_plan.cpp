@@ -30,6 +30,33 @@ namespace {
 
 inline int64_t round_to_int(double x) { return (int64_t)std::nearbyint(x); }   // np.round(x).astype(int)
 
+// memcpy into a page-locked staging buffer with streaming (non-temporal) stores: the destination is read next by the DMA
+// engine, not by a core -- written through the cache every line is first READ for ownership, a third of the copy's memory
+// traffic, and eight ranks staging 30 MB per launch each share one memory system (bench.py host_contention)
+inline void stream_copy(void* dst, const void* src, size_t n) {
+#if defined(__SSE2__) && !defined(MPX_HOST_NO_STREAM)
+    char* d = (char*)dst;
+    const char* s = (const char*)src;
+    size_t head = (16 - ((uintptr_t)d & 15u)) & 15u;
+    if (head > n) head = n;
+    if (head) memcpy(d, s, head);
+    d += head, s += head, n -= head;
+    size_t i = 0;
+    for (; i + 64 <= n; i += 64) {
+        const __m128i a = _mm_loadu_si128((const __m128i*)(s + i)), b = _mm_loadu_si128((const __m128i*)(s + i + 16));
+        const __m128i c = _mm_loadu_si128((const __m128i*)(s + i + 32)), e = _mm_loadu_si128((const __m128i*)(s + i + 48));
+        _mm_stream_si128((__m128i*)(d + i), a);
+        _mm_stream_si128((__m128i*)(d + i + 16), b);
+        _mm_stream_si128((__m128i*)(d + i + 32), c);
+        _mm_stream_si128((__m128i*)(d + i + 48), e);
+    }
+    _mm_sfence();
+    if (i < n) memcpy(d + i, s + i, n - i);
+#else
+    memcpy(dst, src, n);
+#endif
+}
+
 // np.minimum / np.maximum (a NaN operand propagates)
 inline double np_min(double a, double b) { return std::isnan(a) ? a : (std::isnan(b) ? b : (a < b ? a : b)); }
 inline double np_max(double a, double b) { return std::isnan(a) ? a : (std::isnan(b) ? b : (a > b ? a : b)); }
@@ -140,7 +167,7 @@ int64_t mpx_host_plan_analysis_batch(int32_t n_utts, const void* const* pcm, con
         const int64_t e = (a + kBlock < n_smpls[u]) ? a + kBlock : n_smpls[u];
         const int64_t o = sig_off[(size_t)u];
         if (stage_kind == 0) {   // int16 in, int16 staged (widened on the device: mpx_pcm16_to_f32)
-            memcpy((int16_t*)stage + o + a, (const int16_t*)pcm[u] + a, (size_t)(e - a) * 2);
+            stream_copy((int16_t*)stage + o + a, (const int16_t*)pcm[u] + a, (size_t)(e - a) * 2);
             return;
         }
         float* d = (float*)stage + o;
@@ -148,7 +175,7 @@ int64_t mpx_host_plan_analysis_batch(int32_t n_utts, const void* const* pcm, con
             const int16_t* s = (const int16_t*)pcm[u];
             for (int64_t i = a; i < e; ++i) d[i] = (float)s[i] * (1.0f / 32768.0f);
         } else if (pcm_kind[u] == 1) {
-            memcpy(d + a, (const float*)pcm[u] + a, (size_t)(e - a) * 4);
+            stream_copy(d + a, (const float*)pcm[u] + a, (size_t)(e - a) * 4);
         } else {                         // float64 -> float32, round to nearest even (numpy's astype)
             const double* s = (const double*)pcm[u];
             for (int64_t i = a; i < e; ++i) d[i] = (float)s[i];
@@ -572,7 +599,7 @@ int64_t mpx_host_plan_synthesis_batch(int32_t n_utts, const void* const* mag, co
                 const int64_t a = ((int64_t)t - first[(size_t)j]) * kBlock, e = (a + kBlock < c.n) ? a + kBlock : c.n;
                 float* d = stage + c.dst;
                 if (c.kind == 1) {
-                    memcpy(d + a, (const float*)c.src + a, (size_t)(e - a) * 4);
+                    stream_copy(d + a, (const float*)c.src + a, (size_t)(e - a) * 4);
                 } else {   // float64 -> float32, round to nearest even (numpy's astype)
                     const double* sp = (const double*)c.src;
                     for (int64_t i = a; i < e; ++i) d[i] = (float)sp[i];

@@ -550,10 +550,13 @@ __device__ __forceinline__ lds_float* lds_ptr(unsigned byte_addr) {
 }
 
 // NAT: register i holds row q = i (the DIT transform's natural output order) instead of q = brev(i).
-template <int P, int PL, int CH, bool NAT = false, typename CFn, typename LFn>
+// ROT: the rows are taken half a transform apart -- row q of the frame = row (q + P/2) mod P of xv: the fftshift of the
+// inverse transform's output (a spectrum multiplied by (-1)^k) as a renaming of registers instead of a multiplication.
+template <int P, int PL, int CH, bool NAT = false, bool ROT = false, typename CFn, typename LFn>
 __device__ __forceinline__ void ring_add_plane(float* smem_base, const RingAddr& ra, const float (&xv)[P], int lane,
                                                CFn combine, LFn live) {
     constexpr int LB = ilog2(P);
+    constexpr int XR = ROT ? (NAT ? P / 2 : 1) : 0;   // register of row q + P/2: i ^ (P/2) in natural order, i ^ 1 bit-reversed
     static_assert(P % CH == 0, "chunk size must divide P");
     const int kap = kappa<P>(lane);
     const unsigned a = PL ? ra.a1 : ra.a0, b = PL ? ra.b1 : ra.b0, m = PL ? ra.m1 : ra.m0;
@@ -598,7 +601,7 @@ __device__ __forceinline__ void ring_add_plane(float* smem_base, const RingAddr&
 #pragma unroll
             for (int i = 0; i < CH; ++i) {
                 const int q = NAT ? (c + i) : brev(c + i, LB);
-                if (live(q)) *lds_ptr(ad[i]) = combine(o[i], xv[c + i], 2 * (kap + 64 * q) + PL);
+                if (live(q)) *lds_ptr(ad[i]) = combine(o[i], xv[(c + i) ^ XR], 2 * (kap + 64 * q) + PL);
             }
         }
         (void)smem_base;
@@ -623,7 +626,7 @@ __device__ __forceinline__ void ring_add_plane(float* smem_base, const RingAddr&
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
             const int q = NAT ? (c + i) : brev(c + i, LB);
-            if (live(q)) *at(q) = combine(o[i], xv[c + i], 2 * (kap + 64 * q) + PL);
+            if (live(q)) *at(q) = combine(o[i], xv[(c + i) ^ XR], 2 * (kap + 64 * q) + PL);
         }
     }
 }

@@ -210,7 +210,7 @@ class Engine:
         if total == 0 or total > (128 << 20):   # more than 512 MB per stream: not worth page-locking, the plain path does it
             return None
         stage = self.host_staging(total)
-        n_thr = max(1, int(os.environ.get("MAGPHASE_IO_NATIVE_THREADS", "8")))
+        n_thr = self.host_threads(4 * total)
         off = 0
         for p_, r in zip(parts, rows):
             a = np.asarray(p_)
@@ -252,7 +252,10 @@ class Engine:
         Bounded pinned memory (depth x chunk_bytes) whatever the sizes.
         """
         torch = _torch()
-        n_thr = max(1, int(os.environ.get("MAGPHASE_IO_NATIVE_THREADS", "8")))
+        # the widening writes 2 bytes for every byte that crosses PCIe: eight threads sustain ~75 GB/s of streaming stores on
+        # this host, half of what the link delivers (round 6: 16 utterances' features 14 ms for 0.35 GB); 32 threads from
+        # 16 MB up (Engine.host_threads: capped by the cores this rank may use)
+        n_thr = self.host_threads(sum(int(t.numel()) * 4 for t in tensors))
         if chunk_bytes is None:
             chunk_bytes = int(os.environ.get("MAGPHASE_D2H_CHUNK_MB", "32")) << 20
         outs, views, work = [], [], []
@@ -501,9 +504,8 @@ class Engine:
         buffer): float32 C-contiguous blocks are copied, float64 ones narrowed (round to nearest even, as astype), both on
         a few native threads (mpx_host_copy_many / mpx_host_narrow_f64) -- numpy's concatenate is one thread at ~10 GB/s and
         was a quarter of a synthesis plan's build time.  Anything else goes through numpy."""
-        n_thr = max(1, int(os.environ.get("MAGPHASE_IO_NATIVE_THREADS", "8")))
-        if out.nbytes >= (16 << 20) and "MAGPHASE_IO_NATIVE_THREADS" not in os.environ:
-            n_thr = 32   # launches of 100+ utterances stage tens of MB per matrix: 8 / 16 / 32 threads = 116 / 131 / 144 k x real time
+        # (launches of 100+ utterances stage tens of MB per matrix: 8 / 16 / 32 threads = 116 / 131 / 144 k x real time)
+        n_thr = self.host_threads(out.nbytes)
         k = len(arrays)
         if k > 1 and all(a.dtype == np.float32 and a.flags.c_contiguous for a in arrays):
             src = (ctypes.c_void_p * k)(*[a.ctypes.data for a in arrays])
@@ -578,14 +580,22 @@ class Engine:
             with self.__dict__.setdefault("_slots_lock", threading.Lock()):
                 pool = getattr(self, "_slots", None)
                 if pool is None:
+                    # tokens in a SimpleQueue (blocking; safe to put from a destructor running inside the cyclic collector,
+                    # unlike queue.Queue's mutex), the slots themselves on a stack: the most recently returned slot -- page-
+                    # locked, sized, its event long since passed -- goes out first, so one launch at a time keeps reusing ONE
+                    # warm slot instead of walking through all of them (each first use pins tens of MB: 40 ms)
+                    import collections
                     pool = queue.SimpleQueue()
+                    self._slot_stack = collections.deque()
                     for _ in range(self._N_SLOTS):
-                        pool.put({"stage": None, "desc": None, "event": None})
+                        self._slot_stack.append({"stage": None, "desc": None, "event": None})
+                        pool.put(None)
                     self._slots = pool
         try:
-            slot = pool.get(block=bool(wait))
+            pool.get(block=bool(wait))
         except queue.Empty:
             return None
+        slot = self._slot_stack.pop()
         try:
             if slot["event"] is not None:
                 slot["event"].synchronize()
@@ -598,13 +608,15 @@ class Engine:
                         slot[key] = torch.empty(max(int(need * 1.5), 1 << 20), dtype=torch.uint8).pin_memory()
                         slot[key + "_np"] = slot[key].numpy()
         except BaseException:
-            pool.put(slot)
+            self._slot_stack.append(slot)
+            pool.put(None)
             raise
         return slot
 
     def _slot_release(self, slot, event=None):
         slot["event"] = event
-        self._slots.put(slot)
+        self._slot_stack.append(slot)
+        self._slots.put(None)
 
     def _slot_upload(self, slot, stage_bytes, desc_bytes):
         """The first stage_bytes / desc_bytes of the slot's two buffers -> device uint8 tensors (two DMAs on the upload stream);
@@ -1351,9 +1363,7 @@ class LosslessAnalysisPlan:
             src = (ctypes.c_void_p * k)(*[a.ctypes.data for a in arrs])
             nb = np.asarray([a.nbytes for a in arrs], dtype=np.int64)
             doff = np.concatenate(([0], np.cumsum(nb)[:-1])).astype(np.int64)
-            n_thr = max(1, int(os.environ.get("MAGPHASE_IO_NATIVE_THREADS", "8")))
-            if int(nb.sum()) >= (48 << 20) and "MAGPHASE_IO_NATIVE_THREADS" not in os.environ:
-                n_thr = 32   # (launches of more than ~100 utterances; at 64 utterances = 30 MB eight threads measured best)
+            n_thr = engine.host_threads(int(nb.sum())) if hasattr(engine, "host_threads") else 8
 
             def _copy(arrs=arrs, src=src, nb=nb, doff=doff):   # (keeps the arrays alive until the copy is done)
                 if engine.lib.mpx_host_copy_many(len(arrs), src, nb.ctypes.data, doff.ctypes.data, buf.ctypes.data, n_thr) != 0:

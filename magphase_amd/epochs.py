@@ -25,6 +25,9 @@ import numpy as np
 from . import _lib
 
 
+ZFF_ADVANCE_SMPLS = 1.5   # four inclusive cumulative sums (-0.5 sample each) and one first difference (+0.5)
+
+
 def _median5(v):
     """Median of 5 with replicated ends (per frame track)."""
     vp = np.concatenate((v[:1], v[:1], v, v[-1:], v[-1:]))
@@ -107,16 +110,18 @@ def track_epochs_batch(sigs, fs, engine=None, unvoiced_step_s=0.005, nccf_min=0.
     bufs = [torch.empty(total, dtype=torch.float64, device=e.device) for _ in range(3)]
     counts = torch.empty(2 * U, dtype=torch.int32, device=e.device)
     c_idx = torch.zeros(2 * U * cap, dtype=torch.int32, device=e.device)
-    c_slope, c_score = (torch.zeros(2 * U * cap, dtype=torch.float32, device=e.device) for _ in range(2))
+    c_slope, c_score, c_frac = (torch.zeros(2 * U * cap, dtype=torch.float32, device=e.device) for _ in range(3))
     d_half = e.to_device(half_win, np.int32)
     with torch.cuda.device(e.device):
         _lib.check(lib.mpx_epoch_zff(e.stream_ptr(), sig.data_ptr(), d["off"].data_ptr(), U, n_max, d_half.data_ptr(), w,
                                      bufs[0].data_ptr(), bufs[1].data_ptr(), bufs[2].data_ptr(), cap, counts.data_ptr(),
-                                     c_idx.data_ptr(), c_slope.data_ptr(), c_score.data_ptr()), "mpx_epoch_zff")
+                                     c_idx.data_ptr(), c_slope.data_ptr(), c_score.data_ptr(), c_frac.data_ptr()),
+                   "mpx_epoch_zff")
     cnt = counts.cpu().numpy()
     idx_h = c_idx.cpu().numpy().reshape(2 * U, cap)
     slope_h = c_slope.cpu().numpy().reshape(2 * U, cap).astype(np.float64)
     score_h = c_score.cpu().numpy().reshape(2 * U, cap).astype(np.float64)
+    frac_h = c_frac.cpu().numpy().reshape(2 * U, cap).astype(np.float64)
 
     out = []
     for u in range(U):
@@ -130,7 +135,7 @@ def track_epochs_batch(sigs, fs, engine=None, unvoiced_step_s=0.005, nccf_min=0.
             continue
         # polarity: at a closure instant the vocal-tract response is (re-)excited -- the signal energy in the millisecond
         # after it exceeds the energy in the millisecond before; half a period later it is just decaying
-        best, cand = -1e30, (np.zeros(0, dtype=np.int64), np.zeros(0))
+        best, cand = -1e30, (np.zeros(0, dtype=np.int64), np.zeros(0), np.zeros(0))
         for p in (0, 1):
             k = min(int(cnt[2 * u + p]), cap)
             if k == 0:
@@ -138,9 +143,16 @@ def track_epochs_batch(sigs, fs, engine=None, unvoiced_step_s=0.005, nccf_min=0.
             sc = float(score_h[2 * u + p, :k].mean())
             if sc > best:
                 order = np.argsort(idx_h[2 * u + p, :k], kind="stable")
-                best, cand = sc, (idx_h[2 * u + p, :k][order].astype(np.int64), slope_h[2 * u + p, :k][order])
-        idx, slope = cand
-        t_ep = idx / float(fs)
+                best, cand = sc, (idx_h[2 * u + p, :k][order].astype(np.int64), slope_h[2 * u + p, :k][order],
+                                  frac_h[2 * u + p, :k][order])
+        idx, slope, frac = cand
+        # Epoch time = the sub-sample zero of the filtered signal, plus the filter chain's own advance: every inclusive
+        # cumulative sum 1 / (1 - z^-1) leads the integrator it stands for by half a sample (four of them: two zero-frequency
+        # resonators), the first difference lags by half a sample -- 1.5 samples early in all, at any rate; the moving-mean
+        # removals are symmetric.  (Round 5: whole-sample crossings and no compensation gave -130 us at 16 kHz against
+        # synthetic truth, two samples; the rest of that figure is the test generator's own vocal-tract resonators, whose
+        # group delay at zero frequency is -1 sample each plus B / (2 pi f^2) seconds: tools/epoch_natural.py --bias-model.)
+        t_ep = (idx - frac + ZFF_ADVANCE_SMPLS) / float(fs)
         # voicing of each crossing: the F0 frame whose centre is nearest
         fr_of = np.clip(np.round((t_ep - 0.5 * win_s) / hop_s).astype(int), 0, f0_h.size - 1)
         keep = voiced_fr[fr_of] if idx.size else np.zeros(0, dtype=bool)
@@ -244,3 +256,90 @@ def accuracy_against_truth(pm_true, voi_true, pm_est, voi_est, max_period_s=0.02
     if pm_est.size:
         out["voicing_error_rate"] = float((voiced_on(pm_true, voi_true) != voiced_on(pm_est, voi_est)).mean())
     return out
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Natural speech: voicing truth from phone labels.  The reference bundles ten recordings WITH their HTS state-aligned labels
+# (demos/data_48k/labs/*.lab, the input of its label re-timing script); the identity of a phone says whether it is voiced,
+# independently of any epoch tracker -- the one natural-speech truth there is offline (no REAPER output exists here).
+# ----------------------------------------------------------------------------------------------------------------------
+# Unilex phone names of the bundled labels.  Sonorants are voiced throughout; voiceless obstruents and silence are not;
+# voiced obstruents (b d g v D z dZ) and /h/ devoice or voice with their context and are not scored.
+PHONES_VOICED = frozenset("@ @@ a A aI aU E eI i I I@ O OI Q u U @U V n m N r l lw l! w j".split())
+PHONES_UNVOICED = frozenset("# pau sil s t k p f T tS S".split())
+
+
+def label_voicing_spans(lab_file, margin_s=0.015, min_len_s=0.03):
+    """HTS state-aligned label file -> (voiced spans, unvoiced spans), lists of (t0, t1) in seconds: consecutive states of one
+    phone and consecutive phones of one class merged, `margin_s` cut off both ends (forced-alignment boundaries are good to ~10-20 ms, and voicing sets in /
+    dies out inside the neighbouring phones), spans shorter than min_len_s after trimming dropped."""
+    import re
+
+    phones = []
+    with open(lab_file) as fh:
+        for line in fh:
+            p = line.split()
+            if len(p) < 3:
+                continue
+            m = re.match(r"[^-]*-([^+]+)\+", p[2])
+            if not m:
+                continue
+            t0, t1, ph = int(p[0]) * 1e-7, int(p[1]) * 1e-7, m.group(1)
+            if phones and phones[-1][2] == ph and abs(phones[-1][1] - t0) < 1e-9 and "[2]" not in p[2]:
+                phones[-1][1] = t1          # the next state of the same phone
+            else:
+                phones.append([t0, t1, ph])
+    # consecutive phones of one class form a run (a vowel between a nasal and a liquid is voiced throughout): the margins
+    # are cut at the ends of runs, where the class changes
+    runs = []
+    for t0, t1, ph in phones:
+        c = "v" if ph in PHONES_VOICED else ("u" if ph in PHONES_UNVOICED else "x")
+        if runs and runs[-1][2] == c and abs(runs[-1][1] - t0) < 1e-9:
+            runs[-1][1] = t1
+        else:
+            runs.append([t0, t1, c])
+    voiced, unvoiced = [], []
+    for t0, t1, c in runs:
+        a, b = t0 + margin_s, t1 - margin_s
+        if b - a < min_len_s or c == "x":
+            continue
+        (voiced if c == "v" else unvoiced).append((a, b))
+    return voiced, unvoiced
+
+
+def score_against_labels(pm_sec, voi, lab_file, step_s=0.005):
+    """Agreement of a (v_pm_sec, v_voi) track with the voicing the phone labels imply, on a 5 ms grid inside the labelled
+    spans (label_voicing_spans), plus the continuity of F0 inside the voiced spans:
+      voiced_recall      grid points of voiced phones the track calls voiced
+      unvoiced_recall    grid points of voiceless phones / silence the track calls unvoiced
+      agreement          both classes pooled
+      f0_median_hz, f0_jump_rate   consecutive voiced periods inside voiced spans: median 1 / period; share of neighbouring
+                                   periods that differ by more than 20 % (octave slips, dropped or doubled epochs)"""
+    pm_sec, voi = np.asarray(pm_sec, dtype=np.float64), np.asarray(voi) > 0
+    v_spans, u_spans = label_voicing_spans(lab_file)
+
+    def track_voiced(t):
+        k = np.clip(np.searchsorted(pm_sec, t), 0, pm_sec.size - 1)
+        return voi[k]
+
+    def grid(spans):
+        return np.concatenate([np.arange(a, b, step_s) for a, b in spans]) if spans else np.zeros(0)
+
+    gv, gu = grid(v_spans), grid(u_spans)
+    hit_v, hit_u = track_voiced(gv), ~track_voiced(gu)
+    per, jumps = [], []
+    for a, b in v_spans:
+        sel = (pm_sec >= a) & (pm_sec <= b) & voi
+        t = pm_sec[sel]
+        if t.size >= 3:
+            d = np.diff(t)
+            per.append(d)
+            jumps.append(np.abs(d[1:] / d[:-1] - 1.0) > 0.2)
+    per = np.concatenate(per) if per else np.zeros(0)
+    jumps = np.concatenate(jumps) if jumps else np.zeros(0, dtype=bool)
+    return {"voiced_points": int(gv.size), "unvoiced_points": int(gu.size),
+            "voiced_recall": float(hit_v.mean()) if gv.size else float("nan"),
+            "unvoiced_recall": float(hit_u.mean()) if gu.size else float("nan"),
+            "agreement": float((hit_v.sum() + hit_u.sum()) / max(1, gv.size + gu.size)),
+            "f0_median_hz": float(1.0 / np.median(per)) if per.size else float("nan"),
+            "f0_jump_rate": float(jumps.mean()) if jumps.size else float("nan")}

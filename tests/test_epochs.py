@@ -1,7 +1,7 @@
 """
 Built-in epoch / voicing front end (magphase_amd/epochs.py + csrc/magphase_epochs.hip).  PARITY
 UNPINNED (REAPER is an external binary that is not available): quality is measured on synthetic utterances whose epochs
-are known exactly, and on two of the reference's bundled natural recordings (sanity ranges + copy synthesis).
+are known exactly, and on the reference's ten bundled natural recordings (voicing against the phone labels; copy synthesis on two).
 Device kernels: -m gpu.
 """
 import os
@@ -149,3 +149,31 @@ def test_natural_recordings_copy_synthesis(tok, tmp_path):
         assert 0.5 < r < 2.0, r
     finally:
         mp.set_epoch_provider(None)
+
+
+def test_natural_recordings_against_label_voicing(capsys):
+    """All ten of the reference's natural recordings (demos/data_48k/wavs_nat, bundled as data with their HTS state labels):
+    the tracker's voiced / unvoiced decision against the voicing the phone identities imply (sonorants voiced, voiceless
+    obstruents and silence unvoiced; voiced obstruents not scored; 15 ms margins: epochs.score_against_labels), and the
+    continuity of its periods inside voiced phones.  The one natural-speech truth available offline (VERDICT r05 item 6);
+    tools/epoch_natural.py writes the per-file table (profiles/r06_epoch_natural.json)."""
+    from magphase_amd import epochs, libaudio as la
+    d = os.path.join(ROOT, "demos", "data_48k")
+    toks = sorted(f[:-4] for f in os.listdir(os.path.join(d, "wavs_nat")) if f.endswith(".wav"))
+    assert len(toks) == 10
+    sigs = [la.read_audio_file(os.path.join(d, "wavs_nat", t + ".wav"))[0] for t in toks]
+    res = epochs.track_epochs_batch(sigs, 48000)
+    rows = [epochs.score_against_labels(pm, voi, os.path.join(d, "labs", t + ".lab")) for t, (pm, voi) in zip(toks, res)]
+    w = np.array([r["voiced_points"] + r["unvoiced_points"] for r in rows], dtype=np.float64)
+    pooled = {k: float(np.sum(w * np.array([r[k] for r in rows])) / w.sum())
+              for k in ("voiced_recall", "unvoiced_recall", "agreement", "f0_jump_rate")}
+    with capsys.disabled():
+        print("\nepoch tracker on the 10 natural recordings vs label voicing: %s; worst file %.3f; F0 medians %s Hz"
+              % (", ".join("%s %.4f" % kv for kv in pooled.items()), min(r["agreement"] for r in rows),
+                 " ".join("%.0f" % r["f0_median_hz"] for r in rows)))
+    assert all(r["voiced_points"] > 80 and r["unvoiced_points"] > 80 for r in rows)
+    # measured on MI355X (profiles/r06_epoch_natural.json): see the bounds' margins there
+    assert pooled["agreement"] > 0.90 and pooled["voiced_recall"] > 0.88 and pooled["unvoiced_recall"] > 0.90
+    assert min(r["agreement"] for r in rows) > 0.80
+    assert pooled["f0_jump_rate"] < 0.06
+    assert all(60.0 < r["f0_median_hz"] < 400.0 for r in rows)

@@ -49,7 +49,8 @@ def prepare(name, ref, flags):
             shutil.copytree(os.path.join(ROOT, d), os.path.join(dst, d),
                             ignore=shutil.ignore_patterns("__pycache__", "*.so", "*.pyc", "_obj"))
     csrc = os.path.join(dst, "magphase_amd", "csrc")
-    srcs = [os.path.join(csrc, f) for f in sorted(os.listdir(csrc)) if f.endswith((".hip", ".cpp"))]
+    srcs = [os.path.join(csrc, f) for f in sorted(os.listdir(csrc)) if f.endswith((".hip", ".cpp"))
+            and f != "magphase_pyhost.cpp"]   # (the marshalling extension is not part of the C-ABI library)
     from magphase_amd import build
 
     if not ref:   # the working tree: per-unit objects, compiled in parallel and cached per flag set (magphase_amd/_obj)
