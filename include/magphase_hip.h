@@ -367,47 +367,6 @@ int mpx_synthesis_compressed_ola_spectra(void* stream, int fft_len, const void* 
                                  const float* spectra /* as stored by mpx_noise_stats_spectra */);
 
 /*
- * mpx_mel_unwarp_rows + mpx_synthesis_compressed_ola as ONE launch (magphase.py:852-870 followed by :900-973; N = 4096,
- * the 12-wave pair kernel, per_phase_type='magphase').  The unwarped spectra never exist as [F x H] matrices: the host
- * cuts every OLA run into SEGMENTS (hostmath.plan_segments: <= 16 consecutive frames whose rows row0[f] .. row1[f] lie
- * within 16 consecutive coefficient rows), and the wave pair that synthesises a segment first unwarps it --
- * exp(a_mag[16 rows] @ u_mag) and a_real / a_imag[16 rows] @ u_phase on v_mfma_f32_16x16x4_f32, the frames interpolated
- * out of a 16 x 64 LDS tile (on the exponentials, as magphase.py:2242-2252 does) -- into the pair's own scratch rows
- * (mpx_synth_fused_scratch_floats(n_slots) floats), which the same two waves read back frame by frame.
- *   a_mag [n_rows x k_mag], a_real / a_imag [n_rows x k_phase] : DEVICE float32 coefficient matrices (a_mag after the
- *       post-filter, if any); row0 / row1 / row_t [n_frames]: the frame's two rows and the weight of row1 (identity
- *       tables with weight 0 for variable-rate input)
- *   upack_mag / upack_phase : u_mag / u_phase in MFMA fragment order (hostmath.pack_unwarp_frag): float32
- *       [column tiles of 16 bins][ceil(ksteps / 4)][64 lanes][4], element = U[4 (4 q + e) + (lane >> 4)][16 ct + (lane & 15)]
- *       (0 beyond K / beyond the matrix), 132 column tiles for the magnitudes, 32 for the phases (bins < 512);
- *       ksteps = what mpx_synth_fused_ksteps reports for (k_mag, k_phase) -- 0: no fused kernel, stage the spectra
- *   seg_frame_begin / seg_row_begin [n_segments], run_seg_off [n_runs + 1] : the segments of run r are
- *       run_seg_off[r] .. run_seg_off[r + 1] - 1, segment s covers the frames seg_frame_begin[s] .. (next segment's begin or
- *       the run's end) - 1 and the rows seg_row_begin[s] .. + 15
- *   n_per_bins : as mpx_synthesis_compressed_ola, required <= 512
- * Everything else as mpx_synthesis_compressed_ola; followed by mpx_ola_fixup.
- */
-/* Operand format of upack_mag / upack_phase: 1 (default) = hostmath.pack_unwarp_frag_bf16 -- bfloat16 bit patterns
- * [column tiles][2 blocks of 32 coefficients][3 splits][64 lanes][8], the three-way split u = u0 + u1 + u2 of float32(U)
- * for v_mfma_f32_16x16x32_bf16 (six exact partial products per term, float32 accumulation: float32 accuracy at 0.4 of the
- * float32 instruction's matrix-pipe time); 0 (MAGPHASE_FUSED_F32=1) = the float32 fragments described above. */
-int mpx_synth_fused_format(void);
-int mpx_synth_fused_ksteps(int fft_len, int32_t k_mag, int32_t k_phase, int32_t n_per_bins, int32_t* ksteps_mag,
-                           int32_t* ksteps_phase);
-int64_t mpx_synth_fused_scratch_floats(int32_t n_slots);
-int mpx_synthesis_compressed_fused(void* stream, int fft_len, const void* tables, const float* a_mag, int32_t k_mag,
-                                   const float* upack_mag, const float* a_real, const float* a_imag, int32_t k_phase,
-                                   const float* upack_phase, int64_t n_rows, const int32_t* row0, const int32_t* row1,
-                                   const float* row_t, const int32_t* seg_frame_begin, const int32_t* seg_row_begin,
-                                   const int32_t* run_seg_off, const float* noise, const int64_t* noise_pos,
-                                   const int32_t* noise_left, const int32_t* noise_right, const int32_t* noise_wtype,
-                                   const int32_t* voiced, const float* inv_gain, const int32_t* win_left,
-                                   const int32_t* win_right, const int32_t* pm_rel, const float* per_v, const float* ap_v,
-                                   const float* ap_u, const mpx_ola_run* runs, int32_t n_runs, const int32_t* slot_off,
-                                   const int32_t* slot_runs, int32_t n_slots, float* scratch, float* strips,
-                                   float* pcm_out, int32_t n_per_bins);
-
-/*
  * HOST function (no device work, no stream): the serial constant -> variable frame-rate scan of
  * magphase.py:1426-1449 (get_shifts_and_frm_locs_from_const_shifts, Q16) in the reference's float64 operation
  * sequence (scipy interp1d's linear formula, no FMA): bit-identical shifts / frame locations, ~100x faster than one

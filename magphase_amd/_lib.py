@@ -50,10 +50,6 @@ SYMBOLS = (
     "mpx_synth_comp_slot_weights",
     "mpx_synthesis_compressed_ola",
     "mpx_synthesis_compressed_ola_spectra",
-    "mpx_synth_fused_format",
-    "mpx_synth_fused_ksteps",
-    "mpx_synth_fused_scratch_floats",
-    "mpx_synthesis_compressed_fused",
     "mpx_host_const_to_var_scan",
     "mpx_host_plan_analysis",
     "mpx_host_plan_analysis_batch",
@@ -198,15 +194,6 @@ def _load_locked():
     lib.mpx_synthesis_compressed_ola_spectra.restype = ctypes.c_int
     lib.mpx_synthesis_compressed_ola_spectra.argtypes = ([vp, ctypes.c_int, vp] + [vp] * 19 +
                                                          [vp, i32, vp, vp, i32, vp, vp, i64, i32, vp])
-    lib.mpx_synth_fused_format.restype = ctypes.c_int
-    lib.mpx_synth_fused_format.argtypes = []
-    lib.mpx_synth_fused_ksteps.restype = ctypes.c_int
-    lib.mpx_synth_fused_ksteps.argtypes = [ctypes.c_int, i32, i32, i32, vp, vp]
-    lib.mpx_synth_fused_scratch_floats.restype = i64
-    lib.mpx_synth_fused_scratch_floats.argtypes = [i32]
-    lib.mpx_synthesis_compressed_fused.restype = ctypes.c_int
-    lib.mpx_synthesis_compressed_fused.argtypes = ([vp, ctypes.c_int, vp, vp, i32, vp, vp, vp, i32, vp, i64] + [vp] * 6 +
-                                                   [vp] * 13 + [vp, i32, vp, vp, i32, vp, vp, vp, i32])
     lib.mpx_host_const_to_var_scan.restype = i64
     lib.mpx_host_const_to_var_scan.argtypes = [vp, vp, i64, vp, vp]
     lib.mpx_host_plan_analysis.restype = i64

@@ -1,7 +1,7 @@
 // magphase_comp.hip -- compressed-feature synthesis kernels (synthesis_from_compressed, magphase.py:825-997).
 //
-//   k_mel_unwarp          [F x K] x [K x H] -> exp / identity: la.sp_mel_unwarp and phase_uncompress_type1_mcep as the
-//                         linear maps they are, K <= 64.  fp32 VALU GEMM, A tile broadcast from LDS.
+//   k_mel_unwarp_mfma / _tiled   [F x K] x [K x H] -> exp / identity: la.sp_mel_unwarp and phase_uncompress_type1_mcep as the
+//                         linear maps they are, K <= 64, on the f32 matrix instructions
 //   k_noise_stats<P>      per frame: windowed noise frame -> FFT -> sum_k (ln|Ns[k]|)^2, k = 1..N/2-1 (Q10 gain statistics)
 //   k_synth_comp_pair<P>  per chunk of frames: noise FFT (recomputed) + periodic/aperiodic spectrum assembly
 //                         (Appendix A2 steps 9-12) + inverse FFT + anti-ringing window + LDS overlap-add (as k_synth_ola_pair)
@@ -14,9 +14,8 @@
 #define MPX_COMP_PAIR_WAVES 12
 #endif
 #ifndef MPX_COMP_DIT
-#define MPX_COMP_DIT 0   // 1: both transforms of the compact form in the DIT form (fused multiply-add butterflies,
-                         // wave_fft.hpp; parity-green).  Measured: 1.186 vs 1.195-1.205 ms for the synthesis side of configs[2]
-                         // (-1 %), but 10 registers spill again at 12 waves per CU (scratch traffic): off.
+#define MPX_COMP_DIT 0   // 1: both transforms of the compact form in the DIT form (wave_fft.hpp; parity-green): -1 % on the
+                         // synthesis side of configs[2], but 10 registers spill again at 12 waves per CU: off
 #endif
 
 namespace mpx {
@@ -37,42 +36,6 @@ struct UnwarpJobs {
 
 constexpr int kGemmFrames = 64;   // frames per block
 constexpr int kGemmKMax = 64;
-
-__global__ __launch_bounds__(256) void k_mel_unwarp(UnwarpJobs jobs, long long F, int H, long long ld) {
-    __shared__ float As[kGemmKMax][kGemmFrames];   // transposed tile: As[n][f]
-    const UnwarpJob job = jobs.j[blockIdx.z];
-    const long long f0 = (long long)blockIdx.y * kGemmFrames;
-    const int k = blockIdx.x * 256 + threadIdx.x;
-    const int K = job.K;
-    for (int i = threadIdx.x; i < K * kGemmFrames; i += 256) {
-        const int fl = i / K, n = i - fl * K;      // coalesced read of the [64 x K] slab
-        const long long f = f0 + fl;
-        As[n][fl] = (f < F) ? job.A[f * K + n] : 0.0f;
-    }
-    __syncthreads();
-    if (k >= H) return;
-    float acc[kGemmFrames];
-#pragma unroll
-    for (int f = 0; f < kGemmFrames; ++f) acc[f] = 0.0f;
-    const float* ucol = job.U + k;
-    for (int n = 0; n < K; ++n) {
-        const float u = ucol[(long long)n * H];
-        const float4* a4 = reinterpret_cast<const float4*>(&As[n][0]);
-#pragma unroll
-        for (int q = 0; q < kGemmFrames / 4; ++q) {
-            const float4 a = a4[q];   // same address in every lane: LDS broadcast
-            acc[4 * q + 0] = fmaf(a.x, u, acc[4 * q + 0]);
-            acc[4 * q + 1] = fmaf(a.y, u, acc[4 * q + 1]);
-            acc[4 * q + 2] = fmaf(a.z, u, acc[4 * q + 2]);
-            acc[4 * q + 3] = fmaf(a.w, u, acc[4 * q + 3]);
-        }
-    }
-    float* o = job.out + f0 * ld + k;
-#pragma unroll
-    for (int f = 0; f < kGemmFrames; ++f) {
-        if (f0 + f < F) o[(long long)f * ld] = job.op ? expf(acc[f]) : acc[f];
-    }
-}
 
 // ---------------------------------------------------------------------------------------------
 // mel warp GEMM (compressed analysis): out[f][i] = post( sum_k W[i][k] * pre(x[f][k]) ), i < nout <= 64, k < H
@@ -142,84 +105,6 @@ __device__ __forceinline__ int warp_swz(int r15) {
     if (!kWarpSwizzle) return 0;
     const bool mid = (r15 >= 4) && (r15 < 12);
     return mid ? 2 * (r15 - 4) : 2 * ((r15 < 4) ? r15 : r15 - 8) + 1;
-}
-
-__global__ __launch_bounds__(256) void k_mel_warp(WarpJobs jobs, long long F, int H, const int* __restrict__ row0,
-                                                  const int* __restrict__ row1, const float* __restrict__ rowt,
-                                                  long long ld) {
-    __shared__ __attribute__((aligned(16))) float As[kWarpTile][kWarpStride];   // As[kk][f]
-    __shared__ __attribute__((aligned(16))) float Ws[kWarpTile][kWarpStride];   // Ws[kk][i]
-    const WarpJob job = jobs.j[blockIdx.y];
-    const long long f0 = (long long)blockIdx.x * kWarpTile;   // row tiles on x: no 65535 limit on the frame count
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    const int kk = threadIdx.x & 63, fq = threadIdx.x >> 6;   // staging roles
-    float acc[4][4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = 0.0f;
-
-    // per-frame row table of this block (row0 == row1 == f, t == 0 without interpolation), staged once
-    __shared__ int s_r0[kWarpTile], s_r1[kWarpTile];
-    __shared__ float s_rt[kWarpTile];
-    if (threadIdx.x < kWarpTile) {
-        const long long f = min(f0 + (long long)threadIdx.x, F - 1);
-        s_r0[threadIdx.x] = row0 ? row0[f] : (int)f;
-        s_r1[threadIdx.x] = row0 ? row1[f] : (int)f;
-        s_rt[threadIdx.x] = row0 ? rowt[f] : 0.0f;
-    }
-    __syncthreads();
-
-    for (int k0 = 0; k0 < H; k0 += kWarpTile) {
-        const int k = k0 + kk;
-        const int kc = min(k, H - 1);   // clamped: every load below is unconditional (branch-free) so that the 32
-        const bool kok = k < H;         // loads of a chunk are in flight together instead of one vmcnt(0) wait each
-        float xv[16], xw[16], wv16[16];
-#pragma unroll
-        for (int p = 0; p < 16; ++p) {
-            const int fl = fq + 4 * p;
-            xv[p] = job.x[(long long)s_r0[fl] * ld + kc];
-            xw[p] = job.x[(long long)s_r1[fl] * ld + kc];
-            wv16[p] = job.W[(long long)min(fl, job.nout - 1) * H + kc];
-        }
-#pragma unroll
-        for (int p = 0; p < 16; ++p) {
-            const int fl = fq + 4 * p;
-            const float x = fmaf(xw[p] - xv[p], s_rt[fl], xv[p]);
-            // hardware exp2/log2 (v_exp_f32 / v_log_f32, ~1 ulp): the 1e-7 error is far below the stated tolerance
-            // of this (ill-conditioned, unpinned) stage
-            const float v = warp_prologue(job.mode, x);
-            As[kk][fl] = (kok && f0 + fl < F) ? v : 0.0f;
-            Ws[kk][fl] = (kok && fl < job.nout) ? wv16[p] : 0.0f;
-        }
-        __syncthreads();
-#pragma unroll 8
-        for (int q = 0; q < kWarpTile; ++q) {
-            const float4 a = *reinterpret_cast<const float4*>(&As[q][4 * ty]);
-            const float4 w = *reinterpret_cast<const float4*>(&Ws[q][4 * tx]);
-            const float av[4] = {a.x, a.y, a.z, a.w};
-            const float wv[4] = {w.x, w.y, w.z, w.w};
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) acc[r][c] = fmaf(av[r], wv[c], acc[r][c]);
-        }
-        __syncthreads();
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const long long f = f0 + 4 * ty + r;
-        if (f >= F) continue;
-        const float vo = job.voi ? job.voi[f] : 1.0f;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int i = 4 * tx + c;
-            if (i >= job.nout) continue;
-            float y = acc[r][c];
-            y = warp_epilogue(job.mode, y, vo);
-            job.out[f * job.nout + i] = y;
-        }
-    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1179,263 +1064,6 @@ constexpr size_t lds_bytes_comp_pair() {
     return sizeof(float) * (size_t)(comp_tw_floats<P>() + kCompPairWaves * comp_xbuf_floats<P>() + kCompPairs * ring_len<P>() + 16);
 }
 
-// ---------------------------------------------------------------------------------------------
-// FUSED form (round 5): mel unwarp -> spectrum assembly -> inverse FFT -> overlap-add in ONE launch (magphase.py:852-870
-// then :900-973).  The pair's run is cut into SEGMENTS on the host (hostmath.plan_segments): at most kFuseFmax
-// consecutive frames whose constant-rate rows lie within kFuseRows consecutive rows.  Before it synthesises a segment the
-// pair unwarps it: the two waves share the 64-bin column steps of a [16 rows x K] . [K x H] product on
-// v_mfma_f32_16x16x4_f32 (f32 in, f32 accumulate), exponentiate (magnitudes), park the 16 x 64 tile in the wave's
-// exchange buffer (idle between frames), interpolate the segment's frames out of it (magphase.py:2242-2252, on the
-// exponentials as the reference does) and store them in the PAIR's scratch rows -- 16 frames x (2112 + 2 x 512) floats
-// that the same two waves read back a few microseconds later, frame by frame, exactly where the staged form reads the
-// [F x H] spectra.  The spectra never exist as matrices: no mpx_mel_unwarp_rows launch, no 3 x F x H round trip.
-// U is host-packed in fragment order (hostmath.pack_unwarp_frag: one 16-byte load per lane = 4 k-steps of a column
-// tile).  Two waves, two barriers per segment (pair_barrier: an LDS counter): scratch free -> produce -> scratch full.
-// ---------------------------------------------------------------------------------------------
-constexpr int kFuseRows = 16;                       // constant-rate rows per product tile (the MFMA's M)
-constexpr int kFuseFmax = 16;                       // frames per segment (entries of the frame table in the buffer's pad)
-constexpr int kFuseLdm = 2112;                      // magnitude floats per scratch frame (33 steps of 64 bins)
-constexpr int kFuseLdp = 512;                       // real / imag floats per scratch frame (bins below the crossfade's end)
-constexpr int kFuseFrame = kFuseLdm + 2 * kFuseLdp; // floats per scratch frame
-constexpr int kFuseMagSteps = kFuseLdm / 64;        // 33
-constexpr int kFusePhSteps = kFuseLdp / 64;         // 8 per stream
-
-struct FuseArgs {
-    const float* a_mag;      // [n_rows x k_mag] log-mel magnitudes (after the post-filter, if any)
-    const float* a_real;     // [n_rows x k_phase]
-    const float* a_imag;
-    const float4* up_mag;    // hostmath.pack_unwarp_frag(u_mag): [132 column tiles][KQ][64 lanes] float4
-    const float4* up_phase;  // the same of u_phase: [32 column tiles][KQ][64 lanes]
-    const int* seg_fb;       // first frame of every segment
-    const int* seg_rb;       // first constant-rate row of every segment
-    const int* run_seg_off;  // [n_runs + 1] segments of run r: run_seg_off[r] .. run_seg_off[r + 1]
-    float* scratch;          // [n_slots x kFuseFmax x kFuseFrame]
-    long long n_rows;
-    int k_mag, k_phase;
-};
-
-typedef float fuse_f32x4 __attribute__((ext_vector_type(4)));
-
-// Column steps [s0, s1) of one stream of a segment: out[i][64 s + lane] = lerp(op(U A[r0_i]), op(U A[r1_i]), t_i) for the
-// segment's frames i < 16 (table entries past the last frame repeat it: branch-free, the repeats store the same values).
-// KT: k-steps of four coefficients (K <= 4 KT; U is packed in groups of four k-steps, KQ = ceil(KT / 4)).  xbuf: the wave's exchange buffer = the 16 x 64 tile (row stride kXStride) with
-// the frame table in the rows' four pad floats (entry i: tile offsets of its two rows, weight).
-// Interpolation of the segment's frames out of the 16 x 64 tile and their stores, FOUR frames per wave instruction: lane
-// = (frame 4 it + (lane >> 4), bin quad lane & 15) reads its two rows' 16 bytes (a 16-lane group reads one row's 256
-// contiguous bytes: conflict-free at any row offset), interpolates four bins and stores them as one 16-byte store -- a
-// quarter of the LDS reads and global stores of the lane-per-bin form (which cost 0.16 ms of the fused launch).
-__device__ __forceinline__ void fuse_interp_store(const float* xbuf, int nf, float* __restrict__ o /* + 64 s */, int lane) {
-    const int fq = lane >> 4, q4 = 4 * (lane & 15);
-    for (int i0 = 0; i0 < nf; i0 += 8) {   // two batches of four frames in flight
-        float4 e[2], m0[2], m1[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            e[u] = *reinterpret_cast<const float4*>(xbuf + (i0 + 4 * u + fq) * kXStride + 64);   // (entries >= nf repeat the last frame)
-            m0[u] = *reinterpret_cast<const float4*>(xbuf + __builtin_bit_cast(int, e[u].x) + q4);
-            m1[u] = *reinterpret_cast<const float4*>(xbuf + __builtin_bit_cast(int, e[u].y) + q4);
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            if (i0 + 4 * u < nf) {
-                const float w = e[u].z;
-                float4 v;
-                v.x = fmaf(m1[u].x - m0[u].x, w, m0[u].x);
-                v.y = fmaf(m1[u].y - m0[u].y, w, m0[u].y);
-                v.z = fmaf(m1[u].z - m0[u].z, w, m0[u].z);
-                v.w = fmaf(m1[u].w - m0[u].w, w, m0[u].w);
-                *reinterpret_cast<float4*>(o + (size_t)__builtin_bit_cast(int, e[u].w) + q4) = v;
-            }
-        }
-    }
-}
-
-template <int KT, bool EXP>
-__device__ __forceinline__ void fuse_unwarp_steps(const float* __restrict__ A, int K, long long n_rows, int rb,
-                                                  const float4* __restrict__ up, int s0, int s1, int nf,
-                                                  float* xbuf, float* __restrict__ out, int lane) {
-    constexpr int KQ = (KT + 3) / 4;
-    // (laundered: everything derived from the lane id here is invariant over the whole kernel, and hoisted out of the
-    // frame loop it costs the frame body its registers)
-    asm volatile("" : "+v"(lane));
-    const int li = lane & 15, gq = lane >> 4;
-    float a[4 * KQ];
-    {
-        const float* arow = A + min((long long)rb + li, n_rows - 1) * K;
-#pragma unroll
-        for (int t = 0; t < 4 * KQ; ++t) {
-            const int k = 4 * t + gq;
-            const float v = arow[min(k, K - 1)];
-            a[t] = (k < K) ? v : 0.0f;
-        }
-    }
-    // one column tile (16 bins) at a time: its U fragments (KQ 16-byte loads, the NEXT tile's in flight behind this tile's
-    // matrix instructions), KT dependent MFMAs into one accumulator -- the matrix pipe takes one instruction per 32
-    // cycles whatever their dependence --, op, four values per lane into the tile buffer.  Every fourth tile completes a
-    // 64-bin step: the segment's frames are interpolated out of the buffer and stored.
-    // TWO column tiles (2 x 16 bins) at a time, their KT-long accumulator chains interleaved (one dependent chain runs the
-    // matrix pipe at half rate: measured 0.33 ms of MFMA time per launch against 0.165 ms of pipe time); the NEXT pair's U
-    // fragments (2 KQ 16-byte loads) are in flight behind this pair's matrix instructions.  Every second pair completes a
-    // 64-bin step: the segment's frames are interpolated out of the buffer and stored.
-    float4 b[2][2][KQ];   // [buffer][tile of the pair][k-quad]
-    const float4* upl = up + lane;
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int q = 0; q < KQ; ++q) b[0][h][q] = upl[((size_t)(4 * s0 + h) * KQ + q) * 64];
-    for (int s = s0; s < s1; ++s) {
-        wave_sync();   // the previous step's readers are done with the tile
-#pragma unroll
-        for (int cp = 0; cp < 2; ++cp) {
-            const int ct = 4 * s + 2 * cp;
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int ctn = min(ct + 2 + h, 4 * s1 - 1);   // (past the end: the last tile again, branch-free)
-#pragma unroll
-                for (int q = 0; q < KQ; ++q) b[(cp + 1) & 1][h][q] = upl[((size_t)ctn * KQ + q) * 64];
-            }
-            fuse_f32x4 acc0 = fuse_f32x4{0.0f, 0.0f, 0.0f, 0.0f}, acc1 = acc0;
-#pragma unroll
-            for (int q = 0; q < KQ; ++q) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if (4 * q + e < KT) {
-                        const float4 bq0 = b[cp & 1][0][q], bq1 = b[cp & 1][1][q];
-                        const float bv0 = (e == 0) ? bq0.x : ((e == 1) ? bq0.y : ((e == 2) ? bq0.z : bq0.w));
-                        const float bv1 = (e == 0) ? bq1.x : ((e == 1) ? bq1.y : ((e == 2) ? bq1.z : bq1.w));
-#ifdef MPX_PROBE_FUSE_NOMFMA   // ablation (timing only)
-                        acc0[e] = fmaf(a[4 * q + e], bv0, acc0[e]);
-                        acc1[e] = fmaf(a[4 * q + e], bv1, acc1[e]);
-#else
-                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * q + e], bv0, acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * q + e], bv1, acc1, 0, 0, 0);
-#endif
-                    }
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                xbuf[(4 * gq + r) * kXStride + 32 * cp + li] = EXP ? __expf(acc0[r]) : acc0[r];
-                xbuf[(4 * gq + r) * kXStride + 32 * cp + 16 + li] = EXP ? __expf(acc1[r]) : acc1[r];
-            }
-        }
-        wave_sync();
-        float* o = out + 64 * s;
-#ifdef MPX_PROBE_FUSE_NOINTERP   // ablation (timing only): no interpolation / store phase
-        if (xbuf[lane] == 123.456f) o[0] = 1.0f;
-        const int nf_ = 0;
-#else
-        const int nf_ = nf;
-#endif
-        fuse_interp_store(xbuf, nf_, o, lane);
-    }
-    wave_sync();
-}
-
-// The same product on v_mfma_f32_16x16x32_bf16 (the matrix pipe proper: 16 cycles per instruction) with float32 accuracy:
-// every operand is split into three bfloat16 values (x = x0 + x1 + x2 up to 2^-24 |x|; U on the host,
-// hostmath.pack_unwarp_frag_bf16, the 16 coefficient rows here), the six partial products x_i u_j with i + j <= 2 are
-// exact in float32 and summed by the instruction's float32 accumulator, smallest first.  A [16 x 64] . [64 x 16] tile is
-// 2 k-blocks x 6 terms = 12 instructions = 192 cycles against 15 x 32-40 for the float32 form -- and short bursts of
-// these hide under the other waves' VALU work where the float32 ones did not (probe: 176 per frame +0.011 ms on the
-// launch, 208 float32 ones +0.154; profiles/r05_fused_synthesis_ablation.txt).  Accuracy: as the float32 chain
-// (tests/test_fused_synthesis_host.py: 5e-6 against 6e-6 on a log-spectrum warp; the dropped terms are below 2^-24).
-typedef __bf16 fuse_bf16x8 __attribute__((ext_vector_type(8)));
-
-template <bool EXP>
-__device__ __forceinline__ void fuse_unwarp_steps_bf16(const float* __restrict__ A, int K, long long n_rows, int rb,
-                                                       const uint4* __restrict__ up, int s0, int s1, int nf, float* xbuf,
-                                                       float* __restrict__ out, int lane) {
-    asm volatile("" : "+v"(lane));   // (see fuse_unwarp_steps)
-    const int li = lane & 15, gq = lane >> 4;
-    // A fragments: row rb + li, k-slots 32 kb + 8 gq + j, split three ways
-    fuse_bf16x8 a[2][3];
-    {
-        const float* arow = A + min((long long)rb + li, n_rows - 1) * K;
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int k = 32 * kb + 8 * gq + j;
-                const float t = arow[min(k, K - 1)];
-                const float v = (k < K) ? t : 0.0f;
-                const __bf16 h0 = (__bf16)v;
-                const float r1 = v - (float)h0;
-                const __bf16 h1 = (__bf16)r1;
-                const __bf16 h2 = (__bf16)(r1 - (float)h1);
-                a[kb][0][j] = h0;
-                a[kb][1][j] = h1;
-                a[kb][2][j] = h2;
-            }
-        }
-    }
-    // U fragments of a column tile: [kb][split] 16-byte loads; two tiles (two accumulator chains) per pass, the next pair's
-    // loads in flight behind this pair's matrix instructions
-    uint4 b[2][2][2][3];   // [buffer][tile of the pair][kb][split]
-    const uint4* upl = up + lane;
-    auto load_pair = [&](int buf, int ct_first, int ct_last) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int ct = min(ct_first + h, ct_last);
-#pragma unroll
-            for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                for (int sp = 0; sp < 3; ++sp) b[buf][h][kb][sp] = upl[((size_t)(ct * 2 + kb) * 3 + sp) * 64];
-        }
-    };
-    load_pair(0, 4 * s0, 4 * s1 - 1);
-    for (int s = s0; s < s1; ++s) {
-        wave_sync();   // the previous step's readers are done with the tile
-#pragma unroll
-        for (int cp = 0; cp < 2; ++cp) {
-#ifndef MPX_PROBE_FUSE_NOULOAD   // ablation (timing only): the first pair's U fragments for every tile
-            load_pair((cp + 1) & 1, 4 * s + 2 * cp + 2, 4 * s1 - 1);   // (past the end: the last tile again, branch-free)
-#else
-            if (cp == 1) {
-#pragma unroll
-                for (int h = 0; h < 2; ++h)
-#pragma unroll
-                    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-                        for (int sp = 0; sp < 3; ++sp) asm volatile("" : "+v"(b[0][h][kb][sp].x), "+v"(b[1][h][kb][sp].x));
-            }
-#endif
-            fuse_f32x4 acc0 = fuse_f32x4{0.0f, 0.0f, 0.0f, 0.0f}, acc1 = acc0;
-            // terms (i, j) = (split of A, split of U), smallest products first
-#define MPX_FUSE_TERM(I, J)                                                                                                 \
-    do {                                                                                                                    \
-        _Pragma("unroll") for (int kb = 0; kb < 2; ++kb) {                                                                  \
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kb][I], __builtin_bit_cast(fuse_bf16x8, b[cp & 1][0][kb][J]),  \
-                                                           acc0, 0, 0, 0);                                                  \
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kb][I], __builtin_bit_cast(fuse_bf16x8, b[cp & 1][1][kb][J]),  \
-                                                           acc1, 0, 0, 0);                                                  \
-        }                                                                                                                   \
-    } while (0)
-            MPX_FUSE_TERM(2, 0);
-            MPX_FUSE_TERM(1, 1);
-            MPX_FUSE_TERM(0, 2);
-            MPX_FUSE_TERM(1, 0);
-            MPX_FUSE_TERM(0, 1);
-            MPX_FUSE_TERM(0, 0);
-#undef MPX_FUSE_TERM
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                xbuf[(4 * gq + r) * kXStride + 32 * cp + li] = EXP ? __expf(acc0[r]) : acc0[r];
-                xbuf[(4 * gq + r) * kXStride + 32 * cp + 16 + li] = EXP ? __expf(acc1[r]) : acc1[r];
-            }
-        }
-        wave_sync();
-        float* o = out + 64 * s;
-#ifdef MPX_PROBE_FUSE_NOINTERP   // ablation (timing only): no interpolation / store phase
-        if (xbuf[lane] == 123.456f) o[0] = 1.0f;
-        const int nf_ = 0;
-#else
-        const int nf_ = nf;
-#endif
-        fuse_interp_store(xbuf, nf_, o, lane);
-    }
-    wave_sync();
-}
-
 // LERP: every frame interpolates between two spectrum rows (row0 / row1 / rowt tables); false: one row per frame, row
 // index = frame index (variable-rate input, or rows already interpolated by mpx_mel_unwarp_rows) -- half the feature loads.
 // NPQ >= 0 (one-row-per-frame form): the caller's promise n_per <= 64 NPQ at compile time -- only the own bins of the
@@ -1446,7 +1074,7 @@ __device__ __forceinline__ void fuse_unwarp_steps_bf16(const float* __restrict__
 // and the freed registers allow batches of (8, 8) = 56 / 32 loads: two exposed load latencies per frame instead of four.
 // NPQ < 0: anything goes (run-time tests only).
 // SPEC: the noise spectra come from HBM (tb.nspec, stored by k_noise_stats) instead of a second transform of the frame.
-template <int P, bool LERP, int NPQ = -1, bool FUSED = false, int KTM = 15, int KTP = 12, bool SPEC = false>
+template <int P, bool LERP, int NPQ = -1, bool SPEC = false>
 __global__ __launch_bounds__(kCompPairWaves * 64) void k_synth_comp_pair(const float* __restrict__ mag,
                                                                         const float* __restrict__ real,
                                                                         const float* __restrict__ imag,
@@ -1461,11 +1089,8 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_synth_comp_pair(const f
                                                                         int nslots,
                                                                         const float* __restrict__ tw_g,
                                                                         float* __restrict__ strips,
-                                                                        float* __restrict__ pcm, long long ld, int n_per,
-                                                                        FuseArgs fz) {
-    static_assert(!FUSED || (P == 32 && !LERP && NPQ == 8 && comp_compact<P>()),
-                  "the fused form is built on the 12-wave one-row-per-frame kernel of N = 4096");
-    static_assert(!SPEC || (P == 32 && !LERP && !FUSED), "stored noise spectra: N = 4096, one row per frame, staged unwarp");
+                                                                        float* __restrict__ pcm, long long ld, int n_per) {
+    static_assert(!SPEC || (P == 32 && !LERP), "stored noise spectra: N = 4096, one row per frame");
     constexpr int M = 64 * P, N = 2 * M, R = ring_len<P>();
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* tw = smem;
@@ -1479,32 +1104,9 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_synth_comp_pair(const f
     float* ring = smem + kRing0 + pair * R;
     const unsigned ring_byte = 4u * (unsigned)(kRing0 + pair * R);
     int* turn = reinterpret_cast<int*>(smem + kRing0 + kCompPairs * R) + pair;
-    int* pbar = turn + kCompPairs;   // FUSED: the pair's barrier counter (2 kCompPairs <= 16 ints of slack)
-    static_assert(2 * kCompPairs <= 16, "turn + barrier counters fit the 16 floats behind the rings");
-    if constexpr (kCompact) {   // the even registers' twiddles only: entry e of a half row = entry 2 e of the full row
-        for (int i = threadIdx.x; i < tw_half_floats<P>(); i += kCompPairWaves * 64) {
-            const int l = i / tw_half_stride<P>(), c = i - l * tw_half_stride<P>();
-            float v = 0.0f;
-            if (c < P) {
-#if MPX_COMP_DIT   // natural register order for the DIT first pass: entry e = W_M^{l e}, at register brev(e) of the full row
-                v = tw_g[l * tw_stride<P>() + 2 * brev(c >> 1, ilog2(P)) + (c & 1)];
-#else              // the even registers' twiddles: entry e of a half row = entry 2 e of the full row
-                v = tw_g[l * tw_stride<P>() + 4 * (c >> 1) + (c & 1)];
-#endif
-            } else {   // the pad: this lane's constants (tw_half_pad): W_N^{-lane} (cos, sin), W_128^lane (cos, sin)
-                float sn, cs;
-                if (c < P + 2) sincospif(-2.0f * (float)l / (float)N, &sn, &cs);
-                else sincospif((float)l / 64.0f, &sn, &cs);
-                v = ((c - P) & 1) ? sn : cs;
-            }
-            tw[i] = v;
-        }
-    } else {
-        for (int i = threadIdx.x; i < tw_floats<P>(); i += kCompPairWaves * 64) tw[i] = tw_g[i];
-    }
-    for (int i = threadIdx.x; i < kCompPairs * R; i += kCompPairWaves * 64) smem[kRing0 + i] = 0.0f;
-    if (threadIdx.x < 2 * kCompPairs) turn[threadIdx.x - pair] = 0;   // thread t < 2 kCompPairs has pair == 0 (turn + pbar)
-    __syncthreads();
+    static_assert(kCompPairs <= 16, "the tickets fit the 16 floats behind the rings");
+    pair_kernel_prologue<P, kCompact, MPX_COMP_DIT != 0>(tw, tw_g, smem + kRing0, kCompPairs * R, turn - pair, kCompPairs,
+                                                         kCompPairWaves * 64);
 
     float wa_s0, wa_c0, ws_s0, ws_c0;   // analysis-side lane twiddle W_N^kappa and synthesis-side conj(W_N^lane)
     sincospif(-2.0f * (float)kappa<P>(lane_id) / (float)N, &wa_s0, &wa_c0);
@@ -1515,151 +1117,23 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_synth_comp_pair(const f
     if (slot >= nslots) return;
 
     // cursor over this wave's frames: every second frame of every run of the pair's work list (see k_synth_ola_pair)
-    struct Cursor {
-        int wi, fi, ci, ticket_base, fb, fe, x0, valid;
-    };
+    typedef PairCursor Cursor;
     const int wi_end = slot_off[slot + 1];
-    auto settle = [&](Cursor& c) {
-        while (c.wi < wi_end) {
-            c.ci = slot_runs[c.wi];
-            c.fb = runs[c.ci].frame_begin;
-            c.fe = runs[c.ci].frame_end;
-            c.x0 = runs[c.ci].x0;
-            c.fi = c.fb + half;
-            if (c.fi < c.fe) {
-                c.valid = 1;
-                return;
-            }
-            c.ticket_base += c.fe - c.fb;
-            ++c.wi;
-        }
-        c.valid = 0;
-    };
-    auto advance = [&](Cursor& c) {
-        c.fi += 2;
-        if (c.fi >= c.fe) {
-            c.ticket_base += c.fe - c.fb;
-            ++c.wi;
-            settle(c);
-        }
-    };
+    auto advance = [&](Cursor& c) { pair_cursor_advance(c, wi_end, half, runs, slot_runs); };
     Cursor cur;
     cur.wi = slot_off[slot];
     cur.ticket_base = 0;
-    settle(cur);
+    pair_cursor_settle(cur, wi_end, half, runs, slot_runs);
 
-    // ---- FUSED: the pair's production cursor over the segments of its work list.  Both waves call produce_next() once per
-    // segment, in the same order (a wave without a frame in a segment still takes its share of the product), so the two
-    // barriers of a segment pair up: [scratch free] produce [scratch full].
-    int pz_wi = slot_off[slot], pz_s = -1;      // work item / segment to produce next (-1: run not opened yet)
-    int cs_wi = -1, cs_fb = 0, cs_fe = 0;       // the segment the scratch holds: work item, frames [cs_fb, cs_fe)
-    int nbar = 0;
-    float* const scr = FUSED ? fz.scratch + (size_t)slot * (size_t)(kFuseFmax * kFuseFrame) : nullptr;
-    auto pair_barrier = [&]() {
-#ifdef MPX_PROBE_FUSE_NOBAR   // ablation (timing only: the scratch rows are then read while they are written)
-        return;
-#endif
-        ++nbar;
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        if (lane_id == 0) __hip_atomic_fetch_add(pbar, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        int spins = 0;   // bounded: a lost partner must not hang the device (the output is then wrong, and the tests say so)
-        while (__hip_atomic_load(pbar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < 2 * nbar && ++spins < (1 << 24))
-            __builtin_amdgcn_s_sleep(1);
-        asm volatile("" ::: "memory");
-    };
-    auto produce = [&](int sfb, int sfe, int rb) {
-        const int nf = sfe - sfb;
-        int any_v;
-        int lane_p = lane_id;
-        asm volatile("" : "+v"(lane_p));
-        {   // frame table in the pad of the tile's rows: entry i = (tile offsets of the frame's two rows, weight, scratch offset)
-            const int i = min(lane_p & 15, nf - 1);
-            const int f = sfb + i;
-            const int r0 = tb.row0[f] - rb, r1 = tb.row1[f] - rb;
-            if (lane_p < kFuseFmax)
-                *reinterpret_cast<float4*>(xbuf + lane_p * kXStride + 64) =
-                    make_float4(__builtin_bit_cast(float, r0 * kXStride), __builtin_bit_cast(float, r1 * kXStride), tb.rowt[f],
-                                __builtin_bit_cast(float, i * kFuseFrame));
-            any_v = __any(tb.voiced[f] != 0);
-        }
-        wave_sync();
-#ifdef MPX_PROBE_FUSE_NOPROD   // ablation (timing only): barriers and the frame table, no product
-        return;
-#endif
-        // shares: the magnitude steps (60 MFMAs each) and, with a voiced frame in the segment, the 2 x 8 phase steps
-        const int split = any_v ? (kFuseMagSteps * 7) / 10 : (kFuseMagSteps + 1) / 2;
-        if constexpr (KTM == 0) {   // the three-way bfloat16 split on v_mfma_f32_16x16x32_bf16
-            const uint4* um = reinterpret_cast<const uint4*>(fz.up_mag);
-            const uint4* uph = reinterpret_cast<const uint4*>(fz.up_phase);
-            if (half == 0) {
-                fuse_unwarp_steps_bf16<true>(fz.a_mag, fz.k_mag, fz.n_rows, rb, um, 0, split, nf, xbuf, scr, lane_id);
-            } else {
-                fuse_unwarp_steps_bf16<true>(fz.a_mag, fz.k_mag, fz.n_rows, rb, um, split, kFuseMagSteps, nf, xbuf, scr, lane_id);
-                if (any_v) {
-                    fuse_unwarp_steps_bf16<false>(fz.a_real, fz.k_phase, fz.n_rows, rb, uph, 0, kFusePhSteps, nf, xbuf,
-                                                  scr + kFuseLdm, lane_id);
-                    fuse_unwarp_steps_bf16<false>(fz.a_imag, fz.k_phase, fz.n_rows, rb, uph, 0, kFusePhSteps, nf, xbuf,
-                                                  scr + kFuseLdm + kFuseLdp, lane_id);
-                }
-            }
-        } else if (half == 0) {
-            fuse_unwarp_steps<(KTM > 0 ? KTM : 1), true>(fz.a_mag, fz.k_mag, fz.n_rows, rb, fz.up_mag, 0, split, nf, xbuf, scr, lane_id);
-        } else {
-            fuse_unwarp_steps<(KTM > 0 ? KTM : 1), true>(fz.a_mag, fz.k_mag, fz.n_rows, rb, fz.up_mag, split, kFuseMagSteps, nf, xbuf, scr, lane_id);
-            if (any_v) {
-                fuse_unwarp_steps<(KTP > 0 ? KTP : 1), false>(fz.a_real, fz.k_phase, fz.n_rows, rb, fz.up_phase, 0, kFusePhSteps, nf, xbuf,
-                                              scr + kFuseLdm, lane_id);
-                fuse_unwarp_steps<(KTP > 0 ? KTP : 1), false>(fz.a_imag, fz.k_phase, fz.n_rows, rb, fz.up_phase, 0, kFusePhSteps, nf, xbuf,
-                                              scr + kFuseLdm + kFuseLdp, lane_id);
-            }
-        }
-    };
-    auto produce_next = [&]() -> bool {
-        for (;;) {
-            if (pz_wi >= wi_end) return false;
-            const int ci = slot_runs[pz_wi];
-            if (pz_s < 0) pz_s = fz.run_seg_off[ci];
-            const int se = fz.run_seg_off[ci + 1];
-            if (pz_s < se) {
-                cs_wi = pz_wi;
-                cs_fb = fz.seg_fb[pz_s];
-                cs_fe = (pz_s + 1 < se) ? fz.seg_fb[pz_s + 1] : runs[ci].frame_end;
-                const int rb = fz.seg_rb[pz_s];
-                ++pz_s;
-                pair_barrier();   // both waves are done with the previous segment's scratch rows
-                produce(cs_fb, cs_fe, rb);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                pair_barrier();   // both shares are stored
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                return true;
-            }
-            ++pz_wi;
-            pz_s = -1;
-        }
-    };
-    if (!cur.valid) {
-        if constexpr (FUSED) {
-            while (produce_next()) {
-            }
-        }
-        return;
-    }
+    if (!cur.valid) return;
 
     // the noise samples of a frame are copied HBM -> LDS (into the transpose buffer) while the previous frame's
     // inverse FFT finishes and its overlap-add runs (same scheme as k_analysis)
     constexpr int kTile = kCompact ? 32 * P : 64 * P;
     FrameGeom g = frame_geom(noise, tb.npos[cur.fi], tb.nleft[cur.fi], tb.nright[cur.fi], N);
-    bool staged = false;   // FUSED: the exchange buffer is the product tile between segments, the copy starts after it
-    if constexpr (!FUSED && !SPEC) stage_samples_async(g, 0, kTile, xbuf_byte, lane_id);
+    if constexpr (!SPEC) stage_samples_async(g, 0, kTile, xbuf_byte, lane_id);
 
     while (cur.valid) {
-        if constexpr (FUSED) {
-            while (!(cs_wi == cur.wi && cur.fi < cs_fe)) produce_next();
-            if (!staged) {
-                g = frame_geom(noise, tb.npos[cur.fi], tb.nleft[cur.fi], tb.nright[cur.fi], N);
-                stage_samples_async(g, 0, kTile, xbuf_byte, lane_id);
-            }
-        }
         int lane = lane_id;
         float wa_s = 0.0f, wa_c = 1.0f, ws_s = 0.0f, ws_c = 1.0f;
         constexpr float lc = 1.0f, ls = 0.0f;
@@ -1672,58 +1146,6 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_synth_comp_pair(const f
         Cursor nxt = cur;
         advance(nxt);
         const int fi = cur.fi;
-#ifdef MPX_PROBE_SYNTH_MFMA   // probe (timing only): N independent matrix instructions per frame in front of the frame's
-        {                     // VALU work -- what does a wave's own MFMA burst cost the pair kernel?
-            typedef float pf32x4 __attribute__((ext_vector_type(4)));
-            pf32x4 pa0 = {0, 0, 0, 0}, pa1 = pa0, pa2 = pa0, pa3 = pa0;
-            float pav = (float)lane, pbv = 1.0f;
-            asm volatile("" : "+v"(pav), "+v"(pbv));
-#ifndef MPX_PROBE_PACE
-#define MPX_PROBE_PACE 0
-#endif
-#if MPX_PROBE_PACE == 1      // the burst at the lowest priority, the frame's VALU work above it
-            __builtin_amdgcn_s_setprio(0);
-#endif
-#if MPX_PROBE_PACE == 2
-#define MPX_PROBE_GAP() asm volatile("s_nop 15\n\ts_nop 11" ::: "memory")
-#elif MPX_PROBE_PACE == 3
-#define MPX_PROBE_GAP() asm volatile("s_nop 15" ::: "memory")
-#elif MPX_PROBE_PACE == 4
-#define MPX_PROBE_GAP() __builtin_amdgcn_s_sleep(1)
-#else
-#define MPX_PROBE_GAP() do { } while (0)
-#endif
-#ifdef MPX_PROBE_SYNTH_BF16   // the same burst as bf16 matrix instructions (16 cycles each on the matrix pipe proper)
-            typedef __bf16 pbf16x8 __attribute__((ext_vector_type(8)));
-            pbf16x8 pa8, pb8;
-            for (int e_ = 0; e_ < 8; ++e_) {
-                pa8[e_] = (__bf16)pav;
-                pb8[e_] = (__bf16)pbv;
-            }
-            for (int i_ = 0; i_ < MPX_PROBE_SYNTH_MFMA / 4; ++i_) {
-                pa0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa8, pb8, pa0, 0, 0, 0);
-                pa1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa8, pb8, pa1, 0, 0, 0);
-                pa2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa8, pb8, pa2, 0, 0, 0);
-                pa3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pa8, pb8, pa3, 0, 0, 0);
-            }
-#else
-            for (int i_ = 0; i_ < MPX_PROBE_SYNTH_MFMA / 4; ++i_) {
-                pa0 = __builtin_amdgcn_mfma_f32_16x16x4f32(pav, pbv, pa0, 0, 0, 0);
-                MPX_PROBE_GAP();
-                pa1 = __builtin_amdgcn_mfma_f32_16x16x4f32(pav, pbv, pa1, 0, 0, 0);
-                MPX_PROBE_GAP();
-                pa2 = __builtin_amdgcn_mfma_f32_16x16x4f32(pav, pbv, pa2, 0, 0, 0);
-                MPX_PROBE_GAP();
-                pa3 = __builtin_amdgcn_mfma_f32_16x16x4f32(pav, pbv, pa3, 0, 0, 0);
-                MPX_PROBE_GAP();
-            }
-#endif
-            asm volatile("" ::"v"(pa0), "v"(pa1), "v"(pa2), "v"(pa3));
-#if MPX_PROBE_PACE == 1
-            __builtin_amdgcn_s_setprio(2);
-#endif
-        }
-#endif
 
         float xr[P], xi[P];
         const int voiced = tb.voiced[fi];
@@ -1770,9 +1192,9 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_synth_comp_pair(const f
                 nh_r = __shfl(nh_r, src);
                 nh_i = __shfl(nh_i, src);
             }
-            const float* mrow = FUSED ? scr + (size_t)(fi - cs_fb) * kFuseFrame : mag + (long long)fi * ld;
-            const float* arow = FUSED ? mrow + kFuseLdm : real + (long long)fi * ld;
-            const float* brow = FUSED ? arow + kFuseLdp : imag + (long long)fi * ld;
+            const float* mrow = mag + (long long)fi * ld;
+            const float* arow = real + (long long)fi * ld;
+            const float* brow = imag + (long long)fi * ld;
             // Unvoiced frames have no periodic component (its mask is zero, magphase.py:873-876): the phase features and
             // the periodic curve are neither loaded nor used -- one wave-uniform branch per frame, 4 instead of 10 loads and
             // a third of the arithmetic per bin pair for about a third of the frames.
@@ -2072,9 +1494,7 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_synth_comp_pair(const f
         } else {
             wave_fft_front<P, +1>(xr, xi, tw, xbuf, lane);
         }
-        // FUSED: only inside the segment -- the next segment's product needs the buffer first
-        staged = !SPEC && nxt.valid && (!FUSED || (nxt.wi == cur.wi && nxt.fi < cs_fe));
-        if (staged) {   // the exchange buffer is idle from here on: start the copy of the next frame's noise
+        if (!SPEC && nxt.valid) {   // the exchange buffer is idle from here on: start the copy of the next frame's noise
             g = frame_geom(noise, tb.npos[nxt.fi], tb.nleft[nxt.fi], tb.nright[nxt.fi], N);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             stage_samples_async(g, 0, kTile, xbuf_byte, lane);
@@ -2130,10 +1550,6 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_synth_comp_pair(const f
         __hip_atomic_store(turn, ticket + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         cur = nxt;
     }
-    if constexpr (FUSED) {   // segments after this wave's last frame: the partner still needs this wave's share
-        while (produce_next()) {
-        }
-    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2155,29 +1571,6 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_synth_comp_pair(const f
 // transform).  Both are held to the two-launch path's tolerances against the oracle.
 // Every frame index of [0, n_frames) must belong to exactly one run: a frame outside the runs is not analysed.
 // ---------------------------------------------------------------------------------------------
-#ifdef MPX_PROBE_RT   // probe build (tools/roundtrip_phase_probe.py): per wave, start / end on the 100 MHz clock, frames,
-// shader cycles, and the s_memtime ticks spent in 8 phases of the frame loop (accumulated in LDS, written out at the end)
-__device__ unsigned long long g_rt_end[4 * 8192];
-__device__ unsigned long long g_rt_phase[8 * 8192];
-#define MPX_RT_PHASE(i)                                                        \
-    do {                                                                       \
-        const unsigned t_ = (unsigned)clock64();                               \
-        if (lane_id == 0) atomicAdd(probe_ph + (i), t_ - probe_last);          \
-        probe_last = t_;                                                       \
-    } while (0)
-#define MPX_RT_F8(a, o) "+v"(a[o]), "+v"(a[o + 1]), "+v"(a[o + 2]), "+v"(a[o + 3]), "+v"(a[o + 4]), "+v"(a[o + 5]), "+v"(a[o + 6]), "+v"(a[o + 7])
-#define MPX_RT_PIN()                                                                      \
-    do {   /* pin the 64 values here, or the clock read floats above / below the arithmetic */ \
-        if constexpr (P == 32) {                                                          \
-            asm volatile("" : MPX_RT_F8(xr, 0), MPX_RT_F8(xr, 8), MPX_RT_F8(xr, 16));     \
-            asm volatile("" : MPX_RT_F8(xr, 24), MPX_RT_F8(xi, 0), MPX_RT_F8(xi, 8));     \
-            asm volatile("" : MPX_RT_F8(xi, 16), MPX_RT_F8(xi, 24));                      \
-        }                                                                                 \
-    } while (0)
-#else
-#define MPX_RT_PHASE(i) do { } while (0)
-#define MPX_RT_PIN() do { } while (0)
-#endif
 template <int P>
 __global__ __launch_bounds__(kCompPairWaves * 64) void k_roundtrip_pair(const float* __restrict__ sig,
                                                                        const long long* __restrict__ fpos,
@@ -2204,30 +1597,8 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_roundtrip_pair(const fl
     float* ring = smem + kRing0 + pair * R;
     const unsigned ring_byte = 4u * (unsigned)(kRing0 + pair * R);
     int* turn = reinterpret_cast<int*>(smem + kRing0 + kCompPairs * R) + pair;
-    if constexpr (kCompact) {   // half twiddle table + the lane constants in the rows' pads, as k_synth_comp_pair
-        for (int i = threadIdx.x; i < tw_half_floats<P>(); i += kCompPairWaves * 64) {
-            const int l = i / tw_half_stride<P>(), c = i - l * tw_half_stride<P>();
-            float v = 0.0f;
-            if (c < P) {
-#if MPX_COMP_DIT
-                v = tw_g[l * tw_stride<P>() + 2 * brev(c >> 1, ilog2(P)) + (c & 1)];
-#else
-                v = tw_g[l * tw_stride<P>() + 4 * (c >> 1) + (c & 1)];
-#endif
-            } else {
-                float sn, cs;
-                if (c < P + 2) sincospif(-2.0f * (float)l / (float)N, &sn, &cs);
-                else sincospif((float)l / 64.0f, &sn, &cs);
-                v = ((c - P) & 1) ? sn : cs;
-            }
-            tw[i] = v;
-        }
-    } else {
-        for (int i = threadIdx.x; i < tw_floats<P>(); i += kCompPairWaves * 64) tw[i] = tw_g[i];
-    }
-    for (int i = threadIdx.x; i < kCompPairs * R; i += kCompPairWaves * 64) smem[kRing0 + i] = 0.0f;
-    if (threadIdx.x < kCompPairs) turn[threadIdx.x - pair] = 0;   // thread t < kCompPairs has pair == 0
-    __syncthreads();
+    pair_kernel_prologue<P, kCompact, MPX_COMP_DIT != 0>(tw, tw_g, smem + kRing0, kCompPairs * R, turn - pair, kCompPairs,
+                                                         kCompPairWaves * 64);
 
     float wa_s0, wa_c0, ws_s0, ws_c0;   // analysis-side lane twiddle W_N^kappa and synthesis-side conj(W_N^lane)
     sincospif(-2.0f * (float)kappa<P>(lane_id) / (float)N, &wa_s0, &wa_c0);
@@ -2235,51 +1606,18 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_roundtrip_pair(const fl
     const int slot = blockIdx.x * kCompPairs + pair;
     if (slot >= nslots) return;
 
-    struct Cursor {
-        int wi, fi, ci, ticket_base, fb, fe, x0, valid;
-    };
+    typedef PairCursor Cursor;
     const int wi_end = slot_off[slot + 1];
-    auto settle = [&](Cursor& c) {
-        while (c.wi < wi_end) {
-            c.ci = slot_runs[c.wi];
-            c.fb = runs[c.ci].frame_begin;
-            c.fe = runs[c.ci].frame_end;
-            c.x0 = runs[c.ci].x0;
-            c.fi = c.fb + half;
-            if (c.fi < c.fe) {
-                c.valid = 1;
-                return;
-            }
-            c.ticket_base += c.fe - c.fb;
-            ++c.wi;
-        }
-        c.valid = 0;
-    };
-    auto advance = [&](Cursor& c) {
-        c.fi += 2;
-        if (c.fi >= c.fe) {
-            c.ticket_base += c.fe - c.fb;
-            ++c.wi;
-            settle(c);
-        }
-    };
+    auto advance = [&](Cursor& c) { pair_cursor_advance(c, wi_end, half, runs, slot_runs); };
     Cursor cur;
     cur.wi = slot_off[slot];
     cur.ticket_base = 0;
-    settle(cur);
+    pair_cursor_settle(cur, wi_end, half, runs, slot_runs);
     if (!cur.valid) return;
 
     constexpr int kTile = kCompact ? 32 * P : 64 * P;
     FrameGeom g = frame_geom(sig, fpos[cur.fi], fleft[cur.fi], fright[cur.fi], N);
     stage_samples_async(g, 0, kTile, xbuf_byte, lane_id);
-#ifdef MPX_PROBE_RT
-    const unsigned long long probe_t0 = wall_clock64();
-    const unsigned long long probe_c0 = clock64();
-    int probe_frames = 0;
-    unsigned* probe_ph = reinterpret_cast<unsigned*>(smem + kRing0 + kCompPairs * R + 16) + 8 * wave;
-    if (lane_id < 8) probe_ph[lane_id] = 0;
-    unsigned probe_last = (unsigned)probe_c0;
-#endif
 
     while (cur.valid) {
         int lane = lane_id;
@@ -2294,16 +1632,12 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_roundtrip_pair(const fl
         Cursor nxt = cur;
         advance(nxt);
         const int fi = cur.fi;
-#ifdef MPX_PROBE_RT
-        probe_last = (unsigned)clock64();
-#endif
 
         float xr[P], xi[P];
         {
             // ---- analysis: X[k] of the own bins k = lane + 64 q and of their mirrors M - k, bin M/2 on lane 0
             float no_r[HP], no_i[HP], nm_r[HP], nm_i[HP], nh_r, nh_i;
             staged_wait<0>();
-            MPX_RT_PHASE(0);   // wait for the staged samples (gfx9's one counter: and for the previous frame's stores)
             noise_spectrum_paired<P, true, kCompact>(g, 0, tw, xbuf, xbuf_byte, lane, wa_c, wa_s, no_r, no_i, nm_r, nm_i, nh_r,
                                                      nh_i, lc, ls);
             if (P != 32) {   // FFT output lanes hold bins kappa(lane) + 64 q; the rows and the merge want bins lane + 64 q
@@ -2318,7 +1652,6 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_roundtrip_pair(const fl
                 nh_r = __shfl(nh_r, src);
                 nh_i = __shfl(nh_i, src);
             }
-            MPX_RT_PHASE(1);   // window + gather + forward transform + split
             // ---- per bin pair q: lossless features (magphase.py:466-474; as k_analysis: X == 0 -> all three 0), their
             // stores, and the pair's step of the Hermitian merge -- feat_merge_paired's arithmetic on the values just
             // stored (X = mag (R + jI) / |R + jI|, magphase.py:1761-1766), pair by pair so that a pair's four inputs die
@@ -2410,8 +1743,6 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_roundtrip_pair(const fl
                 xi[r] = __shfl(pi, src_lane);
             }
         }
-        MPX_RT_PIN();
-        MPX_RT_PHASE(2);   // features + stores + Hermitian merge
         constexpr bool kDit = kCompact && MPX_COMP_DIT;
         if constexpr (kDit) {
             constexpr int LBJ = ilog2(P);
@@ -2441,8 +1772,6 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_roundtrip_pair(const fl
         }
         if constexpr (kDit) wave_fft_dit_back<P, +1>(xr, xi);
         else fft_inreg<P, +1>(xr, xi);
-        MPX_RT_PIN();
-        MPX_RT_PHASE(3);   // inverse transform (+ issue of the next frame's staging)
 
         // ---- ordered section: wait for this frame's ticket
         const RunDesc rd = runs[cur.ci];
@@ -2456,10 +1785,8 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_roundtrip_pair(const fl
         while (__hip_atomic_load(turn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != ticket)
             __builtin_amdgcn_s_sleep(1);
         asm volatile("" ::: "memory");
-        MPX_RT_PHASE(4);   // run / position scalars + ticket wait
         if (flushed < target) flush_ring<R>(ring, strip, pcm0, rd.head_end, rd.out_lo, rd.out_hi, flushed, target, lane);
         wave_sync();
-        MPX_RT_PHASE(5);   // flush of the finished samples
         constexpr float kScale = 0.5f / (float)M;   // the inverse transform's scale, on the overlap-add's multiply-add
         auto plain_add = [](float o, float v, int) { return fmaf(v, kScale, o); };
         auto all_rows = [](int) { return true; };
@@ -2475,24 +1802,9 @@ __global__ __launch_bounds__(kCompPairWaves * 64) void k_roundtrip_pair(const fl
             wave_sync();
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        MPX_RT_PHASE(6);   // overlap-add (+ the run's final flush)
         __hip_atomic_store(turn, ticket + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         cur = nxt;
-#ifdef MPX_PROBE_RT
-        ++probe_frames;
-#endif
     }
-#ifdef MPX_PROBE_RT
-    if (lane_id == 0) {
-        const int w = (blockIdx.x * kCompPairWaves + wave) % 8192;
-        g_rt_end[4 * w + 0] = probe_t0;
-        g_rt_end[4 * w + 1] = wall_clock64();
-        g_rt_end[4 * w + 2] = (unsigned long long)probe_frames;
-        g_rt_end[4 * w + 3] = clock64() - probe_c0;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        for (int i = 0; i < 8; ++i) g_rt_phase[8 * w + i] = probe_ph[i];
-    }
-#endif
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -3124,13 +2436,6 @@ static int mel_unwarp_impl(void* stream, int64_t n_frames, int32_t n_bins, const
     jobs.j[0] = {a_mag, u_mag, out_mag, (int)k_mag, 1};
     jobs.j[1] = {a_real, u_phase, out_real, (int)k_phase, 0};
     jobs.j[2] = {a_imag, u_phase, out_imag, (int)k_phase, 0};
-#ifdef MPX_UNWARP_VALU
-    if (rw.row0) return fail(MPX_ERR_ARG, "mpx_mel_unwarp_rows: not available in the VALU build%s");
-    const dim3 grid((unsigned)((n_bins + 255) / 256), (unsigned)((n_frames + kGemmFrames - 1) / kGemmFrames), 3);
-    if (grid.y > 65535) return fail(MPX_ERR_ARG, "mpx_mel_unwarp: too many frames per call (max 4194240)%s");
-    hipLaunchKernelGGL(k_mel_unwarp, grid, dim3(256), 0, (hipStream_t)stream, jobs, (long long)n_frames, (int)n_bins,
-                       (long long)ld);
-#else
     if (tile_first) {   // magnitudes: one product per constant-rate row, interpolated out of an LDS tile
         if (int rc = dispatch_unwarp_tiled((hipStream_t)stream, jobs.j[0], (int)k_mag, (long long)n_frames, (long long)n_rows,
                                            (int)n_bins, (int)ld, rw, tile_first)) return rc;
@@ -3138,7 +2443,6 @@ static int mel_unwarp_impl(void* stream, int64_t n_frames, int32_t n_bins, const
         if (int rc = dispatch_unwarp_mfma((hipStream_t)stream, jobs, 0, 1, (int)k_mag, (long long)n_frames, (int)n_bins, (int)ld, rw)) return rc;
     }
     if (int rc = dispatch_unwarp_mfma((hipStream_t)stream, jobs, 1, 2, (int)k_phase, (long long)n_frames, (int)n_bins, (int)ld, rw)) return rc;
-#endif
     MPX_HIP_CHECK(hipGetLastError());
     return MPX_OK;
 }
@@ -3265,15 +2569,15 @@ static int synthesis_compressed_ola_impl(void* stream, int fft_len, const void* 
         if (P != 32 || lerp)
             return fail(MPX_ERR_ARG, "mpx_synthesis_compressed_ola_spectra: fft_len 4096 and one row per frame only%s");
         if (n_per <= 512) {
-            if (int rc = set_lds(k_synth_comp_pair<32, false, 8, false, 15, 12, true>, lds_bytes_comp_pair<32>())) return rc;
-            hipLaunchKernelGGL((k_synth_comp_pair<32, false, 8, false, 15, 12, true>), pgrid, pblock, lds_bytes_comp_pair<32>(),
+            if (int rc = set_lds(k_synth_comp_pair<32, false, 8, true>, lds_bytes_comp_pair<32>())) return rc;
+            hipLaunchKernelGGL((k_synth_comp_pair<32, false, 8, true>), pgrid, pblock, lds_bytes_comp_pair<32>(),
                                s, mag, real, imag, noise, tb, per_v, ap_v, ap_u, (const RunDesc*)runs, slot_off, slot_runs,
-                               (int)n_slots, (const float*)tables, strips, pcm_out, (long long)ld, n_per, FuseArgs{});
+                               (int)n_slots, (const float*)tables, strips, pcm_out, (long long)ld, n_per);
         } else {
-            if (int rc = set_lds(k_synth_comp_pair<32, false, -1, false, 15, 12, true>, lds_bytes_comp_pair<32>())) return rc;
-            hipLaunchKernelGGL((k_synth_comp_pair<32, false, -1, false, 15, 12, true>), pgrid, pblock, lds_bytes_comp_pair<32>(),
+            if (int rc = set_lds(k_synth_comp_pair<32, false, -1, true>, lds_bytes_comp_pair<32>())) return rc;
+            hipLaunchKernelGGL((k_synth_comp_pair<32, false, -1, true>), pgrid, pblock, lds_bytes_comp_pair<32>(),
                                s, mag, real, imag, noise, tb, per_v, ap_v, ap_u, (const RunDesc*)runs, slot_off, slot_runs,
-                               (int)n_slots, (const float*)tables, strips, pcm_out, (long long)ld, n_per, FuseArgs{});
+                               (int)n_slots, (const float*)tables, strips, pcm_out, (long long)ld, n_per);
         }
         MPX_HIP_CHECK(hipGetLastError());
         return MPX_OK;
@@ -3283,7 +2587,7 @@ static int synthesis_compressed_ola_impl(void* stream, int fft_len, const void* 
         if (int rc = set_lds(k_synth_comp_pair<PP, LL>, lds_bytes_comp_pair<PP>())) return rc;                       \
         hipLaunchKernelGGL((k_synth_comp_pair<PP, LL>), pgrid, pblock, lds_bytes_comp_pair<PP>(), s, mag, real, imag, \
                            noise, tb, per_v, ap_v, ap_u, (const RunDesc*)runs, slot_off, slot_runs, (int)n_slots,    \
-                           (const float*)tables, strips, pcm_out, (long long)ld, n_per, FuseArgs{});                 \
+                           (const float*)tables, strips, pcm_out, (long long)ld, n_per);                 \
     } while (0)
     if (lerp) {
         if (P == 32) MPX_LAUNCH_COMP(32, true);
@@ -3294,7 +2598,7 @@ static int synthesis_compressed_ola_impl(void* stream, int fft_len, const void* 
             if (int rc = set_lds(k_synth_comp_pair<32, false, 8>, lds_bytes_comp_pair<32>())) return rc;
             hipLaunchKernelGGL((k_synth_comp_pair<32, false, 8>), pgrid, pblock, lds_bytes_comp_pair<32>(), s, mag, real, imag,
                                noise, tb, per_v, ap_v, ap_u, (const RunDesc*)runs, slot_off, slot_runs, (int)n_slots,
-                               (const float*)tables, strips, pcm_out, (long long)ld, n_per, FuseArgs{});
+                               (const float*)tables, strips, pcm_out, (long long)ld, n_per);
         } else if (P == 32) MPX_LAUNCH_COMP(32, false);
         else if (P == 16) MPX_LAUNCH_COMP(16, false);
         else MPX_LAUNCH_COMP(8, false);
@@ -3334,81 +2638,6 @@ int mpx_synthesis_compressed_ola_spectra(void* stream, int fft_len, const void* 
                                          ap_v, ap_u, runs, n_runs, slot_off, slot_runs, n_slots, strips, pcm_out, ld, n_per_bins, spectra);
 }
 
-// ---- fused form: unwarp + synthesis in one launch (k_synth_comp_pair<32, false, 8, true, KTM, KTP>) ----
-// k-steps of the instantiation that serves (k_mag, k_phase); 0 / 0: none (the caller stages the spectra instead)
-static void fused_ksteps(int fft_len, int k_mag, int k_phase, int n_per, int* ktm, int* ktp) {
-    *ktm = *ktp = 0;
-    if (fft_len != 4096 || kCompPairWaves <= 8 || k_mag < 1 || k_phase < 1 || k_mag > 64 || k_phase > 64) return;
-    if (n_per < 1 || n_per > kFuseLdp) return;
-    if (k_mag <= 60 && k_phase <= 48) *ktm = 15, *ktp = 12;
-    else *ktm = 16, *ktp = 16;
-}
-
-// 1: upack_* are hostmath.pack_unwarp_frag_bf16's three-way bfloat16 splits (v_mfma_f32_16x16x32_bf16, the default);
-// 0: hostmath.pack_unwarp_frag's float32 fragments (v_mfma_f32_16x16x4_f32; MAGPHASE_FUSED_F32=1, kept for A/B runs)
-int mpx_synth_fused_format(void) {
-    const char* e = getenv("MAGPHASE_FUSED_F32");
-    return (e && e[0] == '1') ? 0 : 1;
-}
-
-int mpx_synth_fused_ksteps(int fft_len, int32_t k_mag, int32_t k_phase, int32_t n_per_bins, int32_t* ksteps_mag,
-                           int32_t* ksteps_phase) {
-    if (!ksteps_mag || !ksteps_phase) return fail(MPX_ERR_ARG, "mpx_synth_fused_ksteps: null pointer%s");
-    int a, b;
-    fused_ksteps(fft_len, k_mag, k_phase, n_per_bins, &a, &b);
-    *ksteps_mag = a;
-    *ksteps_phase = b;
-    return MPX_OK;
-}
-
-int64_t mpx_synth_fused_scratch_floats(int32_t n_slots) {
-    return n_slots <= 0 ? 0 : (int64_t)n_slots * kFuseFmax * kFuseFrame;
-}
-
-int mpx_synthesis_compressed_fused(void* stream, int fft_len, const void* tables, const float* a_mag, int32_t k_mag,
-                                   const float* upack_mag, const float* a_real, const float* a_imag, int32_t k_phase,
-                                   const float* upack_phase, int64_t n_rows, const int32_t* row0, const int32_t* row1,
-                                   const float* row_t, const int32_t* seg_frame_begin, const int32_t* seg_row_begin,
-                                   const int32_t* run_seg_off, const float* noise, const int64_t* noise_pos,
-                                   const int32_t* noise_left, const int32_t* noise_right, const int32_t* noise_wtype,
-                                   const int32_t* voiced, const float* inv_gain, const int32_t* win_left,
-                                   const int32_t* win_right, const int32_t* pm_rel, const float* per_v, const float* ap_v,
-                                   const float* ap_u, const mpx_ola_run* runs, int32_t n_runs, const int32_t* slot_off,
-                                   const int32_t* slot_runs, int32_t n_slots, float* scratch, float* strips,
-                                   float* pcm_out, int32_t n_per_bins) {
-    int ktm, ktp;
-    fused_ksteps(fft_len, k_mag, k_phase, n_per_bins, &ktm, &ktp);
-    if (!ktm) return fail(MPX_ERR_ARG, "mpx_synthesis_compressed_fused: no fused kernel for this configuration (see mpx_synth_fused_ksteps)%s");
-    if (n_runs < 0 || n_slots < 0 || n_rows < 0) return fail(MPX_ERR_ARG, "mpx_synthesis_compressed_fused: negative count%s");
-    if (n_runs == 0 || n_slots == 0) return MPX_OK;
-    if (n_rows == 0) return fail(MPX_ERR_ARG, "mpx_synthesis_compressed_fused: frames without coefficient rows%s");
-    if (!tables || !a_mag || !upack_mag || !a_real || !a_imag || !upack_phase || !row0 || !row1 || !row_t ||
-        !seg_frame_begin || !seg_row_begin || !run_seg_off || !noise || !noise_pos || !noise_left || !noise_right ||
-        !noise_wtype || !voiced || !inv_gain || !win_left || !win_right || !pm_rel || !per_v || !ap_v || !ap_u || !runs ||
-        !slot_off || !slot_runs || !scratch || !strips || !pcm_out)
-        return fail(MPX_ERR_ARG, "mpx_synthesis_compressed_fused: null pointer%s");
-    CompFrameTabs tb{(const long long*)noise_pos, noise_left, noise_right, noise_wtype, voiced, inv_gain,
-                     row0, row1, row_t, win_left, win_right, pm_rel};
-    FuseArgs fz{a_mag, a_real, a_imag, (const float4*)upack_mag, (const float4*)upack_phase, seg_frame_begin,
-                seg_row_begin, run_seg_off, scratch, (long long)n_rows, (int)k_mag, (int)k_phase};
-    hipStream_t s = (hipStream_t)stream;
-    const dim3 pgrid((n_slots + kCompPairs - 1) / kCompPairs), pblock(kCompPairWaves * 64);
-#define MPX_LAUNCH_FUSED(KM, KP)                                                                                       \
-    do {                                                                                                             \
-        if (int rc = set_lds(k_synth_comp_pair<32, false, 8, true, KM, KP>, lds_bytes_comp_pair<32>())) return rc;    \
-        hipLaunchKernelGGL((k_synth_comp_pair<32, false, 8, true, KM, KP>), pgrid, pblock, lds_bytes_comp_pair<32>(), \
-                           s, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, noise, tb, per_v,  \
-                           ap_v, ap_u, (const RunDesc*)runs, slot_off, slot_runs, (int)n_slots, (const float*)tables, \
-                           strips, pcm_out, (long long)kFuseFrame, (int)n_per_bins, fz);                             \
-    } while (0)
-    if (mpx_synth_fused_format() == 1) MPX_LAUNCH_FUSED(0, 0);
-    else if (ktm == 15) MPX_LAUNCH_FUSED(15, 12);
-    else MPX_LAUNCH_FUSED(16, 16);
-#undef MPX_LAUNCH_FUSED
-    MPX_HIP_CHECK(hipGetLastError());
-    return MPX_OK;
-}
-
 // Slot weights of k_roundtrip_pair (see mpx_synth_comp_slot_weights: pairs of the oldest / middle / youngest waves of the
 // SIMDs).  Interleaved sweeps of the configs[1] step on two boxes: equal shares 0.592 ms, 100:90:80 0.574, 100:86:73 0.567,
 // 100:82:66 0.555, 100:72:60 0.547, 100:75:55 0.539-0.545; a smallest share below ~25 frames per run (100:70:48, 100:78:50)
@@ -3432,17 +2661,6 @@ int mpx_roundtrip_slot_weights(float* weights_host, int32_t n_slots) {
     return MPX_OK;
 }
 
-#ifdef MPX_PROBE_RT
-constexpr size_t kRtProbeBytes = 4 * 8 * kCompPairWaves;
-int mpx_probe_roundtrip(unsigned long long* host_end, unsigned long long* host_phase, int n_waves) {   // probe builds only
-    MPX_HIP_CHECK(hipDeviceSynchronize());
-    MPX_HIP_CHECK(hipMemcpyFromSymbol(host_end, HIP_SYMBOL(g_rt_end), sizeof(unsigned long long) * 4 * (size_t)n_waves));
-    MPX_HIP_CHECK(hipMemcpyFromSymbol(host_phase, HIP_SYMBOL(g_rt_phase), sizeof(unsigned long long) * 8 * (size_t)n_waves));
-    return MPX_OK;
-}
-#else
-constexpr size_t kRtProbeBytes = 0;
-#endif
 int mpx_roundtrip_lossless_ola(void* stream, int fft_len, const void* tables, const float* sig, const int64_t* frame_pos,
                                const int32_t* frame_left, const int32_t* frame_right, int64_t n_frames,
                                const mpx_ola_run* runs, int32_t n_runs, const int32_t* slot_off, const int32_t* slot_runs,
@@ -3460,8 +2678,8 @@ int mpx_roundtrip_lossless_ola(void* stream, int fft_len, const void* tables, co
     const dim3 pgrid((n_slots + kCompPairs - 1) / kCompPairs), pblock(kCompPairWaves * 64);
 #define MPX_LAUNCH_RT(PP)                                                                                              \
     do {                                                                                                             \
-        if (int rc = set_lds(k_roundtrip_pair<PP>, lds_bytes_comp_pair<PP>() + kRtProbeBytes)) return rc;            \
-        hipLaunchKernelGGL(k_roundtrip_pair<PP>, pgrid, pblock, lds_bytes_comp_pair<PP>() + kRtProbeBytes, s, sig,   \
+        if (int rc = set_lds(k_roundtrip_pair<PP>, lds_bytes_comp_pair<PP>())) return rc;            \
+        hipLaunchKernelGGL(k_roundtrip_pair<PP>, pgrid, pblock, lds_bytes_comp_pair<PP>(), s, sig,   \
                            (const long long*)frame_pos, frame_left, frame_right, (const RunDesc*)runs, slot_off,     \
                            slot_runs, (int)n_slots, pm_rel, (const float*)tables, out_mag, out_real, out_imag, strips, \
                            pcm_out, (long long)ld);                                                                  \
@@ -3503,11 +2721,6 @@ static int mel_warp_impl(void* stream, int64_t n_frames, int32_t n_bins, const f
     }
     const long long max_f = phv ? ((long long)n_frames > (long long)n_var_rows ? (long long)n_frames : (long long)n_var_rows) : (long long)n_frames;
     const dim3 grid((unsigned)((max_f + kWarpTile - 1) / kWarpTile), 3);
-#ifdef MPX_WARP_VALU
-    if (phv) return fail(MPX_ERR_ARG, "mpx_mel_warp_rows: not in the VALU build%s");
-    hipLaunchKernelGGL(k_mel_warp, grid, dim3(256), 0, (hipStream_t)stream, jobs, (long long)n_frames, (int)n_bins,
-                       row0, row1, row_t, (long long)ld);
-#else
     {
         const dim3 g2(grid.x, 3);
         const int ntm = ((int)mag_dim + 15) / 16, ntp = ((int)phase_dim + 15) / 16;
@@ -3540,7 +2753,6 @@ static int mel_warp_impl(void* stream, int64_t n_frames, int32_t n_bins, const f
 #undef MPX_WARP_LAUNCH
 #undef MPX_WARP_GO
     }
-#endif
     if (phv) {
         const long long n_el = (long long)n_frames * phase_dim;
         hipLaunchKernelGGL(k_warp_phase_rows, dim3((unsigned)((n_el + 255) / 256)), dim3(256), 0, (hipStream_t)stream,

@@ -420,6 +420,71 @@ struct RunDesc {
 };
 static_assert(sizeof(RunDesc) == 56, "RunDesc must match mpx_ola_run");
 
+// ---------------------------------------------------------------------------------------------
+// Shared front of the pair kernels (k_synth_comp_pair, k_roundtrip_pair): LDS tables and the cursor over a wave's frames.
+// ---------------------------------------------------------------------------------------------
+// First-pass twiddle table into LDS -- COMPACT: the half table (wave_fft.hpp: the even registers' twiddles, or with DIT the
+// first P/2 in natural register order) with this lane's constants in the pad of its row (tw_half_pad: W_N^{-lane} and
+// W_128^lane as (cos, sin)) -- then the pairs' rings and tickets cleared, one __syncthreads().
+template <int P, bool COMPACT, bool DIT>
+__device__ __forceinline__ void pair_kernel_prologue(float* tw, const float* __restrict__ tw_g, float* rings, int ring_floats,
+                                                     int* tickets, int n_tickets, int n_threads) {
+    constexpr int N = 128 * P;
+    if constexpr (COMPACT) {
+        for (int i = threadIdx.x; i < tw_half_floats<P>(); i += n_threads) {
+            const int l = i / tw_half_stride<P>(), c = i - l * tw_half_stride<P>();
+            float v = 0.0f;
+            if (c < P) {
+                v = DIT ? tw_g[l * tw_stride<P>() + 2 * brev(c >> 1, ilog2(P)) + (c & 1)]
+                        : tw_g[l * tw_stride<P>() + 4 * (c >> 1) + (c & 1)];
+            } else {
+                float sn, cs;
+                if (c < P + 2) sincospif(-2.0f * (float)l / (float)N, &sn, &cs);
+                else sincospif((float)l / 64.0f, &sn, &cs);
+                v = ((c - P) & 1) ? sn : cs;
+            }
+            tw[i] = v;
+        }
+    } else {
+        for (int i = threadIdx.x; i < tw_floats<P>(); i += n_threads) tw[i] = tw_g[i];
+    }
+    for (int i = threadIdx.x; i < ring_floats; i += n_threads) rings[i] = 0.0f;
+    if ((int)threadIdx.x < n_tickets) tickets[threadIdx.x] = 0;
+    __syncthreads();
+}
+
+// Cursor over this wave's frames: every second frame (the wave's half) of every run of the pair's work list; ticket_base
+// counts the frames of the runs already passed (the order of the overlap-adds within the pair).
+struct PairCursor {
+    int wi, fi, ci, ticket_base, fb, fe, x0, valid;
+};
+__device__ __forceinline__ void pair_cursor_settle(PairCursor& c, int wi_end, int half, const RunDesc* __restrict__ runs,
+                                                   const int* __restrict__ slot_runs) {
+    while (c.wi < wi_end) {
+        c.ci = slot_runs[c.wi];
+        c.fb = runs[c.ci].frame_begin;
+        c.fe = runs[c.ci].frame_end;
+        c.x0 = runs[c.ci].x0;
+        c.fi = c.fb + half;
+        if (c.fi < c.fe) {
+            c.valid = 1;
+            return;
+        }
+        c.ticket_base += c.fe - c.fb;
+        ++c.wi;
+    }
+    c.valid = 0;
+}
+__device__ __forceinline__ void pair_cursor_advance(PairCursor& c, int wi_end, int half, const RunDesc* __restrict__ runs,
+                                                    const int* __restrict__ slot_runs) {
+    c.fi += 2;
+    if (c.fi >= c.fe) {
+        c.ticket_base += c.fe - c.fb;
+        ++c.wi;
+        pair_cursor_settle(c, wi_end, half, runs, slot_runs);
+    }
+}
+
 // Streams elements [from, to) out of the ring (head strip / pcm_out / nowhere, see RunDesc) and clears their slots.
 // from is a multiple of 64.  One step = 256 elements, FOUR consecutive elements b .. b+3 per lane (b = b0 + 4 lane):
 // elements 2j / 2j+1 live in the even / odd half of the ring at index j, so a lane's quad is one 8-byte read from each

@@ -1641,7 +1641,7 @@ class CompressedSynthesisPlan:
 
     def __init__(self, engine, utts, fs, fft_len=None, b_voi_ap_win=True, b_const_rate=False, alpha_phase=None,
                  noise=None, frames_per_run=None, per_phase_type="magphase", post_filter=False, b_fbank_mel=False,
-                 noise_mode="reference", noise_seeds=None, defer_rng=False, fused=None, noise_spectra=None, prepared=None):
+                 noise_mode="reference", noise_seeds=None, defer_rng=False, noise_spectra=None, prepared=None):
         # prepared: a PreparedSynthesis of these utterances (Engine.prepare_synthesis, e.g. from the planner thread)
         # noise_spectra: None = MAGPHASE_NOISE_SPECTRA ("recompute", the default / "store"); True: every noise frame is
         #            transformed once, its spectrum kept in HBM between the statistics and the synthesis launch (N = 4096)
@@ -1683,26 +1683,23 @@ class CompressedSynthesisPlan:
         # quarter of the work of the plain form, which unwarped all 2 049 bins of both phase streams for every frame (round 5:
         # 0.81 -> ... ms per 128-utterance generation launch).  MAGPHASE_UNWARP_ROWS_VAR=0: the plain form.
         self.unwarp_rows = self.b_const_rate or os.environ.get("MAGPHASE_UNWARP_ROWS_VAR", "1") != "0"
-        want_fused = (os.environ.get("MAGPHASE_SYNTH_FUSED", "0") == "1") if fused is None else bool(fused)
         # the native whole-launch planner (Engine.prepare_synthesis; `prepared`: built ahead, e.g. on the planner thread) takes
-        # the plain case: ndarray coefficient matrices, the default run planner, no opt-in fused launch
-        if (prepared is None and not want_fused and frames_per_run is None and hasattr(e, "prepare_synthesis")
+        # the plain case: ndarray coefficient matrices, the default run planner
+        if (prepared is None and frames_per_run is None and hasattr(e, "prepare_synthesis")
                 and not os.environ.get("MAGPHASE_OLA_FRAMES_PER_RUN") and os.environ.get("MAGPHASE_NATIVE_PREPARE", "1") != "0"):
             prepared = e.prepare_synthesis(utts, fs, fft_len=fft_len, b_voi_ap_win=b_voi_ap_win, b_const_rate=b_const_rate,
                                            wait=False)
         if prepared is not None and (prepared.n_utts != len(utts) or prepared.engine is not e):
             prepared.release()
             raise ValueError("prepared: not the host side of this batch on this engine")
-        if prepared is not None and (want_fused or frames_per_run is not None or prepared.key != (
+        if prepared is not None and (frames_per_run is not None or prepared.key != (
                 int(fs), N, bool(b_const_rate), bool(b_voi_ap_win), bool(self.unwarp_rows))):
             prepared.release()
             prepared = None
         if prepared is not None:
             mt_device = self._tables_prepared(prepared, noise, noise_mode, noise_seeds)
-            self.fused = False
         else:
-            mt_device = self._tables_generic(utts, b_voi_ap_win, noise, noise_mode, noise_seeds, frames_per_run, b_fbank_mel,
-                                             want_fused)
+            mt_device = self._tables_generic(utts, b_voi_ap_win, noise, noise_mode, noise_seeds, frames_per_run)
         H = N // 2 + 1
         # constants: unwarp matrices and per-bin curves (float64 -> float32)
         # (resident on the device per configuration: rebuilding them costs 7 ms on the host, as much as the rest of a
@@ -1803,7 +1800,7 @@ class CompressedSynthesisPlan:
         d = e.to_device_packed([("s", seeds.view(np.int64), np.int64), ("o", self.noise_off_host, np.int64)])
         self.noise_seeds_dev, self.noise_off_dev = d["s"], d["o"]
 
-    def _tables_generic(self, utts, b_voi_ap_win, noise, noise_mode, noise_seeds, frames_per_run, b_fbank_mel, want_fused):
+    def _tables_generic(self, utts, b_voi_ap_win, noise, noise_mode, noise_seeds, frames_per_run):
         """The generic path: any array-like input, utterance by utterance in Python where the native planner declines."""
         e = self.engine
         fs, N, b_const_rate, per_phase_type = self.fs, self.fft_len, self.b_const_rate, self.per_phase_type
@@ -1916,39 +1913,6 @@ class CompressedSynthesisPlan:
         self.a_mag = coef[:n_m].view(self.n_rows, self.mag_dim)
         self.a_real = coef[n_m:n_m + n_p].view(self.n_rows, self.phase_dim)
         self.a_imag = coef[n_m + n_p:].view(self.n_rows, self.phase_dim)
-        # Fused unwarp -> synthesis (mpx_synthesis_compressed_fused; opt-in: MAGPHASE_SYNTH_FUSED=1 or fused=True): N = 4096,
-        # the transmitted phase, a crossfade that ends at or below bin 512.  The runs are cut into segments of <= 16 frames
-        # within 16 coefficient rows; U goes up in MFMA fragment order.  Built, parity-green and MEASURED SLOWER than the
-        # staged pair mpx_mel_unwarp[_rows] -> mpx_synthesis_compressed_ola (1.20 vs 0.90 ms per 57 k frames, the same HBM
-        # traffic: docs/LAB_NOTES.md, "Round 5: the fused synthesis side"), so the staged pair stays the default.
-        self.fused = False
-        if (want_fused and per_phase_type == "magphase" and self.n_runs > 0
-                and hasattr(e.lib, "mpx_synth_fused_ksteps") and 0 < self.n_per <= 512):
-            ktm, ktp = ctypes.c_int32(0), ctypes.c_int32(0)
-            _lib.check(e.lib.mpx_synth_fused_ksteps(N, self.mag_dim, self.phase_dim, int(self.n_per), ctypes.byref(ktm),
-                                                    ctypes.byref(ktp)), "mpx_synth_fused_ksteps")
-            if ktm.value > 0:
-                self.fused = True
-                key_m = "u_mag_fbank" if b_fbank_mel else "u_mag"
-                fmt = int(e.lib.mpx_synth_fused_format())   # 1: three-way bfloat16 splits, 0: float32 fragments
-                u_mag_fn = lambda: (hm.unwarp_fbank_matrix if b_fbank_mel else hm.unwarp_matrix)(self.mag_dim, H, alpha)  # noqa: E731
-                u_ph_fn = lambda: hm.phase_unwarp_matrix(self.phase_dim, N, fs, self.alpha_phase)                        # noqa: E731
-                if fmt == 1:
-                    self.up_mag = e.constant(("upack_bf16", key_m, self.mag_dim, H, float(alpha)),
-                                             lambda: hm.pack_unwarp_frag_bf16(u_mag_fn(), 132).view(np.int16), dtype=np.int16)
-                    self.up_phase = e.constant(("upack_bf16", "u_phase", self.phase_dim, N, int(fs), float(self.alpha_phase)),
-                                               lambda: hm.pack_unwarp_frag_bf16(u_ph_fn(), 32).view(np.int16), dtype=np.int16)
-                else:
-                    self.up_mag = e.constant(("upack", key_m, self.mag_dim, H, float(alpha), ktm.value),
-                                             lambda: hm.pack_unwarp_frag(u_mag_fn(), ktm.value, 132))
-                    self.up_phase = e.constant(("upack", "u_phase", self.phase_dim, N, int(fs), float(self.alpha_phase), ktp.value),
-                                               lambda: hm.pack_unwarp_frag(u_ph_fn(), ktp.value, 32))
-                seg_fb, seg_rb, run_seg_off = hm.plan_segments(self.runs_host["frame_begin"], self.runs_host["frame_end"],
-                                                               cat(row0), cat(row1))
-                self.n_segments = int(seg_fb.size)
-                _up.append(("seg_fb", seg_fb, np.int32))
-                _up.append(("seg_rb", seg_rb, np.int32))
-                _up.append(("run_seg_off", run_seg_off, np.int32))
         for _k, _t in e.to_device_packed(_up).items():
             setattr(self, _k, _t)
         return mt_device
@@ -2005,27 +1969,18 @@ class CompressedSynthesisPlan:
             gains.append(tuple(g))
         return inv
 
-    def _buffers(self, staged=None):
+    def _buffers(self):
         """Work buffers of run(), allocated once per plan (the caching allocator makes a re-allocation per call cheap
-        but not free: ~1.6 GB of spectra + strips + per-frame scalars).  staged: the [F x H] spectra are needed (the
-        staged form; default: whatever the plan runs)."""
-        staged = (not self.fused) if staged is None else staged
+        but not free: ~1.6 GB of spectra + strips + per-frame scalars)."""
         b = getattr(self, "_buf", None)
-        if b is not None and staged and b.get("spec") is None:
-            H = self.fft_len // 2 + 1
-            b["spec"] = tuple(self.engine.empty((self.total_frames, b["ld"]))[:, :H] for _ in range(3))
-        if b is not None and self.fused and b.get("scratch") is None:
-            b["scratch"] = self.engine.empty((max(int(self.engine.lib.mpx_synth_fused_scratch_floats(self.n_slots)), 1),))
         if b is None:
             e, torch = self.engine, _torch()
             H = self.fft_len // 2 + 1
             ld = int(e.lib.mpx_spec_ld(H))
             b = self._buf = dict(
                 ld=ld,
-                # unwarped spectra at the VARIABLE rate: one row per synthesis frame (mpx_mel_unwarp_rows interpolates);
-                # the fused form keeps a segment's rows in the wave pair's scratch instead
-                spec=tuple(e.empty((self.total_frames, ld))[:, :H] for _ in range(3)) if staged else None,
-                scratch=e.empty((max(int(e.lib.mpx_synth_fused_scratch_floats(self.n_slots)), 1),)) if self.fused else None,
+                # unwarped spectra at the VARIABLE rate: one row per synthesis frame (mpx_mel_unwarp_rows interpolates)
+                spec=tuple(e.empty((self.total_frames, ld))[:, :H] for _ in range(3)),
                 sums=e.empty((self.total_frames,)),
                 inv_gain=e.empty((self.total_frames,)),
                 gains=torch.empty((self.n_utts, 2), dtype=torch.float64, device=e.device),
@@ -2045,14 +2000,13 @@ class CompressedSynthesisPlan:
         H = N // 2 + 1
         tab = e.tables(N)
         mark = mark or (lambda name: None)
-        fused = self.fused and not keep   # keep: the caller wants the unwarped spectra themselves
         ev = getattr(self, "_ready", None)
         if ev is not None:   # (a plan run on another stream than the one it was built on: that stream waits for the uploads too)
             torch.cuda.current_stream(e.device).wait_event(ev)
-        buf = self._buffers(staged=not fused)
+        buf = self._buffers()
         # unwarped spectra: internal matrices, rows 128-byte aligned (mpx_spec_ld: full-line stores of the MFMA unwarp)
         ld = buf["ld"]
-        mag, real, imag = buf["spec"] if not fused else (None, None, None)
+        mag, real, imag = buf["spec"]
         sums, strips, inv_gain = buf["sums"], buf["strips"], buf["inv_gain"]
         pcm = out if out is not None else e.empty((self.total_out,))
         with torch.cuda.device(e.device):
@@ -2065,9 +2019,7 @@ class CompressedSynthesisPlan:
             elif self.apply_post_filter:   # magphase.py:3259-3261
                 a_mag = e.post_filter(self.a_mag, self.fs)
                 mark("k_post_filter")
-            if fused:
-                pass                # the synthesis launch unwarps its own segments
-            elif self.unwarp_rows:   # constant -> variable rate inside the unwarp: one spectrum row per synthesis frame
+            if self.unwarp_rows:   # constant -> variable rate inside the unwarp: one spectrum row per synthesis frame
                 _lib.check(lib.mpx_mel_unwarp_rows(
                     st, self.total_frames, H, a_mag.data_ptr(), self.mag_dim, self.u_mag.data_ptr(), mag.data_ptr(),
                     self.a_real.data_ptr(), self.a_imag.data_ptr(), self.phase_dim, self.u_phase.data_ptr(),
@@ -2080,15 +2032,14 @@ class CompressedSynthesisPlan:
                                               mag.data_ptr(), self.a_real.data_ptr(), self.a_imag.data_ptr(),
                                               self.phase_dim, self.u_phase.data_ptr(), real.data_ptr(), imag.data_ptr(),
                                               ld), "mpx_mel_unwarp")
-            if not fused:
-                mark("k_mel_unwarp_mfma")
+            mark("k_mel_unwarp_mfma")
             # (the noise chain is independent of the unwarp, but a second HIP stream does not help: measured 3.13 vs
             # 3.18 ms per step with 12-wave and 3.15 vs 3.16 with 8-wave noise workgroups -- the two grids do not co-run)
-            # "noise spectra once" (opt-in, MAGPHASE_NOISE_SPECTRA=store; N = 4096, staged unwarp): the statistics launch
+            # "noise spectra once" (opt-in, MAGPHASE_NOISE_SPECTRA=store; N = 4096): the statistics launch
             # stores every frame's noise spectrum and the synthesis launch loads it instead of a second transform --
             # 17.4 KB per frame each way for the arithmetic of one forward FFT (measured: docs/LAB_NOTES.md, round 5)
             nspec = None
-            if not fused and N == 4096 and self.total_frames > 0 and self.noise_spectra:
+            if N == 4096 and self.total_frames > 0 and self.noise_spectra:
                 nspec = buf.get("nspec")
                 if nspec is None:
                     nspec = buf["nspec"] = e.empty((int(lib.mpx_noise_spectra_floats(N, self.total_frames)),))
@@ -2124,21 +2075,6 @@ class CompressedSynthesisPlan:
                 else:
                     real.fill_(1.0)
                     imag.fill_(0.0)
-            if fused:
-                _lib.check(lib.mpx_synthesis_compressed_fused(
-                    st, N, tab.data_ptr(), a_mag.data_ptr(), self.mag_dim, self.up_mag.data_ptr(), self.a_real.data_ptr(),
-                    self.a_imag.data_ptr(), self.phase_dim, self.up_phase.data_ptr(), self.n_rows, self.row0.data_ptr(),
-                    self.row1.data_ptr(), self.rowt.data_ptr(), self.seg_fb.data_ptr(), self.seg_rb.data_ptr(),
-                    self.run_seg_off.data_ptr(), self.noise.data_ptr(), self.npos.data_ptr(), self.nleft.data_ptr(),
-                    self.nright.data_ptr(), self.wtype.data_ptr(), self.voiced.data_ptr(), inv_gain.data_ptr(),
-                    self.win_l.data_ptr(), self.win_r.data_ptr(), self.pm_rel.data_ptr(), self.per_v.data_ptr(),
-                    self.ap_v.data_ptr(), self.ap_u.data_ptr(), self.runs.data_ptr(), self.n_runs, self.slot_off.data_ptr(),
-                    self.slot_runs.data_ptr(), self.n_slots, buf["scratch"].data_ptr(), strips.data_ptr(), pcm.data_ptr(),
-                    int(self.n_per)), "mpx_synthesis_compressed_fused")
-                mark("k_synth_comp_fused")
-                e.ola_fixup(N, self, strips, pcm)
-                mark("k_ola_fixup")
-                return pcm
             ola_args = (
                 st, N, tab.data_ptr(), mag.data_ptr(), real.data_ptr(), imag.data_ptr(), self.noise.data_ptr(),
                 self.npos.data_ptr(), self.nleft.data_ptr(), self.nright.data_ptr(), self.wtype.data_ptr(),

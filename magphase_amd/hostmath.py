@@ -741,107 +741,3 @@ def merlin_tables(dim, fs, pf_coef=1.4, fft_len=4096):
         cf = np.cos(np.outer(np.arange(dim), np.linspace(0, np.pi, num=dim)))
         _MERLIN_CACHE[key] = dict(c1=c1, lifter=lifter, g=fq @ dcos, wk=wk, cf=cf, alpha=alpha)
     return _MERLIN_CACHE[key]
-
-
-# ---------------------------------------------------------------------------------------------
-# Fused unwarp -> synthesis (include/magphase_hip.h: mpx_synthesis_compressed_fused)
-# ---------------------------------------------------------------------------------------------
-FUSE_ROWS = 16     # coefficient rows per product tile (v_mfma_f32_16x16x4_f32)
-FUSE_FMAX = 16     # frames per segment
-
-
-def pack_unwarp_frag(u, ksteps, n_col_tiles):
-    """
-    The unwarp matrix U [K x H] (out = a @ U) in the fragment order of v_mfma_f32_16x16x4_f32's B operand, so that ONE
-    16-byte load per lane brings four k-steps of a 16-bin column tile (csrc/magphase_comp.hip: fuse_unwarp_steps):
-    out[ct][q][lane][e] = U[4 (4 q + e) + (lane >> 4)][16 ct + (lane & 15)], zero beyond K or H.
-    ksteps: k-steps of the kernel instantiation (mpx_synth_fused_ksteps), q < ceil(ksteps / 4).
-    """
-    u = np.asarray(u, dtype=np.float64)
-    K, H = u.shape
-    kq = (int(ksteps) + 3) // 4
-    if 16 * kq < K:
-        raise ValueError("pack_unwarp_frag: %d k-steps cannot hold %d coefficients" % (ksteps, K))
-    pad = np.zeros((16 * kq, 16 * int(n_col_tiles)))
-    hc = min(H, pad.shape[1])
-    pad[:K, :hc] = u[:, :hc]
-    lane = np.arange(64)
-    q, e = np.arange(kq)[:, None, None], np.arange(4)[None, None, :]
-    k = 4 * (4 * q + e) + (lane >> 4)[None, :, None]                       # [kq, 64, 4]
-    col = 16 * np.arange(int(n_col_tiles))[:, None, None, None] + (lane & 15)[None, None, :, None]   # [ct, 1, 64, 1]
-    return np.ascontiguousarray(pad[k[None], col], dtype=np.float32)       # [ct, kq, 64, 4]
-
-
-def bf16_round(v):
-    """float32 -> the nearest bfloat16 (round to nearest even, what v_cvt_pk_bf16_f32 does), returned as float32."""
-    u = np.ascontiguousarray(v, dtype=np.float32).view(np.uint32).astype(np.uint64)
-    r = ((u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000).astype(np.uint32)
-    return r.view(np.float32).reshape(np.shape(v))
-
-
-def bf16_split3(v):
-    """v (float32) = a + b + c up to 2^-24 |v| with a, b, c bfloat16: a = bf16(v), b = bf16(v - a), c = bf16(v - a - b) (the
-    subtractions are exact in float32).  The six products a_i u_j with i + j <= 2 of two such splits, each exact in
-    float32 and accumulated in float32 by v_mfma_f32_16x16x32_bf16, reproduce a float32 product sum to the accuracy of
-    the float32 chain itself (tests/test_fused_synthesis_host.py)."""
-    v = np.ascontiguousarray(v, dtype=np.float32)
-    a = bf16_round(v)
-    r1 = (v - a).astype(np.float32)
-    b = bf16_round(r1)
-    c = bf16_round((r1 - b).astype(np.float32))
-    return a, b, c
-
-
-def pack_unwarp_frag_bf16(u, n_col_tiles):
-    """
-    U [K x H], K <= 64, as the B operand of v_mfma_f32_16x16x32_bf16 in its three-way bfloat16 split: uint16 (bfloat16
-    bit patterns) out[ct][kb][s][lane][j] = split_s(float32(U))[32 kb + 8 (lane >> 4) + j][16 ct + (lane & 15)], zero beyond
-    K or H -- one 16-byte load per lane brings a lane's eight k-slots of one split of one 32-coefficient block of a
-    16-bin column tile (csrc/magphase_comp.hip: fuse_unwarp_steps_bf16).  The instruction sums over its 32 k-slots in any
-    order, so only the pairing of A's and B's slots matters, and both use k = 32 kb + 8 (lane >> 4) + j.
-    """
-    u = np.asarray(u, dtype=np.float64)
-    K, H = u.shape
-    if K > 64:
-        raise ValueError("pack_unwarp_frag_bf16: at most 64 coefficients")
-    pad = np.zeros((64, 16 * int(n_col_tiles)), dtype=np.float32)
-    hc = min(H, pad.shape[1])
-    pad[:K, :hc] = u[:, :hc].astype(np.float32)
-    splits = bf16_split3(pad)                                              # 3 x [64, cols] float32 holding bf16 values
-    lane = np.arange(64)
-    kb, j = np.arange(2)[:, None, None], np.arange(8)[None, None, :]
-    k = 32 * kb + 8 * (lane >> 4)[None, :, None] + j                        # [2, 64, 8]
-    col = 16 * np.arange(int(n_col_tiles))[:, None, None, None] + (lane & 15)[None, None, :, None]   # [ct, 1, 64, 1]
-    out = np.empty((int(n_col_tiles), 2, 3, 64, 8), dtype=np.uint16)
-    for s_, sp in enumerate(splits):
-        out[:, :, s_] = (sp[k[None], col].view(np.uint32) >> 16).astype(np.uint16)
-    return np.ascontiguousarray(out)
-
-
-def plan_segments(frame_begin, frame_end, row0, row1, rows=FUSE_ROWS, fmax=FUSE_FMAX):
-    """
-    Cuts every OLA run [frame_begin[r], frame_end[r]) into segments of at most ``fmax`` consecutive frames whose
-    coefficient rows row0[f] .. row1[f] lie within ``rows`` consecutive rows (row0 ascending within a run, row1 >= row0:
-    what the constant -> variable rate scan yields; a frame's own two rows always fit).  Greedy: a segment takes as many
-    frames as both limits allow.  Returns (seg_frame_begin int32[S], seg_row_begin int32[S], run_seg_off int32[R + 1]).
-    """
-    row0 = np.asarray(row0, dtype=np.int64)
-    row1 = np.asarray(row1, dtype=np.int64)
-    if np.any(row1 - row0 < 0) or np.any(row1 - row0 >= rows):
-        raise ValueError("plan_segments: a frame's rows must satisfy 0 <= row1 - row0 < %d" % rows)
-    seg_fb, seg_rb, off = [], [], [0]
-    for fb, fe in zip(np.asarray(frame_begin, dtype=np.int64), np.asarray(frame_end, dtype=np.int64)):
-        f = int(fb)
-        fe = int(fe)
-        while f < fe:
-            rb = int(row0[f])
-            lim = min(fe, f + int(fmax))
-            # frames f .. e-1 with row1 <= rb + rows - 1 (row1 is non-decreasing inside a run)
-            e = f + int(np.searchsorted(row1[f:lim], rb + rows - 1, side="right"))
-            if e <= f:
-                raise ValueError("plan_segments: rows not ascending inside a run")
-            seg_fb.append(f)
-            seg_rb.append(rb)
-            f = e
-        off.append(len(seg_fb))
-    return (np.asarray(seg_fb, dtype=np.int32), np.asarray(seg_rb, dtype=np.int32), np.asarray(off, dtype=np.int32))

@@ -719,59 +719,6 @@ def test_float64_front_end_with_windows_longer_than_its_lds_region(orc):
     within(max(np.max(np.abs(r - ol[1])[ok]), np.max(np.abs(i - ol[2])[ok])), 6e-8, "F64_PHASE_ABS:long_frames")
 
 
-def test_fused_unwarp_synthesis_matches_reference_golden_and_staged(mp, orc, golden_dir, monkeypatch):
-    """mpx_synthesis_compressed_fused (opt-in, MAGPHASE_SYNTH_FUSED=1): unwarp -> assembly -> IFFT -> overlap-add in one
-    launch, the unwarped spectra only ever in the wave pairs' scratch rows (magphase.py:852-870 + :900-973).  Against
-    the reference's golden outputs (variable rate G5, constant rate G8), the oracle at low pitch (noise frames of two
-    staging tiles, short segments) and the staged pair of launches on a batch that spans several runs per slot."""
-    from magphase_amd import engine as em
-
-    monkeypatch.setenv("MAGPHASE_SYNTH_FUSED", "1")
-    g, mm, rr, ii, lf = _hvd704(golden_dir)
-    seed = int(g["seed"])
-    pf = mp.post_filter(mm, 48000)
-    np.random.seed(seed)
-    v = mp.synthesis_from_compressed(pf, rr, ii, lf, 48000, b_out_hpf=False)
-    ref = g["syn_pf_hpf0"]
-    assert len(v) == len(ref)
-    within(np.max(np.abs(v - ref)) / np.max(np.abs(ref)), COMP_PCM_TOL, "COMP_PCM_TOL:fused_var")
-    g8 = np.load(os.path.join(golden_dir, "g8_compressed_analysis.npz"))
-    np.random.seed(int(g8["cr45_seed"]))
-    v = mp.synthesis_from_compressed(g8["cr45_mag"], g8["cr45_real"], g8["cr45_imag"], g8["cr45_lf0"], int(g8["fs"]),
-                                     b_const_rate=True, b_out_hpf=False)
-    ref = g8["cr45_syn"]
-    assert len(v) == len(ref)
-    within(np.max(np.abs(v - ref)) / np.max(np.abs(ref)), COMP_PCM_TOL, "COMP_PCM_TOL:fused_const")
-    for f0 in (55.0, 400.0):   # long noise frames / many frames per coefficient row
-        lf2 = np.where(lf > 0.0, np.log(f0), lf)[:80]
-        with warnings.catch_warnings():
-            warnings.simplefilter("ignore")
-            np.random.seed(3)
-            v = mp.synthesis_from_compressed(mm[:80], rr[:80], ii[:80], lf2, 48000, b_const_rate=True)
-            np.random.seed(3)
-            ref = orc.synthesis_from_compressed(mm[:80], rr[:80], ii[:80], lf2, 48000, b_const_rate=True)
-        assert v.shape == ref.shape
-        within(np.max(np.abs(v - ref)) / max(1.0, np.max(np.abs(ref))), COMP_PCM_TOL, "COMP_PCM_TOL:fused_f0")
-    # a batch (several utterances, runs cut inside utterances): the plan really is the fused one, and equals the staged pair
-    eng = em.get_engine()
-    rng = np.random.RandomState(5)
-    utts = []
-    for u in range(6):
-        n = min(mm.shape[0] - 1, 150 + 37 * u)
-        a = rng.randint(0, mm.shape[0] - n)
-        utts.append((mm[a:a + n], rr[a:a + n], ii[a:a + n], lf[a:a + n]))
-    outs = {}
-    for fused in (True, False):
-        np.random.seed(11)
-        plan = em.CompressedSynthesisPlan(eng, utts, 48000, b_const_rate=True, fused=fused, frames_per_run=23)
-        assert plan.fused == fused
-        if fused:
-            assert plan.n_segments >= plan.n_runs
-        outs[fused] = plan.run().cpu().numpy().astype(np.float64)
-    peak = np.max(np.abs(outs[False]))
-    within(np.max(np.abs(outs[True] - outs[False])) / peak, COMP_PCM_TOL, "COMP_PCM_TOL:fused_vs_staged")
-
-
 def test_stored_noise_spectra_matches_reference_golden_and_recomputed(mp, orc, golden_dir, monkeypatch):
     """mpx_noise_stats_spectra + mpx_synthesis_compressed_ola_spectra (opt-in, MAGPHASE_NOISE_SPECTRA=store): every noise
     frame is transformed once, its spectrum stored by the statistics launch and loaded by the synthesis launch
@@ -788,13 +735,13 @@ def test_stored_noise_spectra_matches_reference_golden_and_recomputed(mp, orc, g
         a = rng.randint(0, mm.shape[0] - n)
         utts.append((mm[a:a + n], rr[a:a + n], ii[a:a + n], lf[a:a + n]))
     np.random.seed(11)
-    plan = em.CompressedSynthesisPlan(eng, utts, 48000, b_const_rate=True, fused=False, frames_per_run=23)
+    plan = em.CompressedSynthesisPlan(eng, utts, 48000, b_const_rate=True, frames_per_run=23)
     base = plan.run().cpu().numpy().astype(np.float64)
     assert plan._buf.get("nspec") is None
 
     monkeypatch.setenv("MAGPHASE_NOISE_SPECTRA", "store")
     np.random.seed(11)
-    plan = em.CompressedSynthesisPlan(eng, utts, 48000, b_const_rate=True, fused=False, frames_per_run=23)
+    plan = em.CompressedSynthesisPlan(eng, utts, 48000, b_const_rate=True, frames_per_run=23)
     got = plan.run().cpu().numpy().astype(np.float64)
     assert plan._buf.get("nspec") is not None     # the stored form really ran
     within(np.max(np.abs(got - base)) / np.max(np.abs(base)), COMP_PCM_TOL, "COMP_PCM_TOL:nspec_vs_recomputed")

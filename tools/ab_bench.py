@@ -137,12 +137,8 @@ def main():
         else:
             if shared is None:
                 shared = {}
-            # a variant named *_fused builds its synthesis plan with the fused unwarp -> synthesis launch
-            # (MAGPHASE_SYNTH_FUSED=1, opt-in), *_staged forces the staged pair
             # AB_ENV_<name>="K=V,K2=V2": environment of this variant's plan construction (e.g. MAGPHASE_UNWARP_BF16=0)
             extra = dict(kv.split("=", 1) for kv in os.environ.get("AB_ENV_" + name, "").split(",") if "=" in kv)
-            if name.endswith("_staged") or name.endswith("_fused"):
-                extra["MAGPHASE_SYNTH_FUSED"] = "1" if name.endswith("_fused") else "0"
             saved = {k: os.environ.get(k) for k in extra}
             os.environ.update(extra)
             sa, ss = bench.lowdim_plans(em, eng, utts, shared)
