@@ -43,6 +43,7 @@ SYMBOLS = (
     "mpx_noise_numpy_mt19937",
     "mpx_noise_numpy_mt19937_work_words",
     "mpx_host_mt19937_jump_poly",
+    "mpx_host_mt19937_jump_polys",
     "mpx_noise_stats",
     "mpx_noise_spectra_floats",
     "mpx_noise_stats_spectra",

@@ -22,7 +22,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-UNITS = ["magphase_hip.hip", "magphase_comp.hip", "magphase_f64.hip", "magphase_epochs.hip", "magphase_probe.hip", "magphase_merlin.hip",
+UNITS = ["magphase_hip.hip", "magphase_comp.hip", "magphase_f64.hip", "magphase_epochs.hip", "magphase_probe.hip", "magphase_merlin.hip", "magphase_noise.hip",
          "magphase_host.cpp", "magphase_plan.cpp", "magphase_mtjump.cpp"]
 SRCS = [os.path.join(CSRC, u) for u in UNITS]
 SRC = SRCS[0]

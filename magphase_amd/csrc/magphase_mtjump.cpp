@@ -13,6 +13,7 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "../../include/magphase_hip.h"
@@ -174,5 +175,45 @@ extern "C" int32_t mpx_host_mt19937_jump_poly(int64_t jump_words, int32_t n_leve
         lad.g.push_back(a);
     }
     for (int l = 0; l < n_levels; ++l) std::memcpy(out + (size_t)l * 624, lad.g[l].data(), 624 * sizeof(uint32_t));
+    return MPX_OK;
+}
+
+// x^(jumps[i]) mod phi for n arbitrary jumps, independent of each other, on up to n_threads threads (no cache): the
+// polynomials of a radix-R jump ladder -- multiples p * J * R^l, p < R, of the segment length -- which the doubling ladder
+// above does not contain.  out [n x 624] uint32 (HOST), layout as mpx_host_mt19937_jump_poly.
+extern "C" int32_t mpx_host_mt19937_jump_polys(const int64_t* jumps, int32_t n, uint32_t* out, int32_t n_threads) {
+    if (n < 0 || (n > 0 && (!jumps || !out))) return MPX_ERR_ARG;
+    for (int i = 0; i < n; ++i)
+        if (jumps[i] <= 0) return MPX_ERR_ARG;
+    const Bits& phi = phi_poly();
+    if (phi.empty()) return MPX_ERR_ARG;
+    auto one = [&](int i) {
+        Bits a(kW + 1, 0);
+        a[0] = 1;
+        bool started = false;
+        for (int b = 62; b >= 0; --b) {
+            if (started) square_mod(a, phi);
+            if ((jumps[i] >> b) & 1) {
+                times_x_mod(a, phi);
+                started = true;
+            }
+        }
+        std::memcpy(out + (size_t)i * 624, a.data(), 624 * sizeof(uint32_t));
+    };
+    const int nt = n_threads < 1 ? 1 : (n_threads > n ? n : n_threads);
+    try {
+        if (nt <= 1) {
+            for (int i = 0; i < n; ++i) one(i);
+        } else {
+            std::vector<std::thread> th;
+            for (int t = 0; t < nt; ++t)
+                th.emplace_back([&, t] {
+                    for (int i = t; i < n; i += nt) one(i);
+                });
+            for (auto& x : th) x.join();
+        }
+    } catch (...) {
+        return MPX_ERR_HOST;
+    }
     return MPX_OK;
 }

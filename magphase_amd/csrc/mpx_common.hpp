@@ -54,6 +54,27 @@ constexpr size_t lds_bytes_ana() {   // twiddles + one transpose buffer per wave
 
 __device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
+// Phase markers for the per-phase instruction table of a kernel's ISA (tools/asm_phases.py; builds with -DMPX_PHASE_MARKS
+// only: a comment line in the listing, and a compiler barrier for memory operations so that a phase's loads and stores stay
+// inside it -- plain arithmetic may still drift across by a few instructions).
+#ifdef MPX_PHASE_MARKS
+#define MPX_MARK(name) asm volatile("; MPX_MARK " name ::: "memory")
+#else
+#define MPX_MARK(name) do { } while (0)
+#endif
+// ... and, in those builds, the values that cross a phase boundary pinned at it (an empty asm that "uses and defines" them):
+// the arithmetic of the phase before cannot sink below the marker, that of the phase after cannot rise above it.
+template <int K>
+__device__ __forceinline__ void mpx_pin(float (&a)[K]) {
+#ifdef MPX_PHASE_MARKS
+    static_assert(K % 4 == 0, "pinned in groups of four");
+#pragma unroll
+    for (int i = 0; i < K; i += 4) asm volatile("" : "+v"(a[i]), "+v"(a[i + 1]), "+v"(a[i + 2]), "+v"(a[i + 3]));
+#else
+    (void)a;
+#endif
+}
+
 // ---------------------------------------------------------------------------------------------
 // Frame queue of a workgroup.  A SIMD serves its resident waves by AGE (MI355X_MICROARCH.md, "Two waves per SIMD"): with
 // a static frame list per wave (grid-stride) the first-dispatched wave of every SIMD ran 14 us per frame, the last one 21
