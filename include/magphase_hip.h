@@ -287,8 +287,7 @@ int mpx_noise_uniform(void* stream, int32_t n_utts, const uint64_t* seeds, const
  * mpx_noise_numpy_mt19937_work_words() uint32, or NULL.  With work and more than one segment of 319 488 words to draw,
  * the stream is produced by one workgroup per segment: the 624-word window each segment starts from is a jump-ahead of
  * the first one (X[n + J] = xor of X[n + i] over the set bits of x^J mod the generator's characteristic polynomial;
- * log16(segments) rounds of k_mt_jump, fifteen jumps per source window and round, polynomials from
- * mpx_host_mt19937_jump_polys).  Without work, or for short draws,
+ * log2(segments) rounds of k_mt_jump, polynomials from mpx_host_mt19937_jump_polys).  Without work, or for short draws,
  * one workgroup runs the recurrence from the key (454 words per barrier).  A second kernel converts.  Bit-identical
  * either way.  The many-workgroup form waits for the stream once (the polynomials are uploaded from pageable memory);
  * its caller reads key_out / pos_out back right afterwards anyway.
@@ -305,7 +304,8 @@ int64_t mpx_noise_numpy_mt19937_work_words(void);
  */
 int32_t mpx_host_mt19937_jump_poly(int64_t jump_words, int32_t n_levels, uint32_t* out);
 /* The same for n arbitrary jumps, independent of each other (no cache), on up to n_threads host threads: out [n x 624].
- * mpx_noise_numpy_mt19937's radix-16 ladder takes the multiples p * J * 16^l (p < 16) of its segment length from here. */
+ * mpx_noise_numpy_mt19937's ladder takes the multiples p * J * R^l (p < R; R = 2: the doubling ladder) of its segment
+ * length from here. */
 int32_t mpx_host_mt19937_jump_polys(const int64_t* jumps, int32_t n, uint32_t* out, int32_t n_threads);
 
 /*

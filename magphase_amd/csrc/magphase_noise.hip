@@ -149,9 +149,8 @@ __global__ __launch_bounds__(256) void k_mt_first(const unsigned* __restrict__ k
 constexpr int kMtJumpWords = 19937 + 624 + 768;   // generated + read-ahead slack of the threads without a third j
 constexpr int kMtJumpSplit = 16;                  // 624 mask words = 16 x 39
 // blockIdx.z = p - 1: the p-th of the round's jumps (polynomial p - 1 of `poly`), window w -> window p n_src + w: a round of
-// a radix-R ladder makes R - 1 jumps from every source window in ONE launch (round 6: radix 16, two rounds for 256 segments
-// instead of eight doubling rounds -- every round is one workgroup's 19 937-step recurrence long whatever its width, and
-// the ladder was 0.8 of the 1.2 ms the noise stream cost a generation launch).
+// a radix-R ladder makes R - 1 jumps from every source window in ONE launch (kMtRadix below).  gridDim.y workgroups share
+// one jump's mask.
 __global__ __launch_bounds__(256) void k_mt_jump(unsigned* __restrict__ windows, const unsigned* __restrict__ poly,
                                                  int n_src, int n_windows) {
     extern __shared__ __attribute__((aligned(16))) unsigned mt_xs[];
@@ -173,7 +172,7 @@ __global__ __launch_bounds__(256) void k_mt_jump(unsigned* __restrict__ windows,
         __syncthreads();
     }
     unsigned a0 = 0u, a1 = 0u, a2 = 0u;
-    constexpr int QW = 624 / kMtJumpSplit;
+    const int QW = 624 / (int)gridDim.y;   // mask words of this workgroup's share (gridDim.y divides 624: 1, 2, 4, 8 or 16)
     for (int q = part * QW; q < (part + 1) * QW; ++q) {
         unsigned bits = __builtin_amdgcn_readfirstlane(poly[q]);
         while (bits) {   // wave-uniform: the mask is the same for every lane
@@ -220,7 +219,11 @@ int mpx_noise_uniform(void* stream, int32_t n_utts, const uint64_t* seeds, const
 // Segments of the parallel form: kMtSegWords words each (doubled until at most kMtMaxSegs are needed)
 constexpr long long kMtSegWords = 624ll * 512;
 constexpr int kMtMaxSegs = 256, kMtMaxLevels = 8;
-constexpr int kMtRadix = 16;   // jumps per source window and ladder round + 1
+// Jumps per source window and ladder round + 1.  2 = the doubling ladder.  16 (two rounds for 256 segments instead of eight)
+// was measured in round 6 and is SLOWER (generation 185 k -> 147 k x real time): a round is not latency- but throughput-bound
+// -- every workgroup of a jump regenerates the 20 561 words after its source window, 4 080 workgroup executions per call
+// whatever the radix -- and one wide launch no longer slips into the gaps of the synthesis kernels next to it.
+constexpr int kMtRadix = 2;
 static long long ipow_radix(int l) {
     long long v = 1;
     while (l-- > 0) v *= kMtRadix;
@@ -285,7 +288,12 @@ int mpx_noise_numpy_mt19937(void* stream, const uint32_t* key, int32_t pos, int6
         if (int rc = set_lds(k_mt_jump, lds)) return rc;
         for (int l = 0; l < levels; ++l) {
             const int n_src = (int)ipow_radix(l);
-            hipLaunchKernelGGL(k_mt_jump, dim3((unsigned)min(n_src, K), kMtJumpSplit, kMtRadix - 1), dim3(256), lds, s, windows,
+            // kMtJumpSplit workgroups share one jump's mask at every width of the round: measured on an idle device
+            // (tools/mt_ladder_probe.py, 30 M samples per draw) 16 / 8 / 4 / 2 / 1 workgroups per jump = 0.95 / 1.06 / 1.41 /
+            // 2.36 / 4.22 ms -- the xor over the mask's ~10 000 set bits, not the regeneration of the word sequence, is what
+            // a jump costs
+            const int split = kMtJumpSplit;
+            hipLaunchKernelGGL(k_mt_jump, dim3((unsigned)min(n_src, K), (unsigned)split, kMtRadix - 1), dim3(256), lds, s, windows,
                                (const unsigned*)(dpoly + 624ll * (kMtRadix - 1) * l), n_src, K);
         }
         hipLaunchKernelGGL(k_mt19937_stream, dim3((unsigned)K), dim3(256), 0, s, (const unsigned*)key,

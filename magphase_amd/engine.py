@@ -380,33 +380,25 @@ class Engine:
         q = int(pos) + int(n_words)
         return q if (n_words == 0 or q <= 624) else ((q - 1) % 624) + 1
 
-    def numpy_global_uniform(self, n, defer=False):
-        """np.random.uniform(-1, 1, n).astype(float32) drawn from numpy's global generator, on the device
-        (mpx_noise_numpy_mt19937): same values, and the global state is left where the host draw would leave it.
-        defer=True (the batches of a corpus run, iobatch): the advanced state STAYS on the device and the next deferred
-        call continues from it -- no download, no synchronisation per batch; numpy's own state is stale until mt_sync(),
-        which the caller owes before anything else draws from it."""
+    def _mt_generate(self, key, pos, n, key_from_compute):
+        """n uniforms continuing numpy's MT19937 stream from (key [624 words on the device], word cursor pos), on the
+        generator's own stream: (samples float32 [n], state int32 [625] = key + cursor after them, event).
+        key_from_compute: the key was just uploaded in the compute stream (the generator's stream waits for it; a state
+        that comes from the generator's own stream needs no wait -- and must not get one: waiting for the compute stream here
+        is waiting for the previous launch)."""
         torch = _torch()
-        pend = getattr(self, "_mt_pending", None)
-        if pend is not None:
-            key, pos, meta = pend
-        else:
-            st = np.random.get_state()
-            if st[0] != "MT19937":
-                raise RuntimeError("numpy's global generator is not MT19937")
-            key = self.to_device(np.ascontiguousarray(st[1], dtype=np.uint32).view(np.int32), np.int32)
-            pos, meta = int(st[2]), (st[0], st[3], st[4])
-        # The generator's kernels are a ladder of launches of 1 .. 128 workgroups (0.7 ms per 128 utterances with the GPU
-        # nearly idle): they run on their own stream, beside whatever the compute stream has queued (the previous launch's
-        # synthesis), one generation after the other; the compute stream waits for the samples' event.
+        # The generator's kernels are a ladder of launches of 1 .. 128 workgroups: they run on their own stream, beside
+        # whatever the compute stream has queued (the previous launch's synthesis), one generation after the other; the
+        # compute stream waits for the samples' event where it uses them.
         rng = self.copy_stream("rng")
+        done = None
         with torch.cuda.device(self.device):
             cur = torch.cuda.current_stream(self.device)
             if rng is not None:
                 ready = None
-                if pend is None:               # the key was just uploaded in the compute stream; a deferred state comes
-                    ready = torch.cuda.Event()  # from the generator's own stream and needs no wait -- and must not get one:
-                    ready.record(cur)           # waiting for the compute stream here is waiting for the previous launch
+                if key_from_compute:
+                    ready = torch.cuda.Event()
+                    ready.record(cur)
                 ctx = torch.cuda.stream(rng)
             else:
                 import contextlib
@@ -428,48 +420,114 @@ class Engine:
                 if rng is not None:
                     done = torch.cuda.Event()
                     done.record(rng)
-            if rng is not None:
-                cur.wait_event(done)           # everything the caller enqueues from here on sees the samples and the state
-                for t_ in (out, state, key):
-                    t_.record_stream(cur)
-                    t_.record_stream(rng)
-        self._mt_pending = (state, self._mt_next_pos(pos, 2 * int(n)), meta)
+                    for t_ in (key,):
+                        t_.record_stream(rng)
+        return out, state, done
+
+    def numpy_global_uniform(self, n, defer=False):
+        """np.random.uniform(-1, 1, n).astype(float32) drawn from numpy's global generator, on the device
+        (mpx_noise_numpy_mt19937): same values, and the global state is left where the host draw would leave it.
+        defer=True (the batches of a corpus run, iobatch): the advanced state STAYS on the device and the next deferred
+        call continues from it -- no download, no synchronisation per batch; numpy's own state is stale until mt_sync(),
+        which the caller owes before anything else draws from it.  Deferred draws can be generated AHEAD
+        (MAGPHASE_MT_AHEAD = k: k requests' worth per generation; a call that finds its samples in what an earlier call
+        produced launches nothing; mt_sync() puts numpy's state where the samples actually HANDED OUT end).  Measured in
+        round 6 on the generation workload: no gain (k = 4 / 8: 118-160 / 108-146 k x real time against 133-170 k at k = 1
+        on the same box -- the larger draws' allocations and copies cost what the saved jump ladders gain), so k = 1."""
+        torch = _torch()
+        n = int(n)
+        pend = getattr(self, "_mt_pending", None)
+        fresh = pend is None
+        if fresh:
+            st = np.random.get_state()
+            if st[0] != "MT19937":
+                raise RuntimeError("numpy's global generator is not MT19937")
+            key = self.to_device(np.ascontiguousarray(st[1], dtype=np.uint32).view(np.int32), np.int32)
+            pend = {"key": key, "pos": int(st[2]), "meta": (st[0], st[3], st[4]), "buf": None, "gen": 0, "lead": 0, "used": 0,
+                    "end_state": None, "end_pos": int(st[2]), "done": None}
+        with torch.cuda.device(self.device):
+            cur = torch.cuda.current_stream(self.device)
+            if pend["buf"] is not None and pend["used"] + n <= pend["gen"]:      # already generated
+                out = pend["buf"][pend["used"]:pend["used"] + n]
+                pend = dict(pend, used=pend["used"] + n)
+            else:
+                left = pend["gen"] - pend["used"] if pend["buf"] is not None else 0
+                ahead = max(1, int(os.environ.get("MAGPHASE_MT_AHEAD", "1"))) if defer else 1
+                n_gen = max(n - left, ahead * n - left, 0)
+                if pend["buf"] is not None:      # continue where the generated samples end
+                    key, pos, from_compute = pend["end_state"], pend["end_pos"], False
+                else:
+                    key, pos, from_compute = pend["key"], pend["pos"], fresh
+                gen, state, done = self._mt_generate(key, pos, n_gen, from_compute)
+                if left:     # the unused tail of the previous generation in front of the new samples: one contiguous draw
+                    rng = self.copy_stream("rng")
+                    buf = self.empty((left + n_gen,))
+                    ctx = torch.cuda.stream(rng) if rng is not None else None
+                    if ctx is not None:
+                        ctx.__enter__()
+                    try:
+                        buf[:left].copy_(pend["buf"][pend["used"]:pend["gen"]])
+                        buf[left:].copy_(gen[:n_gen])
+                        if rng is not None:
+                            done = torch.cuda.Event()
+                            done.record(rng)
+                            buf.record_stream(rng)
+                    finally:
+                        if ctx is not None:
+                            ctx.__exit__(None, None, None)
+                else:
+                    buf = gen
+                pend = {"key": key, "pos": int(pos), "meta": pend["meta"], "buf": buf, "gen": left + n_gen, "lead": left,
+                        "used": n, "end_state": state, "end_pos": self._mt_next_pos(pos, 2 * n_gen), "done": done}
+                out = buf[:n]
+            if pend["done"] is not None:
+                cur.wait_event(pend["done"])       # everything the caller enqueues from here on sees the samples
+                pend["buf"].record_stream(cur)
+        self._mt_pending = pend
         if not defer:
             self.mt_sync()
-        return out[:int(n)]
+        return out
 
     def mt_sync(self):
-        """Puts a deferred MT19937 state (numpy_global_uniform(defer=True)) back into numpy's global generator."""
+        """Puts a deferred MT19937 state (numpy_global_uniform(defer=True)) back into numpy's global generator: the state
+        after the samples handed out so far (samples generated ahead and not handed out are dropped)."""
         pend = getattr(self, "_mt_pending", None)
         if pend is None:
             return
-        state, pos, meta = pend
         self._mt_pending = None
-        with _torch().cuda.device(self.device):
+        if pend["buf"] is None:
+            return
+        used_gen, total_gen = pend["used"] - pend["lead"], pend["gen"] - pend["lead"]
+        if used_gen < 0:
+            raise RuntimeError("MT19937: cursor inside the carried-over samples")
+        if used_gen == total_gen:
+            state, pos = pend["end_state"], pend["end_pos"]
+        else:      # numpy's state where the handed-out samples end: the generation repeated up to there (once per job)
+            _g, state, _d = self._mt_generate(pend["key"], pend["pos"], used_gen, False)
+            pos = self._mt_next_pos(pend["pos"], 2 * used_gen)
+        torch = _torch()
+        with torch.cuda.device(self.device):
+            rng = self.copy_stream("rng")
+            if rng is not None:
+                rng.synchronize()
             h = state.cpu().numpy()          # synchronises
         if int(h[624]) != int(pos):
             raise RuntimeError("MT19937 cursor: host %d, device %d" % (pos, int(h[624])))
+        meta = pend["meta"]
         np.random.set_state((meta[0], h[:624].view(np.uint32).copy(), int(pos), meta[1], meta[2]))
 
     def mt_snapshot(self):
-        """Opaque copy of the generator's current state (deferred device state or numpy's), for mt_restore."""
+        """Opaque copy of the generator's current state (deferred device state or numpy's), for mt_restore.  (The device
+        tensors of a deferred state are never written again once generated: the snapshot shares them.)"""
         pend = getattr(self, "_mt_pending", None)
         if pend is not None:
-            return ("dev", (pend[0].clone(), pend[1], pend[2]))
+            return ("dev", dict(pend))
         return ("host", np.random.get_state())
 
     def mt_restore(self, snap):
         kind, val = snap
         if kind == "dev":
-            self._mt_pending = (val[0].clone(), val[1], val[2])
-            rng = self.copy_stream("rng")
-            if rng is not None:   # the clone was made in the compute stream: the generator's stream reads it next
-                torch = _torch()
-                with torch.cuda.device(self.device):
-                    ev = torch.cuda.Event()
-                    ev.record(torch.cuda.current_stream(self.device))
-                    rng.wait_event(ev)
-                    self._mt_pending[0].record_stream(rng)
+            self._mt_pending = dict(val)
         else:
             self._mt_pending = None
             np.random.set_state(val)
