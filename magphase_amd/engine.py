@@ -658,13 +658,40 @@ class Engine:
             if slot["event"] is not None:
                 slot["event"].synchronize()
                 slot["event"] = None
+            def grow(sl, sizes):
+                for key, need in sizes:
+                    cur = sl[key]
+                    if cur is None or cur.numel() < need:
+                        sl[key] = None
+                        sl[key] = torch.empty(need, dtype=torch.uint8).pin_memory()
+                        sl[key + "_np"] = sl[key].numpy()
+
             with torch.cuda.device(self.device):
+                sizes = []
                 for key, need in (("stage", int(stage_bytes)), ("desc", int(desc_bytes))):
                     cur = slot[key]
                     if cur is None or cur.numel() < need:   # grown with headroom: page-locking is slow (40 ms per 30 MB)
-                        slot[key] = None
-                        slot[key] = torch.empty(max(int(need * 1.5), 1 << 20), dtype=torch.uint8).pin_memory()
-                        slot[key + "_np"] = slot[key].numpy()
+                        sizes.append((key, max(int(need * 1.5), 1 << 20)))
+                if sizes:
+                    grow(slot, sizes)
+                    # ... and the slots nobody holds grow with it, NOW: a job's first (warm-up) launch pays for all of them
+                    # instead of the next launches paying one by one inside the job (as the output ring does)
+                    idle = []
+                    while True:
+                        try:
+                            pool.get_nowait()
+                        except queue.Empty:
+                            break
+                        idle.append(self._slot_stack.pop())
+                    try:
+                        for sl in idle:
+                            if sl["event"] is None or sl["event"].query():
+                                sl["event"] = None
+                                grow(sl, sizes)
+                    finally:
+                        for sl in idle:
+                            self._slot_stack.append(sl)
+                            pool.put(None)
         except BaseException:
             self._slot_stack.append(slot)
             pool.put(None)

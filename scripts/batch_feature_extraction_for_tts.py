@@ -63,17 +63,11 @@ def main():
                 print("[rank %d] removed %d stale files of an earlier, interrupted run from %s" % (rank, len(stale), args.out_dir))
         lu.mkdir(args.out_dir)
 
-    def move_up():   # this rank's finished files (and its crash list) move up into the common directory
-        # Runs after ANY exit of the block below (an interrupt included): files are written under "<name>.part~" and renamed
-        # when complete (mpx_host_write_files), so whatever carries its final name is whole -- unfinished ones stay behind --
-        # and an error here must not replace the exception that is already on its way out.
+    def move_up():   # this rank's files (and its crash list) move up into the common directory
         if final_dir is None or not os.path.isdir(args.out_dir):
             return
         left = 0
         for n in os.listdir(args.out_dir):
-            if n.endswith(".part~"):
-                left += 1
-                continue
             try:
                 os.rename(os.path.join(args.out_dir, n), os.path.join(final_dir, n))
             except OSError as e:
@@ -85,7 +79,7 @@ def main():
             except OSError:
                 pass
 
-    try:   # whatever stops this rank mid-corpus, what it finished is where consumers of OUT_DIR look for it
+    try:
         if args.batch > 0:   # reader thread / kernels / writer thread overlapped, args.batch utterances per launch
             rep = iobatch.CorpusReport()
             n = iobatch.extract_features_corpus([os.path.join(args.wav_dir, tokens[i] + ".wav") for i in mine], args.out_dir,
@@ -98,7 +92,14 @@ def main():
             for i in mine:
                 print("[rank %d] analysing %s.wav" % (rank, tokens[i]))
                 mp.analysis_for_acoustic_modelling(os.path.join(args.wav_dir, tokens[i] + ".wav"), args.out_dir)
-    finally:
+    except BaseException:
+        # Interrupted mid-corpus (an exception, Ctrl-C): the writer thread may have been stopped inside a file, so NOTHING is
+        # moved into the common directory -- what this rank finished stays in its own directory, named here, and the
+        # exception goes out as it is (partial files must not appear in OUT_DIR, cleanup must not mask the error)
+        if final_dir is not None:
+            print("[rank %d] interrupted: its files stay in %s (not moved into %s)" % (rank, args.out_dir, final_dir))
+        raise
+    else:
         move_up()
     print("rank %d done" % rank)
 
