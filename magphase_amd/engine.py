@@ -210,7 +210,7 @@ class Engine:
         if total == 0 or total > (128 << 20):   # more than 512 MB per stream: not worth page-locking, the plain path does it
             return None
         stage = self.host_staging(total)
-        n_thr = self.host_threads(4 * total)
+        n_thr = self.host_threads(4 * total, big=16)
         off = 0
         for p_, r in zip(parts, rows):
             a = np.asarray(p_)
@@ -255,7 +255,8 @@ class Engine:
         # the widening writes 2 bytes for every byte that crosses PCIe: eight threads sustain ~75 GB/s of streaming stores on
         # this host, half of what the link delivers (round 6: 16 utterances' features 14 ms for 0.35 GB); 32 threads from
         # 16 MB up (Engine.host_threads: capped by the cores this rank may use)
-        n_thr = self.host_threads(sum(int(t.numel()) * 4 for t in tensors))
+        # (tools/array_api_probe.py, 16 utterances: 8 / 16 / 32 / 64 threads = 0.54 / 0.73 / 0.64 / 0.63 M frames/s)
+        n_thr = self.host_threads(sum(int(t.numel()) * 4 for t in tensors), big=16)
         if chunk_bytes is None:
             chunk_bytes = int(os.environ.get("MAGPHASE_D2H_CHUNK_MB", "32")) << 20
         outs, views, work = [], [], []
@@ -609,12 +610,12 @@ class Engine:
         return t
 
     # ------------------------------------------------------------------ prepared launches (native planners, planner thread)
-    def host_threads(self, nbytes=0):
+    def host_threads(self, nbytes=0, big=32):
         """Native threads one staging pass of `nbytes` may use: MAGPHASE_IO_NATIVE_THREADS, or 8 (32 from 16 MB up: launches of
         100+ utterances), never more than the cores this process may run on (sharding.bind_rank_to_cores gives every rank of
         a node its own share -- the reference's model is one worker per core with nothing shared, libutils.py:61-62)."""
         env = os.environ.get("MAGPHASE_IO_NATIVE_THREADS")
-        want = int(env) if env else (32 if nbytes >= (16 << 20) else 8)
+        want = int(env) if env else (int(big) if nbytes >= (16 << 20) else 8)
         try:
             cores = len(os.sched_getaffinity(0))
         except (AttributeError, OSError):

@@ -92,39 +92,44 @@ def run_extraction(rank, mine, dur, fs):
         # the device does not sit idle -- and drop its clocks -- between them and the clock's start)
         gc.collect()
         gc.disable()
-        if items:   # warm-up on the LARGEST launch of the job (page-locked staging and ring slots, device pools, tables: a
-            # launch that outgrows them re-pins / re-allocates inside the clock -- a production job pays that once in minutes)
-            big = max(_batches(items), key=lambda b: sum(int(x[0].shape[0]) for x in b))
-            mp.analysis_compressed_batch(big, **kw)
-            tw, nw = time.perf_counter(), 0
-            while nw < 2 or time.perf_counter() - tw < WARM_S:   # at least twice, and until the device is out of its idle clocks
-                _res, t_ = mp.analysis_compressed_batch(big, async_out=True, **kw)
-                t_.wait()
-                t_.release()
-                nw += 1
-        # pipelined form (see run_generation): a launch's features are taken one launch later, all of them inside the clock;
-        # the host side of launch i + 1 (native planners, samples into page-locked memory) is prepared on the engine's planner
-        # thread while this thread enqueues launch i (engine.prepare_async; the plan constructors take the result)
         from magphase_amd.engine import get_engine
 
         eng = get_engine()
-        t0 = time.perf_counter()
-        frames, prev = 0, None
-        todo = _batches(items)
-        fut = eng.prepare_async("analysis", todo[0]) if todo else None
-        for i, b in enumerate(todo):
-            prep = fut.result()
-            fut = eng.prepare_async("analysis", todo[i + 1]) if i + 1 < len(todo) else None
-            cur = mp.analysis_compressed_batch(b, async_out=True, prepared=prep, **kw)
+
+        def one_pass(todo):
+            # pipelined form (see run_generation): a launch's features are taken one launch later; the host side of launch
+            # i + 1 (native planners, samples into page-locked memory) is prepared on the engine's planner thread while this
+            # thread enqueues launch i (engine.prepare_async; the plan constructors take the result)
+            frames, prev = 0, None
+            fut = eng.prepare_async("analysis", todo[0]) if todo else None
+            for i, b in enumerate(todo):
+                prep = fut.result()
+                fut = eng.prepare_async("analysis", todo[i + 1]) if i + 1 < len(todo) else None
+                cur = mp.analysis_compressed_batch(b, async_out=True, prepared=prep, **kw)
+                if prev is not None:
+                    prev[1].wait()
+                    frames += sum(int(r[0].shape[0]) for r in prev[0])
+                    prev[1].release()
+                prev = cur
             if prev is not None:
                 prev[1].wait()
                 frames += sum(int(r[0].shape[0]) for r in prev[0])
                 prev[1].release()
-            prev = cur
-        if prev is not None:
-            prev[1].wait()
-            frames += sum(int(r[0].shape[0]) for r in prev[0])
-            prev[1].release()
+            return frames
+
+        todo = _batches(items)
+        if items:   # warm-up: the LARGEST launch of the job first (page-locked slots and ring slots, device pools, tables: a
+            # launch that outgrows them re-pins / re-allocates inside the clock -- a production job pays that once in minutes),
+            # then a few launches through the SAME pipelined loop as the timed pass (planner thread, copy streams, every slot in
+            # rotation), until the device is out of its idle clocks
+            big = max(todo, key=lambda b: sum(int(x[0].shape[0]) for x in b))
+            mp.analysis_compressed_batch(big, **kw)
+            tw, nw = time.perf_counter(), 0
+            while nw < 2 or time.perf_counter() - tw < WARM_S:
+                one_pass([big] + todo[:3])
+                nw += 1
+        t0 = time.perf_counter()
+        frames = one_pass(todo)
         dt = time.perf_counter() - t0
         gc.enable()
     return {"seconds": dt, "frames": frames, "audio_s": float(np.sum(dur[mine])) if len(mine) else 0.0, "utts": len(mine)}
@@ -191,24 +196,27 @@ def run_generation(rank, mine, dur, fs):
         np.random.seed(1000 + rank)
         gc.collect()
         gc.disable()   # (see run_extraction)
-        if items:   # warm-up on the largest launch (see run_extraction), twice: both staging buffers, every ring slot
+        def one_pass(todo):
+            frames, smpls = 0, 0
+            fut = prepare(todo[0]) if todo else None
+            for i, g in enumerate(todo):
+                cur, fut = fut, (prepare(todo[i + 1]) if i + 1 < len(todo) else None)
+                frames += synth(g, cur)
+                smpls += take(2)            # the two rate groups of the launch just issued stay in flight
+            smpls += take(0)
+            eng.mt_sync()
+            return frames, smpls
+
+        todo = [groups_of(b) for b in _batches(items, BATCH_GEN)]
+        if items:   # warm-up (see run_extraction): the largest launch, then launches through the same pipelined loop as the
+            # timed pass (planner thread, generator stream, every slot in rotation)
             big = max(_batches(items, BATCH_GEN), key=lambda b: sum(int(x[1][0].shape[0]) for x in b))
             tw, nw = time.perf_counter(), 0
-            while nw < 2 or time.perf_counter() - tw < WARM_S:   # (see run_extraction)
-                synth(groups_of(big))
-                take(0)
+            while nw < 2 or time.perf_counter() - tw < WARM_S:
+                one_pass([groups_of(big)] + todo[:2])
                 nw += 1
-            eng.mt_sync()
         t0 = time.perf_counter()
-        frames, smpls = 0, 0
-        todo = [groups_of(b) for b in _batches(items, BATCH_GEN)]
-        fut = prepare(todo[0]) if todo else None
-        for i, g in enumerate(todo):
-            cur, fut = fut, (prepare(todo[i + 1]) if i + 1 < len(todo) else None)
-            frames += synth(g, cur)
-            smpls += take(2)            # the two rate groups of the launch just issued stay in flight
-        smpls += take(0)
-        eng.mt_sync()
+        frames, smpls = one_pass(todo)
         dt = time.perf_counter() - t0
         gc.enable()
     return {"seconds": dt, "frames": frames, "audio_s": float(np.sum(dur[mine])) if len(mine) else 0.0, "utts": len(mine)}
