@@ -182,7 +182,9 @@ def _lowdim_state(em, eng, utts, shared=None):
 
     aplan = em.CompressedAnalysisPlan(eng, utts, mag_dim=60, phase_dim=45, b_const_rate=True)
     H = aplan.fft_len // 2 + 1
-    if shared is not None and "feats" in shared:
+    if getattr(aplan, "fused_cr", False):   # one kernel, no staged lossless rows (mpx_analysis_compressed_fused_cr)
+        feats = None
+    elif shared is not None and "feats" in shared:
         feats = shared["feats"]
     else:
         feats = tuple(eng.empty_feats(aplan.lossless.total_frames, H) for _ in range(3))
@@ -405,6 +407,10 @@ def measure_lowdim(eng, utts, steps, warmup, live=None, live_src=None, n_streams
         # magnitude row of every frame, phase rows of the frames a voiced constant-rate frame interpolates from
         "k_analysis_f64": ("hbm", 4.0 * H * Fv + 8.0 * H * n_phase_rows + 4.0 * n_in),
         "k_mel_warp_mfma": ("mfma", 2.0 * H * dims * Fc),
+        # the one-kernel form (mpx_analysis_compressed_fused_cr): samples in, constant-rate magnitudes and the variable-rate
+        # phase coefficients of the rows in use out; then those rows interpolated to the constant rate
+        "k_analysis_warp_fused_cr": ("hbm", 4.0 * n_in + 4.0 * aplan.mag_dim * Fc + 8.0 * aplan.phase_dim * n_phase_rows),
+        "k_warp_phase_rows": ("hbm", 8.0 * aplan.phase_dim * (n_phase_rows + Fc)),
         "k_post_filter": ("hbm", 8.0 * aplan.mag_dim * Fc),
         # variable-rate rows.  Magnitudes: two products over all H bins (k_mel_unwarp_tiled, timed under this mark too);
         # phases: real + imaginary, voiced frames only, bins below the periodic / aperiodic crossfade only
@@ -475,7 +481,55 @@ def measure_lowdim(eng, utts, steps, warmup, live=None, live_src=None, n_streams
             del st2
         except Exception as e:   # the comparison is a side measurement: never the reason a bench line is lost
             nso = {"error": "%s: %s" % (type(e).__name__, e)}
+    # the analysis side as ONE kernel (opt-in, MAGPHASE_COMP_FUSED_CR=1): interleaved with the default form in this process
+    aok = None
+    if side_forms and not getattr(aplan, "fused_cr", False) and hasattr(eng.lib, "mpx_analysis_compressed_fused_cr"):
+        try:
+            saved = os.environ.get("MAGPHASE_COMP_FUSED_CR")
+            os.environ["MAGPHASE_COMP_FUSED_CR"] = "1"
+            try:
+                ap1 = em.CompressedAnalysisPlan(eng, utts, mag_dim=60, phase_dim=45, b_const_rate=True)
+            finally:
+                if saved is None:
+                    os.environ.pop("MAGPHASE_COMP_FUSED_CR", None)
+                else:
+                    os.environ["MAGPHASE_COMP_FUSED_CR"] = saved
+            if ap1.fused_cr:
+                o1 = ap1.run()
+                torch.cuda.synchronize()
+                diff = [float((x - y).abs().max().item()) for x, y in zip(o1, st["out"])]
+                forms = (("staged", lambda: aplan.run(feats=st["feats"], out=st["out"])), ("one_kernel", lambda: ap1.run(out=o1)))
+                ts = {n: [] for n, _ in forms}
+                for r in range(17):
+                    for n, fn in forms:
+                        e0.record()
+                        fn()
+                        e1.record()
+                        torch.cuda.synchronize()
+                        if r >= 2:
+                            ts[n].append(e0.elapsed_time(e1))
+                one_b = (sum(live[k] for k in ("k_cr_index", "k_analysis_warp_fused_cr", "k_warp_phase_rows") if k in live)
+                         if live is not None and "k_analysis_warp_fused_cr" in live else None)
+                stg_b = (sum(live[k] for k in ("k_analysis_f64", "k_mel_warp_mfma", "k_warp_phase_rows") if k in live)
+                         if live is not None and "k_analysis_f64" in live else None)
+                aok = {"what": "analysis side of the same step, default (k_analysis_f64 -> k_mel_warp_mfma + k_warp_phase_rows: the "
+                               "lossless rows staged in HBM) vs ONE transform-and-warp kernel with the row interpolation inside "
+                               "(mpx_analysis_compressed_fused_cr + mpx_warp_phase_rows, MAGPHASE_COMP_FUSED_CR=1); median of 15 "
+                               "interleaved rounds, HIP events; traffic from the same PMC child passes as the rest",
+                       "analysis_ms_staged": round(float(np.median(ts["staged"])), 4),
+                       "analysis_ms_one_kernel": round(float(np.median(ts["one_kernel"])), 4),
+                       "hbm_traffic_staged": (round(stg_b, 1) if stg_b else None),
+                       "hbm_traffic_one_kernel": (round(one_b, 1) if one_b else None),
+                       "step_hbm_traffic_with_one_kernel": (round(traffic - stg_b + one_b, 1) if (traffic and stg_b and one_b) else None),
+                       "staged_rows_bytes_not_allocated": 12.0 * H * Fv,
+                       "max_abs_difference_of_outputs": {"mag": diff[0], "real": diff[1], "imag": diff[2]},
+                       "default": "staged"}
+                del o1
+            del ap1
+        except Exception as e:
+            aok = {"error": "%s: %s" % (type(e).__name__, e)}
     return {
+        "analysis_one_kernel": aok,
         "noise_spectra_once": nso,
         "workload": "configs[2]: the same 64 x 5 s @48 kHz; analysis_compressed(mag 60, phase 45, constant 5 ms rate) -> "
                     "post-filter -> synthesis_from_compressed(b_const_rate=True, per_phase_type='magphase')",
@@ -712,6 +766,7 @@ def measure_power(torch, dev_index, phases, seconds=1.6):
 
 
 # kernels of one configs[2] step (each launched once per step; the unwarp is two launches of different kernels)
+LOWDIM_ONE_KERNEL = ("k_cr_index", "k_analysis_warp_fused_cr")   # instead of the first two with MAGPHASE_COMP_FUSED_CR=1
 LOWDIM_KERNELS = ("k_analysis_f64", "k_mel_warp_mfma", "k_warp_phase_rows", "k_post_filter", "k_mel_unwarp_tiled",
                   "k_mel_unwarp_mfma", "k_noise_stats", "k_noise_gains", "k_synth_comp_pair")
 
@@ -786,7 +841,14 @@ def live_traffic(timeout_s=170):
     out["_insts"] = {k: {c_: sum(v_) / len(v_) for c_, v_ in c.items() if c_.startswith("SQ_")} for k, c in vals.items()
                      if any(c_.startswith("SQ_") for c_ in c)}
     if "k_noise_stats" in out:
-        ks = [k for k in LOWDIM_KERNELS if k in out]
+        names = LOWDIM_KERNELS
+        if os.environ.get("MAGPHASE_COMP_FUSED_CR") == "1":
+            names = LOWDIM_ONE_KERNEL + tuple(k for k in LOWDIM_KERNELS if k not in ("k_analysis_f64", "k_mel_warp_mfma"))
+        ks = [k for k in names if k in out]
+        if "k_analysis_warp_fused_cr" in launches and "k_analysis_f64" in launches and "k_warp_phase_rows" in launches:
+            # (the child ran the analysis side in both forms: each launched k_warp_phase_rows -- same bytes -- once per step)
+            launches["k_warp_phase_rows"] = max(1, launches["k_warp_phase_rows"] - min(launches["k_analysis_warp_fused_cr"],
+                                                                                      launches["k_analysis_f64"]))
         out["lowdim_step"] = sum(max(1, round(launches[k] / launches["k_noise_stats"])) * out[k] for k in ks)
     return out, ("measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE child passes of `bench.py --pmc-child` "
                  "(4 lossless + 3 configs[2] steps) on this box, (2 x FETCH_SIZE + WRITE_SIZE) KiB per launch, %.0f s"
@@ -1108,6 +1170,16 @@ def main():
         for _ in range(3):
             xp.run()
         torch.cuda.synchronize()
+        if not os.environ.get("MAGPHASE_COMP_FUSED_CR"):   # configs[2]'s analysis side in its one-kernel form
+            os.environ["MAGPHASE_COMP_FUSED_CR"] = "1"
+            try:
+                xc = em.CompressedAnalysisPlan(eng, utts, mag_dim=60, phase_dim=45, b_const_rate=True)
+            finally:
+                os.environ.pop("MAGPHASE_COMP_FUSED_CR", None)
+            if getattr(xc, "fused_cr", False):
+                for _ in range(3):
+                    xc.run()
+                torch.cuda.synchronize()
         return
     dt_own = dt
     if dist is not None:

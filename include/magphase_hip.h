@@ -107,6 +107,27 @@ int mpx_analysis_compressed_fused(void* stream, int fft_len, const void* tables_
                                   int64_t n_frames, const double* win_tab, int32_t win_cap, const float* wpack,
                                   const float* whalf, int32_t mag_dim, int32_t phase_dim, const float* voiced,
                                   int32_t mag_fbank, float* out_mag, float* out_real, float* out_imag);
+/*
+ * The same at the CONSTANT frame rate (analysis_compressed_type1(..., const_rate_ms=5.0), magphase.py:2967-2983: the
+ * lossless features are interpolated to the 5 ms grid by interp_from_variable_to_const_frm_rate, :2219-2239, BEFORE
+ * format_for_modelling, :2490-2544).  Constant-rate frame c lies between the frames row0[c] and row1[c] (== row0[c] + 1, or
+ * == row0[c] for the duplicated first row; row1 ascending over the batch) with weight row_t[c]:
+ *   out_mag [n_const x mag_dim]            ln((|X_row0| + t (|X_row1| - |X_row0|))^2 + 1e-8) . W_mag -- the operand rows of
+ *                                          the matrix product are built per constant-rate frame inside the kernel;
+ *   tmp_real / tmp_imag [n_frames x phase_dim]   the phase streams' warp of the VARIABLE-rate frames with rows_in_use != 0
+ *                                          (no mask, no clip), to be finished by mpx_warp_phase_rows -- the split
+ *                                          mpx_mel_warp_rows makes.
+ * wpack / whalf as for mpx_analysis_compressed_fused (layout 1, eight waves; mel-warp magnitudes only).  work: DEVICE
+ * scratch of mpx_analysis_compressed_fused_cr_work_bytes(fft_len, n_frames) bytes (an index of row1 and 8 KB per
+ * workgroup for the frame a round hands to the next).  The lossless features never reach HBM.
+ */
+int mpx_analysis_compressed_fused_cr(void* stream, int fft_len, const void* tables_f64, const float* sig,
+                                     const int64_t* frame_pos, const int32_t* frame_left, const int32_t* frame_right,
+                                     int64_t n_frames, const double* win_tab, int32_t win_cap, const float* wpack,
+                                     const float* whalf, int32_t mag_dim, int32_t phase_dim, const float* rows_in_use,
+                                     const int32_t* row0, const int32_t* row1, const float* row_t, int64_t n_const,
+                                     float* out_mag, float* tmp_real, float* tmp_imag, void* work);
+int64_t mpx_analysis_compressed_fused_cr_work_bytes(int fft_len, int64_t n_frames);
 /* column tiles of 16 the fused kernel runs for the magnitude / phase job (what pack_warp_fused must produce) */
 int mpx_analysis_compressed_fused_tiles(int32_t mag_dim, int32_t phase_dim, int32_t* ntm, int32_t* ntp);
 /* waves per workgroup = frames per round = K slices the packed weights are cut into (pack_warp_fused's n_waves) */
@@ -425,6 +446,14 @@ int mpx_mel_warp_rows(void* stream, int64_t n_frames, int32_t n_bins, const floa
                       int32_t mag_dim, const float* w_phase, int32_t phase_dim, const float* voiced, float* out_mag,
                       float* out_real, float* out_imag, int64_t ld, int32_t mag_fbank, int64_t n_var_rows,
                       const float* rows_in_use, float* tmp_real, float* tmp_imag);
+
+/*
+ * The second half of mpx_mel_warp_rows' phase streams on its own: out[f] = clip(voiced[f] * ((1 - t) tmp[row0[f]] +
+ * t tmp[row1[f]])) for the phase_dim columns of both streams, 0 where voiced[f] == 0 (magphase.py:2219-2239, :2527-2532).
+ */
+int mpx_warp_phase_rows(void* stream, int64_t n_frames, int32_t phase_dim, const float* tmp_real, const float* tmp_imag,
+                        const int32_t* row0, const int32_t* row1, const float* row_t, const float* voiced, float* out_real,
+                        float* out_imag);
 
 /*
  * Minimum-phase spectrum of a magnitude spectrum by the complex cepstrum (la.build_min_phase_from_mag_spec,

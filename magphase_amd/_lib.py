@@ -23,6 +23,8 @@ SYMBOLS = (
     "mpx_analysis_frames_f64",
     "mpx_analysis_frames_f64w",
     "mpx_analysis_compressed_fused",
+    "mpx_analysis_compressed_fused_cr",
+    "mpx_analysis_compressed_fused_cr_work_bytes",
     "mpx_analysis_compressed_fused_tiles",
     "mpx_analysis_compressed_fused_waves",
     "mpx_analysis_compressed_fused_layout",
@@ -68,6 +70,7 @@ SYMBOLS = (
     "mpx_mel_warp",
     "mpx_mel_warp_fbank",
     "mpx_mel_warp_rows",
+    "mpx_warp_phase_rows",
     "mpx_min_phase",
     "mpx_noise_gains",
     "mpx_post_filter",
@@ -135,6 +138,11 @@ def _load_locked():
     lib.mpx_analysis_compressed_fused.restype = ctypes.c_int
     lib.mpx_analysis_compressed_fused.argtypes = [vp, ctypes.c_int, vp, vp, vp, vp, vp, i64, vp, i32, vp, vp, i32, i32, vp, i32,
                                                   vp, vp, vp]
+    lib.mpx_analysis_compressed_fused_cr.restype = ctypes.c_int
+    lib.mpx_analysis_compressed_fused_cr.argtypes = [vp, ctypes.c_int, vp, vp, vp, vp, vp, i64, vp, i32, vp, vp, i32, i32, vp,
+                                                     vp, vp, vp, i64, vp, vp, vp, vp]
+    lib.mpx_analysis_compressed_fused_cr_work_bytes.restype = i64
+    lib.mpx_analysis_compressed_fused_cr_work_bytes.argtypes = [ctypes.c_int, i64]
     lib.mpx_analysis_compressed_fused_blocks_per_cu.restype = ctypes.c_int
     lib.mpx_analysis_compressed_fused_blocks_per_cu.argtypes = [ctypes.c_int, i32]
     lib.mpx_analysis_compressed_fused_waves.restype = ctypes.c_int
@@ -230,6 +238,8 @@ def _load_locked():
     lib.mpx_mel_warp_fbank.argtypes = lib.mpx_mel_warp.argtypes
     lib.mpx_mel_warp_rows.restype = ctypes.c_int
     lib.mpx_mel_warp_rows.argtypes = lib.mpx_mel_warp.argtypes + [i32, i64, vp, vp, vp]
+    lib.mpx_warp_phase_rows.restype = ctypes.c_int
+    lib.mpx_warp_phase_rows.argtypes = [vp, i64, i32, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.mpx_min_phase.restype = ctypes.c_int
     lib.mpx_min_phase.argtypes = [vp, ctypes.c_int, vp, vp, vp, vp, vp, i64, vp, vp, vp, i64]
     lib.mpx_noise_gains.restype = ctypes.c_int

@@ -2594,6 +2594,22 @@ static int mel_warp_impl(void* stream, int64_t n_frames, int32_t n_bins, const f
     return MPX_OK;
 }
 
+// The second half of the constant-rate phase streams on its own (mpx_analysis_compressed_fused_cr leaves their
+// variable-rate warp in tmp_real / tmp_imag): row interpolation, voicing mask, clip.
+int mpx_warp_phase_rows(void* stream, int64_t n_frames, int32_t phase_dim, const float* tmp_real, const float* tmp_imag,
+                        const int32_t* row0, const int32_t* row1, const float* row_t, const float* voiced, float* out_real,
+                        float* out_imag) {
+    if (n_frames < 0 || phase_dim <= 0) return fail(MPX_ERR_ARG, "mpx_warp_phase_rows: bad size%s");
+    if (n_frames == 0) return MPX_OK;
+    if (!tmp_real || !tmp_imag || !row0 || !row1 || !row_t || !voiced || !out_real || !out_imag)
+        return fail(MPX_ERR_ARG, "mpx_warp_phase_rows: null pointer%s");
+    const long long n_el = (long long)n_frames * phase_dim;
+    hipLaunchKernelGGL(k_warp_phase_rows, dim3((unsigned)((n_el + 255) / 256)), dim3(256), 0, (hipStream_t)stream, tmp_real,
+                       tmp_imag, row0, row1, row_t, voiced, (long long)n_frames, (int)phase_dim, out_real, out_imag);
+    MPX_HIP_CHECK(hipGetLastError());
+    return MPX_OK;
+}
+
 int mpx_mel_warp_rows(void* stream, int64_t n_frames, int32_t n_bins, const float* mag, const float* real,
                       const float* imag, const int32_t* row0, const int32_t* row1, const float* row_t, const float* w_mag,
                       int32_t mag_dim, const float* w_phase, int32_t phase_dim, const float* voiced, float* out_mag,

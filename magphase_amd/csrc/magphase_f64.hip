@@ -412,6 +412,94 @@ __device__ __forceinline__ float fused_prologue_phase(float x) {
 #endif
 }
 
+// Operand values of one bin: (ln-power, phase operands of Re X/|X| and Im X/|X|) as the staged path forms them.  RAW: the
+// magnitude operand is |X| itself -- the constant-rate form interpolates it between two frames BEFORE the logarithm
+// (k_analysis_warp_fused_cr).
+template <int MAGMODE, bool RAW>
+__device__ __forceinline__ void fused_operand(double xr, double xi, double zero2, float mag_scale, bool voi, float& a_m, float& a_r,
+                                              float& a_i) {
+    const double s2 = xr * xr + xi * xi;
+    const bool nz = s2 > zero2;
+#if MPX_FUSED_F32NORM   // |X| and the unit phasor in float32 from the float64 spectrum: v_rsq_f32 (1 ulp) and float32 products, no
+    // Newton step -- <= 2 ulp on operands that the float32 matrix product then sums over 2 049 bins (the staged path
+    // rounds the float64 quotient once instead: k_analysis_f64's rows are API outputs, these operands are not)
+    const float s2f = (float)s2;
+    const float rf = nz ? __builtin_amdgcn_rsqf(s2f) : 0.0f;
+    a_m = RAW ? (s2f * rf) * mag_scale : fused_prologue_mag(MAGMODE, (s2f * rf) * mag_scale);
+    // (pinned: the two products were sunk to their first use after the phase loop, s2f AND rf of every bin live until then --
+    // 64 registers instead of 32 and 200 spills)
+    if (RAW) asm volatile("" : "+v"(a_m));
+    if (voi) {
+        a_r = fused_prologue_phase((float)xr * rf);
+        a_i = fused_prologue_phase((float)xi * rf);
+    } else {
+        a_r = a_i = 0.0f;
+    }
+    return;
+#endif
+    const double rr = nz ? rsqrt_f64(s2) : 0.0;
+    a_m = RAW ? (float)(s2 * rr) * mag_scale : fused_prologue_mag(MAGMODE, (float)(s2 * rr) * mag_scale);
+    if (RAW) asm volatile("" : "+v"(a_m));
+#if MPX_FUSED_VOIBRANCH   // a real (wave-uniform) branch: an unvoiced frame skips the phase operands' arithmetic instead of discarding it
+    if (voi) {
+        a_r = fused_prologue_phase((float)(xr * rr));
+        a_i = fused_prologue_phase((float)(xi * rr));
+    } else {
+        a_r = a_i = 0.0f;
+    }
+#else
+    a_r = voi ? fused_prologue_phase((float)(xr * rr)) : 0.0f;
+    a_i = voi ? fused_prologue_phase((float)(xi * rr)) : 0.0f;
+#endif
+}
+
+#ifndef MPX_FUSED_EB
+#define MPX_FUSED_EB 2
+#endif
+// The split of every bin pair row of a frame's half-size transform (k_analysis_f64's epilogue arithmetic) into float32 operand
+// registers: entry 2 q = the low bin kappa + 64 q of step q, 2 q + 1 = its mirror M - kappa - 64 q; (m0, m1, m2) = bin M/2
+// (its own mirror; lane kappa == 0 holds it).
+template <int P, int MAGMODE, bool RAW>
+__device__ __forceinline__ void fused_split_operands(double (&re)[P], double (&im)[P], double zero2, float mag_scale, bool voi,
+                                                     bool lane0, int src_lane, double wl_c, double wl_s, float (&vm)[P],
+                                                     float (&vr)[P], float (&vi)[P], float& m0, float& m1, float& m2) {
+    constexpr int EB = MPX_FUSED_EB;
+#pragma unroll
+    for (int qb = 0; qb < P / 2; qb += EB) {
+        // (fence: the partner exchanges of LATER batches must not be scheduled ahead -- every batch in flight
+        // holds 4 EB more registers while the float64 spectrum is still live)
+        asm volatile("" : "+v"(re[f64_out_reg<P>(qb)]), "+v"(im[f64_out_reg<P>(qb)]));
+        double zpr[EB], zpi[EB];
+#pragma unroll
+        for (int u = 0; u < EB; ++u) {   // Z[M - k]: lane (64 - kappa) & 63, register of row P - 1 - q
+            const int i = f64_out_reg<P>(qb + u);
+            unsigned a, b, c, d;
+            split64(re[P - 1 - i], a, b);
+            split64(im[P - 1 - i], c, d);
+            zpr[u] = join64((unsigned)__shfl((int)a, src_lane), (unsigned)__shfl((int)b, src_lane));
+            zpi[u] = join64((unsigned)__shfl((int)c, src_lane), (unsigned)__shfl((int)d, src_lane));
+        }
+#pragma unroll
+        for (int u = 0; u < EB; ++u) {
+            const int q = qb + u;
+            const int i = f64_out_reg<P>(q);
+            const int i0 = f64_out_reg<P>((P - q) % P);
+            const double pr_ = lane0 ? re[i0] : zpr[u];
+            const double pi_ = lane0 ? im[i0] : zpi[u];
+            const double er = 0.5 * (re[i] + pr_), ei = 0.5 * (im[i] - pi_);
+            const double orr = 0.5 * (im[i] + pi_), oi = -0.5 * (re[i] - pr_);
+            constexpr int kq = 64 / (2 * P);
+            const double cq = dc64(q * kq), sq = -ds64(q * kq);
+            const double wr = wl_c * cq - wl_s * sq, wi = wl_c * sq + wl_s * cq;
+            const double tr = wr * orr - wi * oi, ti = wr * oi + wi * orr;
+            fused_operand<MAGMODE, RAW>(er + tr, ei + ti, zero2, mag_scale, voi, vm[2 * q], vr[2 * q], vi[2 * q]);
+            fused_operand<MAGMODE, RAW>(er - tr, ti - ei, zero2, mag_scale, voi, vm[2 * q + 1], vr[2 * q + 1], vi[2 * q + 1]);
+        }
+    }
+    constexpr int ih = f64_out_reg<P>(P / 2);
+    fused_operand<MAGMODE, RAW>(re[ih], -im[ih], zero2, mag_scale, voi, m0, m1, m2);
+}
+
 // (measured, 57 k frames: 60 / 45 coefficients 1.043 -> 1.018 ms; 60 / 10: 0.893 -> 0.909 ms -- so only with three phase tiles)
 template <int P, int NTP>
 constexpr bool fused_pair() {
@@ -490,82 +578,12 @@ __global__ __launch_bounds__(kFusedWaves * 64) void k_analysis_warp_fused(
             for (int j = 0; j < P; ++j) re[j] = im[j] = 0.0;
         }
 
-        // operand values of one bin: (ln-power, phase operands of Re X/|X| and Im X/|X|) as the staged path forms them
-        auto operand = [&](double xr, double xi, float& a_m, float& a_r, float& a_i) {
-            const double s2 = xr * xr + xi * xi;
-            const bool nz = s2 > zero2;
-#if MPX_FUSED_F32NORM   // |X| and the unit phasor in float32 from the float64 spectrum: v_rsq_f32 (1 ulp) and float32 products, no
-            // Newton step -- <= 2 ulp on operands that the float32 matrix product then sums over 2 049 bins (the staged path
-            // rounds the float64 quotient once instead: k_analysis_f64's rows are API outputs, these operands are not)
-            const float s2f = (float)s2;
-            const float rf = nz ? __builtin_amdgcn_rsqf(s2f) : 0.0f;
-            a_m = fused_prologue_mag(MAGMODE, (s2f * rf) * mag_scale);
-            if (voi) {
-                a_r = fused_prologue_phase((float)xr * rf);
-                a_i = fused_prologue_phase((float)xi * rf);
-            } else {
-                a_r = a_i = 0.0f;
-            }
-            return;
-#endif
-            const double rr = nz ? rsqrt_f64(s2) : 0.0;
-            a_m = fused_prologue_mag(MAGMODE, (float)(s2 * rr) * mag_scale);
-#if MPX_FUSED_VOIBRANCH   // a real (wave-uniform) branch: an unvoiced frame skips the phase operands' arithmetic instead of discarding it
-            if (voi) {
-                a_r = fused_prologue_phase((float)(xr * rr));
-                a_i = fused_prologue_phase((float)(xi * rr));
-            } else {
-                a_r = a_i = 0.0f;
-            }
-#else
-            a_r = voi ? fused_prologue_phase((float)(xr * rr)) : 0.0f;
-            a_i = voi ? fused_prologue_phase((float)(xi * rr)) : 0.0f;
-#endif
-        };
-        // The split of every bin pair row FIRST (k_analysis_f64's epilogue arithmetic), into float32 operand registers:
-        // entry 2 q = the low bin kappa + 64 q of step q, 2 q + 1 = its mirror M - kappa - 64 q.  The float64 spectrum
-        // (128 registers) is dead after this block; what stays live through the chunk loop is 3 x P floats.
+        // the split of every bin pair row into float32 operand registers (fused_split_operands): the float64 spectrum (128
+        // registers) is dead after it; what stays live through the chunk loop is 3 x P floats
         float vm[P], vr[P], vi[P];
         {
-#ifndef MPX_FUSED_EB
-#define MPX_FUSED_EB 2
-#endif
-            constexpr int EB = MPX_FUSED_EB;
-#pragma unroll
-            for (int qb = 0; qb < P / 2; qb += EB) {
-                // (fence: the partner exchanges of LATER batches must not be scheduled ahead -- every batch in flight
-                // holds 4 EB more registers while the float64 spectrum is still live)
-                asm volatile("" : "+v"(re[f64_out_reg<P>(qb)]), "+v"(im[f64_out_reg<P>(qb)]));
-                double zpr[EB], zpi[EB];
-#pragma unroll
-                for (int u = 0; u < EB; ++u) {   // Z[M - k]: lane (64 - kappa) & 63, register of row P - 1 - q
-                    const int i = f64_out_reg<P>(qb + u);
-                    unsigned a, b, c, d;
-                    split64(re[P - 1 - i], a, b);
-                    split64(im[P - 1 - i], c, d);
-                    zpr[u] = join64((unsigned)__shfl((int)a, src_lane), (unsigned)__shfl((int)b, src_lane));
-                    zpi[u] = join64((unsigned)__shfl((int)c, src_lane), (unsigned)__shfl((int)d, src_lane));
-                }
-#pragma unroll
-                for (int u = 0; u < EB; ++u) {
-                    const int q = qb + u;
-                    const int i = f64_out_reg<P>(q);
-                    const int i0 = f64_out_reg<P>((P - q) % P);
-                    const double pr_ = lane0 ? re[i0] : zpr[u];
-                    const double pi_ = lane0 ? im[i0] : zpi[u];
-                    const double er = 0.5 * (re[i] + pr_), ei = 0.5 * (im[i] - pi_);
-                    const double orr = 0.5 * (im[i] + pi_), oi = -0.5 * (re[i] - pr_);
-                    constexpr int kq = 64 / (2 * P);
-                    const double cq = dc64(q * kq), sq = -ds64(q * kq);
-                    const double wr = wl_c * cq - wl_s * sq, wi = wl_c * sq + wl_s * cq;
-                    const double tr = wr * orr - wi * oi, ti = wr * oi + wi * orr;
-                    operand(er + tr, ei + ti, vm[2 * q], vr[2 * q], vi[2 * q]);
-                    operand(er - tr, ti - ei, vm[2 * q + 1], vr[2 * q + 1], vi[2 * q + 1]);
-                }
-            }
-            constexpr int ih = f64_out_reg<P>(P / 2);   // bin M/2 (its own mirror; lane kappa == 0 holds it)
             float m0, m1, m2;
-            operand(re[ih], -im[ih], m0, m1, m2);
+            fused_split_operands<P, MAGMODE, false>(re, im, zero2, mag_scale, voi, lane0, src_lane, wl_c, wl_s, vm, vr, vi, m0, m1, m2);
             if (lane0) {
                 mid[0 * kFusedWaves + wave] = m0;
                 mid[1 * kFusedWaves + wave] = m1;
@@ -791,6 +809,424 @@ __global__ __launch_bounds__(kFusedWaves * 64) void k_analysis_warp_fused(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The same launch at the CONSTANT frame rate (magphase.py:2967-2983, 2219-2239: the features of the pitch-synchronous frames
+// are interpolated to a 5 ms grid BEFORE the warp).  Constant-rate frame c lies between the variable-rate frames row0[c] and
+// row1[c] = row0[c] + 1 (or == row0[c]: the duplicated first row) with weight rowt[c]:
+//   magnitudes  ln((|X_lo| + t (|X_hi| - |X_lo|))^2 + 1e-8) . W_mag -- the logarithm follows the interpolation, so the matrix
+//               product's operand rows are the CONSTANT-rate frames: built in LDS from the published |X| rows of the round's
+//               eight frames and of the frame before them (the halo), two passes of eight rows per sweep of the chunk loop
+//               (a round with more than 16 constant-rate frames -- F0 below ~100 Hz -- sweeps again);
+//   phases      linear up to the 1e-8 floor term of their operand: the product runs on the variable-rate frames as in
+//               k_analysis_warp_fused and its phase_dim outputs are interpolated afterwards (k_warp_phase_rows,
+//               magphase_comp.hip), exactly as the staged path does since round 3 (mpx_mel_warp_rows).
+// A workgroup takes a CONTIGUOUS range of frames (frames_per_wg = 8 R - 1): its first round's window starts one frame early
+// (that frame is transformed twice per launch boundary: once per workgroup), every later round finds the halo -- |X| of the
+// previous round's last frame, 8 KB -- where wave 7 left it in global memory (`halo`, two round parities per workgroup; the
+// LDS is full), fetched four chunks ahead of its use.  A constant-rate frame belongs to the round whose window holds
+// row1[c]; cstart[f] = the first c with row1[c] >= f (k_cr_index).  Nothing of the lossless features reaches HBM: the staged
+// pair k_analysis_f64 -> k_mel_warp_mfma writes and re-reads 24.6 KB per frame.
+//
+// Two chunk loops per round.  Phases: two chunks per barrier.  Magnitudes, one barrier per chunk: before barrier q every wave
+// publishes its raw row of chunk q + 2 (three raw buffers); after it the matrix instructions read the operand rows of chunk q
+// while the workgroup builds those of chunk q + 1 (two operand buffers).  Weight fragments are fetched two chunks ahead.
+//
+// Measured (round 6, configs[2]: 56 985 -> 63 926 frames): 1.36 ms against 0.98 ms of the staged pair, HBM traffic of the
+// analysis side 0.37 GB against 2.87 GB.  Where the time goes (ablations, tools/ab_bench.py): transform + split 0.57 ms (as
+// in k_analysis_warp_fused), phase loop 0.25 ms, magnitude sweeps 0.55 ms -- of which the weights' reload 0.11, the matrix
+// instructions 0.10, the operand build 0.09, the raw publish 0.05, the halo 0.05: a chain of short steps between barriers
+// in which the two waves of a SIMD do the same thing at the same time.  (One loop for both products, as in the variable-rate
+// kernel: 60 registers spilled at N = 4096, 1.56 ms.)  The staged pair stays the default (engine.py: MAGPHASE_COMP_FUSED_CR).
+// ---------------------------------------------------------------------------------------------
+constexpr int kCrRows = 16;             // constant-rate frames per sweep: two passes of eight operand rows
+constexpr int kCrRawRows = 9;          // published magnitude rows per chunk: |X| of the window's eight frames + the halo (row 8)
+constexpr int kCrPhRows = 2 * 2 * 2 * kFusedWaves;   // the phase loop's tiles: two buffers of two chunks of [real 8][imaginary 8]
+template <int P>
+constexpr int cr_tile_floats() {
+    // (the phase loop's two tiles of 16 rows lie over the same space)
+    constexpr int mag_rows = 3 * kCrRawRows + 2 * kCrRows;   // three raw buffers, two operand buffers
+    constexpr int win = kFusedWaves * f64_win_floats<P>(), tiles = (mag_rows > kCrPhRows ? mag_rows : kCrPhRows) * kFusedAStride;
+    return win > tiles ? win : tiles;
+}
+template <int P>
+constexpr int cr_halo_floats() { return 64 * P + 64; }   // per round parity: |X| registers of a frame [P][64] + bin M/2
+template <int P, int NTP>
+constexpr size_t lds_bytes_fused_cr() {
+    constexpr size_t work = sizeof(float) * (size_t)(kFusedWaves * P * kXStride + cr_tile_floats<P>());
+    constexpr size_t red = sizeof(float) * (size_t)(kFusedWaves * (4 + NTP) * 4 * kFusedRedStride);
+    static_assert(work >= red, "the reduction buffer must fit the regions it aliases");
+    return sizeof(double) * (size_t)tw64_doubles<P>() + work + sizeof(float) * (48 + 3 * kCrRows);   // + bin M/2 values [25], frame flags [8], the sweep's row table
+}
+
+__global__ __launch_bounds__(256) void k_cr_index(const int* __restrict__ row1, int n_const, long long nframes,
+                                                  int* __restrict__ cstart) {
+    const long long f = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (f > nframes) return;
+    int lo = 0, hi = n_const;   // first c with row1[c] >= f (row1 ascends over the batch)
+    while (lo < hi) {
+        const int m = (lo + hi) >> 1;
+        if ((long long)row1[m] < f) lo = m + 1; else hi = m;
+    }
+    cstart[f] = lo;
+}
+
+template <int P, int NTP>
+__attribute__((amdgpu_waves_per_eu(2, 2)))
+__global__ __launch_bounds__(kFusedWaves * 64) void k_analysis_warp_fused_cr(
+    const float* __restrict__ sig, const long long* __restrict__ fpos, const int* __restrict__ fleft,
+    const int* __restrict__ fright, long long nframes, const double* __restrict__ tw_g,
+    const double* __restrict__ win_tab, int win_cap, const float* __restrict__ wpack, const float* __restrict__ whalf,
+    const float* __restrict__ rows_in_use, const int* __restrict__ row0, const int* __restrict__ row1,
+    const float* __restrict__ rowt, const int* __restrict__ cstart, int frames_per_wg, int mag_dim, int phase_dim,
+    float* __restrict__ omag, float* __restrict__ tr_out, float* __restrict__ ti_out, float* halo) {
+    static_assert(kFusedWaves == 8 && kFusedKH == 1 && MPX_FUSED_M4 != 0, "the constant-rate form is written for 8 waves and the 4 x 4 magnitude product");
+    constexpr int M = 64 * P, N = 2 * M, LB = ilog2(P), NC = P / 2, AS = kFusedAStride;
+    constexpr int TR = 4 + NTP;   // accumulators per wave: [pass][half] of the magnitudes, then the phase tiles
+    constexpr int FR = 8 + NTP;   // weight fragments per (chunk, wave): hostmath.pack_warp_fused(..., layout=1)
+    extern __shared__ __attribute__((aligned(16))) double smem64[];
+    double* tw = smem64;
+    float* xbase = reinterpret_cast<float*>(smem64 + tw64_doubles<P>());
+    const int lane_id = threadIdx.x & 63;
+    const int wave = rfl((int)(threadIdx.x >> 6));
+    float* xbuf = xbase + wave * (P * kXStride);
+    const unsigned xbuf_byte = 8u * (unsigned)tw64_doubles<P>() + 4u * (unsigned)(wave * (P * kXStride));
+    float* rawb = xbase + kFusedWaves * (P * kXStride);   // [3][kCrRawRows][AS]: the head of the window regions
+    float* abuf = rawb + 3 * kCrRawRows * AS;               // [2][kCrRows][AS]: the magnitudes' operand rows
+    float* wbuf = rawb + wave * f64_win_floats<P>();
+    const unsigned wbuf_byte = 8u * (unsigned)tw64_doubles<P>() + 4u * (unsigned)(kFusedWaves * (P * kXStride) + wave * f64_win_floats<P>());
+    float* red = xbase;
+    float* mid = rawb + cr_tile_floats<P>();   // bin M/2: [0..7] |X| of the window's frames, [8] the halo's, [9..16] real, [17..24] imaginary; [32..39] frame flags
+    float* prm = mid + 48;                     // [kCrRows][3]: (row0, row1, weight) of the sweep's constant-rate frames
+    for (int i = threadIdx.x; i < tw64_doubles<P>(); i += kFusedWaves * 64) {
+        const int l = i / tw64_stride<P>(), c = i - l * tw64_stride<P>();
+        const int src = (kF64Dit && c < 2 * P) ? l * tw64_stride<P>() + 2 * brev(c >> 1, LB) + (c & 1) : i;
+        tw[i] = tw_g[src];
+    }
+    __syncthreads();
+
+    double wl_s0, wl_c0;
+    sincospi(-2.0 * (double)kappa<P>(lane_id) / (double)N, &wl_s0, &wl_c0);
+    const int li = lane_id & 15, g = lane_id >> 4;
+    const f32x4_t* wp4 = reinterpret_cast<const f32x4_t*>(wpack) + ((long long)wave * FR) * 64;   // wave-uniform
+    float* hs = halo + (long long)blockIdx.x * (2 * cr_halo_floats<P>());
+    const long long own_lo = (long long)blockIdx.x * frames_per_wg;
+    const long long own_end = (own_lo + frames_per_wg < nframes) ? own_lo + frames_per_wg : nframes;
+    const int arow4 = (4 * (lane_id >> 5) + (lane_id & 3)) * AS + kFusedCols * wave;
+    const int jr = (int)(threadIdx.x >> 5), col4 = 4 * (int)(threadIdx.x & 31);   // operand-row build: row of the sweep, four columns
+
+    int c_next0 = 0, c_next1 = 0;
+    bool prm_ready = false;   // the first sweep's row table is already in `prm` (left there by the previous round)
+    for (int r = 0;; ++r) {
+        // window [a, a + 8); owned: the constant-rate frames with row1 in [a + (r == 0), min(a + 8, own_end))
+        const long long a = own_lo - 1 + 8ll * r;
+        const long long hi_lo = (r == 0) ? a + 1 : a;
+        if (hi_lo >= own_end) break;
+        const long long hi_hi = (a + 8 < own_end) ? a + 8 : own_end;
+        // constant-rate frames of this round [c0, c1) and the end of the NEXT round's (its begin is this round's c1): the
+        // scalar loads fly under the transform
+        const int c0 = (r == 0) ? cstart[hi_lo] : c_next0;
+        const int c1 = (r == 0) ? cstart[hi_hi] : c_next1;
+        const bool more = a + 8 < own_end;   // another round follows
+        c_next0 = c1;
+        c_next1 = more ? cstart[(a + 16 < own_end) ? a + 16 : own_end] : c1;
+        int lane = lane_id;   // laundered per round (see k_analysis_f64)
+        double wl_s = wl_s0, wl_c = wl_c0;
+        asm volatile("" : "+v"(lane), "+v"(wl_s), "+v"(wl_c));
+        const int kap = kappa<P>(lane);
+        const int src_lane = kappa<P>((64 - kap) & 63);
+        const bool lane0 = (kap == 0);
+        const long long f = a + wave;
+        const bool has = f >= 0 && f < own_end;   // wave-uniform
+        double re[P], im[P];
+        double zero2 = 1.0e-36;
+        float mag_scale = 1.0f;
+        bool voi = false;
+        if (has) {
+            f64_frame_transform<P>(sig, fpos[f], fleft[f], fright[f], win_tab, win_cap, tw, xbuf, xbuf_byte, wbuf, wbuf_byte, lane,
+                                   re, im, zero2, mag_scale);
+            voi = rfl((int)(rows_in_use[f] != 0.0f)) != 0;
+        } else {
+#pragma unroll
+            for (int j = 0; j < P; ++j) re[j] = im[j] = 0.0;
+        }
+        float vm[P], vr[P], vi[P];
+        const bool halo_on = r >= 1;
+        const float* hp = hs + ((r + 1) & 1) * cr_halo_floats<P>();   // where the previous round left its last frame
+        {
+            float m0, m1, m2;
+            fused_split_operands<P, 0, true>(re, im, zero2, mag_scale, voi, lane0, src_lane, wl_c, wl_s, vm, vr, vi, m0, m1, m2);
+            if (lane0) {
+                mid[wave] = m0;
+                mid[9 + wave] = m1;
+                mid[17 + wave] = m2;
+            }
+            if (wave == kFusedWaves - 1) {   // the next round's halo
+                float* hw = hs + (r & 1) * cr_halo_floats<P>();
+#pragma unroll
+                for (int j = 0; j < P; ++j) hw[j * 64 + lane_id] = vm[j];
+                if (lane0) {
+                    hw[64 * P] = m0;
+                    if (halo_on) mid[8] = hp[64 * P];
+                }
+            }
+        }
+        // A round without a frame in use has nothing for the phase tiles to do.  (Not __syncthreads_or: its workgroup reduction
+        // brings a static LDS variable with it, the dynamic array then no longer starts at LDS address 0 and the byte
+        // offsets the transform's direct-to-LDS loads are given -- xbuf_byte, wbuf_byte -- point elsewhere.)
+        if (lane_id == 0) mid[32 + wave] = voi ? 1.0f : 0.0f;
+        __syncthreads();   // also the barrier the tiles need: they overlay the other waves' window regions
+        bool any_ph = false;
+#pragma unroll
+        for (int w = 0; w < kFusedWaves; ++w) any_ph |= mid[32 + w] != 0.0f;
+        any_ph = rfl((int)any_ph) != 0;
+
+        // The halo row comes back from global memory (L2) kHaloAhead chunks ahead of its use: with one chunk of lead the whole
+        // workgroup waited at every barrier for wave 7's load (1.2 us per chunk instead of 0.4).
+        constexpr int kHaloAhead = 4;
+        const bool halo_w = halo_on && wave == kFusedWaves - 1;   // wave-uniform: this wave also publishes the halo row
+        float hq[kHaloAhead][2];
+#pragma unroll
+        for (int u = 0; u < kHaloAhead; ++u) hq[u][0] = hq[u][1] = 0.0f;
+        if (halo_w && c1 > c0) {
+#pragma unroll
+            for (int u = 0; u < kHaloAhead; ++u) {
+                hq[u][0] = hp[(2 * u) * 64 + lane_id];
+                hq[u][1] = hp[(2 * u + 1) * 64 + lane_id];
+            }
+        }
+
+        // ---- phase streams of the window's frames (variable rate): their own chunk loop, two chunks per barrier, so that the
+        // 64 operand registers (vr, vi) are dead before the magnitude sweeps need theirs (one loop for both: 60 registers
+        // spilled at N = 4096 and 1.56 ms instead of 1.38)
+        f32x4_t accp[NTP];
+#pragma unroll
+        for (int t = 0; t < NTP; ++t) accp[t] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
+        if (any_ph) {
+            // weight fragments TWO chunks ahead (an L2 round trip is longer than one chunk of this loop: with the reload right
+            // behind the use, as in k_analysis_warp_fused where the magnitude product covers it, every chunk waited for it)
+            f32x4_t bp[2][NTP];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                int wo = u * (kFusedWaves * FR * 64);
+                asm volatile("" : "+s"(wo));   // (the offset, not the pointer: see k_analysis_warp_fused)
+#pragma unroll
+                for (int t = 0; t < NTP; ++t) bp[u][t] = wp4[wo + (8 + t) * 64 + lane_id];
+            }
+#pragma unroll
+            for (int q = 0; q < NC; ++q) {
+                // buffer (q >> 1) & 1, half q & 1: [real rows 0..7][imaginary rows 8..15]
+                float* tile = rawb + (((q >> 1) & 1) * 2 + (q & 1)) * (2 * kFusedWaves * AS);
+                if ((q & 1) == 0) {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        float* row = tile + u * (2 * kFusedWaves * AS) + wave * AS;
+                        row[kap] = vr[2 * (q + u)];
+                        row[64 + kap] = vr[2 * (q + u) + 1];
+                        row += kFusedWaves * AS;
+                        row[kap] = vi[2 * (q + u)];
+                        row[64 + kap] = vi[2 * (q + u) + 1];
+                    }
+                    __syncthreads();
+                }
+                const f32x4_t ap = *reinterpret_cast<const f32x4_t*>(tile + li * AS + kFusedCols * wave + 4 * g);
+                int wo = (q + 2 < NC ? q + 2 : q) * (kFusedWaves * FR * 64);
+                asm volatile("" : "+s"(wo));
+#pragma unroll
+                for (int t = 0; t < NTP; ++t) {
+                    f32x4_t ca = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ca = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[e], bp[q & 1][t][e], ca, 0, 0, 0);
+                    if (q + 2 < NC) bp[q & 1][t] = wp4[wo + (8 + t) * 64 + lane_id];
+                    accp[t] += ca;
+                }
+            }
+            __syncthreads();   // the magnitude sweep's first rows go where the last phase tiles were read
+        }
+
+        // ---- magnitudes: sweeps of up to kCrRows constant-rate frames
+        for (int cb = c0, sweep = 0; sweep == 0 || cb < c1; cb += kCrRows, ++sweep) {
+            const bool ph = sweep == 0 && any_ph;               // the phase accumulators go out with the first sweep
+            const int nrows = (c1 - cb < kCrRows) ? c1 - cb : kCrRows;
+            const int npass = nrows > 8 ? 2 : (nrows > 0 ? 1 : 0);
+            // The sweep's row table in LDS: prm[j] = (row0, row1, weight) of constant-rate frame cb + j.  The first sweep of a
+            // round finds it there (the previous round fetched it under its output stage); otherwise sixteen threads fetch it
+            // now -- three dependent-free loads whose latency every thread of the workgroup would otherwise wait for twice.
+            if (!(sweep == 0 && prm_ready)) {
+                if (threadIdx.x < kCrRows && (int)threadIdx.x < nrows) {
+                    prm[3 * threadIdx.x] = __int_as_float(row0[cb + threadIdx.x]);
+                    prm[3 * threadIdx.x + 1] = __int_as_float(row1[cb + threadIdx.x]);
+                    prm[3 * threadIdx.x + 2] = rowt[cb + threadIdx.x];
+                }
+                __syncthreads();
+            }
+            // this thread's operand row of the sweep: its two source rows (8 = the halo) and the weight; rows past the sweep's
+            // end are built from row 0 and never read
+            int lo_rel = 0, hi_rel = 0;
+            float tt = 0.0f;
+            if (jr < nrows) {
+                lo_rel = __float_as_int(prm[3 * jr]) - (int)a;
+                hi_rel = __float_as_int(prm[3 * jr + 1]) - (int)a;
+                tt = prm[3 * jr + 2];
+                if (lo_rel < 0) lo_rel = 8;
+            }
+            f32x4_t acc[4];   // [pass][half]
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[t] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
+            // The chunk loop for NP passes: straight-line code per pass count.  (A run-time `p < npass` inside the unrolled loop
+            // put every chunk's accumulator update into a block of its own; the compiler sank all of them behind the loop and
+            // kept 16 chunks' matrix results alive until then -- 200 registers spilled, 2.4 ms.  The accumulators are pinned
+            // where they are formed for the same reason.)
+            // Pipeline, one barrier per chunk: before barrier q every wave publishes its raw row of chunk q + 2 (three raw
+            // buffers); after it the matrix instructions read the operand rows of chunk q while the workgroup builds those of
+            // chunk q + 1 (two operand buffers) from the raw rows of chunk q + 1, published before barrier q - 1.
+            auto chunks = [&](auto np_tag) {
+                constexpr int NP = decltype(np_tag)::value;
+                f32x4_t bm[2][4][2];   // weight fragments of two chunks: chunk q + 2's are fetched behind chunk q's last use
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    int wo = u * (kFusedWaves * FR * 64);
+                    asm volatile("" : "+s"(wo));
+#pragma unroll
+                    for (int fi = 0; fi < 8; ++fi) bm[u][fi >> 1][fi & 1] = wp4[wo + fi * 64 + lane_id];
+                }
+                const bool builder = NP == 2 || wave < kFusedWaves / 2;   // wave-uniform: operand rows 8..15 belong to waves 4..7
+                if (sweep > 0 && halo_w) {   // (the first sweep's ring was filled before the phase loop)
+#pragma unroll
+                    for (int u = 0; u < kHaloAhead; ++u) {
+                        hq[u][0] = hp[(2 * u) * 64 + lane_id];
+                        hq[u][1] = hp[(2 * u + 1) * 64 + lane_id];
+                    }
+                }
+                auto publish = [&](int q) {
+                    float* row = rawb + (q % 3) * (kCrRawRows * AS) + wave * AS;
+                    row[kap] = vm[2 * q];
+                    row[64 + kap] = vm[2 * q + 1];
+                    if (halo_w) {
+                        float* hr = rawb + (q % 3) * (kCrRawRows * AS) + 8 * AS;
+                        hr[kap] = hq[q % kHaloAhead][0];
+                        hr[64 + kap] = hq[q % kHaloAhead][1];
+                        if (q + kHaloAhead < NC) {
+                            hq[q % kHaloAhead][0] = hp[(2 * (q + kHaloAhead)) * 64 + lane_id];
+                            hq[q % kHaloAhead][1] = hp[(2 * (q + kHaloAhead) + 1) * 64 + lane_id];
+                        }
+                    }
+                };
+                auto build = [&](int q) {   // operand row jr of chunk q: ln((lo + t (hi - lo))^2 + 1e-8), four columns per thread
+                    const float* rb = rawb + (q % 3) * (kCrRawRows * AS);
+                    const f32x4_t x0 = *reinterpret_cast<const f32x4_t*>(rb + lo_rel * AS + col4);
+                    const f32x4_t x1 = *reinterpret_cast<const f32x4_t*>(rb + hi_rel * AS + col4);
+                    f32x4_t av;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) av[e] = fused_prologue_mag(0, fmaf(x1[e] - x0[e], tt, x0[e]));
+                    *reinterpret_cast<f32x4_t*>(abuf + (q & 1) * (kCrRows * AS) + jr * AS + col4) = av;
+                };
+                publish(0);
+                publish(1);
+                __syncthreads();
+                if (builder) build(0);
+#pragma unroll
+                for (int q = 0; q < NC; ++q) {
+                    const float* ab = abuf + (q & 1) * (kCrRows * AS);
+                    if (q + 2 < NC) publish(q + 2);
+                    __syncthreads();
+                    int wo = (q + 2 < NC ? q + 2 : q) * (kFusedWaves * FR * 64);
+                    asm volatile("" : "+s"(wo));
+                    if (q + 1 < NC && builder) build(q + 1);
+#pragma unroll
+                    for (int p = 0; p < NP; ++p) {
+                        f32x4_t a4[4];
+#pragma unroll
+                        for (int kg = 0; kg < 4; ++kg) a4[kg] = *reinterpret_cast<const f32x4_t*>(ab + 8 * p * AS + arow4 + 4 * kg);
+                        // FRESH accumulators per chunk, two per half (see k_analysis_warp_fused)
+                        f32x4_t cm[2][2];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) cm[i >> 1][i & 1] = f32x4_t{0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                        for (int kg = 0; kg < 4; ++kg)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                                for (int hf = 0; hf < 2; ++hf)
+                                    cm[hf][e & 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a4[kg][e], bm[q & 1][kg][hf][e], cm[hf][e & 1], 0, 0, 0);
+                        acc[2 * p] += cm[0][0] + cm[0][1];
+                        acc[2 * p + 1] += cm[1][0] + cm[1][1];
+                        asm volatile("" : "+v"(acc[2 * p]), "+v"(acc[2 * p + 1]));   // (formed HERE, see above)
+                    }
+                    if (q + 2 < NC) {
+#pragma unroll
+                        for (int fi = 0; fi < 8; ++fi) bm[q & 1][fi >> 1][fi & 1] = wp4[wo + fi * 64 + lane_id];
+                    }
+                }
+            };
+            if (npass == 2) chunks(std::integral_constant<int, 2>{});
+            else if (npass == 1) chunks(std::integral_constant<int, 1>{});
+            // the NEXT round's first sweep: its row table is fetched now and goes to LDS behind this sweep's output stage
+            const bool last_sweep = cb + kCrRows >= c1;
+            const bool fetch = last_sweep && more && threadIdx.x < kCrRows && c_next0 + (int)threadIdx.x < c_next1;
+            int n_lo = 0, n_hi = 0;
+            float n_t = 0.0f;
+            if (fetch) {
+                n_lo = row0[c_next0 + threadIdx.x];
+                n_hi = row1[c_next0 + threadIdx.x];
+                n_t = rowt[c_next0 + threadIdx.x];
+            }
+            __syncthreads();   // every wave is done with the tiles and its transpose buffer: `red` may overwrite them
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int rr = 0; rr < 4; ++rr) red[((wave * TR + t) * 4 + rr) * kFusedRedStride + lane_id] = acc[t][rr];
+            if (ph) {
+#pragma unroll
+                for (int t = 0; t < NTP; ++t)
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr) red[((wave * TR + 4 + t) * 4 + rr) * kFusedRedStride + lane_id] = accp[t][rr];
+            }
+            __syncthreads();
+            // magnitudes of the sweep's constant-rate frames: row jo = 8 p + fr of pass p is register fr & 3 of lane
+            // (n & 31) + 32 (fr >> 2) of accumulator 2 p + (n >> 5)
+            for (int idx = threadIdx.x; idx < kCrRows * 64; idx += kFusedWaves * 64) {
+                const int jo = idx >> 6, n = idx & 63;
+                if (jo >= nrows || n >= mag_dim) continue;
+                const int p = jo >> 3, fr = jo & 7;
+                float y = 0.0f;
+#pragma unroll
+                for (int w = 0; w < kFusedWaves; ++w)
+                    y += red[((w * TR + 2 * p + (n >> 5)) * 4 + (fr & 3)) * kFusedRedStride + (n & 31) + 32 * (fr >> 2)];
+                int lo = __float_as_int(prm[3 * jo]) - (int)a;
+                const int hi = __float_as_int(prm[3 * jo + 1]) - (int)a;
+                if (lo < 0) lo = 8;
+                const float xm = fmaf(mid[hi] - mid[lo], prm[3 * jo + 2], mid[lo]);
+                omag[(long long)(cb + jo) * mag_dim + n] = fmaf(fused_prologue_mag(0, xm), whalf[n], y);
+            }
+            if (ph) {   // phase coefficients of the window's frames, at the variable rate (no mask, no clip: k_warp_phase_rows)
+                for (int idx = threadIdx.x; idx < kFusedWaves * 2 * NTP * 16; idx += kFusedWaves * 64) {
+                    const int c = idx & 15, to = (idx >> 4) % (2 * NTP), fr = idx / (16 * 2 * NTP);
+                    const long long fo = a + fr;
+                    if (fo < 0 || fo >= own_end) continue;
+                    const int sa = (to < NTP) ? 1 : 2;
+                    const int tp = (sa == 2) ? to - NTP : to;
+                    const int row = (sa == 2) ? 8 + fr : fr;
+                    const int n = 16 * tp + c;
+                    if (n >= phase_dim || mid[32 + fr] == 0.0f) continue;   // (the frame's flag: rows_in_use[fo])
+                    float y = 0.0f;
+#pragma unroll
+                    for (int w = 0; w < kFusedWaves; ++w)
+                        y += red[((w * TR + 4 + tp) * 4 + (row & 3)) * kFusedRedStride + c + 16 * (row >> 2)];
+                    y = fmaf(mid[(sa == 1 ? 9 : 17) + fr], whalf[(4 + tp) * 16 + c], y);
+                    (sa == 1 ? tr_out : ti_out)[fo * phase_dim + n] = y;
+                }
+            }
+            __syncthreads();   // `red` and `prm` are reused by the next sweep / round
+            if (fetch) {
+                prm[3 * threadIdx.x] = __int_as_float(n_lo);
+                prm[3 * threadIdx.x + 1] = __int_as_float(n_hi);
+                prm[3 * threadIdx.x + 2] = n_t;
+            }
+            prm_ready = last_sweep && more;
+        }
+    }
+}
+
 // First-pass twiddle table in double (layout: wave_fft_f64.hpp).  One block per lane row, one thread per entry.
 __global__ void k_tables_init_f64(int P, double* __restrict__ tab) {
     const int l = blockIdx.x, i = threadIdx.x;
@@ -911,6 +1347,68 @@ int mpx_analysis_compressed_fused(void* stream, int fft_len, const void* tables_
     else MPX_FUSED_P(16);
 #undef MPX_FUSED_P
 #undef MPX_FUSED_GO
+    MPX_HIP_CHECK(hipGetLastError());
+    return MPX_OK;
+}
+
+// Scratch of mpx_analysis_compressed_fused_cr: cstart (int32 x (n_frames + 1), padded to 256 bytes), then the workgroups' halos
+int64_t mpx_analysis_compressed_fused_cr_work_bytes(int fft_len, int64_t n_frames) {
+    const int P = p_of(fft_len);
+    if ((P != 32 && P != 16) || n_frames < 0) return MPX_ERR_ARG;
+    const int64_t idx = ((int64_t)sizeof(int32_t) * (n_frames + 1) + 255) / 256 * 256;
+    return idx + (int64_t)sizeof(float) * device_cus() * 2 * (64 * P + 64);
+}
+
+/* (declared in include/magphase_hip.h) */
+int mpx_analysis_compressed_fused_cr(void* stream, int fft_len, const void* tables_f64, const float* sig,
+                                     const int64_t* frame_pos, const int32_t* frame_left, const int32_t* frame_right,
+                                     int64_t n_frames, const double* win_tab, int32_t win_cap, const float* wpack,
+                                     const float* whalf, int32_t mag_dim, int32_t phase_dim, const float* rows_in_use,
+                                     const int32_t* row0, const int32_t* row1, const float* row_t, int64_t n_const,
+                                     float* out_mag, float* tmp_real, float* tmp_imag, void* work) {
+    const int P = p_of(fft_len);
+    if (P != 32 && P != 16) return fail(MPX_ERR_ARG, "mpx_analysis_compressed_fused_cr: fft_len must be 2048 or 4096%s");
+    if (n_frames < 0 || n_const < 0 || n_const > 2147483647ll || n_frames > 2147483647ll)
+        return fail(MPX_ERR_ARG, "mpx_analysis_compressed_fused_cr: bad frame count%s");
+    if (mag_dim <= 0 || mag_dim > 64 || phase_dim <= 0 || phase_dim > 48)
+        return fail(MPX_ERR_ARG, "mpx_analysis_compressed_fused_cr: mag_dim must be in 1..64 and phase_dim in 1..48%s");
+    if (win_tab && win_cap < 0) return fail(MPX_ERR_ARG, "mpx_analysis_compressed_fused_cr: negative win_cap%s");
+    if (kFusedWaves != 8 || kFusedKH != 1 || MPX_FUSED_M4 == 0)
+        return fail(MPX_ERR_ARG, "mpx_analysis_compressed_fused_cr: this build's fused kernel has another tile shape%s");
+    if (n_frames == 0) return MPX_OK;
+    if (!tables_f64 || !sig || !frame_pos || !frame_left || !frame_right || !wpack || !whalf || !rows_in_use || !work ||
+        !tmp_real || !tmp_imag || (n_const > 0 && (!row0 || !row1 || !row_t || !out_mag)))
+        return fail(MPX_ERR_ARG, "mpx_analysis_compressed_fused_cr: null pointer%s");
+    hipStream_t s = (hipStream_t)stream;
+    int* cstart = (int*)work;
+    float* halo = (float*)((char*)work + ((int64_t)sizeof(int32_t) * (n_frames + 1) + 255) / 256 * 256);
+    hipLaunchKernelGGL(k_cr_index, dim3((unsigned)((n_frames + 1 + 255) / 256)), dim3(256), 0, s, row1, (int)n_const,
+                       (long long)n_frames, cstart);
+    // contiguous frame ranges of 8 R - 1 frames (the first round's window starts one frame early), one workgroup per CU
+    const long long slots = device_cus();
+    const long long per = (n_frames + slots - 1) / slots;
+    const long long fw = 8 * ((per + 1 + 7) / 8) - 1;
+    const dim3 grid((unsigned)((n_frames + fw - 1) / fw)), block(kFusedWaves * 64);
+    const int ntp = (phase_dim + 15) / 16;
+#define MPX_FUSED_CR_GO(PP, NTP_)                                                                                       \
+    do {                                                                                                                \
+        if (int rc = set_lds(k_analysis_warp_fused_cr<PP, NTP_>, (lds_bytes_fused_cr<PP, NTP_>()))) return rc;          \
+        hipLaunchKernelGGL((k_analysis_warp_fused_cr<PP, NTP_>), grid, block, (lds_bytes_fused_cr<PP, NTP_>()), s, sig, \
+                           (const long long*)frame_pos, frame_left, frame_right, (long long)n_frames,                   \
+                           (const double*)tables_f64, win_tab, (int)win_cap, wpack, whalf, rows_in_use, row0, row1,     \
+                           row_t, (const int*)cstart, (int)fw, (int)mag_dim, (int)phase_dim, out_mag, tmp_real,         \
+                           tmp_imag, halo);                                                                             \
+    } while (0)
+#define MPX_FUSED_CR_P(PP)                       \
+    do {                                         \
+        if (ntp == 1) MPX_FUSED_CR_GO(PP, 1);    \
+        else if (ntp == 2) MPX_FUSED_CR_GO(PP, 2); \
+        else MPX_FUSED_CR_GO(PP, 3);             \
+    } while (0)
+    if (P == 32) MPX_FUSED_CR_P(32);
+    else MPX_FUSED_CR_P(16);
+#undef MPX_FUSED_CR_P
+#undef MPX_FUSED_CR_GO
     MPX_HIP_CHECK(hipGetLastError());
     return MPX_OK;
 }

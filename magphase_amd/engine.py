@@ -2356,10 +2356,23 @@ class CompressedAnalysisPlan:
         # Variable frame rate: ONE fused kernel, the lossless features never reach HBM (mpx_analysis_compressed_fused;
         # MAGPHASE_COMP_FUSED=0 keeps the staged pair k_analysis_f64 -> k_mel_warp_mfma).  The constant-rate path
         # interpolates staged lossless rows, as the reference does (SURVEY.md 8d allows that staging).
-        self.fused = (not b_const_rate and N in (2048, 4096) and self.mag_dim <= 64 and self.phase_dim <= 48
-                      and os.environ.get("MAGPHASE_COMP_FUSED", "1") != "0"
-                      and os.environ.get("MAGPHASE_COMP_ANALYSIS", "f64") != "f32")
-        if self.fused:
+        fusable = (N in (2048, 4096) and self.mag_dim <= 64 and self.phase_dim <= 48
+                   and os.environ.get("MAGPHASE_COMP_FUSED", "1") != "0"
+                   and os.environ.get("MAGPHASE_COMP_ANALYSIS", "f64") != "f32")
+        self.fused = fusable and not b_const_rate
+        # Constant rate: the staged pair k_analysis_f64 -> k_mel_warp_mfma, which interpolates staged lossless rows as the
+        # reference does (SURVEY.md 8d allows that staging), or -- MAGPHASE_COMP_FUSED_CR=1 -- the same ONE kernel with the
+        # row interpolation inside (mpx_analysis_compressed_fused_cr: the magnitudes' operand rows are built per
+        # constant-rate frame, the phase streams are warped at the variable rate and finished by mpx_warp_phase_rows).
+        # Measured on configs[2] (round 6, bench.py configs2.analysis_one_kernel): HBM traffic of the analysis side 2.87 ->
+        # 0.37 GB, no 1.4 GB of staged rows -- and 1.38 ms instead of 0.98: opt-in.  (The filter-bank magnitudes take the
+        # logarithm AFTER the product: staged only.)
+        self.fused_cr = (fusable and b_const_rate and self.phase_on_rows and self._warp_name != "mpx_mel_warp_fbank"
+                         and self.total_out_frames > 0 and int(e.lib.mpx_analysis_compressed_fused_waves()) == 8
+                         and int(e.lib.mpx_analysis_compressed_fused_layout()) == 1
+                         and os.environ.get("MAGPHASE_COMP_FUSED_CR", "0") == "1")
+        self._cr_work = None
+        if self.fused or self.fused_cr:
             nw = int(e.lib.mpx_analysis_compressed_fused_waves())
             layout = int(e.lib.mpx_analysis_compressed_fused_layout())   # fragment order this build of the kernel reads
             key = ("wpack", self._warp_name, int(mag_dim), int(k_full), int(phase_dim), H, float(alpha), float(a_ph), nw,
@@ -2395,6 +2408,33 @@ class CompressedAnalysisPlan:
                     1 if self._warp_name == "mpx_mel_warp_fbank" else 0, out[0].data_ptr(), out[1].data_ptr(),
                     out[2].data_ptr()), "mpx_analysis_compressed_fused")
             mark("k_analysis_warp_fused")
+            return out
+        if self.fused_cr:
+            if out is None:
+                out = (e.empty((self.total_out_frames, self.mag_dim)), e.empty((self.total_out_frames, self.phase_dim)),
+                       e.empty((self.total_out_frames, self.phase_dim)))
+            pl = self.lossless
+            n_var = int(pl.total_frames)
+            if self._phase_tmp is None:
+                self._phase_tmp = (e.empty((n_var, self.phase_dim)), e.empty((n_var, self.phase_dim)))
+                nbytes = int(e.lib.mpx_analysis_compressed_fused_cr_work_bytes(int(self.fft_len), n_var))
+                self._cr_work = e.empty(((nbytes + 3) // 4,))
+            wt = e.hann_table() if os.environ.get("MAGPHASE_F64_WINDOW", "table") != "analytic" else None
+            with torch.cuda.device(e.device):
+                _lib.check(e.lib.mpx_analysis_compressed_fused_cr(
+                    e.stream_ptr(), int(self.fft_len), e.tables_f64(self.fft_len).data_ptr(), pl.sig.data_ptr(),
+                    pl.pos.data_ptr(), pl.left.data_ptr(), pl.right.data_ptr(), n_var,
+                    (wt.data_ptr() if wt is not None else None), (hm.HANN_TABLE_CAP if wt is not None else 0),
+                    self.wpack.data_ptr(), self.whalf.data_ptr(), self.mag_dim, self.phase_dim,
+                    self.rows_in_use.data_ptr(), self.row0.data_ptr(), self.row1.data_ptr(), self.rowt.data_ptr(),
+                    int(self.total_out_frames), out[0].data_ptr(), self._phase_tmp[0].data_ptr(),
+                    self._phase_tmp[1].data_ptr(), self._cr_work.data_ptr()), "mpx_analysis_compressed_fused_cr")
+                mark("k_analysis_warp_fused_cr")
+                _lib.check(e.lib.mpx_warp_phase_rows(
+                    e.stream_ptr(), int(self.total_out_frames), self.phase_dim, self._phase_tmp[0].data_ptr(),
+                    self._phase_tmp[1].data_ptr(), self.row0.data_ptr(), self.row1.data_ptr(), self.rowt.data_ptr(),
+                    self.voi.data_ptr(), out[1].data_ptr(), out[2].data_ptr()), "mpx_warp_phase_rows")
+            mark("k_warp_phase_rows")
             return out
         # (the phase rows nobody reads -- rows_in_use == 0 -- are not written either)
         mag, real, imag = self.lossless.run(out=feats, precise=precise,

@@ -794,3 +794,94 @@ def test_stored_noise_spectra_matches_reference_golden_and_recomputed(mp, orc, g
         v = mp.synthesis_from_compressed(f[0], f[1], f[2], f[3], 16000)
     assert len(v) == len(ref)
     within(np.max(np.abs(v - ref)) / np.max(np.abs(ref)), COMP_PCM_TOL, "COMP_PCM_TOL:nspec_16k")
+
+
+@pytest.mark.parametrize("fs,mag_dim,phase_dim,n_utts", [(48000, 60, 45, 12), (16000, 60, 45, 70), (16000, 24, 16, 5),
+                                                         (48000, 64, 48, 4), (16000, 3, 1, 4)])
+def test_one_kernel_constant_rate_analysis_matches_oracle_and_staged_path(orc, monkeypatch, fs, mag_dim, phase_dim, n_utts):
+    """mpx_analysis_compressed_fused_cr + mpx_warp_phase_rows (MAGPHASE_COMP_FUSED_CR=1: transform, interpolation to the 5 ms
+    grid and both warps without the lossless rows in HBM) against the oracle at the constant-rate path's tolerances and
+    against the staged pair.  The batch holds what the kernel's bookkeeping has to get right: more frames than one round per
+    workgroup (the halo row handed from round to round), an utterance with a single voiced frame (rounds without phase
+    tiles), a 60 Hz voice (more than
+    16 constant-rate frames per window of eight: a second sweep), a 400 Hz voice (frames without a constant-rate frame of
+    their own), a one-frame tail (frame counts that are no multiple of eight) and bit-reproducibility."""
+    from magphase_amd import synthetic as syn
+    from magphase_amd.engine import CompressedAnalysisPlan, get_engine
+    eng = get_engine()
+    utts = []
+    for u in range(n_utts):
+        pcm, pm, voi = syn.make_utterance(90 + u, dur_s=0.8 + 0.11 * (u % 7), fs=fs)
+        x = syn.pcm_to_float(pcm)
+        dur = len(x) / float(fs)
+        if u == 1:       # one voiced frame only (none at all: the reference's constant-rate f0 interpolation has nothing to
+            voi = np.zeros_like(voi)   # interpolate from and raises, magphase.py:2975-2980)
+            voi[len(voi) // 2] = 1.0
+        elif u == 2:     # 60 Hz: 3.3 constant-rate frames per pitch period
+            pm = np.round(np.arange(0.02, dur - 0.03, 1.0 / 60.0), 6)
+            voi = np.ones_like(pm)
+        elif u == 3:     # 400 Hz: two frames per 5 ms
+            pm = np.round(np.arange(0.01, dur - 0.02, 1.0 / 400.0), 6)
+            voi = np.ones_like(pm)
+        utts.append((x, fs, pm, voi))
+    kw = dict(mag_dim=mag_dim, phase_dim=phase_dim, b_const_rate=True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        monkeypatch.setenv("MAGPHASE_COMP_FUSED_CR", "1")
+        pf = CompressedAnalysisPlan(eng, utts, **kw)
+        if pf.lossless.total_frames % 8 == 0:
+            x0, f0_, pm0, voi0 = utts[0]
+            utts[0] = (x0, f0_, pm0[:-1], voi0[:-1])
+            pf = CompressedAnalysisPlan(eng, utts, **kw)
+        assert pf.fused_cr and not pf.fused and pf.lossless.total_frames % 8 != 0
+        a = [t.cpu().numpy() for t in pf.run()]
+        a2 = [t.cpu().numpy() for t in pf.run()]
+        monkeypatch.setenv("MAGPHASE_COMP_FUSED_CR", "0")
+        ps = CompressedAnalysisPlan(eng, utts, **kw)
+        assert not ps.fused_cr
+        b = [t.cpu().numpy() for t in ps.run()]
+    if n_utts >= 12:   # several rounds per workgroup: the halo path is in use
+        assert pf.lossless.total_frames > 8 * 256
+    for x, y in zip(a, a2):
+        assert np.array_equal(x, y)
+    assert all(np.all(np.isfinite(x)) for x in a)
+    within(np.max(np.abs(a[0].astype(np.float64) - b[0])), 1.5e-5, "ONE_KERNEL_CR_VS_STAGED:mag")
+    within(max(np.max(np.abs(a[1].astype(np.float64) - b[1])), np.max(np.abs(a[2].astype(np.float64) - b[2]))), 2e-6,
+           "ONE_KERNEL_CR_VS_STAGED:phase")
+    voi_c = pf.voi.cpu().numpy()
+    assert np.all(a[1][voi_c == 0] == 0.0) and np.all(a[2][voi_c == 0] == 0.0)
+    for u in ([0, 1, 2, 3] + ([n_utts - 1] if n_utts > 4 else [])):
+        x, _fs, pm, voi = utts[u]
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            o = orc.analysis_compressed_from_epochs(x, fs, pm, voi, mag_dim=mag_dim, phase_dim=phase_dim, b_const_rate=True)
+        s0, s1 = int(pf.out_off[u]), int(pf.out_off[u + 1])
+        assert o[0].shape == (s1 - s0, mag_dim)
+        if u == 3:   # frames of 240 samples with a 4096-point transform: both forms are 3.6e-5 from the oracle on the first
+            # coefficient of one frame (measured, round 6; the typical utterance: 2.8e-6 here, 5.5e-6 staged)
+            within(np.max(np.abs(a[0][s0:s1] - o[0])), 6e-5, "WARP_TOL:one_kernel_cr_400Hz")
+            within(np.max(np.abs(b[0][s0:s1] - o[0])), 6e-5, "WARP_TOL:staged_cr_400Hz")
+        else:
+            within(np.max(np.abs(a[0][s0:s1] - o[0])), WARP_TOL, "WARP_TOL:one_kernel_cr")
+        within(max(np.max(np.abs(a[1][s0:s1] - o[1])), np.max(np.abs(a[2][s0:s1] - o[2]))), WARP_PHASE_TOL,
+               "WARP_PHASE_TOL:one_kernel_cr")
+
+
+def test_one_kernel_constant_rate_analysis_through_the_batch_api(mp, orc, monkeypatch):
+    """analysis_compressed_batch(..., b_const_rate=True) with MAGPHASE_COMP_FUSED_CR=1: the caller-level results (features,
+    lf0, shifts) of a single short utterance -- fewer frames than one round -- equal the default form's to the kernels'
+    tolerances, lf0 / shifts exactly."""
+    from magphase_amd import synthetic as syn
+    pcm, pm, voi = syn.make_utterance(5, dur_s=0.06, fs=48000)
+    x = syn.pcm_to_float(pcm)
+    outs = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("MAGPHASE_COMP_FUSED_CR", flag)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            outs[flag] = mp.analysis_compressed_batch([(x, 48000, pm, voi)], mag_dim=60, phase_dim=45, b_const_rate=True)[0]
+    r1, r0 = outs["1"], outs["0"]
+    assert r1[0].shape == r0[0].shape and r1[0].shape[0] >= 1
+    within(np.max(np.abs(r1[0] - r0[0])), 1.5e-5, "ONE_KERNEL_CR_VS_STAGED:mag")
+    within(max(np.max(np.abs(r1[1] - r0[1])), np.max(np.abs(r1[2] - r0[2]))), 2e-6, "ONE_KERNEL_CR_VS_STAGED:phase")
+    assert np.array_equal(r1[3], r0[3]) and np.array_equal(r1[4], r0[4])
