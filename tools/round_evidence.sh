@@ -7,6 +7,7 @@
 #   gpurun_out/ev_<tag>/corpus_busy.json    tools/corpus_wait_probe.py 1250 (compute-stream busy fraction)
 #   gpurun_out/ev_<tag>/epoch_natural.json  tools/epoch_natural.py (tracker vs label-derived voicing on the bundled recordings)
 #   gpurun_out/ev_<tag>/array_api.txt, mt_ladder.txt   tools/array_api_probe.py, tools/mt_ladder_probe.py
+#   gpurun_out/ev_<tag>/fused_cr_check.txt  tools/fused_cr_check.py (constant-rate analysis: one kernel vs the staged pair)
 TAG=${1:-r06}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 E=$R/gpurun_out/ev_$TAG
@@ -25,5 +26,6 @@ timeout 600 python tools/corpus_wait_probe.py 1250 $E/corpus_busy.json > $E/corp
 timeout 600 python tools/epoch_natural.py $E/epoch_natural.json > $E/epoch_natural.txt 2>&1
 timeout 300 python tools/array_api_probe.py > $E/array_api.txt 2>&1
 timeout 300 python tools/mt_ladder_probe.py > $E/mt_ladder.txt 2>&1
+timeout 600 python tools/fused_cr_check.py > $E/fused_cr_check.txt 2>&1
 timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $E/smoke.txt 2>&1
 tail -1 $E/smoke.txt
