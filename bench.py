@@ -576,7 +576,7 @@ def measure_e2e(utts):
         fin = [(f[0], f[1], f[2], f[3], f[4]) for f in feats]
         mp.synthesis_from_lossless_batch(fin[:2])
         runs = []
-        for _ in range(3):                                             # median of three (fresh 0.7 GB of pages per run)
+        for _ in range(7):                                             # median of seven (fresh 0.7 GB of pages per run: single runs scatter 0.02-0.15 s)
             t0 = time.perf_counter()
             feats = mp.analysis_lossless_batch(sub, copy=False)        # row views of the batch's arrays
             t_a = time.perf_counter() - t0
@@ -585,14 +585,14 @@ def measure_e2e(utts):
             mp.synthesis_from_lossless_batch(fin)
             runs.append((t_a + time.perf_counter() - t0, t_a))
         runs.sort()
-        t_a = runs[1][1]
-        t_s = runs[1][0] - t_a
+        t_a = runs[len(runs) // 2][1]
+        t_s = runs[len(runs) // 2][0] - t_a
     nfr = int(sum(f[0].shape[0] for f in feats))
     out["array_api_lossless"] = {
         "what": "mp.analysis_lossless_batch + mp.synthesis_from_lossless_batch on %d utterances: int16 PCM + epochs in, "
                 "float64 numpy features out (%.2f GB of float32 across PCIe, widened on the host by native threads), the same "
                 "features back in (narrowed into pinned staging), float64 PCM out" % (len(sub), 3 * 4.0 * nfr * 2049 / 1e9),
-        "analysis_s": round(t_a, 3), "synthesis_s": round(t_s, 3), "timing": "median of 3 runs",
+        "analysis_s": round(t_a, 3), "synthesis_s": round(t_s, 3), "timing": "median of %d runs" % len(runs),
         "samples_s": [round(r[0], 3) for r in runs],
         "frames_per_s": round(nfr / (t_a + t_s), 1), "x_realtime": round(audio / (t_a + t_s), 1)}
     try:
