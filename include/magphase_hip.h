@@ -308,7 +308,7 @@ int mpx_noise_uniform(void* stream, int32_t n_utts, const uint64_t* seeds, const
  * mpx_noise_numpy_mt19937_work_words() uint32, or NULL.  With work and more than one segment of 319 488 words to draw,
  * the stream is produced by one workgroup per segment: the 624-word window each segment starts from is a jump-ahead of
  * the first one (X[n + J] = xor of X[n + i] over the set bits of x^J mod the generator's characteristic polynomial;
- * log2(segments) rounds of k_mt_jump, polynomials from mpx_host_mt19937_jump_polys).  Without work, or for short draws,
+ * log2(segments) rounds of k_mt_seq + k_mt_xor, polynomials from mpx_host_mt19937_jump_polys).  Without work, or for short draws,
  * one workgroup runs the recurrence from the key (454 words per barrier).  A second kernel converts.  Bit-identical
  * either way.  The many-workgroup form waits for the stream once (the polynomials are uploaded from pageable memory);
  * its caller reads key_out / pos_out back right afterwards anyway.

@@ -68,7 +68,7 @@ __device__ __forceinline__ unsigned mt_temper(unsigned y) {
 }
 
 // With ``windows`` the stream is cut into segments of J words (J a multiple of 624), one workgroup each: segment k
-// starts from the 624-word window X[624 + k J ..] (k_mt_jump below), emits its own words and stops at the next
+// starts from the 624-word window X[624 + k J ..] (k_mt_seq / k_mt_xor below), emits its own words and stops at the next
 // segment's start; workgroup 0 also emits what is left of numpy's current block (X[pos .. 623], straight from the key)
 // and the last one leaves the state.  Without windows: one segment, from the key.
 __global__ __launch_bounds__(256) void k_mt19937_stream(const unsigned* __restrict__ key_in,
@@ -141,49 +141,73 @@ __global__ __launch_bounds__(256) void k_mt_first(const unsigned* __restrict__ k
     for (int i = t; i < 624; i += 256) windows[i] = xs[624 + i];
 }
 
-// Jump-ahead: windows[dst_off + w] = the window J' words after windows[w], J' the jump whose polynomial g = x^J' mod phi
-// is given as a 19968-bit mask (magphase_mtjump.cpp):  X[n + J'] = xor_{i : g_i} X[n + i].  kMtJumpSplit workgroups share
-// one jump (the first rounds of the doubling have 1, 2, 4 ... jumps to make: a lone workgroup took 0.48 ms per round):
-// each runs the recurrence for the 19937 + 623 words after the source window (LDS, 85 KB; 13 us) and xors the words
-// i + j of ITS share of the set bits i for three j per thread, then xors the partial window into the (zeroed) result.
-constexpr int kMtJumpWords = 19937 + 624 + 768;   // generated + read-ahead slack of the threads without a third j
+// Jump-ahead: dst[w] = the window J' words after windows[w], J' the jump whose polynomial g = x^J' mod phi is given as a
+// 19968-bit mask (magphase_mtjump.cpp):  X[n + J'] = xor_{i : g_i} X[n + i].  Two launches per round of the doubling ladder
+// (round 6; before: ONE kernel in which each of the 16 workgroups that share a jump's mask regenerated the 20 561 words behind
+// the source window itself, 85 KB of LDS and 13 of its 20 us -- 4 080 such workgroups per draw, which took the CUs away from
+// the synthesis kernels running beside the generator's stream):
+//   k_mt_seq  one workgroup per SOURCE window: the recurrence for the 19937 + 623 words after it, through an 8 KB ring, written
+//             to global memory once (seq, 84 KB per window);
+//   k_mt_xor  kMtJumpSplit workgroups per jump: each stages the 1 248 + 768 words its share of the mask (39 mask words = bits
+//             1248 p .. 1248 p + 1247) can reach, xors the words i + j of the set bits i for three j per thread and xors the
+//             partial window into the (zeroed) result.
 constexpr int kMtJumpSplit = 16;                  // 624 mask words = 16 x 39
-// blockIdx.z = p - 1: the p-th of the round's jumps (polynomial p - 1 of `poly`), window w -> window p n_src + w: a round of
-// a radix-R ladder makes R - 1 jumps from every source window in ONE launch (kMtRadix below).  gridDim.y workgroups share
-// one jump's mask.
-__global__ __launch_bounds__(256) void k_mt_jump(unsigned* __restrict__ windows, const unsigned* __restrict__ poly,
-                                                 int n_src, int n_windows) {
-    extern __shared__ __attribute__((aligned(16))) unsigned mt_xs[];
-    const int t = threadIdx.x, w = blockIdx.x, part = blockIdx.y;
-    const int dst_off = ((int)blockIdx.z + 1) * n_src;
-    poly += 624ll * blockIdx.z;
-    if (w >= n_src || dst_off + w >= n_windows) return;
-    for (int i = t; i < 624; i += 256) mt_xs[i] = windows[624ll * w + i];
-    for (int i = 19937 + 624 + t; i < kMtJumpWords; i += 256) mt_xs[i] = 0u;
+constexpr int kMtSeqWords = 19937 + 624;          // words of a source window's sequence the mask can reach
+constexpr int kMtSeqStride = 21376;               // + the read-ahead slack of the threads without a third j (zeros), 256-byte rows
+constexpr int kMtXorSpan = 1248 + 768;            // words a share's workgroup stages
+__global__ __launch_bounds__(256) void k_mt_seq(const unsigned* __restrict__ windows, unsigned* __restrict__ seq) {
+    constexpr int R = 2048;   // ring: X[i] lives in ring[i & (R - 1)] (k_mt19937_stream's scheme)
+    __shared__ unsigned ring[R];
+    const int t = threadIdx.x;
+    const unsigned* src = windows + 624ll * blockIdx.x;
+    unsigned* out = seq + (long long)blockIdx.x * kMtSeqStride;
+    for (int i = t; i < 624; i += 256) {
+        const unsigned v = src[i];
+        ring[i] = v;
+        out[i] = v;
+    }
+    for (int i = kMtSeqWords + t; i < kMtSeqStride; i += 256) out[i] = 0u;
     __syncthreads();
-    constexpr int NX = 19937 + 624;
-    for (int base = 0; base + 624 < NX; base += 454) {
+    unsigned v = (t < 227) ? ring[t + 397] : 0u;
+    unsigned k = 0;
+    int o = 624 + t;
+    for (int it = 0; it < (kMtSeqWords - 624 + 453) / 454; ++it) {
         if (t < 227) {
-            const unsigned v1 = mt_xs[base + 397 + t] ^ mt_twist(mt_xs[base + t], mt_xs[base + t + 1]);
-            const unsigned v2 = v1 ^ mt_twist(mt_xs[base + 227 + t], mt_xs[base + 228 + t]);
-            if (base + 624 + t < NX) mt_xs[base + 624 + t] = v1;
-            if (base + 851 + t < NX) mt_xs[base + 851 + t] = v2;
+            const unsigned x = ring[(k + t) & (R - 1)], y = ring[(k + t + 1) & (R - 1)];
+            const unsigned x2 = ring[(k + 227 + t) & (R - 1)], y2 = ring[(k + 228 + t) & (R - 1)];
+            const unsigned v1 = v ^ mt_twist(x, y);
+            v = v1 ^ mt_twist(x2, y2);
+            ring[(k + 624 + t) & (R - 1)] = v1;
+            ring[(k + 851 + t) & (R - 1)] = v;
+            if (o < kMtSeqWords) out[o] = v1;
+            if (o + 227 < kMtSeqWords) out[o + 227] = v;
         }
+        k = (k + 454) & (R - 1);
+        o += 454;
         __syncthreads();
     }
+}
+
+__global__ __launch_bounds__(256) void k_mt_xor(const unsigned* __restrict__ seq, const unsigned* __restrict__ poly,
+                                                unsigned* __restrict__ dst_windows) {
+    __shared__ unsigned xs[kMtXorSpan];
+    const int t = threadIdx.x, part = blockIdx.y;
+    const unsigned* src = seq + (long long)blockIdx.x * kMtSeqStride + 1248 * part;
+    for (int i = t; i < kMtXorSpan; i += 256) xs[i] = src[i];
+    __syncthreads();
     unsigned a0 = 0u, a1 = 0u, a2 = 0u;
-    const int QW = 624 / (int)gridDim.y;   // mask words of this workgroup's share (gridDim.y divides 624: 1, 2, 4, 8 or 16)
-    for (int q = part * QW; q < (part + 1) * QW; ++q) {
-        unsigned bits = __builtin_amdgcn_readfirstlane(poly[q]);
+    constexpr int QW = 624 / kMtJumpSplit;
+    for (int q = 0; q < QW; ++q) {
+        unsigned bits = __builtin_amdgcn_readfirstlane(poly[part * QW + q]);
         while (bits) {   // wave-uniform: the mask is the same for every lane
             const int i = 32 * q + __builtin_ctz(bits);
             bits &= bits - 1u;
-            a0 ^= mt_xs[i + t];
-            a1 ^= mt_xs[i + t + 256];
-            a2 ^= mt_xs[i + t + 512];
+            a0 ^= xs[i + t];
+            a1 ^= xs[i + t + 256];
+            a2 ^= xs[i + t + 512];
         }
     }
-    unsigned* dst = windows + 624ll * (dst_off + w);
+    unsigned* dst = dst_windows + 624ll * blockIdx.x;
     atomicXor(&dst[t], a0);
     atomicXor(&dst[t + 256], a1);
     if (t + 512 < 624) atomicXor(&dst[t + 512], a2);
@@ -219,18 +243,13 @@ int mpx_noise_uniform(void* stream, int32_t n_utts, const uint64_t* seeds, const
 // Segments of the parallel form: kMtSegWords words each (doubled until at most kMtMaxSegs are needed)
 constexpr long long kMtSegWords = 624ll * 512;
 constexpr int kMtMaxSegs = 256, kMtMaxLevels = 8;
-// Jumps per source window and ladder round + 1.  2 = the doubling ladder.  16 (two rounds for 256 segments instead of eight)
-// was measured in round 6 and is SLOWER (generation 185 k -> 147 k x real time): a round is not latency- but throughput-bound
-// -- every workgroup of a jump regenerates the 20 561 words after its source window, 4 080 workgroup executions per call
-// whatever the radix -- and one wide launch no longer slips into the gaps of the synthesis kernels next to it.
-constexpr int kMtRadix = 2;
-static long long ipow_radix(int l) {
-    long long v = 1;
-    while (l-- > 0) v *= kMtRadix;
-    return v;
-}
+// (A radix-16 ladder -- two rounds of fifteen jumps per source window instead of eight doubling rounds -- and narrower mask
+// splits were measured in round 6 and are slower inside a generation job: docs/LAB_NOTES.md, round 6.)
 
-int64_t mpx_noise_numpy_mt19937_work_words(void) { return (int64_t)(kMtMaxSegs + kMtMaxLevels) * 624; }
+// windows [kMtMaxSegs + kMtMaxLevels][624], then the sequences of a round's source windows [kMtMaxSegs / 2][kMtSeqStride]
+int64_t mpx_noise_numpy_mt19937_work_words(void) {
+    return (int64_t)(kMtMaxSegs + kMtMaxLevels) * 624 + (int64_t)(kMtMaxSegs / 2) * kMtSeqStride;
+}
 
 int mpx_noise_numpy_mt19937(void* stream, const uint32_t* key, int32_t pos, int64_t n_samples, uint32_t* raw,
                             float* out, uint32_t* key_out, int32_t* pos_out, uint32_t* work) {
@@ -251,12 +270,13 @@ int mpx_noise_numpy_mt19937(void* stream, const uint32_t* key, int32_t pos, int6
         hipLaunchKernelGGL(k_mt19937_stream, dim3(1), dim3(256), 0, s, (const unsigned*)key, (const unsigned*)nullptr, 0ll,
                            (int)pos, n_words, (unsigned*)raw, (unsigned*)key_out, (int*)pos_out);
     } else {
-        int levels = 0;   // rounds of the radix-kMtRadix ladder
-        while (ipow_radix(levels) < K) ++levels;
-        // The ladder's jump polynomials (x^(p J R^l) mod the characteristic polynomial, p < R, l < levels) live on the device,
-        // one copy per (device, shift, levels), uploaded once: round 5 found this call copying them from pageable memory and
-        // then SYNCHRONISING the stream on every launch of a generation job -- the host could never run ahead of the device.
+        int levels = 0;   // rounds of the doubling ladder
+        while ((1 << levels) < K) ++levels;
+        // The ladder's jump polynomials (x^(J 2^l) mod the characteristic polynomial, l < levels) live on the device, one copy
+        // per (device, shift, levels), uploaded once: round 5 found this call copying them from pageable memory and then
+        // SYNCHRONISING the stream on every launch of a generation job -- the host could never run ahead of the device.
         unsigned* windows = (unsigned*)work;
+        unsigned* seq = windows + (size_t)(kMtMaxSegs + kMtMaxLevels) * 624;
         const unsigned* dpoly = nullptr;
         {
             struct Entry { int dev, shift, levels; unsigned* ptr; };
@@ -268,12 +288,10 @@ int mpx_noise_numpy_mt19937(void* stream, const uint32_t* key, int32_t pos, int6
             for (const Entry& e : cache)
                 if (e.dev == dev && e.shift == shift && e.levels >= levels) dpoly = e.ptr;
             if (!dpoly) {
-                const int np = levels * (kMtRadix - 1);
-                std::vector<int64_t> jumps((size_t)np);
-                for (int l = 0; l < levels; ++l)
-                    for (int p_ = 1; p_ < kMtRadix; ++p_) jumps[(size_t)(l * (kMtRadix - 1) + p_ - 1)] = (int64_t)p_ * J * ipow_radix(l);
-                std::vector<uint32_t> polys((size_t)np * 624);
-                if (mpx_host_mt19937_jump_polys(jumps.data(), np, polys.data(), 16) != MPX_OK)
+                std::vector<int64_t> jumps((size_t)levels);
+                for (int l = 0; l < levels; ++l) jumps[(size_t)l] = J << l;
+                std::vector<uint32_t> polys((size_t)levels * 624);
+                if (mpx_host_mt19937_jump_polys(jumps.data(), levels, polys.data(), 16) != MPX_OK)
                     return fail(MPX_ERR_ARG, "mpx_noise_numpy_mt19937: jump polynomials unavailable%s");
                 unsigned* p = nullptr;
                 MPX_HIP_CHECK(hipMalloc((void**)&p, polys.size() * sizeof(uint32_t)));
@@ -284,17 +302,12 @@ int mpx_noise_numpy_mt19937(void* stream, const uint32_t* key, int32_t pos, int6
         }
         MPX_HIP_CHECK(hipMemsetAsync(windows, 0, (size_t)K * 624 * sizeof(unsigned), s));   // jump results are xor-ed in
         hipLaunchKernelGGL(k_mt_first, dim3(1), dim3(256), 0, s, (const unsigned*)key, windows);
-        const size_t lds = (size_t)kMtJumpWords * sizeof(unsigned);
-        if (int rc = set_lds(k_mt_jump, lds)) return rc;
         for (int l = 0; l < levels; ++l) {
-            const int n_src = (int)ipow_radix(l);
-            // kMtJumpSplit workgroups share one jump's mask at every width of the round: measured on an idle device
-            // (tools/mt_ladder_probe.py, 30 M samples per draw) 16 / 8 / 4 / 2 / 1 workgroups per jump = 0.95 / 1.06 / 1.41 /
-            // 2.36 / 4.22 ms -- the xor over the mask's ~10 000 set bits, not the regeneration of the word sequence, is what
-            // a jump costs
-            const int split = kMtJumpSplit;
-            hipLaunchKernelGGL(k_mt_jump, dim3((unsigned)min(n_src, K), (unsigned)split, kMtRadix - 1), dim3(256), lds, s, windows,
-                               (const unsigned*)(dpoly + 624ll * (kMtRadix - 1) * l), n_src, K);
+            const int n_src = 1 << l;
+            const int n_jump = min(n_src, K - n_src);   // window w -> window n_src + w
+            hipLaunchKernelGGL(k_mt_seq, dim3((unsigned)n_jump), dim3(256), 0, s, (const unsigned*)windows, seq);
+            hipLaunchKernelGGL(k_mt_xor, dim3((unsigned)n_jump, kMtJumpSplit), dim3(256), 0, s, (const unsigned*)seq,
+                               (const unsigned*)(dpoly + 624ll * l), windows + 624ll * n_src);
         }
         hipLaunchKernelGGL(k_mt19937_stream, dim3((unsigned)K), dim3(256), 0, s, (const unsigned*)key,
                            (const unsigned*)windows, J, (int)pos, n_words, (unsigned*)raw, (unsigned*)key_out,

@@ -158,6 +158,8 @@ class Engine:
         if cs is None:
             torch = _torch()
             cs = self._copy_streams = {"up": torch.cuda.Stream(self.device), "down": torch.cuda.Stream(self.device)}
+        if kind == "rng" and os.environ.get("MAGPHASE_RNG_STREAM", "1") == "0":
+            return None          # the noise generator's kernels in the compute stream (measured: generation -10 %)
         if kind not in cs:   # "rng": the noise stream's generator kernels (a few workgroups each: numpy_global_uniform)
             cs[kind] = _torch().cuda.Stream(self.device)
         return cs[kind]
@@ -310,7 +312,7 @@ class Engine:
     def out_ring(self):
         r = getattr(self, "_out_ring", None)
         if r is None:
-            r = self._out_ring = _PinnedRing()
+            r = self._out_ring = _PinnedRing(slots=max(2, int(os.environ.get("MAGPHASE_OUT_RING_SLOTS", "4"))))
         return r
 
     def to_host_f32_async(self, tensors):
@@ -622,7 +624,11 @@ class Engine:
             cores = os.cpu_count() or 1
         return max(1, min(want, cores))
 
-    _N_SLOTS = 3
+    # Staging slots.  A slot is held from prepare_* until the upload out of it has completed; a generation batch is TWO launches
+    # (one per sample rate) and the planner works one batch ahead of the thread that enqueues, so four are in use at once: with
+    # three (rounds 5-6) the planner thread waited for a slot in every batch, the enqueuing thread for the planner, and the
+    # device for the upload -- 13-19 ms of a 45 ms generation pass (tools/corpus_marks_probe.py)
+    _N_SLOTS = max(2, int(os.environ.get("MAGPHASE_STAGE_SLOTS", "6")))
 
     def _slot_acquire(self, stage_bytes, desc_bytes, wait=True):
         """One of the engine's sets of page-locked buffers (sample / coefficient staging + table image) for a prepared launch;
@@ -654,7 +660,16 @@ class Engine:
             pool.get(block=bool(wait))
         except queue.Empty:
             return None
-        slot = self._slot_stack.pop()
+        # the most recently returned slot whose upload has completed (warm, and free NOW); none: the oldest one
+        slot = None
+        for k in range(len(self._slot_stack) - 1, -1, -1):
+            ev_ = self._slot_stack[k]["event"]
+            if ev_ is None or ev_.query():
+                slot = self._slot_stack[k]
+                del self._slot_stack[k]
+                break
+        if slot is None:
+            slot = self._slot_stack.popleft()
         try:
             if slot["event"] is not None:
                 slot["event"].synchronize()
