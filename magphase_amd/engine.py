@@ -662,14 +662,15 @@ class Engine:
             return None
         # the most recently returned slot whose upload has completed (warm, and free NOW); none: the oldest one
         slot = None
-        for k in range(len(self._slot_stack) - 1, -1, -1):
-            ev_ = self._slot_stack[k]["event"]
-            if ev_ is None or ev_.query():
-                slot = self._slot_stack[k]
-                del self._slot_stack[k]
-                break
-        if slot is None:
-            slot = self._slot_stack.popleft()
+        with self._slots_lock:   # (two acquirers -- the planner thread and a caller on the generic path -- must not pick the same entry)
+            for k in range(len(self._slot_stack) - 1, -1, -1):
+                ev_ = self._slot_stack[k]["event"]
+                if ev_ is None or ev_.query():
+                    slot = self._slot_stack[k]
+                    del self._slot_stack[k]
+                    break
+            if slot is None:
+                slot = self._slot_stack.popleft()
         try:
             if slot["event"] is not None:
                 slot["event"].synchronize()
