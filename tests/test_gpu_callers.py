@@ -347,3 +347,39 @@ def test_prepared_synthesis_equals_generic_path(monkeypatch, b_const_rate):
         again = mp.synthesis_from_compressed_batch(feats, 48000, prepared=prep2, **kw)
         for a, b in zip(ref, again):
             assert np.array_equal(a, b)
+
+
+def test_staging_slot_pool_hands_out_ready_slots_first_and_never_blocks_a_pipeline_of_two_batches():
+    """Engine._slot_acquire / _slot_release (round 6): six page-locked staging slots -- a generation batch is two launches and
+    the planner works one batch ahead, so four are held at once and a fifth / sixth must come without waiting (with three
+    the planner thread, the enqueuing thread and the device waited for each other); a slot whose upload event has not completed
+    is passed over while another one is free; an exhausted pool returns None to a non-blocking caller."""
+    import torch
+    from magphase_amd.engine import Engine
+    e = Engine()
+    n = e._N_SLOTS
+    assert n >= 6
+    held = [e._slot_acquire(1 << 20, 1 << 16, wait=False) for _ in range(n)]
+    assert all(s is not None for s in held) and len({id(s) for s in held}) == n
+    assert e._slot_acquire(1 << 20, 1 << 16, wait=False) is None          # exhausted: no blocking, no slot
+    assert all(s["stage"].is_pinned() and s["stage"].numel() >= (1 << 20) for s in held)
+    # one slot goes back behind an event that cannot complete yet (a long kernel chain is queued in front of it), another one
+    # with a completed upload: the next acquire must take the READY one although the pending one was returned last
+    a = torch.randn(4096, 4096, device="cuda")
+    ready_ev = torch.cuda.Event()
+    ready_ev.record()
+    torch.cuda.synchronize()
+    e._slot_release(held[0], ready_ev)
+    for _ in range(40):
+        a = a @ a * 1e-4
+    pending_ev = torch.cuda.Event()
+    pending_ev.record()
+    e._slot_release(held[1], pending_ev)
+    assert not pending_ev.query()
+    got = e._slot_acquire(1 << 20, 1 << 16, wait=False)
+    assert got is held[0]
+    got2 = e._slot_acquire(1 << 20, 1 << 16, wait=False)                  # only the pending one is left: waited for, not refused
+    assert got2 is held[1] and pending_ev.query()
+    for s in [got, got2] + held[2:]:
+        e._slot_release(s)
+    torch.cuda.synchronize()
